@@ -1,0 +1,209 @@
+"""TEST INFRASTRUCTURE ONLY -- generate tests/golden/* from the *reference*.
+
+Run in the build container (needs /root/reference):  python oracle/gen_golden.py
+Imports the reference's own Python under the shims of ref_loader.py, loads the
+deterministic name-keyed weights of ppst_amd/weights.py into it, runs the
+reference's commands and stores *data only* (inputs are regenerated from seeds;
+outputs are stored as sampled values + summary statistics so the fixtures stay
+small).  The reference never travels to the GPU box; these fixtures do.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_loader  # noqa: E402
+from ppst_amd import weights as W  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+NSAMP = 2048
+
+
+def sample_idx(name, numel, n=NSAMP):
+    import zlib
+    rng = np.random.default_rng([99, zlib.crc32(name.encode())])
+    return rng.integers(0, numel, size=min(n, numel))
+
+
+def pack(out, name, t):
+    """Store sampled values + stats of tensor t under key prefix name."""
+    a = t.detach().cpu().contiguous().view(-1).double().numpy()
+    idx = sample_idx(name, a.size)
+    out[name + ".shape"] = np.array(t.shape, dtype=np.int64)
+    out[name + ".samples"] = a[idx].astype(np.float32)
+    out[name + ".stats"] = np.array([a.mean(), a.std(), np.abs(a).max()], dtype=np.float64)
+
+
+def gen_ops(ns):
+    """Per-op goldens from the reference's own fallbacks: upfirdn2d for every
+    pad/kernel combination the path uses (+ the up/down modes of the CUDA
+    dispatcher, upfirdn2d_kernel.cu:177-211), fused_leaky_relu fwd and the
+    autograd of its fallback."""
+    out = {}
+    rng = np.random.default_rng(11)
+    up = ns.stylegan2_op.upfirdn2d
+    cases = []
+    k3 = ns.layers.make_kernel([1, 2, 1])
+    k4 = ns.layers.make_kernel([1, 3, 3, 1])
+    k2 = ns.layers.make_kernel([1, 1])
+    ka = torch.tensor(rng.standard_normal((4, 4)), dtype=torch.float32)  # asymmetric: catches a missing flip
+    kb = torch.tensor(rng.standard_normal((3, 3)), dtype=torch.float32)
+    # (kernel, up, down, pad0, pad1, H, W)
+    for (k, u, d, p0, p1, H, Wd) in [
+        (k3, 1, 1, 0, 0, 35, 35), (k3, 1, 1, 1, 0, 32, 32), (k4, 1, 1, 2, 2, 32, 32),
+        (k4, 1, 1, 1, 1, 32, 32), (ka, 1, 1, 2, 1, 19, 70), (kb, 1, 1, 0, 2, 17, 33),
+        (ka, 2, 1, 2, 1, 16, 24), (k2 * 4, 2, 1, 1, 0, 9, 11), (ka, 1, 2, 1, 1, 21, 30),
+        (k2, 1, 2, 0, 0, 16, 16), (ka, 1, 1, -1, -1, 20, 20), (k4 * 4, 2, 1, 2, 1, 8, 8),
+    ]:
+        x = torch.tensor(rng.standard_normal((2, 3, H, Wd)), dtype=torch.float32)
+        y = up(x, k, up=u, down=d, pad=(p0, p1))
+        i = len(cases)
+        out["upfirdn2d.%d.x" % i] = x.numpy()
+        out["upfirdn2d.%d.k" % i] = k.numpy()
+        out["upfirdn2d.%d.cfg" % i] = np.array([u, d, p0, p1], dtype=np.int64)
+        out["upfirdn2d.%d.y" % i] = y.numpy()
+        cases.append(i)
+    out["upfirdn2d.n"] = np.array(len(cases))
+    # fused leaky relu (fallback path of fused_act.py:89-96) fwd + grads
+    x = torch.tensor(rng.standard_normal((2, 5, 7, 6)), dtype=torch.float32, requires_grad=True)
+    b = torch.tensor(rng.standard_normal((5,)), dtype=torch.float32, requires_grad=True)
+    y = ns.stylegan2_op.fused_leaky_relu(x, b)
+    g = torch.tensor(rng.standard_normal(tuple(y.shape)), dtype=torch.float32)
+    gx, gb = torch.autograd.grad(y, [x, b], g)
+    out.update({"flrelu.x": x.detach().numpy(), "flrelu.b": b.detach().numpy(), "flrelu.y": y.detach().numpy(),
+                "flrelu.g": g.numpy(), "flrelu.gx": gx.numpy(), "flrelu.gb": gb.numpy()})
+    x2 = torch.tensor(rng.standard_normal((3, 8)), dtype=torch.float32)
+    b2 = torch.tensor(rng.standard_normal((8,)), dtype=torch.float32)
+    out.update({"flrelu2.x": x2.numpy(), "flrelu2.b": b2.numpy(),
+                "flrelu2.y": ns.stylegan2_op.fused_leaky_relu(x2, b2, 0.1, 1.5).numpy()})
+    np.savez_compressed(os.path.join(GOLD, "ops.npz"), **out)
+    print("ops.npz", len(out))
+
+
+def set_noise(m, noise):
+    for name, mod in m.G.named_modules():
+        if type(mod).__name__ == "NoiseInjection":
+            mod.fixed_noise = None if noise is None else noise[name[:-len(".noise")]]
+
+
+def gen_swap(ns, m):
+    """simple_swapping recipe at 512^2 (simple_swapping_evaluator.py:44-60, with
+    the intended tensor corr matrix) + D forward, stress weights (non-zero
+    biases and noise weights, explicit noise)."""
+    out = {}
+    sd = W.make_state_dict(1, bias_std=0.1, noise_weight=0.1)
+    m.load_state_dict(sd, strict=True)
+    noise = W.make_noise(3, 1)
+    set_noise(m, noise)
+    imgs = W.synthetic_images(5, 2)
+    c, s = imgs[0:1], imgs[1:2]
+    with torch.no_grad():
+        sp, gl = m(c, command="encode")
+        fc, fc1 = m(c, command="extract_feat_from_image")
+        fs, fs1 = m(s, command="extract_feat_from_image")
+        rc = m(fc1, command="Rselfcorr")
+        rs = m(fs1, command="Rselfcorr")
+        fcc = torch.cat((fc, rc), 1)
+        fss = torch.cat((fs, rs), 1)
+        corr = m(fss, fcc, command="corrm")
+        _, glw = m(s, corr, command="encode2")
+        for alpha in (0.0, 0.7, 1.0):
+            code = ns.util.lerp(gl, glw, alpha)
+            o = m(sp, code, target=None, command="decode")
+            pack(out, "out_a%.1f" % alpha, o)
+            if alpha == 1.0:
+                u8 = ((o[0].clamp(-1.0, 1.0) + 1.0) * 0.5 * 255).to(torch.uint8)  # ToPILImage quantisation
+                out["out_u8.hist"] = np.bincount(u8.flatten().numpy(), minlength=256).astype(np.int64)
+        d = m.D(imgs)
+        wimg = m(c, corr, command="warp")
+    pack(out, "sp", sp)
+    for i in range(4):
+        out["gl%d" % i] = gl[i].numpy()
+        out["glw%d" % i] = glw[i].numpy()
+    pack(out, "fea_c", fc)
+    pack(out, "fea_c1", fc1)
+    pack(out, "rself_c", rc)
+    pack(out, "fea_s", fs)
+    pack(out, "rself_s", rs)
+    pack(out, "corr", corr)
+    out["corr.argmax"] = corr[0].argmax(-1).numpy().astype(np.int32)
+    out["corr.rowmax"] = corr[0].max(-1)[0].numpy()
+    rows = sample_idx("corr.rows", 4096, 16)
+    out["corr.rows.idx"] = rows
+    out["corr.rows.val"] = corr[0, rows].numpy().astype(np.float32)
+    pack(out, "warp_img", wimg)
+    out["D"] = d.numpy()
+    np.savez_compressed(os.path.join(GOLD, "swap512.npz"), **out)
+    print("swap512.npz", len(out))
+
+
+def gen_cfg1(ns, m):
+    """BASELINE config 1: 256^2 encode/decode only (the correspondence path is
+    impossible at 256^2 in the reference), init-like weights
+    (zero biases / noise weights => deterministic without explicit noise)."""
+    out = {}
+    sd = W.make_state_dict(0)
+    m.load_state_dict(sd, strict=True)
+    set_noise(m, None)
+    imgs = W.synthetic_images(0, 2, size=256, smooth=False)
+    with torch.no_grad():
+        sp, _ = m(imgs[0:1], command="encode")
+        _, gl = m(imgs[1:2], command="encode")
+        o = m(sp, gl, target=None, command="decode")
+    pack(out, "sp", sp)
+    for i in range(4):
+        out["gl%d" % i] = gl[i].numpy()
+    pack(out, "out", o)
+    np.savez_compressed(os.path.join(GOLD, "cfg1_256.npz"), **out)
+    print("cfg1_256.npz", len(out))
+
+
+def gen_glue(ns, m):
+    """Exact / integer glue: tensor2im truncation
+    (util/util.py:98-131), swap permutation (ppst_model.py:59-66), lerp and
+    normalize (util/util.py:18-35)."""
+    out = {}
+    rng = np.random.default_rng(21)
+    x = torch.tensor(rng.uniform(-1.3, 1.3, size=(4, 3, 16, 16)), dtype=torch.float32)
+    out["t2i.x"] = x.numpy()
+    out["t2i.y"] = ns.util.tensor2im(x, tile=False)
+    out["swap.y"] = m.swap(x).numpy()
+    a = torch.tensor(rng.standard_normal((2, 64)), dtype=torch.float32)
+    b = torch.tensor(rng.standard_normal((2, 64)), dtype=torch.float32)
+    out["vec.a"], out["vec.b"] = a.numpy(), b.numpy()
+    out["lerp.y"] = ns.util.lerp([a], [b], 0.3)[0].numpy()
+    out["normalize.y"] = ns.util.normalize(a).numpy()
+    out["gan.real"] = ns.loss.gan_loss(a, True).numpy()
+    out["gan.fake"] = ns.loss.gan_loss(a, False).numpy()
+    np.savez_compressed(os.path.join(GOLD, "glue.npz"), **out)
+    print("glue.npz", len(out))
+
+
+def gen_keys(m):
+    sd = m.state_dict()
+    keys = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]
+    with open(os.path.join(GOLD, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0)
+    print("state_dict_keys.json", len(keys))
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    ns = ref_loader.load_reference()
+    m = ref_loader.build_reference_model()
+    gen_keys(m)
+    gen_glue(ns, m)
+    gen_ops(ns)
+    gen_cfg1(ns, m)
+    gen_swap(ns, m)
+
+
+if __name__ == "__main__":
+    main()
