@@ -1,0 +1,256 @@
+/*
+ * libppst_hip.so -- C ABI of the MI355X (gfx950) PPST hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers + sizes and an
+ * explicit HIP stream, allocates nothing, keeps no global state (except the
+ * opt-in profiling event pool of ppst_prof_*), never throws and returns
+ *      0            success
+ *      > 0          a hipError_t from the launch
+ *      < 0          PPST_E* argument error (nothing was launched)
+ * so it can be bound from ctypes / cgo / JNI alike.  Each declaration cites the
+ * reference interface (file:line under wangxb29/PPST) it replaces.
+ *
+ * Tensor layouts: "NCHW" = the reference's contiguous torch layout;
+ * "NHWC" = channels-last [B][H][W][C], the internal layout of the fused path.
+ * All tensors are fp32 unless stated; `dtype` arguments are reserved for
+ * f16/bf16 I/O (only PPST_F32 is accepted today).
+ */
+#ifndef PPST_HIP_H
+#define PPST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPST_OK 0
+#define PPST_EINVAL (-1)      /* bad size / flag combination */
+#define PPST_EUNSUPPORTED (-2) /* valid but not implemented (e.g. dtype) */
+#define PPST_ENULL (-3)       /* null pointer where data is required */
+
+enum { PPST_F32 = 0, PPST_F16 = 1, PPST_BF16 = 2 };
+
+/* padding modes of the fused conv (nn.ReflectionPad2d / ReplicationPad2d /
+ * zero padding, stylegan2_layers.py:528-531, generator.py:13-17) */
+enum { PPST_PAD_ZERO = 0, PPST_PAD_REFLECT = 1, PPST_PAD_REPLICATE = 2 };
+
+/* epilogue activation of the fused conv */
+enum { PPST_ACT_NONE = 0, PPST_ACT_LRELU = 1 /* lrelu(0.2)*sqrt2 */, PPST_ACT_PRELU = 2 };
+
+int ppst_version(void);
+
+/* ---------------------------------------------------------------- ops ----
+ * upfirdn2d_op.upfirdn2d(input[major,H,W,minor], kernel[kh,kw], up_x, up_y,
+ * down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
+ *   -- models/networks/stylegan2_op/upfirdn2d.cpp:4-23,
+ *      upfirdn2d_kernel.cu:52-137 (kernel), :140-272 (dispatch).
+ * y must hold major*out_h*out_w*minor floats with
+ *   out_h = (in_h*up_y + pad_y0 + pad_y1 - kh + down_y) / down_y  (.cu:166).
+ * minor=1 is the reference's NCHW use; minor=C, major=B is NHWC.
+ * Any kh,kw <= 8 is supported (the reference silently launches nothing for
+ * combinations outside its 6 modes, .cu:172-223).  The backward of the op is
+ * the same entry with the flipped kernel and g_pad (upfirdn2d.py:116-121). */
+int ppst_upfirdn2d(const void* x, const void* k, void* y,
+                   int major, int in_h, int in_w, int minor, int kh, int kw,
+                   int up_x, int up_y, int down_x, int down_y,
+                   int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                   int dtype, void* stream);
+
+/* Fused-path Blur on NHWC activations (Blur inside ConvLayer(downsample=True),
+ * stylegan2_layers.py:142-164,513-520): square FIR (ksize 3 or 4), pad (pad0 before,
+ * pad1 after) with zero or reflection padding folded in (the reference runs
+ * nn.ReflectionPad2d first, :151-159); down=2 keeps every second sample (all that a
+ * following stride-2 1x1 conv reads); s2d=1 writes the output space-to-depth
+ * y[B][ceil(oh/2)][ceil(ow/2)][4*C] (phase (oy&1)*2+(ox&1) major) for the stride-2
+ * 3x3 conv that ppst_conv2d_mfma runs as a stride-1 conv over that layout. */
+int ppst_blur_nhwc(const void* x, const void* k, void* y, int B, int in_h, int in_w, int C,
+                   int ksize, int pad0, int pad1, int pad_mode, int down, int s2d, void* stream);
+
+/* fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)
+ *   -- stylegan2_op/fused_bias_act.cpp:4-20, fused_bias_act_kernel.cu:19-49.
+ * y[i] = f(x[i] + b[(i/step_b) % size_b]) * scale; b==NULL => no bias,
+ * ref==NULL => no reference.  act: 1 linear, 3 leaky-relu; grad: 0 forward,
+ * 1 first derivative gated by sign(ref), 2 second derivative (= 0). */
+int ppst_fused_bias_act(const void* x, const void* b, const void* ref, void* y,
+                        int64_t n, int step_b, int size_b, int act, int grad,
+                        float alpha, float scale, int dtype, void* stream);
+
+/* -------------------------------------------------------------- layout --- */
+int ppst_nchw_to_nhwc(const void* x, void* y, int B, int C, int H, int W, void* stream);
+int ppst_nhwc_to_nchw(const void* x, void* y, int B, int C, int H, int W, void* stream);
+
+/* ---------------------------------------------------- fused conv (MFMA) ---
+ * Implicit-GEMM convolution on NHWC fp32 activations with bf16 MFMA
+ * (v_mfma_f32_16x16x32_bf16).  precision 0: every fp32 operand is split into
+ * hi+lo bf16 and 3 MFMAs (hi*hi, hi*lo, lo*hi) accumulate in fp32 ("bf16x3",
+ * fp32-class, relative error ~1e-5); precision 1: single bf16 pass.
+ * Replaces F.conv2d / F.conv_transpose2d inside EqualConv2d
+ * (stylegan2_layers.py:184-193), EqualizedConv2d (:305-347, incl. the fused
+ * 4x4 stride-2 transposed-conv upscale :312-321) and nn.Conv2d of the
+ * generator heads (generator.py:174-238), with the StyledConv epilogue
+ * (stylegan2_layers.py:467-475) fused in.
+ *
+ * The convolution is described by a packed-weight blob + step table built by
+ * ppst_conv_pack (one-time per weight tensor). */
+
+typedef struct ppst_conv_step {
+  int32_t chan_off;   /* first input channel (in the in_ld-strided pixel) of this 32-ch chunk */
+  int32_t dy, dx;     /* tap offset relative to the output pixel, each in [-1,1] */
+  int32_t new_chunk;  /* 1 if this step starts a new input chunk (LDS restage) */
+} ppst_conv_step;
+
+/* Pack one weight tensor for ppst_conv2d_mfma (one-time per weight tensor).
+ *  w        fp32 weights; element (n, c, ky, kx) at w[n*sn + c*sc + ky*sy + kx*sx]
+ *  scale    multiplied in (EqualConv2d runtime scale, stylegan2_layers.py:177)
+ *  src_*    DEVICE int32 arrays [n_groups*nsteps]: the K-slice of step s of group g is
+ *           w[n][src_c .. src_c+31][src_ky][src_kx]
+ *  bn       64 or 128 = N tile of the kernel variant that will consume the blob
+ *  out      n_groups * ceil(cout/bn) * nsteps * (precision==0 ? 8 : 4) * bn * 8 bf16 */
+int ppst_conv_pack(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx,
+                   float scale, int cout, int bn,
+                   const int32_t* src_c, const int32_t* src_ky, const int32_t* src_kx,
+                   int nsteps, int n_groups, int precision, void* out, void* stream);
+/* EqualizedConv2d fused-upscale weight (stylegan2_layers.py:314-319):
+ * w (Cout,Cin,3,3)*scale -> out (Cin,Cout,4,4), the F.conv_transpose2d operand */
+int ppst_upscale_weight(const void* w, void* out, int cout, int cin, float scale, void* stream);
+
+typedef struct ppst_conv_args {
+  const void* x;        /* NHWC fp32 input, pixel stride in_ld floats */
+  const void* wpack;    /* from ppst_conv_pack */
+  const void* steps;    /* device array ppst_conv_step[n_groups*nsteps] */
+  void* y;              /* NHWC fp32 output, pixel stride out_ld floats */
+  const void* bias;     /* [cout] or NULL (sum of all per-channel biases) */
+  const void* noise;    /* [B][out_h][out_w] or NULL (NoiseInjection, stylegan2_layers.py:376-399) */
+  const void* prelu;    /* [1] PReLU slope (device) when act == PPST_ACT_PRELU */
+  void* stats;          /* [B][tiles_per_image][cout][2] per-tile (sum, sumsq) of the stored output, or NULL */
+  const void* residual; /* NHWC fp32 [B][out_h][out_w][res_ld] added before act, or NULL */
+  float noise_weight;
+  float out_scale;      /* multiplies the activated output (1.0 default) */
+  int32_t B, in_h, in_w, in_ld;
+  int32_t out_h, out_w, out_ld, cout;
+  int32_t nsteps, n_groups;      /* n_groups: 1, or 4 output phases (transposed conv) */
+  int32_t pad_mode;              /* PPST_PAD_* applied to out-of-image taps */
+  int32_t in_off_y, in_off_x;    /* input pixel = tile pixel + tap + in_off (e.g. -pad) */
+  int32_t out_sy, out_sx;        /* output pixel stride (2 for the transposed conv) ... */
+  int32_t act;                   /* PPST_ACT_* | 0x100: residual joins AFTER the activation */
+  int32_t precision;             /* 0 bf16x3, 1 bf16 */
+  int32_t res_ld;
+  int32_t tile_h, tile_w;        /* logical (pre-scatter) output extent tiled by 16x16 */
+  int32_t halo;                  /* 0: every tap is (0,0) (1x1 conv); 1: taps in [-1,1]^2 */
+  int32_t bn;                    /* N tile the weights were packed for (64 or 128) */
+} ppst_conv_args;
+
+int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream);
+/* number of 16x16 tiles per image for (tile_h, tile_w) -- size of the stats buffer */
+int ppst_conv_tiles(int tile_h, int tile_w);
+
+/* FromRGB-type conv: 1x1, Cin <= 4 (HBM-bound), NHWC in (in_ld) -> NHWC out, fused
+ * bias + leaky relu (ConvLayer(3, C, 1), stylegan2_layers.py:497-555). */
+int ppst_conv1x1_small_cin(const void* x, const void* w, const void* bias, void* y,
+                           int64_t npix, int cin, int in_ld, int cout, float wscale,
+                           int act, void* stream);
+/* ToRGB-type conv: 1x1, Cout <= 4 (stylegan2_layers.py:487-489); y NHWC [npix][cout] */
+int ppst_conv1x1_small_cout(const void* x, const void* w, const void* bias, void* y,
+                            int64_t npix, int cin, int cout, float wscale, void* stream);
+
+/* ------------------------------------------- instance norm / style mod ---
+ * nn.InstanceNorm2d (eps 1e-5, biased var) + StyleMod (stylegan2_layers.py:361-374,
+ * :414-437).  Statistics come either from the conv epilogue partials or from
+ * ppst_in_stats (optionally weighting the border as if the tensor had been
+ * ReplicationPad2d(1)-padded first: generator.py:175-176). */
+int ppst_in_stats(const void* x, void* partial, int B, int H, int W, int C, int ld,
+                  int rep_pad, int* n_partials, void* stream);
+/* reduce partials -> per (b,c) scale a and shift s with  y = a*x + s:
+ *   a = rstd * (style0+1), s = style1 - mean*a   (style==NULL: a=rstd, s=-mean*rstd)
+ * style: [B][2*C] rows = StyleMod linear output. count = #elements per (b,c). */
+int ppst_in_finalize(const void* partial, int n_partials, const void* style,
+                     const void* post_bias /* [C] added to the shift, or NULL */,
+                     void* scale_shift /* [B][C][2] */, int B, int C, double count,
+                     float eps, void* stream);
+/* y = act(a*x + s [+ res]) * out_scale ; (skip + res)/sqrt2 of the resnet blocks
+ * (generator.py:47-78) is res + out_scale. act as PPST_ACT_*; PReLU slope ptr. */
+int ppst_affine_act(const void* x, const void* scale_shift, const void* res,
+                    const void* res_scale_shift /* optional affine of res */, void* y,
+                    int B, int64_t hw, int C, int x_ld, int res_ld, int y_ld,
+                    int act /* | 0x100: res joins before act */, const void* prelu,
+                    float out_scale, void* stream);
+/* nearest x2 upsample NHWC (Upscale2d, stylegan2_layers.py:86-97) */
+int ppst_upsample_nearest2(const void* x, void* y, int B, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------- pooling / resizing ---- */
+/* GAP + GMP over HxW per (b,c): out [B][2C] = cat(mean, max)  (encoder_col.py:159-161).
+ * mask: optional [B][H][W] multiplier (mask channel i of encoder_col.py:176-178). */
+int64_t ppst_gap_gmp_ws(int B, int64_t hw, int C); /* workspace bytes */
+int ppst_gap_gmp(const void* x, const void* mask, void* out, void* ws, int B, int H, int W,
+                 int C, int ld, void* stream);
+/* integer-factor average pool (adaptive_avg_pool2d to H/f) NHWC -> dst slice */
+int ppst_avgpool(const void* x, void* y, int B, int H, int W, int C, int x_ld, int f,
+                 int y_ld, void* stream);
+/* bilinear resize, align_corners=False (F.interpolate; generator.py:75,274-277,
+ * encoder_col.py:129) NHWC -> dst slice with pixel stride y_ld */
+int ppst_bilinear(const void* x, void* y, int B, int H, int W, int C, int x_ld,
+                  int OH, int OW, int y_ld, void* stream);
+/* 2x2 max pool on masks (encoder_col.py:218) NHWC */
+int ppst_maxpool2(const void* x, void* y, int B, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------- linear ----
+ * y[b][n] = act( sum_k f(x[b][k]) * w[n][k] * wscale + bias[n]*bscale )
+ * (EqualLinear stylegan2_layers.py:222-242, EqualizedLinear :268-273,
+ * nn.Linear of the E2 projectors encoder_col.py:52-88).  relu_in applies ReLU
+ * to x first (the projectors' leading nn.ReLU). act: PPST_ACT_NONE/LRELU. */
+int ppst_linear(const void* x, const void* w, const void* bias, void* y,
+                int B, int K, int N, float wscale, float bscale, int relu_in, int act,
+                void* stream);
+/* rows: y = x * rsqrt(sum x^2 + eps)  (util.normalize, util/util.py:18-22; mode 0)
+ *       y = x / max(||x||, eps)        (F.normalize; mode 1) */
+int ppst_l2norm_rows(const void* x, void* y, int B, int K, float eps, int mode, void* stream);
+/* y = a*(1-r) + b*r (util.lerp, util/util.py:32-35) */
+int ppst_lerp(const void* a, const void* b, void* y, int64_t n, float r, void* stream);
+/* GeneratorModulation (generator.py:80-91): y[b,p,c] = x[b,p,c]*scale[b,c] + bias[b,c] */
+int ppst_spatial_modulation(const void* x, const void* scale, const void* bias, void* y,
+                            int B, int64_t hw, int C, void* stream);
+
+/* ------------------------------------------------------ correspondence --- */
+/* PPSTModel.Rselfcorr (ppst_model.py:330-339): fea NHWC [B][H][W][C] ->
+ * out NHWC slice [B][H/4][W/4][256] at pixel stride out_ld. */
+int ppst_rselfcorr(const void* fea, void* out, int B, int H, int W, int C, int out_ld,
+                   void* stream);
+/* corrm feature prep (ppst_model.py:349-361): per pixel, mean-centre the first
+ * `ncenter` channels, then L2-normalise all C channels (+eps). [B][P][C] rows. */
+int ppst_corr_prep(const void* fea, void* out, int B, int P, int C, int ncenter, void* stream);
+/* fp32 MFMA GEMM, C[b] = alpha * A[b] (MxK, row-major) * B[b]^T (NxK row-major) */
+int ppst_gemm_nt_f32(const void* A, const void* Bm, void* C, int batch, int M, int N, int K,
+                     float alpha, void* stream);
+/* fp32 MFMA GEMM, C[b] = A[b] (MxK row-major) * B[b] (KxN row-major, ldb) -> ldc */
+int ppst_gemm_nn_f32(const void* A, const void* Bm, void* C, int batch, int M, int N, int K,
+                     int ldb, int ldc, void* stream);
+/* in-place row softmax of x/div (F.softmax(matmul/0.01, dim=-1), ppst_model.py:363) */
+int ppst_softmax_rows(void* x, int64_t rows, int cols, float div, void* stream);
+/* PPSTModel.warp unfold/fold plumbing (ppst_model.py:366-387): NCHW image
+ * [B][C][H][W] <-> patch rows [B][P][C*s*s] */
+int ppst_unfold_patches(const void* x, void* y, int B, int C, int H, int W, int s, void* stream);
+int ppst_fold_patches(const void* x, void* y, int B, int C, int H, int W, int s, void* stream);
+
+/* ------------------------------------------------------- post-process ---- */
+/* util.tensor2im quantisation (util/util.py:98-131): NCHW fp32 [-1,1] ->
+ * HWC uint8, ((x+1)/2*255) clipped and truncated. */
+int ppst_tensor2im_u8(const void* x, void* y, int B, int C, int H, int W, void* stream);
+/* colour-guided filter (photo_gif.py:43 cv2.ximgproc.guidedFilter): guide, src
+ * uint8 HWC [B][H][W][3]; out fp32 NCHW = (q/255 - 0.5)*2 as
+ * PPSTModel.decode does (ppst_model.py:296-305).  work: >= ppst_guided_filter_ws() bytes. */
+int64_t ppst_guided_filter_ws(int B, int H, int W);
+int ppst_guided_filter(const void* guide_u8, const void* src_u8, void* out, void* out_u8,
+                       int B, int H, int W, int r, float eps, void* work, void* stream);
+
+/* ---------------------------------------------------------- profiling ----
+ * Opt-in HIP-event timing of the conv launches (bench.py roofline): when
+ * enabled every ppst_conv2d_mfma call is bracketed by events on its stream. */
+int ppst_prof_enable(int on);
+/* after a stream sync: total ms, launches, algorithmic flop of bracketed calls */
+int ppst_prof_collect(double* ms, int64_t* launches, double* flop);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPST_HIP_H */

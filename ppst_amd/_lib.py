@@ -1,0 +1,93 @@
+"""ctypes binding of libppst_hip.so (the C ABI declared in include/ppst_hip.h).
+
+The product path has NO fallback: if the library is missing or a symbol cannot
+be resolved, importing this module raises, and every op that reaches a kernel
+raises on non-CUDA tensors (like the reference's CHECK_CUDA,
+stylegan2_op/upfirdn2d.cpp:9, fused_bias_act.cpp:8).
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libppst_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "ppst_amd: %s is missing -- build it with `python -m ppst_amd.build` "
+        "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+
+lib = ctypes.CDLL(LIB_PATH)
+
+vp, i32, i64, f32, f64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+
+
+class ConvArgs(ctypes.Structure):
+    """ppst_conv_args (include/ppst_hip.h)."""
+    _fields_ = [
+        ("x", vp), ("wpack", vp), ("steps", vp), ("y", vp), ("bias", vp), ("noise", vp),
+        ("prelu", vp), ("stats", vp), ("residual", vp),
+        ("noise_weight", f32), ("out_scale", f32),
+        ("B", i32), ("in_h", i32), ("in_w", i32), ("in_ld", i32),
+        ("out_h", i32), ("out_w", i32), ("out_ld", i32), ("cout", i32),
+        ("nsteps", i32), ("n_groups", i32), ("pad_mode", i32),
+        ("in_off_y", i32), ("in_off_x", i32), ("out_sy", i32), ("out_sx", i32),
+        ("act", i32), ("precision", i32), ("res_ld", i32), ("tile_h", i32), ("tile_w", i32),
+        ("halo", i32), ("bn", i32),
+    ]
+
+
+_SIGS = {
+    "ppst_version": (i32, []),
+    "ppst_upfirdn2d": (i32, [vp, vp, vp] + [i32] * 14 + [i32, vp]),
+    "ppst_blur_nhwc": (i32, [vp, vp, vp] + [i32] * 10 + [vp]),
+    "ppst_fused_bias_act": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, i32, vp]),
+    "ppst_nchw_to_nhwc": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ppst_nhwc_to_nchw": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ppst_conv_pack": (i32, [vp, i64, i64, i64, i64, f32, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "ppst_upscale_weight": (i32, [vp, vp, i32, i32, f32, vp]),
+    "ppst_conv2d_mfma": (i32, [ctypes.POINTER(ConvArgs), vp]),
+    "ppst_conv_tiles": (i32, [i32, i32]),
+    "ppst_conv1x1_small_cin": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp]),
+    "ppst_conv1x1_small_cout": (i32, [vp, vp, vp, vp, i64, i32, i32, f32, vp]),
+    "ppst_in_stats": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(i32), vp]),
+    "ppst_in_finalize": (i32, [vp, i32, vp, vp, vp, i32, i32, f64, f32, vp]),
+    "ppst_affine_act": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, f32, vp]),
+    "ppst_upsample_nearest2": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ppst_gap_gmp_ws": (i64, [i32, i64, i32]),
+    "ppst_gap_gmp": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ppst_avgpool": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ppst_bilinear": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ppst_maxpool2": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ppst_linear": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, f32, i32, i32, vp]),
+    "ppst_l2norm_rows": (i32, [vp, vp, i32, i32, f32, i32, vp]),
+    "ppst_lerp": (i32, [vp, vp, vp, i64, f32, vp]),
+    "ppst_spatial_modulation": (i32, [vp, vp, vp, vp, i32, i64, i32, vp]),
+    "ppst_rselfcorr": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ppst_corr_prep": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ppst_gemm_nt_f32": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp]),
+    "ppst_gemm_nn_f32": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ppst_softmax_rows": (i32, [vp, i64, i32, f32, vp]),
+    "ppst_unfold_patches": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ppst_fold_patches": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ppst_tensor2im_u8": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ppst_guided_filter_ws": (i64, [i32, i32, i32]),
+    "ppst_guided_filter": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp]),
+    "ppst_prof_enable": (i32, [i32]),
+    "ppst_prof_collect": (i32, [ctypes.POINTER(f64), ctypes.POINTER(i64), ctypes.POINTER(f64)]),
+}
+
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here == ABI mismatch: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+_ERR = {-1: "PPST_EINVAL (bad size / flag combination)", -2: "PPST_EUNSUPPORTED", -3: "PPST_ENULL"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, _ERR.get(rc, "hipError_t %d" % rc)))
+
+
+def exported_symbols():
+    return sorted(_SIGS)

@@ -1,0 +1,335 @@
+// Semantic-correspondence kernels (models/ppst_model.py:330-387):
+//   Rselfcorr  -> ppst_rselfcorr      (no 268 MB (B,64,4096,16,16) intermediate)
+//   corrm      -> ppst_corr_prep (centre + L2 normalise) + ppst_gemm_nt_f32 + ppst_softmax_rows
+//   warp / E2.warp -> ppst_gemm_nn_f32 (+ unfold/fold plumbing)
+// The two GEMMs use the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the logits are cosine
+// similarities divided by T = 0.01, so a bf16-class error would move softmax outputs by
+// ~1e-2 relative.  fp32 MFMA peak is 157 TFLOP/s; these GEMMs are ~33 GFLOP per swap.
+#include "common.h"
+
+// ---------------------------------------------------------------- Rselfcorr --
+// fea NHWC [B][H][W][C=64]; one wave per 4x4 patch.  lane = channel while loading,
+// centring and normalising (wave reductions over the 64 channels); the normalised patch
+// goes to LDS [c][16] and lane (i = l>>2, j = 4*(l&3)..+3) accumulates 4 Gram entries
+// over c.  out NHWC [B][H/4][W/4][256], channel = i*16 + j, written as one 1-KB row per wave.
+__global__ __launch_bounds__(256) void rselfcorr_kernel(const float* __restrict__ fea, float* __restrict__ out, int B, int H, int W,
+                                                        int out_ld, float eps, int64_t npatch) {
+  __shared__ __attribute__((aligned(16))) float xs[4][64][16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int gy = H >> 2, gx = W >> 2;
+  for (int64_t p = (int64_t)blockIdx.x * 4 + wv; p < npatch; p += (int64_t)gridDim.x * 4) {
+    int px = (int)(p % gx);
+    int64_t r = p / gx;
+    int py = (int)(r % gy);
+    int b = (int)(r / gy);
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int iy = py * 4 + (i >> 2), ix = px * 4 + (i & 3);
+      v[i] = fea[(((int64_t)b * H + iy) * W + ix) * 64 + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float m = wave_sum(v[i]) * (1.f / 64.f);
+      float d = v[i] - m;
+      float nrm = sqrtf(wave_sum(d * d)) + eps;
+      v[i] = d / nrm;
+    }
+    float4* row = (float4*)&xs[wv][lane][0];
+    row[0] = make_float4(v[0], v[1], v[2], v[3]);
+    row[1] = make_float4(v[4], v[5], v[6], v[7]);
+    row[2] = make_float4(v[8], v[9], v[10], v[11]);
+    row[3] = make_float4(v[12], v[13], v[14], v[15]);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes (no other wave touches xs[wv])
+    __builtin_amdgcn_wave_barrier();
+    const int i = lane >> 2, j4 = (lane & 3) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int c = 0; c < 64; ++c) {
+      float xi = xs[wv][c][i];
+      float4 xj = *(const float4*)&xs[wv][c][j4];
+      acc.x += xi * xj.x; acc.y += xi * xj.y; acc.z += xi * xj.z; acc.w += xi * xj.w;
+    }
+    *(float4*)(out + (((int64_t)b * gy + py) * gx + px) * out_ld + i * 16 + j4) = acc;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+extern "C" int ppst_rselfcorr(const void* fea, void* out, int B, int H, int W, int C, int out_ld, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || H % 4 || W % 4 || C != 64 || out_ld < 256 || out_ld % 4) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!fea || !out) return PPST_ENULL;
+  int64_t npatch = (int64_t)B * (H / 4) * (W / 4);
+  int64_t blocks = cdiv64(npatch, 4);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(rselfcorr_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)fea, (float*)out, B, H,
+                     W, out_ld, 2.220446049250313e-16f, npatch);
+  return PPST_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------- corr prep --
+// rows [B*P][C]: mean-centre the first `ncenter` channels, L2-normalise all C (+eps).
+// One wave per row, C <= 1024, C % 64 == 0.
+__global__ __launch_bounds__(256) void corr_prep_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int C,
+                                                        int ncenter, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int per = C >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+    const float* xr = x + r * C;
+    float v[16];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < per) {
+        int c = i * 64 + lane;
+        v[i] = xr[c];
+        if (c < ncenter) s += v[i];
+      }
+    float mean = ncenter > 0 ? wave_sum(s) / (float)ncenter : 0.f;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < per) {
+        int c = i * 64 + lane;
+        if (c < ncenter) v[i] -= mean;
+        q += v[i] * v[i];
+      }
+    float nrm = sqrtf(wave_sum(q)) + eps;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < per) y[r * C + i * 64 + lane] = v[i] / nrm;
+  }
+}
+extern "C" int ppst_corr_prep(const void* fea, void* out, int B, int P, int C, int ncenter, void* stream) {
+  if (B < 0 || P <= 0 || C <= 0 || C % 64 || C > 1024 || ncenter < 0 || ncenter > C) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!fea || !out) return PPST_ENULL;
+  int64_t rows = (int64_t)B * P;
+  int64_t blocks = cdiv64(rows, 4);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(corr_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)fea, (float*)out, rows, C,
+                     ncenter, 2.220446049250313e-16f);
+  return PPST_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------ fp32 MFMA GEMM --
+// C[b] = alpha * A[b] (M x K, row-major lda) * op(B[b]); B_NT: B is N x K row-major (ldb)
+// else K x N row-major (ldb).  Block 128 x (32*NTL) x 16, 4 waves (32 rows each), register
+// prefetch + double-buffered LDS (one barrier per 16-deep K tile).
+template <int NTL, bool B_NT>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
+                                                       int M, int N, int K, int lda, int ldb, int ldc, int64_t sA, int64_t sB,
+                                                       int64_t sC, float alpha) {
+  constexpr int BM = 128, BN = 32 * NTL, BK = 16;
+  constexpr int LDA_S = BK + 1;
+  constexpr int LDB_S = B_NT ? BK + 1 : BN + 1;
+  constexpr int BS_SIZE = B_NT ? BN * LDB_S : BK * LDB_S;
+  constexpr int B_F4 = BN * BK / 4;
+  constexpr int B_IT = (B_F4 + 255) / 256;
+  __shared__ float As[2][BM * LDA_S];
+  __shared__ float Bs[2][BS_SIZE];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  A += (int64_t)blockIdx.z * sA;
+  Bm += (int64_t)blockIdx.z * sB;
+  C += (int64_t)blockIdx.z * sC;
+  float4 ra[2], rb[B_IT];
+  auto g_load = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      int idx = tid + it * 256, row = idx >> 2, c4 = idx & 3;
+      ra[it] = (m0 + row < M) ? *(const float4*)(A + (int64_t)(m0 + row) * lda + k0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      int idx = tid + it * 256;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < B_F4) {
+        if (B_NT) {
+          int row = idx >> 2, c4 = idx & 3;
+          if (n0 + row < N) v = *(const float4*)(Bm + (int64_t)(n0 + row) * ldb + k0 + c4 * 4);
+        } else {
+          int k = idx / (BN / 4), n4 = idx - k * (BN / 4);
+          if (n0 + n4 * 4 < N) v = *(const float4*)(Bm + (int64_t)(k0 + k) * ldb + n0 + n4 * 4);
+        }
+      }
+      rb[it] = v;
+    }
+  };
+  auto s_store = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      int idx = tid + it * 256, row = idx >> 2, c4 = idx & 3;
+      float* d = &As[buf][row * LDA_S + c4 * 4];
+      d[0] = ra[it].x; d[1] = ra[it].y; d[2] = ra[it].z; d[3] = ra[it].w;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      int idx = tid + it * 256;
+      if (idx < B_F4) {
+        float* d;
+        if (B_NT) { int row = idx >> 2, c4 = idx & 3; d = &Bs[buf][row * LDB_S + c4 * 4]; }
+        else { int k = idx / (BN / 4), n4 = idx - k * (BN / 4); d = &Bs[buf][k * LDB_S + n4 * 4]; }
+        d[0] = rb[it].x; d[1] = rb[it].y; d[2] = rb[it].z; d[3] = rb[it].w;
+      }
+    }
+  };
+  f32x16 acc[NTL];
+#pragma unroll
+  for (int t = 0; t < NTL; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  g_load(0);
+  s_store(0);
+  __syncthreads();
+  const int nk = K / BK;
+  const int li = lane & 31, lk = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) g_load((kt + 1) * BK);
+    const float* as = &As[buf][(wv * 32 + li) * LDA_S];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float av = as[kk + lk];
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        float bv = B_NT ? Bs[buf][(t * 32 + li) * LDB_S + kk + lk] : Bs[buf][(kk + lk) * LDB_S + t * 32 + li];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) s_store(buf ^ 1);
+    __syncthreads();
+  }
+  // C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    int n = n0 + t * 32 + li;
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      int m = m0 + wv * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * lk;
+      if (m < M && n < N) C[(int64_t)m * ldc + n] = acc[t][rg] * alpha;
+    }
+  }
+}
+
+template <bool B_NT>
+static int gemm_dispatch(const float* A, const float* Bm, float* C, int batch, int M, int N, int K, int lda, int ldb, int ldc,
+                         int64_t sA, int64_t sB, int64_t sC, float alpha, hipStream_t st) {
+  int ntl = N >= 160 ? 5 : (N >= 128 ? 4 : (N + 31) / 32);
+  if (N % 160 != 0 && N % 128 == 0) ntl = 4;
+  dim3 grid(cdiv(M, 128), cdiv(N, 32 * ntl), batch);
+#define GL(NTL) hipLaunchKernelGGL((gemm_f32_kernel<NTL, B_NT>), grid, dim3(256), 0, st, A, Bm, C, M, N, K, lda, ldb, ldc, sA, sB, sC, alpha)
+  switch (ntl) {
+    case 1: GL(1); break;
+    case 2: GL(2); break;
+    case 3: GL(3); break;
+    case 4: GL(4); break;
+    default: GL(5); break;
+  }
+#undef GL
+  return PPST_LAUNCH_CHECK();
+}
+extern "C" int ppst_gemm_nt_f32(const void* A, const void* Bm, void* C, int batch, int M, int N, int K, float alpha, void* stream) {
+  if (batch < 0 || M <= 0 || N <= 0 || K <= 0 || K % 16) return PPST_EINVAL;
+  if (batch == 0) return PPST_OK;
+  if (!A || !Bm || !C) return PPST_ENULL;
+  return gemm_dispatch<true>((const float*)A, (const float*)Bm, (float*)C, batch, M, N, K, K, K, N, (int64_t)M * K, (int64_t)N * K,
+                             (int64_t)M * N, alpha, as_stream(stream));
+}
+extern "C" int ppst_gemm_nn_f32(const void* A, const void* Bm, void* C, int batch, int M, int N, int K, int ldb, int ldc, void* stream) {
+  if (batch < 0 || M <= 0 || N <= 0 || K <= 0 || K % 16 || N % 4 || ldb % 4 || ldb < N || ldc < N) return PPST_EINVAL;
+  if (batch == 0) return PPST_OK;
+  if (!A || !Bm || !C) return PPST_ENULL;
+  return gemm_dispatch<false>((const float*)A, (const float*)Bm, (float*)C, batch, M, N, K, K, ldb, ldc, (int64_t)M * K,
+                              (int64_t)K * ldb, (int64_t)M * ldc, 1.f, as_stream(stream));
+}
+
+// ------------------------------------------------------------------ softmax --
+// in-place softmax(x / div) over rows of `cols` (<= 16384) floats; one block per row.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int cols, float div) {
+  __shared__ float red[4];
+  float* row = x + (int64_t)blockIdx.x * cols;
+  constexpr int MAXV = 16;
+  float4 v[MAXV];
+  const int n4 = cols >> 2;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int idx = threadIdx.x + i * 256;
+    if (idx < n4) {
+      float4 t = ((const float4*)row)[idx];
+      t.x /= div; t.y /= div; t.z /= div; t.w /= div;
+      v[i] = t;
+      mx = fmaxf(mx, fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w)));
+    }
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int idx = threadIdx.x + i * 256;
+    if (idx < n4) {
+      v[i].x = __expf(v[i].x - mx); v[i].y = __expf(v[i].y - mx); v[i].z = __expf(v[i].z - mx); v[i].w = __expf(v[i].w - mx);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  s = (red[0] + red[1]) + (red[2] + red[3]);
+  const float inv = 1.f / s;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int idx = threadIdx.x + i * 256;
+    if (idx < n4) ((float4*)row)[idx] = make_float4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+  }
+}
+extern "C" int ppst_softmax_rows(void* x, int64_t rows, int cols, float div, void* stream) {
+  if (rows < 0 || cols <= 0 || cols % 4 || cols > 16384 || div == 0.f || rows > 0x7fffffff) return PPST_EINVAL;
+  if (rows == 0) return PPST_OK;
+  if (!x) return PPST_ENULL;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, as_stream(stream), (float*)x, cols, div);
+  return PPST_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------- unfold / fold (F.unfold) --
+// x NCHW [B][C][H][W] <-> y [B][P][C*s*s], P = (H/s)*(W/s), column = c*s*s + ky*s + kx
+template <bool FOLD>
+__global__ __launch_bounds__(256) void patches_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W, int s,
+                                                      int64_t total) {
+  const int gx = W / s, css = C * s * s;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int col = (int)(t % css);
+    int64_t r = t / css;
+    int p = (int)(r % ((H / s) * gx));
+    int b = (int)(r / ((H / s) * gx));
+    int c = col / (s * s), k = col - c * s * s, ky = k / s, kx = k - ky * s;
+    int py = p / gx, px = p - py * gx;
+    int64_t img = (((int64_t)b * C + c) * H + py * s + ky) * W + px * s + kx;
+    if (FOLD) dst[img] = src[t];
+    else dst[t] = src[img];
+  }
+}
+extern "C" int ppst_unfold_patches(const void* x, void* y, int B, int C, int H, int W, int s, void* stream) {
+  if (B < 0 || C <= 0 || H <= 0 || W <= 0 || s <= 0 || H % s || W % s) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !y) return PPST_ENULL;
+  int64_t total = (int64_t)B * C * H * W;
+  int64_t blocks = cdiv64(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(patches_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, C, H, W, s, total);
+  return PPST_LAUNCH_CHECK();
+}
+extern "C" int ppst_fold_patches(const void* x, void* y, int B, int C, int H, int W, int s, void* stream) {
+  if (B < 0 || C <= 0 || H <= 0 || W <= 0 || s <= 0 || H % s || W % s) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !y) return PPST_ENULL;
+  int64_t total = (int64_t)B * C * H * W;
+  int64_t blocks = cdiv64(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(patches_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, C, H, W, s, total);
+  return PPST_LAUNCH_CHECK();
+}

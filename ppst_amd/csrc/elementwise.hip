@@ -1,0 +1,547 @@
+// HBM-bound glue kernels of the PPST path on NHWC fp32 activations:
+// layout transposes, instance-norm statistics / finalize / apply (+StyleMod, +residual,
+// +activation), pooling, bilinear resize, small-channel 1x1 convs, lerp, tensor2im.
+// Each is a single pass at 16 B per lane; algorithmic bytes are listed in DESIGN.md.
+#include "common.h"
+
+#define GRID_CAP (256 * 16)
+static inline unsigned grid_for(int64_t work, int threads = 256) {
+  int64_t b = cdiv64(work, threads);
+  if (b > GRID_CAP) b = GRID_CAP;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// ------------------------------------------------------------------ layout --
+// x[b][c][p] <-> y[b][p][c]; 32(c) x 64(p) tiles through LDS (pad 1: conflict-free)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int64_t P) {
+  __shared__ float sm[32][65];
+  const int64_t p0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 32;
+  const int b = blockIdx.z;
+  const float* xb = x + (int64_t)b * C * P;
+  float* yb = y + (int64_t)b * C * P;
+  {
+    int tp = threadIdx.x & 63, tc = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int c = c0 + tc + i * 4;
+      int64_t p = p0 + tp;
+      sm[tc + i * 4][tp] = (c < C && p < P) ? xb[(int64_t)c * P + p] : 0.f;
+    }
+  }
+  __syncthreads();
+  {
+    int tc = threadIdx.x & 31, tp = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int c = c0 + tc;
+      int64_t p = p0 + tp + i * 8;
+      if (c < C && p < P) yb[p * C + c] = sm[tc][tp + i * 8];
+    }
+  }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int64_t P) {
+  __shared__ float sm[64][33];
+  const int64_t p0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 32;
+  const int b = blockIdx.z;
+  const float* xb = x + (int64_t)b * C * P;
+  float* yb = y + (int64_t)b * C * P;
+  {
+    int tc = threadIdx.x & 31, tp = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int c = c0 + tc;
+      int64_t p = p0 + tp + i * 8;
+      sm[tp + i * 8][tc] = (c < C && p < P) ? xb[p * C + c] : 0.f;
+    }
+  }
+  __syncthreads();
+  {
+    int tp = threadIdx.x & 63, tc = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int c = c0 + tc + i * 4;
+      int64_t p = p0 + tp;
+      if (c < C && p < P) yb[(int64_t)c * P + p] = sm[tp][tc + i * 4];
+    }
+  }
+}
+extern "C" int ppst_nchw_to_nhwc(const void* x, void* y, int B, int C, int H, int W, void* stream) {
+  if (B < 0 || C <= 0 || H <= 0 || W <= 0) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !y) return PPST_ENULL;
+  int64_t P = (int64_t)H * W;
+  dim3 grid((unsigned)cdiv64(P, 64), cdiv(C, 32), B);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, C, P);
+  return PPST_LAUNCH_CHECK();
+}
+extern "C" int ppst_nhwc_to_nchw(const void* x, void* y, int B, int C, int H, int W, void* stream) {
+  if (B < 0 || C <= 0 || H <= 0 || W <= 0) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !y) return PPST_ENULL;
+  int64_t P = (int64_t)H * W;
+  dim3 grid((unsigned)cdiv64(P, 64), cdiv(C, 32), B);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, C, P);
+  return PPST_LAUNCH_CHECK();
+}
+
+// --------------------------------------------------- per-(b,c) reductions --
+// One block reduces PIX_CHUNK pixels of one image for all channels and writes a
+// partial (v0, v1) per channel: MODE 0 = (sum w*x, sum w*x^2) [instance norm; w = border
+// multiplicity when the statistics are those of the ReplicationPad2d(1)-padded tensor],
+// MODE 1 = (sum m*x, max m*x) [GAP/GMP with optional mask].
+#define PIX_CHUNK 1024
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                          float* __restrict__ partial, int H, int W, int C, int ld,
+                                                          int rep_pad, int nchunks) {
+  __shared__ float s0[256], s1[256];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int64_t P = (int64_t)H * W;
+  const int64_t pbeg = (int64_t)chunk * PIX_CHUNK;
+  const int64_t pend = (pbeg + PIX_CHUNK < P) ? pbeg + PIX_CHUNK : P;
+  int lanesC = 1;
+  while (lanesC < C && lanesC < 256) lanesC <<= 1;
+  const int rows = 256 / lanesC;
+  const int cl = threadIdx.x % lanesC, pr = threadIdx.x / lanesC;
+  const float* xb = x + (int64_t)b * P * ld;
+  const float* mb = mask ? mask + (int64_t)b * P : nullptr;
+  for (int cbase = 0; cbase < C; cbase += lanesC) {
+    int c = cbase + cl;
+    float a0 = 0.f, a1 = (MODE == 1) ? -INFINITY : 0.f;
+    if (c < C) {
+      for (int64_t p = pbeg + pr; p < pend; p += rows) {
+        float v = xb[p * ld + c];
+        if (MODE == 0) {
+          float w = 1.f;
+          if (rep_pad) {
+            int py = (int)(p / W), px = (int)(p - (int64_t)py * W);
+            w = (float)((1 + (py == 0) + (py == H - 1)) * (1 + (px == 0) + (px == W - 1)));
+          }
+          a0 += w * v;
+          a1 += w * v * v;
+        } else {
+          if (mb) v *= mb[p];
+          a0 += v;
+          a1 = fmaxf(a1, v);
+        }
+      }
+    }
+    s0[threadIdx.x] = a0;
+    s1[threadIdx.x] = a1;
+    __syncthreads();
+    if (pr == 0 && c < C) {
+      for (int r = 1; r < rows; ++r) {
+        a0 += s0[r * lanesC + cl];
+        a1 = (MODE == 1) ? fmaxf(a1, s1[r * lanesC + cl]) : a1 + s1[r * lanesC + cl];
+      }
+      float* o = partial + (((int64_t)b * nchunks + chunk) * C + c) * 2;
+      o[0] = a0;
+      o[1] = a1;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int ppst_in_stats(const void* x, void* partial, int B, int H, int W, int C, int ld, int rep_pad,
+                             int* n_partials, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || ld < C) return PPST_EINVAL;
+  int nchunks = (int)cdiv64((int64_t)H * W, PIX_CHUNK);
+  if (n_partials) *n_partials = nchunks;
+  if (!x && !partial) return PPST_OK;  // size query
+  if (B == 0) return PPST_OK;
+  if (!x || !partial) return PPST_ENULL;
+  hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
+                     (const float*)nullptr, (float*)partial, H, W, C, ld, rep_pad, nchunks);
+  return PPST_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ partial, int n_partials,
+                                                          const float* __restrict__ style, const float* __restrict__ post_bias,
+                                                          float* __restrict__ ss, int B, int C, double count, float eps) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * C) return;
+  int b = i / C, c = i - b * C;
+  double s = 0.0, q = 0.0;
+  const float* p = partial + ((int64_t)b * n_partials * C + c) * 2;
+  for (int k = 0; k < n_partials; ++k) {
+    s += (double)p[(int64_t)k * C * 2];
+    q += (double)p[(int64_t)k * C * 2 + 1];
+  }
+  double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  double rstd = 1.0 / sqrt(var + (double)eps);
+  double a = rstd, sh = -mean * rstd;
+  if (style) {
+    double s0 = (double)style[(int64_t)b * 2 * C + c] + 1.0;
+    double s1 = (double)style[(int64_t)b * 2 * C + C + c];
+    a = rstd * s0;
+    sh = s1 - mean * a;
+  }
+  if (post_bias) sh += (double)post_bias[c];  // FusedLeakyReLU bias that follows the norm (ConvLayer norm='in')
+  ss[(int64_t)i * 2] = (float)a;
+  ss[(int64_t)i * 2 + 1] = (float)sh;
+}
+extern "C" int ppst_in_finalize(const void* partial, int n_partials, const void* style, const void* post_bias,
+                                void* scale_shift, int B, int C, double count, float eps, void* stream) {
+  if (B < 0 || C <= 0 || n_partials <= 0 || count <= 0) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!partial || !scale_shift) return PPST_ENULL;
+  hipLaunchKernelGGL(in_finalize_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, as_stream(stream),
+                     (const float*)partial, n_partials, (const float*)style, (const float*)post_bias, (float*)scale_shift, B, C,
+                     count, eps);
+  return PPST_LAUNCH_CHECK();
+}
+
+// y = act(a*x + s [+ res (before act)]) ; then [+ res (after act)] ; * out_scale
+// act flags: low byte = PPST_ACT_*, bit 8 = residual is added before the activation
+__device__ __forceinline__ float act_apply(float t, int act, float slope) {
+  if (act == PPST_ACT_LRELU) return (t > 0.f ? t : t * 0.2f) * 1.41421356237309515f;
+  if (act == PPST_ACT_PRELU) return t >= 0.f ? t : t * slope;
+  return t;
+}
+template <bool VEC>
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ ss,
+                                                         const float* __restrict__ res, const float* __restrict__ rss,
+                                                         float* __restrict__ y, int64_t hw, int C, int x_ld, int res_ld,
+                                                         int y_ld, int actf,
+                                                         const float* __restrict__ prelu, float out_scale, int64_t total) {
+  const int act = actf & 0xff;
+  const bool res_first = (actf >> 8) & 1;
+  const float slope = (act == PPST_ACT_PRELU && prelu) ? prelu[0] : 0.f;
+  constexpr int V = VEC ? 4 : 1;
+  const int cv = C / V;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int c = (int)(t % cv) * V;
+    int64_t bp = t / cv;  // b*hw + p
+    int b = (int)(bp / hw);
+    const float* sp = ss ? ss + ((int64_t)b * C + c) * 2 : nullptr;
+    const float* rp = (res && rss) ? rss + ((int64_t)b * C + c) * 2 : nullptr;
+    float xv[V], rv[V], o[V];
+    if (VEC) {
+      float4 v = *(const float4*)(x + bp * x_ld + c);
+      xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
+      if (res) {
+        float4 r = *(const float4*)(res + bp * res_ld + c);
+        rv[0] = r.x; rv[1] = r.y; rv[2] = r.z; rv[3] = r.w;
+      }
+    } else {
+      xv[0] = x[bp * x_ld + c];
+      if (res) rv[0] = res[bp * res_ld + c];
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      float tt = sp ? sp[i * 2] * xv[i] + sp[i * 2 + 1] : xv[i];
+      if (rp) rv[i] = rp[i * 2] * rv[i] + rp[i * 2 + 1];
+      if (res && res_first) tt += rv[i];
+      tt = act_apply(tt, act, slope);
+      if (res && !res_first) tt += rv[i];
+      o[i] = tt * out_scale;
+    }
+    if (VEC) *(float4*)(y + bp * y_ld + c) = make_float4(o[0], o[1], o[2], o[3]);
+    else y[bp * y_ld + c] = o[0];
+  }
+}
+extern "C" int ppst_affine_act(const void* x, const void* scale_shift, const void* res, const void* res_scale_shift, void* y,
+                               int B, int64_t hw, int C, int x_ld, int res_ld, int y_ld, int act, const void* prelu,
+                               float out_scale, void* stream) {
+  if (B < 0 || hw <= 0 || C <= 0 || x_ld < C || y_ld < C || (res && res_ld < C)) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !y) return PPST_ENULL;
+  bool vec = C % 4 == 0 && x_ld % 4 == 0 && y_ld % 4 == 0 && (!res || res_ld % 4 == 0) &&
+             (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) % 16 == 0);
+  int64_t total = (int64_t)B * hw * (vec ? C / 4 : C);
+  if (vec)
+    hipLaunchKernelGGL(affine_act_kernel<true>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
+                       (const float*)scale_shift, (const float*)res, (const float*)res_scale_shift, (float*)y, hw, C, x_ld,
+                       res_ld, y_ld, act, (const float*)prelu, out_scale, total);
+  else
+    hipLaunchKernelGGL(affine_act_kernel<false>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
+                       (const float*)scale_shift, (const float*)res, (const float*)res_scale_shift, (float*)y, hw, C, x_ld,
+                       res_ld, y_ld, act, (const float*)prelu, out_scale, total);
+  return PPST_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------- GAP/GMP --
+__global__ __launch_bounds__(256) void gap_gmp_finalize_kernel(const float* __restrict__ partial, int n_partials,
+                                                               float* __restrict__ out, int B, int C, double count) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * C) return;
+  int b = i / C, c = i - b * C;
+  double s = 0.0;
+  float m = -INFINITY;
+  const float* p = partial + ((int64_t)b * n_partials * C + c) * 2;
+  for (int k = 0; k < n_partials; ++k) {
+    s += (double)p[(int64_t)k * C * 2];
+    m = fmaxf(m, p[(int64_t)k * C * 2 + 1]);
+  }
+  out[(int64_t)b * 2 * C + c] = (float)(s / count);
+  out[(int64_t)b * 2 * C + C + c] = m;
+}
+extern "C" int64_t ppst_gap_gmp_ws(int B, int64_t hw, int C) { return cdiv64(hw, PIX_CHUNK) * C * 2 * B * (int64_t)sizeof(float); }
+extern "C" int ppst_gap_gmp(const void* x, const void* mask, void* out, void* ws, int B, int H, int W, int C, int ld,
+                             void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || ld < C) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !out || !ws) return PPST_ENULL;
+  int nchunks = (int)cdiv64((int64_t)H * W, PIX_CHUNK);
+  hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
+                     (const float*)mask, (float*)ws, H, W, C, ld, 0, nchunks);
+  int e = PPST_LAUNCH_CHECK();
+  if (e) return e;
+  hipLaunchKernelGGL(gap_gmp_finalize_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, as_stream(stream),
+                     (const float*)ws, nchunks, (float*)out, B, C, (double)H * W);
+  return PPST_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------ pooling / resize ---
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
+                                                      int C, int x_ld, int f, int y_ld, int64_t total) {
+  const int OH = H / f, OW = W / f, c4n = C >> 2;
+  const float inv = 1.f / (float)(f * f);
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int c = (int)(t % c4n) * 4;
+    int64_t r = t / c4n;
+    int ox = (int)(r % OW); r /= OW;
+    int oy = (int)(r % OH);
+    int b = (int)(r / OH);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int dy = 0; dy < f; ++dy)
+      for (int dx = 0; dx < f; ++dx) {
+        float4 v = *(const float4*)(x + (((int64_t)b * H + oy * f + dy) * W + ox * f + dx) * x_ld + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    *(float4*)(y + (((int64_t)b * OH + oy) * OW + ox) * y_ld + c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  }
+}
+extern "C" int ppst_avgpool(const void* x, void* y, int B, int H, int W, int C, int x_ld, int f, int y_ld, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || x_ld % 4 || y_ld % 4 || f <= 0 || H % f || W % f || x_ld < C || y_ld < C)
+    return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !y) return PPST_ENULL;
+  int64_t total = (int64_t)B * (H / f) * (W / f) * (C / 4);
+  hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y,
+                     H, W, C, x_ld, f, y_ld, total);
+  return PPST_LAUNCH_CHECK();
+}
+
+// F.interpolate(mode='bilinear', align_corners=False): src = (dst+0.5)*in/out - 0.5, clamped at 0
+__global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
+                                                       int C, int x_ld, int OH, int OW, int y_ld, int64_t total) {
+  const int c4n = C >> 2;
+  const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int c = (int)(t % c4n) * 4;
+    int64_t r = t / c4n;
+    int ox = (int)(r % OW); r /= OW;
+    int oy = (int)(r % OH);
+    int b = (int)(r / OH);
+    float fy = fmaxf(((float)oy + 0.5f) * sh - 0.5f, 0.f);
+    float fx = fmaxf(((float)ox + 0.5f) * sw - 0.5f, 0.f);
+    int y0 = (int)fy, x0 = (int)fx;
+    int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+    float ly = fy - (float)y0, lx = fx - (float)x0;
+    float hy = 1.f - ly, hx = 1.f - lx;
+    const float* base = x + (int64_t)b * H * W * x_ld + c;
+    float4 v00 = *(const float4*)(base + ((int64_t)y0 * W + x0) * x_ld);
+    float4 v01 = *(const float4*)(base + ((int64_t)y0 * W + x1) * x_ld);
+    float4 v10 = *(const float4*)(base + ((int64_t)y1 * W + x0) * x_ld);
+    float4 v11 = *(const float4*)(base + ((int64_t)y1 * W + x1) * x_ld);
+    float4 o;
+    o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+    o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+    o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+    o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+    *(float4*)(y + (((int64_t)b * OH + oy) * OW + ox) * y_ld + c) = o;
+  }
+}
+extern "C" int ppst_bilinear(const void* x, void* y, int B, int H, int W, int C, int x_ld, int OH, int OW, int y_ld,
+                             void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || x_ld % 4 || y_ld % 4 || OH <= 0 || OW <= 0 || x_ld < C || y_ld < C)
+    return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !y) return PPST_ENULL;
+  int64_t total = (int64_t)B * OH * OW * (C / 4);
+  hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y,
+                     H, W, C, x_ld, OH, OW, y_ld, total);
+  return PPST_LAUNCH_CHECK();
+}
+
+// nearest x2 upsample (Upscale2d, stylegan2_layers.py:86-97; the <128 px branch of
+// EqualizedConv2d :322-323)
+__global__ __launch_bounds__(256) void upsample_nearest2_kernel(const float4* __restrict__ x, float4* __restrict__ y, int H, int W,
+                                                                int c4n, int64_t total) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int c = (int)(t % c4n);
+    int64_t r = t / c4n;
+    int ox = (int)(r % (2 * W)); r /= (2 * W);
+    int oy = (int)(r % (2 * H));
+    int64_t b = r / (2 * H);
+    y[t] = x[((b * H + (oy >> 1)) * W + (ox >> 1)) * c4n + c];
+  }
+}
+extern "C" int ppst_upsample_nearest2(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || C % 4) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !y) return PPST_ENULL;
+  int64_t total = (int64_t)B * 4 * H * W * (C / 4);
+  hipLaunchKernelGGL(upsample_nearest2_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float4*)x,
+                     (float4*)y, H, W, C / 4, total);
+  return PPST_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C,
+                                                       int64_t total) {
+  const int OH = H / 2, OW = W / 2;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int c = (int)(t % C);
+    int64_t r = t / C;
+    int ox = (int)(r % OW); r /= OW;
+    int oy = (int)(r % OH);
+    int b = (int)(r / OH);
+    const float* p = x + (((int64_t)b * H + oy * 2) * W + ox * 2) * C + c;
+    y[t] = fmaxf(fmaxf(p[0], p[C]), fmaxf(p[(int64_t)W * C], p[(int64_t)W * C + C]));
+  }
+}
+extern "C" int ppst_maxpool2(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+  if (B < 0 || H <= 1 || W <= 1 || C <= 0) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !y) return PPST_ENULL;
+  int64_t total = (int64_t)B * (H / 2) * (W / 2) * C;
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, H, W, C, total);
+  return PPST_LAUNCH_CHECK();
+}
+
+// --------------------------------------------------------- small 1x1 convs --
+// Cin <= 4 (FromRGB): thread = (pixel, 4 output channels)
+__global__ __launch_bounds__(256) void conv1x1_small_cin_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, float* __restrict__ y,
+                                                                int64_t npix, int cin, int in_ld, int cout, float wscale,
+                                                                int act, int64_t total) {
+  const int c4n = cout >> 2;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int co = (int)(t % c4n) * 4;
+    int64_t p = t / c4n;
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float acc = 0.f;
+      for (int ci = 0; ci < cin; ++ci) acc += x[p * in_ld + ci] * (w[(co + j) * cin + ci] * wscale);
+      if (bias) acc += bias[co + j];
+      o[j] = act_apply(acc, act, 0.f);
+    }
+    *(float4*)(y + p * cout + co) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+extern "C" int ppst_conv1x1_small_cin(const void* x, const void* w, const void* bias, void* y, int64_t npix, int cin,
+                                      int in_ld, int cout, float wscale, int act, void* stream) {
+  if (npix < 0 || cin <= 0 || cin > 4 || in_ld < cin || cout <= 0 || cout % 4) return PPST_EINVAL;
+  if (npix == 0) return PPST_OK;
+  if (!x || !w || !y) return PPST_ENULL;
+  int64_t total = npix * (cout / 4);
+  hipLaunchKernelGGL(conv1x1_small_cin_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
+                     (const float*)w, (const float*)bias, (float*)y, npix, cin, in_ld, cout, wscale, act, total);
+  return PPST_LAUNCH_CHECK();
+}
+
+// Cout <= 4 (ToRGB): 32 lanes cooperate on one pixel (float4 of channels each, strided over
+// Cin), xor-shuffle reduction inside the half wave.
+__global__ __launch_bounds__(256) void conv1x1_small_cout_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, float* __restrict__ y,
+                                                                 int64_t npix, int cin, int cout, float wscale) {
+  const int hl = threadIdx.x & 31;
+  const int64_t half_id = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
+  const int64_t nhalf = ((int64_t)gridDim.x * 256) >> 5;
+  for (int64_t p = half_id; p < npix; p += nhalf) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = hl * 4; c < cin; c += 128) {
+      float4 v = *(const float4*)(x + p * cin + c);
+      for (int j = 0; j < cout; ++j) {
+        float4 ww = *(const float4*)(w + (int64_t)j * cin + c);
+        acc[j] += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+      }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+    if (hl < cout) {
+      float r = hl == 0 ? acc[0] : hl == 1 ? acc[1] : hl == 2 ? acc[2] : acc[3];
+      y[p * cout + hl] = r * wscale + (bias ? bias[hl] : 0.f);
+    }
+  }
+}
+extern "C" int ppst_conv1x1_small_cout(const void* x, const void* w, const void* bias, void* y, int64_t npix, int cin,
+                                       int cout, float wscale, void* stream) {
+  if (npix < 0 || cin <= 0 || cin % 4 || cout <= 0 || cout > 4) return PPST_EINVAL;
+  if (npix == 0) return PPST_OK;
+  if (!x || !w || !y) return PPST_ENULL;
+  hipLaunchKernelGGL(conv1x1_small_cout_kernel, dim3(grid_for(npix * 32)), dim3(256), 0, as_stream(stream),
+                     (const float*)x, (const float*)w, (const float*)bias, (float*)y, npix, cin, cout, wscale);
+  return PPST_LAUNCH_CHECK();
+}
+
+// --------------------------------------------------------------- misc glue --
+__global__ __launch_bounds__(256) void lerp_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                                                   int64_t n, float r) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = a[i] * (1.f - r) + b[i] * r;  // util/util.py:35 (same operation order)
+}
+extern "C" int ppst_lerp(const void* a, const void* b, void* y, int64_t n, float r, void* stream) {
+  if (n < 0) return PPST_EINVAL;
+  if (n == 0) return PPST_OK;
+  if (!a || !b || !y) return PPST_ENULL;
+  hipLaunchKernelGGL(lerp_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), (const float*)a, (const float*)b, (float*)y, n, r);
+  return PPST_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void spatial_mod_kernel(const float* __restrict__ x, const float* __restrict__ sc,
+                                                          const float* __restrict__ bi, float* __restrict__ y, int64_t hw,
+                                                          int C, int64_t total) {
+  const int c4n = C >> 2;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int c = (int)(t % c4n) * 4;
+    int64_t bp = t / c4n;
+    int b = (int)(bp / hw);
+    float4 v = *(const float4*)(x + bp * C + c);
+    float4 s = *(const float4*)(sc + (int64_t)b * C + c);
+    float4 o = *(const float4*)(bi + (int64_t)b * C + c);
+    *(float4*)(y + bp * C + c) = make_float4(v.x * s.x + o.x, v.y * s.y + o.y, v.z * s.z + o.z, v.w * s.w + o.w);
+  }
+}
+extern "C" int ppst_spatial_modulation(const void* x, const void* scale, const void* bias, void* y, int B, int64_t hw, int C,
+                                       void* stream) {
+  if (B < 0 || hw <= 0 || C <= 0 || C % 4) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !scale || !bias || !y) return PPST_ENULL;
+  int64_t total = (int64_t)B * hw * (C / 4);
+  hipLaunchKernelGGL(spatial_mod_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
+                     (const float*)scale, (const float*)bias, (float*)y, hw, C, total);
+  return PPST_LAUNCH_CHECK();
+}
+
+// util.tensor2im (util/util.py:125-131): NCHW [-1,1] -> HWC uint8, clip then truncate.
+// The reference computes (x + 1) / 2.0 * 255.0 in fp32 numpy: same operation order here.
+__global__ __launch_bounds__(256) void tensor2im_kernel(const float* __restrict__ x, unsigned char* __restrict__ y, int C,
+                                                        int64_t P, int64_t total) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int c = (int)(t % C);
+    int64_t bp = t / C;
+    int64_t b = bp / P, p = bp - b * P;
+    float v = (x[(b * C + c) * P + p] + 1.f) / 2.0f * 255.0f;
+    v = fminf(fmaxf(v, 0.f), 255.f);
+    y[t] = (unsigned char)v;
+  }
+}
+extern "C" int ppst_tensor2im_u8(const void* x, void* y, int B, int C, int H, int W, void* stream) {
+  if (B < 0 || C <= 0 || H <= 0 || W <= 0) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !y) return PPST_ENULL;
+  int64_t P = (int64_t)H * W, total = (int64_t)B * P * C;
+  hipLaunchKernelGGL(tensor2im_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
+                     (unsigned char*)y, C, P, total);
+  return PPST_LAUNCH_CHECK();
+}

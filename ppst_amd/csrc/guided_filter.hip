@@ -1,0 +1,181 @@
+// Colour-guided filter post-process of PPSTModel.decode (models/ppst_model.py:288-306 ->
+// photo_gif.py:25-46 -> cv2.ximgproc.guidedFilter(guide=content, src=output, radius, eps)).
+// The arithmetic lives in opencv-contrib 4.8.1.78, which is not vendored by the reference:
+// this restates the published algorithm (He et al., as OpenCV implements it: fp32 work type,
+// normalised (2r+1)^2 box mean with BORDER_REFLECT, eps on the covariance diagonal, 3x3
+// symmetric inverse by cofactors, cvRound + saturate to uint8).  PARITY UNPINNED against
+// OpenCV itself; pinned against oracle/ppst_oracle.py:guided_filter_color.
+//
+// Box means are separable direct sums (no running sums: order-independent fp32 error):
+//   H pass: one block per image row, row staged in LDS with reflected borders;
+//   V pass: lanes along x (coalesced), 2r+1 row reads per output served by L1/L2.
+// Pipeline per batch (planes are [B][plane][H][W] fp32 in the caller's workspace):
+//   gf_h_stage1 (uint8 -> 21 h-sums: I(3), p(3), I_i*I_j(6), I_i*p_c(9))
+//   gf_v        (21 means)
+//   gf_solve    (-> 12 planes a_c[3], b_c)
+//   gf_h        (12 h-sums)
+//   gf_v_final  (means of a, b; q = sum a_k I_k + b; round; uint8 + fp32 NCHW (q/255-0.5)*2)
+#include "common.h"
+
+#define GF_MAXW 2048
+#define GF_MAXR 64
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {  // cv2.BORDER_REFLECT (edge pixel repeated)
+  if (i < 0) i = -i - 1;
+  if (i >= n) i = 2 * n - 1 - i;
+  return i;
+}
+
+// plane value for stage 1 from the uint8 inputs at one pixel
+__device__ __forceinline__ float gf_plane_value(int pl, const unsigned char* g, const unsigned char* s) {
+  float I0 = g[0], I1 = g[1], I2 = g[2];
+  float P0 = s[0], P1 = s[1], P2 = s[2];
+  switch (pl) {
+    case 0: return I0; case 1: return I1; case 2: return I2;
+    case 3: return P0; case 4: return P1; case 5: return P2;
+    case 6: return I0 * I0; case 7: return I0 * I1; case 8: return I0 * I2;
+    case 9: return I1 * I1; case 10: return I1 * I2; case 11: return I2 * I2;
+    default: {
+      int k = pl - 12, c = k / 3, i = k - c * 3;  // 12 + c*3 + i = I_i * p_c
+      float Iv = i == 0 ? I0 : (i == 1 ? I1 : I2);
+      float Pv = c == 0 ? P0 : (c == 1 ? P1 : P2);
+      return Iv * Pv;
+    }
+  }
+}
+
+// H pass.  grid = (H, nplanes, B).  STAGE1: read uint8 guide/src; else read fp32 planes.
+template <bool STAGE1>
+__global__ __launch_bounds__(256) void gf_h_kernel(const unsigned char* __restrict__ guide, const unsigned char* __restrict__ src,
+                                                   const float* __restrict__ in, float* __restrict__ out, int H, int W, int r,
+                                                   int nplanes) {
+  __shared__ float row[GF_MAXW + 2 * GF_MAXR];
+  const int y = blockIdx.x, pl = blockIdx.y, b = blockIdx.z;
+  const int64_t P = (int64_t)H * W;
+  for (int i = threadIdx.x; i < W + 2 * r; i += 256) {
+    int x = reflect_idx(i - r, W);
+    float v;
+    if (STAGE1) {
+      int64_t o = (((int64_t)b * H + y) * W + x) * 3;
+      v = gf_plane_value(pl, guide + o, src + o);
+    } else {
+      v = in[((int64_t)b * nplanes + pl) * P + (int64_t)y * W + x];
+    }
+    row[i] = v;
+  }
+  __syncthreads();
+  float* o = out + ((int64_t)b * nplanes + pl) * P + (int64_t)y * W;
+  for (int x = threadIdx.x; x < W; x += 256) {
+    float s = 0.f;
+    for (int k = 0; k <= 2 * r; ++k) s += row[x + k];
+    o[x] = s;
+  }
+}
+
+// V pass: out = (sum over 2r+1 rows of in) / (2r+1)^2.  grid-stride over (b, plane, y, x).
+__global__ __launch_bounds__(256) void gf_v_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int r,
+                                                   int64_t total) {
+  const float inv = 1.f / (float)((2 * r + 1) * (2 * r + 1));
+  const int64_t P = (int64_t)H * W;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int x = (int)(t % W);
+    int64_t q = t / W;
+    int y = (int)(q % H);
+    int64_t bp = q / H;
+    const float* col = in + bp * P + x;
+    float s = 0.f;
+    for (int k = -r; k <= r; ++k) s += col[(int64_t)reflect_idx(y + k, H) * W];
+    out[t] = s * inv;
+  }
+}
+
+// per-pixel 3x3 solve.  means: [B][21][P] -> ab: [B][12][P] (a_c0,a_c1,a_c2,b_c for c=0..2)
+__global__ __launch_bounds__(256) void gf_solve_kernel(const float* __restrict__ m, float* __restrict__ ab, int64_t P, float eps,
+                                                       int64_t total) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int64_t b = t / P, p = t - b * P;
+    const float* mp = m + b * 21 * P + p;
+    float mI0 = mp[0], mI1 = mp[P], mI2 = mp[2 * P];
+    float a00 = mp[6 * P] - mI0 * mI0 + eps, a01 = mp[7 * P] - mI0 * mI1, a02 = mp[8 * P] - mI0 * mI2;
+    float a11 = mp[9 * P] - mI1 * mI1 + eps, a12 = mp[10 * P] - mI1 * mI2, a22 = mp[11 * P] - mI2 * mI2 + eps;
+    float c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+    float c11 = a00 * a22 - a02 * a02, c12 = a02 * a01 - a00 * a12, c22 = a00 * a11 - a01 * a01;
+    float det = a00 * c00 + a01 * c01 + a02 * c02;
+    float i00 = c00 / det, i01 = c01 / det, i02 = c02 / det, i11 = c11 / det, i12 = c12 / det, i22 = c22 / det;
+    float* o = ab + b * 12 * P + p;
+    for (int c = 0; c < 3; ++c) {
+      float mp_c = mp[(3 + c) * P];
+      float cp0 = mp[(12 + c * 3 + 0) * P] - mI0 * mp_c;
+      float cp1 = mp[(12 + c * 3 + 1) * P] - mI1 * mp_c;
+      float cp2 = mp[(12 + c * 3 + 2) * P] - mI2 * mp_c;
+      float A0 = i00 * cp0 + i01 * cp1 + i02 * cp2;
+      float A1 = i01 * cp0 + i11 * cp1 + i12 * cp2;
+      float A2 = i02 * cp0 + i12 * cp1 + i22 * cp2;
+      float bb = mp_c - A0 * mI0 - A1 * mI1 - A2 * mI2;
+      o[(c * 4 + 0) * P] = A0; o[(c * 4 + 1) * P] = A1; o[(c * 4 + 2) * P] = A2; o[(c * 4 + 3) * P] = bb;
+    }
+  }
+}
+
+// final V pass over the 12 h-summed (a,b) planes + combination with the guide.
+__global__ __launch_bounds__(256) void gf_v_final_kernel(const float* __restrict__ hs, const unsigned char* __restrict__ guide,
+                                                         float* __restrict__ out, unsigned char* __restrict__ out_u8, int H, int W,
+                                                         int r, int64_t total) {
+  const float inv = 1.f / (float)((2 * r + 1) * (2 * r + 1));
+  const int64_t P = (int64_t)H * W;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int x = (int)(t % W);
+    int64_t q = t / W;
+    int y = (int)(q % H);
+    int64_t b = q / H;
+    float m[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) m[i] = 0.f;
+    const float* base = hs + b * 12 * P + x;
+    for (int k = -r; k <= r; ++k) {
+      int64_t ro = (int64_t)reflect_idx(y + k, H) * W;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) m[i] += base[i * P + ro];
+    }
+    const unsigned char* g = guide + ((b * H + y) * W + x) * 3;
+    float I0 = g[0], I1 = g[1], I2 = g[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float qv = (m[c * 4] * inv) * I0 + (m[c * 4 + 1] * inv) * I1 + (m[c * 4 + 2] * inv) * I2 + m[c * 4 + 3] * inv;
+      float rq = fminf(fmaxf(rintf(qv), 0.f), 255.f);
+      if (out_u8) out_u8[((b * H + y) * W + x) * 3 + c] = (unsigned char)rq;
+      if (out) out[(b * 3 + c) * P + (int64_t)y * W + x] = (rq / 255.0f - 0.5f) * 2.f;  // ToTensor, (x-0.5)*2 (ppst_model.py:301-303)
+    }
+  }
+}
+
+extern "C" int64_t ppst_guided_filter_ws(int B, int H, int W) { return (int64_t)B * 42 * H * W * (int64_t)sizeof(float); }
+
+extern "C" int ppst_guided_filter(const void* guide_u8, const void* src_u8, void* out, void* out_u8, int B, int H, int W, int r,
+                                  float eps, void* work, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || W > GF_MAXW || r <= 0 || r > GF_MAXR || r >= H || r >= W) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!guide_u8 || !src_u8 || !work || (!out && !out_u8)) return PPST_ENULL;
+  hipStream_t st = as_stream(stream);
+  const int64_t P = (int64_t)H * W;
+  float* bufA = (float*)work;              // [B][21][P]
+  float* bufB = bufA + (int64_t)B * 21 * P;  // [B][21][P]
+  const unsigned char* g = (const unsigned char*)guide_u8;
+  const unsigned char* s = (const unsigned char*)src_u8;
+  auto blocks_for = [](int64_t total) { int64_t b = cdiv64(total, 256); return (unsigned)(b > 256 * 32 ? 256 * 32 : b); };
+  int e;
+  hipLaunchKernelGGL(gf_h_kernel<true>, dim3(H, 21, B), dim3(256), 0, st, g, s, (const float*)nullptr, bufA, H, W, r, 21);
+  if ((e = PPST_LAUNCH_CHECK())) return e;
+  int64_t t21 = (int64_t)B * 21 * P;
+  hipLaunchKernelGGL(gf_v_kernel, dim3(blocks_for(t21)), dim3(256), 0, st, (const float*)bufA, bufB, H, W, r, t21);
+  if ((e = PPST_LAUNCH_CHECK())) return e;
+  hipLaunchKernelGGL(gf_solve_kernel, dim3(blocks_for(B * P)), dim3(256), 0, st, (const float*)bufB, bufA, P, eps, (int64_t)B * P);
+  if ((e = PPST_LAUNCH_CHECK())) return e;
+  hipLaunchKernelGGL(gf_h_kernel<false>, dim3(H, 12, B), dim3(256), 0, st, g, s, (const float*)bufA, bufB, H, W, r, 12);
+  if ((e = PPST_LAUNCH_CHECK())) return e;
+  hipLaunchKernelGGL(gf_v_final_kernel, dim3(blocks_for(B * P)), dim3(256), 0, st, (const float*)bufB, g, (float*)out,
+                     (unsigned char*)out_u8, H, W, r, (int64_t)B * P);
+  return PPST_LAUNCH_CHECK();
+}
+
+extern "C" int ppst_version(void) { return 1; }

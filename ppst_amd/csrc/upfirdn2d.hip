@@ -1,0 +1,245 @@
+// upfirdn2d: zero-insert upsample -> pad/crop -> 2-D FIR (true convolution) -> decimate.
+// Replaces models/networks/stylegan2_op/upfirdn2d_kernel.cu:52-137 (+dispatch :140-272).
+// Tensor layout [major, H, W, minor] fp32 as in the reference (upfirdn2d.py:104,123-127).
+//
+// Three kernels, all HBM-bound (algorithmic bytes = 4*(in + out) per element):
+//   * planes (minor == 1, up = down = 1): the NCHW hot case of the path (Blur of the
+//     encoders / discriminator).  One 32x64 output tile per block, input tile (+kh-1,
+//     +kw-1 halo) staged once in LDS, each lane owns one output column and slides down
+//     8 rows so every LDS word is read kw times only; stores are 256-B wave rows.
+//   * chan (minor % 4 == 0, up = down = 1): NHWC; lane = 4 channels (16-B loads/stores),
+//     each thread slides over 4 output pixels along x re-using the kh x (4+kw-1) window.
+//   * generic: any up/down/minor, one output per thread (modes 3-6 of the reference
+//     dispatcher, never hit on the PPST path).
+#include "common.h"
+
+#define UF_MAXK 8
+
+struct UfParams {
+  int major, in_h, in_w, minor, kh, kw;
+  int up_x, up_y, down_x, down_y, pad_x0, pad_y0;
+  int out_h, out_w;
+  const float* k;  // device taps [kh][kw]; flipped on read (true convolution, .cu:81)
+  int pad_mode;    // chan kernel only: PPST_PAD_ZERO or PPST_PAD_REFLECT (fused nn.ReflectionPad2d)
+};
+
+__device__ __forceinline__ int uf_reflect(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+
+// ---- planes: minor == 1, up == down == 1 ---------------------------------
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void upfirdn2d_planes(const float* __restrict__ x, float* __restrict__ y, UfParams p) {
+  constexpr int TH = 32, TW = 64, IH = TH + KH - 1, IW = TW + KW - 1;
+  __shared__ float sx[IH][IW + 1];
+  float kf[KH * KW];
+#pragma unroll
+  for (int i = 0; i < KH * KW; ++i) kf[i] = p.k[KH * KW - 1 - i];
+  const int tiles_x = (p.out_w + TW - 1) / TW;
+  const int tile_x = (blockIdx.x % tiles_x) * TW;
+  const int tile_y = (blockIdx.x / tiles_x) * TH;
+  const int64_t plane = blockIdx.y;
+  const float* xp = x + plane * (int64_t)p.in_h * p.in_w;
+  float* yp = y + plane * (int64_t)p.out_h * p.out_w;
+  const int in_x0 = tile_x - p.pad_x0, in_y0 = tile_y - p.pad_y0;
+  for (int i = threadIdx.x; i < IH * IW; i += 256) {
+    int ry = i / IW, rx = i - ry * IW;
+    int iy = in_y0 + ry, ix = in_x0 + rx;
+    float v = 0.f;
+    if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) v = xp[(int64_t)iy * p.in_w + ix];
+    sx[ry][rx] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int ox = tile_x + lane;
+  float win[KH][KW];
+#pragma unroll
+  for (int r = 0; r < KH - 1; ++r)
+#pragma unroll
+    for (int c = 0; c < KW; ++c) win[r + 1][c] = sx[w * 8 + r][lane + c];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+#pragma unroll
+    for (int rr = 0; rr < KH - 1; ++rr)
+#pragma unroll
+      for (int c = 0; c < KW; ++c) win[rr][c] = win[rr + 1][c];
+#pragma unroll
+    for (int c = 0; c < KW; ++c) win[KH - 1][c] = sx[w * 8 + r + KH - 1][lane + c];
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx) acc += win[ky][kx] * kf[ky * KW + kx];
+    int oy = tile_y + w * 8 + r;
+    if (oy < p.out_h && ox < p.out_w) yp[(int64_t)oy * p.out_w + ox] = acc;
+  }
+}
+
+// ---- chan: minor % 4 == 0, up == down == 1 --------------------------------
+// DOWN = 2 keeps every second sample (the blur in front of a stride-2 1x1 conv only needs
+// those).  S2D writes the output space-to-depth: out[m][oy>>1][ox>>1][((oy&1)*2+(ox&1))*C + c]
+// with spatial extent ceil(out/2) -- the layout the fused conv consumes for stride-2 3x3 convs.
+template <int KH, int KW, int DOWN, bool S2D>
+__global__ __launch_bounds__(256) void upfirdn2d_chan(const float4* __restrict__ x, float4* __restrict__ y, UfParams p, int64_t nwork) {
+  constexpr int PX = 4;
+  const int c4n = p.minor >> 2;
+  float kf[KH * KW];
+#pragma unroll
+  for (int i = 0; i < KH * KW; ++i) kf[i] = p.k[KH * KW - 1 - i];
+  const int xs = (p.out_w + PX - 1) / PX;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nwork; t += (int64_t)gridDim.x * 256) {
+    int c4 = (int)(t % c4n);
+    int64_t r = t / c4n;
+    int sx_ = (int)(r % xs); r /= xs;
+    int oy = (int)(r % p.out_h);
+    int m = (int)(r / p.out_h);
+    int ox0 = sx_ * PX;
+    float4 acc[PX];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ky = 0; ky < KH; ++ky) {
+      int iy = oy * DOWN + ky - p.pad_y0;
+      if (p.pad_mode == PPST_PAD_REFLECT) iy = uf_reflect(iy, p.in_h);
+      bool yok = iy >= 0 && iy < p.in_h;
+      const float4* row = x + ((int64_t)m * p.in_h + (yok ? iy : 0)) * p.in_w * c4n + c4;
+#pragma unroll
+      for (int j = 0; j < (PX - 1) * DOWN + KW; ++j) {
+        int ix = ox0 * DOWN + j - p.pad_x0;
+        if (p.pad_mode == PPST_PAD_REFLECT) ix = uf_reflect(ix, p.in_w);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (yok && ix >= 0 && ix < p.in_w) v = row[(int64_t)ix * c4n];
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+          int kx = j - i * DOWN;
+          if (kx >= 0 && kx < KW) {
+            float f = kf[ky * KW + kx];
+            acc[i].x += v.x * f; acc[i].y += v.y * f; acc[i].z += v.z * f; acc[i].w += v.w * f;
+          }
+        }
+      }
+    }
+    if (S2D) {
+      const int oh2 = (p.out_h + 1) >> 1, ow2 = (p.out_w + 1) >> 1;
+#pragma unroll
+      for (int i = 0; i < PX; ++i) {
+        int ox = ox0 + i;
+        if (ox < p.out_w)
+          y[((((int64_t)m * oh2 + (oy >> 1)) * ow2 + (ox >> 1)) * 4 + (oy & 1) * 2 + (ox & 1)) * c4n + c4] = acc[i];
+      }
+    } else {
+      float4* orow = y + ((int64_t)m * p.out_h + oy) * p.out_w * c4n + c4;
+#pragma unroll
+      for (int i = 0; i < PX; ++i)
+        if (ox0 + i < p.out_w) orow[(int64_t)(ox0 + i) * c4n] = acc[i];
+    }
+  }
+}
+
+// ---- generic ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void upfirdn2d_generic(const float* __restrict__ x, float* __restrict__ y, UfParams p, int64_t n) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+    int mi = (int)(t % p.minor);
+    int64_t r = t / p.minor;
+    int ox = (int)(r % p.out_w); r /= p.out_w;
+    int oy = (int)(r % p.out_h);
+    int m = (int)(r / p.out_h);
+    float acc = 0.f;
+    for (int ky = 0; ky < p.kh; ++ky) {
+      int Y = oy * p.down_y + ky - p.pad_y0;
+      if (Y < 0 || Y % p.up_y) continue;
+      int iy = Y / p.up_y;
+      if (iy >= p.in_h) continue;
+      for (int kx = 0; kx < p.kw; ++kx) {
+        int X = ox * p.down_x + kx - p.pad_x0;
+        if (X < 0 || X % p.up_x) continue;
+        int ix = X / p.up_x;
+        if (ix >= p.in_w) continue;
+        acc += x[(((int64_t)m * p.in_h + iy) * p.in_w + ix) * p.minor + mi] * p.k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+      }
+    }
+    y[t] = acc;
+  }
+}
+
+template <int KH, int KW>
+static int launch_chan(const float* x, float* y, const UfParams& p, int down, bool s2d, hipStream_t st) {
+  int64_t nwork = (int64_t)p.major * p.out_h * cdiv(p.out_w, 4) * (p.minor / 4);
+  int64_t blocks = cdiv64(nwork, 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  dim3 g((unsigned)blocks), b(256);
+  if (s2d) hipLaunchKernelGGL((upfirdn2d_chan<KH, KW, 1, true>), g, b, 0, st, (const float4*)x, (float4*)y, p, nwork);
+  else if (down == 2) hipLaunchKernelGGL((upfirdn2d_chan<KH, KW, 2, false>), g, b, 0, st, (const float4*)x, (float4*)y, p, nwork);
+  else hipLaunchKernelGGL((upfirdn2d_chan<KH, KW, 1, false>), g, b, 0, st, (const float4*)x, (float4*)y, p, nwork);
+  return PPST_LAUNCH_CHECK();
+}
+
+template <int KH, int KW>
+static int launch_fast(const float* x, float* y, const UfParams& p, hipStream_t st) {
+  if (p.minor == 1) {
+    dim3 grid(cdiv(p.out_w, 64) * cdiv(p.out_h, 32), p.major);
+    hipLaunchKernelGGL((upfirdn2d_planes<KH, KW>), grid, dim3(256), 0, st, x, y, p);
+  } else {
+    return launch_chan<KH, KW>(x, y, p, 1, false, st);
+  }
+  return PPST_LAUNCH_CHECK();
+}
+
+extern "C" int ppst_upfirdn2d(const void* x, const void* k, void* y, int major, int in_h, int in_w, int minor,
+                              int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                              int pad_y0, int pad_y1, int dtype, void* stream) {
+  if (dtype != PPST_F32) return PPST_EUNSUPPORTED;
+  if (!x || !k || !y) return PPST_ENULL;
+  if (major < 0 || in_h <= 0 || in_w <= 0 || minor <= 0 || kh <= 0 || kw <= 0 || kh > UF_MAXK || kw > UF_MAXK ||
+      up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0)
+    return PPST_EINVAL;
+  UfParams p;
+  p.major = major; p.in_h = in_h; p.in_w = in_w; p.minor = minor; p.kh = kh; p.kw = kw;
+  p.up_x = up_x; p.up_y = up_y; p.down_x = down_x; p.down_y = down_y; p.pad_x0 = pad_x0; p.pad_y0 = pad_y0;
+  p.out_h = (in_h * up_y + pad_y0 + pad_y1 - kh + down_y) / down_y;
+  p.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw + down_x) / down_x;
+  if (p.out_h <= 0 || p.out_w <= 0) return PPST_EINVAL;
+  if (major == 0) return PPST_OK;
+  p.k = (const float*)k;
+  p.pad_mode = PPST_PAD_ZERO;
+  hipStream_t st = as_stream(stream);
+  const float* xf = (const float*)x;
+  float* yf = (float*)y;
+  bool fast = up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && (minor == 1 || minor % 4 == 0) && kh == kw;
+  if (fast && kh == 3) return launch_fast<3, 3>(xf, yf, p, st);
+  if (fast && kh == 4) return launch_fast<4, 4>(xf, yf, p, st);
+  bool down2 = up_x == 1 && up_y == 1 && down_x == 2 && down_y == 2 && minor % 4 == 0 && kh == kw;
+  if (down2 && kh == 3) return launch_chan<3, 3>(xf, yf, p, 2, false, st);
+  if (down2 && kh == 4) return launch_chan<4, 4>(xf, yf, p, 2, false, st);
+  int64_t n = (int64_t)major * p.out_h * p.out_w * minor;
+  int64_t blocks = cdiv64(n, 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(upfirdn2d_generic, dim3((unsigned)blocks), dim3(256), 0, st, xf, yf, p, n);
+  return PPST_LAUNCH_CHECK();
+}
+
+// Fused-path blur on NHWC activations (Blur of ConvLayer(downsample=True),
+// stylegan2_layers.py:142-164,513-520): zero or reflection padding folded in (the reference
+// runs nn.ReflectionPad2d first, :151-159), optional decimation by 2 (all a following
+// stride-2 1x1 conv reads) or space-to-depth output for a following stride-2 3x3 conv:
+//   s2d: y [B][ceil(oh/2)][ceil(ow/2)][4*C], phase (oy&1)*2+(ox&1) major over channels.
+extern "C" int ppst_blur_nhwc(const void* x, const void* k, void* y, int B, int in_h, int in_w, int C, int ksize, int pad0,
+                              int pad1, int pad_mode, int down, int s2d, void* stream) {
+  if (!x || !k || !y) return PPST_ENULL;
+  if (B < 0 || in_h <= 0 || in_w <= 0 || C <= 0 || C % 4 || (ksize != 3 && ksize != 4) || (down != 1 && down != 2) ||
+      (s2d && down != 1) || (pad_mode != PPST_PAD_ZERO && pad_mode != PPST_PAD_REFLECT))
+    return PPST_EINVAL;
+  UfParams p;
+  p.major = B; p.in_h = in_h; p.in_w = in_w; p.minor = C; p.kh = ksize; p.kw = ksize;
+  p.up_x = p.up_y = 1; p.down_x = p.down_y = down; p.pad_x0 = pad0; p.pad_y0 = pad0;
+  p.out_h = (in_h + pad0 + pad1 - ksize + down) / down;
+  p.out_w = (in_w + pad0 + pad1 - ksize + down) / down;
+  p.k = (const float*)k;
+  p.pad_mode = pad_mode;
+  if (p.out_h <= 0 || p.out_w <= 0) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (ksize == 3) return launch_chan<3, 3>((const float*)x, (float*)y, p, down, s2d != 0, as_stream(stream));
+  return launch_chan<4, 4>((const float*)x, (float*)y, p, down, s2d != 0, as_stream(stream));
+}

@@ -1,0 +1,149 @@
+"""Generator G on HIP kernels (reference: models/networks/generator.py:104-281, class
+StyleGAN2ResnetGenerator, built from StyledConv / ToRGB of stylegan2_layers.py:439-495).
+
+forward(spatial_code (B,256,h,w), [4 x (B,2048)], extract_features=False, noise=None)
+  -> rgb (B,3,8h,8w)            | (rgb, feat (B,256,h,w), feat1 (B,64,256,256))
+
+Every StyledConv = one fused MFMA conv launch (bias + noise + leaky-relu epilogue and
+instance-norm tile statistics in the same kernel) + a (B,2C) style GEMV + a tiny finalize
++ one apply pass that also carries the residual add / 1/sqrt2 of the resnet blocks.  The
+upsampling StyledConv is the 4x4 stride-2 transposed conv of stylegan2_layers.py:312-321
+executed as four 2x2 output-phase convs inside the same kernel.
+
+``noise``: dict '<Block>.<conv>' -> (B,1,H,W) tensors for the 14 NoiseInjection layers
+(stylegan2_layers.py:376-399).  The reference draws them on the fly; here they must be
+given explicitly whenever a noise weight is non-zero (parity needs identical noise);
+``noise='random'`` draws them with torch.randn like the reference.
+"""
+import math
+
+import torch
+
+from .. import ops
+from .base_network import BaseNetwork, as_nchw, to_nhwc, INV_SQRT2
+
+HEAD_CH = [(256, 256), (256, 256), (256, 384), (384, 512)]
+UP = [(16, 512, 512), (32, 512, 256), (64, 256, 128)]
+
+
+class StyleGAN2ResnetGenerator(BaseNetwork):
+    prefix = "G."
+
+    # -- StyledConv (stylegan2_layers.py:439-475) -----------------------------
+    def _styled_consts(self, p):
+        """folded per-channel bias (conv.bias + bias + activate.bias) and the noise weight."""
+        ts = [self.p(p + "conv.bias"), self.p(p + "bias"), self.p(p + "activate.bias"), self.p(p + "noise.weight")]
+
+        def build():
+            b = (ts[0] + ts[1].reshape(-1) + ts[2]).contiguous()
+            return b, float(ts[3].item())
+        return self.cached(("sc", p), ts, build)
+
+    def styled_conv(self, x, p, style, key, noise, upsample=False, res=None, out_scale=1.0):
+        B, H, W, cin = x.shape
+        bias, nw = self._styled_consts(p)
+        kind = "conv"
+        if upsample:
+            if min(H, W) * 2 >= 128:
+                kind = "convT"
+            else:  # the <128 px branch: nearest x2 + 3x3 conv (stylegan2_layers.py:322-323)
+                x = ops.upsample_nearest2(x)
+        nz = None
+        if nw != 0.0:
+            if noise is None:
+                raise RuntimeError("noise weight of %s is non-zero: pass noise tensors (or noise='random')" % p)
+            nz = noise[key].contiguous()
+        y, st = self.plan(p + "conv.weight", kind)(x, bias=bias, noise=nz, noise_weight=nw, act=ops.ACT_LRELU, stats=True)
+        wl = self.p(p + "epi1.style_mod.lin.weight")
+        s = ops.linear(style, wl, self.p(p + "epi1.style_mod.lin.bias"), wscale=wl.shape[1] ** -0.5)
+        ss = ops.in_finalize(st, y.shape[1] * y.shape[2], style=s)
+        return ops.affine_act(y, ss, res=res, out_scale=out_scale)
+
+    # -- correspondence feature heads (generator.py:174-238) ------------------
+    def _feat_head(self, x, p, k, out):
+        B, H, W, C = x.shape
+        pad = ops.PAD_REPLICATE
+        # InstanceNorm runs on the ReplicationPad2d(1)-padded tensor for the 3x3 heads
+        st = ops.in_stats(x, rep_pad=(k == 3))
+        cnt = (H + 2) * (W + 2) if k == 3 else H * W
+        xn = ops.affine_act(x, ops.in_finalize(st, cnt))
+        y, st = self.plan(p + "2.weight")(xn, bias=self.p(p + "2.bias"), stats=True, pad_mode=pad)
+        y = ops.affine_act(y, ops.in_finalize(st, H * W), act=ops.ACT_PRELU, prelu=self.p(p + "4.weight"))
+        y, st = self.plan(p + "6.weight")(y, bias=self.p(p + "6.bias"), stats=True, pad_mode=pad)
+        return ops.affine_act(y, ops.in_finalize(st, H * W), act=ops.ACT_PRELU, prelu=self.p(p + "8.weight"), out=out)
+
+    def _residual_block(self, x, p):
+        B, H, W, C = x.shape
+        a = self.p(p + "prelu.weight")
+        y, st = self.plan(p + "conv1.weight")(x, bias=self.p(p + "conv1.bias"), stats=True, pad_mode=ops.PAD_REPLICATE)
+        y = ops.affine_act(y, ops.in_finalize(st, H * W), act=ops.ACT_PRELU, prelu=a)
+        y, st = self.plan(p + "conv2.weight")(y, bias=self.p(p + "conv2.bias"), stats=True, pad_mode=ops.PAD_REPLICATE)
+        return ops.affine_act(y, ops.in_finalize(st, H * W), res=x, res_before_act=True, act=ops.ACT_PRELU, prelu=a)
+
+    def make_noise(self, B, S, device):
+        out = {}
+        for i in range(4):
+            for c in ("conv1", "conv2"):
+                out["HeadResnetBlock%d.%s" % (i, c)] = torch.randn(B, 1, S, S, device=device)
+        s = S
+        for key, _, _ in UP:
+            s *= 2
+            for c in ("conv1", "conv2"):
+                out["UpsamplingResBlock%d.%s" % (key, c)] = torch.randn(B, 1, s, s, device=device)
+        return out
+
+    def forward(self, spatial_code, global_codes, extract_features=False, noise=None):
+        sp = to_nhwc(spatial_code)
+        B, S = sp.shape[0], sp.shape[1]
+        if isinstance(noise, str) and noise == "random":
+            noise = self.make_noise(B, S, sp.device)
+        codes = [ops.l2norm_rows(c, 1e-8, 0) for c in global_codes]  # util.normalize (generator.py:246)
+        g = codes[-1]
+        ws = self.p("SpatialCodeModulation.scale.weight")
+        inv = 1.0 / math.sqrt(ws.shape[1])
+        scale = ops.linear(g, ws, self.p("SpatialCodeModulation.scale.bias"), wscale=inv)
+        shift = ops.linear(g, self.p("SpatialCodeModulation.bias.weight"), self.p("SpatialCodeModulation.bias.bias"), wscale=inv)
+        x = ops.spatial_modulation(sp if sp.is_contiguous() else sp.contiguous(), scale, shift)
+        for i, (ci, co) in enumerate(HEAD_CH):
+            q = "HeadResnetBlock%d." % i
+            skip = x if ci == co else self.plan(q + "skip.Conv.weight", scale=1.0 / math.sqrt(ci))(x)
+            r = self.styled_conv(x, q + "conv1.", g, "HeadResnetBlock%d.conv1" % i, noise)
+            x = self.styled_conv(r, q + "conv2.", g, "HeadResnetBlock%d.conv2" % i, noise, res=skip, out_scale=INV_SQRT2)
+        feat = feat1 = None
+        if extract_features:
+            h, w = x.shape[1], x.shape[2]
+            feat = torch.empty((B, h, w, 256), device=x.device, dtype=torch.float32)
+            feat1 = torch.empty((B, 256, 256, 256), device=x.device, dtype=torch.float32)
+            f = self._feat_head(x, "layer32.", 3, out=feat[..., 0:64])
+            ops.bilinear(f, 256, 256, out=feat1[..., 0:64])
+        for j, (key, ci, co) in enumerate(UP):
+            q = "UpsamplingResBlock%d." % key
+            g = codes[-2 - j]
+            if ci == co:
+                skip = x
+            else:
+                skip = self.plan(q + "skip.Conv.weight", scale=1.0 / math.sqrt(ci))(x, bias=self.p(q + "skip.Act.bias"), act=ops.ACT_LRELU)
+            skip = ops.bilinear(skip, 2 * x.shape[1], 2 * x.shape[2])
+            r = self.styled_conv(x, q + "conv1.", g, "UpsamplingResBlock%d.conv1" % key, noise, upsample=True)
+            x = self.styled_conv(r, q + "conv2.", g, "UpsamplingResBlock%d.conv2" % key, noise, res=skip, out_scale=INV_SQRT2)
+            if extract_features:
+                f = self._feat_head(x, "layer%d." % (2 ** (j + 6)), 3 if j < 2 else 1, out=None)
+                c0 = 64 * (j + 1)
+                ops.avgpool(f, f.shape[1] // h, out=feat[..., c0:c0 + 64])
+                ops.bilinear(f, 256, 256, out=feat1[..., c0:c0 + 64])
+        # ToRGB (stylegan2_layers.py:477-495): 1x1 conv + biases -> InstanceNorm(3) -> StyleMod
+        wr = self.p("ToRGB.conv.weight")
+        brgb = self.cached(("rgbb",), [self.p("ToRGB.conv.bias"), self.p("ToRGB.bias")],
+                           lambda: (self.p("ToRGB.conv.bias") + self.p("ToRGB.bias").reshape(-1)).contiguous())
+        y = ops.conv1x1_small_cout(x, wr, brgb, 1.0 / math.sqrt(wr.shape[1]))
+        wl = self.p("ToRGB.epi1.style_mod.lin.weight")
+        s = ops.linear(codes[0], wl, self.p("ToRGB.epi1.style_mod.lin.bias"), wscale=wl.shape[1] ** -0.5)
+        ss = ops.in_finalize(ops.in_stats(y), y.shape[1] * y.shape[2], style=s)
+        rgb = ops.nhwc_to_nchw(ops.affine_act(y, ss))
+        if not extract_features:
+            return rgb
+        for i in range(3):
+            feat = self._residual_block(feat, "layert.%d." % i)
+        feat1 = self._residual_block(feat1, "layert1.0.")
+        feat1 = self.plan("layert1.1.weight")(feat1, bias=self.p("layert1.1.bias"))
+        return rgb, as_nchw(feat), as_nchw(feat1)

@@ -1,0 +1,514 @@
+"""Torch-facing wrappers over the C ABI (include/ppst_hip.h).
+
+PyTorch is used here for device memory and streams only: every arithmetic
+operation of the path is a HIP kernel in libppst_hip.so.  Activations of the
+fused path are NHWC fp32 tensors of shape (B, H, W, C) (or channel-slice views
+of such tensors: pixel stride ``ld`` = stride(2)).
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+PAD_ZERO, PAD_REFLECT, PAD_REPLICATE = 0, 1, 2
+ACT_NONE, ACT_LRELU, ACT_PRELU = 0, 1, 2
+RES_BEFORE_ACT = 1 << 8
+
+PRECISION = {"value": 0}  # 0 = bf16x3 (fp32-class), 1 = single-pass bf16
+
+
+def set_precision(p):
+    assert p in (0, 1)
+    PRECISION["value"] = p
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name="tensor"):
+    if t is None:
+        return
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA (HIP) tensor" % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s must be float32, got %s" % (name, t.dtype))
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _nhwc_ld(t, name="activation"):
+    """validate a (B,H,W,C) tensor or channel-slice view; return pixel stride."""
+    _chk(t, name)
+    B, H, W, C = t.shape
+    ld = t.stride(2)
+    if t.stride(3) != 1 or t.stride(1) != W * ld or (B > 1 and t.stride(0) != H * W * ld):
+        raise RuntimeError("%s must be NHWC-contiguous (or a channel slice of one)" % name)
+    return ld
+
+
+def empty_nhwc(B, H, W, C, like):
+    return torch.empty((B, H, W, C), device=like.device, dtype=torch.float32)
+
+
+# ---------------------------------------------------------------- layout ----
+def nchw_to_nhwc(x):
+    _chk(x, "x")
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+    check(lib.ppst_nchw_to_nhwc(_p(x), _p(y), B, C, H, W, _stream()), "ppst_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x):
+    ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    if ld != C:
+        raise RuntimeError("nhwc_to_nchw needs a dense tensor")
+    y = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
+    check(lib.ppst_nhwc_to_nchw(_p(x), _p(y), B, C, H, W, _stream()), "ppst_nhwc_to_nchw")
+    return y
+
+
+# ------------------------------------------------------ upfirdn2d / blur ----
+def upfirdn2d_raw(x4, kernel, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
+    """x4: [major, H, W, minor] contiguous (upfirdn2d.cpp:4-23). Returns [major, oh, ow, minor]."""
+    _chk(x4, "input")
+    _chk(kernel, "kernel")
+    x4 = x4.contiguous()
+    kernel = kernel.contiguous()
+    major, in_h, in_w, minor = x4.shape
+    kh, kw = kernel.shape
+    out_h = (in_h * up_y + py0 + py1 - kh + down_y) // down_y
+    out_w = (in_w * up_x + px0 + px1 - kw + down_x) // down_x
+    y = torch.empty((major, out_h, out_w, minor), device=x4.device, dtype=torch.float32)
+    check(lib.ppst_upfirdn2d(_p(x4), _p(kernel), _p(y), major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y,
+                             px0, px1, py0, py1, 0, _stream()), "ppst_upfirdn2d")
+    return y
+
+
+def blur_nhwc(x, kernel, pad0, pad1, pad_mode=PAD_ZERO, down=1, s2d=False):
+    ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    if ld != C:
+        raise RuntimeError("blur_nhwc needs a dense tensor")
+    _chk(kernel, "kernel")
+    ks = kernel.shape[0]
+    oh = (H + pad0 + pad1 - ks + down) // down
+    ow = (W + pad0 + pad1 - ks + down) // down
+    if s2d:
+        y = torch.zeros((B, (oh + 1) // 2, (ow + 1) // 2, 4 * C), device=x.device, dtype=torch.float32)
+    else:
+        y = torch.empty((B, oh, ow, C), device=x.device, dtype=torch.float32)
+    check(lib.ppst_blur_nhwc(_p(x), _p(kernel.contiguous()), _p(y), B, H, W, C, ks, pad0, pad1, pad_mode, down,
+                             1 if s2d else 0, _stream()), "ppst_blur_nhwc")
+    return y, (oh, ow)
+
+
+def fused_bias_act_raw(x, b, ref, act, grad, alpha, scale):
+    """fused.fused_bias_act (fused_bias_act.cpp:4-20): empty tensor == absent."""
+    _chk(x, "input")
+    x = x.contiguous()
+    b = None if (b is None or b.numel() == 0) else b.contiguous()
+    ref = None if (ref is None or ref.numel() == 0) else ref.contiguous()
+    _chk(b, "bias")
+    _chk(ref, "refer")
+    y = torch.empty_like(x)
+    step_b = 1
+    for i in range(2, x.dim()):
+        step_b *= x.size(i)
+    size_b = b.numel() if b is not None else 1
+    check(lib.ppst_fused_bias_act(_p(x), _p(b), _p(ref), _p(y), x.numel(), step_b, size_b, act, grad, float(alpha),
+                                  float(scale), 0, _stream()), "ppst_fused_bias_act")
+    return y
+
+
+# ------------------------------------------------------------- fused conv ----
+class ConvPlan:
+    """Packed weights + step table for ppst_conv2d_mfma.
+
+    kind: 'conv' (k in {1,3}, stride 1), 's2d' (3x3 stride 2 over a space-to-depth
+    input), 'convT' (fused 4x4 stride-2 transposed conv = 4 output phases of 2x2 taps).
+    weight: (Cout, Cin, k, k) fp32 CUDA tensor; scale multiplies the weights.
+    """
+
+    def __init__(self, weight, kind="conv", scale=1.0, chan_base=0, precision=None):
+        _chk(weight, "weight")
+        w = weight.detach().contiguous()
+        self.kind = kind
+        self.precision = PRECISION["value"] if precision is None else precision
+        cout, cin, k, _ = w.shape
+        assert cin % 32 == 0, "fused conv needs Cin % 32 == 0 (got %d)" % cin
+        self.cout, self.cin, self.k = cout, cin, k
+        self.bn = 128 if cout >= 128 else 64
+        steps, src = [], []
+        nchunk = cin // 32
+        if kind == "conv":
+            assert k in (1, 3)
+            self.n_groups = 1
+            self.halo = 0 if k == 1 else 1
+            for c in range(nchunk):
+                first = True
+                for ky in range(k):
+                    for kx in range(k):
+                        steps.append((chan_base + 32 * c, ky - k // 2, kx - k // 2, 1 if first else 0))
+                        src.append((32 * c, ky, kx))
+                        first = False
+            sn, sc, sy, sx = cin * k * k, k * k, k, 1
+            wsrc = w
+        elif kind == "s2d":
+            assert k == 3
+            self.n_groups = 1
+            self.halo = 1
+            for py in range(2):
+                for px in range(2):
+                    for c in range(nchunk):
+                        first = True
+                        for ey in range(2):
+                            for ex in range(2):
+                                ky, kx = 2 * ey + py, 2 * ex + px
+                                if ky > 2 or kx > 2:
+                                    continue
+                                steps.append(((py * 2 + px) * cin + 32 * c, ey, ex, 1 if first else 0))
+                                src.append((32 * c, ky, kx))
+                                first = False
+            sn, sc, sy, sx = cin * 9, 9, 3, 1
+            wsrc = w
+        elif kind == "convT":
+            assert k == 3
+            self.n_groups = 4
+            self.halo = 1
+            # F.conv_transpose2d(x, w4, stride=2, padding=1): oy = 2*iy - 1 + ky
+            wsrc = torch.empty((cin, cout, 4, 4), device=w.device, dtype=torch.float32)
+            check(lib.ppst_upscale_weight(_p(w), _p(wsrc), cout, cin, float(scale), _stream()), "ppst_upscale_weight")
+            scale = 1.0
+            taps = {0: [(-1, 3), (0, 1)], 1: [(0, 2), (1, 0)]}
+            for a in range(2):
+                for b in range(2):
+                    for c in range(nchunk):
+                        first = True
+                        for dy, ky in taps[a]:
+                            for dx, kx in taps[b]:
+                                steps.append((chan_base + 32 * c, dy, dx, 1 if first else 0))
+                                src.append((32 * c, ky, kx))
+                                first = False
+            sn, sc, sy, sx = 16, cout * 16, 4, 1
+        else:
+            raise ValueError(kind)
+        self.nsteps = len(steps) // self.n_groups
+        dev = w.device
+        self.steps = torch.tensor(steps, dtype=torch.int32, device=dev).contiguous()
+        s = torch.tensor(src, dtype=torch.int32, device=dev)
+        src_c, src_ky, src_kx = s[:, 0].contiguous(), s[:, 1].contiguous(), s[:, 2].contiguous()
+        n_tiles = (cout + self.bn - 1) // self.bn
+        npl = 8 if self.precision == 0 else 4
+        self.wpack = torch.empty(self.n_groups * n_tiles * self.nsteps * npl * self.bn * 8, dtype=torch.int16, device=dev)
+        check(lib.ppst_conv_pack(_p(wsrc), sn, sc, sy, sx, float(scale), cout, self.bn, _p(src_c), _p(src_ky), _p(src_kx),
+                                 self.nsteps, self.n_groups, self.precision, _p(self.wpack), _stream()), "ppst_conv_pack")
+
+    def __call__(self, x, bias=None, noise=None, noise_weight=0.0, act=ACT_NONE, prelu=None, stats=False,
+                 residual=None, out=None, out_scale=1.0, pad_mode=PAD_ZERO, out_hw=None, res_after_act=False):
+        in_ld = _nhwc_ld(x, "conv input")
+        B, H, W, _ = x.shape
+        if self.kind == "convT":
+            th, tw, oh, ow, osy = H, W, 2 * H, 2 * W, 2
+        elif self.kind == "s2d":
+            oh, ow = out_hw
+            th, tw, osy = oh, ow, 1
+        else:
+            th, tw, oh, ow, osy = H, W, H, W, 1
+        if out is None:
+            out = torch.empty((B, oh, ow, self.cout), device=x.device, dtype=torch.float32)
+        out_ld = _nhwc_ld(out, "conv output")
+        assert out.shape[0] == B and out.shape[1] == oh and out.shape[2] == ow and out.shape[3] == self.cout
+        for t, n in ((bias, "bias"), (noise, "noise"), (prelu, "prelu"), (residual, "residual")):
+            _chk(t, n)
+        st = None
+        if stats:
+            tiles = lib.ppst_conv_tiles(th, tw)
+            st = torch.empty((B, self.n_groups * tiles, self.cout, 2), device=x.device, dtype=torch.float32)
+        a = _lib.ConvArgs()
+        a.x, a.wpack, a.steps, a.y = _p(x), _p(self.wpack), _p(self.steps), _p(out)
+        a.bias, a.noise, a.prelu, a.stats = _p(bias), _p(noise), _p(prelu), _p(st)
+        a.residual = _p(residual)
+        a.res_ld = _nhwc_ld(residual, "residual") if residual is not None else 0
+        a.noise_weight, a.out_scale = float(noise_weight), float(out_scale)
+        a.B, a.in_h, a.in_w, a.in_ld = B, H, W, in_ld
+        a.out_h, a.out_w, a.out_ld, a.cout = oh, ow, out_ld, self.cout
+        a.nsteps, a.n_groups, a.pad_mode = self.nsteps, self.n_groups, pad_mode
+        a.in_off_y = a.in_off_x = 0
+        a.out_sy = a.out_sx = osy
+        a.act, a.precision = act | (0x100 if res_after_act else 0), self.precision
+        a.tile_h, a.tile_w, a.halo, a.bn = th, tw, self.halo, self.bn
+        check(lib.ppst_conv2d_mfma(ctypes.byref(a), _stream()), "ppst_conv2d_mfma")
+        if stats:
+            return out, st
+        return out
+
+
+def conv1x1_small_cin(x, w, bias, wscale, act):
+    ld = _nhwc_ld(x)
+    B, H, W, cin = x.shape
+    cout = w.shape[0]
+    y = torch.empty((B, H, W, cout), device=x.device, dtype=torch.float32)
+    w2 = w.detach().reshape(cout, cin).contiguous()
+    check(lib.ppst_conv1x1_small_cin(_p(x), _p(w2), _p(bias), _p(y), B * H * W, cin, ld, cout, float(wscale), act,
+                                     _stream()), "ppst_conv1x1_small_cin")
+    return y
+
+
+def conv1x1_small_cout(x, w, bias, wscale):
+    ld = _nhwc_ld(x)
+    B, H, W, cin = x.shape
+    assert ld == cin
+    cout = w.shape[0]
+    y = torch.empty((B, H, W, cout), device=x.device, dtype=torch.float32)
+    w2 = w.detach().reshape(cout, cin).contiguous()
+    check(lib.ppst_conv1x1_small_cout(_p(x), _p(w2), _p(bias), _p(y), B * H * W, cin, cout, float(wscale), _stream()),
+          "ppst_conv1x1_small_cout")
+    return y
+
+
+# ------------------------------------------------- instance norm / affine ----
+def in_stats(x, rep_pad=False):
+    ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    n = ctypes.c_int(0)
+    check(lib.ppst_in_stats(None, None, B, H, W, C, ld, 0, ctypes.byref(n), None), "ppst_in_stats(size)")
+    part = torch.empty((B, n.value, C, 2), device=x.device, dtype=torch.float32)
+    check(lib.ppst_in_stats(_p(x), _p(part), B, H, W, C, ld, 1 if rep_pad else 0, ctypes.byref(n), _stream()), "ppst_in_stats")
+    return part
+
+
+def in_finalize(partial, count, style=None, post_bias=None, eps=1e-5):
+    """partial (B, n, C, 2) -> scale_shift (B, C, 2); style (B, 2C) optional (StyleMod);
+    post_bias (C,) optional, added to the shift (activation bias after the norm)."""
+    _chk(partial)
+    _chk(style, "style")
+    _chk(post_bias, "post_bias")
+    B, n, C, _ = partial.shape
+    ss = torch.empty((B, C, 2), device=partial.device, dtype=torch.float32)
+    check(lib.ppst_in_finalize(_p(partial), n, _p(style), _p(post_bias), _p(ss), B, C, float(count), float(eps), _stream()),
+          "ppst_in_finalize")
+    return ss
+
+
+def affine_act(x, scale_shift=None, res=None, act=ACT_NONE, prelu=None, out_scale=1.0, res_before_act=False, out=None,
+               res_scale_shift=None):
+    x_ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+    y_ld = _nhwc_ld(out)
+    res_ld = _nhwc_ld(res, "res") if res is not None else 0
+    _chk(scale_shift, "scale_shift")
+    _chk(res_scale_shift, "res_scale_shift")
+    _chk(prelu, "prelu")
+    flag = act | (RES_BEFORE_ACT if res_before_act else 0)
+    check(lib.ppst_affine_act(_p(x), _p(scale_shift), _p(res), _p(res_scale_shift), _p(out), B, H * W, C, x_ld, res_ld, y_ld,
+                              flag, _p(prelu), float(out_scale), _stream()), "ppst_affine_act")
+    return out
+
+
+def upsample_nearest2(x):
+    ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    assert ld == C
+    y = torch.empty((B, 2 * H, 2 * W, C), device=x.device, dtype=torch.float32)
+    check(lib.ppst_upsample_nearest2(_p(x), _p(y), B, H, W, C, _stream()), "ppst_upsample_nearest2")
+    return y
+
+
+# ------------------------------------------------------- pooling / resize ----
+def gap_gmp(x, mask=None):
+    """(B,H,W,C) -> (B, 2C) = cat(mean, max) over pixels; mask (B,H,W) optional multiplier."""
+    ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    _chk(mask, "mask")
+    ws = torch.empty(lib.ppst_gap_gmp_ws(B, H * W, C) // 4, device=x.device, dtype=torch.float32)
+    out = torch.empty((B, 2 * C), device=x.device, dtype=torch.float32)
+    check(lib.ppst_gap_gmp(_p(x), _p(mask), _p(out), _p(ws), B, H, W, C, ld, _stream()), "ppst_gap_gmp")
+    return out
+
+
+def avgpool(x, f, out=None):
+    x_ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((B, H // f, W // f, C), device=x.device, dtype=torch.float32)
+    y_ld = _nhwc_ld(out)
+    check(lib.ppst_avgpool(_p(x), _p(out), B, H, W, C, x_ld, f, y_ld, _stream()), "ppst_avgpool")
+    return out
+
+
+def bilinear(x, OH, OW, out=None):
+    x_ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((B, OH, OW, C), device=x.device, dtype=torch.float32)
+    y_ld = _nhwc_ld(out)
+    check(lib.ppst_bilinear(_p(x), _p(out), B, H, W, C, x_ld, OH, OW, y_ld, _stream()), "ppst_bilinear")
+    return out
+
+
+def maxpool2(x):
+    ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    assert ld == C
+    y = torch.empty((B, H // 2, W // 2, C), device=x.device, dtype=torch.float32)
+    check(lib.ppst_maxpool2(_p(x), _p(y), B, H, W, C, _stream()), "ppst_maxpool2")
+    return y
+
+
+# ----------------------------------------------------------------- linear ----
+def linear(x, w, bias=None, wscale=1.0, bscale=1.0, relu_in=False, act=ACT_NONE):
+    _chk(x, "x"); _chk(w, "weight"); _chk(bias, "bias")
+    x = x.contiguous()
+    w = w.detach().contiguous()
+    B, K = x.shape
+    N = w.shape[0]
+    assert w.numel() == N * K
+    y = torch.empty((B, N), device=x.device, dtype=torch.float32)
+    check(lib.ppst_linear(_p(x), _p(w), _p(bias), _p(y), B, K, N, float(wscale), float(bscale), 1 if relu_in else 0, act,
+                          _stream()), "ppst_linear")
+    return y
+
+
+def l2norm_rows(x, eps, mode):
+    _chk(x)
+    x = x.contiguous()
+    B, K = x.shape
+    y = torch.empty_like(x)
+    check(lib.ppst_l2norm_rows(_p(x), _p(y), B, K, float(eps), mode, _stream()), "ppst_l2norm_rows")
+    return y
+
+
+def lerp(a, b, r):
+    _chk(a); _chk(b)
+    a, b = a.contiguous(), b.contiguous()
+    y = torch.empty_like(a)
+    check(lib.ppst_lerp(_p(a), _p(b), _p(y), a.numel(), float(r), _stream()), "ppst_lerp")
+    return y
+
+
+def spatial_modulation(x, scale, bias):
+    ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    assert ld == C
+    y = torch.empty_like(x)
+    check(lib.ppst_spatial_modulation(_p(x), _p(scale.contiguous()), _p(bias.contiguous()), _p(y), B, H * W, C, _stream()),
+          "ppst_spatial_modulation")
+    return y
+
+
+# --------------------------------------------------------- correspondence ----
+def rselfcorr(fea, out=None):
+    ld = _nhwc_ld(fea)
+    B, H, W, C = fea.shape
+    assert ld == C
+    if out is None:
+        out = torch.empty((B, H // 4, W // 4, 256), device=fea.device, dtype=torch.float32)
+    out_ld = _nhwc_ld(out)
+    check(lib.ppst_rselfcorr(_p(fea), _p(out), B, H, W, C, out_ld, _stream()), "ppst_rselfcorr")
+    return out
+
+
+def corr_prep(fea, ncenter=256):
+    """fea (B, P, C) dense -> centred / L2-normalised rows."""
+    _chk(fea)
+    fea = fea.contiguous()
+    B, P, C = fea.shape
+    y = torch.empty_like(fea)
+    check(lib.ppst_corr_prep(_p(fea), _p(y), B, P, C, ncenter, _stream()), "ppst_corr_prep")
+    return y
+
+
+def gemm_nt(A, Bm, alpha=1.0):
+    """A (b,M,K), Bm (b,N,K) -> (b,M,N) = alpha * A @ Bm^T (exact-fp32 MFMA)."""
+    _chk(A); _chk(Bm)
+    A, Bm = A.contiguous(), Bm.contiguous()
+    b, M, K = A.shape
+    N = Bm.shape[1]
+    C = torch.empty((b, M, N), device=A.device, dtype=torch.float32)
+    check(lib.ppst_gemm_nt_f32(_p(A), _p(Bm), _p(C), b, M, N, K, float(alpha), _stream()), "ppst_gemm_nt_f32")
+    return C
+
+
+def gemm_nn(A, Bm):
+    """A (b,M,K), Bm (b,K,N) -> (b,M,N) (exact-fp32 MFMA)."""
+    _chk(A); _chk(Bm)
+    A, Bm = A.contiguous(), Bm.contiguous()
+    b, M, K = A.shape
+    N = Bm.shape[2]
+    C = torch.empty((b, M, N), device=A.device, dtype=torch.float32)
+    check(lib.ppst_gemm_nn_f32(_p(A), _p(Bm), _p(C), b, M, N, K, N, N, _stream()), "ppst_gemm_nn_f32")
+    return C
+
+
+def softmax_rows_(x, div=1.0):
+    _chk(x)
+    assert x.is_contiguous()
+    cols = x.shape[-1]
+    check(lib.ppst_softmax_rows(_p(x), x.numel() // cols, cols, float(div), _stream()), "ppst_softmax_rows")
+    return x
+
+
+def unfold_patches(x, s):
+    _chk(x)
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    y = torch.empty((B, (H // s) * (W // s), C * s * s), device=x.device, dtype=torch.float32)
+    check(lib.ppst_unfold_patches(_p(x), _p(y), B, C, H, W, s, _stream()), "ppst_unfold_patches")
+    return y
+
+
+def fold_patches(x, C, H, W, s):
+    _chk(x)
+    x = x.contiguous()
+    B = x.shape[0]
+    y = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
+    check(lib.ppst_fold_patches(_p(x), _p(y), B, C, H, W, s, _stream()), "ppst_fold_patches")
+    return y
+
+
+# ----------------------------------------------------------- post-process ----
+def tensor2im_u8(x):
+    """NCHW fp32 -> (B,H,W,C) uint8 (util.tensor2im truncation)."""
+    _chk(x)
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, C), device=x.device, dtype=torch.uint8)
+    check(lib.ppst_tensor2im_u8(_p(x), _p(y), B, C, H, W, _stream()), "ppst_tensor2im_u8")
+    return y
+
+
+def guided_filter(guide_u8, src_u8, r=30, eps=(0.02 * 255) ** 2, want_u8=False):
+    """guide/src (B,H,W,3) uint8 -> fp32 NCHW in [-1,1] (and the uint8 HWC result)."""
+    for t in (guide_u8, src_u8):
+        if not t.is_cuda or t.dtype != torch.uint8:
+            raise RuntimeError("guided_filter needs CUDA uint8 tensors")
+    guide_u8, src_u8 = guide_u8.contiguous(), src_u8.contiguous()
+    B, H, W, _ = guide_u8.shape
+    ws = torch.empty(lib.ppst_guided_filter_ws(B, H, W), device=guide_u8.device, dtype=torch.uint8)
+    out = torch.empty((B, 3, H, W), device=guide_u8.device, dtype=torch.float32)
+    out_u8 = torch.empty((B, H, W, 3), device=guide_u8.device, dtype=torch.uint8) if want_u8 else None
+    check(lib.ppst_guided_filter(_p(guide_u8), _p(src_u8), _p(out), _p(out_u8), B, H, W, r, float(eps), _p(ws), _stream()),
+          "ppst_guided_filter")
+    return (out, out_u8) if want_u8 else out
+
+
+# --------------------------------------------------------------- profiling ----
+def prof_enable(on):
+    check(lib.ppst_prof_enable(1 if on else 0), "ppst_prof_enable")
+
+
+def prof_collect():
+    ms, n, fl = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
+    check(lib.ppst_prof_collect(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "ppst_prof_collect")
+    return ms.value, n.value, fl.value

@@ -1,0 +1,129 @@
+"""PPSTModel facade on the HIP path: ``model(*args, command="<method>", **kw)``.
+
+Mirrors the model-level plugin boundary of the reference (models/base_model.py:114-123
+string dispatch; models/ppst_model.py commands encode / encode2 / extract_feat /
+extract_feat_from_image / Rselfcorr / corrm / warp / decode), with the same argument
+order and return structure (lists of four codes, ``corr`` as a (B,4096,4096) tensor), so the
+evaluator recipes (evaluation/simple_swapping_evaluator.py:44-60,
+content_style_grid_generation_evaluator.py:36-99) run unchanged on top of it.
+State-dict keys are the reference's (``E1. E2. G. D.`` prefixes).
+"""
+import torch
+from torch import nn
+
+from . import glue, ops, weights
+from .networks import create_network
+from .networks.base_network import as_nchw, to_nhwc
+
+
+class Options:
+    """The flags that shape the hot path with the reference's defaults."""
+
+    def __init__(self, **kw):
+        d = dict(netE1="StyleGAN2Resnet", netE2="StyleGAN2Resnet", netG="StyleGAN2Resnet", netD="StyleGAN2",
+                 spatial_code_ch=256, global_code_ch=2048, crop_size=512, lambda_GAN=1.0, match_kernel=1,
+                 num_gpus=1, local_rank=1, isTrain=False)
+        d.update(kw)
+        self.__dict__.update(d)
+
+
+class PPSTModel(nn.Module):
+    def __init__(self, opt=None, with_D=False):
+        super().__init__()
+        self.opt = opt or Options()
+        self.E1 = create_network(self.opt, self.opt.netE1, "encoder_con")
+        self.E2 = create_network(self.opt, self.opt.netE2, "encoder_col")
+        self.G = create_network(self.opt, self.opt.netG, "generator")
+        if with_D:
+            self.D = create_network(self.opt, self.opt.netD, "discriminator")
+        self.noise = None  # dict of explicit noise tensors, 'random', or None
+
+    # BaseModel.forward (models/base_model.py:114-123)
+    def forward(self, *args, command=None, **kwargs):
+        if command is not None:
+            method = getattr(self, command)
+            assert callable(method), "[%s] is not a method of %s" % (command, type(self).__name__)
+            return method(*args, **kwargs)
+        raise ValueError(command)
+
+    def load_weights(self, sd):
+        own = self.state_dict()
+        missing = [k for k in own if k not in sd]
+        if missing:
+            raise KeyError("state dict lacks %d keys, e.g. %s" % (len(missing), missing[:3]))
+        self.load_state_dict({k: sd[k] for k in own}, strict=True)
+        return self
+
+    def per_gpu_initialize(self):
+        pass
+
+    def swap(self, x):
+        return glue.swap(x)
+
+    # -- commands (models/ppst_model.py:264-387) ------------------------------
+    def encode(self, image, extract_features=False, testtime=False):
+        return self.E1(image), self.E2(image, extract_features=extract_features)[0]
+
+    def encode2(self, image, corrmatrix):
+        return self.E2(image, corrmatrix=corrmatrix)
+
+    def extract_feat(self, spatial_code, global_code):
+        return self.G(spatial_code, global_code, extract_features=True, noise=self.noise)
+
+    def extract_feat_from_image(self, img):
+        sp = self.E1(img)
+        gl = self.E2(img)[0]
+        _, fea, fea1 = self.G(sp, gl, extract_features=True, noise=self.noise)
+        return fea, fea1
+
+    def Rselfcorr(self, fea):
+        """(B,64,256,256) -> (B,256,64,64) (ppst_model.py:330-339)."""
+        return as_nchw(ops.rselfcorr(to_nhwc(fea).contiguous()))
+
+    def corrm(self, fea, fea0):
+        """softmax(cos(fea0_i, fea_j)/0.01) over j -> (B, hw, hw) (ppst_model.py:341-364);
+        fea = style/key features, fea0 = content/query features, both (B,512,h,w)."""
+        if getattr(self.opt, "match_kernel", 1) != 1:
+            raise NotImplementedError("match_kernel != 1 (F.unfold matching) is not on the PPST path")
+        k = to_nhwc(fea)
+        q = to_nhwc(fea0)
+        B, h, w, C = k.shape
+        kn = ops.corr_prep(k.reshape(B, h * w, C), 256)
+        qn = ops.corr_prep(q.reshape(B, h * w, C), 256)
+        corr = ops.gemm_nt(qn, kn)
+        return ops.softmax_rows_(corr, 0.01)
+
+    def warp(self, fea, corr):
+        """PPSTModel.warp (ppst_model.py:366-387)."""
+        b, c, h, w = fea.shape
+        H = corr.shape[1]
+        if H != h * w:
+            s = int(((h * w) / H) ** 0.5)
+            patches = ops.unfold_patches(fea, s)
+            return ops.fold_patches(ops.gemm_nn(corr, patches), c, h, w, s)
+        f = to_nhwc(fea).reshape(b, h * w, c)
+        return as_nchw(ops.gemm_nn(corr, f.contiguous()).view(b, h, w, c))
+
+    def decode(self, spatial_code, global_code, target=None):
+        out = self.G(spatial_code, global_code, noise=self.noise)
+        if target is not None:
+            # GIFSmoothing(r=30, eps=(0.02*255)^2) with guide = target (ppst_model.py:290-305)
+            return ops.guided_filter(glue.tensor2im(target), glue.tensor2im(out), 30, (0.02 * 255) ** 2)
+        return out
+
+    def discriminate(self, x):
+        return self.D(x)
+
+    def get_parameters_for_mode(self, mode):
+        m = {"generator": "G", "contentencoder": "E1", "colorencoder": "E2", "discriminator": "D"}[mode]
+        return list(getattr(self, m).parameters()) if hasattr(self, m) else []
+
+
+def create_model(opt=None, state_dict=None, seed=0, with_D=False, device="cuda"):
+    """models.create_model (models/__init__.py:57-72) without the DDP wrapper: inference
+    is collective-free."""
+    m = PPSTModel(opt, with_D=with_D)
+    if state_dict is None:
+        state_dict = weights.make_state_dict(seed, with_D=with_D, with_nce=False)
+    m.load_weights(state_dict)
+    return m.to(device)

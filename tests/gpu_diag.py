@@ -1,0 +1,435 @@
+"""GPU diagnostic: run every HIP kernel against the CPU oracle and print error tables.
+Usage (on the GPU box):  python tests/gpu_diag.py [ops|nets|all]  > gpurun_out/diag.log
+Not a pytest file; the pytest -m gpu tests assert the same comparisons with tolerances."""
+import math
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import ppst_oracle as O  # noqa: E402
+from ppst_amd import ops, weights as W  # noqa: E402
+
+dev = "cuda"
+RES = []
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    if a.shape != b.shape:
+        return float("nan"), "SHAPE %s vs %s" % (tuple(a.shape), tuple(b.shape))
+    d = (a - b).abs().max().item()
+    return d / (b.abs().max().item() + 1e-30), "maxabs %.3e refmax %.3e" % (d, b.abs().max().item())
+
+
+def report(name, a, b, tol):
+    r, info = rel(a, b)
+    ok = r <= tol
+    RES.append((name, ok))
+    print("%-46s %s rel %.3e (tol %.0e) %s" % (name, "ok  " if ok else "FAIL", r, tol, info), flush=True)
+
+
+def run(fn):
+    try:
+        fn()
+    except Exception:
+        RES.append((fn.__name__, False))
+        print("EXC in %s\n%s" % (fn.__name__, traceback.format_exc()), flush=True)
+
+
+def g(t):
+    return t.to(dev)
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+# ------------------------------------------------------------------ ops ----
+def t_upfirdn2d():
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "ops.npz"))
+    from ppst_amd.stylegan2_op import upfirdn2d
+    for i in range(int(gold["upfirdn2d.n"])):
+        x = torch.from_numpy(gold["upfirdn2d.%d.x" % i])
+        k = torch.from_numpy(gold["upfirdn2d.%d.k" % i])
+        u, d, p0, p1 = [int(v) for v in gold["upfirdn2d.%d.cfg" % i]]
+        y = upfirdn2d(g(x), g(k), up=u, down=d, pad=(p0, p1))
+        report("upfirdn2d golden %d (k%d u%d d%d p%d,%d)" % (i, k.shape[0], u, d, p0, p1), y, torch.from_numpy(gold["upfirdn2d.%d.y" % i]), 2e-6)
+    # bigger planes incl. tile edges, NCHW
+    torch.manual_seed(0)
+    for (ks, p0, p1, H, Wd) in [(3, 0, 0, 131, 131), (3, 1, 0, 128, 128), (4, 2, 2, 64, 64), (4, 1, 1, 100, 70)]:
+        x = torch.randn(2, 5, H, Wd)
+        k = torch.randn(ks, ks)
+        report("upfirdn2d planes k%d p%d,%d %dx%d" % (ks, p0, p1, H, Wd), upfirdn2d(g(x), g(k), pad=(p0, p1)), O.upfirdn2d(x, k, pad=(p0, p1)), 2e-6)
+    # NHWC raw op (minor = C)
+    x = torch.randn(2, 37, 41, 8)
+    k = torch.randn(4, 4)
+    y = ops.upfirdn2d_raw(g(x), g(k), 1, 1, 1, 1, 2, 1, 2, 1)
+    report("upfirdn2d NHWC minor=8 k4", nchw(y.cpu()), O.upfirdn2d(nchw(x), k, pad=(2, 1)), 2e-6)
+    y = ops.upfirdn2d_raw(g(x), g(k), 1, 1, 2, 2, 1, 1, 1, 1)
+    report("upfirdn2d NHWC minor=8 k4 down2", nchw(y.cpu()), O.upfirdn2d(nchw(x), k, down=2, pad=(1, 1)), 2e-6)
+    # fused-path blur: reflect pad, s2d, down2
+    x = torch.randn(2, 32, 40, 40)
+    k3 = O.make_kernel([1, 2, 1])
+    yb, hw = ops.blur_nhwc(g(nhwc(x)), g(k3), 2, 1, ops.PAD_REFLECT, s2d=True)
+    ref = O.upfirdn2d(F.pad(x, (2, 1, 2, 1), mode="reflect"), k3)
+    oh, ow = ref.shape[2:]
+    s2d = torch.zeros(2, (oh + 1) // 2, (ow + 1) // 2, 4, 32)
+    for py in range(2):
+        for px in range(2):
+            sub = ref[:, :, py::2, px::2]
+            s2d[:, :sub.shape[2], :sub.shape[3], py * 2 + px] = sub.permute(0, 2, 3, 1)
+    report("blur_nhwc reflect s2d (%d,%d)" % hw, yb.cpu().view(2, (oh + 1) // 2, (ow + 1) // 2, 4, 32), s2d, 2e-6)
+    yd, hw = ops.blur_nhwc(g(nhwc(x)), g(k3), 1, 0, ops.PAD_ZERO, down=2)
+    report("blur_nhwc zero down2 (%d,%d)" % hw, nchw(yd.cpu()), O.upfirdn2d(x, k3, down=2, pad=(1, 0)), 2e-6)
+    k4 = O.make_kernel([1, 3, 3, 1])
+    yd, hw = ops.blur_nhwc(g(nhwc(x)), g(k4), 1, 1, ops.PAD_ZERO, down=2)
+    report("blur_nhwc k4 zero down2", nchw(yd.cpu()), O.upfirdn2d(x, k4, down=2, pad=(1, 1)), 2e-6)
+
+
+def t_fused_act():
+    from ppst_amd.stylegan2_op import fused_leaky_relu, FusedLeakyReLU
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "ops.npz"))
+    x = g(torch.from_numpy(gold["flrelu.x"])).requires_grad_()
+    b = g(torch.from_numpy(gold["flrelu.b"])).requires_grad_()
+    y = fused_leaky_relu(x, b)
+    report("fused_leaky_relu fwd golden", y, torch.from_numpy(gold["flrelu.y"]), 1e-6)
+    gy = g(torch.from_numpy(gold["flrelu.g"]))
+    gx, gb = torch.autograd.grad(y, [x, b], gy, create_graph=True)
+    report("fused_leaky_relu grad_x golden", gx, torch.from_numpy(gold["flrelu.gx"]), 1e-6)
+    report("fused_leaky_relu grad_b golden", gb, torch.from_numpy(gold["flrelu.gb"]), 1e-5)
+    # double backward: d/d(gy) of sum(gx * v) == gate(v)
+    v = torch.randn_like(gx)
+    gy2 = gy.clone().requires_grad_()
+    gx2, gb2 = torch.autograd.grad(fused_leaky_relu(x, b), [x, b], gy2, create_graph=True)
+    gg, = torch.autograd.grad((gx2 * v).sum(), gy2)
+    ref_gate = torch.where(y.detach() > 0, v, v * 0.2) * math.sqrt(2)
+    report("fused_leaky_relu double backward", gg, ref_gate, 1e-6)
+    x2, b2 = torch.from_numpy(gold["flrelu2.x"]), torch.from_numpy(gold["flrelu2.b"])
+    report("fused_leaky_relu 2-D slope .1 scale 1.5", fused_leaky_relu(g(x2), g(b2), 0.1, 1.5), torch.from_numpy(gold["flrelu2.y"]), 1e-6)
+    m = FusedLeakyReLU(5).to(dev)
+    report("FusedLeakyReLU module", m(x.detach()), O.fused_leaky_relu(x.detach().cpu(), torch.zeros(5)), 1e-6)
+    # upfirdn2d autograd (first + second order) against the oracle's autograd
+    from ppst_amd.stylegan2_op import upfirdn2d
+    xc = torch.randn(2, 3, 20, 22, dtype=torch.float64, requires_grad=True)
+    k = torch.randn(4, 4, dtype=torch.float64)
+    yc = O.upfirdn2d(xc, k, pad=(2, 1))
+    gyc = torch.randn_like(yc, requires_grad=True)
+    gxc, = torch.autograd.grad(yc, xc, gyc, create_graph=True)
+    vc = torch.randn_like(gxc)
+    ggc, = torch.autograd.grad((gxc * vc).sum(), gyc)
+    xg = g(xc.detach().float()).requires_grad_()
+    yg = upfirdn2d(xg, g(k.float()), pad=(2, 1))
+    gyg = g(gyc.detach().float()).requires_grad_()
+    gxg, = torch.autograd.grad(yg, xg, gyg, create_graph=True)
+    ggg, = torch.autograd.grad((gxg * g(vc.float())).sum(), gyg)
+    report("upfirdn2d backward", gxg, gxc, 2e-6)
+    report("upfirdn2d double backward", ggg, ggc, 2e-6)
+
+
+def t_layout_misc():
+    torch.manual_seed(1)
+    for (B, C, H, Wd) in [(2, 3, 17, 19), (1, 32, 64, 64), (2, 70, 9, 33)]:
+        x = torch.randn(B, C, H, Wd)
+        report("nchw_to_nhwc %s" % ((B, C, H, Wd),), ops.nchw_to_nhwc(g(x)), nhwc(x), 0)
+        report("nhwc_to_nchw %s" % ((B, C, H, Wd),), ops.nhwc_to_nchw(g(nhwc(x))), x, 0)
+    a, b = torch.randn(3, 2048), torch.randn(3, 2048)
+    report("lerp", ops.lerp(g(a), g(b), 0.3), O.lerp(a, b, 0.3), 0)
+    report("l2norm mode0 (util.normalize)", ops.l2norm_rows(g(a), 1e-8, 0), O.normalize(a), 1e-6)
+    report("l2norm mode1 (F.normalize)", ops.l2norm_rows(g(a), 1e-12, 1), F.normalize(a), 1e-6)
+    x = torch.rand(2, 3, 33, 31) * 2.6 - 1.3
+    y = ops.tensor2im_u8(g(x)).cpu().numpy()
+    RES.append(("tensor2im exact", bool(np.array_equal(y, O.tensor2im(x)))))
+    print("tensor2im exact:", np.array_equal(y, O.tensor2im(x)), flush=True)
+    for (B, K, N, relu, act) in [(1, 2048, 512, False, 0), (8, 2048, 1024, False, 0), (3, 64, 32, False, 0), (5, 32, 1024, True, 0),
+                                 (2, 8192, 512, False, 1), (17, 100, 7, True, 1)]:
+        x = torch.randn(B, K); w = torch.randn(N, K); bb = torch.randn(N)
+        xr = F.relu(x) if relu else x
+        ref = F.linear(xr, w * 0.1, bb * 0.5)
+        if act:
+            ref = O.fused_leaky_relu(ref, None)
+        report("linear B%d K%d N%d relu%d act%d" % (B, K, N, relu, act), ops.linear(g(x), g(w), g(bb), 0.1, 0.5, relu, act), ref, 3e-6)
+    x = torch.randn(2, 16, 16, 256); sc = torch.randn(2, 256); bi = torch.randn(2, 256)
+    report("spatial_modulation", ops.spatial_modulation(g(x), g(sc), g(bi)), x * sc[:, None, None] + bi[:, None, None], 1e-6)
+
+
+def conv_ref(x, w, kind, pad_mode):
+    mode = {0: "constant", 1: "reflect", 2: "replicate"}[pad_mode]
+    if kind == "conv":
+        k = w.shape[2]
+        if k == 3:
+            x = F.pad(x, (1, 1, 1, 1), mode=mode)
+        return F.conv2d(x, w)
+    if kind == "convT":
+        return F.conv_transpose2d(x, O.upscale_weight(w), stride=2, padding=1)
+    raise ValueError
+
+
+def t_conv():
+    torch.manual_seed(2)
+    cases = [
+        # name, B, Cin, Cout, H, W, k, kind, pad_mode
+        ("3x3 zero 64->128 32x32", 2, 64, 128, 32, 32, 3, "conv", 0),
+        ("3x3 zero 32->32 40x24 (ragged)", 1, 32, 32, 40, 24, 3, "conv", 0),
+        ("3x3 reflect 32->64 33x47", 2, 32, 64, 33, 47, 3, "conv", 1),
+        ("3x3 replicate 128->64 16x16", 1, 128, 64, 16, 16, 3, "conv", 2),
+        ("3x3 zero 256->384 16x16", 1, 256, 384, 16, 16, 3, "conv", 0),
+        ("1x1 64->128 20x20", 2, 64, 128, 20, 20, 1, "conv", 0),
+        ("1x1 256->64 8x8", 1, 256, 64, 8, 8, 1, "conv", 0),
+        ("convT 64->128 16x16", 2, 64, 128, 16, 16, 3, "convT", 0),
+        ("convT 128->64 20x12", 1, 128, 64, 20, 12, 3, "convT", 0),
+        ("3x3 zero 512->512 8x8", 1, 512, 512, 8, 8, 3, "conv", 0),
+    ]
+    for name, B, ci, co, H, Wd, k, kind, pm in cases:
+        x = torch.randn(B, ci, H, Wd)
+        w = torch.randn(co, ci, k, k) / math.sqrt(ci * k * k)
+        ref = conv_ref(x.double(), w.double(), kind, pm)
+        plan = ops.ConvPlan(g(w), kind=kind)
+        y = plan(g(nhwc(x)), pad_mode=pm)
+        report("conv bf16x3 " + name, nchw(y.cpu()), ref, 3e-5)
+        plan1 = ops.ConvPlan(g(w), kind=kind, precision=1)
+        y1 = plan1(g(nhwc(x)), pad_mode=pm)
+        report("conv bf16x1 " + name, nchw(y1.cpu()), ref, 2e-2)
+    # scale folded into the pack
+    x = torch.randn(1, 64, 16, 16); w = torch.randn(64, 64, 3, 3)
+    y = ops.ConvPlan(g(w), scale=0.05)(g(nhwc(x)))
+    report("conv weight scale", nchw(y.cpu()), F.conv2d(x.double(), w.double() * 0.05, padding=1), 3e-5)
+    # stride-2 3x3 over blur output (s2d) == blur + conv stride 2
+    x = torch.randn(2, 32, 40, 40); w = torch.randn(64, 32, 3, 3) / 17.0
+    k3 = O.make_kernel([1, 2, 1])
+    xb = O.upfirdn2d(F.pad(x, (2, 1, 2, 1), mode="reflect"), k3)
+    ref = F.conv2d(xb.double(), w.double(), stride=2)
+    yb, bhw = ops.blur_nhwc(g(nhwc(x)), g(k3), 2, 1, ops.PAD_REFLECT, s2d=True)
+    ohw = ((bhw[0] - 3) // 2 + 1, (bhw[1] - 3) // 2 + 1)
+    y = ops.ConvPlan(g(w), kind="s2d")(yb, out_hw=ohw)
+    report("conv s2d stride-2 32->64 (blur 41->20)", nchw(y.cpu()), ref, 3e-5)
+    x = torch.randn(1, 64, 34, 34); w = torch.randn(128, 64, 3, 3) / 24.0
+    k4 = O.make_kernel([1, 3, 3, 1])
+    xb = O.upfirdn2d(x, k4, pad=(2, 2))
+    ref = F.conv2d(xb.double(), w.double(), stride=2)
+    yb, bhw = ops.blur_nhwc(g(nhwc(x)), g(k4), 2, 2, ops.PAD_ZERO, s2d=True)
+    ohw = ((bhw[0] - 3) // 2 + 1, (bhw[1] - 3) // 2 + 1)
+    y = ops.ConvPlan(g(w), kind="s2d")(yb, out_hw=ohw)
+    report("conv s2d stride-2 64->128 k4 (35->17)", nchw(y.cpu()), ref, 3e-5)
+    # epilogue: bias + noise + lrelu + stats; residual before/after; prelu; out slice
+    B, ci, co, H, Wd = 2, 64, 128, 24, 40
+    x = torch.randn(B, ci, H, Wd); w = torch.randn(co, ci, 3, 3) / 24.0
+    bias = torch.randn(co); noise = torch.randn(B, 1, H, Wd); res = torch.randn(B, co, H, Wd)
+    conv = F.conv2d(x.double(), w.double(), padding=1)
+    ref = O.fused_leaky_relu(conv + 0.3 * noise.double() + bias.double().view(1, -1, 1, 1), None)
+    plan = ops.ConvPlan(g(w))
+    y, st = plan(g(nhwc(x)), bias=g(bias), noise=g(noise), noise_weight=0.3, act=ops.ACT_LRELU, stats=True)
+    report("conv epilogue bias+noise+lrelu", nchw(y.cpu()), ref, 3e-5)
+    s = st.cpu().double().sum(1)
+    report("conv tile stats sum", s[..., 0], ref.sum((2, 3)), 1e-5)
+    report("conv tile stats sumsq", s[..., 1], (ref ** 2).sum((2, 3)), 1e-5)
+    ss = ops.in_finalize(st, H * Wd)
+    report("in_finalize+affine == instance_norm", nchw(ops.affine_act(y, ss).cpu()), O.instance_norm(ref), 3e-5)
+    y = plan(g(nhwc(x)), bias=g(bias), act=ops.ACT_LRELU, residual=g(nhwc(res)), res_after_act=True, out_scale=0.5)
+    report("conv residual after act * scale", nchw(y.cpu()), (O.fused_leaky_relu(conv + bias.double().view(1, -1, 1, 1), None) + res.double()) * 0.5, 3e-5)
+    a = torch.tensor([0.25])
+    y = plan(g(nhwc(x)), bias=g(bias), act=ops.ACT_PRELU, prelu=g(a), residual=g(nhwc(res)))
+    report("conv residual before prelu", nchw(y.cpu()), O.prelu(conv + bias.double().view(1, -1, 1, 1) + res.double(), a.double()), 3e-5)
+    big = torch.zeros(B, H, Wd, 200, device=dev)
+    plan(g(nhwc(x)), out=big[..., 40:168])
+    report("conv out slice", nchw(big[..., 40:168].contiguous().cpu()), conv, 3e-5)
+    report("conv out slice untouched", big[..., :40], torch.zeros(B, H, Wd, 40), 0)
+    # convT stats cover the 4 phases
+    x = torch.randn(1, 64, 16, 16); w = torch.randn(64, 64, 3, 3) / 24.0
+    y, st = ops.ConvPlan(g(w), kind="convT")(g(nhwc(x)), stats=True)
+    ref = conv_ref(x.double(), w.double(), "convT", 0)
+    report("convT stats sum", st.cpu().double().sum(1)[..., 0], ref.sum((2, 3)), 1e-5)
+    # small-channel convs
+    x = torch.randn(2, 3, 20, 20); w = torch.randn(32, 3, 1, 1); b = torch.randn(32)
+    y = ops.conv1x1_small_cin(g(nhwc(x)), g(w), g(b), 1 / math.sqrt(3), ops.ACT_LRELU)
+    report("conv1x1 small cin (FromRGB)", nchw(y.cpu()), O.fused_leaky_relu(O.equal_conv2d(x, w), b), 2e-6)
+    x = torch.randn(2, 128, 20, 20); w = torch.randn(3, 128, 1, 1); b = torch.randn(3)
+    y = ops.conv1x1_small_cout(g(nhwc(x)), g(w), g(b), 1 / math.sqrt(128))
+    report("conv1x1 small cout (ToRGB)", nchw(y.cpu()), O.equal_conv2d(x, w, b), 3e-6)
+
+
+def t_norm_pool():
+    torch.manual_seed(3)
+    for (B, C, H, Wd) in [(2, 64, 40, 40), (1, 3, 64, 64), (2, 512, 16, 16), (1, 128, 70, 30)]:
+        x = torch.randn(B, C, H, Wd) * 2 + 0.5
+        st = ops.in_stats(g(nhwc(x)))
+        ss = ops.in_finalize(st, H * Wd)
+        report("in_stats+affine C%d %dx%d" % (C, H, Wd), nchw(ops.affine_act(g(nhwc(x)), ss).cpu()), O.instance_norm(x.double()), 1e-5)
+    x = torch.randn(2, 64, 20, 24)
+    st = ops.in_stats(g(nhwc(x)), rep_pad=True)
+    ss = ops.in_finalize(st, 22 * 26)
+    ref = O.instance_norm(F.pad(x.double(), (1, 1, 1, 1), mode="replicate"))[:, :, 1:-1, 1:-1]
+    report("in_stats rep_pad (head quirk)", nchw(ops.affine_act(g(nhwc(x)), ss).cpu()), ref, 1e-5)
+    style = torch.randn(2, 128); pb = torch.randn(64)
+    ss = ops.in_finalize(ops.in_stats(g(nhwc(x))), 20 * 24, style=g(style), post_bias=g(pb))
+    s = style.view(2, 2, 64, 1, 1)
+    ref = O.instance_norm(x.double()) * (s[:, 0] + 1) + s[:, 1] + pb.view(1, -1, 1, 1)
+    report("in_finalize style+post_bias", nchw(ops.affine_act(g(nhwc(x)), ss).cpu()), ref, 1e-5)
+    res = torch.randn(2, 64, 20, 24)
+    rss = torch.randn(2, 64, 2)
+    y = ops.affine_act(g(nhwc(x)), ss, res=g(nhwc(res)), res_scale_shift=g(rss), act=ops.ACT_LRELU, out_scale=0.7)
+    ref2 = (O.fused_leaky_relu(ref, None) + (res * rss[:, :, 0, None, None] + rss[:, :, 1, None, None])) * 0.7
+    report("affine_act lrelu + affine residual", nchw(y.cpu()), ref2, 1e-5)
+    gg = ops.gap_gmp(g(nhwc(x)))
+    report("gap_gmp", gg, torch.cat([x.mean((2, 3)), x.amax((2, 3))], 1), 2e-6)
+    mask = (torch.rand(2, 20, 24) > 0.5).float()
+    xm = x * mask[:, None]
+    report("gap_gmp masked", ops.gap_gmp(g(nhwc(x)), g(mask)), torch.cat([xm.mean((2, 3)), xm.amax((2, 3))], 1), 2e-6)
+    x = torch.randn(2, 32, 64, 64)
+    for f in (1, 2, 4, 8):
+        report("avgpool f%d" % f, nchw(ops.avgpool(g(nhwc(x)), f).cpu()), F.adaptive_avg_pool2d(x, 64 // f), 2e-6)
+    for (oh, ow) in [(128, 128), (256, 256), (64, 64), (32, 32), (512, 512)]:
+        report("bilinear 64->%d" % oh, nchw(ops.bilinear(g(nhwc(x)), oh, ow).cpu()), F.interpolate(x, (oh, ow), mode="bilinear"), 2e-6)
+    report("bilinear scale_factor 8 (E2.warp)", nchw(ops.bilinear(g(nhwc(x[:, :, :16, :16])), 128, 128).cpu()), F.interpolate(x[:, :, :16, :16], scale_factor=8, mode="bilinear"), 2e-6)
+    dst = torch.zeros(2, 32, 32, 96, device=dev)
+    ops.avgpool(g(nhwc(x)), 2, out=dst[..., 32:64])
+    report("avgpool into slice", nchw(dst[..., 32:64].contiguous().cpu()), F.adaptive_avg_pool2d(x, 32), 2e-6)
+    m = (torch.rand(2, 3, 32, 32) > 0.6).float()
+    report("maxpool2 mask", nchw(ops.maxpool2(g(nhwc(m))).cpu()), F.max_pool2d(m, 2, 2), 0)
+    report("upsample_nearest2", nchw(ops.upsample_nearest2(g(nhwc(x))).cpu()), x.repeat_interleave(2, 2).repeat_interleave(2, 3), 0)
+
+
+def t_corr():
+    torch.manual_seed(4)
+    fea = torch.randn(2, 64, 64, 48)
+    report("rselfcorr", nchw(ops.rselfcorr(g(nhwc(fea))).cpu()), O.rselfcorr(fea.double()), 1e-5)
+    f = torch.randn(2, 512, 16, 16)
+    fr = f.reshape(2, 512, -1)
+    h1 = fr[:, :256] - fr[:, :256].mean(1, keepdim=True)
+    ref = torch.cat((h1, fr[:, 256:]), 1)
+    ref = (ref / (ref.norm(2, 1, keepdim=True) + O.EPS64)).permute(0, 2, 1)
+    report("corr_prep", ops.corr_prep(g(nhwc(f)).reshape(2, 256, 512), 256), ref, 2e-6)
+    for (b, M, N, K) in [(2, 256, 256, 512), (1, 4096, 4096, 512), (1, 130, 70, 64)]:
+        A = torch.randn(b, M, K); Bm = torch.randn(b, N, K)
+        report("gemm_nt f32 %dx%dx%d" % (M, N, K), ops.gemm_nt(g(A), g(Bm), 0.5), 0.5 * torch.matmul(A.double(), Bm.double().transpose(1, 2)), 2e-6)
+    for (b, M, N, K) in [(2, 256, 480, 256), (1, 4096, 480, 4096), (1, 200, 192, 64), (1, 128, 32, 128)]:
+        A = torch.randn(b, M, K); Bm = torch.randn(b, K, N)
+        report("gemm_nn f32 %dx%dx%d" % (M, N, K), ops.gemm_nn(g(A), g(Bm)), torch.matmul(A.double(), Bm.double()), 2e-6)
+    x = torch.randn(300, 4096) * 0.3
+    report("softmax rows /0.01", ops.softmax_rows_(g(x).clone(), 0.01), F.softmax(x.double() / 0.01, -1), 2e-5)
+    fa = torch.randn(1, 512, 64, 64); fb = torch.randn(1, 512, 64, 64)
+    from ppst_amd.ppst_model import PPSTModel
+    img = torch.randn(2, 3, 64, 64)
+    corr = F.softmax(torch.randn(2, 64, 64) * 3, -1)
+    pt = ops.unfold_patches(g(img), 8)
+    report("unfold_patches", pt, F.unfold(img, 8, stride=8).permute(0, 2, 1), 0)
+    report("fold_patches", ops.fold_patches(pt, 3, 64, 64, 8), img, 0)
+    wf = ops.fold_patches(ops.gemm_nn(g(corr), pt), 3, 64, 64, 8)
+    report("model warp (unfold, gemm, fold)", wf, O.model_warp(img.double(), corr.double()), 2e-6)
+
+
+def t_guided():
+    rng = np.random.default_rng(5)
+    H = Wd = 96
+    yy, xx = np.meshgrid(np.arange(H), np.arange(Wd), indexing="ij")
+    guide = np.stack([(128 + 100 * np.sin(xx / 9.0 + c) * np.cos(yy / 7.0)) for c in range(3)], -1)
+    guide = np.clip(guide + rng.normal(0, 12, guide.shape), 0, 255).astype(np.uint8)
+    src = np.clip(guide.astype(np.float64) * 0.6 + 50 + rng.normal(0, 25, guide.shape), 0, 255).astype(np.uint8)
+    gb = torch.from_numpy(np.stack([guide, guide[::-1].copy()])).to(dev)
+    sb = torch.from_numpy(np.stack([src, src[::-1].copy()])).to(dev)
+    out, u8 = ops.guided_filter(gb, sb, 30, (0.02 * 255) ** 2, want_u8=True)
+    ref = np.stack([O.guided_filter_color(guide, src, 30), O.guided_filter_color(guide[::-1].copy(), src[::-1].copy(), 30)])
+    d = np.abs(u8.cpu().numpy().astype(int) - ref.astype(int))
+    print("guided_filter u8: max |diff| %d, frac != %.4f" % (d.max(), (d > 0).mean()), flush=True)
+    RES.append(("guided filter u8 within 1 LSB", bool(d.max() <= 1 and (d > 0).mean() < 0.02)))
+    reff = (torch.from_numpy(ref).permute(0, 3, 1, 2).float() / 255.0 - 0.5) * 2
+    report("guided_filter fp32 out (vs oracle)", out, reff, 1.0 / 255 + 1e-6)
+
+
+# ----------------------------------------------------------------- nets ----
+def t_networks():
+    from ppst_amd.ppst_model import create_model
+    sd = W.make_state_dict(1, bias_std=0.1, noise_weight=0.1)
+    noise = W.make_noise(3, 1)
+    imgs = W.synthetic_images(5, 2)
+    t0 = time.time()
+    orc = O.PPSTOracle(sd, noise=noise)
+    with torch.no_grad():
+        r = orc.simple_swap(imgs[0:1], imgs[1:2], alpha=1.0)
+        d_ref = O.discriminator(sd, imgs)
+    print("oracle swap %.1fs" % (time.time() - t0), flush=True)
+    m = create_model(state_dict=sd, with_D=True)
+    m.noise = {k: v.to(dev) for k, v in noise.items()}
+    c, s = g(imgs[0:1]), g(imgs[1:2])
+    with torch.no_grad():
+        sp, gl = m(c, command="encode")
+        report("E1 sp", sp, r["sp"], 1e-3)
+        for i in range(4):
+            report("E2 gl[%d]" % i, gl[i], r["gl"][i], 1e-3)
+        fc, fc1 = m(c, command="extract_feat_from_image")
+        fs, fs1 = m(s, command="extract_feat_from_image")
+        report("G feat (content)", fc, r["fea_c"][:, :256], 1e-3)
+        rc = m(fc1, command="Rselfcorr")
+        rs = m(fs1, command="Rselfcorr")
+        report("Rselfcorr (content)", rc, r["fea_c"][:, 256:], 1e-3)
+        fcc = torch.cat((fc, rc), 1)
+        fss = torch.cat((fs, rs), 1)
+        report("fea_s cat", fss, r["fea_s"], 1e-3)
+        corr = m(fss, fcc, command="corrm")
+        agree = (corr[0].argmax(-1).cpu() == r["corr"][0].argmax(-1)).float().mean().item()
+        print("corr argmax agreement %.5f ; max|dcorr| %.3e" % (agree, (corr.cpu() - r["corr"]).abs().max().item()), flush=True)
+        RES.append(("corr argmax", agree > 0.995))
+        _, glw = m(s, corr, command="encode2")
+        for i in range(4):
+            report("E2 gl_w[%d]" % i, glw[i], r["gl_w"][i], 1e-3)
+        # E2 warp alone on the oracle's corr (isolates the GEMM from upstream noise)
+        _, glw2 = m(s, g(r["corr"]), command="encode2")
+        for i in range(4):
+            report("E2 gl_w[%d] (oracle corr)" % i, glw2[i], r["gl_w"][i], 1e-3)
+        out = m(sp, glw, target=None, command="decode")
+        report("decode out", out, r["out"], 1e-3)
+        out2 = m(g(r["sp"]), [g(t) for t in r["gl_w"]], target=None, command="decode")
+        report("decode out (oracle inputs)", out2, r["out"], 1e-3)
+        u8 = O.to_pil_uint8(out2[0].cpu()); u8r = O.to_pil_uint8(r["out"][0])
+        print("uint8 image: frac pixels differing %.5f, max diff %d" % ((u8 != u8r).mean(), np.abs(u8.astype(int) - u8r.astype(int)).max()), flush=True)
+        report("D(x)", m.discriminate(g(imgs)), d_ref, 1e-3)
+        wimg = m(c, g(r["corr"]), command="warp")
+        report("model.warp image", wimg, O.model_warp(imgs[0:1], r["corr"]), 1e-4)
+        sm = m(g(r["sp"]), [g(t) for t in r["gl_w"]], target=c, command="decode")
+        smr = O.smooth(r["out"], imgs[0:1])
+        d = ((sm.cpu() - smr).abs() * 127.5).round()
+        print("decode+guided filter: max LSB diff %d, frac != %.4f" % (d.max().item(), (d > 0).float().mean().item()), flush=True)
+    # cfg1: 256^2 encode/decode only, init-like weights
+    sd0 = W.make_state_dict(0)
+    im = W.synthetic_images(0, 2, size=256, smooth=False)
+    with torch.no_grad():
+        spr = O.encoder_con(sd0, im[0:1]); glr = O.encoder_col(sd0, im[1:2])[0]; outr = O.generator(sd0, spr, glr)
+        m0 = create_model(state_dict=sd0)
+        sp0, _ = m0(g(im[0:1]), command="encode")
+        _, gl0 = m0(g(im[1:2]), command="encode")
+        report("cfg1 256^2 sp", sp0, spr, 1e-3)
+        report("cfg1 256^2 decode", m0(sp0, gl0, command="decode"), outr, 1e-3)
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    print("device:", torch.cuda.get_device_name(0), flush=True)
+    if which in ("ops", "all"):
+        for fn in (t_upfirdn2d, t_fused_act, t_layout_misc, t_conv, t_norm_pool, t_corr, t_guided):
+            print("== " + fn.__name__, flush=True)
+            run(fn)
+            torch.cuda.synchronize()
+    if which in ("nets", "all"):
+        print("== t_networks", flush=True)
+        run(t_networks)
+    bad = [n for n, ok in RES if not ok]
+    print("\nSUMMARY: %d checks, %d failed" % (len(RES), len(bad)))
+    for n in bad:
+        print("  FAILED:", n)
+
+
+if __name__ == "__main__":
+    main()
