@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py -- 512x512 portrait swaps / s on MI355X (BASELINE.json metric).
+
+One "step" = the reference's single-pair swap recipe
+(evaluation/simple_swapping_evaluator.py:44-60: encode(content),
+extract_feat_from_image(content), extract_feat_from_image(style), Rselfcorr x2,
+corrm, encode2(style, corr), lerp, decode) over a batch of 8 (content, style)
+pairs at 512x512 = BASELINE.json configs[1] ("simple_swapping 512x512 batch=8,
+generator+encoders forward only").  Inputs, weights and noise tensors are
+resident in HBM before the timed region.  Weights are random-init (name-keyed
+generator, ppst_amd/weights.py) with non-zero noise weights so the noise path is
+exercised; data is synthetic.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 8] [--precision bf16x3|bf16]
+    N>1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: pairs are independent -> each rank swaps its own batch (weak scaling),
+no data-path collective; only the timing barrier / max-reduction use RCCL.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_SWAP = 2189e9           # SURVEY.md section 8d / BASELINE.md section 3 (dense conv/GEMM only)
+PEAK_BF16_DENSE_TF = 2500.0      # MI355X_MICROARCH.md: BF16 MFMA dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def swap_step(model, content, style, alpha, glue):
+    """The reference recipe, batched; returns the output image tensor."""
+    sp, gl_c = model(content, command="encode")
+    fea_c, fea_c1 = model(content, command="extract_feat_from_image")
+    fea_s, fea_s1 = model(style, command="extract_feat_from_image")
+    fea_c = torch.cat((fea_c, model(fea_c1, command="Rselfcorr")), dim=1)
+    fea_s = torch.cat((fea_s, model(fea_s1, command="Rselfcorr")), dim=1)
+    corr = model(fea_s, fea_c, command="corrm")
+    _, gl_w = model(style, corr, command="encode2")
+    code = glue.lerp(gl_c, gl_w, alpha)
+    return model(sp, code, target=None, command="decode")
+
+
+def cpu_baseline(seed):
+    """The CPU oracle (a port of the reference's PyTorch-CPU path, pinned to it by
+    tests/golden) timed on ONE pair at 512x512 on the host cores of this box."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ppst_oracle as O
+    from ppst_amd import weights as W
+    sd = W.make_state_dict(seed, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
+    noise = W.make_noise(seed + 2, 1)
+    imgs = W.synthetic_images(seed + 4, 2)
+    orc = O.PPSTOracle(sd, noise=noise)
+    with torch.no_grad():
+        t0 = time.time()
+        orc.simple_swap(imgs[0:1], imgs[1:2], alpha=1.0)
+        dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "swaps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 pair (batch 1) of the same 512x512 recipe, fp32, %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world)
+
+    from ppst_amd import glue, ops, weights as W
+    from ppst_amd.ppst_model import create_model
+    ops.set_precision(0 if args.precision == "bf16x3" else 1)
+
+    B = args.batch
+    sd = W.make_state_dict(0, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
+    model = create_model(state_dict=sd, device=dev)
+    model.noise = {k: v.to(dev) for k, v in W.make_noise(2 + rank, B).items()}
+    imgs = W.synthetic_images(4 + rank, 2 * B).to(dev)
+    content, style = imgs[:B].contiguous(), imgs[B:].contiguous()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = swap_step(model, content, style, 1.0, glue)
+        barrier()
+        ops.prof_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = swap_step(model, content, style, 1.0, glue)
+        barrier()
+        dt = time.perf_counter() - t0
+        conv_ms, conv_launches, conv_flop = ops.prof_collect()
+        ops.prof_enable(False)
+    assert torch.isfinite(out).all()
+
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        swaps = world * B * args.steps
+        passes = 3 if args.precision == "bf16x3" else 1
+        achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        peak = PEAK_BF16_DENSE_TF / passes
+        res = {
+            "metric": "512x512 portrait swaps/sec/GPU", "value": swaps / dt, "unit": "swaps/s (all GPUs)",
+            "per_gpu": swaps / dt / world, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16x3 (fp32 split into hi+lo bf16, 3 MFMA passes, fp32 accumulate)" if passes == 3 else "bf16",
+            "data": "synthetic",
+            "config": {"workload": "simple_swapping 512x512 batch=%d per GPU, generator+encoders forward only (BASELINE configs[1])" % B,
+                       "recipe": "encode + 2x extract_feat_from_image + 2x Rselfcorr + corrm + encode2 + decode",
+                       "image_parallel": "1 batch per rank, no data-path collective"},
+            "algorithmic_tflops_whole_job": swaps * FLOP_PER_SWAP / dt / 1e12,
+            "roofline": {
+                "kernel": "conv_mfma_kernel (StyledConv / EqualConv2d / nn.Conv2d implicit GEMM, all launches)",
+                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "peak_note": "bf16 dense MFMA 2500 TF / %d MFMA passes per algorithmic MAC" % passes,
+                "frac_vs_dense_bf16": achieved / PEAK_BF16_DENSE_TF,
+                "launches": conv_launches, "kernel_ms_total": conv_ms,
+                "share_of_step_time": conv_ms * 1e-3 / dt, "traffic": None,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(0)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -249,6 +249,9 @@ int ppst_guided_filter(const void* guide_u8, const void* src_u8, void* out, void
 int ppst_prof_enable(int on);
 /* after a stream sync: total ms, launches, algorithmic flop of bracketed calls */
 int ppst_prof_collect(double* ms, int64_t* launches, double* flop);
+/* per-launch detail of bracketed call idx (before ppst_prof_collect resets the pool):
+ * info = {B, tile_h, tile_w, nsteps, cout, n_groups, halo, bn} */
+int ppst_prof_detail(int idx, double* ms, double* flop, int32_t* info);
 
 #ifdef __cplusplus
 }

@@ -8,8 +8,15 @@ stylegan2_op/upfirdn2d.cpp:9, fused_bias_act.cpp:8).
 import ctypes
 import os
 
+# PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64; it must be in the
+# process BEFORE libppst_hip.so is dlopen'ed so that both resolve to ONE HIP runtime (the
+# dynamic loader matches the SONAME).  Loading ours first pulls /opt/rocm's runtime in
+# and torch's allocations then live in a different runtime: launches fail with
+# hipErrorNoDevice.  Hosts without torch (cgo/JNI) use the system runtime.
+import torch  # noqa: F401  (import order matters)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libppst_hip.so")
+LIB_PATH = os.environ.get("PPST_HIP_LIB") or os.path.join(HERE, "libppst_hip.so")  # env override: diagnostic builds only
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -74,6 +81,7 @@ _SIGS = {
     "ppst_guided_filter": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp]),
     "ppst_prof_enable": (i32, [i32]),
     "ppst_prof_collect": (i32, [ctypes.POINTER(f64), ctypes.POINTER(i64), ctypes.POINTER(f64)]),
+    "ppst_prof_detail": (i32, [i32, ctypes.POINTER(f64), ctypes.POINTER(f64), ctypes.POINTER(i32)]),
 }
 
 for _name, (_res, _args) in _SIGS.items():

@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include "../../include/ppst_hip.h"
 
+// hipGetLastError() is sticky across libraries: clear stale errors (e.g. from the caller's own
+// device probing) before a launch so the check after it reports this launch only.
+#define PPST_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 #define PPST_LAUNCH_CHECK() ((int)hipGetLastError())
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;

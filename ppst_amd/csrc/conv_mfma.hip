@@ -16,9 +16,9 @@
 //    LDS image [hi/lo][g][n][8 k]; staging is a linear 16-B copy.
 //  * MFMA: v_mfma_f32_16x16x32_bf16; fp32-class accuracy from 3 passes
 //    (hi*hi + hi*lo + lo*hi, "bf16x3"), or 1 pass in bf16 mode.  Wave tile 64 px x 64 ch.
-//  * Pipeline: register-prefetch double buffering -- global loads for step s+1 are issued
-//    before the MFMAs of step s and written to the other LDS buffer after them; one
-//    __syncthreads per K-step (= per tap), >= 48 MFMAs per wave between barriers.
+//  * Pipeline: two-deep software pipeline -- global loads of step s+2 and LDS fragment reads
+//    of step s+1 are issued under the MFMAs of step s; one __syncthreads per K-step (= per
+//    tap), >= 48 MFMAs per wave between barriers; A ring of 3 LDS slots, B ring of 2.
 //  * Stride-2 convs run as stride-1 convs over a space-to-depth input, the 4x4 stride-2
 //    transposed conv as 4 output-phase groups of 2x2 taps; both are just step tables.
 //  * Block -> tile map is XCD-aware: the 8 XCDs each get a contiguous range of an N-major
@@ -39,7 +39,21 @@ struct ConvKArgs {
   int B, in_h, in_w, in_ld, out_h, out_w, out_ld, cout;
   int nsteps, n_groups, pad_mode, in_off_y, in_off_x, out_sy, out_sx, act, res_ld, tile_h, tile_w;
   int tiles_y, tiles_x, n_tiles;
+  unsigned long long* dbg;  // stamp build: [block][wave][8] cycle sums (else unused)
 };
+
+// Diagnostic build only (-DPPST_CONV_STAMP): s_memtime stamps around the phases of a K-step
+// (MI355X guide, "In-kernel stamps").  The product library is built without it.
+#ifdef PPST_CONV_STAMP
+__device__ __forceinline__ unsigned long long conv_stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define STAMP(var) __builtin_amdgcn_sched_barrier(0); unsigned long long var = conv_stamp(); __builtin_amdgcn_sched_barrier(0);
+#else
+#define STAMP(var)
+#endif
 
 __device__ __forceinline__ int pad_index(int i, int n, int mode) {
   if (mode == PPST_PAD_REFLECT) {
@@ -68,9 +82,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
   constexpr int B_IT = (B_ITEMS + NT - 1) / NT;
   static_assert(B_ITEMS % NT == 0, "B blob must split evenly");
 
-  __shared__ __attribute__((aligned(256))) unsigned char smem[2 * ABUF + 2 * BBUF];
+  constexpr int NA = 3;  // A ring slots (see the hazard note at the main loop)
+  constexpr int EPI_TILE = 64 * 36;                              // floats per wave: 64 px x (32 ch + 4 pad)
+  constexpr int EPI_BYTES = (NT / 64) * EPI_TILE * 4 + WM * BN * 2 * 4;  // transposition tiles + stats scratch
+  constexpr int MAIN_BYTES = NA * ABUF + 2 * BBUF;
+  __shared__ __attribute__((aligned(256))) unsigned char smem[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
   unsigned char* smA = smem;
-  unsigned char* smB = smem + 2 * ABUF;
+  unsigned char* smB = smem + NA * ABUF;
 
   // ---- XCD-aware block -> (n index, m tile) map (bijective remap, N-major order)
   const int nwg = gridDim.x;
@@ -92,21 +110,32 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
   const int wn = wave % WN, wm = wave / WN;
   const int r16 = lane & 15, g = lane >> 4;
 
+  STAMP(t_begin)
+#ifdef PPST_CONV_STAMP
+  unsigned long long acc_top = 0, acc_mfma = 0, acc_store = 0, acc_bar = 0;
+#endif
   const int4* steps = a.steps + (int64_t)group * a.nsteps;
   const unsigned char* wblob = (const unsigned char*)a.wpack + ((int64_t)nidx * a.nsteps) * BBUF;
   const float* xb = a.x + (int64_t)b * a.in_h * a.in_w * a.in_ld;
 
   static_assert(B_IT == 1 || B_IT == 2, "B staging assumes 1 or 2 16-B items per thread");
-  float4 ra[A_IT];
+  constexpr int A_WCH = (HP + 7) / 8;                      // wave-chunks of 8 pixels x 8 float4
+  constexpr int A_IT2 = (A_WCH * 64 + NT - 1) / NT;
+  float4 ra[A_IT2];
   uint4 rb0, rb1;  // (named, not an array: hipcc promoted a 2-element array to LDS)
 
+  // A staging.  One wave-instruction covers 8 pixels x 128 B (fully coalesced global read);
+  // inside it lane l -> plane g = l>>4, pixel (l>>1)&7, half h = l&1, so the 16 lanes of a
+  // ds_write_b64 group write 128 contiguous bytes of ONE plane (conflict-free; the planes
+  // alias each other's banks because their stride is a multiple of 256 B).
   auto a_load = [&](int chan_off) {
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
+    for (int it = 0; it < A_IT2; ++it) {
       int i = tid + it * NT;
+      int l = i & 63;
+      int pix = (i >> 6) * 8 + ((l >> 1) & 7), q4 = (l >> 4) * 2 + (l & 1);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < A_ITEMS) {
-        int pix = i >> 3, q4 = i & 7;
+      if (pix < HP) {
         int hy = pix / HW, hx = pix - hy * HW;
         int iy = ty0 + hy - HALO + a.in_off_y, ix = tx0 + hx - HALO + a.in_off_x;
         bool inb = iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w;
@@ -119,17 +148,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
       ra[it] = v;
     }
   };
-  auto a_store = [&](int buf) {
-    unsigned char* base = smA + buf * ABUF;
+  auto a_store = [&](int slot) {
+    unsigned char* base = smA + slot * ABUF;
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
+    for (int it = 0; it < A_IT2; ++it) {
       int i = tid + it * NT;
-      if (i < A_ITEMS) {
-        int pix = i >> 3, q4 = i & 7;
+      int l = i & 63;
+      int pix = (i >> 6) * 8 + ((l >> 1) & 7);
+      if (pix < HP) {
         float4 v = ra[it];
         unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
         split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
-        int off = (q4 >> 1) * PLANE + pix * 16 + (q4 & 1) * 8;
+        int off = (l >> 4) * PLANE + pix * 16 + (l & 1) * 8;
         uint2 hv = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
         *(uint2*)(base + off) = hv;
         if (X3) {
@@ -149,6 +179,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
     dst[tid] = rb0;
     if (B_IT > 1) dst[tid + NT] = rb1;
   };
+  // fragment reads
+  auto ld_b = [&](bf16x8 (&h)[4], bf16x8 (&lo)[4], int slot) {
+    const unsigned char* Bb = smB + slot * BBUF + g * BPLANE + (wn * 64 + r16) * 16;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      h[nt] = *(const bf16x8*)(Bb + nt * 256);
+      if (X3) lo[nt] = *(const bf16x8*)(Bb + 4 * BPLANE + nt * 256);
+    }
+  };
+  // LDS byte offset of the A fragment (tile row mt) of a step with tap (dy, dx) in ring slot `slot`
+  STAMP(t_setup)
+#define A_OFF(slot, dy, dx, mt) ((slot) * ABUF + g * PLANE + (((wm * 4 + (mt) + HALO + (dy)) * HW + HALO + (dx) + r16) * 16))
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -156,109 +198,210 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  int4 st = steps[0];
-  a_load(st.x);
+  // ---- software pipeline -------------------------------------------------------------
+  // During step s a wave (1) issues the global loads of step s+2 (B blob; A chunk if step
+  // s+2 opens one), (2) reads the LDS fragments of step s+1 (all B fragments, A fragment
+  // mt=0) interleaved with the MFMAs of step s (whose B fragments were read during step
+  // s-1; its A fragments mt=1..3 rotate in one tile ahead), (3) writes the step-s+2 data to
+  // LDS and hits the one barrier of the step.  Hazards: B(s+2) overwrites the slot of B(s)
+  // (last read during step s-1: a barrier ago) -> 2 B slots.  A(chunk of s+2) must not
+  // overwrite the chunks of steps s and s+1, both still being read by slower waves -> 3 A
+  // slots (chunk index mod 3), which also covers single-step chunks (1x1 convs).
+  // Stagger: the two waves that share a SIMD (wave w and w+4 of a 512-thread block) run the
+  // same program, so without help they reach the MFMA phase and the staging phase together
+  // and the matrix pipe idles while both stage.  Group 1 (waves 4..7) therefore does its
+  // staging work FIRST in every barrier interval (write the data it loaded one interval
+  // earlier, issue the loads of step s+3) and its MFMAs last; group 0 does MFMAs first and
+  // stages (loads of step s+2 issued at the top, written after the MFMAs) last.  Both
+  // groups deliver their share of step s+2 inside interval s, so the ring hazards above
+  // are unchanged.
+  // (measured on MI355X: the stagger made the loop ~15% slower than lockstep; kept behind a switch)
+#ifdef PPST_CONV_STAGGER
+  const bool grp1 = (NT == 512) && (__builtin_amdgcn_readfirstlane(tid) >= 256);
+#else
+  constexpr bool grp1 = false;
+#endif
+  // step descriptors live in scalars (cur = 0, next = 1): chan_off, dy, dx, new_chunk
+  int4 d = steps[0];
+  int dy0 = d.y, dx0 = d.z, sl0 = 0;
+  int dy1 = d.y, dx1 = d.z, sl1 = 0;
+  a_load(d.x);
   b_load(0);
   a_store(0);
   b_store(0);
-  __syncthreads();
-  int curA = 0;
-
-  for (int s = 0; s < a.nsteps; ++s) {
-    const bool has_next = s + 1 < a.nsteps;
-    int4 nx = st;
-    if (has_next) nx = steps[s + 1];
-    const bool nextA = has_next && nx.w != 0;
-    if (has_next) b_load(s + 1);
-    if (nextA) a_load(nx.x);
-
-    // ---- MFMA over this tap: A window shifted by (dy, dx) inside the halo tile
-    {
-      const unsigned char* Ab = smA + curA * ABUF + g * PLANE;
-      const unsigned char* Bb = smB + (s & 1) * BBUF + g * BPLANE + (wn * 64 + r16) * 16;
-      const int pix0 = (wm * 4 + HALO + st.y) * HW + (HALO + st.z) + r16;
-      bf16x8 bh[4], bl[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        bh[nt] = *(const bf16x8*)(Bb + nt * 256);
-        if (X3) bl[nt] = *(const bf16x8*)(Bb + 4 * BPLANE + nt * 256);
-      }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const int off = (pix0 + mt * HW) * 16;
-        bf16x8 ah = *(const bf16x8*)(Ab + off);
-        bf16x8 al;
-        if (X3) al = *(const bf16x8*)(Ab + 4 * PLANE + off);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          if (X3) {
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nt], acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nt], acc[mt][nt], 0, 0, 0);
-          }
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
-        }
-      }
-    }
-
-    if (has_next) b_store((s + 1) & 1);
-    if (nextA) a_store(curA ^ 1);
-    __syncthreads();
-    if (nextA) curA ^= 1;
-    st = nx;
+  if (a.nsteps > 1) {
+    d = steps[1];
+    dy1 = d.y; dx1 = d.z;
+    sl1 = d.w != 0 ? 1 : 0;
+    b_load(1);
+    if (d.w != 0) a_load(d.x);
+    b_store(1);
+    if (d.w != 0) a_store(sl1);
   }
+  // group 1 runs one interval ahead on loads: issue step 2 now
+  bool pendA = false;
+  int pendSlot = 0;
+  if (grp1 && a.nsteps > 2) {
+    d = steps[2];
+    b_load(2);
+    pendA = d.w != 0;
+    pendSlot = pendA ? (sl1 == NA - 1 ? 0 : sl1 + 1) : sl1;
+    if (pendA) a_load(d.x);
+  }
+  __syncthreads();
+  STAMP(t_prologue)
 
-  // ---- epilogue: + bias + noise [+ residual] -> act -> * out_scale -> store, tile statistics
+  bf16x8 b0h[4], b0l[4], b1h[4], b1l[4];
+  bf16x8 ah, al;
+  ld_b(b0h, b0l, 0);
+  ah = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, 0));
+  if (X3) al = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, 0) + 4 * PLANE);
+
+#ifdef PPST_CONV_STAMP
+#define ST_A STAMP(t0_)
+#define ST_B STAMP(t1_)
+#define ST_C STAMP(t2_)
+#define ST_D STAMP(t3_) acc_mfma += t1_ - t0_; acc_store += t2_ - t1_; acc_bar += t3_ - t2_;
+#else
+#define ST_A
+#define ST_B
+#define ST_C
+#define ST_D
+#endif
+#define CONV_STEP(bch, bcl, bnh, bnl, s)                                                              \
+  {                                                                                                   \
+    ST_A                                                                                              \
+    const bool has1 = (s) + 1 < a.nsteps, has2 = (s) + 2 < a.nsteps, has3 = (s) + 3 < a.nsteps;       \
+    int ch2 = 0, dy2 = dy1, dx2 = dx1, nw2 = 0;                                                       \
+    if (has2) { int4 d2 = steps[(s) + 2]; ch2 = d2.x; dy2 = d2.y; dx2 = d2.z; nw2 = d2.w; }           \
+    int sl2 = sl1;                                                                                    \
+    if (has2 && nw2 != 0) sl2 = (sl1 == NA - 1) ? 0 : sl1 + 1;                                        \
+    if (grp1) {                                                                                       \
+      /* write what was loaded one interval ago (step s+2), then load step s+3 */                     \
+      if (has2) b_store((s) & 1);                                                                     \
+      if (pendA) a_store(pendSlot);                                                                   \
+      pendA = false;                                                                                  \
+      if (has3) {                                                                                     \
+        int4 d3 = steps[(s) + 3];                                                                     \
+        b_load((s) + 3);                                                                              \
+        pendA = d3.w != 0;                                                                            \
+        pendSlot = pendA ? ((sl2 == NA - 1) ? 0 : sl2 + 1) : sl2;                                     \
+        if (pendA) a_load(d3.x);                                                                      \
+      }                                                                                               \
+    } else {                                                                                          \
+      if (has2) b_load((s) + 2);                                                                      \
+      if (has2 && nw2 != 0) a_load(ch2);                                                              \
+    }                                                                                                 \
+    if (has1) ld_b(bnh, bnl, ((s) + 1) & 1);                                                          \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                \
+      bf16x8 nh, nl;                                                                                  \
+      if (mt < 3) {                                                                                   \
+        nh = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1));                                    \
+        if (X3) nl = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1) + 4 * PLANE);                \
+      } else if (has1) {                                                                              \
+        nh = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0));                                         \
+        if (X3) nl = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0) + 4 * PLANE);                     \
+      }                                                                                               \
+      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                              \
+        if (X3) {                                                                                     \
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bch[nt], acc[mt][nt], 0, 0, 0);   \
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcl[nt], acc[mt][nt], 0, 0, 0);   \
+        }                                                                                             \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bch[nt], acc[mt][nt], 0, 0, 0);     \
+      }                                                                                               \
+      ah = nh;                                                                                        \
+      if (X3) al = nl;                                                                                \
+    }                                                                                                 \
+    ST_B                                                                                              \
+    if (!grp1) {                                                                                      \
+      if (has2) b_store((s) & 1);                                                                     \
+      if (has2 && nw2 != 0) a_store(sl2);                                                             \
+    }                                                                                                 \
+    ST_C                                                                                              \
+    __syncthreads();                                                                                  \
+    ST_D                                                                                              \
+    dy0 = dy1; dx0 = dx1; sl0 = sl1;                                                                  \
+    dy1 = dy2; dx1 = dx2; sl1 = sl2;                                                                  \
+  }
+  for (int s = 0; s < a.nsteps; s += 2) {
+    CONV_STEP(b0h, b0l, b1h, b1l, s)
+    if (s + 1 < a.nsteps) CONV_STEP(b1h, b1l, b0h, b0l, s + 1)
+  }
+#undef CONV_STEP
+#undef A_OFF
+  STAMP(t_loop_end)
+
+  // ---- epilogue: + bias + noise [+ residual] -> act -> * out_scale -> store, tile statistics.
+  // The accumulators (lane = channel, registers = pixels) are transposed through a per-wave
+  // LDS tile so that every lane stores 16 contiguous bytes of one pixel (128-B segments per
+  // pixel per wave-instruction instead of 64-B ones, 4x fewer store instructions, and the
+  // pixel address arithmetic runs once per float4).  Two passes of 32 channels each.
   const int gy = group >> 1, gx = group & 1;  // output phase of the transposed conv
   const int act = a.act & 0xff;
   const bool res_after = (a.act >> 8) & 1;  // residual joins after the activation (resnet skip)
   const float slope = (act == PPST_ACT_PRELU && a.prelu) ? a.prelu[0] : 0.f;
-  float ssum[4], ssq[4];
+  float* tw = (float*)smem + wave * EPI_TILE;            // main-loop buffers are dead: last barrier passed
+  float* red = (float*)smem + (NT / 64) * EPI_TILE;      // [WM][BN][2]
+  const int f8 = lane & 7, prow = lane >> 3;
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const int n = ntile * BN + wn * 64 + nt * 16 + r16;
-    const bool nok = n < a.cout;
-    const float bv = (nok && a.bias) ? a.bias[n] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int ty = ty0 + wm * 4 + mt;
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int tx = tx0 + g * 4 + j;
-        if (nok && ty < a.tile_h && tx < a.tile_w) {
-          const int oy = ty * a.out_sy + (a.n_groups > 1 ? gy : 0), ox = tx * a.out_sx + (a.n_groups > 1 ? gx : 0);
-          const int64_t opix = ((int64_t)b * a.out_h + oy) * a.out_w + ox;
-          float v = acc[mt][nt][j] + bv;
-          if (a.noise) v += a.noise_weight * a.noise[opix];
-          float rv = a.residual ? a.residual[opix * a.res_ld + n] : 0.f;
-          if (!res_after) v += rv;
-          if (act == PPST_ACT_LRELU) v = (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
-          else if (act == PPST_ACT_PRELU) v = v >= 0.f ? v : v * slope;
-          if (res_after) v += rv;
-          v *= a.out_scale;
-          a.y[opix * a.out_ld + n] = v;
-          s1 += v;
-          s2 += v * v;
+      for (int ntl = 0; ntl < 2; ++ntl)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tw[(mt * 16 + g * 4 + j) * 36 + ntl * 16 + r16] = acc[mt][pass * 2 + ntl][j];
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): only this wave touches its tile
+    __builtin_amdgcn_wave_barrier();
+    const int nl0 = wn * 64 + pass * 32 + f8 * 4;
+    const int n0 = ntile * BN + nl0;
+    const bool nok = n0 < a.cout;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nok && a.bias) bv = *(const float4*)(a.bias + n0);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int p = it * 8 + prow;
+      const int ty = ty0 + wm * 4 + (p >> 4), tx = tx0 + (p & 15);
+      float4 v = *(const float4*)(tw + p * 36 + f8 * 4);
+      if (nok && ty < a.tile_h && tx < a.tile_w) {
+        const int oy = ty * a.out_sy + (a.n_groups > 1 ? gy : 0), ox = tx * a.out_sx + (a.n_groups > 1 ? gx : 0);
+        const int64_t opix = ((int64_t)b * a.out_h + oy) * a.out_w + ox;
+        float nz = a.noise ? a.noise_weight * a.noise[opix] : 0.f;
+        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.residual) rv = *(const float4*)(a.residual + opix * a.res_ld + n0);
+        float o[4] = {v.x + bv.x + nz, v.y + bv.y + nz, v.z + bv.z + nz, v.w + bv.w + nz};
+        const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float t = o[c];
+          if (!res_after) t += r4[c];
+          if (act == PPST_ACT_LRELU) t = (t > 0.f ? t : t * 0.2f) * 1.41421356237309515f;
+          else if (act == PPST_ACT_PRELU) t = t >= 0.f ? t : t * slope;
+          if (res_after) t += r4[c];
+          o[c] = t * a.out_scale;
         }
+        *(float4*)(a.y + opix * a.out_ld + n0) = make_float4(o[0], o[1], o[2], o[3]);
+        s1.x += o[0]; s1.y += o[1]; s1.z += o[2]; s1.w += o[3];
+        s2.x += o[0] * o[0]; s2.y += o[1] * o[1]; s2.z += o[2] * o[2]; s2.w += o[3] * o[3];
       }
     }
-    ssum[nt] = s1;
-    ssq[nt] = s2;
+    if (a.stats) {
+      // sum over the 8 pixel rows of the wave (lanes with equal f8): xor 8, 16, 32
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64); s1.z += __shfl_xor(s1.z, o, 64); s1.w += __shfl_xor(s1.w, o, 64);
+        s2.x += __shfl_xor(s2.x, o, 64); s2.y += __shfl_xor(s2.y, o, 64); s2.z += __shfl_xor(s2.z, o, 64); s2.w += __shfl_xor(s2.w, o, 64);
+      }
+      if (prow == 0) {
+        float* r = red + (wm * BN + nl0) * 2;
+        r[0] = s1.x; r[1] = s2.x; r[2] = s1.y; r[3] = s2.y; r[4] = s1.z; r[5] = s2.z; r[6] = s1.w; r[7] = s2.w;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();  // tile reads done before the next pass overwrites it
   }
   if (a.stats) {
-    // reduce over the 4 lane groups (pixels), then over the WM waves through LDS
-    float* red = (float*)smem;  // [WM][BN][2]  (main-loop buffers are dead: last barrier passed)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      float s1 = ssum[nt], s2 = ssq[nt];
-      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-      if (g == 0) {
-        int nl = wn * 64 + nt * 16 + r16;
-        red[(wm * BN + nl) * 2] = s1;
-        red[(wm * BN + nl) * 2 + 1] = s2;
-      }
-    }
     __syncthreads();
     const int tiles = a.tiles_y * a.tiles_x;
     for (int nl = tid; nl < BN; nl += NT) {
@@ -273,6 +416,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
       }
     }
   }
+#ifdef PPST_CONV_STAMP
+  {
+    STAMP(t_end)
+    if (a.dbg && lane == 0) {
+      unsigned long long* o = a.dbg + ((int64_t)blockIdx.x * (NT / 64) + wave) * 8;
+      o[0] = t_setup - t_begin;         // index math
+      o[1] = t_prologue - t_setup;      // prologue staging (first loads + LDS stores + barrier)
+      o[2] = t_loop_end - t_prologue;   // main loop
+      o[3] = t_end - t_loop_end;        // epilogue
+      o[4] = acc_mfma;                  // barrier-exit -> MFMAs issued (incl. desc load, global-load issue, LDS reads)
+      o[5] = acc_store;                 // staging stores (waits for the global loads)
+      o[6] = acc_bar;                   // barrier wait
+      o[7] = acc_top;
+    }
+  }
+#endif
 }
 
 // ------------------------------------------------------------ weight packing --
@@ -323,7 +482,7 @@ extern "C" int ppst_conv_pack(const void* w, int64_t sn, int64_t sc, int64_t sy,
   int64_t total = (int64_t)n_groups * n_tiles * nsteps * 4 * bn;
   int64_t blocks = cdiv64(total, 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)w, sn, sc, sy, sx,
+  PPST_LAUNCH(conv_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)w, sn, sc, sy, sx,
                      scale, cout, bn, src_c, src_ky, src_kx, nsteps, n_groups, precision == 0 ? 1 : 0, (unsigned short*)out, total);
   return PPST_LAUNCH_CHECK();
 }
@@ -348,7 +507,7 @@ extern "C" int ppst_upscale_weight(const void* w, void* out, int cout, int cin, 
   int64_t total = (int64_t)cin * cout * 16;
   int64_t blocks = cdiv64(total, 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(upscale_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)w, (float*)out,
+  PPST_LAUNCH(upscale_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)w, (float*)out,
                      cout, cin, scale, total);
   return PPST_LAUNCH_CHECK();
 }
@@ -358,6 +517,7 @@ extern "C" int ppst_upscale_weight(const void* w, void* out, int cout, int cin, 
 static int g_prof_on = 0;
 static hipEvent_t g_ev[PROF_MAX][2];
 static double g_flop[PROF_MAX];
+static int g_info[PROF_MAX][8];
 static int g_ev_made = 0, g_ev_used = 0;
 
 extern "C" int ppst_prof_enable(int on) {
@@ -380,18 +540,29 @@ extern "C" int ppst_prof_collect(double* ms, int64_t* launches, double* flop) {
   g_ev_used = 0;
   return PPST_OK;
 }
+// per-launch detail (call before ppst_prof_collect): info = {B, tile_h, tile_w, cin_steps(nsteps), cout, n_groups, halo, bn}
+extern "C" int ppst_prof_detail(int idx, double* ms, double* flop, int32_t* info) {
+  if (idx < 0 || idx >= g_ev_used) return PPST_EINVAL;
+  float e = 0.f;
+  hipError_t err = hipEventElapsedTime(&e, g_ev[idx][0], g_ev[idx][1]);
+  if (err != hipSuccess) return (int)err;
+  if (ms) *ms = e;
+  if (flop) *flop = g_flop[idx];
+  if (info) for (int i = 0; i < 8; ++i) info[i] = g_info[idx][i];
+  return PPST_OK;
+}
 
 extern "C" int ppst_conv_tiles(int tile_h, int tile_w) { return cdiv(tile_h, 16) * cdiv(tile_w, 16); }
 
 template <int WM, int WN, int HALO, bool X3>
 static void launch_conv(const ConvKArgs& k, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, HALO, X3>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
+  PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
 }
 
 extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   if (!a) return PPST_ENULL;
   if (a->B < 0 || a->in_h <= 0 || a->in_w <= 0 || a->in_ld <= 0 || a->in_ld % 4 || a->out_h <= 0 || a->out_w <= 0 ||
-      a->out_ld < a->cout || a->cout <= 0 || a->nsteps <= 0 || (a->n_groups != 1 && a->n_groups != 4) || a->pad_mode < 0 ||
+      a->out_ld < a->cout || a->cout <= 0 || a->cout % 4 || a->out_ld % 4 || (a->residual && a->res_ld % 4) || a->nsteps <= 0 || (a->n_groups != 1 && a->n_groups != 4) || a->pad_mode < 0 ||
       a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 || a->precision < 0 ||
       a->precision > 1 || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128) || (a->residual && a->res_ld < a->cout))
     return PPST_EINVAL;
@@ -412,6 +583,11 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   k.res_ld = a->res_ld; k.tile_h = a->tile_h; k.tile_w = a->tile_w;
   k.tiles_y = cdiv(a->tile_h, 16); k.tiles_x = cdiv(a->tile_w, 16);
   k.n_tiles = cdiv(a->cout, a->bn);
+  k.dbg = nullptr;
+#ifdef PPST_CONV_STAMP
+  k.dbg = (unsigned long long*)a->prelu;  // stamp build: the (unused) prelu slot carries the debug buffer
+  k.prelu = nullptr;
+#endif
   int64_t blocks64 = (int64_t)a->n_groups * k.n_tiles * a->B * k.tiles_y * k.tiles_x;
   if (blocks64 > 0x7fffffff) return PPST_EINVAL;
   int blocks = (int)blocks64;
@@ -424,6 +600,8 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
     }
     slot = g_ev_used++;
     g_flop[slot] = 2.0 * 32.0 * a->nsteps * (double)a->n_groups * a->cout * (double)a->B * a->tile_h * a->tile_w;
+    int inf[8] = {a->B, a->tile_h, a->tile_w, a->nsteps, a->cout, a->n_groups, a->halo, a->bn};
+    for (int i = 0; i < 8; ++i) g_info[slot][i] = inf[i];
     (void)hipEventRecord(g_ev[slot][0], st);
   }
   const bool x3 = a->precision == 0;

@@ -61,7 +61,7 @@ extern "C" int ppst_rselfcorr(const void* fea, void* out, int B, int H, int W, i
   int64_t npatch = (int64_t)B * (H / 4) * (W / 4);
   int64_t blocks = cdiv64(npatch, 4);
   if (blocks > 256 * 8) blocks = 256 * 8;
-  hipLaunchKernelGGL(rselfcorr_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)fea, (float*)out, B, H,
+  PPST_LAUNCH(rselfcorr_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)fea, (float*)out, B, H,
                      W, out_ld, 2.220446049250313e-16f, npatch);
   return PPST_LAUNCH_CHECK();
 }
@@ -106,7 +106,7 @@ extern "C" int ppst_corr_prep(const void* fea, void* out, int B, int P, int C, i
   int64_t rows = (int64_t)B * P;
   int64_t blocks = cdiv64(rows, 4);
   if (blocks > 256 * 8) blocks = 256 * 8;
-  hipLaunchKernelGGL(corr_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)fea, (float*)out, rows, C,
+  PPST_LAUNCH(corr_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)fea, (float*)out, rows, C,
                      ncenter, 2.220446049250313e-16f);
   return PPST_LAUNCH_CHECK();
 }
@@ -217,7 +217,7 @@ static int gemm_dispatch(const float* A, const float* Bm, float* C, int batch, i
   int ntl = N >= 160 ? 5 : (N >= 128 ? 4 : (N + 31) / 32);
   if (N % 160 != 0 && N % 128 == 0) ntl = 4;
   dim3 grid(cdiv(M, 128), cdiv(N, 32 * ntl), batch);
-#define GL(NTL) hipLaunchKernelGGL((gemm_f32_kernel<NTL, B_NT>), grid, dim3(256), 0, st, A, Bm, C, M, N, K, lda, ldb, ldc, sA, sB, sC, alpha)
+#define GL(NTL) PPST_LAUNCH((gemm_f32_kernel<NTL, B_NT>), grid, dim3(256), 0, st, A, Bm, C, M, N, K, lda, ldb, ldc, sA, sB, sC, alpha)
   switch (ntl) {
     case 1: GL(1); break;
     case 2: GL(2); break;
@@ -291,7 +291,7 @@ extern "C" int ppst_softmax_rows(void* x, int64_t rows, int cols, float div, voi
   if (rows < 0 || cols <= 0 || cols % 4 || cols > 16384 || div == 0.f || rows > 0x7fffffff) return PPST_EINVAL;
   if (rows == 0) return PPST_OK;
   if (!x) return PPST_ENULL;
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, as_stream(stream), (float*)x, cols, div);
+  PPST_LAUNCH(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, as_stream(stream), (float*)x, cols, div);
   return PPST_LAUNCH_CHECK();
 }
 
@@ -320,7 +320,7 @@ extern "C" int ppst_unfold_patches(const void* x, void* y, int B, int C, int H, 
   int64_t total = (int64_t)B * C * H * W;
   int64_t blocks = cdiv64(total, 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(patches_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, C, H, W, s, total);
+  PPST_LAUNCH(patches_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, C, H, W, s, total);
   return PPST_LAUNCH_CHECK();
 }
 extern "C" int ppst_fold_patches(const void* x, void* y, int B, int C, int H, int W, int s, void* stream) {
@@ -330,6 +330,6 @@ extern "C" int ppst_fold_patches(const void* x, void* y, int B, int C, int H, in
   int64_t total = (int64_t)B * C * H * W;
   int64_t blocks = cdiv64(total, 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(patches_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, C, H, W, s, total);
+  PPST_LAUNCH(patches_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, C, H, W, s, total);
   return PPST_LAUNCH_CHECK();
 }

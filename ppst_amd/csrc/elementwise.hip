@@ -74,7 +74,7 @@ extern "C" int ppst_nchw_to_nhwc(const void* x, void* y, int B, int C, int H, in
   if (!x || !y) return PPST_ENULL;
   int64_t P = (int64_t)H * W;
   dim3 grid((unsigned)cdiv64(P, 64), cdiv(C, 32), B);
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, C, P);
+  PPST_LAUNCH(nchw_to_nhwc_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, C, P);
   return PPST_LAUNCH_CHECK();
 }
 extern "C" int ppst_nhwc_to_nchw(const void* x, void* y, int B, int C, int H, int W, void* stream) {
@@ -83,7 +83,7 @@ extern "C" int ppst_nhwc_to_nchw(const void* x, void* y, int B, int C, int H, in
   if (!x || !y) return PPST_ENULL;
   int64_t P = (int64_t)H * W;
   dim3 grid((unsigned)cdiv64(P, 64), cdiv(C, 32), B);
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, C, P);
+  PPST_LAUNCH(nhwc_to_nchw_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, C, P);
   return PPST_LAUNCH_CHECK();
 }
 
@@ -153,44 +153,57 @@ extern "C" int ppst_in_stats(const void* x, void* partial, int B, int H, int W, 
   if (!x && !partial) return PPST_OK;  // size query
   if (B == 0) return PPST_OK;
   if (!x || !partial) return PPST_ENULL;
-  hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
+  PPST_LAUNCH(chan_reduce_kernel<0>, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
                      (const float*)nullptr, (float*)partial, H, W, C, ld, rep_pad, nchunks);
   return PPST_LAUNCH_CHECK();
 }
 
+// One block per (image b, 32-channel group): 8 partial rows are in flight per step (each a
+// 256-B coalesced read of 32 (sum, sumsq) pairs), double accumulation, LDS tree at the end.
 __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ partial, int n_partials,
                                                           const float* __restrict__ style, const float* __restrict__ post_bias,
                                                           float* __restrict__ ss, int B, int C, double count, float eps) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= B * C) return;
-  int b = i / C, c = i - b * C;
+  __shared__ double sm[8][32][2];
+  const int cgroups = (C + 31) / 32;
+  const int b = blockIdx.x / cgroups, c0 = (blockIdx.x % cgroups) * 32;
+  const int cl = threadIdx.x & 31, kk = threadIdx.x >> 5;
+  const int c = c0 + cl;
   double s = 0.0, q = 0.0;
-  const float* p = partial + ((int64_t)b * n_partials * C + c) * 2;
-  for (int k = 0; k < n_partials; ++k) {
-    s += (double)p[(int64_t)k * C * 2];
-    q += (double)p[(int64_t)k * C * 2 + 1];
+  if (c < C) {
+    const float2* p = (const float2*)partial + ((int64_t)b * n_partials * C + c);
+    for (int k = kk; k < n_partials; k += 8) {
+      float2 v = p[(int64_t)k * C];
+      s += (double)v.x;
+      q += (double)v.y;
+    }
   }
-  double mean = s / count;
-  double var = q / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  double rstd = 1.0 / sqrt(var + (double)eps);
-  double a = rstd, sh = -mean * rstd;
-  if (style) {
-    double s0 = (double)style[(int64_t)b * 2 * C + c] + 1.0;
-    double s1 = (double)style[(int64_t)b * 2 * C + C + c];
-    a = rstd * s0;
-    sh = s1 - mean * a;
+  sm[kk][cl][0] = s;
+  sm[kk][cl][1] = q;
+  __syncthreads();
+  if (kk == 0 && c < C) {
+    for (int r = 1; r < 8; ++r) { s += sm[r][cl][0]; q += sm[r][cl][1]; }
+    double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    double rstd = 1.0 / sqrt(var + (double)eps);
+    double a = rstd, sh = -mean * rstd;
+    if (style) {
+      double s0 = (double)style[(int64_t)b * 2 * C + c] + 1.0;
+      double s1 = (double)style[(int64_t)b * 2 * C + C + c];
+      a = rstd * s0;
+      sh = s1 - mean * a;
+    }
+    if (post_bias) sh += (double)post_bias[c];  // FusedLeakyReLU bias that follows the norm (ConvLayer norm='in')
+    ss[((int64_t)b * C + c) * 2] = (float)a;
+    ss[((int64_t)b * C + c) * 2 + 1] = (float)sh;
   }
-  if (post_bias) sh += (double)post_bias[c];  // FusedLeakyReLU bias that follows the norm (ConvLayer norm='in')
-  ss[(int64_t)i * 2] = (float)a;
-  ss[(int64_t)i * 2 + 1] = (float)sh;
 }
 extern "C" int ppst_in_finalize(const void* partial, int n_partials, const void* style, const void* post_bias,
                                 void* scale_shift, int B, int C, double count, float eps, void* stream) {
   if (B < 0 || C <= 0 || n_partials <= 0 || count <= 0) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!partial || !scale_shift) return PPST_ENULL;
-  hipLaunchKernelGGL(in_finalize_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, as_stream(stream),
+  PPST_LAUNCH(in_finalize_kernel, dim3(B * cdiv(C, 32)), dim3(256), 0, as_stream(stream),
                      (const float*)partial, n_partials, (const float*)style, (const float*)post_bias, (float*)scale_shift, B, C,
                      count, eps);
   return PPST_LAUNCH_CHECK();
@@ -255,11 +268,11 @@ extern "C" int ppst_affine_act(const void* x, const void* scale_shift, const voi
              (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) % 16 == 0);
   int64_t total = (int64_t)B * hw * (vec ? C / 4 : C);
   if (vec)
-    hipLaunchKernelGGL(affine_act_kernel<true>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
+    PPST_LAUNCH(affine_act_kernel<true>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
                        (const float*)scale_shift, (const float*)res, (const float*)res_scale_shift, (float*)y, hw, C, x_ld,
                        res_ld, y_ld, act, (const float*)prelu, out_scale, total);
   else
-    hipLaunchKernelGGL(affine_act_kernel<false>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
+    PPST_LAUNCH(affine_act_kernel<false>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
                        (const float*)scale_shift, (const float*)res, (const float*)res_scale_shift, (float*)y, hw, C, x_ld,
                        res_ld, y_ld, act, (const float*)prelu, out_scale, total);
   return PPST_LAUNCH_CHECK();
@@ -288,11 +301,11 @@ extern "C" int ppst_gap_gmp(const void* x, const void* mask, void* out, void* ws
   if (B == 0) return PPST_OK;
   if (!x || !out || !ws) return PPST_ENULL;
   int nchunks = (int)cdiv64((int64_t)H * W, PIX_CHUNK);
-  hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
+  PPST_LAUNCH(chan_reduce_kernel<1>, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
                      (const float*)mask, (float*)ws, H, W, C, ld, 0, nchunks);
   int e = PPST_LAUNCH_CHECK();
   if (e) return e;
-  hipLaunchKernelGGL(gap_gmp_finalize_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, as_stream(stream),
+  PPST_LAUNCH(gap_gmp_finalize_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, as_stream(stream),
                      (const float*)ws, nchunks, (float*)out, B, C, (double)H * W);
   return PPST_LAUNCH_CHECK();
 }
@@ -323,7 +336,7 @@ extern "C" int ppst_avgpool(const void* x, void* y, int B, int H, int W, int C, 
   if (B == 0) return PPST_OK;
   if (!x || !y) return PPST_ENULL;
   int64_t total = (int64_t)B * (H / f) * (W / f) * (C / 4);
-  hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y,
+  PPST_LAUNCH(avgpool_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y,
                      H, W, C, x_ld, f, y_ld, total);
   return PPST_LAUNCH_CHECK();
 }
@@ -365,7 +378,7 @@ extern "C" int ppst_bilinear(const void* x, void* y, int B, int H, int W, int C,
   if (B == 0) return PPST_OK;
   if (!x || !y) return PPST_ENULL;
   int64_t total = (int64_t)B * OH * OW * (C / 4);
-  hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y,
+  PPST_LAUNCH(bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y,
                      H, W, C, x_ld, OH, OW, y_ld, total);
   return PPST_LAUNCH_CHECK();
 }
@@ -388,7 +401,7 @@ extern "C" int ppst_upsample_nearest2(const void* x, void* y, int B, int H, int 
   if (B == 0) return PPST_OK;
   if (!x || !y) return PPST_ENULL;
   int64_t total = (int64_t)B * 4 * H * W * (C / 4);
-  hipLaunchKernelGGL(upsample_nearest2_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float4*)x,
+  PPST_LAUNCH(upsample_nearest2_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float4*)x,
                      (float4*)y, H, W, C / 4, total);
   return PPST_LAUNCH_CHECK();
 }
@@ -411,7 +424,7 @@ extern "C" int ppst_maxpool2(const void* x, void* y, int B, int H, int W, int C,
   if (B == 0) return PPST_OK;
   if (!x || !y) return PPST_ENULL;
   int64_t total = (int64_t)B * (H / 2) * (W / 2) * C;
-  hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, H, W, C, total);
+  PPST_LAUNCH(maxpool2_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, H, W, C, total);
   return PPST_LAUNCH_CHECK();
 }
 
@@ -442,7 +455,7 @@ extern "C" int ppst_conv1x1_small_cin(const void* x, const void* w, const void* 
   if (npix == 0) return PPST_OK;
   if (!x || !w || !y) return PPST_ENULL;
   int64_t total = npix * (cout / 4);
-  hipLaunchKernelGGL(conv1x1_small_cin_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
+  PPST_LAUNCH(conv1x1_small_cin_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
                      (const float*)w, (const float*)bias, (float*)y, npix, cin, in_ld, cout, wscale, act, total);
   return PPST_LAUNCH_CHECK();
 }
@@ -479,7 +492,7 @@ extern "C" int ppst_conv1x1_small_cout(const void* x, const void* w, const void*
   if (npix < 0 || cin <= 0 || cin % 4 || cout <= 0 || cout > 4) return PPST_EINVAL;
   if (npix == 0) return PPST_OK;
   if (!x || !w || !y) return PPST_ENULL;
-  hipLaunchKernelGGL(conv1x1_small_cout_kernel, dim3(grid_for(npix * 32)), dim3(256), 0, as_stream(stream),
+  PPST_LAUNCH(conv1x1_small_cout_kernel, dim3(grid_for(npix * 32)), dim3(256), 0, as_stream(stream),
                      (const float*)x, (const float*)w, (const float*)bias, (float*)y, npix, cin, cout, wscale);
   return PPST_LAUNCH_CHECK();
 }
@@ -494,7 +507,7 @@ extern "C" int ppst_lerp(const void* a, const void* b, void* y, int64_t n, float
   if (n < 0) return PPST_EINVAL;
   if (n == 0) return PPST_OK;
   if (!a || !b || !y) return PPST_ENULL;
-  hipLaunchKernelGGL(lerp_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), (const float*)a, (const float*)b, (float*)y, n, r);
+  PPST_LAUNCH(lerp_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), (const float*)a, (const float*)b, (float*)y, n, r);
   return PPST_LAUNCH_CHECK();
 }
 
@@ -518,7 +531,7 @@ extern "C" int ppst_spatial_modulation(const void* x, const void* scale, const v
   if (B == 0) return PPST_OK;
   if (!x || !scale || !bias || !y) return PPST_ENULL;
   int64_t total = (int64_t)B * hw * (C / 4);
-  hipLaunchKernelGGL(spatial_mod_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
+  PPST_LAUNCH(spatial_mod_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
                      (const float*)scale, (const float*)bias, (float*)y, hw, C, total);
   return PPST_LAUNCH_CHECK();
 }
@@ -541,7 +554,7 @@ extern "C" int ppst_tensor2im_u8(const void* x, void* y, int B, int C, int H, in
   if (B == 0) return PPST_OK;
   if (!x || !y) return PPST_ENULL;
   int64_t P = (int64_t)H * W, total = (int64_t)B * P * C;
-  hipLaunchKernelGGL(tensor2im_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
+  PPST_LAUNCH(tensor2im_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
                      (unsigned char*)y, C, P, total);
   return PPST_LAUNCH_CHECK();
 }

@@ -56,10 +56,10 @@ extern "C" int ppst_fused_bias_act(const void* x, const void* b, const void* ref
   int64_t blocks = cdiv64(work, 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (vec)
-    hipLaunchKernelGGL(fused_bias_act_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+    PPST_LAUNCH(fused_bias_act_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
                        (const float*)x, (const float*)b, (const float*)ref, (float*)y, n, step_b, size_b, mode, alpha, scale);
   else
-    hipLaunchKernelGGL(fused_bias_act_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+    PPST_LAUNCH(fused_bias_act_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
                        (const float*)x, (const float*)b, (const float*)ref, (float*)y, n, step_b, size_b, mode, alpha, scale);
   return PPST_LAUNCH_CHECK();
 }

@@ -164,16 +164,16 @@ extern "C" int ppst_guided_filter(const void* guide_u8, const void* src_u8, void
   const unsigned char* s = (const unsigned char*)src_u8;
   auto blocks_for = [](int64_t total) { int64_t b = cdiv64(total, 256); return (unsigned)(b > 256 * 32 ? 256 * 32 : b); };
   int e;
-  hipLaunchKernelGGL(gf_h_kernel<true>, dim3(H, 21, B), dim3(256), 0, st, g, s, (const float*)nullptr, bufA, H, W, r, 21);
+  PPST_LAUNCH(gf_h_kernel<true>, dim3(H, 21, B), dim3(256), 0, st, g, s, (const float*)nullptr, bufA, H, W, r, 21);
   if ((e = PPST_LAUNCH_CHECK())) return e;
   int64_t t21 = (int64_t)B * 21 * P;
-  hipLaunchKernelGGL(gf_v_kernel, dim3(blocks_for(t21)), dim3(256), 0, st, (const float*)bufA, bufB, H, W, r, t21);
+  PPST_LAUNCH(gf_v_kernel, dim3(blocks_for(t21)), dim3(256), 0, st, (const float*)bufA, bufB, H, W, r, t21);
   if ((e = PPST_LAUNCH_CHECK())) return e;
-  hipLaunchKernelGGL(gf_solve_kernel, dim3(blocks_for(B * P)), dim3(256), 0, st, (const float*)bufB, bufA, P, eps, (int64_t)B * P);
+  PPST_LAUNCH(gf_solve_kernel, dim3(blocks_for(B * P)), dim3(256), 0, st, (const float*)bufB, bufA, P, eps, (int64_t)B * P);
   if ((e = PPST_LAUNCH_CHECK())) return e;
-  hipLaunchKernelGGL(gf_h_kernel<false>, dim3(H, 12, B), dim3(256), 0, st, g, s, (const float*)bufA, bufB, H, W, r, 12);
+  PPST_LAUNCH(gf_h_kernel<false>, dim3(H, 12, B), dim3(256), 0, st, g, s, (const float*)bufA, bufB, H, W, r, 12);
   if ((e = PPST_LAUNCH_CHECK())) return e;
-  hipLaunchKernelGGL(gf_v_final_kernel, dim3(blocks_for(B * P)), dim3(256), 0, st, (const float*)bufB, g, (float*)out,
+  PPST_LAUNCH(gf_v_final_kernel, dim3(blocks_for(B * P)), dim3(256), 0, st, (const float*)bufB, g, (float*)out,
                      (unsigned char*)out_u8, H, W, r, (int64_t)B * P);
   return PPST_LAUNCH_CHECK();
 }

@@ -66,7 +66,7 @@ extern "C" int ppst_linear(const void* x, const void* w, const void* bias, void*
   for (int b0 = 0; b0 < B; b0 += LIN_BMAX) {
     int nb = B - b0 < LIN_BMAX ? B - b0 : LIN_BMAX;
     dim3 grid(cdiv(N, 4));
-#define LAUNCH(BT) hipLaunchKernelGGL(linear_kernel<BT>, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)w, \
+#define LAUNCH(BT) PPST_LAUNCH(linear_kernel<BT>, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)w, \
                                       (const float*)bias, (float*)y, B, K, N, wscale, bscale, relu_in, act, b0)
     if (nb <= 1) LAUNCH(1);
     else if (nb <= 2) LAUNCH(2);
@@ -99,6 +99,6 @@ extern "C" int ppst_l2norm_rows(const void* x, void* y, int B, int K, float eps,
   if (B < 0 || K <= 0 || mode < 0 || mode > 1) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!x || !y) return PPST_ENULL;
-  hipLaunchKernelGGL(l2norm_rows_kernel, dim3(B), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, K, eps, mode);
+  PPST_LAUNCH(l2norm_rows_kernel, dim3(B), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, K, eps, mode);
   return PPST_LAUNCH_CHECK();
 }

@@ -170,9 +170,9 @@ static int launch_chan(const float* x, float* y, const UfParams& p, int down, bo
   int64_t blocks = cdiv64(nwork, 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
   dim3 g((unsigned)blocks), b(256);
-  if (s2d) hipLaunchKernelGGL((upfirdn2d_chan<KH, KW, 1, true>), g, b, 0, st, (const float4*)x, (float4*)y, p, nwork);
-  else if (down == 2) hipLaunchKernelGGL((upfirdn2d_chan<KH, KW, 2, false>), g, b, 0, st, (const float4*)x, (float4*)y, p, nwork);
-  else hipLaunchKernelGGL((upfirdn2d_chan<KH, KW, 1, false>), g, b, 0, st, (const float4*)x, (float4*)y, p, nwork);
+  if (s2d) PPST_LAUNCH((upfirdn2d_chan<KH, KW, 1, true>), g, b, 0, st, (const float4*)x, (float4*)y, p, nwork);
+  else if (down == 2) PPST_LAUNCH((upfirdn2d_chan<KH, KW, 2, false>), g, b, 0, st, (const float4*)x, (float4*)y, p, nwork);
+  else PPST_LAUNCH((upfirdn2d_chan<KH, KW, 1, false>), g, b, 0, st, (const float4*)x, (float4*)y, p, nwork);
   return PPST_LAUNCH_CHECK();
 }
 
@@ -180,7 +180,7 @@ template <int KH, int KW>
 static int launch_fast(const float* x, float* y, const UfParams& p, hipStream_t st) {
   if (p.minor == 1) {
     dim3 grid(cdiv(p.out_w, 64) * cdiv(p.out_h, 32), p.major);
-    hipLaunchKernelGGL((upfirdn2d_planes<KH, KW>), grid, dim3(256), 0, st, x, y, p);
+    PPST_LAUNCH((upfirdn2d_planes<KH, KW>), grid, dim3(256), 0, st, x, y, p);
   } else {
     return launch_chan<KH, KW>(x, y, p, 1, false, st);
   }
@@ -191,7 +191,7 @@ extern "C" int ppst_upfirdn2d(const void* x, const void* k, void* y, int major, 
                               int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
                               int pad_y0, int pad_y1, int dtype, void* stream) {
   if (dtype != PPST_F32) return PPST_EUNSUPPORTED;
-  if (!x || !k || !y) return PPST_ENULL;
+  if (major != 0 && (!x || !k || !y)) return PPST_ENULL;  // an empty batch has no storage
   if (major < 0 || in_h <= 0 || in_w <= 0 || minor <= 0 || kh <= 0 || kw <= 0 || kh > UF_MAXK || kw > UF_MAXK ||
       up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0)
     return PPST_EINVAL;
@@ -216,7 +216,7 @@ extern "C" int ppst_upfirdn2d(const void* x, const void* k, void* y, int major, 
   int64_t n = (int64_t)major * p.out_h * p.out_w * minor;
   int64_t blocks = cdiv64(n, 256);
   if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(upfirdn2d_generic, dim3((unsigned)blocks), dim3(256), 0, st, xf, yf, p, n);
+  PPST_LAUNCH(upfirdn2d_generic, dim3((unsigned)blocks), dim3(256), 0, st, xf, yf, p, n);
   return PPST_LAUNCH_CHECK();
 }
 

@@ -512,3 +512,17 @@ def prof_collect():
     ms, n, fl = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
     check(lib.ppst_prof_collect(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "ppst_prof_collect")
     return ms.value, n.value, fl.value
+
+
+def prof_detail():
+    """list of (ms, flop, (B, tile_h, tile_w, nsteps, cout, n_groups, halo, bn)) per bracketed conv launch."""
+    out = []
+    i = 0
+    while True:
+        ms, fl = ctypes.c_double(0), ctypes.c_double(0)
+        info = (ctypes.c_int * 8)()
+        if lib.ppst_prof_detail(i, ctypes.byref(ms), ctypes.byref(fl), info) != 0:
+            break
+        out.append((ms.value, fl.value, tuple(info)))
+        i += 1
+    return out

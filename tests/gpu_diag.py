@@ -317,7 +317,7 @@ def t_corr():
         report("gemm_nt f32 %dx%dx%d" % (M, N, K), ops.gemm_nt(g(A), g(Bm), 0.5), 0.5 * torch.matmul(A.double(), Bm.double().transpose(1, 2)), 2e-6)
     for (b, M, N, K) in [(2, 256, 480, 256), (1, 4096, 480, 4096), (1, 200, 192, 64), (1, 128, 32, 128)]:
         A = torch.randn(b, M, K); Bm = torch.randn(b, K, N)
-        report("gemm_nn f32 %dx%dx%d" % (M, N, K), ops.gemm_nn(g(A), g(Bm)), torch.matmul(A.double(), Bm.double()), 2e-6)
+        report("gemm_nn f32 %dx%dx%d" % (M, N, K), ops.gemm_nn(g(A), g(Bm)), torch.matmul(A.double(), Bm.double()), 2e-6 if K <= 256 else 1e-5)
     x = torch.randn(300, 4096) * 0.3
     report("softmax rows /0.01", ops.softmax_rows_(g(x).clone(), 0.01), F.softmax(x.double() / 0.01, -1), 2e-5)
     fa = torch.randn(1, 512, 64, 64); fb = torch.randn(1, 512, 64, 64)
@@ -346,7 +346,8 @@ def t_guided():
     print("guided_filter u8: max |diff| %d, frac != %.4f" % (d.max(), (d > 0).mean()), flush=True)
     RES.append(("guided filter u8 within 1 LSB", bool(d.max() <= 1 and (d > 0).mean() < 0.02)))
     reff = (torch.from_numpy(ref).permute(0, 3, 1, 2).float() / 255.0 - 0.5) * 2
-    report("guided_filter fp32 out (vs oracle)", out, reff, 1.0 / 255 + 1e-6)
+    # one uint8 step is 2/255 in [-1,1]; relative to refmax ~0.6
+    report("guided_filter fp32 out (vs oracle, 1 LSB)", out, reff, (2.0 / 255 + 1e-6) / reff.abs().max().item())
 
 
 # ----------------------------------------------------------------- nets ----
