@@ -139,11 +139,20 @@ typedef struct ppst_conv_args {
   int32_t tile_h, tile_w;        /* logical (pre-scatter) output extent tiled by 16x16 */
   int32_t halo;                  /* 0: every tap is (0,0) (1x1 conv); 1: taps in [-1,1]^2 */
   int32_t bn;                    /* N tile the weights were packed for (64 or 128) */
+  const void* in_scale_shift;    /* optional [B][in_c][2] (a, s): the input is read as in_act(a*x + s) --
+                                    "normalise on load" of the producer's InstanceNorm/StyleMod/activation; padding
+                                    positions stay 0 (they pad the normalised tensor).  NULL: input used as is */
+  const void* in_prelu;          /* [1] slope when in_act == PPST_ACT_PRELU */
+  int32_t in_c, in_act;          /* channel count of the in_scale_shift table; PPST_ACT_* */
+  int32_t flop_steps;            /* steps that carry real weights (profiling only; 0 = nsteps) */
+  int32_t tile_rows;             /* 16: 16x16-pixel tiles, 512- (bn 128) / 256-thread blocks, 1 block per CU;
+                                    8:  8x16-pixel tiles, 256- / 128-thread blocks, 2 blocks per CU -- with halo=1
+                                    every chunk of the step table must then span >= 2 steps */
 } ppst_conv_args;
 
 int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream);
-/* number of 16x16 tiles per image for (tile_h, tile_w) -- size of the stats buffer */
-int ppst_conv_tiles(int tile_h, int tile_w);
+/* number of tile_rows x 16 tiles per image for (tile_h, tile_w) -- size of the stats buffer */
+int ppst_conv_tiles(int tile_h, int tile_w, int tile_rows);
 
 /* FromRGB-type conv: 1x1, Cin <= 4 (HBM-bound), NHWC in (in_ld) -> NHWC out, fused
  * bias + leaky relu (ConvLayer(3, C, 1), stylegan2_layers.py:497-555). */
@@ -175,6 +184,13 @@ int ppst_affine_act(const void* x, const void* scale_shift, const void* res,
                     int B, int64_t hw, int C, int x_ld, int res_ld, int y_ld,
                     int act /* | 0x100: res joins before act */, const void* prelu,
                     float out_scale, void* stream);
+/* ppst_affine_act that also emits the instance-norm partials of its OUTPUT (the layout
+ * ppst_in_stats produces for (H, W); rep_pad as there), so the norm that follows needs no
+ * read pass of its own.  C % 4 == 0. */
+int ppst_affine_act_stats(const void* x, const void* scale_shift, const void* res,
+                          const void* res_scale_shift, void* y, void* partial,
+                          int B, int H, int W, int C, int x_ld, int res_ld, int y_ld,
+                          int act, const void* prelu, float out_scale, int rep_pad, void* stream);
 /* nearest x2 upsample NHWC (Upscale2d, stylegan2_layers.py:86-97) */
 int ppst_upsample_nearest2(const void* x, void* y, int B, int H, int W, int C, void* stream);
 

@@ -39,7 +39,8 @@ class ConvArgs(ctypes.Structure):
         ("nsteps", i32), ("n_groups", i32), ("pad_mode", i32),
         ("in_off_y", i32), ("in_off_x", i32), ("out_sy", i32), ("out_sx", i32),
         ("act", i32), ("precision", i32), ("res_ld", i32), ("tile_h", i32), ("tile_w", i32),
-        ("halo", i32), ("bn", i32),
+        ("halo", i32), ("bn", i32), ("in_scale_shift", vp), ("in_prelu", vp), ("in_c", i32), ("in_act", i32),
+        ("flop_steps", i32), ("tile_rows", i32),
     ]
 
 
@@ -53,12 +54,13 @@ _SIGS = {
     "ppst_conv_pack": (i32, [vp, i64, i64, i64, i64, f32, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp]),
     "ppst_upscale_weight": (i32, [vp, vp, i32, i32, f32, vp]),
     "ppst_conv2d_mfma": (i32, [ctypes.POINTER(ConvArgs), vp]),
-    "ppst_conv_tiles": (i32, [i32, i32]),
+    "ppst_conv_tiles": (i32, [i32, i32, i32]),
     "ppst_conv1x1_small_cin": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp]),
     "ppst_conv1x1_small_cout": (i32, [vp, vp, vp, vp, i64, i32, i32, f32, vp]),
     "ppst_in_stats": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(i32), vp]),
     "ppst_in_finalize": (i32, [vp, i32, vp, vp, vp, i32, i32, f64, f32, vp]),
     "ppst_affine_act": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, f32, vp]),
+    "ppst_affine_act_stats": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, f32, i32, vp]),
     "ppst_upsample_nearest2": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ppst_gap_gmp_ws": (i64, [i32, i64, i32]),
     "ppst_gap_gmp": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

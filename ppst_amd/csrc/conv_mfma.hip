@@ -39,6 +39,9 @@ struct ConvKArgs {
   int B, in_h, in_w, in_ld, out_h, out_w, out_ld, cout;
   int nsteps, n_groups, pad_mode, in_off_y, in_off_x, out_sy, out_sx, act, res_ld, tile_h, tile_w;
   int tiles_y, tiles_x, n_tiles;
+  const float* in_ss;     // optional [B][in_c][2] (scale, shift) applied to the input while staging
+  const float* in_prelu;  // slope for in_act == PRELU
+  int in_c, in_act;
   unsigned long long* dbg;  // stamp build: [block][wave][8] cycle sums (else unused)
 };
 
@@ -65,7 +68,7 @@ __device__ __forceinline__ int pad_index(int i, int n, int mode) {
   return i;
 }
 
-template <int WM, int WN, int HALO, bool X3>
+template <int WM, int WN, int HALO, bool X3, bool INSS>
 __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TH = 4 * WM, TW = 16;
@@ -82,7 +85,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
   constexpr int B_IT = (B_ITEMS + NT - 1) / NT;
   static_assert(B_ITEMS % NT == 0, "B blob must split evenly");
 
-  constexpr int NA = 3;  // A ring slots (see the hazard note at the main loop)
+  // A ring slots (hazard note at the main loop).  The 8-row tile variants keep 2 slots so
+  // that two blocks fit one CU (2 x 80 KB); they require every chunk to span >= 2 steps
+  // (the host pads single-tap chunks with a zero-weight step).
+  constexpr int NA = (WM == 2 && HALO == 1) ? 2 : 3;
   constexpr int EPI_TILE = 64 * 36;                              // floats per wave: 64 px x (32 ch + 4 pad)
   constexpr int EPI_BYTES = (NT / 64) * EPI_TILE * 4 + WM * BN * 2 * 4;  // transposition tiles + stats scratch
   constexpr int MAIN_BYTES = NA * ABUF + 2 * BBUF;
@@ -118,35 +124,60 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
   const unsigned char* wblob = (const unsigned char*)a.wpack + ((int64_t)nidx * a.nsteps) * BBUF;
   const float* xb = a.x + (int64_t)b * a.in_h * a.in_w * a.in_ld;
 
-  static_assert(B_IT == 1 || B_IT == 2, "B staging assumes 1 or 2 16-B items per thread");
+  static_assert(B_IT >= 1 && B_IT <= 4, "B staging assumes 1..4 16-B items per thread");
   constexpr int A_WCH = (HP + 7) / 8;                      // wave-chunks of 8 pixels x 8 float4
   constexpr int A_IT2 = (A_WCH * 64 + NT - 1) / NT;
   float4 ra[A_IT2];
-  uint4 rb0, rb1;  // (named, not an array: hipcc promoted a 2-element array to LDS)
+  uint4 rb0, rb1, rb2, rb3;  // (named, not an array: hipcc promoted a small array to LDS)
 
   // A staging.  One wave-instruction covers 8 pixels x 128 B (fully coalesced global read);
   // inside it lane l -> plane g = l>>4, pixel (l>>1)&7, half h = l&1, so the 16 lanes of a
   // ds_write_b64 group write 128 contiguous bytes of ONE plane (conflict-free; the planes
   // alias each other's banks because their stride is a multiple of 256 B).
+  // per-item input pixel offsets (elements, -1 = zero padding) are fixed for the whole tile:
+  // compute them once, the per-chunk load is then one add + one 16-B load per item
+  int aoff[A_IT2];
+#pragma unroll
+  for (int it = 0; it < A_IT2; ++it) {
+    int i = tid + it * NT;
+    int l = i & 63;
+    int pix = (i >> 6) * 8 + ((l >> 1) & 7), q4 = (l >> 4) * 2 + (l & 1);
+    int o = -1;
+    if (pix < HP) {
+      int hy = pix / HW, hx = pix - hy * HW;
+      int iy = ty0 + hy - HALO + a.in_off_y, ix = tx0 + hx - HALO + a.in_off_x;
+      bool inb = iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w;
+      if (inb || a.pad_mode != PPST_PAD_ZERO) {
+        iy = pad_index(iy, a.in_h, a.pad_mode);
+        ix = pad_index(ix, a.in_w, a.pad_mode);
+        o = (iy * a.in_w + ix) * a.in_ld + q4 * 4;  // < 2^31: one image is at most 512*512*2048 elements
+      }
+    }
+    aoff[it] = o;
+  }
+  // normalise-on-load: the instance-norm / StyleMod affine (and activation) of the producer
+  // layer is applied to the tile while it is staged, so that layer needs no apply pass.
+  // A thread's 4 channels are the same for all its items: (a, s) x 4 loaded once per chunk.
+  float4 ras0 = make_float4(1.f, 0.f, 1.f, 0.f), ras1 = ras0;
+  const int q4lane = ((tid & 63) >> 4) * 2 + (tid & 1);
+  const float in_slope = (INSS && a.in_act == PPST_ACT_PRELU && a.in_prelu) ? a.in_prelu[0] : 0.f;
   auto a_load = [&](int chan_off) {
 #pragma unroll
     for (int it = 0; it < A_IT2; ++it) {
-      int i = tid + it * NT;
-      int l = i & 63;
-      int pix = (i >> 6) * 8 + ((l >> 1) & 7), q4 = (l >> 4) * 2 + (l & 1);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pix < HP) {
-        int hy = pix / HW, hx = pix - hy * HW;
-        int iy = ty0 + hy - HALO + a.in_off_y, ix = tx0 + hx - HALO + a.in_off_x;
-        bool inb = iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w;
-        if (inb || a.pad_mode != PPST_PAD_ZERO) {
-          iy = pad_index(iy, a.in_h, a.pad_mode);
-          ix = pad_index(ix, a.in_w, a.pad_mode);
-          v = *(const float4*)(xb + ((int64_t)iy * a.in_w + ix) * a.in_ld + chan_off + q4 * 4);
-        }
-      }
+      if (aoff[it] >= 0) v = *(const float4*)(xb + aoff[it] + chan_off);
       ra[it] = v;
     }
+    if (INSS) {
+      const float4* p = (const float4*)(a.in_ss + ((int64_t)b * a.in_c + chan_off + q4lane * 4) * 2);
+      ras0 = p[0];
+      ras1 = p[1];
+    }
+  };
+  auto in_act = [&](float t) -> float {
+    if (a.in_act == PPST_ACT_LRELU) return (t > 0.f ? t : t * 0.2f) * 1.41421356237309515f;
+    if (a.in_act == PPST_ACT_PRELU) return t >= 0.f ? t : t * in_slope;
+    return t;
   };
   auto a_store = [&](int slot) {
     unsigned char* base = smA + slot * ABUF;
@@ -157,6 +188,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
       int pix = (i >> 6) * 8 + ((l >> 1) & 7);
       if (pix < HP) {
         float4 v = ra[it];
+        if (INSS && aoff[it] >= 0) {  // padding zeros stay zeros (they pad the normalised tensor)
+          v.x = in_act(ras0.x * v.x + ras0.y); v.y = in_act(ras0.z * v.y + ras0.w);
+          v.z = in_act(ras1.x * v.z + ras1.y); v.w = in_act(ras1.z * v.w + ras1.w);
+        }
         unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
         split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
         int off = (l >> 4) * PLANE + pix * 16 + (l & 1) * 8;
@@ -173,11 +208,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
     const uint4* src = (const uint4*)(wblob + (int64_t)s * BBUF);
     rb0 = src[tid];
     if (B_IT > 1) rb1 = src[tid + NT];
+    if (B_IT > 2) rb2 = src[tid + 2 * NT];
+    if (B_IT > 3) rb3 = src[tid + 3 * NT];
   };
   auto b_store = [&](int buf) {
     uint4* dst = (uint4*)(smB + buf * BBUF);
     dst[tid] = rb0;
     if (B_IT > 1) dst[tid + NT] = rb1;
+    if (B_IT > 2) dst[tid + 2 * NT] = rb2;
+    if (B_IT > 3) dst[tid + 3 * NT] = rb3;
   };
   // fragment reads
   auto ld_b = [&](bf16x8 (&h)[4], bf16x8 (&lo)[4], int slot) {
@@ -256,6 +295,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
   ld_b(b0h, b0l, 0);
   ah = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, 0));
   if (X3) al = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, 0) + 4 * PLANE);
+  // drain the prologue's LDS reads so both edges into the loop header carry an empty LDS
+  // scoreboard (otherwise hipcc makes the first MFMAs of every step wait for the prefetch
+  // reads issued just before them)
+  __builtin_amdgcn_s_waitcnt(0xC07F);
 
 #ifdef PPST_CONV_STAMP
 #define ST_A STAMP(t0_)
@@ -457,7 +500,7 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict_
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = 0.f;
-      if (n < cout) v = w[n * sn + (int64_t)(c0 + j) * sc + ky * sy + kx * sx] * scale;
+      if (n < cout && src_c[gs] >= 0) v = w[n * sn + (int64_t)(c0 + j) * sc + ky * sy + kx * sx] * scale;  // src_c < 0: zero-weight pad step
       split_bf16(v, hi[j], lo[j]);
     }
     int64_t blob = (((int64_t)group * n_tiles + ntile) * nsteps + s) * ((int64_t)npl * bn * 8);
@@ -552,11 +595,12 @@ extern "C" int ppst_prof_detail(int idx, double* ms, double* flop, int32_t* info
   return PPST_OK;
 }
 
-extern "C" int ppst_conv_tiles(int tile_h, int tile_w) { return cdiv(tile_h, 16) * cdiv(tile_w, 16); }
+extern "C" int ppst_conv_tiles(int tile_h, int tile_w, int tile_rows) { return cdiv(tile_h, tile_rows) * cdiv(tile_w, 16); }
 
 template <int WM, int WN, int HALO, bool X3>
 static void launch_conv(const ConvKArgs& k, int blocks, hipStream_t st) {
-  PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
+  if (k.in_ss) PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, true>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
+  else PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, false>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
 }
 
 extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
@@ -564,7 +608,8 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   if (a->B < 0 || a->in_h <= 0 || a->in_w <= 0 || a->in_ld <= 0 || a->in_ld % 4 || a->out_h <= 0 || a->out_w <= 0 ||
       a->out_ld < a->cout || a->cout <= 0 || a->cout % 4 || a->out_ld % 4 || (a->residual && a->res_ld % 4) || a->nsteps <= 0 || (a->n_groups != 1 && a->n_groups != 4) || a->pad_mode < 0 ||
       a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 || a->precision < 0 ||
-      a->precision > 1 || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128) || (a->residual && a->res_ld < a->cout))
+      a->precision > 1 || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128) || (a->residual && a->res_ld < a->cout) ||
+      (a->tile_rows != 16) || (a->in_scale_shift && a->in_c <= 0))
     return PPST_EINVAL;
   // the scattered output must stay inside the output tensor
   if ((a->tile_h - 1) * a->out_sy + (a->n_groups > 1 ? 1 : 0) >= a->out_h ||
@@ -581,8 +626,10 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   k.out_ld = a->out_ld; k.cout = a->cout; k.nsteps = a->nsteps; k.n_groups = a->n_groups; k.pad_mode = a->pad_mode;
   k.in_off_y = a->in_off_y; k.in_off_x = a->in_off_x; k.out_sy = a->out_sy; k.out_sx = a->out_sx; k.act = a->act;
   k.res_ld = a->res_ld; k.tile_h = a->tile_h; k.tile_w = a->tile_w;
-  k.tiles_y = cdiv(a->tile_h, 16); k.tiles_x = cdiv(a->tile_w, 16);
+  k.tiles_y = cdiv(a->tile_h, a->tile_rows); k.tiles_x = cdiv(a->tile_w, 16);
   k.n_tiles = cdiv(a->cout, a->bn);
+  k.in_ss = (const float*)a->in_scale_shift; k.in_prelu = (const float*)a->in_prelu;
+  k.in_c = a->in_c; k.in_act = a->in_act;
   k.dbg = nullptr;
 #ifdef PPST_CONV_STAMP
   k.dbg = (unsigned long long*)a->prelu;  // stamp build: the (unused) prelu slot carries the debug buffer
@@ -599,19 +646,21 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       ++g_ev_made;
     }
     slot = g_ev_used++;
-    g_flop[slot] = 2.0 * 32.0 * a->nsteps * (double)a->n_groups * a->cout * (double)a->B * a->tile_h * a->tile_w;
+    g_flop[slot] = 2.0 * 32.0 * (a->flop_steps > 0 ? a->flop_steps : a->nsteps) * (double)a->n_groups * a->cout * (double)a->B * a->tile_h * a->tile_w;
     int inf[8] = {a->B, a->tile_h, a->tile_w, a->nsteps, a->cout, a->n_groups, a->halo, a->bn};
     for (int i = 0; i < 8; ++i) g_info[slot][i] = inf[i];
     (void)hipEventRecord(g_ev[slot][0], st);
   }
   const bool x3 = a->precision == 0;
-  if (a->bn == 128) {
-    if (a->halo) { if (x3) launch_conv<4, 2, 1, true>(k, blocks, st); else launch_conv<4, 2, 1, false>(k, blocks, st); }
-    else         { if (x3) launch_conv<4, 2, 0, true>(k, blocks, st); else launch_conv<4, 2, 0, false>(k, blocks, st); }
-  } else {
-    if (a->halo) { if (x3) launch_conv<4, 1, 1, true>(k, blocks, st); else launch_conv<4, 1, 1, false>(k, blocks, st); }
-    else         { if (x3) launch_conv<4, 1, 0, true>(k, blocks, st); else launch_conv<4, 1, 0, false>(k, blocks, st); }
-  }
+#define DISPATCH(WM_, WN_)                                                                                         \
+  do {                                                                                                             \
+    if (a->halo) { if (x3) launch_conv<WM_, WN_, 1, true>(k, blocks, st); else launch_conv<WM_, WN_, 1, false>(k, blocks, st); } \
+    else         { if (x3) launch_conv<WM_, WN_, 0, true>(k, blocks, st); else launch_conv<WM_, WN_, 0, false>(k, blocks, st); } \
+  } while (0)
+  // (8-row tiles -- two 80-KB blocks per CU -- were measured 35 % slower than one 16-row block
+  //  per CU on MI355X and are not instantiated; tile_rows == 8 is rejected above.)
+  if (a->bn == 128) DISPATCH(4, 2); else DISPATCH(4, 1);
+#undef DISPATCH
   int e = PPST_LAUNCH_CHECK();
   if (slot >= 0) (void)hipEventRecord(g_ev[slot][1], st);
   return e;

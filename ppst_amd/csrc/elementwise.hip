@@ -12,6 +12,8 @@ static inline unsigned grid_for(int64_t work, int threads = 256) {
   return (unsigned)b;
 }
 
+__device__ __forceinline__ float act_apply(float t, int act, float slope);
+
 // ------------------------------------------------------------------ layout --
 // x[b][c][p] <-> y[b][p][c]; 32(c) x 64(p) tiles through LDS (pad 1: conflict-free)
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int64_t P) {
@@ -145,6 +147,103 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
   }
 }
 
+// 16-B-per-lane version of the reduction (C % 4 == 0): lane = 4 channels, the block's other
+// threads walk different pixel rows; optionally (APPLY) the elements are first transformed
+// like ppst_affine_act and stored, so a producer's apply pass also yields the statistics of
+// its output (no separate read pass for the instance norm that follows).
+struct ApplyArgs {
+  const float* ss; const float* res; const float* rss; float* y; const float* prelu;
+  int res_ld, y_ld, actf; float out_scale;
+};
+template <int MODE, bool APPLY>
+__global__ __launch_bounds__(256) void chan_reduce4_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                           float* __restrict__ partial, int H, int W, int C, int ld,
+                                                           int rep_pad, int nchunks, ApplyArgs ap) {
+  __shared__ float4 s0[256], s1[256];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int64_t P = (int64_t)H * W;
+  const int64_t pbeg = (int64_t)chunk * PIX_CHUNK;
+  const int64_t pend = (pbeg + PIX_CHUNK < P) ? pbeg + PIX_CHUNK : P;
+  const int c4n = C >> 2;
+  int lanes = 1;
+  while (lanes < c4n && lanes < 256) lanes <<= 1;
+  const int rows = 256 / lanes;
+  const int cl = threadIdx.x % lanes, pr = threadIdx.x / lanes;
+  const float* mb = mask ? mask + (int64_t)b * P : nullptr;
+  const int act = ap.actf & 0xff;
+  const bool res_first = (ap.actf >> 8) & 1;
+  const float slope = (APPLY && act == PPST_ACT_PRELU && ap.prelu) ? ap.prelu[0] : 0.f;
+  for (int cbase = 0; cbase < c4n; cbase += lanes) {
+    const int c = (cbase + cl) * 4;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a1 = (MODE == 1) ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : a0;
+    if (c < C) {
+      float4 sa = make_float4(1.f, 1.f, 1.f, 1.f), sb = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 ra = sa, rb = sb;
+      if (APPLY && ap.ss) {
+        const float4* q = (const float4*)(ap.ss + ((int64_t)b * C + c) * 2);
+        float4 q0 = q[0], q1 = q[1];
+        sa = make_float4(q0.x, q0.z, q1.x, q1.z); sb = make_float4(q0.y, q0.w, q1.y, q1.w);
+      }
+      if (APPLY && ap.res && ap.rss) {
+        const float4* q = (const float4*)(ap.rss + ((int64_t)b * C + c) * 2);
+        float4 q0 = q[0], q1 = q[1];
+        ra = make_float4(q0.x, q0.z, q1.x, q1.z); rb = make_float4(q0.y, q0.w, q1.y, q1.w);
+      }
+      for (int64_t p = pbeg + pr; p < pend; p += rows) {
+        const int64_t bp = (int64_t)b * P + p;
+        float4 v = *(const float4*)(x + bp * ld + c);
+        if (APPLY) {
+          float t[4] = {sa.x * v.x + sb.x, sa.y * v.y + sb.y, sa.z * v.z + sb.z, sa.w * v.w + sb.w};
+          float r[4] = {0.f, 0.f, 0.f, 0.f};
+          if (ap.res) {
+            float4 rv = *(const float4*)(ap.res + bp * ap.res_ld + c);
+            r[0] = ra.x * rv.x + rb.x; r[1] = ra.y * rv.y + rb.y; r[2] = ra.z * rv.z + rb.z; r[3] = ra.w * rv.w + rb.w;
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float tt = t[i];
+            if (res_first) tt += r[i];
+            tt = act_apply(tt, act, slope);
+            if (!res_first) tt += r[i];
+            t[i] = tt * ap.out_scale;
+          }
+          v = make_float4(t[0], t[1], t[2], t[3]);
+          *(float4*)(ap.y + bp * ap.y_ld + c) = v;
+        }
+        if (MODE == 0) {
+          float w = 1.f;
+          if (rep_pad) {
+            int py = (int)(p / W), px = (int)(p - (int64_t)py * W);
+            w = (float)((1 + (py == 0) + (py == H - 1)) * (1 + (px == 0) + (px == W - 1)));
+          }
+          a0.x += w * v.x; a0.y += w * v.y; a0.z += w * v.z; a0.w += w * v.w;
+          a1.x += w * v.x * v.x; a1.y += w * v.y * v.y; a1.z += w * v.z * v.z; a1.w += w * v.w * v.w;
+        } else {
+          if (mb) { float m = mb[p]; v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
+          a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+          a1.x = fmaxf(a1.x, v.x); a1.y = fmaxf(a1.y, v.y); a1.z = fmaxf(a1.z, v.z); a1.w = fmaxf(a1.w, v.w);
+        }
+      }
+    }
+    s0[threadIdx.x] = a0;
+    s1[threadIdx.x] = a1;
+    __syncthreads();
+    if (pr == 0 && c < C) {
+      for (int r = 1; r < rows; ++r) {
+        float4 u = s0[r * lanes + cl], w = s1[r * lanes + cl];
+        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+        if (MODE == 1) { a1.x = fmaxf(a1.x, w.x); a1.y = fmaxf(a1.y, w.y); a1.z = fmaxf(a1.z, w.z); a1.w = fmaxf(a1.w, w.w); }
+        else { a1.x += w.x; a1.y += w.y; a1.z += w.z; a1.w += w.w; }
+      }
+      float4* o = (float4*)(partial + (((int64_t)b * nchunks + chunk) * C + c) * 2);
+      o[0] = make_float4(a0.x, a1.x, a0.y, a1.y);
+      o[1] = make_float4(a0.z, a1.z, a0.w, a1.w);
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" int ppst_in_stats(const void* x, void* partial, int B, int H, int W, int C, int ld, int rep_pad,
                              int* n_partials, void* stream) {
   if (B < 0 || H <= 0 || W <= 0 || C <= 0 || ld < C) return PPST_EINVAL;
@@ -153,8 +252,14 @@ extern "C" int ppst_in_stats(const void* x, void* partial, int B, int H, int W, 
   if (!x && !partial) return PPST_OK;  // size query
   if (B == 0) return PPST_OK;
   if (!x || !partial) return PPST_ENULL;
-  PPST_LAUNCH(chan_reduce_kernel<0>, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
-                     (const float*)nullptr, (float*)partial, H, W, C, ld, rep_pad, nchunks);
+  if (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0) {
+    ApplyArgs ap = {};
+    PPST_LAUNCH((chan_reduce4_kernel<0, false>), dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
+                (const float*)nullptr, (float*)partial, H, W, C, ld, rep_pad, nchunks, ap);
+  } else {
+    PPST_LAUNCH(chan_reduce_kernel<0>, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
+                (const float*)nullptr, (float*)partial, H, W, C, ld, rep_pad, nchunks);
+  }
   return PPST_LAUNCH_CHECK();
 }
 
@@ -278,6 +383,25 @@ extern "C" int ppst_affine_act(const void* x, const void* scale_shift, const voi
   return PPST_LAUNCH_CHECK();
 }
 
+// ppst_affine_act that also emits the instance-norm partials of its OUTPUT
+// (partial [B][n_partials][C][2], n_partials as ppst_in_stats reports for (H, W)).
+extern "C" int ppst_affine_act_stats(const void* x, const void* scale_shift, const void* res, const void* res_scale_shift,
+                                     void* y, void* partial, int B, int H, int W, int C, int x_ld, int res_ld, int y_ld,
+                                     int act, const void* prelu, float out_scale, int rep_pad, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || x_ld % 4 || y_ld % 4 || x_ld < C || y_ld < C ||
+      (res && (res_ld < C || res_ld % 4)))
+    return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !y || !partial) return PPST_ENULL;
+  int nchunks = (int)cdiv64((int64_t)H * W, PIX_CHUNK);
+  ApplyArgs ap;
+  ap.ss = (const float*)scale_shift; ap.res = (const float*)res; ap.rss = (const float*)res_scale_shift; ap.y = (float*)y;
+  ap.prelu = (const float*)prelu; ap.res_ld = res_ld; ap.y_ld = y_ld; ap.actf = act; ap.out_scale = out_scale;
+  PPST_LAUNCH((chan_reduce4_kernel<0, true>), dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
+              (const float*)nullptr, (float*)partial, H, W, C, x_ld, rep_pad, nchunks, ap);
+  return PPST_LAUNCH_CHECK();
+}
+
 // ---------------------------------------------------------------- GAP/GMP --
 __global__ __launch_bounds__(256) void gap_gmp_finalize_kernel(const float* __restrict__ partial, int n_partials,
                                                                float* __restrict__ out, int B, int C, double count) {
@@ -301,8 +425,14 @@ extern "C" int ppst_gap_gmp(const void* x, const void* mask, void* out, void* ws
   if (B == 0) return PPST_OK;
   if (!x || !out || !ws) return PPST_ENULL;
   int nchunks = (int)cdiv64((int64_t)H * W, PIX_CHUNK);
-  PPST_LAUNCH(chan_reduce_kernel<1>, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
-                     (const float*)mask, (float*)ws, H, W, C, ld, 0, nchunks);
+  if (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0) {
+    ApplyArgs ap = {};
+    PPST_LAUNCH((chan_reduce4_kernel<1, false>), dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
+                (const float*)mask, (float*)ws, H, W, C, ld, 0, nchunks, ap);
+  } else {
+    PPST_LAUNCH(chan_reduce_kernel<1>, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
+                (const float*)mask, (float*)ws, H, W, C, ld, 0, nchunks);
+  }
   int e = PPST_LAUNCH_CHECK();
   if (e) return e;
   PPST_LAUNCH(gap_gmp_finalize_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, as_stream(stream),

@@ -39,7 +39,11 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
             return b, float(ts[3].item())
         return self.cached(("sc", p), ts, build)
 
-    def styled_conv(self, x, p, style, key, noise, upsample=False, res=None, out_scale=1.0):
+    def styled_conv(self, x, p, style, key, noise, upsample=False, res=None, out_scale=1.0, in_ss=None, defer=False,
+                    out_stats=None):
+        """in_ss: (scale, shift) of the producer StyledConv, applied while this conv stages its
+        input ("normalise on load").  defer=True returns (raw conv output, its scale/shift)
+        instead of running the apply pass."""
         B, H, W, cin = x.shape
         bias, nw = self._styled_consts(p)
         kind = "conv"
@@ -47,37 +51,44 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
             if min(H, W) * 2 >= 128:
                 kind = "convT"
             else:  # the <128 px branch: nearest x2 + 3x3 conv (stylegan2_layers.py:322-323)
+                assert in_ss is None
                 x = ops.upsample_nearest2(x)
         nz = None
         if nw != 0.0:
             if noise is None:
                 raise RuntimeError("noise weight of %s is non-zero: pass noise tensors (or noise='random')" % p)
             nz = noise[key].contiguous()
-        y, st = self.plan(p + "conv.weight", kind)(x, bias=bias, noise=nz, noise_weight=nw, act=ops.ACT_LRELU, stats=True)
+        y, st = self.plan(p + "conv.weight", kind)(x, bias=bias, noise=nz, noise_weight=nw, act=ops.ACT_LRELU, stats=True,
+                                                   in_ss=in_ss)
         wl = self.p(p + "epi1.style_mod.lin.weight")
         s = ops.linear(style, wl, self.p(p + "epi1.style_mod.lin.bias"), wscale=wl.shape[1] ** -0.5)
         ss = ops.in_finalize(st, y.shape[1] * y.shape[2], style=s)
+        if defer:
+            return y, ss
+        if out_stats is not None:  # 'rep' | 'plain': also emit the IN partials of the block output (feature heads)
+            return ops.affine_act_stats(y, ss, res=res, out_scale=out_scale, rep_pad=(out_stats == "rep"))
         return ops.affine_act(y, ss, res=res, out_scale=out_scale)
 
     # -- correspondence feature heads (generator.py:174-238) ------------------
-    def _feat_head(self, x, p, k, out):
+    def _feat_head(self, x, p, k, out, st=None):
         B, H, W, C = x.shape
         pad = ops.PAD_REPLICATE
         # InstanceNorm runs on the ReplicationPad2d(1)-padded tensor for the 3x3 heads
-        st = ops.in_stats(x, rep_pad=(k == 3))
+        if st is None:
+            st = ops.in_stats(x, rep_pad=(k == 3))
         cnt = (H + 2) * (W + 2) if k == 3 else H * W
-        xn = ops.affine_act(x, ops.in_finalize(st, cnt))
-        y, st = self.plan(p + "2.weight")(xn, bias=self.p(p + "2.bias"), stats=True, pad_mode=pad)
-        y = ops.affine_act(y, ops.in_finalize(st, H * W), act=ops.ACT_PRELU, prelu=self.p(p + "4.weight"))
-        y, st = self.plan(p + "6.weight")(y, bias=self.p(p + "6.bias"), stats=True, pad_mode=pad)
+        # both inner norms (+PReLU) are applied by the consuming conv while it stages its input
+        y, st = self.plan(p + "2.weight")(x, bias=self.p(p + "2.bias"), stats=True, pad_mode=pad, in_ss=ops.in_finalize(st, cnt))
+        y, st = self.plan(p + "6.weight")(y, bias=self.p(p + "6.bias"), stats=True, pad_mode=pad,
+                                          in_ss=ops.in_finalize(st, H * W), in_act=ops.ACT_PRELU, in_prelu=self.p(p + "4.weight"))
         return ops.affine_act(y, ops.in_finalize(st, H * W), act=ops.ACT_PRELU, prelu=self.p(p + "8.weight"), out=out)
 
     def _residual_block(self, x, p):
         B, H, W, C = x.shape
         a = self.p(p + "prelu.weight")
         y, st = self.plan(p + "conv1.weight")(x, bias=self.p(p + "conv1.bias"), stats=True, pad_mode=ops.PAD_REPLICATE)
-        y = ops.affine_act(y, ops.in_finalize(st, H * W), act=ops.ACT_PRELU, prelu=a)
-        y, st = self.plan(p + "conv2.weight")(y, bias=self.p(p + "conv2.bias"), stats=True, pad_mode=ops.PAD_REPLICATE)
+        y, st = self.plan(p + "conv2.weight")(y, bias=self.p(p + "conv2.bias"), stats=True, pad_mode=ops.PAD_REPLICATE,
+                                              in_ss=ops.in_finalize(st, H * W), in_act=ops.ACT_PRELU, in_prelu=a)
         return ops.affine_act(y, ops.in_finalize(st, H * W), res=x, res_before_act=True, act=ops.ACT_PRELU, prelu=a)
 
     def make_noise(self, B, S, device):
@@ -107,14 +118,18 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
         for i, (ci, co) in enumerate(HEAD_CH):
             q = "HeadResnetBlock%d." % i
             skip = x if ci == co else self.plan(q + "skip.Conv.weight", scale=1.0 / math.sqrt(ci))(x)
-            r = self.styled_conv(x, q + "conv1.", g, "HeadResnetBlock%d.conv1" % i, noise)
-            x = self.styled_conv(r, q + "conv2.", g, "HeadResnetBlock%d.conv2" % i, noise, res=skip, out_scale=INV_SQRT2)
+            r, rss = self.styled_conv(x, q + "conv1.", g, "HeadResnetBlock%d.conv1" % i, noise, defer=True)
+            want = "rep" if (extract_features and i == len(HEAD_CH) - 1) else None
+            x = self.styled_conv(r, q + "conv2.", g, "HeadResnetBlock%d.conv2" % i, noise, res=skip, out_scale=INV_SQRT2, in_ss=rss,
+                                 out_stats=want)
+            if want:
+                x, xst = x
         feat = feat1 = None
         if extract_features:
             h, w = x.shape[1], x.shape[2]
             feat = torch.empty((B, h, w, 256), device=x.device, dtype=torch.float32)
             feat1 = torch.empty((B, 256, 256, 256), device=x.device, dtype=torch.float32)
-            f = self._feat_head(x, "layer32.", 3, out=feat[..., 0:64])
+            f = self._feat_head(x, "layer32.", 3, out=feat[..., 0:64], st=xst)
             ops.bilinear(f, 256, 256, out=feat1[..., 0:64])
         for j, (key, ci, co) in enumerate(UP):
             q = "UpsamplingResBlock%d." % key
@@ -124,10 +139,13 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
             else:
                 skip = self.plan(q + "skip.Conv.weight", scale=1.0 / math.sqrt(ci))(x, bias=self.p(q + "skip.Act.bias"), act=ops.ACT_LRELU)
             skip = ops.bilinear(skip, 2 * x.shape[1], 2 * x.shape[2])
-            r = self.styled_conv(x, q + "conv1.", g, "UpsamplingResBlock%d.conv1" % key, noise, upsample=True)
-            x = self.styled_conv(r, q + "conv2.", g, "UpsamplingResBlock%d.conv2" % key, noise, res=skip, out_scale=INV_SQRT2)
+            r, rss = self.styled_conv(x, q + "conv1.", g, "UpsamplingResBlock%d.conv1" % key, noise, upsample=True, defer=True)
+            want = ("rep" if j < 2 else "plain") if extract_features else None
+            x = self.styled_conv(r, q + "conv2.", g, "UpsamplingResBlock%d.conv2" % key, noise, res=skip, out_scale=INV_SQRT2, in_ss=rss,
+                                 out_stats=want)
             if extract_features:
-                f = self._feat_head(x, "layer%d." % (2 ** (j + 6)), 3 if j < 2 else 1, out=None)
+                x, xst = x
+                f = self._feat_head(x, "layer%d." % (2 ** (j + 6)), 3 if j < 2 else 1, out=None, st=xst)
                 c0 = 64 * (j + 1)
                 ops.avgpool(f, f.shape[1] // h, out=feat[..., c0:c0 + 64])
                 ops.bilinear(f, 256, 256, out=feat1[..., c0:c0 + 64])

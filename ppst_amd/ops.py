@@ -18,6 +18,7 @@ ACT_NONE, ACT_LRELU, ACT_PRELU = 0, 1, 2
 RES_BEFORE_ACT = 1 << 8
 
 PRECISION = {"value": 0}  # 0 = bf16x3 (fp32-class), 1 = single-pass bf16
+TILE_ROWS = {"value": 16}  # conv tile rows: 8 (2 blocks per CU) or 16 (1 block per CU)
 
 
 def set_precision(p):
@@ -178,6 +179,11 @@ class ConvPlan:
                                 steps.append(((py * 2 + px) * cin + 32 * c, ey, ex, 1 if first else 0))
                                 src.append((32 * c, ky, kx))
                                 first = False
+                        if py == 1 and px == 1:
+                            # the (1,1) phase has a single tap: pad the chunk with a zero-weight step
+                            # (8-row tile kernels need >= 2 steps per chunk, ppst_hip.h tile_rows)
+                            steps.append(((py * 2 + px) * cin + 32 * c, 0, 0, 0))
+                            src.append((-1, 0, 0))
             sn, sc, sy, sx = cin * 9, 9, 3, 1
             wsrc = w
         elif kind == "convT":
@@ -202,6 +208,7 @@ class ConvPlan:
         else:
             raise ValueError(kind)
         self.nsteps = len(steps) // self.n_groups
+        self.flop_steps = sum(1 for t in src if t[0] >= 0) // self.n_groups
         dev = w.device
         self.steps = torch.tensor(steps, dtype=torch.int32, device=dev).contiguous()
         s = torch.tensor(src, dtype=torch.int32, device=dev)
@@ -213,7 +220,8 @@ class ConvPlan:
                                  self.nsteps, self.n_groups, self.precision, _p(self.wpack), _stream()), "ppst_conv_pack")
 
     def __call__(self, x, bias=None, noise=None, noise_weight=0.0, act=ACT_NONE, prelu=None, stats=False,
-                 residual=None, out=None, out_scale=1.0, pad_mode=PAD_ZERO, out_hw=None, res_after_act=False):
+                 residual=None, out=None, out_scale=1.0, pad_mode=PAD_ZERO, out_hw=None, res_after_act=False,
+                 in_ss=None, in_act=ACT_NONE, in_prelu=None):
         in_ld = _nhwc_ld(x, "conv input")
         B, H, W, _ = x.shape
         if self.kind == "convT":
@@ -229,9 +237,10 @@ class ConvPlan:
         assert out.shape[0] == B and out.shape[1] == oh and out.shape[2] == ow and out.shape[3] == self.cout
         for t, n in ((bias, "bias"), (noise, "noise"), (prelu, "prelu"), (residual, "residual")):
             _chk(t, n)
+        rows = TILE_ROWS["value"]
         st = None
         if stats:
-            tiles = lib.ppst_conv_tiles(th, tw)
+            tiles = lib.ppst_conv_tiles(th, tw, rows)
             st = torch.empty((B, self.n_groups * tiles, self.cout, 2), device=x.device, dtype=torch.float32)
         a = _lib.ConvArgs()
         a.x, a.wpack, a.steps, a.y = _p(x), _p(self.wpack), _p(self.steps), _p(out)
@@ -245,7 +254,11 @@ class ConvPlan:
         a.in_off_y = a.in_off_x = 0
         a.out_sy = a.out_sx = osy
         a.act, a.precision = act | (0x100 if res_after_act else 0), self.precision
-        a.tile_h, a.tile_w, a.halo, a.bn = th, tw, self.halo, self.bn
+        a.tile_h, a.tile_w, a.halo, a.bn, a.tile_rows = th, tw, self.halo, self.bn, rows
+        _chk(in_ss, "in_ss"); _chk(in_prelu, "in_prelu")
+        a.in_scale_shift, a.in_prelu, a.in_act = _p(in_ss), _p(in_prelu), in_act
+        a.in_c = in_ss.shape[1] if in_ss is not None else 0
+        a.flop_steps = self.flop_steps
         check(lib.ppst_conv2d_mfma(ctypes.byref(a), _stream()), "ppst_conv2d_mfma")
         if stats:
             return out, st
@@ -314,6 +327,25 @@ def affine_act(x, scale_shift=None, res=None, act=ACT_NONE, prelu=None, out_scal
     check(lib.ppst_affine_act(_p(x), _p(scale_shift), _p(res), _p(res_scale_shift), _p(out), B, H * W, C, x_ld, res_ld, y_ld,
                               flag, _p(prelu), float(out_scale), _stream()), "ppst_affine_act")
     return out
+
+
+def affine_act_stats(x, scale_shift=None, res=None, act=ACT_NONE, prelu=None, out_scale=1.0, res_before_act=False,
+                     res_scale_shift=None, rep_pad=False):
+    """affine_act that also returns the instance-norm partials (B, n, C, 2) of its output."""
+    x_ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    out = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+    res_ld = _nhwc_ld(res, "res") if res is not None else 0
+    for t in (scale_shift, res_scale_shift, prelu):
+        _chk(t)
+    n = ctypes.c_int(0)
+    check(lib.ppst_in_stats(None, None, B, H, W, C, x_ld, 0, ctypes.byref(n), None), "ppst_in_stats(size)")
+    part = torch.empty((B, n.value, C, 2), device=x.device, dtype=torch.float32)
+    flag = act | (RES_BEFORE_ACT if res_before_act else 0)
+    check(lib.ppst_affine_act_stats(_p(x), _p(scale_shift), _p(res), _p(res_scale_shift), _p(out), _p(part), B, H, W, C, x_ld,
+                                    res_ld, C, flag, _p(prelu), float(out_scale), 1 if rep_pad else 0, _stream()),
+          "ppst_affine_act_stats")
+    return out, part
 
 
 def upsample_nearest2(x):

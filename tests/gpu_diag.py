@@ -247,6 +247,18 @@ def t_conv():
     plan(g(nhwc(x)), out=big[..., 40:168])
     report("conv out slice", nchw(big[..., 40:168].contiguous().cpu()), conv, 3e-5)
     report("conv out slice untouched", big[..., :40], torch.zeros(B, H, Wd, 40), 0)
+    # normalise-on-load: conv(act(a*x+s)) with zero / replicate padding of the normalised tensor
+    B, ci, co, H, Wd = 2, 64, 128, 24, 40
+    x = torch.randn(B, ci, H, Wd); w = torch.randn(co, ci, 3, 3) / 24.0
+    ssin = torch.randn(B, ci, 2)
+    xa = x.double() * ssin[:, :, 0, None, None].double() + ssin[:, :, 1, None, None].double()
+    y = ops.ConvPlan(g(w))(g(nhwc(x)), in_ss=g(ssin))
+    report("conv normalise-on-load (zero pad)", nchw(y.cpu()), F.conv2d(xa, w.double(), padding=1), 3e-5)
+    a = torch.tensor([0.25])
+    y = ops.ConvPlan(g(w))(g(nhwc(x)), in_ss=g(ssin), in_act=ops.ACT_PRELU, in_prelu=g(a), pad_mode=ops.PAD_REPLICATE)
+    report("conv normalise-on-load prelu (replicate)", nchw(y.cpu()), F.conv2d(F.pad(O.prelu(xa, a.double()), (1, 1, 1, 1), mode="replicate"), w.double()), 3e-5)
+    y = ops.ConvPlan(g(w))(g(nhwc(x)), in_ss=g(ssin), in_act=ops.ACT_LRELU)
+    report("conv normalise-on-load lrelu", nchw(y.cpu()), F.conv2d(O.fused_leaky_relu(xa, None), w.double(), padding=1), 3e-5)
     # convT stats cover the 4 phases
     x = torch.randn(1, 64, 16, 16); w = torch.randn(64, 64, 3, 3) / 24.0
     y, st = ops.ConvPlan(g(w), kind="convT")(g(nhwc(x)), stats=True)
@@ -283,6 +295,10 @@ def t_norm_pool():
     y = ops.affine_act(g(nhwc(x)), ss, res=g(nhwc(res)), res_scale_shift=g(rss), act=ops.ACT_LRELU, out_scale=0.7)
     ref2 = (O.fused_leaky_relu(ref, None) + (res * rss[:, :, 0, None, None] + rss[:, :, 1, None, None])) * 0.7
     report("affine_act lrelu + affine residual", nchw(y.cpu()), ref2, 1e-5)
+    y2, part = ops.affine_act_stats(g(nhwc(x)), ss, res=g(nhwc(res)), res_scale_shift=g(rss), act=ops.ACT_LRELU, out_scale=0.7, rep_pad=True)
+    report("affine_act_stats output", nchw(y2.cpu()), ref2, 1e-5)
+    refn = O.instance_norm(F.pad(ref2, (1, 1, 1, 1), mode="replicate"))[:, :, 1:-1, 1:-1]
+    report("affine_act_stats partials (rep_pad IN)", nchw(ops.affine_act(y2, ops.in_finalize(part, 22 * 26)).cpu()), refn, 1e-5)
     gg = ops.gap_gmp(g(nhwc(x)))
     report("gap_gmp", gg, torch.cat([x.mean((2, 3)), x.amax((2, 3))], 1), 2e-6)
     mask = (torch.rand(2, 20, 24) > 0.5).float()

@@ -41,7 +41,7 @@ def test_argument_errors_need_no_gpu():
     assert lib.ppst_fused_bias_act(None, None, None, None, 0, 1, 1, 3, 0, 0.2, 1.0, 0, None) == 0  # empty input
     assert lib.ppst_gemm_nt_f32(None, None, None, 1, 4, 4, 7, 1.0, None) == -1                      # K % 16
     assert lib.ppst_softmax_rows(None, 0, 4096, 0.01, None) == 0
-    assert lib.ppst_conv_tiles(512, 512) == 1024 and lib.ppst_conv_tiles(17, 16) == 2
+    assert lib.ppst_conv_tiles(512, 512, 16) == 1024 and lib.ppst_conv_tiles(17, 16, 8) == 3
 
 
 def test_ops_refuse_cpu_tensors():
