@@ -172,8 +172,10 @@ int ppst_in_stats(const void* x, void* partial, int B, int H, int W, int C, int 
                   int rep_pad, int* n_partials, void* stream);
 /* reduce partials -> per (b,c) scale a and shift s with  y = a*x + s:
  *   a = rstd * (style0+1), s = style1 - mean*a   (style==NULL: a=rstd, s=-mean*rstd)
- * style: [B][2*C] rows = StyleMod linear output. count = #elements per (b,c). */
+ * style: [B][style_ld] rows whose first 2*C entries are the StyleMod linear output.
+ * count = #elements per (b,c). */
 int ppst_in_finalize(const void* partial, int n_partials, const void* style,
+                     int style_ld /* row stride of style (>= 2C): slices of a batched StyleMod GEMV */,
                      const void* post_bias /* [C] added to the shift, or NULL */,
                      void* scale_shift /* [B][C][2] */, int B, int C, double count,
                      float eps, void* stream);
@@ -183,14 +185,18 @@ int ppst_affine_act(const void* x, const void* scale_shift, const void* res,
                     const void* res_scale_shift /* optional affine of res */, void* y,
                     int B, int64_t hw, int C, int x_ld, int res_ld, int y_ld,
                     int act /* | 0x100: res joins before act */, const void* prelu,
-                    float out_scale, void* stream);
+                    float out_scale,
+                    int res_up2_w /* >0: res is a HALF-resolution tensor, upsampled x2 bilinearly on the
+                                     fly (resnet skip, generator.py:75); value = output width W */,
+                    void* stream);
 /* ppst_affine_act that also emits the instance-norm partials of its OUTPUT (the layout
  * ppst_in_stats produces for (H, W); rep_pad as there), so the norm that follows needs no
  * read pass of its own.  C % 4 == 0. */
 int ppst_affine_act_stats(const void* x, const void* scale_shift, const void* res,
                           const void* res_scale_shift, void* y, void* partial,
                           int B, int H, int W, int C, int x_ld, int res_ld, int y_ld,
-                          int act, const void* prelu, float out_scale, int rep_pad, void* stream);
+                          int act, const void* prelu, float out_scale, int rep_pad,
+                          int res_up2 /* as res_up2_w, boolean */, void* stream);
 /* nearest x2 upsample NHWC (Upscale2d, stylegan2_layers.py:86-97) */
 int ppst_upsample_nearest2(const void* x, void* y, int B, int H, int W, int C, void* stream);
 

@@ -58,9 +58,9 @@ _SIGS = {
     "ppst_conv1x1_small_cin": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp]),
     "ppst_conv1x1_small_cout": (i32, [vp, vp, vp, vp, i64, i32, i32, f32, vp]),
     "ppst_in_stats": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(i32), vp]),
-    "ppst_in_finalize": (i32, [vp, i32, vp, vp, vp, i32, i32, f64, f32, vp]),
-    "ppst_affine_act": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, f32, vp]),
-    "ppst_affine_act_stats": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, f32, i32, vp]),
+    "ppst_in_finalize": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, f64, f32, vp]),
+    "ppst_affine_act": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, f32, i32, vp]),
+    "ppst_affine_act_stats": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, f32, i32, i32, vp]),
     "ppst_upsample_nearest2": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ppst_gap_gmp_ws": (i64, [i32, i64, i32]),
     "ppst_gap_gmp": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -14,6 +14,29 @@ static inline unsigned grid_for(int64_t work, int threads = 256) {
 
 __device__ __forceinline__ float act_apply(float t, int act, float slope);
 
+// residual that is a half-resolution tensor, bilinearly upsampled x2 on the fly
+// (F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) of the resnet skip,
+// generator.py:75): output pixel (oy, ox) of an H x W image, res is [B][H/2][W/2][res_ld]
+__device__ __forceinline__ float4 res_up2_sample(const float* __restrict__ res, int b, int oy, int ox, int H, int W, int res_ld,
+                                                 int c) {
+  const int h = H >> 1, w = W >> 1;
+  float fy = fmaxf(((float)oy + 0.5f) * 0.5f - 0.5f, 0.f), fx = fmaxf(((float)ox + 0.5f) * 0.5f - 0.5f, 0.f);
+  int y0 = (int)fy, x0 = (int)fx;
+  int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
+  float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+  const float* base = res + (int64_t)b * h * w * res_ld + c;
+  float4 v00 = *(const float4*)(base + ((int64_t)y0 * w + x0) * res_ld);
+  float4 v01 = *(const float4*)(base + ((int64_t)y0 * w + x1) * res_ld);
+  float4 v10 = *(const float4*)(base + ((int64_t)y1 * w + x0) * res_ld);
+  float4 v11 = *(const float4*)(base + ((int64_t)y1 * w + x1) * res_ld);
+  float4 o;
+  o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+  o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+  o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+  o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+  return o;
+}
+
 // ------------------------------------------------------------------ layout --
 // x[b][c][p] <-> y[b][p][c]; 32(c) x 64(p) tiles through LDS (pad 1: conflict-free)
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int64_t P) {
@@ -154,6 +177,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
 struct ApplyArgs {
   const float* ss; const float* res; const float* rss; float* y; const float* prelu;
   int res_ld, y_ld, actf; float out_scale;
+  int res_up2;  // residual is half-resolution, bilinearly upsampled x2 on the fly
 };
 template <int MODE, bool APPLY>
 __global__ __launch_bounds__(256) void chan_reduce4_kernel(const float* __restrict__ x, const float* __restrict__ mask,
@@ -197,7 +221,9 @@ __global__ __launch_bounds__(256) void chan_reduce4_kernel(const float* __restri
           float t[4] = {sa.x * v.x + sb.x, sa.y * v.y + sb.y, sa.z * v.z + sb.z, sa.w * v.w + sb.w};
           float r[4] = {0.f, 0.f, 0.f, 0.f};
           if (ap.res) {
-            float4 rv = *(const float4*)(ap.res + bp * ap.res_ld + c);
+            float4 rv;
+            if (ap.res_up2) { int py = (int)(p / W), px = (int)(p - (int64_t)py * W); rv = res_up2_sample(ap.res, b, py, px, H, W, ap.res_ld, c); }
+            else rv = *(const float4*)(ap.res + bp * ap.res_ld + c);
             r[0] = ra.x * rv.x + rb.x; r[1] = ra.y * rv.y + rb.y; r[2] = ra.z * rv.z + rb.z; r[3] = ra.w * rv.w + rb.w;
           }
 #pragma unroll
@@ -266,8 +292,9 @@ extern "C" int ppst_in_stats(const void* x, void* partial, int B, int H, int W, 
 // One block per (image b, 32-channel group): 8 partial rows are in flight per step (each a
 // 256-B coalesced read of 32 (sum, sumsq) pairs), double accumulation, LDS tree at the end.
 __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ partial, int n_partials,
-                                                          const float* __restrict__ style, const float* __restrict__ post_bias,
-                                                          float* __restrict__ ss, int B, int C, double count, float eps) {
+                                                          const float* __restrict__ style, int style_ld,
+                                                          const float* __restrict__ post_bias, float* __restrict__ ss, int B,
+                                                          int C, double count, float eps) {
   __shared__ double sm[8][32][2];
   const int cgroups = (C + 31) / 32;
   const int b = blockIdx.x / cgroups, c0 = (blockIdx.x % cgroups) * 32;
@@ -293,8 +320,8 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restric
     double rstd = 1.0 / sqrt(var + (double)eps);
     double a = rstd, sh = -mean * rstd;
     if (style) {
-      double s0 = (double)style[(int64_t)b * 2 * C + c] + 1.0;
-      double s1 = (double)style[(int64_t)b * 2 * C + C + c];
+      double s0 = (double)style[(int64_t)b * style_ld + c] + 1.0;
+      double s1 = (double)style[(int64_t)b * style_ld + C + c];
       a = rstd * s0;
       sh = s1 - mean * a;
     }
@@ -303,14 +330,14 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restric
     ss[((int64_t)b * C + c) * 2 + 1] = (float)sh;
   }
 }
-extern "C" int ppst_in_finalize(const void* partial, int n_partials, const void* style, const void* post_bias,
+extern "C" int ppst_in_finalize(const void* partial, int n_partials, const void* style, int style_ld, const void* post_bias,
                                 void* scale_shift, int B, int C, double count, float eps, void* stream) {
-  if (B < 0 || C <= 0 || n_partials <= 0 || count <= 0) return PPST_EINVAL;
+  if (B < 0 || C <= 0 || n_partials <= 0 || count <= 0 || (style && style_ld < 2 * C)) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!partial || !scale_shift) return PPST_ENULL;
   PPST_LAUNCH(in_finalize_kernel, dim3(B * cdiv(C, 32)), dim3(256), 0, as_stream(stream),
-                     (const float*)partial, n_partials, (const float*)style, (const float*)post_bias, (float*)scale_shift, B, C,
-                     count, eps);
+                     (const float*)partial, n_partials, (const float*)style, style_ld, (const float*)post_bias,
+                     (float*)scale_shift, B, C, count, eps);
   return PPST_LAUNCH_CHECK();
 }
 
@@ -326,7 +353,8 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
                                                          const float* __restrict__ res, const float* __restrict__ rss,
                                                          float* __restrict__ y, int64_t hw, int C, int x_ld, int res_ld,
                                                          int y_ld, int actf,
-                                                         const float* __restrict__ prelu, float out_scale, int64_t total) {
+                                                         const float* __restrict__ prelu, float out_scale, int64_t total,
+                                                         int up2_w) {
   const int act = actf & 0xff;
   const bool res_first = (actf >> 8) & 1;
   const float slope = (act == PPST_ACT_PRELU && prelu) ? prelu[0] : 0.f;
@@ -343,7 +371,14 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
       float4 v = *(const float4*)(x + bp * x_ld + c);
       xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
       if (res) {
-        float4 r = *(const float4*)(res + bp * res_ld + c);
+        float4 r;
+        if (up2_w > 0) {
+          int64_t p = bp - (int64_t)b * hw;
+          int oy = (int)(p / up2_w), ox = (int)(p - (int64_t)oy * up2_w);
+          r = res_up2_sample(res, b, oy, ox, (int)(hw / up2_w), up2_w, res_ld, c);
+        } else {
+          r = *(const float4*)(res + bp * res_ld + c);
+        }
         rv[0] = r.x; rv[1] = r.y; rv[2] = r.z; rv[3] = r.w;
       }
     } else {
@@ -365,21 +400,23 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
 }
 extern "C" int ppst_affine_act(const void* x, const void* scale_shift, const void* res, const void* res_scale_shift, void* y,
                                int B, int64_t hw, int C, int x_ld, int res_ld, int y_ld, int act, const void* prelu,
-                               float out_scale, void* stream) {
+                               float out_scale, int res_up2_w, void* stream) {
+  if (res_up2_w < 0 || (res_up2_w > 0 && (!res || hw % res_up2_w || res_up2_w % 2 || (hw / res_up2_w) % 2 || C % 4))) return PPST_EINVAL;
   if (B < 0 || hw <= 0 || C <= 0 || x_ld < C || y_ld < C || (res && res_ld < C)) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!x || !y) return PPST_ENULL;
+  if (res_up2_w > 0 && (x_ld % 4 || y_ld % 4 || res_ld % 4)) return PPST_EINVAL;
   bool vec = C % 4 == 0 && x_ld % 4 == 0 && y_ld % 4 == 0 && (!res || res_ld % 4 == 0) &&
              (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) % 16 == 0);
   int64_t total = (int64_t)B * hw * (vec ? C / 4 : C);
   if (vec)
     PPST_LAUNCH(affine_act_kernel<true>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
                        (const float*)scale_shift, (const float*)res, (const float*)res_scale_shift, (float*)y, hw, C, x_ld,
-                       res_ld, y_ld, act, (const float*)prelu, out_scale, total);
+                       res_ld, y_ld, act, (const float*)prelu, out_scale, total, res_up2_w);
   else
     PPST_LAUNCH(affine_act_kernel<false>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
                        (const float*)scale_shift, (const float*)res, (const float*)res_scale_shift, (float*)y, hw, C, x_ld,
-                       res_ld, y_ld, act, (const float*)prelu, out_scale, total);
+                       res_ld, y_ld, act, (const float*)prelu, out_scale, total, 0);
   return PPST_LAUNCH_CHECK();
 }
 
@@ -387,7 +424,7 @@ extern "C" int ppst_affine_act(const void* x, const void* scale_shift, const voi
 // (partial [B][n_partials][C][2], n_partials as ppst_in_stats reports for (H, W)).
 extern "C" int ppst_affine_act_stats(const void* x, const void* scale_shift, const void* res, const void* res_scale_shift,
                                      void* y, void* partial, int B, int H, int W, int C, int x_ld, int res_ld, int y_ld,
-                                     int act, const void* prelu, float out_scale, int rep_pad, void* stream) {
+                                     int act, const void* prelu, float out_scale, int rep_pad, int res_up2, void* stream) {
   if (B < 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || x_ld % 4 || y_ld % 4 || x_ld < C || y_ld < C ||
       (res && (res_ld < C || res_ld % 4)))
     return PPST_EINVAL;
@@ -397,6 +434,8 @@ extern "C" int ppst_affine_act_stats(const void* x, const void* scale_shift, con
   ApplyArgs ap;
   ap.ss = (const float*)scale_shift; ap.res = (const float*)res; ap.rss = (const float*)res_scale_shift; ap.y = (float*)y;
   ap.prelu = (const float*)prelu; ap.res_ld = res_ld; ap.y_ld = y_ld; ap.actf = act; ap.out_scale = out_scale;
+  ap.res_up2 = (res && res_up2) ? 1 : 0;
+  if (ap.res_up2 && (H % 2 || W % 2)) return PPST_EINVAL;
   PPST_LAUNCH((chan_reduce4_kernel<0, true>), dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
               (const float*)nullptr, (float*)partial, H, W, C, x_ld, rep_pad, nchunks, ap);
   return PPST_LAUNCH_CHECK();

@@ -39,8 +39,30 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
             return b, float(ts[3].item())
         return self.cached(("sc", p), ts, build)
 
+    # -- all StyleMod GEMVs that share a style code run as ONE weight-streaming launch -----
+    def _style_groups(self):
+        groups = [["HeadResnetBlock%d.%s." % (i, c) for i in range(4) for c in ("conv1", "conv2")]]
+        groups += [["UpsamplingResBlock%d.%s." % (key, c) for c in ("conv1", "conv2")] for key, _, _ in UP]
+        groups[-1].append("ToRGB.")  # ToRGB is modulated by codes[0] like the last upsampling block
+        return groups
+
+    def _style_table(self, codes):
+        """{layer prefix: (B, 2C) StyleMod output} -- EqualizedLinear(2048 -> 2C, wscale) per layer
+        (stylegan2_layers.py:361-374), batched per style code: groups use codes[-1], [-2], [-3], [-4]."""
+        out = {}
+        for gi, names in enumerate(self._style_groups()):
+            ws = [self.p(n + "epi1.style_mod.lin.weight") for n in names]
+            bs = [self.p(n + "epi1.style_mod.lin.bias") for n in names]
+            W, Bv = self.cached(("stylecat", gi), ws + bs, lambda: (torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous()))
+            y = ops.linear(codes[-1 - gi], W, Bv, wscale=W.shape[1] ** -0.5)
+            off = 0
+            for n, w in zip(names, ws):
+                out[n] = y[:, off:off + w.shape[0]]
+                off += w.shape[0]
+        return out
+
     def styled_conv(self, x, p, style, key, noise, upsample=False, res=None, out_scale=1.0, in_ss=None, defer=False,
-                    out_stats=None):
+                    out_stats=None, res_up2=False):
         """in_ss: (scale, shift) of the producer StyledConv, applied while this conv stages its
         input ("normalise on load").  defer=True returns (raw conv output, its scale/shift)
         instead of running the apply pass."""
@@ -60,14 +82,12 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
             nz = noise[key].contiguous()
         y, st = self.plan(p + "conv.weight", kind)(x, bias=bias, noise=nz, noise_weight=nw, act=ops.ACT_LRELU, stats=True,
                                                    in_ss=in_ss)
-        wl = self.p(p + "epi1.style_mod.lin.weight")
-        s = ops.linear(style, wl, self.p(p + "epi1.style_mod.lin.bias"), wscale=wl.shape[1] ** -0.5)
-        ss = ops.in_finalize(st, y.shape[1] * y.shape[2], style=s)
+        ss = ops.in_finalize(st, y.shape[1] * y.shape[2], style=style[p])
         if defer:
             return y, ss
         if out_stats is not None:  # 'rep' | 'plain': also emit the IN partials of the block output (feature heads)
-            return ops.affine_act_stats(y, ss, res=res, out_scale=out_scale, rep_pad=(out_stats == "rep"))
-        return ops.affine_act(y, ss, res=res, out_scale=out_scale)
+            return ops.affine_act_stats(y, ss, res=res, out_scale=out_scale, rep_pad=(out_stats == "rep"), res_up2=res_up2)
+        return ops.affine_act(y, ss, res=res, out_scale=out_scale, res_up2=res_up2)
 
     # -- correspondence feature heads (generator.py:174-238) ------------------
     def _feat_head(self, x, p, k, out, st=None):
@@ -110,6 +130,7 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
             noise = self.make_noise(B, S, sp.device)
         codes = [ops.l2norm_rows(c, 1e-8, 0) for c in global_codes]  # util.normalize (generator.py:246)
         g = codes[-1]
+        styles = self._style_table(codes)
         ws = self.p("SpatialCodeModulation.scale.weight")
         inv = 1.0 / math.sqrt(ws.shape[1])
         scale = ops.linear(g, ws, self.p("SpatialCodeModulation.scale.bias"), wscale=inv)
@@ -118,9 +139,9 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
         for i, (ci, co) in enumerate(HEAD_CH):
             q = "HeadResnetBlock%d." % i
             skip = x if ci == co else self.plan(q + "skip.Conv.weight", scale=1.0 / math.sqrt(ci))(x)
-            r, rss = self.styled_conv(x, q + "conv1.", g, "HeadResnetBlock%d.conv1" % i, noise, defer=True)
+            r, rss = self.styled_conv(x, q + "conv1.", styles, "HeadResnetBlock%d.conv1" % i, noise, defer=True)
             want = "rep" if (extract_features and i == len(HEAD_CH) - 1) else None
-            x = self.styled_conv(r, q + "conv2.", g, "HeadResnetBlock%d.conv2" % i, noise, res=skip, out_scale=INV_SQRT2, in_ss=rss,
+            x = self.styled_conv(r, q + "conv2.", styles, "HeadResnetBlock%d.conv2" % i, noise, res=skip, out_scale=INV_SQRT2, in_ss=rss,
                                  out_stats=want)
             if want:
                 x, xst = x
@@ -138,11 +159,11 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
                 skip = x
             else:
                 skip = self.plan(q + "skip.Conv.weight", scale=1.0 / math.sqrt(ci))(x, bias=self.p(q + "skip.Act.bias"), act=ops.ACT_LRELU)
-            skip = ops.bilinear(skip, 2 * x.shape[1], 2 * x.shape[2])
-            r, rss = self.styled_conv(x, q + "conv1.", g, "UpsamplingResBlock%d.conv1" % key, noise, upsample=True, defer=True)
+            # (the x2 bilinear upsample of the skip is sampled on the fly by the apply pass)
+            r, rss = self.styled_conv(x, q + "conv1.", styles, "UpsamplingResBlock%d.conv1" % key, noise, upsample=True, defer=True)
             want = ("rep" if j < 2 else "plain") if extract_features else None
-            x = self.styled_conv(r, q + "conv2.", g, "UpsamplingResBlock%d.conv2" % key, noise, res=skip, out_scale=INV_SQRT2, in_ss=rss,
-                                 out_stats=want)
+            x = self.styled_conv(r, q + "conv2.", styles, "UpsamplingResBlock%d.conv2" % key, noise, res=skip, out_scale=INV_SQRT2, in_ss=rss,
+                                 out_stats=want, res_up2=True)
             if extract_features:
                 x, xst = x
                 f = self._feat_head(x, "layer%d." % (2 ** (j + 6)), 3 if j < 2 else 1, out=None, st=xst)
@@ -154,9 +175,7 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
         brgb = self.cached(("rgbb",), [self.p("ToRGB.conv.bias"), self.p("ToRGB.bias")],
                            lambda: (self.p("ToRGB.conv.bias") + self.p("ToRGB.bias").reshape(-1)).contiguous())
         y = ops.conv1x1_small_cout(x, wr, brgb, 1.0 / math.sqrt(wr.shape[1]))
-        wl = self.p("ToRGB.epi1.style_mod.lin.weight")
-        s = ops.linear(codes[0], wl, self.p("ToRGB.epi1.style_mod.lin.bias"), wscale=wl.shape[1] ** -0.5)
-        ss = ops.in_finalize(ops.in_stats(y), y.shape[1] * y.shape[2], style=s)
+        ss = ops.in_finalize(ops.in_stats(y), y.shape[1] * y.shape[2], style=styles["ToRGB."])
         rgb = ops.nhwc_to_nchw(ops.affine_act(y, ss))
         if not extract_features:
             return rgb

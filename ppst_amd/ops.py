@@ -306,14 +306,19 @@ def in_finalize(partial, count, style=None, post_bias=None, eps=1e-5):
     _chk(style, "style")
     _chk(post_bias, "post_bias")
     B, n, C, _ = partial.shape
+    style_ld = 0
+    if style is not None:  # (B, 2C) rows, possibly a column slice of a wider batched GEMV output
+        assert style.shape == (B, 2 * C) and style.stride(1) == 1
+        style_ld = style.stride(0) if B > 1 else max(style.stride(0), 2 * C)
     ss = torch.empty((B, C, 2), device=partial.device, dtype=torch.float32)
-    check(lib.ppst_in_finalize(_p(partial), n, _p(style), _p(post_bias), _p(ss), B, C, float(count), float(eps), _stream()),
-          "ppst_in_finalize")
+    check(lib.ppst_in_finalize(_p(partial), n, _p(style), style_ld, _p(post_bias), _p(ss), B, C, float(count), float(eps),
+                               _stream()), "ppst_in_finalize")
     return ss
 
 
 def affine_act(x, scale_shift=None, res=None, act=ACT_NONE, prelu=None, out_scale=1.0, res_before_act=False, out=None,
-               res_scale_shift=None):
+               res_scale_shift=None, res_up2=False):
+    """res_up2: ``res`` is a half-resolution tensor, bilinearly upsampled x2 on the fly."""
     x_ld = _nhwc_ld(x)
     B, H, W, C = x.shape
     if out is None:
@@ -323,14 +328,16 @@ def affine_act(x, scale_shift=None, res=None, act=ACT_NONE, prelu=None, out_scal
     _chk(scale_shift, "scale_shift")
     _chk(res_scale_shift, "res_scale_shift")
     _chk(prelu, "prelu")
+    if res_up2:
+        assert res.shape[1] * 2 == H and res.shape[2] * 2 == W
     flag = act | (RES_BEFORE_ACT if res_before_act else 0)
     check(lib.ppst_affine_act(_p(x), _p(scale_shift), _p(res), _p(res_scale_shift), _p(out), B, H * W, C, x_ld, res_ld, y_ld,
-                              flag, _p(prelu), float(out_scale), _stream()), "ppst_affine_act")
+                              flag, _p(prelu), float(out_scale), W if res_up2 else 0, _stream()), "ppst_affine_act")
     return out
 
 
 def affine_act_stats(x, scale_shift=None, res=None, act=ACT_NONE, prelu=None, out_scale=1.0, res_before_act=False,
-                     res_scale_shift=None, rep_pad=False):
+                     res_scale_shift=None, rep_pad=False, res_up2=False):
     """affine_act that also returns the instance-norm partials (B, n, C, 2) of its output."""
     x_ld = _nhwc_ld(x)
     B, H, W, C = x.shape
@@ -343,7 +350,8 @@ def affine_act_stats(x, scale_shift=None, res=None, act=ACT_NONE, prelu=None, ou
     part = torch.empty((B, n.value, C, 2), device=x.device, dtype=torch.float32)
     flag = act | (RES_BEFORE_ACT if res_before_act else 0)
     check(lib.ppst_affine_act_stats(_p(x), _p(scale_shift), _p(res), _p(res_scale_shift), _p(out), _p(part), B, H, W, C, x_ld,
-                                    res_ld, C, flag, _p(prelu), float(out_scale), 1 if rep_pad else 0, _stream()),
+                                    res_ld, C, flag, _p(prelu), float(out_scale), 1 if rep_pad else 0, 1 if res_up2 else 0,
+                                    _stream()),
           "ppst_affine_act_stats")
     return out, part
 

@@ -299,6 +299,12 @@ def t_norm_pool():
     report("affine_act_stats output", nchw(y2.cpu()), ref2, 1e-5)
     refn = O.instance_norm(F.pad(ref2, (1, 1, 1, 1), mode="replicate"))[:, :, 1:-1, 1:-1]
     report("affine_act_stats partials (rep_pad IN)", nchw(ops.affine_act(y2, ops.in_finalize(part, 22 * 26)).cpu()), refn, 1e-5)
+    lo = torch.randn(2, 64, 10, 12)
+    up = F.interpolate(lo, scale_factor=2, mode="bilinear", align_corners=False)
+    y3 = ops.affine_act(g(nhwc(x)), ss, res=g(nhwc(lo)), out_scale=0.7, res_up2=True)
+    report("affine_act + on-the-fly x2 bilinear residual", nchw(y3.cpu()), (ref + up) * 0.7, 1e-5)
+    y4, _ = ops.affine_act_stats(g(nhwc(x)), ss, res=g(nhwc(lo)), out_scale=0.7, res_up2=True)
+    report("affine_act_stats + x2 bilinear residual", nchw(y4.cpu()), (ref + up) * 0.7, 1e-5)
     gg = ops.gap_gmp(g(nhwc(x)))
     report("gap_gmp", gg, torch.cat([x.mean((2, 3)), x.amax((2, 3))], 1), 2e-6)
     mask = (torch.rand(2, 20, 24) > 0.5).float()
