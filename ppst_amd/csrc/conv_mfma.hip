@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
   const int tyi = midx / a.tiles_x, txi = midx - tyi * a.tiles_x;
   const int ty0 = tyi * TH, tx0 = txi * TW;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WN, wm = wave / WN;
   const int r16 = lane & 15, g = lane >> 4;
 
@@ -124,11 +124,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
   const unsigned char* wblob = (const unsigned char*)a.wpack + ((int64_t)nidx * a.nsteps) * BBUF;
   const float* xb = a.x + (int64_t)b * a.in_h * a.in_w * a.in_ld;
 
-  static_assert(B_IT >= 1 && B_IT <= 4, "B staging assumes 1..4 16-B items per thread");
   constexpr int A_WCH = (HP + 7) / 8;                      // wave-chunks of 8 pixels x 8 float4
   constexpr int A_IT2 = (A_WCH * 64 + NT - 1) / NT;
   float4 ra[A_IT2];
-  uint4 rb0, rb1, rb2, rb3;  // (named, not an array: hipcc promoted a small array to LDS)
 
   // A staging.  One wave-instruction covers 8 pixels x 128 B (fully coalesced global read);
   // inside it lane l -> plane g = l>>4, pixel (l>>1)&7, half h = l&1, so the 16 lanes of a
@@ -204,19 +202,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
       }
     }
   };
-  auto b_load = [&](int s) {
-    const uint4* src = (const uint4*)(wblob + (int64_t)s * BBUF);
-    rb0 = src[tid];
-    if (B_IT > 1) rb1 = src[tid + NT];
-    if (B_IT > 2) rb2 = src[tid + 2 * NT];
-    if (B_IT > 3) rb3 = src[tid + 3 * NT];
-  };
-  auto b_store = [&](int buf) {
-    uint4* dst = (uint4*)(smB + buf * BBUF);
-    dst[tid] = rb0;
-    if (B_IT > 1) dst[tid + NT] = rb1;
-    if (B_IT > 2) dst[tid + 2 * NT] = rb2;
-    if (B_IT > 3) dst[tid + 3 * NT] = rb3;
+  // B staging: LDS-DMA (global_load_lds_dwordx4): each wave-instruction copies 1 KB of the
+  // pre-packed step blob straight into the ring slot (LDS address = wave-uniform base +
+  // lane*16); no VGPR round trip, no ds_write.  Completion is covered by the vmcnt(0) that
+  // __syncthreads() places in front of the barrier ending the step.
+  constexpr int B_WI = BBUF / 1024;            // wave-instructions per step blob
+  constexpr int NW = NT / 64;
+  static_assert(B_WI % NW == 0, "B blob must split evenly over the waves");
+  auto b_dma = [&](int s, int slot) {
+    const unsigned char* src = wblob + (int64_t)s * BBUF + lane * 16;
+    unsigned char* dst = smB + slot * BBUF;
+#pragma unroll
+    for (int it = 0; it < B_WI / NW; ++it) {
+      const int wi = it * NW + wave;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + wi * 1024),
+                                       (void __attribute__((address_space(3)))*)(dst + wi * 1024), 16, 0, 0);
+    }
   };
   // fragment reads
   auto ld_b = [&](bf16x8 (&h)[4], bf16x8 (&lo)[4], int slot) {
@@ -246,47 +247,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
   // (last read during step s-1: a barrier ago) -> 2 B slots.  A(chunk of s+2) must not
   // overwrite the chunks of steps s and s+1, both still being read by slower waves -> 3 A
   // slots (chunk index mod 3), which also covers single-step chunks (1x1 convs).
-  // Stagger: the two waves that share a SIMD (wave w and w+4 of a 512-thread block) run the
-  // same program, so without help they reach the MFMA phase and the staging phase together
-  // and the matrix pipe idles while both stage.  Group 1 (waves 4..7) therefore does its
-  // staging work FIRST in every barrier interval (write the data it loaded one interval
-  // earlier, issue the loads of step s+3) and its MFMAs last; group 0 does MFMAs first and
-  // stages (loads of step s+2 issued at the top, written after the MFMAs) last.  Both
-  // groups deliver their share of step s+2 inside interval s, so the ring hazards above
-  // are unchanged.
-  // (measured on MI355X: the stagger made the loop ~15% slower than lockstep; kept behind a switch)
-#ifdef PPST_CONV_STAGGER
-  const bool grp1 = (NT == 512) && (__builtin_amdgcn_readfirstlane(tid) >= 256);
-#else
-  constexpr bool grp1 = false;
-#endif
-  // step descriptors live in scalars (cur = 0, next = 1): chan_off, dy, dx, new_chunk
+  // step descriptors live in scalars (cur = 0, next = 1); the descriptor of step s+2 is
+  // loaded one step before it is needed (its scalar-load latency would otherwise sit
+  // between the barrier and the first instruction of every step)
   int4 d = steps[0];
   int dy0 = d.y, dx0 = d.z, sl0 = 0;
   int dy1 = d.y, dx1 = d.z, sl1 = 0;
   a_load(d.x);
-  b_load(0);
+  b_dma(0, 0);
   a_store(0);
-  b_store(0);
   if (a.nsteps > 1) {
     d = steps[1];
     dy1 = d.y; dx1 = d.z;
     sl1 = d.w != 0 ? 1 : 0;
-    b_load(1);
+    b_dma(1, 1);
     if (d.w != 0) a_load(d.x);
-    b_store(1);
     if (d.w != 0) a_store(sl1);
   }
-  // group 1 runs one interval ahead on loads: issue step 2 now
-  bool pendA = false;
-  int pendSlot = 0;
-  if (grp1 && a.nsteps > 2) {
-    d = steps[2];
-    b_load(2);
-    pendA = d.w != 0;
-    pendSlot = pendA ? (sl1 == NA - 1 ? 0 : sl1 + 1) : sl1;
-    if (pendA) a_load(d.x);
-  }
+  int4 dE = d, dO = d;                       // descriptor of step s+2, alternating register sets
+  if (a.nsteps > 2) dE = steps[2];
   __syncthreads();
   STAMP(t_prologue)
 
@@ -311,30 +290,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
 #define ST_C
 #define ST_D
 #endif
-#define CONV_STEP(bch, bcl, bnh, bnl, s)                                                              \
+#define CONV_STEP(bch, bcl, bnh, bnl, s, D2, D3)                                                      \
   {                                                                                                   \
     ST_A                                                                                              \
-    const bool has1 = (s) + 1 < a.nsteps, has2 = (s) + 2 < a.nsteps, has3 = (s) + 3 < a.nsteps;       \
-    int ch2 = 0, dy2 = dy1, dx2 = dx1, nw2 = 0;                                                       \
-    if (has2) { int4 d2 = steps[(s) + 2]; ch2 = d2.x; dy2 = d2.y; dx2 = d2.z; nw2 = d2.w; }           \
+    const bool has1 = (s) + 1 < a.nsteps, has2 = (s) + 2 < a.nsteps;                                  \
+    if ((s) + 3 < a.nsteps) D3 = steps[(s) + 3];                                                      \
+    const bool newA2 = has2 && D2.w != 0;                                                             \
     int sl2 = sl1;                                                                                    \
-    if (has2 && nw2 != 0) sl2 = (sl1 == NA - 1) ? 0 : sl1 + 1;                                        \
-    if (grp1) {                                                                                       \
-      /* write what was loaded one interval ago (step s+2), then load step s+3 */                     \
-      if (has2) b_store((s) & 1);                                                                     \
-      if (pendA) a_store(pendSlot);                                                                   \
-      pendA = false;                                                                                  \
-      if (has3) {                                                                                     \
-        int4 d3 = steps[(s) + 3];                                                                     \
-        b_load((s) + 3);                                                                              \
-        pendA = d3.w != 0;                                                                            \
-        pendSlot = pendA ? ((sl2 == NA - 1) ? 0 : sl2 + 1) : sl2;                                     \
-        if (pendA) a_load(d3.x);                                                                      \
-      }                                                                                               \
-    } else {                                                                                          \
-      if (has2) b_load((s) + 2);                                                                      \
-      if (has2 && nw2 != 0) a_load(ch2);                                                              \
-    }                                                                                                 \
+    if (newA2) sl2 = (sl1 == NA - 1) ? 0 : sl1 + 1;                                                   \
+    if (has2) b_dma((s) + 2, (s) & 1);                                                                \
+    if (newA2) a_load(D2.x);                                                                          \
     if (has1) ld_b(bnh, bnl, ((s) + 1) & 1);                                                          \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                \
       bf16x8 nh, nl;                                                                                  \
@@ -356,19 +321,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
       if (X3) al = nl;                                                                                \
     }                                                                                                 \
     ST_B                                                                                              \
-    if (!grp1) {                                                                                      \
-      if (has2) b_store((s) & 1);                                                                     \
-      if (has2 && nw2 != 0) a_store(sl2);                                                             \
-    }                                                                                                 \
+    if (newA2) a_store(sl2);                                                                          \
     ST_C                                                                                              \
     __syncthreads();                                                                                  \
     ST_D                                                                                              \
     dy0 = dy1; dx0 = dx1; sl0 = sl1;                                                                  \
-    dy1 = dy2; dx1 = dx2; sl1 = sl2;                                                                  \
+    if (has2) { dy1 = D2.y; dx1 = D2.z; }                                                             \
+    sl1 = sl2;                                                                                        \
   }
   for (int s = 0; s < a.nsteps; s += 2) {
-    CONV_STEP(b0h, b0l, b1h, b1l, s)
-    if (s + 1 < a.nsteps) CONV_STEP(b1h, b1l, b0h, b0l, s + 1)
+    CONV_STEP(b0h, b0l, b1h, b1l, s, dE, dO)
+    if (s + 1 < a.nsteps) CONV_STEP(b1h, b1l, b0h, b0l, s + 1, dO, dE)
   }
 #undef CONV_STEP
 #undef A_OFF
