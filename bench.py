@@ -47,6 +47,18 @@ def swap_step(model, content, style, alpha, glue):
     return model(sp, code, target=None, command="decode")
 
 
+def conv_traffic():
+    """HBM bytes per conv launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
+    rocprofv3 --pmc runs of this same command; summary committed under profiles/).  PMC
+    counters cannot be read from inside the process, so the committed measurement is quoted;
+    None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        return json.load(open(path))["conv_mfma"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(seed):
     """The CPU oracle (a port of the reference's PyTorch-CPU path, pinned to it by
     tests/golden) timed on ONE pair at 512x512 on the host cores of this box."""
@@ -143,7 +155,7 @@ def main():
                 "peak_note": "bf16 dense MFMA 2500 TF / %d MFMA passes per algorithmic MAC" % passes,
                 "frac_vs_dense_bf16": achieved / PEAK_BF16_DENSE_TF,
                 "launches": conv_launches, "kernel_ms_total": conv_ms,
-                "share_of_step_time": conv_ms * 1e-3 / dt, "traffic": None,
+                "share_of_step_time": conv_ms * 1e-3 / dt, "traffic": conv_traffic(),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
