@@ -319,9 +319,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
       }                                                                                               \
       ah = nh;                                                                                        \
       if (X3) al = nl;                                                                                \
+      /* convert + write the next chunk's tile while the last MFMA group executes: the VALU   */     \
+      /* work of the staging store overlaps the matrix pipe instead of following it            */     \
+      if (mt == 2 && newA2) a_store(sl2);                                                             \
     }                                                                                                 \
     ST_B                                                                                              \
-    if (newA2) a_store(sl2);                                                                          \
     ST_C                                                                                              \
     __syncthreads();                                                                                  \
     ST_D                                                                                              \
