@@ -266,6 +266,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
   }
   int4 dE = d, dO = d;                       // descriptor of step s+2, alternating register sets
   if (a.nsteps > 2) dE = steps[2];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA of steps 0/1 (see the note at the loop barrier)
   __syncthreads();
   STAMP(t_prologue)
 
@@ -325,6 +326,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
     }                                                                                                 \
     ST_B                                                                                              \
     ST_C                                                                                              \
+    /* hipcc (ROCm 7.2) does NOT add vmcnt(0) for an in-flight LDS-DMA at this barrier (it only  */  \
+    /* emits lgkmcnt(0)): without the explicit wait a slow (cold-cache) B copy lands after the   */  \
+    /* next step has started reading the slot.                                                   */  \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
     __syncthreads();                                                                                  \
     ST_D                                                                                              \
     dy0 = dy1; dx0 = dx1; sl0 = sl1;                                                                  \

@@ -49,6 +49,12 @@ def test_networks_and_swap_recipe_vs_oracle():
     _run("t_networks")
 
 
+def test_grid_1024_and_mask_configs_vs_oracle():
+    """BASELINE configs 3 (grid + guided filter, pair sharding) and 5 (1024x1024 encode/decode +
+    guided filter, fp32-class and single-pass bf16) and the E2 mask heads."""
+    _run("t_configs")
+
+
 def test_swap_matches_reference_golden():
     """The HIP path against the fixtures produced by the *reference itself*
     (oracle/gen_golden.py): sampled activations of the full recipe."""
