@@ -265,6 +265,39 @@ int64_t ppst_guided_filter_ws(int B, int H, int W);
 int ppst_guided_filter(const void* guide_u8, const void* src_u8, void* out, void* out_u8,
                        int B, int H, int W, int r, float eps, void* work, void* stream);
 
+/* ------------------------------------------------- train step (backward) ---
+ * Gradients of the discriminator update (optimizers/ppst_optimizer.py:96-130; torch autograd
+ * of F.conv2d / F.linear in stylegan2_layers.py).  The conv INPUT gradient is
+ * ppst_conv2d_mfma itself on a transposed/flipped pack of the weights. */
+/* conv weight gradient, exact-fp32 MFMA, reduction over pixels; shares the forward step table
+ * (steps: device ppst_conv_step[nsteps]; chunk_start: device int32[nchunks+1], steps of one
+ * chunk share chan_off, at most 9 per chunk).  partial: [splits][nsteps][cout][32] fp32. */
+int ppst_conv_wgrad_f32(const void* x, const void* dy, const void* steps, const void* chunk_start,
+                        void* partial, int B, int in_h, int in_w, int in_ld, int oh, int ow,
+                        int dy_ld, int cout, int nsteps, int nchunks, int splits, void* stream);
+/* dw[n*sn + (src_c+k)*sc + ky*sy + kx*sx] (+)= scale * sum_splits partial[.][step][n][k] */
+int ppst_wgrad_scatter(const void* partial, const void* src_c, const void* src_ky, const void* src_kx,
+                       void* dw, int64_t sn, int64_t sc, int64_t sy, int64_t sx, int cout, int nsteps,
+                       int splits, float scale, int accumulate, void* stream);
+/* FromRGB (Cin <= 4) weight gradient: dw[n][c] (+)= scale * sum_p dy[p][n]*x[p][c] */
+int64_t ppst_wgrad_small_cin_ws(int64_t npix, int cin, int cout);
+int ppst_wgrad_small_cin(const void* x, const void* dy, void* dw, void* ws, int64_t npix, int cin,
+                         int in_ld, int cout, float scale, int accumulate, void* stream);
+/* out[c] (+)= scale * sum_rows x[row][c]  (bias gradients) */
+int64_t ppst_colsum_ws(int64_t rows, int C);
+int ppst_colsum(const void* x, void* out, void* ws, int64_t rows, int C, int ld, float scale,
+                int accumulate, void* stream);
+/* F.linear gradients: dW[n][k] (+)= scale*sum_b dY[b][n] X[b][k];  dX[b][k] = scale*sum_n dY[b][n] W[n][k] */
+int ppst_linear_wgrad(const void* dy, const void* x, void* dw, int B, int N, int K, float scale,
+                      int accumulate, void* stream);
+int ppst_linear_dgrad(const void* dy, const void* w, void* dx, int B, int N, int K, float scale,
+                      void* stream);
+/* LSGAN (models/networks/loss.py:11-18): loss = weight*mean((p-target)^2), grad = d loss / d p */
+int ppst_lsgan(const void* pred, void* loss, void* grad, int n, float target, float weight, void* stream);
+/* torch.optim.Adam step (ppst_optimizer.py:34-49), step counted from 1 */
+int ppst_adam_step(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1,
+                   float beta2, float eps, int step, void* stream);
+
 /* ---------------------------------------------------------- profiling ----
  * Opt-in HIP-event timing of the conv launches (bench.py roofline): when
  * enabled every ppst_conv2d_mfma call is bracketed by events on its stream. */

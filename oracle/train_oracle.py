@@ -1,0 +1,81 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle of the GAN train step.
+
+Functional restatement (PyTorch CPU autograd over oracle/ppst_oracle.py) of
+  * PPSTModel.compute_discriminator_losses   (models/ppst_model.py:105-138)
+  * PPSTModel.compute_R1_loss                (models/ppst_model.py:140-159)
+  * the D update of PPSTOptimizer.train_discriminator_one_step (optimizers/ppst_optimizer.py:96-130):
+    loss = sum(v.mean()), backward, Adam(lr*c, betas**c) with c = R1_every/(1+R1_every).
+Parameters that require grad are those whose key starts with ``D.``.
+Parity: the discriminator forward is pinned by tests/golden/swap512.npz ("D"); the loss /
+gradient composition is plain autograd over those pinned functions.
+"""
+import torch
+
+import ppst_oracle as O
+
+
+def d_inputs(sd, real, noise=None, training_stage=2, lambda_StyleCon=1.0):
+    """The images the D step classifies: (real, rec (B/2), mix (B)) -- generated under no_grad,
+    exactly as the reference's frozen G/E produce them (ppst_model.py:106-131)."""
+    B = real.shape[0]
+    assert B % 2 == 0, "Batch size must be even on each GPU."
+    with torch.no_grad():
+        sp = O.encoder_con(sd, real)
+        gl, _ = O.encoder_col(sd, real)
+        _, feas, feas1 = O.generator(sd, sp, gl, extract_features=True, noise=noise)
+        sps = torch.cat((feas, O.rselfcorr(feas1)), dim=1)
+        corrms = O.corrm(sps, O.swap(sps))
+        corr_self = O.corrm(sps, sps)
+        mix = None
+        if lambda_StyleCon > 0.0:
+            _, gl_w = O.encoder_col(sd, real, corrmatrix=corrms)
+            mix = O.generator(sd, O.swap(sp), gl_w, noise=noise)
+        _, gl2 = O.encoder_col(sd, real, corrmatrix=corr_self)
+        nz = None if noise is None else {k: v[:B // 2] for k, v in noise.items()}
+        rec = O.generator(sd, sp[:B // 2], [g[:B // 2] for g in gl2], noise=nz)
+    return rec, mix
+
+
+def d_losses(sd, real, rec, mix, size=512, lambda_GAN=1.0):
+    """compute_image_discriminator_losses (ppst_model.py:68-92), LSGAN (loss.py:11-18)."""
+    losses = {
+        "D_real": O.gan_loss(O.discriminator(sd, real, size), True) * lambda_GAN,
+        "D_rec": O.gan_loss(O.discriminator(sd, rec, size), False) * (0.5 * lambda_GAN),
+    }
+    if mix is not None:
+        losses["D_mix"] = O.gan_loss(O.discriminator(sd, mix, size), False) * (0.5 * lambda_GAN)
+    return losses
+
+
+def d_step_grads(sd, real, rec, mix, size=512):
+    """losses + d(sum of losses)/d(theta_D) by autograd.  Returns (losses, {key: grad})."""
+    keys = [k for k in sd if k.startswith("D.") and sd[k].is_floating_point() and "kernel" not in k]
+    p = {k: (sd[k].detach().clone().requires_grad_(True) if k in keys else sd[k]) for k in sd}
+    losses = d_losses(p, real, rec, mix, size)
+    total = sum(v.mean() for v in losses.values())
+    grads = torch.autograd.grad(total, [p[k] for k in keys])
+    return {k: float(v) for k, v in losses.items()}, dict(zip(keys, grads))
+
+
+def r1_loss(sd, real, size=512, lambda_R1=10.0):
+    """compute_R1_loss: 0.5*lambda*||d D(x).sum() / dx||^2 per sample."""
+    x = real.detach().clone().requires_grad_(True)
+    pred = O.discriminator(sd, x, size).sum()
+    g, = torch.autograd.grad(pred, [x], create_graph=True, retain_graph=True)
+    return g.pow(2).sum(dim=(1, 2, 3)) * (lambda_R1 * 0.5)
+
+
+def adam_reference(params, grads, state, lr, beta1, beta2, eps=1e-8):
+    """torch.optim.Adam (no weight decay, no amsgrad) single step, functional."""
+    state["step"] = state.get("step", 0) + 1
+    t = state["step"]
+    out = {}
+    for k in params:
+        m = state.setdefault("m." + k, torch.zeros_like(params[k]))
+        v = state.setdefault("v." + k, torch.zeros_like(params[k]))
+        m.mul_(beta1).add_(grads[k], alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(grads[k], grads[k], value=1 - beta2)
+        bc1, bc2 = 1 - beta1 ** t, 1 - beta2 ** t
+        denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
+        out[k] = params[k] - (lr / bc1) * (m / denom)
+    return out

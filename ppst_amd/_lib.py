@@ -81,6 +81,16 @@ _SIGS = {
     "ppst_tensor2im_u8": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ppst_guided_filter_ws": (i64, [i32, i32, i32]),
     "ppst_guided_filter": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp]),
+    "ppst_conv_wgrad_f32": (i32, [vp, vp, vp, vp, vp] + [i32] * 11 + [vp]),
+    "ppst_wgrad_scatter": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, f32, i32, vp]),
+    "ppst_wgrad_small_cin_ws": (i64, [i64, i32, i32]),
+    "ppst_wgrad_small_cin": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp]),
+    "ppst_colsum_ws": (i64, [i64, i32]),
+    "ppst_colsum": (i32, [vp, vp, vp, i64, i32, i32, f32, i32, vp]),
+    "ppst_linear_wgrad": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, vp]),
+    "ppst_linear_dgrad": (i32, [vp, vp, vp, i32, i32, i32, f32, vp]),
+    "ppst_lsgan": (i32, [vp, vp, vp, i32, f32, f32, vp]),
+    "ppst_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]),
     "ppst_prof_enable": (i32, [i32]),
     "ppst_prof_collect": (i32, [ctypes.POINTER(f64), ctypes.POINTER(i64), ctypes.POINTER(f64)]),
     "ppst_prof_detail": (i32, [i32, ctypes.POINTER(f64), ctypes.POINTER(f64), ctypes.POINTER(i32)]),

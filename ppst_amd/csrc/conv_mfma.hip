@@ -379,6 +379,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
       float4 v = *(const float4*)(tw + p * 36 + f8 * 4);
       if (nok && ty < a.tile_h && tx < a.tile_w) {
         const int oy = ty * a.out_sy + (a.n_groups > 1 ? gy : 0), ox = tx * a.out_sx + (a.n_groups > 1 ? gx : 0);
+        if (oy >= a.out_h || ox >= a.out_w) continue;  // odd scattered extents (input gradient of a stride-2 conv)
         const int64_t opix = ((int64_t)b * a.out_h + oy) * a.out_w + ox;
         float nz = a.noise ? a.noise_weight * a.noise[opix] : 0.f;
         float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -581,10 +582,8 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       a->precision > 1 || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128) || (a->residual && a->res_ld < a->cout) ||
       (a->tile_rows != 16) || (a->in_scale_shift && a->in_c <= 0))
     return PPST_EINVAL;
-  // the scattered output must stay inside the output tensor
-  if ((a->tile_h - 1) * a->out_sy + (a->n_groups > 1 ? 1 : 0) >= a->out_h ||
-      (a->tile_w - 1) * a->out_sx + (a->n_groups > 1 ? 1 : 0) >= a->out_w)
-    return PPST_EINVAL;
+  // the scattered output must reach into the output tensor (elements beyond it are dropped)
+  if ((a->tile_h - 1) * a->out_sy >= a->out_h || (a->tile_w - 1) * a->out_sx >= a->out_w) return PPST_EINVAL;
   if (a->B == 0) return PPST_OK;
   if (!a->x || !a->wpack || !a->steps || !a->y) return PPST_ENULL;
   ConvKArgs k;

@@ -1,0 +1,303 @@
+// Backward / optimiser kernels of the GAN train step (reference:
+// optimizers/ppst_optimizer.py:96-130 discriminator update, torch autograd of F.conv2d /
+// F.linear inside models/networks/stylegan2_layers.py).
+//
+//  * conv weight gradient: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) with the reduction over
+//    pixels.  NHWC makes both operands lane-contiguous for that instruction (A = dY[p][n0+i],
+//    B = X[p+tap][c0+j], k = 2 consecutive pixels), so fragments come straight from L1/L2
+//    with 128-B coalesced loads: no LDS, no transposition.  It shares the forward's step
+//    table, so plain, 1x1 and space-to-depth (stride-2) convs are one code path.
+//  * conv input gradient: not here -- it is the forward kernel (ppst_conv2d_mfma) run on a
+//    transposed / flipped pack of the same weights.
+//  * small glue: scatter of the per-step gradients into the (Cout,Cin,k,k) parameter layout,
+//    FromRGB weight gradient, column sums (bias gradients), linear layer gradients, LSGAN
+//    loss/gradient, Adam.
+#include "common.h"
+
+// ------------------------------------------------------------ conv wgrad ----
+// partial[split][step][n][32] = sum over this split's pixels of dY[p][n] * X[p + tap(step)][chan(step) + k]
+// grid = (cout/128 n-tiles, chunks, splits); block = 4 waves, wave w owns n = n0 + 32w .. +31;
+// one block handles ONE chunk = up to 9 consecutive steps that share chan_off (registers: 9 x 16).
+#define WG_MAXT 9
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const int4* __restrict__ steps, const int* __restrict__ chunk_start,
+                                                         float* __restrict__ partial, int B, int in_h, int in_w, int in_ld,
+                                                         int oh, int ow, int dy_ld, int cout, int nsteps, int rows_per_split) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const int n = blockIdx.x * 128 + wave * 32 + li;
+  const int s0 = chunk_start[blockIdx.y], s1 = chunk_start[blockIdx.y + 1];
+  const int T = s1 - s0;
+  const int chan = steps[s0].x;
+  int tdy[WG_MAXT], tdx[WG_MAXT];
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t) {
+    int4 d = steps[s0 + (t < T ? t : 0)];
+    tdy[t] = d.y; tdx[t] = d.z;
+  }
+  f32x16 acc[WG_MAXT];
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  const int rows_total = B * oh;
+  const int r_begin = blockIdx.z * rows_per_split;
+  const int r_end = min(r_begin + rows_per_split, rows_total);
+  const bool nok = n < cout;
+  for (int r = r_begin; r < r_end; ++r) {
+    const int b = r / oh, y = r - b * oh;
+    const float* dyr = dy + ((int64_t)(b * oh + y) * ow) * dy_ld + n;
+    const float* xb = x + (int64_t)b * in_h * in_w * in_ld + chan + li;
+    for (int x0 = 0; x0 < ow; x0 += 2) {
+      const int xx = x0 + lk;
+      const float av = (nok && xx < ow) ? dyr[(int64_t)xx * dy_ld] : 0.f;
+#pragma unroll
+      for (int t = 0; t < WG_MAXT; ++t) {
+        if (t < T) {
+          const int iy = y + tdy[t], ix = xx + tdx[t];
+          float bv = 0.f;
+          if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w && xx < ow) bv = xb[((int64_t)iy * in_w + ix) * in_ld];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D tile: col = lane&31 (k within the 32-channel chunk), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (n)
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t) {
+    if (t < T) {
+      float* o = partial + (((int64_t)blockIdx.z * nsteps + s0 + t) * cout) * 32;
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        int nn = blockIdx.x * 128 + wave * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * lk;
+        if (nn < cout) o[(int64_t)nn * 32 + li] = acc[t][rg];
+      }
+    }
+  }
+}
+
+extern "C" int ppst_conv_wgrad_f32(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial,
+                                   int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
+                                   int nchunks, int splits, void* stream) {
+  if (B < 0 || in_h <= 0 || in_w <= 0 || in_ld <= 0 || oh <= 0 || ow <= 0 || dy_ld < cout || cout <= 0 || nsteps <= 0 ||
+      nchunks <= 0 || splits <= 0)
+    return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !dy || !steps || !chunk_start || !partial) return PPST_ENULL;
+  int rows_total = B * oh;
+  int rps = cdiv(rows_total, splits);
+  dim3 grid(cdiv(cout, 128), nchunks, splits);
+  PPST_LAUNCH(conv_wgrad_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (const int4*)steps,
+              (const int*)chunk_start, (float*)partial, B, in_h, in_w, in_ld, oh, ow, dy_ld, cout, nsteps, rps);
+  return PPST_LAUNCH_CHECK();
+}
+
+// dW[n][src_c+k][ky][kx] (strides sn, sc, sy, sx) (+)= scale * sum_splits partial[split][step][n][k]
+__global__ __launch_bounds__(256) void wgrad_scatter_kernel(const float* __restrict__ partial, const int* __restrict__ src_c,
+                                                            const int* __restrict__ src_ky, const int* __restrict__ src_kx,
+                                                            float* __restrict__ dw, int64_t sn, int64_t sc, int64_t sy, int64_t sx,
+                                                            int cout, int nsteps, int splits, float scale, int accumulate,
+                                                            int64_t total) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int k = (int)(t & 31);
+    int64_t r = t >> 5;
+    int n = (int)(r % cout);
+    int s = (int)(r / cout);
+    if (src_c[s] < 0) continue;  // zero-weight pad step
+    float v = 0.f;
+    for (int sp = 0; sp < splits; ++sp) v += partial[(((int64_t)sp * nsteps + s) * cout + n) * 32 + k];
+    float* o = dw + n * sn + (int64_t)(src_c[s] + k) * sc + src_ky[s] * sy + src_kx[s] * sx;
+    *o = accumulate ? *o + v * scale : v * scale;
+  }
+}
+extern "C" int ppst_wgrad_scatter(const void* partial, const void* src_c, const void* src_ky, const void* src_kx, void* dw,
+                                  int64_t sn, int64_t sc, int64_t sy, int64_t sx, int cout, int nsteps, int splits, float scale,
+                                  int accumulate, void* stream) {
+  if (cout <= 0 || nsteps <= 0 || splits <= 0) return PPST_EINVAL;
+  if (!partial || !src_c || !src_ky || !src_kx || !dw) return PPST_ENULL;
+  int64_t total = (int64_t)nsteps * cout * 32;
+  int64_t blocks = cdiv64(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  PPST_LAUNCH(wgrad_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)partial, (const int*)src_c,
+              (const int*)src_ky, (const int*)src_kx, (float*)dw, sn, sc, sy, sx, cout, nsteps, splits, scale, accumulate, total);
+  return PPST_LAUNCH_CHECK();
+}
+
+// FromRGB weight gradient: dw[n][c] (+)= scale * sum_p dy[p][n] * x[p][c], c < cin <= 4.
+// One block per 64-pixel-row slab: lane = n (<= 64 per pass), partial sums through atomics-free
+// two-stage reduction: partial[block][n][cin] then summed by the scatter-style finalize below.
+__global__ __launch_bounds__(256) void wgrad_small_cin_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ partial, int64_t npix, int cin, int in_ld,
+                                                              int cout, int64_t pix_per_block) {
+  __shared__ float sm[4][64][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t p0 = (int64_t)blockIdx.x * pix_per_block, p1 = min(p0 + pix_per_block, npix);
+  for (int nb = 0; nb < cout; nb += 64) {
+    const int n = nb + lane;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < cout)
+      for (int64_t p = p0 + w; p < p1; p += 4) {
+        float g = dy[p * cout + n];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < cin) a[c] += g * x[p * in_ld + c];
+      }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sm[w][lane][c] = a[c];
+    __syncthreads();
+    if (w == 0 && n < cout)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < cin) partial[((int64_t)blockIdx.x * cout + n) * cin + c] = sm[0][lane][c] + sm[1][lane][c] + sm[2][lane][c] + sm[3][lane][c];
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void sum_blocks_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblocks,
+                                                         int64_t n, float scale, int accumulate) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += (double)partial[(int64_t)b * n + i];
+  float v = (float)s * scale;
+  out[i] = accumulate ? out[i] + v : v;
+}
+extern "C" int64_t ppst_wgrad_small_cin_ws(int64_t npix, int cin, int cout) { return cdiv64(npix, 4096) * cout * cin * (int64_t)sizeof(float); }
+extern "C" int ppst_wgrad_small_cin(const void* x, const void* dy, void* dw, void* ws, int64_t npix, int cin, int in_ld, int cout,
+                                    float scale, int accumulate, void* stream) {
+  if (npix <= 0 || cin <= 0 || cin > 4 || in_ld < cin || cout <= 0) return PPST_EINVAL;
+  if (!x || !dy || !dw || !ws) return PPST_ENULL;
+  int nblocks = (int)cdiv64(npix, 4096);
+  PPST_LAUNCH(wgrad_small_cin_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (float*)ws,
+              npix, cin, in_ld, cout, (int64_t)4096);
+  int e = PPST_LAUNCH_CHECK();
+  if (e) return e;
+  int64_t n = (int64_t)cout * cin;
+  PPST_LAUNCH(sum_blocks_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, as_stream(stream), (const float*)ws, (float*)dw, nblocks,
+              n, scale, accumulate);
+  return PPST_LAUNCH_CHECK();
+}
+
+// column sums: out[c] (+)= scale * sum over rows of x[row][c]  (bias gradients; rows = B*H*W)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t rows,
+                                                             int C, int ld, int64_t rows_per_block) {
+  __shared__ float sm[256];
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, rows);
+  int lanes = 1;
+  while (lanes < C && lanes < 256) lanes <<= 1;
+  const int nrows = 256 / lanes, cl = threadIdx.x % lanes, pr = threadIdx.x / lanes;
+  for (int cb = 0; cb < C; cb += lanes) {
+    int c = cb + cl;
+    float a = 0.f;
+    if (c < C)
+      for (int64_t r = r0 + pr; r < r1; r += nrows) a += x[r * ld + c];
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    if (pr == 0 && c < C) {
+      for (int q = 1; q < nrows; ++q) a += sm[q * lanes + cl];
+      partial[(int64_t)blockIdx.x * C + c] = a;
+    }
+    __syncthreads();
+  }
+}
+extern "C" int64_t ppst_colsum_ws(int64_t rows, int C) { return cdiv64(rows, 2048) * C * (int64_t)sizeof(float); }
+extern "C" int ppst_colsum(const void* x, void* out, void* ws, int64_t rows, int C, int ld, float scale, int accumulate, void* stream) {
+  if (rows <= 0 || C <= 0 || ld < C) return PPST_EINVAL;
+  if (!x || !out || !ws) return PPST_ENULL;
+  int nblocks = (int)cdiv64(rows, 2048);
+  PPST_LAUNCH(colsum_partial_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), (const float*)x, (float*)ws, rows, C, ld, (int64_t)2048);
+  int e = PPST_LAUNCH_CHECK();
+  if (e) return e;
+  PPST_LAUNCH(sum_blocks_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), (const float*)ws, (float*)out, nblocks, (int64_t)C,
+              scale, accumulate);
+  return PPST_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------- linear ----
+// dW[n][k] (+)= scale * sum_b dY[b][n] * X[b][k] ;  dX[b][k] = scale * sum_n dY[b][n] * W[n][k]
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
+                                                           int B, int N, int K, float scale, int accumulate, int64_t total) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int k = (int)(t % K), n = (int)(t / K);
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dy[(int64_t)b * N + n] * x[(int64_t)b * K + k];
+    dw[t] = accumulate ? dw[t] + s * scale : s * scale;
+  }
+}
+__global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                           int B, int N, int K, float scale, int64_t total) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int k = (int)(t % K), b = (int)(t / K);
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dy[(int64_t)b * N + n] * w[(int64_t)n * K + k];
+    dx[t] = s * scale;
+  }
+}
+extern "C" int ppst_linear_wgrad(const void* dy, const void* x, void* dw, int B, int N, int K, float scale, int accumulate, void* stream) {
+  if (B <= 0 || N <= 0 || K <= 0) return PPST_EINVAL;
+  if (!dy || !x || !dw) return PPST_ENULL;
+  int64_t total = (int64_t)N * K, blocks = cdiv64(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  PPST_LAUNCH(linear_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)dy, (const float*)x, (float*)dw, B, N,
+              K, scale, accumulate, total);
+  return PPST_LAUNCH_CHECK();
+}
+extern "C" int ppst_linear_dgrad(const void* dy, const void* w, void* dx, int B, int N, int K, float scale, void* stream) {
+  if (B <= 0 || N <= 0 || K <= 0) return PPST_EINVAL;
+  if (!dy || !w || !dx) return PPST_ENULL;
+  int64_t total = (int64_t)B * K, blocks = cdiv64(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  PPST_LAUNCH(linear_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)dy, (const float*)w, (float*)dx, B, N, K,
+              scale, total);
+  return PPST_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------ loss / Adam ----
+// LSGAN (models/networks/loss.py:11-18): loss = weight * mean((p - target)^2); grad[i] = weight * 2 (p_i - target) / n
+__global__ void lsgan_kernel(const float* __restrict__ pred, float* __restrict__ loss, float* __restrict__ grad, int n, float target,
+                             float weight) {
+  __shared__ float sm[64];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    float d = pred[i] - target;
+    s += d * d;
+    if (grad) grad[i] = weight * 2.f * d / (float)n;
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 64; ++i) t += sm[i];
+    loss[0] = weight * t / (float)n;
+  }
+}
+extern "C" int ppst_lsgan(const void* pred, void* loss, void* grad, int n, float target, float weight, void* stream) {
+  if (n <= 0) return PPST_EINVAL;
+  if (!pred || !loss) return PPST_ENULL;
+  PPST_LAUNCH(lsgan_kernel, dim3(1), dim3(64), 0, as_stream(stream), (const float*)pred, (float*)loss, (float*)grad, n, target, weight);
+  return PPST_LAUNCH_CHECK();
+}
+
+// torch.optim.Adam step (no weight decay / amsgrad): m, v updated in place, p <- p - lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   int64_t n, float lr, float b1, float b2, float eps, float bc1, float sqrt_bc2) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float gi = g[i];
+    float mi = m[i] * b1 + gi * (1.f - b1);
+    float vi = v[i] * b2 + gi * gi * (1.f - b2);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= (lr / bc1) * (mi / (sqrtf(vi) / sqrt_bc2 + eps));
+  }
+}
+extern "C" int ppst_adam_step(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
+                              void* stream) {
+  if (n < 0 || step <= 0) return PPST_EINVAL;
+  if (n == 0) return PPST_OK;
+  if (!p || !g || !m || !v) return PPST_ENULL;
+  float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  int64_t blocks = cdiv64(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  PPST_LAUNCH(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (float*)p, (const float*)g, (float*)m, (float*)v, n, lr, beta1,
+              beta2, eps, bc1, sqrtf(bc2));
+  return PPST_LAUNCH_CHECK();
+}

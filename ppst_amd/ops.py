@@ -205,14 +205,65 @@ class ConvPlan:
                                 src.append((32 * c, ky, kx))
                                 first = False
             sn, sc, sy, sx = 16, cout * 16, 4, 1
+        elif kind == "dgrad":
+            # input gradient of a stride-1 conv (zero padding): a conv of dY with the transposed,
+            # flipped weights  Wd[c][n][ky][kx] = W[n][c][k-1-ky][k-1-kx]  -- same memory, other strides
+            assert k in (1, 3)
+            self.n_groups = 1
+            self.halo = 0 if k == 1 else 1
+            nchunk = cout // 32                      # the reduction now runs over the forward's Cout
+            assert cout % 32 == 0
+            for c in range(nchunk):
+                first = True
+                for ky in range(k):
+                    for kx in range(k):
+                        steps.append((32 * c, ky - k // 2, kx - k // 2, 1 if first else 0))
+                        src.append((32 * c, ky, kx))
+                        first = False
+            wsrc = w.view(-1)[k * k - 1:]            # element (ky', kx') = (0,0) is W[..][k-1][k-1]
+            sn, sc, sy, sx = k * k, cin * k * k, -k, -1
+            self.cout, self.cin = cin, cout          # roles swap
+            cout, cin = cin, cout
+            self.bn = 128 if cout >= 128 else 64
+        elif kind == "dgrad_s2d":
+            # input gradient of the stride-2 3x3 conv: element i = 2q+p of the (blurred) input grid
+            # receives  sum_{ky = p (mod 2)} W[.,.,ky,.]^T dY[q - ky//2]  -> 4 output phases scattered
+            # with stride 2, like the transposed conv; groups are padded to 4 steps per chunk.
+            assert k == 3 and cout % 32 == 0
+            self.n_groups = 4
+            self.halo = 1
+            taps = {0: [(0, 0), (-1, 2)], 1: [(0, 1)]}
+            for py in range(2):
+                for px in range(2):
+                    for c in range(cout // 32):
+                        tl = [(dy, dx, ky, kx) for dy, ky in taps[py] for dx, kx in taps[px]]
+                        for i in range(4):
+                            if i < len(tl):
+                                dy, dx, ky, kx = tl[i]
+                                steps.append((32 * c, dy, dx, 1 if i == 0 else 0))
+                                src.append((32 * c, ky, kx))
+                            else:
+                                steps.append((32 * c, 0, 0, 0))
+                                src.append((-1, 0, 0))
+            wsrc = w
+            sn, sc, sy, sx = 9, cin * 9, 3, 1     # n' = c (stride 9), c' = n (stride cin*9), no flip
+            self.cout, self.cin = cin, cout
+            cout, cin = cin, cout
+            self.bn = 128 if cout >= 128 else 64
         else:
             raise ValueError(kind)
+        self.src = src
+        self.wstrides = (sn, sc, sy, sx)
         self.nsteps = len(steps) // self.n_groups
         self.flop_steps = sum(1 for t in src if t[0] >= 0) // self.n_groups
         dev = w.device
         self.steps = torch.tensor(steps, dtype=torch.int32, device=dev).contiguous()
         s = torch.tensor(src, dtype=torch.int32, device=dev)
         src_c, src_ky, src_kx = s[:, 0].contiguous(), s[:, 1].contiguous(), s[:, 2].contiguous()
+        self.src_dev = (src_c, src_ky, src_kx)
+        cs = [i for i, t in enumerate(steps) if t[3] == 1] + [len(steps)]
+        self.chunk_start = torch.tensor(cs, dtype=torch.int32, device=dev)
+        self.scale = float(scale)
         n_tiles = (cout + self.bn - 1) // self.bn
         npl = 8 if self.precision == 0 else 4
         self.wpack = torch.empty(self.n_groups * n_tiles * self.nsteps * npl * self.bn * 8, dtype=torch.int16, device=dev)
@@ -226,6 +277,9 @@ class ConvPlan:
         B, H, W, _ = x.shape
         if self.kind == "convT":
             th, tw, oh, ow, osy = H, W, 2 * H, 2 * W, 2
+        elif self.kind == "dgrad_s2d":
+            oh, ow = out_hw                      # extent of the (blurred) tensor the forward conv read
+            th, tw, osy = (oh + 1) // 2, (ow + 1) // 2, 2
         elif self.kind == "s2d":
             oh, ow = out_hw
             th, tw, osy = oh, ow, 1
@@ -263,6 +317,95 @@ class ConvPlan:
         if stats:
             return out, st
         return out
+
+
+def conv_wgrad(plan, x, dy, splits=None):
+    """Weight gradient of the conv described by forward ``plan`` ('conv' or 's2d'):
+    x = the tensor the forward conv read (NHWC, or the space-to-depth tensor for 's2d'),
+    dy = gradient w.r.t. the conv output (before bias/activation).  Returns dW shaped
+    (Cout, Cin, k, k), already multiplied by the plan's weight scale (EqualConv2d)."""
+    assert plan.kind in ("conv", "s2d")
+    in_ld = _nhwc_ld(x, "x")
+    dy_ld = _nhwc_ld(dy, "dy")
+    B, H, W, _ = x.shape
+    _, oh, ow, cout = dy.shape
+    assert cout == plan.cout
+    nchunks = plan.chunk_start.numel() - 1
+    if splits is None:
+        splits = max(1, min(64, (2048 + nchunks * ((cout + 127) // 128) - 1) // (nchunks * ((cout + 127) // 128))))
+        splits = min(splits, B * oh)
+    partial = torch.empty((splits, plan.nsteps, cout, 32), device=x.device, dtype=torch.float32)
+    check(lib.ppst_conv_wgrad_f32(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), B, H, W, in_ld, oh, ow, dy_ld,
+                                  cout, plan.nsteps, nchunks, splits, _stream()), "ppst_conv_wgrad_f32")
+    dw = torch.zeros((plan.cout, plan.cin, plan.k, plan.k), device=x.device, dtype=torch.float32)
+    sn, sc, sy, sx = plan.wstrides
+    c_, ky_, kx_ = plan.src_dev
+    check(lib.ppst_wgrad_scatter(_p(partial), _p(c_), _p(ky_), _p(kx_), _p(dw), sn, sc, sy, sx, cout, plan.nsteps, splits,
+                                 plan.scale, 0, _stream()), "ppst_wgrad_scatter")
+    return dw
+
+
+def wgrad_small_cin(x, dy, scale):
+    """FromRGB: x (B,H,W,cin<=4), dy (B,H,W,cout) -> dW (cout, cin, 1, 1)."""
+    in_ld = _nhwc_ld(x)
+    B, H, W, cin = x.shape
+    cout = dy.shape[3]
+    assert _nhwc_ld(dy) == cout
+    ws = torch.empty(lib.ppst_wgrad_small_cin_ws(B * H * W, cin, cout) // 4, device=x.device, dtype=torch.float32)
+    dw = torch.empty((cout, cin, 1, 1), device=x.device, dtype=torch.float32)
+    check(lib.ppst_wgrad_small_cin(_p(x), _p(dy), _p(dw), _p(ws), B * H * W, cin, in_ld, cout, float(scale), 0, _stream()),
+          "ppst_wgrad_small_cin")
+    return dw
+
+
+def colsum(x2d, scale=1.0):
+    """x2d (rows, C) [row stride ld] -> (C,) column sums (bias gradients)."""
+    _chk(x2d)
+    rows, C = x2d.shape
+    ld = x2d.stride(0)
+    assert x2d.stride(1) == 1
+    ws = torch.empty(lib.ppst_colsum_ws(rows, C) // 4, device=x2d.device, dtype=torch.float32)
+    out = torch.empty((C,), device=x2d.device, dtype=torch.float32)
+    check(lib.ppst_colsum(_p(x2d), _p(out), _p(ws), rows, C, ld, float(scale), 0, _stream()), "ppst_colsum")
+    return out
+
+
+def linear_wgrad(dy, x, scale=1.0):
+    _chk(dy); _chk(x)
+    dy, x = dy.contiguous(), x.contiguous()
+    B, N = dy.shape
+    K = x.shape[1]
+    dw = torch.empty((N, K), device=x.device, dtype=torch.float32)
+    check(lib.ppst_linear_wgrad(_p(dy), _p(x), _p(dw), B, N, K, float(scale), 0, _stream()), "ppst_linear_wgrad")
+    return dw
+
+
+def linear_dgrad(dy, w, scale=1.0):
+    _chk(dy); _chk(w)
+    dy, w = dy.contiguous(), w.detach().contiguous()
+    B, N = dy.shape
+    K = w.shape[1]
+    dx = torch.empty((B, K), device=dy.device, dtype=torch.float32)
+    check(lib.ppst_linear_dgrad(_p(dy), _p(w), _p(dx), B, N, K, float(scale), _stream()), "ppst_linear_dgrad")
+    return dx
+
+
+def lsgan(pred, target, weight):
+    """(loss (1,), dloss/dpred) of weight*mean((pred-target)^2)."""
+    _chk(pred)
+    pred = pred.contiguous()
+    loss = torch.empty((1,), device=pred.device, dtype=torch.float32)
+    grad = torch.empty_like(pred)
+    check(lib.ppst_lsgan(_p(pred), _p(loss), _p(grad), pred.numel(), float(target), float(weight), _stream()), "ppst_lsgan")
+    return loss, grad
+
+
+def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step):
+    for t in (p, g, m, v):
+        _chk(t)
+        assert t.is_contiguous()
+    check(lib.ppst_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps), int(step),
+                             _stream()), "ppst_adam_step")
 
 
 def conv1x1_small_cin(x, w, bias, wscale, act):

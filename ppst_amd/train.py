@@ -1,0 +1,229 @@
+"""Discriminator update of the GAN train step on HIP kernels.
+
+Reference: PPSTOptimizer.train_discriminator_one_step (optimizers/ppst_optimizer.py:96-130)
+-> PPSTModel.compute_discriminator_losses (models/ppst_model.py:105-138): the frozen E1/E2/G
+produce ``rec`` (half batch) and ``mix`` under no_grad, D classifies real / rec / mix with the
+LSGAN loss (loss.py:11-18), ``sum(v.mean())`` is back-propagated through D only and Adam
+(lr*c, betas**c, c = R1_every/(1+R1_every)) updates D.  Data parallel: one process per GPU,
+gradients averaged with one flat all-reduce (RCCL over xGMI; 29.0 M fp32 = 116 MB, SURVEY
+section 2 "Collective call sites") before the optimiser step.
+
+Everything numerical is a HIP kernel: the forward kernels of the inference path (unfused
+where the backward needs the pre-merge activation), the conv input gradient = the same MFMA
+conv kernel on a transposed / flipped pack, the conv weight gradient = fp32-MFMA reduction over
+pixels (csrc/train.hip).  Not built yet: the lazy R1 penalty (double backward) and the
+generator/encoder update (compute_generator_losses) -- see DESIGN.md.
+"""
+import math
+
+import torch
+
+from . import ops, weights
+from .networks.base_network import to_nhwc
+
+SQRT2 = math.sqrt(2.0)
+INV_SQRT2 = 1.0 / SQRT2
+
+
+def _lrelu_bwd(g, out, scale=1.0):
+    """grad wrt the pre-activation of y = lrelu(x)*sqrt2 given grad wrt y, gated by sign(y)
+    (fused_bias_act_kernel.cu:43); ``scale`` folds an upstream constant factor in."""
+    return ops.fused_bias_act_raw(g, None, out, 3, 1, 0.2, SQRT2 * scale)
+
+
+class DiscriminatorTrainer:
+    """Owns D's parameters (views into one flat buffer), their gradients and Adam state."""
+
+    def __init__(self, D, lr=1e-3, beta1=0.0, beta2=0.99, R1_once_every=16, world=1):
+        self.D = D
+        self.size = D.size
+        c = R1_once_every / (1 + R1_once_every)
+        self.lr, self.b1, self.b2, self.eps = lr * c, beta1 ** c, beta2 ** c, 1e-8
+        self.step_count = 0
+        self.world = world
+        # flatten parameters so the all-reduce and Adam are single launches
+        self.names = [n for n, _ in D.named_parameters()]
+        params = [p for _, p in D.named_parameters()]
+        self.sizes = [p.numel() for p in params]
+        flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+        self.flat = flat
+        off = 0
+        for p, n in zip(params, self.sizes):
+            p.data = flat[off:off + n].view_as(p)
+            off += n
+        D._flat.clear(); D._cache.clear()
+        self.grad = torch.zeros_like(flat)
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+        self.offsets = {}
+        off = 0
+        for n_, sz in zip(self.names, self.sizes):
+            self.offsets[n_] = (off, sz)
+            off += sz
+
+    def g(self, name):
+        off, sz = self.offsets[name]
+        return self.grad[off:off + sz]
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, img):
+        """D forward keeping what the backward needs.  img NCHW.  Returns (pred (B,1), tape)."""
+        D, p = self.D, "stylegan2_D."
+        tape = {}
+        x0 = to_nhwc(img)
+        x0 = x0 if x0.is_contiguous() else x0.contiguous()
+        tape["img"] = x0
+        x = D.from_rgb(x0, p + "convs.0.")
+        tape["x0"] = x
+        blocks = []
+        for name in weights.discriminator_block_names(self.size):
+            q = p + "convs.%s." % name
+            B, S, _, cin = x.shape
+            k = D.p(q + "conv2.Blur.kernel")
+            sc1, scs = 1.0 / math.sqrt(cin * 9), 1.0 / math.sqrt(cin)
+            y1 = D.plan(q + "conv1.Conv.weight", scale=sc1)(x, bias=D.p(q + "conv1.Act.bias"), act=ops.ACT_LRELU)
+            xs, _ = ops.blur_nhwc(x, D.p(q + "skip.Blur.kernel"), 1, 1, ops.PAD_ZERO, down=2)
+            skip = D.plan(q + "skip.Conv.weight", scale=scs)(xs)
+            xb, bhw = ops.blur_nhwc(y1, k, 2, 2, ops.PAD_ZERO, s2d=True)
+            ohw = ((bhw[0] - 3) // 2 + 1, (bhw[1] - 3) // 2 + 1)
+            a2 = D.plan(q + "conv2.Conv.weight", "s2d", sc1)(xb, bias=D.p(q + "conv2.Act.bias"), act=ops.ACT_LRELU, out_hw=ohw)
+            out = ops.affine_act(a2, None, res=skip, out_scale=INV_SQRT2)
+            blocks.append(dict(q=q, x=x, y1=y1, xs=xs, xb=xb, bhw=bhw, a2=a2, cin=cin, S=S))
+            x = out
+        tape["blocks"] = blocks
+        cin = x.shape[3]
+        fc = D.plan(p + "final_conv.Conv.weight", scale=1.0 / math.sqrt(cin * 9))(x, bias=D.p(p + "final_conv.Act.bias"), act=ops.ACT_LRELU)
+        tape["x_last"], tape["fc"] = x, fc
+        f = ops.nhwc_to_nchw(fc).reshape(fc.shape[0], -1)
+        w0, w1 = D.p(p + "final_linear.0.weight"), D.p(p + "final_linear.1.weight")
+        h = ops.linear(f, w0, D.p(p + "final_linear.0.bias"), wscale=1.0 / math.sqrt(w0.shape[1]), act=ops.ACT_LRELU)
+        pred = ops.linear(h, w1, D.p(p + "final_linear.1.bias"), wscale=1.0 / math.sqrt(w1.shape[1]))
+        tape["f"], tape["h"] = f, h
+        return pred, tape
+
+    # --------------------------------------------------------------- backward
+    def _acc(self, name, val):
+        g = self.g("stylegan2_D." + name)
+        g.add_(val.reshape(-1))  # gradient accumulation over the real / rec / mix passes (memory op)
+
+    def backward(self, tape, dpred):
+        D, p = self.D, "stylegan2_D."
+        w0, w1 = D.p(p + "final_linear.0.weight"), D.p(p + "final_linear.1.weight")
+        s0, s1 = 1.0 / math.sqrt(w0.shape[1]), 1.0 / math.sqrt(w1.shape[1])
+        f, h = tape["f"], tape["h"]
+        # final_linear.1 (EqualLinear 512 -> 1)
+        self._acc("final_linear.1.weight", ops.linear_wgrad(dpred, h, s1))
+        self._acc("final_linear.1.bias", ops.colsum(dpred))
+        dh = ops.linear_dgrad(dpred, w1, s1)
+        # final_linear.0 (EqualLinear 8192 -> 512, fused lrelu)
+        gpre = _lrelu_bwd(dh, h)
+        self._acc("final_linear.0.weight", ops.linear_wgrad(gpre, f, s0))
+        self._acc("final_linear.0.bias", ops.colsum(gpre))
+        df = ops.linear_dgrad(gpre, w0, s0)
+        fc = tape["fc"]
+        B, hh, ww, C = fc.shape
+        dfc = ops.nchw_to_nhwc(df.view(B, C, hh, ww))
+        # final_conv (3x3 + fused lrelu)
+        gpre = _lrelu_bwd(dfc, fc)
+        plan = D.plan(p + "final_conv.Conv.weight", scale=1.0 / math.sqrt(tape["x_last"].shape[3] * 9))
+        self._acc("final_conv.Conv.weight", ops.conv_wgrad(plan, tape["x_last"], gpre))
+        self._acc("final_conv.Act.bias", ops.colsum(gpre.view(-1, C)))
+        dx = self._dgrad(p + "final_conv.Conv.weight", "dgrad", 1.0 / math.sqrt(tape["x_last"].shape[3] * 9))(gpre)
+        for blk in reversed(tape["blocks"]):
+            q, cin = blk["q"], blk["cin"]
+            name = q[len(p):]
+            sc1, scs = 1.0 / math.sqrt(cin * 9), 1.0 / math.sqrt(cin)
+            cout = blk["a2"].shape[3]
+            # out = (a2 + skip)/sqrt2 ;  a2 = lrelu(conv2 + b)*sqrt2
+            g2 = _lrelu_bwd(dx, blk["a2"], INV_SQRT2)
+            self._acc(name + "conv2.Act.bias", ops.colsum(g2.view(-1, cout)))
+            self._acc(name + "conv2.Conv.weight", ops.conv_wgrad(D.plan(q + "conv2.Conv.weight", "s2d", sc1), blk["xb"], g2))
+            d_xb = self._dgrad(q + "conv2.Conv.weight", "dgrad_s2d", sc1)(g2, out_hw=blk["bhw"])
+            # blur backward: upfirdn2d with the flipped (symmetric) taps and g_pad = (1, 1)
+            kf = torch.flip(D.p(q + "conv2.Blur.kernel"), [0, 1]).contiguous()
+            d_y1, _ = ops.blur_nhwc(d_xb, kf, 1, 1, ops.PAD_ZERO)
+            g1 = _lrelu_bwd(d_y1, blk["y1"])
+            self._acc(name + "conv1.Act.bias", ops.colsum(g1.view(-1, cin)))
+            self._acc(name + "conv1.Conv.weight", ops.conv_wgrad(D.plan(q + "conv1.Conv.weight", scale=sc1), blk["x"], g1))
+            d_xa = self._dgrad(q + "conv1.Conv.weight", "dgrad", sc1)(g1)
+            # skip branch: 1x1 conv on the blurred + decimated input, no bias / activation
+            gs = ops.affine_act(dx, None, out_scale=INV_SQRT2)
+            self._acc(name + "skip.Conv.weight", ops.conv_wgrad(D.plan(q + "skip.Conv.weight", scale=scs), blk["xs"], gs))
+            d_xs = self._dgrad(q + "skip.Conv.weight", "dgrad", scs)(gs)
+            # blur(down=2, pad (1,1)) backward = zero-insert x2 then FIR with g_pad (upfirdn2d.py:116-121)
+            S = blk["S"]
+            ks = D.p(q + "skip.Blur.kernel")
+            ksz = ks.shape[0]
+            oh = d_xs.shape[1]
+            gp0 = ksz - 1 - 1
+            gp1 = S - oh * 2 + 1 - 1 + 1
+            d_xb2 = ops.upfirdn2d_raw(d_xs, torch.flip(ks, [0, 1]).contiguous(), 2, 2, 1, 1, gp0, gp1, gp0, gp1)
+            dx = ops.affine_act(d_xa, None, res=d_xb2)
+        # FromRGB: 1x1 conv (no bias) + fused lrelu
+        x0 = tape["x0"]
+        g0 = _lrelu_bwd(dx, x0)
+        w = D.p(p + "convs.0.Conv.weight")
+        self._acc("convs.0.Act.bias", ops.colsum(g0.view(-1, g0.shape[3])))
+        self._acc("convs.0.Conv.weight", ops.wgrad_small_cin(tape["img"], g0, 1.0 / math.sqrt(w.shape[1])))
+
+    def _dgrad(self, wname, kind, scale):
+        return self.D.plan(wname, kind, scale)
+
+    # ------------------------------------------------------------------- step
+    def losses_and_grads(self, real, rec, mix, lambda_GAN=1.0):
+        """LSGAN losses on real / rec / mix and d(sum of losses)/d(theta_D) into self.grad."""
+        self.grad.zero_()
+        losses = {}
+        for name, img, target, wgt in (("D_real", real, 1.0, lambda_GAN), ("D_rec", rec, 0.0, 0.5 * lambda_GAN),
+                                       ("D_mix", mix, 0.0, 0.5 * lambda_GAN)):
+            if img is None:
+                continue
+            pred, tape = self.forward(img)
+            loss, dpred = ops.lsgan(pred, target, wgt)
+            losses[name] = loss
+            self.backward(tape, dpred)
+            del tape
+        return losses
+
+    def all_reduce(self):
+        """DDP gradient averaging: one flat all-reduce (RCCL when the tensors are on the GPU)."""
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+            self.grad.div_(self.world)
+
+    def adam(self):
+        self.step_count += 1
+        ops.adam_step_(self.flat, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, self.step_count)
+        self.D._cache.clear()  # packed weights are stale
+
+    def train_step(self, model, real, lambda_StyleCon=1.0):
+        """One discriminator iteration: images from the frozen E1/E2/G, losses, backward, all-reduce, Adam."""
+        rec, mix = d_step_images(model, real, lambda_StyleCon)
+        losses = self.losses_and_grads(real, rec, mix)
+        self.all_reduce()
+        self.adam()
+        return losses
+
+
+def d_step_images(model, real, lambda_StyleCon=1.0):
+    """rec (B/2) and mix (B) of compute_discriminator_losses (ppst_model.py:106-131), inference path."""
+    from . import glue
+    B = real.shape[0]
+    assert B % 2 == 0, "Batch size must be even on each GPU."
+    sp = model.E1(real)
+    gl, _ = model.E2(real)
+    _, feas, feas1 = model.G(sp, gl, extract_features=True, noise=model.noise)
+    sps = torch.cat((feas, model.Rselfcorr(feas1)), dim=1)
+    corrms = model.corrm(sps, glue.swap(sps))
+    corr_self = model.corrm(sps, sps)
+    mix = None
+    if lambda_StyleCon > 0.0:
+        _, gl_w = model.E2(real, corrmatrix=corrms)
+        mix = model.G(glue.swap(sp), gl_w, noise=model.noise)
+    _, gl2 = model.E2(real, corrmatrix=corr_self)
+    nz = model.noise
+    if isinstance(nz, dict):
+        nz = {k: v[:B // 2] for k, v in nz.items()}
+    rec = model.G(sp[:B // 2], [g[:B // 2] for g in gl2], noise=nz)
+    return rec, mix

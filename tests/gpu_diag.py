@@ -514,6 +514,46 @@ def t_configs():
         RES.append(("cfg5 bf16 rms", rms < 2e-2)); print("cfg5 single-pass bf16 relative RMS error %.3e" % rms, flush=True)
 
 
+def t_train_d():
+    """Discriminator update (SURVEY 8 a14, D part): LSGAN losses, every parameter gradient and one
+    Adam step against the CPU autograd oracle (oracle/train_oracle.py, pinned to the reference)."""
+    import train_oracle as T
+    from ppst_amd.networks.discriminator import StyleGAN2Discriminator
+    from ppst_amd.train import DiscriminatorTrainer
+    for size, B in ((128, 2), (256, 2)):
+        sd = W.make_state_dict(2, size=size, with_nce=False, bias_std=0.1)
+        D = StyleGAN2Discriminator(None, size=size)
+        D.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith("D.")}, strict=True)
+        D = D.to(dev)
+        tr = DiscriminatorTrainer(D)
+        torch.manual_seed(size)
+        real = torch.rand(B, 3, size, size) * 2 - 1
+        rec = torch.rand(B // 2, 3, size, size) * 2 - 1
+        mix = torch.rand(B, 3, size, size) * 2 - 1
+        lo, gr = T.d_step_grads(sd, real, rec, mix, size=size)
+        losses = tr.losses_and_grads(g(real), g(rec), g(mix))
+        for k in lo:
+            report("D-step %d loss %s" % (size, k), losses[k], torch.tensor([lo[k]]), 1e-4)
+        worst, worst_k = 0.0, ""
+        for k, gref in gr.items():
+            got = tr.g(k[2:]).view_as(gref)
+            r = rel(got, gref)[0]
+            if r > worst:
+                worst, worst_k = r, k
+        ok = worst <= 5e-3  # deep 4x4 / 8x8 layers: few-term sums with cancellation, error relative to max|grad|
+        RES.append(("D-step %d gradients" % size, ok))
+        print("D-step %d: worst relative gradient error %.3e (%s) over %d tensors %s" % (size, worst, worst_k, len(gr), "ok" if ok else "FAIL"), flush=True)
+        # one Adam step
+        keys = list(gr)
+        newp = T.adam_reference({k: sd[k] for k in keys}, gr, {}, tr.lr, tr.b1, tr.b2)
+        tr.adam()
+        w2 = 0.0
+        for k in keys:
+            off, sz = tr.offsets[k[2:]]
+            w2 = max(w2, rel(tr.flat[off:off + sz].view_as(newp[k]), newp[k])[0])
+        RES.append(("D-step %d Adam" % size, w2 <= 1e-3)); print("D-step %d: Adam-updated parameters worst rel diff %.3e" % (size, w2), flush=True)
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     print("device:", torch.cuda.get_device_name(0), flush=True)
@@ -525,6 +565,9 @@ def main():
     if which in ("nets", "all"):
         print("== t_networks", flush=True)
         run(t_networks)
+    if which in ("train", "all"):
+        print("== t_train_d", flush=True)
+        run(t_train_d)
     if which in ("configs", "all"):
         print("== t_configs", flush=True)
         run(t_configs)

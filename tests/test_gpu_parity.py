@@ -55,6 +55,12 @@ def test_grid_1024_and_mask_configs_vs_oracle():
     _run("t_configs")
 
 
+def test_discriminator_train_step_vs_autograd_oracle():
+    """LSGAN losses, all D parameter gradients (conv wgrad/dgrad, blur, lrelu, linear) and one Adam
+    step against oracle/train_oracle.py (CPU autograd, pinned to the reference's own backward)."""
+    _run("t_train_d")
+
+
 def test_swap_matches_reference_golden():
     """The HIP path against the fixtures produced by the *reference itself*
     (oracle/gen_golden.py): sampled activations of the full recipe."""
