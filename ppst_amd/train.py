@@ -187,10 +187,7 @@ class DiscriminatorTrainer:
 
     def all_reduce(self):
         """DDP gradient averaging: one flat all-reduce (RCCL when the tensors are on the GPU)."""
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
-            self.grad.div_(self.world)
+        ddp_average_(self.grad, self.world)
 
     def adam(self):
         self.step_count += 1
@@ -204,6 +201,17 @@ class DiscriminatorTrainer:
         self.all_reduce()
         self.adam()
         return losses
+
+
+def ddp_average_(flat_grad, world):
+    """What DistributedDataParallel does for the reference (models/__init__.py:88): sum the
+    gradients of all ranks and divide by the world size -- here as ONE flat collective instead of
+    25-MB buckets (the whole D gradient is 116 MB; xGMI ring all-reduce ~ 2*(N-1)/N * S / 153 GB/s)."""
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        flat_grad.div_(world)
+    return flat_grad
 
 
 def d_step_images(model, real, lambda_StyleCon=1.0):

@@ -101,6 +101,36 @@ dist.destroy_process_group()
 '''
 
 
+WORKER_DDP = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from ppst_amd.train import ddp_average_
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
+torch.manual_seed(rank)
+g = torch.randn(1000)
+ref = (torch.manual_seed(0), torch.randn(1000))[1] * 0.5 + (torch.manual_seed(1), torch.randn(1000))[1] * 0.5
+out = ddp_average_(g.clone(), world)
+assert torch.allclose(out, ref, atol=1e-6)
+if rank == 0:
+    print("OK")
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_gradient_average(tmp_path):
+    """The train step's only collective (flat gradient all-reduce + divide), world_size 2 on gloo."""
+    script = tmp_path / "w2.py"
+    script.write_text(WORKER_DDP)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29614")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert b"OK" in outs[0][0]
+
+
 def test_two_rank_gloo_sharding(tmp_path):
     """world_size-2 rehearsal (gloo, CPU) of the image-parallel pair sharding + the timing
     reduction bench.py performs."""
