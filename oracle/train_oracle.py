@@ -65,6 +65,19 @@ def r1_loss(sd, real, size=512, lambda_R1=10.0):
     return g.pow(2).sum(dim=(1, 2, 3)) * (lambda_R1 * 0.5)
 
 
+def r1_step_grads(sd, real, size=512, lambda_R1=10.0, R1_once_every=16):
+    """The lazy-R1 iteration of train_discriminator_one_step (optimizers/ppst_optimizer.py:116-126):
+    per-sample penalties and d(mean(penalty) * R1_once_every)/d(theta_D) by double backward."""
+    keys = [k for k in sd if k.startswith("D.") and not k.endswith("Blur.kernel")]
+    sd2 = dict(sd)
+    for k in keys:
+        sd2[k] = sd[k].detach().clone().requires_grad_(True)
+    pen = r1_loss(sd2, real, size, lambda_R1)
+    loss = pen.mean() * R1_once_every
+    grads = torch.autograd.grad(loss, [sd2[k] for k in keys], allow_unused=True)
+    return pen.detach(), {k: (torch.zeros_like(sd[k]) if g is None else g) for k, g in zip(keys, grads)}
+
+
 def adam_reference(params, grads, state, lr, beta1, beta2, eps=1e-8):
     """torch.optim.Adam (no weight decay, no amsgrad) single step, functional."""
     state["step"] = state.get("step", 0) + 1

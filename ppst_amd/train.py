@@ -11,8 +11,9 @@ section 2 "Collective call sites") before the optimiser step.
 Everything numerical is a HIP kernel: the forward kernels of the inference path (unfused
 where the backward needs the pre-merge activation), the conv input gradient = the same MFMA
 conv kernel on a transposed / flipped pack, the conv weight gradient = fp32-MFMA reduction over
-pixels (csrc/train.hip).  Not built yet: the lazy R1 penalty (double backward) and the
-generator/encoder update (compute_generator_losses) -- see DESIGN.md.
+pixels (csrc/train.hip).  The lazy R1 penalty (double backward) is one more forward sweep with
+the same kernels (r1_losses_and_grads).  Not built yet: the generator/encoder update
+(compute_generator_losses) -- see DESIGN.md.
 """
 import math
 
@@ -40,6 +41,8 @@ class DiscriminatorTrainer:
         c = R1_once_every / (1 + R1_once_every)
         self.lr, self.b1, self.b2, self.eps = lr * c, beta1 ** c, beta2 ** c, 1e-8
         self.step_count = 0
+        self.iter_counter = 0            # discriminator_iter_counter (ppst_optimizer.py:103)
+        self.R1_once_every = R1_once_every
         self.world = world
         # flatten parameters so the all-reduce and Adam are single launches
         self.names = [n for n, _ in D.named_parameters()]
@@ -106,29 +109,39 @@ class DiscriminatorTrainer:
         g = self.g("stylegan2_D." + name)
         g.add_(val.reshape(-1))  # gradient accumulation over the real / rec / mix passes (memory op)
 
-    def backward(self, tape, dpred):
+    def backward(self, tape, dpred, param_grads=True, keep=None):
+        """Back-propagate ``dpred`` (B,1) through the taped forward.  ``param_grads`` accumulates
+        d/d(theta_D) into self.grad; ``keep`` (a dict) receives the gradient wrt every conv / linear
+        pre-activation and wrt the image (what the R1 second-order pass contracts against)."""
         D, p = self.D, "stylegan2_D."
+        acc = self._acc if param_grads else (lambda *a: None)
+        pg = param_grads
         w0, w1 = D.p(p + "final_linear.0.weight"), D.p(p + "final_linear.1.weight")
         s0, s1 = 1.0 / math.sqrt(w0.shape[1]), 1.0 / math.sqrt(w1.shape[1])
         f, h = tape["f"], tape["h"]
         # final_linear.1 (EqualLinear 512 -> 1)
-        self._acc("final_linear.1.weight", ops.linear_wgrad(dpred, h, s1))
-        self._acc("final_linear.1.bias", ops.colsum(dpred))
+        if pg:
+            acc("final_linear.1.weight", ops.linear_wgrad(dpred, h, s1))
+            acc("final_linear.1.bias", ops.colsum(dpred))
         dh = ops.linear_dgrad(dpred, w1, s1)
         # final_linear.0 (EqualLinear 8192 -> 512, fused lrelu)
-        gpre = _lrelu_bwd(dh, h)
-        self._acc("final_linear.0.weight", ops.linear_wgrad(gpre, f, s0))
-        self._acc("final_linear.0.bias", ops.colsum(gpre))
-        df = ops.linear_dgrad(gpre, w0, s0)
+        gpre_h = _lrelu_bwd(dh, h)
+        if pg:
+            acc("final_linear.0.weight", ops.linear_wgrad(gpre_h, f, s0))
+            acc("final_linear.0.bias", ops.colsum(gpre_h))
+        df = ops.linear_dgrad(gpre_h, w0, s0)
         fc = tape["fc"]
         B, hh, ww, C = fc.shape
         dfc = ops.nchw_to_nhwc(df.view(B, C, hh, ww))
         # final_conv (3x3 + fused lrelu)
         gpre = _lrelu_bwd(dfc, fc)
-        plan = D.plan(p + "final_conv.Conv.weight", scale=1.0 / math.sqrt(tape["x_last"].shape[3] * 9))
-        self._acc("final_conv.Conv.weight", ops.conv_wgrad(plan, tape["x_last"], gpre))
-        self._acc("final_conv.Act.bias", ops.colsum(gpre.view(-1, C)))
-        dx = self._dgrad(p + "final_conv.Conv.weight", "dgrad", 1.0 / math.sqrt(tape["x_last"].shape[3] * 9))(gpre)
+        scf = 1.0 / math.sqrt(tape["x_last"].shape[3] * 9)
+        if pg:
+            acc("final_conv.Conv.weight", ops.conv_wgrad(D.plan(p + "final_conv.Conv.weight", scale=scf), tape["x_last"], gpre))
+            acc("final_conv.Act.bias", ops.colsum(gpre.view(-1, C)))
+        dx = self._dgrad(p + "final_conv.Conv.weight", "dgrad", scf)(gpre)
+        if keep is not None:
+            keep["dpred"], keep["gpre_h"], keep["gpre_fc"], keep["blocks"] = dpred, gpre_h, gpre, []
         for blk in reversed(tape["blocks"]):
             q, cin = blk["q"], blk["cin"]
             name = q[len(p):]
@@ -136,19 +149,22 @@ class DiscriminatorTrainer:
             cout = blk["a2"].shape[3]
             # out = (a2 + skip)/sqrt2 ;  a2 = lrelu(conv2 + b)*sqrt2
             g2 = _lrelu_bwd(dx, blk["a2"], INV_SQRT2)
-            self._acc(name + "conv2.Act.bias", ops.colsum(g2.view(-1, cout)))
-            self._acc(name + "conv2.Conv.weight", ops.conv_wgrad(D.plan(q + "conv2.Conv.weight", "s2d", sc1), blk["xb"], g2))
+            if pg:
+                acc(name + "conv2.Act.bias", ops.colsum(g2.view(-1, cout)))
+                acc(name + "conv2.Conv.weight", ops.conv_wgrad(D.plan(q + "conv2.Conv.weight", "s2d", sc1), blk["xb"], g2))
             d_xb = self._dgrad(q + "conv2.Conv.weight", "dgrad_s2d", sc1)(g2, out_hw=blk["bhw"])
             # blur backward: upfirdn2d with the flipped (symmetric) taps and g_pad = (1, 1)
             kf = torch.flip(D.p(q + "conv2.Blur.kernel"), [0, 1]).contiguous()
             d_y1, _ = ops.blur_nhwc(d_xb, kf, 1, 1, ops.PAD_ZERO)
             g1 = _lrelu_bwd(d_y1, blk["y1"])
-            self._acc(name + "conv1.Act.bias", ops.colsum(g1.view(-1, cin)))
-            self._acc(name + "conv1.Conv.weight", ops.conv_wgrad(D.plan(q + "conv1.Conv.weight", scale=sc1), blk["x"], g1))
+            if pg:
+                acc(name + "conv1.Act.bias", ops.colsum(g1.view(-1, cin)))
+                acc(name + "conv1.Conv.weight", ops.conv_wgrad(D.plan(q + "conv1.Conv.weight", scale=sc1), blk["x"], g1))
             d_xa = self._dgrad(q + "conv1.Conv.weight", "dgrad", sc1)(g1)
             # skip branch: 1x1 conv on the blurred + decimated input, no bias / activation
             gs = ops.affine_act(dx, None, out_scale=INV_SQRT2)
-            self._acc(name + "skip.Conv.weight", ops.conv_wgrad(D.plan(q + "skip.Conv.weight", scale=scs), blk["xs"], gs))
+            if pg:
+                acc(name + "skip.Conv.weight", ops.conv_wgrad(D.plan(q + "skip.Conv.weight", scale=scs), blk["xs"], gs))
             d_xs = self._dgrad(q + "skip.Conv.weight", "dgrad", scs)(gs)
             # blur(down=2, pad (1,1)) backward = zero-insert x2 then FIR with g_pad (upfirdn2d.py:116-121)
             S = blk["S"]
@@ -159,12 +175,78 @@ class DiscriminatorTrainer:
             gp1 = S - oh * 2 + 1 - 1 + 1
             d_xb2 = ops.upfirdn2d_raw(d_xs, torch.flip(ks, [0, 1]).contiguous(), 2, 2, 1, 1, gp0, gp1, gp0, gp1)
             dx = ops.affine_act(d_xa, None, res=d_xb2)
+            if keep is not None:
+                keep["blocks"].append(dict(g1=g1, g2=g2, gs=gs))
         # FromRGB: 1x1 conv (no bias) + fused lrelu
         x0 = tape["x0"]
         g0 = _lrelu_bwd(dx, x0)
         w = D.p(p + "convs.0.Conv.weight")
-        self._acc("convs.0.Act.bias", ops.colsum(g0.view(-1, g0.shape[3])))
-        self._acc("convs.0.Conv.weight", ops.wgrad_small_cin(tape["img"], g0, 1.0 / math.sqrt(w.shape[1])))
+        sc0 = 1.0 / math.sqrt(w.shape[1])
+        if pg:
+            acc("convs.0.Act.bias", ops.colsum(g0.view(-1, g0.shape[3])))
+            acc("convs.0.Conv.weight", ops.wgrad_small_cin(tape["img"], g0, sc0))
+        if keep is not None:
+            keep["blocks"].reverse()
+            keep["g0"] = g0
+            # d/d(image) = W0^T g0  (3 output channels)
+            wt = w.reshape(w.shape[0], w.shape[1]).t().contiguous()
+            keep["d_img"] = ops.conv1x1_small_cout(g0, wt, None, wscale=sc0)
+
+    # -------------------------------------------------------------- R1 penalty
+    def r1_losses_and_grads(self, real, lambda_R1=10.0, R1_once_every=16):
+        """Lazy R1 (ppst_model.py:140-159, ppst_optimizer.py:116-126): per-sample penalty
+        0.5*lambda*||d sum(D(x)) / dx||^2 and d(mean(penalty) * R1_once_every)/d(theta_D) into self.grad.
+
+        Leaky-ReLU gates are piecewise constant, so g(x) = J(theta)^T 1 is linear in each weight
+        with the taped gates fixed and biases drop out.  Reverse mode over the *backward* pass
+        turns into one more forward sweep: t = dL/dg enters at the image, runs through the same
+        convs / blurs / gates (no biases), and every layer adds wgrad(input = t_in, dy = the
+        first backward's gradient at that layer's pre-activation)."""
+        D, p = self.D, "stylegan2_D."
+        self.grad.zero_()
+        pred, tape = self.forward(real)
+        B = pred.shape[0]
+        ones = torch.ones_like(pred)
+        keep = {}
+        self.backward(tape, ones, param_grads=False, keep=keep)
+        g_img = keep["d_img"]                                    # (B,S,S,3)
+        part = ops.in_stats(g_img)                                # (B, n, 3, 2): per-channel (sum, sumsq) partials
+        pen = torch.stack([ops.colsum(part[b].view(-1, 2), 0.5 * lambda_R1)[1] for b in range(B)])
+        # L = R1_once_every * mean_b(pen_b)  ->  dL/dg = R1_once_every * lambda / B * g
+        t = ops.affine_act(g_img, None, out_scale=R1_once_every * lambda_R1 / B)
+        w = D.p(p + "convs.0.Conv.weight")
+        sc0 = 1.0 / math.sqrt(w.shape[1])
+        self._acc("convs.0.Conv.weight", ops.wgrad_small_cin(t, keep["g0"], sc0))
+        t = ops.conv1x1_small_cin(t, w, None, sc0, ops.ACT_NONE)
+        t = _lrelu_bwd(t, tape["x0"])
+        for blk, kb in zip(tape["blocks"], keep["blocks"]):
+            q, cin = blk["q"], blk["cin"]
+            name = q[len(p):]
+            sc1, scs = 1.0 / math.sqrt(cin * 9), 1.0 / math.sqrt(cin)
+            self._acc(name + "conv1.Conv.weight", ops.conv_wgrad(D.plan(q + "conv1.Conv.weight", scale=sc1), t, kb["g1"]))
+            t1 = D.plan(q + "conv1.Conv.weight", scale=sc1)(t)
+            t1 = _lrelu_bwd(t1, blk["y1"])
+            ts, _ = ops.blur_nhwc(t, D.p(q + "skip.Blur.kernel"), 1, 1, ops.PAD_ZERO, down=2)
+            self._acc(name + "skip.Conv.weight", ops.conv_wgrad(D.plan(q + "skip.Conv.weight", scale=scs), ts, kb["gs"]))
+            tskip = D.plan(q + "skip.Conv.weight", scale=scs)(ts)
+            tb, bhw = ops.blur_nhwc(t1, D.p(q + "conv2.Blur.kernel"), 2, 2, ops.PAD_ZERO, s2d=True)
+            self._acc(name + "conv2.Conv.weight", ops.conv_wgrad(D.plan(q + "conv2.Conv.weight", "s2d", sc1), tb, kb["g2"]))
+            ohw = ((bhw[0] - 3) // 2 + 1, (bhw[1] - 3) // 2 + 1)
+            t2 = D.plan(q + "conv2.Conv.weight", "s2d", sc1)(tb, out_hw=ohw)
+            t2 = _lrelu_bwd(t2, blk["a2"])
+            t = ops.affine_act(t2, None, res=tskip, out_scale=INV_SQRT2)
+        scf = 1.0 / math.sqrt(t.shape[3] * 9)
+        self._acc("final_conv.Conv.weight", ops.conv_wgrad(D.plan(p + "final_conv.Conv.weight", scale=scf), t, keep["gpre_fc"]))
+        t = D.plan(p + "final_conv.Conv.weight", scale=scf)(t)
+        t = _lrelu_bwd(t, tape["fc"])
+        tf = ops.nhwc_to_nchw(t).reshape(B, -1)
+        w0, w1 = D.p(p + "final_linear.0.weight"), D.p(p + "final_linear.1.weight")
+        s0, s1 = 1.0 / math.sqrt(w0.shape[1]), 1.0 / math.sqrt(w1.shape[1])
+        self._acc("final_linear.0.weight", ops.linear_wgrad(keep["gpre_h"], tf, s0))
+        th = ops.linear(tf, w0, None, wscale=s0)
+        th = _lrelu_bwd(th, tape["h"])
+        self._acc("final_linear.1.weight", ops.linear_wgrad(keep["dpred"], th, s1))
+        return {"D_R1": pen}
 
     def _dgrad(self, wname, kind, scale):
         return self.D.plan(wname, kind, scale)
@@ -194,12 +276,19 @@ class DiscriminatorTrainer:
         ops.adam_step_(self.flat, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, self.step_count)
         self.D._cache.clear()  # packed weights are stale
 
-    def train_step(self, model, real, lambda_StyleCon=1.0):
-        """One discriminator iteration: images from the frozen E1/E2/G, losses, backward, all-reduce, Adam."""
+    def train_step(self, model, real, lambda_StyleCon=1.0, lambda_R1=10.0):
+        """One discriminator iteration (ppst_optimizer.py:96-130): images from the frozen E1/E2/G,
+        LSGAN losses, backward, all-reduce, Adam; every R1_once_every-th iteration a second
+        zero_grad / R1 backward / all-reduce / Adam on the same real images."""
+        self.iter_counter += 1
         rec, mix = d_step_images(model, real, lambda_StyleCon)
         losses = self.losses_and_grads(real, rec, mix)
         self.all_reduce()
         self.adam()
+        if lambda_R1 > 0.0 and self.iter_counter % self.R1_once_every == 0:
+            losses.update(self.r1_losses_and_grads(real, lambda_R1, self.R1_once_every))
+            self.all_reduce()
+            self.adam()
         return losses
 
 

@@ -17,6 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 import ppst_oracle as O  # noqa: E402
 from ppst_amd import ops, weights as W  # noqa: E402
+from ppst_amd.networks.base_network import to_nhwc  # noqa: E402
 
 dev = "cuda"
 RES = []
@@ -554,6 +555,82 @@ def t_train_d():
         RES.append(("D-step %d Adam" % size, w2 <= 1e-3)); print("D-step %d: Adam-updated parameters worst rel diff %.3e" % (size, w2), flush=True)
 
 
+def t_train_ops():
+    """Backward building blocks alone (no activation gates): conv input gradient ('dgrad', 'dgrad_s2d'
+    = the forward MFMA kernel on a transposed pack) and weight gradient against torch autograd."""
+    import torch.nn.functional as F
+    torch.manual_seed(5)
+    for (B, S, cin, cout) in ((2, 32, 64, 128), (1, 16, 256, 256), (2, 8, 512, 512)):
+        x = torch.randn(B, cin, S, S)
+        w = torch.randn(cout, cin, 3, 3)
+        dy = torch.randn(B, cout, S, S)
+        sc = 1.0 / math.sqrt(cin * 9)
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        F.conv2d(xr, wr * sc, padding=1).backward(dy)
+        wg = g(w)
+        dx = ops.ConvPlan(wg, "dgrad", sc)(to_nhwc(g(dy)).contiguous())
+        report("dgrad 3x3 %dx%d %d->%d" % (S, S, cout, cin), dx.permute(0, 3, 1, 2), xr.grad, 3e-5)
+        dw = ops.conv_wgrad(ops.ConvPlan(wg, "conv", sc), to_nhwc(g(x)).contiguous(), to_nhwc(g(dy)).contiguous())
+        report("wgrad 3x3 %dx%d %d->%d" % (S, S, cin, cout), dw, wr.grad, 3e-5)
+        # stride-2 conv on the blurred (padded) tensor, as ConvLayer(downsample=True)
+        k = torch.tensor([1., 3., 3., 1.]); k2 = k[:, None] * k[None, :]; k2 = k2 / k2.sum()
+        xg = to_nhwc(g(x)).contiguous()
+        xb, bhw = ops.blur_nhwc(xg, g(k2), 2, 2, ops.PAD_ZERO, s2d=True)
+        oh = (bhw[0] - 3) // 2 + 1
+        xbr = O.upfirdn2d(x, k2, pad=(2, 2)).detach().requires_grad_(True)
+        wr2 = w.clone().requires_grad_(True)
+        dy2 = torch.randn(B, cout, oh, oh)
+        F.conv2d(xbr, wr2 * sc, stride=2).backward(dy2)
+        dy2g = to_nhwc(g(dy2)).contiguous()
+        dxb = ops.ConvPlan(wg, "dgrad_s2d", sc)(dy2g, out_hw=bhw)
+        report("dgrad_s2d %d->%d out %dx%d" % (cout, cin, bhw[0], bhw[1]), dxb.permute(0, 3, 1, 2), xbr.grad, 3e-5)
+        dw2 = ops.conv_wgrad(ops.ConvPlan(wg, "s2d", sc), xb, dy2g)
+        report("wgrad s2d %d->%d" % (cin, cout), dw2, wr2.grad, 3e-5)
+
+
+def t_train_r1():
+    """Lazy R1 penalty: per-sample penalties and the second-order parameter gradients
+    against the CPU double-backward oracle.
+
+    Tolerance: the kernels themselves are exact to ~5e-6 (t_train_ops).  End to end, a leaky-ReLU
+    whose pre-activation is within the conv rounding error of 0 takes the other slope than in the
+    oracle; each such flip changes the image gradient in its receptive-field patch by O(1) of the
+    local value (tests/dbg_r1.py shows the isolated patches).  Any two fp32 implementations with
+    different summation order differ this way, so the bar is on the L2-relative error per tensor
+    (sparse flips average out, a wrong term or scale would give O(1))."""
+    import train_oracle as T
+    from ppst_amd.networks.discriminator import StyleGAN2Discriminator
+    from ppst_amd.train import DiscriminatorTrainer
+    for size, B in ((128, 2), (256, 2)):
+        sd = W.make_state_dict(3, size=size, with_nce=False, bias_std=0.1)
+        D = StyleGAN2Discriminator(None, size=size)
+        D.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith("D.")}, strict=True)
+        D = D.to(dev)
+        tr = DiscriminatorTrainer(D)
+        torch.manual_seed(size + 1)
+        real = torch.rand(B, 3, size, size) * 2 - 1
+        pen, gr = T.r1_step_grads(sd, real, size=size)
+        losses = tr.r1_losses_and_grads(g(real))
+        report("R1 %d per-sample penalty" % size, losses["D_R1"], pen, 1e-3)
+        worst, worst_k, worst_max = 0.0, "", 0.0
+        for k, gref in gr.items():
+            got = tr.g(k[2:]).view_as(gref).cpu()
+            if float(gref.abs().max()) == 0.0:
+                r = rmax = float(got.abs().max())  # biases: exactly no R1 gradient
+            else:
+                r = float((got - gref).norm() / gref.norm())
+                rmax = float((got - gref).abs().max() / gref.abs().max())
+            if os.environ.get("PPST_DIAG_VERBOSE"):
+                print("   %-50s L2 rel %.3e max rel %.3e" % (k, r, rmax), flush=True)
+            worst_max = max(worst_max, rmax)
+            if r > worst:
+                worst, worst_k = r, k
+        ok = worst <= 2e-2 and worst_max <= 1e-1
+        RES.append(("R1 %d gradients" % size, ok))
+        print("R1 %d: worst L2-relative gradient error %.3e (%s), worst max-relative %.3e over %d tensors %s"
+              % (size, worst, worst_k, worst_max, len(gr), "ok" if ok else "FAIL"), flush=True)
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     print("device:", torch.cuda.get_device_name(0), flush=True)
@@ -565,9 +642,15 @@ def main():
     if which in ("nets", "all"):
         print("== t_networks", flush=True)
         run(t_networks)
+    if which == "trainops":
+        run(t_train_ops)
     if which in ("train", "all"):
+        print("== t_train_ops", flush=True)
+        run(t_train_ops)
         print("== t_train_d", flush=True)
         run(t_train_d)
+        print("== t_train_r1", flush=True)
+        run(t_train_r1)
     if which in ("configs", "all"):
         print("== t_configs", flush=True)
         run(t_configs)

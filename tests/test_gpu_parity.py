@@ -61,6 +61,17 @@ def test_discriminator_train_step_vs_autograd_oracle():
     _run("t_train_d")
 
 
+def test_backward_kernels_vs_autograd():
+    """conv dgrad / dgrad over the space-to-depth input / wgrad alone, 3e-5 against torch autograd."""
+    _run("t_train_ops")
+
+
+def test_lazy_r1_penalty_vs_double_backward_oracle():
+    """compute_R1_loss + the second-order parameter gradients (one extra forward sweep on the HIP
+    kernels) against CPU double backward."""
+    _run("t_train_r1")
+
+
 def test_swap_matches_reference_golden():
     """The HIP path against the fixtures produced by the *reference itself*
     (oracle/gen_golden.py): sampled activations of the full recipe."""
