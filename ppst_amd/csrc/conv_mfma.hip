@@ -291,20 +291,43 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
 #define ST_C
 #define ST_D
 #endif
+// timing ablations (tests/conv_ablate.sh): results are WRONG with any of these defined
+#ifdef PPST_ABL_NOA
+#define ABL_A(c) false
+#else
+#define ABL_A(c) (c)
+#endif
+#ifdef PPST_ABL_NOB
+#define ABL_B(c) false
+#else
+#define ABL_B(c) (c)
+#endif
+#ifdef PPST_ABL_NOLDS
+#define ABL_L(c) false
+#else
+#define ABL_L(c) (c)
+#endif
+#ifdef PPST_ABL_NOBAR
+#define ABL_BAR(x)
+#else
+#define ABL_BAR(x) x
+#endif
 #define CONV_STEP(bch, bcl, bnh, bnl, s, D2, D3)                                                      \
   {                                                                                                   \
     ST_A                                                                                              \
     const bool has1 = (s) + 1 < a.nsteps, has2 = (s) + 2 < a.nsteps;                                  \
     if ((s) + 3 < a.nsteps) D3 = steps[(s) + 3];                                                      \
-    const bool newA2 = has2 && D2.w != 0;                                                             \
+    const bool newA2 = ABL_A(has2 && D2.w != 0);                                                      \
     int sl2 = sl1;                                                                                    \
     if (newA2) sl2 = (sl1 == NA - 1) ? 0 : sl1 + 1;                                                   \
-    if (has2) b_dma((s) + 2, (s) & 1);                                                                \
+    if (ABL_B(has2)) b_dma((s) + 2, (s) & 1);                                                         \
     if (newA2) a_load(D2.x);                                                                          \
-    if (has1) ld_b(bnh, bnl, ((s) + 1) & 1);                                                          \
+    if (ABL_L(has1)) ld_b(bnh, bnl, ((s) + 1) & 1);                                                   \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                \
       bf16x8 nh, nl;                                                                                  \
-      if (mt < 3) {                                                                                   \
+      if (!ABL_L(true)) {                                                                             \
+        nh = ah; nl = al;                                                                             \
+      } else if (mt < 3) {                                                                            \
         nh = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1));                                    \
         if (X3) nl = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1) + 4 * PLANE);                \
       } else if (has1) {                                                                              \
@@ -329,8 +352,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
     /* hipcc (ROCm 7.2) does NOT add vmcnt(0) for an in-flight LDS-DMA at this barrier (it only  */  \
     /* emits lgkmcnt(0)): without the explicit wait a slow (cold-cache) B copy lands after the   */  \
     /* next step has started reading the slot.                                                   */  \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
-    __syncthreads();                                                                                  \
+    ABL_BAR(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();)                        \
     ST_D                                                                                              \
     dy0 = dy1; dx0 = dx1; sl0 = sl1;                                                                  \
     if (has2) { dy1 = D2.y; dx1 = D2.z; }                                                             \
