@@ -19,6 +19,33 @@ static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Division of a 32-bit index by a launch constant without the 64-bit divide sequence hipcc emits
+// for `int64 / int` (about 100 instructions per quotient: it made the elementwise kernels
+// ALU-bound): Granlund-Montgomery round-up multiplier, exact for every n < 2^32 and d >= 1.
+struct FastDiv { unsigned d, m, s1, s2; };
+static inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  if (d == 0) d = 1;  // never dereferenced for empty shapes; keeps the host math defined
+  f.d = d;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;  // ceil(log2 d)
+  f.m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l == 0 ? 0 : l - 1;
+  return f;
+}
+__device__ __forceinline__ unsigned fd_div(unsigned n, const FastDiv& f) {
+  unsigned t = __umulhi(f.m, n);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+// n -> (n / d, n % d)
+__device__ __forceinline__ unsigned fd_divmod(unsigned n, const FastDiv& f, unsigned& rem) {
+  unsigned q = fd_div(n, f);
+  rem = n - q * f.d;
+  return q;
+}
+#define PPST_IDX32_MAX 0xFFFFFFFFll  // element-index limit of the kernels that use FastDiv
+
 // fp32 -> bf16 round-to-nearest-even as raw 16 bits (plain cast: hipcc emits
 // v_cvt_pk_bf16_f32 on gfx950, which keeps NaN a NaN)
 __device__ __forceinline__ unsigned short f2bf(float f) {

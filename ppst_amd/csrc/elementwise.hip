@@ -117,16 +117,22 @@ extern "C" int ppst_nhwc_to_nchw(const void* x, void* y, int B, int C, int H, in
 // partial (v0, v1) per channel: MODE 0 = (sum w*x, sum w*x^2) [instance norm; w = border
 // multiplicity when the statistics are those of the ReplicationPad2d(1)-padded tensor],
 // MODE 1 = (sum m*x, max m*x) [GAP/GMP with optional mask].
-#define PIX_CHUNK 1024
+// Pixels per block: 1024 for big images, fewer when that would leave CUs idle (>= 2048 blocks
+// wanted, >= 64 pixels per block).  n_partials = ceil(H*W / pix_chunk(B, H*W)) everywhere.
+static inline int pix_chunk(int B, int64_t hw) {
+  int chunk = 1024;
+  while (chunk > 64 && (int64_t)B * cdiv64(hw, chunk) < 2048) chunk >>= 1;
+  return chunk;
+}
 template <int MODE>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ x, const float* __restrict__ mask,
                                                           float* __restrict__ partial, int H, int W, int C, int ld,
-                                                          int rep_pad, int nchunks) {
+                                                          int rep_pad, int nchunks, int PIX_CHUNK) {
   __shared__ float s0[256], s1[256];
   const int b = blockIdx.y, chunk = blockIdx.x;
-  const int64_t P = (int64_t)H * W;
-  const int64_t pbeg = (int64_t)chunk * PIX_CHUNK;
-  const int64_t pend = (pbeg + PIX_CHUNK < P) ? pbeg + PIX_CHUNK : P;
+  const int P = H * W;
+  const int pbeg = chunk * PIX_CHUNK;
+  const int pend = (pbeg + PIX_CHUNK < P) ? pbeg + PIX_CHUNK : P;
   int lanesC = 1;
   while (lanesC < C && lanesC < 256) lanesC <<= 1;
   const int rows = 256 / lanesC;
@@ -137,12 +143,12 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
     int c = cbase + cl;
     float a0 = 0.f, a1 = (MODE == 1) ? -INFINITY : 0.f;
     if (c < C) {
-      for (int64_t p = pbeg + pr; p < pend; p += rows) {
-        float v = xb[p * ld + c];
+      for (int p = pbeg + pr; p < pend; p += rows) {
+        float v = xb[(int64_t)p * ld + c];
         if (MODE == 0) {
           float w = 1.f;
           if (rep_pad) {
-            int py = (int)(p / W), px = (int)(p - (int64_t)py * W);
+            int py = p / W, px = p - py * W;
             w = (float)((1 + (py == 0) + (py == H - 1)) * (1 + (px == 0) + (px == W - 1)));
           }
           a0 += w * v;
@@ -182,12 +188,12 @@ struct ApplyArgs {
 template <int MODE, bool APPLY>
 __global__ __launch_bounds__(256) void chan_reduce4_kernel(const float* __restrict__ x, const float* __restrict__ mask,
                                                            float* __restrict__ partial, int H, int W, int C, int ld,
-                                                           int rep_pad, int nchunks, ApplyArgs ap) {
+                                                           int rep_pad, int nchunks, ApplyArgs ap, int PIX_CHUNK, FastDiv d_w) {
   __shared__ float4 s0[256], s1[256];
   const int b = blockIdx.y, chunk = blockIdx.x;
-  const int64_t P = (int64_t)H * W;
-  const int64_t pbeg = (int64_t)chunk * PIX_CHUNK;
-  const int64_t pend = (pbeg + PIX_CHUNK < P) ? pbeg + PIX_CHUNK : P;
+  const int P = H * W;
+  const int pbeg = chunk * PIX_CHUNK;
+  const int pend = (pbeg + PIX_CHUNK < P) ? pbeg + PIX_CHUNK : P;
   const int c4n = C >> 2;
   int lanes = 1;
   while (lanes < c4n && lanes < 256) lanes <<= 1;
@@ -214,15 +220,17 @@ __global__ __launch_bounds__(256) void chan_reduce4_kernel(const float* __restri
         float4 q0 = q[0], q1 = q[1];
         ra = make_float4(q0.x, q0.z, q1.x, q1.z); rb = make_float4(q0.y, q0.w, q1.y, q1.w);
       }
-      for (int64_t p = pbeg + pr; p < pend; p += rows) {
+      for (int p = pbeg + pr; p < pend; p += rows) {
         const int64_t bp = (int64_t)b * P + p;
+        unsigned pxu = 0;
+        const int py = (APPLY || MODE == 0) ? (int)fd_divmod((unsigned)p, d_w, pxu) : 0, px = (int)pxu;
         float4 v = *(const float4*)(x + bp * ld + c);
         if (APPLY) {
           float t[4] = {sa.x * v.x + sb.x, sa.y * v.y + sb.y, sa.z * v.z + sb.z, sa.w * v.w + sb.w};
           float r[4] = {0.f, 0.f, 0.f, 0.f};
           if (ap.res) {
             float4 rv;
-            if (ap.res_up2) { int py = (int)(p / W), px = (int)(p - (int64_t)py * W); rv = res_up2_sample(ap.res, b, py, px, H, W, ap.res_ld, c); }
+            if (ap.res_up2) rv = res_up2_sample(ap.res, b, py, px, H, W, ap.res_ld, c);
             else rv = *(const float4*)(ap.res + bp * ap.res_ld + c);
             r[0] = ra.x * rv.x + rb.x; r[1] = ra.y * rv.y + rb.y; r[2] = ra.z * rv.z + rb.z; r[3] = ra.w * rv.w + rb.w;
           }
@@ -239,10 +247,7 @@ __global__ __launch_bounds__(256) void chan_reduce4_kernel(const float* __restri
         }
         if (MODE == 0) {
           float w = 1.f;
-          if (rep_pad) {
-            int py = (int)(p / W), px = (int)(p - (int64_t)py * W);
-            w = (float)((1 + (py == 0) + (py == H - 1)) * (1 + (px == 0) + (px == W - 1)));
-          }
+          if (rep_pad) w = (float)((1 + (py == 0) + (py == H - 1)) * (1 + (px == 0) + (px == W - 1)));
           a0.x += w * v.x; a0.y += w * v.y; a0.z += w * v.z; a0.w += w * v.w;
           a1.x += w * v.x * v.x; a1.y += w * v.y * v.y; a1.z += w * v.z * v.z; a1.w += w * v.w * v.w;
         } else {
@@ -272,8 +277,9 @@ __global__ __launch_bounds__(256) void chan_reduce4_kernel(const float* __restri
 
 extern "C" int ppst_in_stats(const void* x, void* partial, int B, int H, int W, int C, int ld, int rep_pad,
                              int* n_partials, void* stream) {
-  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || ld < C) return PPST_EINVAL;
-  int nchunks = (int)cdiv64((int64_t)H * W, PIX_CHUNK);
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || ld < C || (int64_t)H * W > 0x7fffffffll) return PPST_EINVAL;
+  const int chunk = pix_chunk(B, (int64_t)H * W);
+  int nchunks = (int)cdiv64((int64_t)H * W, chunk);
   if (n_partials) *n_partials = nchunks;
   if (!x && !partial) return PPST_OK;  // size query
   if (B == 0) return PPST_OK;
@@ -281,10 +287,10 @@ extern "C" int ppst_in_stats(const void* x, void* partial, int B, int H, int W, 
   if (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0) {
     ApplyArgs ap = {};
     PPST_LAUNCH((chan_reduce4_kernel<0, false>), dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
-                (const float*)nullptr, (float*)partial, H, W, C, ld, rep_pad, nchunks, ap);
+                (const float*)nullptr, (float*)partial, H, W, C, ld, rep_pad, nchunks, ap, chunk, make_fastdiv(W));
   } else {
     PPST_LAUNCH(chan_reduce_kernel<0>, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
-                (const float*)nullptr, (float*)partial, H, W, C, ld, rep_pad, nchunks);
+                (const float*)nullptr, (float*)partial, H, W, C, ld, rep_pad, nchunks, chunk);
   }
   return PPST_LAUNCH_CHECK();
 }
@@ -351,19 +357,24 @@ __device__ __forceinline__ float act_apply(float t, int act, float slope) {
 template <bool VEC>
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ ss,
                                                          const float* __restrict__ res, const float* __restrict__ rss,
-                                                         float* __restrict__ y, int64_t hw, int C, int x_ld, int res_ld,
+                                                         float* __restrict__ y, unsigned hw, int C, int x_ld, int res_ld,
                                                          int y_ld, int actf,
-                                                         const float* __restrict__ prelu, float out_scale, int64_t total,
-                                                         int up2_w) {
+                                                         const float* __restrict__ prelu, float out_scale, unsigned total,
+                                                         int up2_w, FastDiv d_cv, FastDiv d_hw, FastDiv d_w) {
   const int act = actf & 0xff;
   const bool res_first = (actf >> 8) & 1;
   const float slope = (act == PPST_ACT_PRELU && prelu) ? prelu[0] : 0.f;
   constexpr int V = VEC ? 4 : 1;
   const int cv = C / V;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    int c = (int)(t % cv) * V;
-    int64_t bp = t / cv;  // b*hw + p
-    int b = (int)(bp / hw);
+  (void)cv;
+  // 32-bit indices + multiplier division (host guarantees total <= PPST_IDX32_MAX)
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    const unsigned t = (unsigned)t64;
+    unsigned cq;
+    const unsigned bpu = fd_divmod(t, d_cv, cq);  // b*hw + p
+    const int c = (int)cq * V;
+    const int64_t bp = bpu;
+    const int b = (int)fd_div(bpu, d_hw);
     const float* sp = ss ? ss + ((int64_t)b * C + c) * 2 : nullptr;
     const float* rp = (res && rss) ? rss + ((int64_t)b * C + c) * 2 : nullptr;
     float xv[V], rv[V], o[V];
@@ -373,9 +384,9 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
       if (res) {
         float4 r;
         if (up2_w > 0) {
-          int64_t p = bp - (int64_t)b * hw;
-          int oy = (int)(p / up2_w), ox = (int)(p - (int64_t)oy * up2_w);
-          r = res_up2_sample(res, b, oy, ox, (int)(hw / up2_w), up2_w, res_ld, c);
+          unsigned oxu;
+          const int oy = (int)fd_divmod(bpu - (unsigned)b * hw, d_w, oxu), ox = (int)oxu;
+          r = res_up2_sample(res, b, oy, ox, (int)(hw / (unsigned)up2_w), up2_w, res_ld, c);
         } else {
           r = *(const float4*)(res + bp * res_ld + c);
         }
@@ -409,14 +420,17 @@ extern "C" int ppst_affine_act(const void* x, const void* scale_shift, const voi
   bool vec = C % 4 == 0 && x_ld % 4 == 0 && y_ld % 4 == 0 && (!res || res_ld % 4 == 0) &&
              (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) % 16 == 0);
   int64_t total = (int64_t)B * hw * (vec ? C / 4 : C);
+  if (total > PPST_IDX32_MAX) return PPST_EINVAL;
+  const FastDiv d_cv = make_fastdiv((unsigned)(vec ? C / 4 : C)), d_hw = make_fastdiv((unsigned)hw),
+                d_w = make_fastdiv(res_up2_w > 0 ? (unsigned)res_up2_w : 1u);
   if (vec)
     PPST_LAUNCH(affine_act_kernel<true>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
-                       (const float*)scale_shift, (const float*)res, (const float*)res_scale_shift, (float*)y, hw, C, x_ld,
-                       res_ld, y_ld, act, (const float*)prelu, out_scale, total, res_up2_w);
+                       (const float*)scale_shift, (const float*)res, (const float*)res_scale_shift, (float*)y, (unsigned)hw, C, x_ld,
+                       res_ld, y_ld, act, (const float*)prelu, out_scale, (unsigned)total, res_up2_w, d_cv, d_hw, d_w);
   else
     PPST_LAUNCH(affine_act_kernel<false>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
-                       (const float*)scale_shift, (const float*)res, (const float*)res_scale_shift, (float*)y, hw, C, x_ld,
-                       res_ld, y_ld, act, (const float*)prelu, out_scale, total, 0);
+                       (const float*)scale_shift, (const float*)res, (const float*)res_scale_shift, (float*)y, (unsigned)hw, C, x_ld,
+                       res_ld, y_ld, act, (const float*)prelu, out_scale, (unsigned)total, 0, d_cv, d_hw, d_w);
   return PPST_LAUNCH_CHECK();
 }
 
@@ -430,14 +444,16 @@ extern "C" int ppst_affine_act_stats(const void* x, const void* scale_shift, con
     return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!x || !y || !partial) return PPST_ENULL;
-  int nchunks = (int)cdiv64((int64_t)H * W, PIX_CHUNK);
+  if ((int64_t)H * W > 0x7fffffffll) return PPST_EINVAL;
+  const int chunk = pix_chunk(B, (int64_t)H * W);
+  int nchunks = (int)cdiv64((int64_t)H * W, chunk);
   ApplyArgs ap;
   ap.ss = (const float*)scale_shift; ap.res = (const float*)res; ap.rss = (const float*)res_scale_shift; ap.y = (float*)y;
   ap.prelu = (const float*)prelu; ap.res_ld = res_ld; ap.y_ld = y_ld; ap.actf = act; ap.out_scale = out_scale;
   ap.res_up2 = (res && res_up2) ? 1 : 0;
   if (ap.res_up2 && (H % 2 || W % 2)) return PPST_EINVAL;
   PPST_LAUNCH((chan_reduce4_kernel<0, true>), dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
-              (const float*)nullptr, (float*)partial, H, W, C, x_ld, rep_pad, nchunks, ap);
+              (const float*)nullptr, (float*)partial, H, W, C, x_ld, rep_pad, nchunks, ap, chunk, make_fastdiv(W));
   return PPST_LAUNCH_CHECK();
 }
 
@@ -457,20 +473,25 @@ __global__ __launch_bounds__(256) void gap_gmp_finalize_kernel(const float* __re
   out[(int64_t)b * 2 * C + c] = (float)(s / count);
   out[(int64_t)b * 2 * C + C + c] = m;
 }
-extern "C" int64_t ppst_gap_gmp_ws(int B, int64_t hw, int C) { return cdiv64(hw, PIX_CHUNK) * C * 2 * B * (int64_t)sizeof(float); }
+extern "C" int64_t ppst_gap_gmp_ws(int B, int64_t hw, int C) {
+  if (B <= 0 || hw <= 0) return 0;
+  return cdiv64(hw, pix_chunk(B, hw)) * C * 2 * B * (int64_t)sizeof(float);
+}
 extern "C" int ppst_gap_gmp(const void* x, const void* mask, void* out, void* ws, int B, int H, int W, int C, int ld,
                              void* stream) {
   if (B < 0 || H <= 0 || W <= 0 || C <= 0 || ld < C) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!x || !out || !ws) return PPST_ENULL;
-  int nchunks = (int)cdiv64((int64_t)H * W, PIX_CHUNK);
+  if ((int64_t)H * W > 0x7fffffffll) return PPST_EINVAL;
+  const int chunk = pix_chunk(B, (int64_t)H * W);
+  int nchunks = (int)cdiv64((int64_t)H * W, chunk);
   if (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0) {
     ApplyArgs ap = {};
     PPST_LAUNCH((chan_reduce4_kernel<1, false>), dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
-                (const float*)mask, (float*)ws, H, W, C, ld, 0, nchunks, ap);
+                (const float*)mask, (float*)ws, H, W, C, ld, 0, nchunks, ap, chunk, make_fastdiv(W));
   } else {
     PPST_LAUNCH(chan_reduce_kernel<1>, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
-                (const float*)mask, (float*)ws, H, W, C, ld, 0, nchunks);
+                (const float*)mask, (float*)ws, H, W, C, ld, 0, nchunks, chunk);
   }
   int e = PPST_LAUNCH_CHECK();
   if (e) return e;
@@ -481,15 +502,16 @@ extern "C" int ppst_gap_gmp(const void* x, const void* mask, void* out, void* ws
 
 // ------------------------------------------------------ pooling / resize ---
 __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
-                                                      int C, int x_ld, int f, int y_ld, int64_t total) {
-  const int OH = H / f, OW = W / f, c4n = C >> 2;
+                                                      int C, int x_ld, int f, int y_ld, unsigned total, FastDiv d_c,
+                                                      FastDiv d_ow, FastDiv d_oh) {
+  const int OH = H / f, OW = W / f;
   const float inv = 1.f / (float)(f * f);
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    int c = (int)(t % c4n) * 4;
-    int64_t r = t / c4n;
-    int ox = (int)(r % OW); r /= OW;
-    int oy = (int)(r % OH);
-    int b = (int)(r / OH);
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned cq, oxu, oyu;
+    unsigned r = fd_divmod((unsigned)t64, d_c, cq);
+    r = fd_divmod(r, d_ow, oxu);
+    const int b = (int)fd_divmod(r, d_oh, oyu);
+    const int c = (int)cq * 4, ox = (int)oxu, oy = (int)oyu;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int dy = 0; dy < f; ++dy)
       for (int dx = 0; dx < f; ++dx) {
@@ -505,22 +527,23 @@ extern "C" int ppst_avgpool(const void* x, void* y, int B, int H, int W, int C, 
   if (B == 0) return PPST_OK;
   if (!x || !y) return PPST_ENULL;
   int64_t total = (int64_t)B * (H / f) * (W / f) * (C / 4);
+  if (total > PPST_IDX32_MAX) return PPST_EINVAL;
   PPST_LAUNCH(avgpool_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y,
-                     H, W, C, x_ld, f, y_ld, total);
+                     H, W, C, x_ld, f, y_ld, (unsigned)total, make_fastdiv(C / 4), make_fastdiv(W / f), make_fastdiv(H / f));
   return PPST_LAUNCH_CHECK();
 }
 
 // F.interpolate(mode='bilinear', align_corners=False): src = (dst+0.5)*in/out - 0.5, clamped at 0
 __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
-                                                       int C, int x_ld, int OH, int OW, int y_ld, int64_t total) {
-  const int c4n = C >> 2;
+                                                       int C, int x_ld, int OH, int OW, int y_ld, unsigned total,
+                                                       FastDiv d_c, FastDiv d_ow, FastDiv d_oh) {
   const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    int c = (int)(t % c4n) * 4;
-    int64_t r = t / c4n;
-    int ox = (int)(r % OW); r /= OW;
-    int oy = (int)(r % OH);
-    int b = (int)(r / OH);
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned cq, oxu, oyu;
+    unsigned r = fd_divmod((unsigned)t64, d_c, cq);
+    r = fd_divmod(r, d_ow, oxu);
+    const int b = (int)fd_divmod(r, d_oh, oyu);
+    const int c = (int)cq * 4, ox = (int)oxu, oy = (int)oyu;
     float fy = fmaxf(((float)oy + 0.5f) * sh - 0.5f, 0.f);
     float fx = fmaxf(((float)ox + 0.5f) * sw - 0.5f, 0.f);
     int y0 = (int)fy, x0 = (int)fx;
@@ -547,21 +570,24 @@ extern "C" int ppst_bilinear(const void* x, void* y, int B, int H, int W, int C,
   if (B == 0) return PPST_OK;
   if (!x || !y) return PPST_ENULL;
   int64_t total = (int64_t)B * OH * OW * (C / 4);
+  if (total > PPST_IDX32_MAX) return PPST_EINVAL;
   PPST_LAUNCH(bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y,
-                     H, W, C, x_ld, OH, OW, y_ld, total);
+                     H, W, C, x_ld, OH, OW, y_ld, (unsigned)total, make_fastdiv(C / 4), make_fastdiv(OW), make_fastdiv(OH));
   return PPST_LAUNCH_CHECK();
 }
 
 // nearest x2 upsample (Upscale2d, stylegan2_layers.py:86-97; the <128 px branch of
 // EqualizedConv2d :322-323)
 __global__ __launch_bounds__(256) void upsample_nearest2_kernel(const float4* __restrict__ x, float4* __restrict__ y, int H, int W,
-                                                                int c4n, int64_t total) {
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    int c = (int)(t % c4n);
-    int64_t r = t / c4n;
-    int ox = (int)(r % (2 * W)); r /= (2 * W);
-    int oy = (int)(r % (2 * H));
-    int64_t b = r / (2 * H);
+                                                                int c4n, unsigned total, FastDiv d_c, FastDiv d_ow,
+                                                                FastDiv d_oh) {
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    const unsigned t = (unsigned)t64;
+    unsigned cq, oxu, oyu;
+    unsigned r = fd_divmod(t, d_c, cq);
+    r = fd_divmod(r, d_ow, oxu);
+    const int64_t b = fd_divmod(r, d_oh, oyu);
+    const int c = (int)cq, ox = (int)oxu, oy = (int)oyu;
     y[t] = x[((b * H + (oy >> 1)) * W + (ox >> 1)) * c4n + c];
   }
 }
@@ -570,20 +596,21 @@ extern "C" int ppst_upsample_nearest2(const void* x, void* y, int B, int H, int 
   if (B == 0) return PPST_OK;
   if (!x || !y) return PPST_ENULL;
   int64_t total = (int64_t)B * 4 * H * W * (C / 4);
+  if (total > PPST_IDX32_MAX) return PPST_EINVAL;
   PPST_LAUNCH(upsample_nearest2_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float4*)x,
-                     (float4*)y, H, W, C / 4, total);
+                     (float4*)y, H, W, C / 4, (unsigned)total, make_fastdiv(C / 4), make_fastdiv(2 * W), make_fastdiv(2 * H));
   return PPST_LAUNCH_CHECK();
 }
 
 __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C,
-                                                       int64_t total) {
-  const int OH = H / 2, OW = W / 2;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    int c = (int)(t % C);
-    int64_t r = t / C;
-    int ox = (int)(r % OW); r /= OW;
-    int oy = (int)(r % OH);
-    int b = (int)(r / OH);
+                                                       unsigned total, FastDiv d_c, FastDiv d_ow, FastDiv d_oh) {
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    const unsigned t = (unsigned)t64;
+    unsigned cq, oxu, oyu;
+    unsigned r = fd_divmod(t, d_c, cq);
+    r = fd_divmod(r, d_ow, oxu);
+    const int b = (int)fd_divmod(r, d_oh, oyu);
+    const int c = (int)cq, ox = (int)oxu, oy = (int)oyu;
     const float* p = x + (((int64_t)b * H + oy * 2) * W + ox * 2) * C + c;
     y[t] = fmaxf(fmaxf(p[0], p[C]), fmaxf(p[(int64_t)W * C], p[(int64_t)W * C + C]));
   }
@@ -593,27 +620,43 @@ extern "C" int ppst_maxpool2(const void* x, void* y, int B, int H, int W, int C,
   if (B == 0) return PPST_OK;
   if (!x || !y) return PPST_ENULL;
   int64_t total = (int64_t)B * (H / 2) * (W / 2) * C;
-  PPST_LAUNCH(maxpool2_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, H, W, C, total);
+  if (total > PPST_IDX32_MAX) return PPST_EINVAL;
+  PPST_LAUNCH(maxpool2_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, H, W, C,
+              (unsigned)total, make_fastdiv(C), make_fastdiv(W / 2), make_fastdiv(H / 2));
   return PPST_LAUNCH_CHECK();
 }
 
 // --------------------------------------------------------- small 1x1 convs --
-// Cin <= 4 (FromRGB): thread = (pixel, 4 output channels)
+// Cin <= 4 (FromRGB): thread = (pixel, 4 output channels).  The grid stride is a multiple of
+// cout/4, so a thread keeps its output-channel group: its 4 x cin weights and biases are loaded
+// once, the loop is one pixel read + one 16-B store.
 __global__ __launch_bounds__(256) void conv1x1_small_cin_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ bias, float* __restrict__ y,
                                                                 int64_t npix, int cin, int in_ld, int cout, float wscale,
-                                                                int act, int64_t total) {
-  const int c4n = cout >> 2;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    int co = (int)(t % c4n) * 4;
-    int64_t p = t / c4n;
+                                                                int act, FastDiv d_c) {
+  const unsigned t0 = blockIdx.x * 256 + threadIdx.x;
+  unsigned cq;
+  int64_t p = fd_divmod(t0, d_c, cq);
+  const int64_t pstep = ((int64_t)gridDim.x * 256) / d_c.d;  // exact: the host rounds the grid
+  const int co = (int)cq * 4;
+  float wr[4][4], br[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    br[j] = bias ? bias[co + j] : 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) wr[j][ci] = ci < cin ? w[(co + j) * cin + ci] * wscale : 0.f;
+  }
+  for (; p < npix; p += pstep) {
+    float xv[4];
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) xv[ci] = ci < cin ? x[p * in_ld + ci] : 0.f;
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float acc = 0.f;
-      for (int ci = 0; ci < cin; ++ci) acc += x[p * in_ld + ci] * (w[(co + j) * cin + ci] * wscale);
-      if (bias) acc += bias[co + j];
-      o[j] = act_apply(acc, act, 0.f);
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) acc += xv[ci] * wr[j][ci];  // ci >= cin adds +0 (same sum as the cin-term loop)
+      o[j] = act_apply(acc + br[j], act, 0.f);
     }
     *(float4*)(y + p * cout + co) = make_float4(o[0], o[1], o[2], o[3]);
   }
@@ -623,9 +666,16 @@ extern "C" int ppst_conv1x1_small_cin(const void* x, const void* w, const void* 
   if (npix < 0 || cin <= 0 || cin > 4 || in_ld < cin || cout <= 0 || cout % 4) return PPST_EINVAL;
   if (npix == 0) return PPST_OK;
   if (!x || !w || !y) return PPST_ENULL;
-  int64_t total = npix * (cout / 4);
-  PPST_LAUNCH(conv1x1_small_cin_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
-                     (const float*)w, (const float*)bias, (float*)y, npix, cin, in_ld, cout, wscale, act, total);
+  const int c4n = cout / 4;
+  int64_t total = npix * c4n;
+  // grid stride (blocks * 256) must be a multiple of c4n: blocks a multiple of c4n / gcd(c4n, 256)
+  int g = c4n, t256 = 256;
+  while (t256) { int r = g % t256; g = t256; t256 = r; }
+  const int unit = c4n / g;
+  int64_t blocks = (int64_t)grid_for(total);
+  blocks = ((blocks + unit - 1) / unit) * unit;
+  PPST_LAUNCH(conv1x1_small_cin_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)x,
+                     (const float*)w, (const float*)bias, (float*)y, npix, cin, in_ld, cout, wscale, act, make_fastdiv(c4n));
   return PPST_LAUNCH_CHECK();
 }
 
@@ -681,13 +731,13 @@ extern "C" int ppst_lerp(const void* a, const void* b, void* y, int64_t n, float
 }
 
 __global__ __launch_bounds__(256) void spatial_mod_kernel(const float* __restrict__ x, const float* __restrict__ sc,
-                                                          const float* __restrict__ bi, float* __restrict__ y, int64_t hw,
-                                                          int C, int64_t total) {
-  const int c4n = C >> 2;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    int c = (int)(t % c4n) * 4;
-    int64_t bp = t / c4n;
-    int b = (int)(bp / hw);
+                                                          const float* __restrict__ bi, float* __restrict__ y,
+                                                          int C, unsigned total, FastDiv d_c, FastDiv d_hw) {
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned cq;
+    const int64_t bp = fd_divmod((unsigned)t64, d_c, cq);
+    const int c = (int)cq * 4;
+    const int b = (int)fd_div((unsigned)bp, d_hw);
     float4 v = *(const float4*)(x + bp * C + c);
     float4 s = *(const float4*)(sc + (int64_t)b * C + c);
     float4 o = *(const float4*)(bi + (int64_t)b * C + c);
@@ -700,8 +750,10 @@ extern "C" int ppst_spatial_modulation(const void* x, const void* scale, const v
   if (B == 0) return PPST_OK;
   if (!x || !scale || !bias || !y) return PPST_ENULL;
   int64_t total = (int64_t)B * hw * (C / 4);
+  if (total > PPST_IDX32_MAX || hw > PPST_IDX32_MAX) return PPST_EINVAL;
   PPST_LAUNCH(spatial_mod_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
-                     (const float*)scale, (const float*)bias, (float*)y, hw, C, total);
+                     (const float*)scale, (const float*)bias, (float*)y, C, (unsigned)total, make_fastdiv(C / 4),
+                     make_fastdiv((unsigned)hw));
   return PPST_LAUNCH_CHECK();
 }
 

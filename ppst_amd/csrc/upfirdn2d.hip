@@ -82,20 +82,22 @@ __global__ __launch_bounds__(256) void upfirdn2d_planes(const float* __restrict_
 // those).  S2D writes the output space-to-depth: out[m][oy>>1][ox>>1][((oy&1)*2+(ox&1))*C + c]
 // with spatial extent ceil(out/2) -- the layout the fused conv consumes for stride-2 3x3 convs.
 template <int KH, int KW, int DOWN, bool S2D>
-__global__ __launch_bounds__(256) void upfirdn2d_chan(const float4* __restrict__ x, float4* __restrict__ y, UfParams p, int64_t nwork) {
+__global__ __launch_bounds__(256) void upfirdn2d_chan(const float4* __restrict__ x, float4* __restrict__ y, UfParams p, unsigned nwork,
+                                                      FastDiv d_c, FastDiv d_xs, FastDiv d_oh) {
   constexpr int PX = 4;
   const int c4n = p.minor >> 2;
   float kf[KH * KW];
 #pragma unroll
   for (int i = 0; i < KH * KW; ++i) kf[i] = p.k[KH * KW - 1 - i];
   const int xs = (p.out_w + PX - 1) / PX;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nwork; t += (int64_t)gridDim.x * 256) {
-    int c4 = (int)(t % c4n);
-    int64_t r = t / c4n;
-    int sx_ = (int)(r % xs); r /= xs;
-    int oy = (int)(r % p.out_h);
-    int m = (int)(r / p.out_h);
-    int ox0 = sx_ * PX;
+  (void)xs;
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < nwork; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned c4u, sxu, oyu;
+    unsigned r = fd_divmod((unsigned)t64, d_c, c4u);
+    r = fd_divmod(r, d_xs, sxu);
+    const int m = (int)fd_divmod(r, d_oh, oyu);
+    const int c4 = (int)c4u, oy = (int)oyu;
+    int ox0 = (int)sxu * PX;
     float4 acc[PX];
 #pragma unroll
     for (int i = 0; i < PX; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -167,12 +169,15 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic(const float* __restrict
 template <int KH, int KW>
 static int launch_chan(const float* x, float* y, const UfParams& p, int down, bool s2d, hipStream_t st) {
   int64_t nwork = (int64_t)p.major * p.out_h * cdiv(p.out_w, 4) * (p.minor / 4);
+  if (nwork > PPST_IDX32_MAX) return PPST_EINVAL;
   int64_t blocks = cdiv64(nwork, 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
   dim3 g((unsigned)blocks), b(256);
-  if (s2d) PPST_LAUNCH((upfirdn2d_chan<KH, KW, 1, true>), g, b, 0, st, (const float4*)x, (float4*)y, p, nwork);
-  else if (down == 2) PPST_LAUNCH((upfirdn2d_chan<KH, KW, 2, false>), g, b, 0, st, (const float4*)x, (float4*)y, p, nwork);
-  else PPST_LAUNCH((upfirdn2d_chan<KH, KW, 1, false>), g, b, 0, st, (const float4*)x, (float4*)y, p, nwork);
+  const FastDiv d_c = make_fastdiv(p.minor / 4), d_xs = make_fastdiv(cdiv(p.out_w, 4)), d_oh = make_fastdiv(p.out_h);
+  const unsigned nw = (unsigned)nwork;
+  if (s2d) PPST_LAUNCH((upfirdn2d_chan<KH, KW, 1, true>), g, b, 0, st, (const float4*)x, (float4*)y, p, nw, d_c, d_xs, d_oh);
+  else if (down == 2) PPST_LAUNCH((upfirdn2d_chan<KH, KW, 2, false>), g, b, 0, st, (const float4*)x, (float4*)y, p, nw, d_c, d_xs, d_oh);
+  else PPST_LAUNCH((upfirdn2d_chan<KH, KW, 1, false>), g, b, 0, st, (const float4*)x, (float4*)y, p, nw, d_c, d_xs, d_oh);
   return PPST_LAUNCH_CHECK();
 }
 
