@@ -148,6 +148,11 @@ typedef struct ppst_conv_args {
   int32_t tile_rows;             /* 16: 16x16-pixel tiles, 512- (bn 128) / 256-thread blocks, 1 block per CU;
                                     8:  8x16-pixel tiles, 256- / 128-thread blocks, 2 blocks per CU -- with halo=1
                                     every chunk of the step table must then span >= 2 steps */
+  int32_t a_slots;               /* depth of the activation-tile ring in LDS: 0 = default (3).  1 or 2 may be given when
+                                    NO group of the step table has more chunks (steps with new_chunk = 1) than that:
+                                    with bn = 64 the smaller footprint lets two blocks share a CU (small-K layers are
+                                    latency/HBM-bound with one).  The caller owns this promise: the table is on the
+                                    device and is not re-read by the host. */
 } ppst_conv_args;
 
 int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream);

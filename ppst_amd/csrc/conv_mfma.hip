@@ -68,8 +68,10 @@ __device__ __forceinline__ int pad_index(int i, int n, int mode) {
   return i;
 }
 
-template <int WM, int WN, int HALO, bool X3, bool INSS>
-__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
+// NAS: activation-tile ring depth (0 = default rule below).  1 or 2 only when no group has more
+// chunks than that; those variants also ask for two waves per SIMD so two blocks share a CU.
+template <int WM, int WN, int HALO, bool X3, bool INSS, int NAS = 0>
+__global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(ConvKArgs a) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TH = 4 * WM, TW = 16;
   constexpr int HH = TH + 2 * HALO, HW = TW + 2 * HALO, HP = HH * HW;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
   // A ring slots (hazard note at the main loop).  The 8-row tile variants keep 2 slots so
   // that two blocks fit one CU (2 x 80 KB); they require every chunk to span >= 2 steps
   // (the host pads single-tap chunks with a zero-weight step).
-  constexpr int NA = (WM == 2 && HALO == 1) ? 2 : 3;
+  constexpr int NA = NAS ? NAS : ((WM == 2 && HALO == 1) ? 2 : 3);
   constexpr int EPI_TILE = 64 * 36;                              // floats per wave: 64 px x (32 ch + 4 pad)
   constexpr int EPI_BYTES = (NT / 64) * EPI_TILE * 4 + WM * BN * 2 * 4;  // transposition tiles + stats scratch
   constexpr int MAIN_BYTES = NA * ABUF + 2 * BBUF;
@@ -590,10 +592,10 @@ extern "C" int ppst_prof_detail(int idx, double* ms, double* flop, int32_t* info
 
 extern "C" int ppst_conv_tiles(int tile_h, int tile_w, int tile_rows) { return cdiv(tile_h, tile_rows) * cdiv(tile_w, 16); }
 
-template <int WM, int WN, int HALO, bool X3>
+template <int WM, int WN, int HALO, bool X3, int NAS = 0>
 static void launch_conv(const ConvKArgs& k, int blocks, hipStream_t st) {
-  if (k.in_ss) PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, true>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
-  else PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, false>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
+  if (k.in_ss) PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, true, NAS>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
+  else PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, false, NAS>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
 }
 
 extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
@@ -602,7 +604,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       a->out_ld < a->cout || a->cout <= 0 || a->cout % 4 || a->out_ld % 4 || (a->residual && a->res_ld % 4) || a->nsteps <= 0 || (a->n_groups != 1 && a->n_groups != 4) || a->pad_mode < 0 ||
       a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 || a->precision < 0 ||
       a->precision > 1 || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128) || (a->residual && a->res_ld < a->cout) ||
-      (a->tile_rows != 16) || (a->in_scale_shift && a->in_c <= 0))
+      (a->tile_rows != 16) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
     return PPST_EINVAL;
   // the scattered output must reach into the output tensor (elements beyond it are dropped)
   if ((a->tile_h - 1) * a->out_sy >= a->out_h || (a->tile_w - 1) * a->out_sx >= a->out_w) return PPST_EINVAL;
@@ -650,7 +652,12 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   } while (0)
   // (8-row tiles -- two 80-KB blocks per CU -- were measured 35 % slower than one 16-row block
   //  per CU on MI355X and are not instantiated; tile_rows == 8 is rejected above.)
-  if (a->bn == 128) DISPATCH(4, 2); else DISPATCH(4, 1);
+  // small-K layers on the 64-channel tile: a shallower activation ring (59 / 48 / 80 KB of LDS instead of
+  // 145 / 112) puts two blocks on a CU, so one block's loads and stores overlap the other's MFMAs
+  if (a->bn == 64 && x3 && a->halo == 1 && a->a_slots == 1) launch_conv<4, 1, 1, true, 1>(k, blocks, st);
+  else if (a->bn == 64 && x3 && a->halo == 0 && a->a_slots == 1) launch_conv<4, 1, 0, true, 1>(k, blocks, st);
+  else if (a->bn == 64 && x3 && a->halo == 0 && a->a_slots == 2) launch_conv<4, 1, 0, true, 2>(k, blocks, st);
+  else if (a->bn == 128) DISPATCH(4, 2); else DISPATCH(4, 1);
 #undef DISPATCH
   int e = PPST_LAUNCH_CHECK();
   if (slot >= 0) (void)hipEventRecord(g_ev[slot][1], st);

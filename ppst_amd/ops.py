@@ -263,6 +263,8 @@ class ConvPlan:
         self.src_dev = (src_c, src_ky, src_kx)
         cs = [i for i, t in enumerate(steps) if t[3] == 1] + [len(steps)]
         self.chunk_start = torch.tensor(cs, dtype=torch.int32, device=dev)
+        # chunks per group (every group has the same count): ring depth hint for the kernel
+        self.chunks_per_group = (len(cs) - 1) // self.n_groups
         self.scale = float(scale)
         n_tiles = (cout + self.bn - 1) // self.bn
         npl = 8 if self.precision == 0 else 4
@@ -313,6 +315,7 @@ class ConvPlan:
         a.in_scale_shift, a.in_prelu, a.in_act = _p(in_ss), _p(in_prelu), in_act
         a.in_c = in_ss.shape[1] if in_ss is not None else 0
         a.flop_steps = self.flop_steps
+        a.a_slots = min(3, self.chunks_per_group)
         check(lib.ppst_conv2d_mfma(ctypes.byref(a), _stream()), "ppst_conv2d_mfma")
         if stats:
             return out, st

@@ -19,7 +19,7 @@ def timeit(fn, n=10):
     return ts[len(ts) // 2]
 
 shapes = [(8, 256, 256, 256, 3, "conv"), (8, 128, 128, 512, 3, "conv"), (8, 512, 512, 128, 3, "conv"), (8, 512, 256, 128, 3, "convT"),
-          (8, 32, 32, 512, 3, "conv")]
+          (8, 32, 32, 512, 3, "conv"), (8, 64, 64, 512, 1, "conv"), (8, 32, 64, 256, 1, "conv"), (8, 64, 64, 256, 3, "conv")]
 out = []
 for (B, ci, co, H, k, kind) in shapes:
     x = torch.randn(B, H, H, ci, device="cuda")
