@@ -458,20 +458,34 @@ extern "C" int ppst_affine_act_stats(const void* x, const void* scale_shift, con
 }
 
 // ---------------------------------------------------------------- GAP/GMP --
+// One block per (image b, 32-channel group), 8 partial rows in flight (256-B coalesced reads of
+// 32 (sum, max) pairs), double accumulation of the sums in a fixed order, LDS tree at the end.
 __global__ __launch_bounds__(256) void gap_gmp_finalize_kernel(const float* __restrict__ partial, int n_partials,
                                                                float* __restrict__ out, int B, int C, double count) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= B * C) return;
-  int b = i / C, c = i - b * C;
+  __shared__ double ss[8][32];
+  __shared__ float sm[8][32];
+  const int cgroups = (C + 31) / 32;
+  const int b = blockIdx.x / cgroups, c0 = (blockIdx.x % cgroups) * 32;
+  const int cl = threadIdx.x & 31, kk = threadIdx.x >> 5;
+  const int c = c0 + cl;
   double s = 0.0;
   float m = -INFINITY;
-  const float* p = partial + ((int64_t)b * n_partials * C + c) * 2;
-  for (int k = 0; k < n_partials; ++k) {
-    s += (double)p[(int64_t)k * C * 2];
-    m = fmaxf(m, p[(int64_t)k * C * 2 + 1]);
+  if (c < C) {
+    const float2* p = (const float2*)partial + ((int64_t)b * n_partials * C + c);
+    for (int k = kk; k < n_partials; k += 8) {
+      float2 v = p[(int64_t)k * C];
+      s += (double)v.x;
+      m = fmaxf(m, v.y);
+    }
   }
-  out[(int64_t)b * 2 * C + c] = (float)(s / count);
-  out[(int64_t)b * 2 * C + C + c] = m;
+  ss[kk][cl] = s;
+  sm[kk][cl] = m;
+  __syncthreads();
+  if (kk == 0 && c < C) {
+    for (int r = 1; r < 8; ++r) { s += ss[r][cl]; m = fmaxf(m, sm[r][cl]); }
+    out[(int64_t)b * 2 * C + c] = (float)(s / count);
+    out[(int64_t)b * 2 * C + C + c] = m;
+  }
 }
 extern "C" int64_t ppst_gap_gmp_ws(int B, int64_t hw, int C) {
   if (B <= 0 || hw <= 0) return 0;
@@ -495,7 +509,7 @@ extern "C" int ppst_gap_gmp(const void* x, const void* mask, void* out, void* ws
   }
   int e = PPST_LAUNCH_CHECK();
   if (e) return e;
-  PPST_LAUNCH(gap_gmp_finalize_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, as_stream(stream),
+  PPST_LAUNCH(gap_gmp_finalize_kernel, dim3(B * cdiv(C, 32)), dim3(256), 0, as_stream(stream),
                      (const float*)ws, nchunks, (float*)out, B, C, (double)H * W);
   return PPST_LAUNCH_CHECK();
 }

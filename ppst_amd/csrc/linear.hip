@@ -58,6 +58,46 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
   }
 }
 
+// Same contract, long rows (K >= 1024, K % 4 == 0): the 4 waves of a block share ONE output row
+// (each streams a quarter of it), so a 512-row layer runs 512 blocks instead of 128 -- the
+// one-wave-per-row form leaves half the CUs idle on the StyleMod / projector GEMVs.
+template <int BT>
+__global__ __launch_bounds__(256) void linear_ksplit_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int B, int K,
+                                                            int N, float wscale, float bscale, int relu_in, int act, int b0) {
+  __shared__ float sm[4][BT];
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float acc[BT];
+#pragma unroll
+  for (int b = 0; b < BT; ++b) acc[b] = 0.f;
+  const float* wr = w + (int64_t)n * K;
+  for (int k = threadIdx.x * 4; k < K; k += 1024) {
+    float4 ww = *(const float4*)(wr + k);
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      if (b0 + b < B) {
+        float4 xv = *(const float4*)(x + (int64_t)(b0 + b) * K + k);
+        if (relu_in) { xv.x = fmaxf(xv.x, 0.f); xv.y = fmaxf(xv.y, 0.f); xv.z = fmaxf(xv.z, 0.f); xv.w = fmaxf(xv.w, 0.f); }
+        acc[b] += xv.x * ww.x + xv.y * ww.y + xv.z * ww.z + xv.w * ww.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < BT; ++b) acc[b] = wave_sum(acc[b]);
+  if (lane == 0) {
+#pragma unroll
+    for (int b = 0; b < BT; ++b) sm[wv][b] = acc[b];
+  }
+  __syncthreads();
+  if (threadIdx.x < BT && b0 + (int)threadIdx.x < B) {
+    const int b = threadIdx.x;
+    float v = ((sm[0][b] + sm[1][b]) + (sm[2][b] + sm[3][b])) * wscale + (bias ? bias[n] * bscale : 0.f);
+    if (act == PPST_ACT_LRELU) v = (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
+    y[(int64_t)(b0 + b) * N + n] = v;
+  }
+}
+
 extern "C" int ppst_linear(const void* x, const void* w, const void* bias, void* y, int B, int K, int N, float wscale,
                            float bscale, int relu_in, int act, void* stream) {
   if (B < 0 || K <= 0 || N <= 0) return PPST_EINVAL;
@@ -65,9 +105,17 @@ extern "C" int ppst_linear(const void* x, const void* w, const void* bias, void*
   if (!x || !w || !y) return PPST_ENULL;
   for (int b0 = 0; b0 < B; b0 += LIN_BMAX) {
     int nb = B - b0 < LIN_BMAX ? B - b0 : LIN_BMAX;
-    dim3 grid(cdiv(N, 4));
-#define LAUNCH(BT) PPST_LAUNCH(linear_kernel<BT>, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)w, \
-                                      (const float*)bias, (float*)y, B, K, N, wscale, bscale, relu_in, act, b0)
+    const bool ksplit = K >= 1024 && (K & 3) == 0 && N <= 8192;
+    dim3 grid(ksplit ? N : cdiv(N, 4));
+#define LAUNCH(BT)                                                                                                          \
+  do {                                                                                                                      \
+    if (ksplit)                                                                                                             \
+      PPST_LAUNCH(linear_ksplit_kernel<BT>, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)w,       \
+                  (const float*)bias, (float*)y, B, K, N, wscale, bscale, relu_in, act, b0);                                \
+    else                                                                                                                    \
+      PPST_LAUNCH(linear_kernel<BT>, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)w,              \
+                  (const float*)bias, (float*)y, B, K, N, wscale, bscale, relu_in, act, b0);                                \
+  } while (0)
     if (nb <= 1) LAUNCH(1);
     else if (nb <= 2) LAUNCH(2);
     else if (nb <= 4) LAUNCH(4);
