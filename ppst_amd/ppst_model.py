@@ -22,7 +22,8 @@ class Options:
     def __init__(self, **kw):
         d = dict(netE1="StyleGAN2Resnet", netE2="StyleGAN2Resnet", netG="StyleGAN2Resnet", netD="StyleGAN2",
                  spatial_code_ch=256, global_code_ch=2048, crop_size=512, lambda_GAN=1.0, match_kernel=1,
-                 num_gpus=1, local_rank=1, isTrain=False)
+                 num_gpus=1, local_rank=1, isTrain=False, checkpoints_dir="./checkpoints", name="ppst",
+                 resume_iter="latest", pretrained_name=None)
         d.update(kw)
         self.__dict__.update(d)
 
@@ -53,6 +54,64 @@ class PPSTModel(nn.Module):
             raise KeyError("state dict lacks %d keys, e.g. %s" % (len(missing), missing[:3]))
         self.load_state_dict({k: sd[k] for k in own}, strict=True)
         return self
+
+    # BaseModel.save / BaseModel.load (models/base_model.py:33-112): same file layout
+    # (<checkpoints_dir>/<name>/<iter>_checkpoint.pth + latest_checkpoint.pth symlink), same key
+    # walk -- own keys only, D.* skipped at test time, missing keys skipped with a message.  A
+    # shape mismatch asks the reference's user on stdin; here ``force`` decides (None: raise,
+    # "all": copy the overlapping corner and zero the rest, the reference's "all" answer).
+    def save(self, total_steps_so_far):
+        import os
+        savedir = os.path.join(self.opt.checkpoints_dir, self.opt.name)
+        os.makedirs(savedir, exist_ok=True)
+        checkpoint_name = "%dk_checkpoint.pth" % (total_steps_so_far // 1000)
+        torch.save({k: v.detach().cpu() for k, v in self.state_dict().items()}, os.path.join(savedir, checkpoint_name))
+        sympath = os.path.join(savedir, "latest_checkpoint.pth")
+        if os.path.lexists(sympath):
+            os.remove(sympath)
+        os.symlink(checkpoint_name, sympath)
+        return os.path.join(savedir, checkpoint_name)
+
+    def load(self, checkpoint_path=None, force=None, verbose=True):
+        import os
+        opt = self.opt
+        if checkpoint_path is None:
+            name = opt.pretrained_name if (opt.isTrain and getattr(opt, "pretrained_name", None) is not None) else opt.name
+            checkpoint_path = os.path.join(opt.checkpoints_dir, name, "%s_checkpoint.pth" % opt.resume_iter)
+        if not os.path.exists(checkpoint_path):
+            assert opt.isTrain, "In test mode, the checkpoint file must exist (%s)" % checkpoint_path
+            if verbose:
+                print("checkpoint %s does not exist! Training will start from scratch" % checkpoint_path)
+            return False
+        sd = torch.load(checkpoint_path, map_location="cpu")
+        with torch.no_grad():
+            for name, own in self.state_dict().items():
+                if not opt.isTrain and (name.startswith("D.") or name.startswith("Dpatch.")):
+                    continue
+                if name not in sd:
+                    if verbose:
+                        print("Key %s does not exist in checkpoint. Skipping..." % name)
+                    continue
+                param = sd[name]
+                if own.shape != param.shape:
+                    msg = "Key [%s]: Shape does not match the created model (%s) and loaded checkpoint (%s)" % (
+                        name, str(own.shape), str(param.shape))
+                    if force != "all":
+                        raise ValueError(msg)
+                    ms = [min(a, b) for a, b in zip(own.shape, param.shape)]
+                    if len(ms) in (1, 2, 4):
+                        lo = tuple(slice(0, m) for m in ms)
+                        hi = tuple(slice(m, None) for m in ms)
+                        own[lo].copy_(param[lo])
+                        own[hi].zero_()
+                    continue
+                own.copy_(param)
+        for net in (self.E1, self.E2, self.G, getattr(self, "D", None)):
+            if net is not None and hasattr(net, "_cache"):
+                net._cache.clear()  # packed weights / style tables are stale
+        if verbose:
+            print("checkpoint loaded from %s" % checkpoint_path)
+        return True
 
     def per_gpu_initialize(self):
         pass
