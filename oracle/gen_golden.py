@@ -194,6 +194,49 @@ def gen_keys(m):
     print("state_dict_keys.json", len(keys))
 
 
+def train_inputs(size=128, B=2):
+    """Seeded inputs of the train-step fixture (shared with tests/test_oracle_golden.py)."""
+    g = torch.Generator().manual_seed(1234)
+    real = torch.rand(B, 3, size, size, generator=g) * 2 - 1
+    rec = torch.rand(B // 2, 3, size, size, generator=g) * 2 - 1
+    mix = torch.rand(B, 3, size, size, generator=g) * 2 - 1
+    return real, rec, mix
+
+
+def gen_train(ns, size=128):
+    """Discriminator iteration + lazy R1 from the reference's own methods and autograd
+    (models/ppst_model.py:68-92, 140-159; optimizers/ppst_optimizer.py:112-125) on the reference's
+    own Discriminator at crop_size 128: loss values, every parameter gradient (sampled)."""
+    opt = ref_loader.default_opt(crop_size=size, load_size=size)
+    D = ns.ppst_model.networks.create_network(opt, opt.netD, "discriminator")
+    sd = W.make_state_dict(11, size=size, with_nce=False, bias_std=0.1)
+    D.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith("D.")}, strict=True)
+    D.train()
+
+    class Host:
+        pass
+    h = Host()
+    h.D, h.opt = D, opt
+    PM = ns.ppst_model.PPSTModel
+    real, rec, mix = train_inputs(size)
+    out = {}
+    losses = PM.compute_image_discriminator_losses(h, real, rec, mix, None)
+    for k, v in losses.items():
+        out["loss." + k] = v.detach().numpy().astype(np.float64)
+    D.zero_grad()
+    sum(v.mean() for v in losses.values()).backward()
+    for n, p in D.named_parameters():
+        pack(out, "dgrad.D." + n, p.grad)
+    D.zero_grad()
+    r1 = PM.compute_R1_loss(h, real.clone())
+    out["loss.D_R1"] = r1["D_R1"].detach().numpy().astype(np.float64)
+    (sum(v.mean() for v in r1.values()) * opt.R1_once_every).backward()
+    for n, p in D.named_parameters():
+        pack(out, "r1grad.D." + n, p.grad if p.grad is not None else torch.zeros_like(p))
+    np.savez_compressed(os.path.join(GOLD, "train128.npz"), **out)
+    print("train128.npz", len(out), {k: v for k, v in out.items() if k.startswith("loss.")})
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ns = ref_loader.load_reference()
@@ -203,6 +246,7 @@ def main():
     gen_ops(ns)
     gen_cfg1(ns, m)
     gen_swap(ns, m)
+    gen_train(ns)
 
 
 if __name__ == "__main__":

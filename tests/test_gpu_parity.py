@@ -72,6 +72,44 @@ def test_lazy_r1_penalty_vs_double_backward_oracle():
     _run("t_train_r1")
 
 
+def test_train_step_matches_reference_golden():
+    """The HIP D iteration + lazy R1 against tests/golden/train128.npz, which holds what the
+    reference's own compute_image_discriminator_losses / compute_R1_loss + autograd produced."""
+    import numpy as np
+    from ppst_amd import weights as W
+    from ppst_amd.networks.discriminator import StyleGAN2Discriminator
+    from ppst_amd.train import DiscriminatorTrainer
+    from test_oracle_golden import sample_idx, train_inputs
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train128.npz"))
+    size = 128
+    sd = W.make_state_dict(11, size=size, with_nce=False, bias_std=0.1)
+    D = StyleGAN2Discriminator(None, size=size)
+    D.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith("D.")}, strict=True)
+    tr = DiscriminatorTrainer(D.cuda())
+    real, rec, mix = (t.cuda() for t in train_inputs(size))
+
+    def check(prefix, tol_l2, tol_max):
+        for name in tr.names:
+            key = prefix + "D." + name
+            got = tr.g(name).double().cpu().numpy()
+            ref = g[key + ".samples"].astype(np.float64)
+            scale = float(g[key + ".stats"][2])
+            d = got[sample_idx(key, got.size)] - ref
+            if scale == 0.0:
+                assert np.abs(got).max() == 0.0, key
+                continue
+            assert np.abs(d).max() <= tol_max * scale, (key, np.abs(d).max(), scale)
+            assert np.linalg.norm(d) <= tol_l2 * np.linalg.norm(ref) + 1e-12, (key, np.linalg.norm(d), np.linalg.norm(ref))
+
+    losses = tr.losses_and_grads(real, rec, mix)
+    for k in ("D_real", "D_rec", "D_mix"):
+        assert abs(float(losses[k]) - float(g["loss." + k])) <= 1e-4 * max(1.0, abs(float(g["loss." + k]))), k
+    check("dgrad.", 5e-3, 5e-3)
+    r1 = tr.r1_losses_and_grads(real)
+    assert np.allclose(r1["D_R1"].cpu().numpy(), g["loss.D_R1"], rtol=1e-3)
+    check("r1grad.", 2e-2, 1e-1)   # tolerance rationale: gpu_diag.t_train_r1
+
+
 def test_swap_matches_reference_golden():
     """The HIP path against the fixtures produced by the *reference itself*
     (oracle/gen_golden.py): sampled activations of the full recipe."""

@@ -123,3 +123,39 @@ def test_swap512_recipe(golden_dir):
     assert np.abs(hist - g["out_u8.hist"]).sum() <= 1e-3 * hist.sum()
     assert np.allclose(d.numpy(), g["D"], atol=1e-5)
     check_packed(g, "warp_img", wimg, rtol=5e-5)
+
+
+def train_inputs(size=128, B=2):
+    """The seeded inputs oracle/gen_golden.py:train_inputs used for train128.npz."""
+    g = torch.Generator().manual_seed(1234)
+    real = torch.rand(B, 3, size, size, generator=g) * 2 - 1
+    rec = torch.rand(B // 2, 3, size, size, generator=g) * 2 - 1
+    mix = torch.rand(B, 3, size, size, generator=g) * 2 - 1
+    return real, rec, mix
+
+
+def test_train_step_oracle_vs_reference_autograd(golden_dir):
+    """oracle/train_oracle.py (D losses, their parameter gradients, the lazy R1 penalty and its
+    double-backward gradients) against what the reference's own methods + autograd produced on
+    the reference's Discriminator (crop_size 128, fixtures in train128.npz)."""
+    import train_oracle as T
+    g = np.load(os.path.join(golden_dir, "train128.npz"))
+    size = 128
+    sd = W.make_state_dict(11, size=size, with_nce=False, bias_std=0.1)
+    real, rec, mix = train_inputs(size)
+    losses, grads = T.d_step_grads(sd, real, rec, mix, size=size)
+    for k in ("D_real", "D_rec", "D_mix"):
+        assert abs(losses[k] - float(g["loss." + k])) <= 2e-6 * max(1.0, abs(float(g["loss." + k]))), k
+    n = 0
+    for k, v in grads.items():
+        check_packed(g, "dgrad." + k, v, rtol=5e-4)  # a leaky-ReLU gate flipping between two fp32 summation orders moves a few-term sum
+        n += 1
+    assert n == len([k for k in g.files if k.startswith("dgrad.") and k.endswith(".shape")])
+    pen, r1g = T.r1_step_grads(sd, real, size=size)
+    assert np.allclose(pen.numpy(), g["loss.D_R1"], rtol=1e-4)
+    for k, v in r1g.items():
+        name = "r1grad." + k
+        if float(g[name + ".stats"][2]) == 0.0:
+            assert float(v.abs().max()) == 0.0, k   # biases: no R1 gradient
+        else:
+            check_packed(g, name, v, rtol=2e-3)     # leaky-ReLU gate flips between two fp32 summation orders
