@@ -63,9 +63,15 @@ int ppst_upfirdn2d(const void* x, const void* k, void* y,
  * nn.ReflectionPad2d first, :151-159); down=2 keeps every second sample (all that a
  * following stride-2 1x1 conv reads); s2d=1 writes the output space-to-depth
  * y[B][ceil(oh/2)][ceil(ow/2)][4*C] (phase (oy&1)*2+(ox&1) major) for the stride-2
- * 3x3 conv that ppst_conv2d_mfma runs as a stride-1 conv over that layout. */
+ * 3x3 conv that ppst_conv2d_mfma runs as a stride-1 conv over that layout (the padded
+ * extent is written in full: zeros beyond (oh, ow), so y needs no initialisation).
+ * in_scale_shift (optional, [B][C][2] (a, s)) + in_act (PPST_ACT_NONE / PPST_ACT_LRELU):
+ * the input is read as in_act(a*x + s) -- the InstanceNorm + FusedLeakyReLU that
+ * ConvLayer(norm='in') puts in front of the Blur (:542-549) without a pass of its own;
+ * zero-padding positions stay 0. */
 int ppst_blur_nhwc(const void* x, const void* k, void* y, int B, int in_h, int in_w, int C,
-                   int ksize, int pad0, int pad1, int pad_mode, int down, int s2d, void* stream);
+                   int ksize, int pad0, int pad1, int pad_mode, int down, int s2d,
+                   const void* in_scale_shift, int in_act, void* stream);
 
 /* fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)
  *   -- stylegan2_op/fused_bias_act.cpp:4-20, fused_bias_act_kernel.cu:19-49.

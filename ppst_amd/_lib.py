@@ -47,7 +47,7 @@ class ConvArgs(ctypes.Structure):
 _SIGS = {
     "ppst_version": (i32, []),
     "ppst_upfirdn2d": (i32, [vp, vp, vp] + [i32] * 14 + [i32, vp]),
-    "ppst_blur_nhwc": (i32, [vp, vp, vp] + [i32] * 10 + [vp]),
+    "ppst_blur_nhwc": (i32, [vp, vp, vp] + [i32] * 10 + [vp, i32, vp]),
     "ppst_fused_bias_act": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, i32, vp]),
     "ppst_nchw_to_nhwc": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ppst_nhwc_to_nchw": (i32, [vp, vp, i32, i32, i32, i32, vp]),

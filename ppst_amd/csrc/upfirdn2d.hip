@@ -21,6 +21,8 @@ struct UfParams {
   int out_h, out_w;
   const float* k;  // device taps [kh][kw]; flipped on read (true convolution, .cu:81)
   int pad_mode;    // chan kernel only: PPST_PAD_ZERO or PPST_PAD_REFLECT (fused nn.ReflectionPad2d)
+  const float* in_ss;  // chan kernel only: optional [major][minor][2] (a, s): input read as in_act(a*x + s)
+  int in_act;          // PPST_ACT_NONE / PPST_ACT_LRELU
 };
 
 __device__ __forceinline__ int uf_reflect(int i, int n) {
@@ -91,6 +93,8 @@ __global__ __launch_bounds__(256) void upfirdn2d_chan(const float4* __restrict__
   for (int i = 0; i < KH * KW; ++i) kf[i] = p.k[KH * KW - 1 - i];
   const int xs = (p.out_w + PX - 1) / PX;
   (void)xs;
+  // S2D: the padded extent (2*ceil(oh/2) x 2*ceil(ow/2)) is written in full, zeros beyond (oh, ow)
+  const int eh = S2D ? ((p.out_h + 1) & ~1) : p.out_h, ew = S2D ? ((p.out_w + 1) & ~1) : p.out_w;
   for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < nwork; t64 += (uint64_t)gridDim.x * 256) {
     unsigned c4u, sxu, oyu;
     unsigned r = fd_divmod((unsigned)t64, d_c, c4u);
@@ -101,18 +105,34 @@ __global__ __launch_bounds__(256) void upfirdn2d_chan(const float4* __restrict__
     float4 acc[PX];
 #pragma unroll
     for (int i = 0; i < PX; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sa = make_float4(1.f, 1.f, 1.f, 1.f), sb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.in_ss) {
+      const float4* q = (const float4*)(p.in_ss + ((int64_t)m * p.minor + c4 * 4) * 2);
+      float4 q0 = q[0], q1 = q[1];
+      sa = make_float4(q0.x, q0.z, q1.x, q1.z); sb = make_float4(q0.y, q0.w, q1.y, q1.w);
+    }
+    const bool row_ok = oy < p.out_h;
 #pragma unroll
     for (int ky = 0; ky < KH; ++ky) {
       int iy = oy * DOWN + ky - p.pad_y0;
       if (p.pad_mode == PPST_PAD_REFLECT) iy = uf_reflect(iy, p.in_h);
-      bool yok = iy >= 0 && iy < p.in_h;
+      bool yok = row_ok && iy >= 0 && iy < p.in_h;
       const float4* row = x + ((int64_t)m * p.in_h + (yok ? iy : 0)) * p.in_w * c4n + c4;
 #pragma unroll
       for (int j = 0; j < (PX - 1) * DOWN + KW; ++j) {
         int ix = ox0 * DOWN + j - p.pad_x0;
         if (p.pad_mode == PPST_PAD_REFLECT) ix = uf_reflect(ix, p.in_w);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (yok && ix >= 0 && ix < p.in_w) v = row[(int64_t)ix * c4n];
+        if (yok && ix >= 0 && ix < p.in_w) {
+          v = row[(int64_t)ix * c4n];
+          if (p.in_ss) {  // normalise on load; zero padding stays zero (it pads the normalised tensor)
+            v.x = sa.x * v.x + sb.x; v.y = sa.y * v.y + sb.y; v.z = sa.z * v.z + sb.z; v.w = sa.w * v.w + sb.w;
+            if (p.in_act == PPST_ACT_LRELU) {
+              v.x = (v.x > 0.f ? v.x : v.x * 0.2f) * 1.41421356237309515f; v.y = (v.y > 0.f ? v.y : v.y * 0.2f) * 1.41421356237309515f;
+              v.z = (v.z > 0.f ? v.z : v.z * 0.2f) * 1.41421356237309515f; v.w = (v.w > 0.f ? v.w : v.w * 0.2f) * 1.41421356237309515f;
+            }
+          }
+        }
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
           int kx = j - i * DOWN;
@@ -128,8 +148,9 @@ __global__ __launch_bounds__(256) void upfirdn2d_chan(const float4* __restrict__
 #pragma unroll
       for (int i = 0; i < PX; ++i) {
         int ox = ox0 + i;
-        if (ox < p.out_w)
-          y[((((int64_t)m * oh2 + (oy >> 1)) * ow2 + (ox >> 1)) * 4 + (oy & 1) * 2 + (ox & 1)) * c4n + c4] = acc[i];
+        if (ox < ew)
+          y[((((int64_t)m * oh2 + (oy >> 1)) * ow2 + (ox >> 1)) * 4 + (oy & 1) * 2 + (ox & 1)) * c4n + c4] =
+              (row_ok && ox < p.out_w) ? acc[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
       float4* orow = y + ((int64_t)m * p.out_h + oy) * p.out_w * c4n + c4;
@@ -168,12 +189,13 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic(const float* __restrict
 
 template <int KH, int KW>
 static int launch_chan(const float* x, float* y, const UfParams& p, int down, bool s2d, hipStream_t st) {
-  int64_t nwork = (int64_t)p.major * p.out_h * cdiv(p.out_w, 4) * (p.minor / 4);
+  const int eh = s2d ? ((p.out_h + 1) & ~1) : p.out_h, ew = s2d ? ((p.out_w + 1) & ~1) : p.out_w;
+  int64_t nwork = (int64_t)p.major * eh * cdiv(ew, 4) * (p.minor / 4);
   if (nwork > PPST_IDX32_MAX) return PPST_EINVAL;
   int64_t blocks = cdiv64(nwork, 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
   dim3 g((unsigned)blocks), b(256);
-  const FastDiv d_c = make_fastdiv(p.minor / 4), d_xs = make_fastdiv(cdiv(p.out_w, 4)), d_oh = make_fastdiv(p.out_h);
+  const FastDiv d_c = make_fastdiv(p.minor / 4), d_xs = make_fastdiv(cdiv(ew, 4)), d_oh = make_fastdiv(eh);
   const unsigned nw = (unsigned)nwork;
   if (s2d) PPST_LAUNCH((upfirdn2d_chan<KH, KW, 1, true>), g, b, 0, st, (const float4*)x, (float4*)y, p, nw, d_c, d_xs, d_oh);
   else if (down == 2) PPST_LAUNCH((upfirdn2d_chan<KH, KW, 2, false>), g, b, 0, st, (const float4*)x, (float4*)y, p, nw, d_c, d_xs, d_oh);
@@ -207,6 +229,7 @@ extern "C" int ppst_upfirdn2d(const void* x, const void* k, void* y, int major, 
   p.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw + down_x) / down_x;
   if (p.out_h <= 0 || p.out_w <= 0) return PPST_EINVAL;
   if (major == 0) return PPST_OK;
+  p.in_ss = nullptr; p.in_act = PPST_ACT_NONE;
   p.k = (const float*)k;
   p.pad_mode = PPST_PAD_ZERO;
   hipStream_t st = as_stream(stream);
@@ -231,10 +254,11 @@ extern "C" int ppst_upfirdn2d(const void* x, const void* k, void* y, int major, 
 // stride-2 1x1 conv reads) or space-to-depth output for a following stride-2 3x3 conv:
 //   s2d: y [B][ceil(oh/2)][ceil(ow/2)][4*C], phase (oy&1)*2+(ox&1) major over channels.
 extern "C" int ppst_blur_nhwc(const void* x, const void* k, void* y, int B, int in_h, int in_w, int C, int ksize, int pad0,
-                              int pad1, int pad_mode, int down, int s2d, void* stream) {
+                              int pad1, int pad_mode, int down, int s2d, const void* in_scale_shift, int in_act, void* stream) {
   if (!x || !k || !y) return PPST_ENULL;
   if (B < 0 || in_h <= 0 || in_w <= 0 || C <= 0 || C % 4 || (ksize != 3 && ksize != 4) || (down != 1 && down != 2) ||
-      (s2d && down != 1) || (pad_mode != PPST_PAD_ZERO && pad_mode != PPST_PAD_REFLECT))
+      (s2d && down != 1) || (pad_mode != PPST_PAD_ZERO && pad_mode != PPST_PAD_REFLECT) ||
+      (in_act != PPST_ACT_NONE && in_act != PPST_ACT_LRELU) || (in_act != PPST_ACT_NONE && !in_scale_shift))
     return PPST_EINVAL;
   UfParams p;
   p.major = B; p.in_h = in_h; p.in_w = in_w; p.minor = C; p.kh = ksize; p.kw = ksize;
@@ -243,6 +267,7 @@ extern "C" int ppst_blur_nhwc(const void* x, const void* k, void* y, int B, int 
   p.out_w = (in_w + pad0 + pad1 - ksize + down) / down;
   p.k = (const float*)k;
   p.pad_mode = pad_mode;
+  p.in_ss = (const float*)in_scale_shift; p.in_act = in_act;
   if (p.out_h <= 0 || p.out_w <= 0) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (ksize == 3) return launch_chan<3, 3>((const float*)x, (float*)y, p, down, s2d != 0, as_stream(stream));

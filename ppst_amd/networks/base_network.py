@@ -144,9 +144,10 @@ class BaseNetwork(nn.Module):
                 out_scale=INV_SQRT2, out_hw=ohw)
         # norm == 'in' (E1): conv -> InstanceNorm -> FusedLeakyReLU (:542-549)
         y1, st1 = self.plan(p + "conv1.Conv.weight", scale=sc1)(x, stats=True, pad_mode=conv_pad)
-        y1, _ = self._norm_act(y1, st1, H * W, self.p(p + "conv1.Act.bias"), ops.ACT_LRELU)
+        ss1 = ops.in_finalize(st1, H * W, post_bias=self.p(p + "conv1.Act.bias"))
         ys, sts = self.plan(p + "skip.Conv.weight", scale=scs)(xs, stats=True)
-        xb, bhw = ops.blur_nhwc(y1, k, (pad_c + 1) // 2, pad_c // 2, blur_pad_mode, s2d=True)
+        # the norm + leaky-relu of conv1 is applied by the blur while it reads (no apply pass)
+        xb, bhw = ops.blur_nhwc(y1, k, (pad_c + 1) // 2, pad_c // 2, blur_pad_mode, s2d=True, in_ss=ss1, in_act=ops.ACT_LRELU)
         ohw = ((bhw[0] - 3) // 2 + 1, (bhw[1] - 3) // 2 + 1)
         y2, st2 = self.plan(p + "conv2.Conv.weight", "s2d", sc1)(xb, stats=True, out_hw=ohw)
         cnt = ohw[0] * ohw[1]

@@ -94,7 +94,7 @@ def upfirdn2d_raw(x4, kernel, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
     return y
 
 
-def blur_nhwc(x, kernel, pad0, pad1, pad_mode=PAD_ZERO, down=1, s2d=False):
+def blur_nhwc(x, kernel, pad0, pad1, pad_mode=PAD_ZERO, down=1, s2d=False, in_ss=None, in_act=ACT_NONE):
     ld = _nhwc_ld(x)
     B, H, W, C = x.shape
     if ld != C:
@@ -104,11 +104,12 @@ def blur_nhwc(x, kernel, pad0, pad1, pad_mode=PAD_ZERO, down=1, s2d=False):
     oh = (H + pad0 + pad1 - ks + down) // down
     ow = (W + pad0 + pad1 - ks + down) // down
     if s2d:
-        y = torch.zeros((B, (oh + 1) // 2, (ow + 1) // 2, 4 * C), device=x.device, dtype=torch.float32)
+        y = torch.empty((B, (oh + 1) // 2, (ow + 1) // 2, 4 * C), device=x.device, dtype=torch.float32)
     else:
         y = torch.empty((B, oh, ow, C), device=x.device, dtype=torch.float32)
+    _chk(in_ss, "in_ss")
     check(lib.ppst_blur_nhwc(_p(x), _p(kernel.contiguous()), _p(y), B, H, W, C, ks, pad0, pad1, pad_mode, down,
-                             1 if s2d else 0, _stream()), "ppst_blur_nhwc")
+                             1 if s2d else 0, _p(in_ss), in_act, _stream()), "ppst_blur_nhwc")
     return y, (oh, ow)
 
 
