@@ -59,6 +59,38 @@ def conv_traffic():
         return None
 
 
+def upfirdn2d_rate(B, dev):
+    """North-star side metric: achieved HBM GB/s of the Blur (upfirdn2d) on the largest encoder
+    blur of the step -- (B,32,512,512) NHWC, 3x3 [1,2,1] taps, reflection pad, space-to-depth
+    output -- algorithmic bytes 4*B*C*(Hin*Win + Hout*Wout) / HIP-event time."""
+    from ppst_amd import ops
+    x = torch.randn(B, 512, 512, 32, device=dev)
+    k = torch.tensor([1., 2., 1.], device=dev)
+    k2 = (k[:, None] * k[None, :] / 16).contiguous()
+    for _ in range(3):
+        y, (oh, ow) = ops.blur_nhwc(x, k2, 2, 1, ops.PAD_REFLECT, s2d=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n):
+        ops.blur_nhwc(x, k2, 2, 1, ops.PAD_REFLECT, s2d=True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    nbytes = 4.0 * B * 32 * (512 * 512 + oh * ow)
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": "upfirdn2d_chan<3,3,1,s2d> (B,512,512,32) reflect pad", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "us_per_launch": ms * 1e3}
+
+
+def conv_pmc():
+    """Effective clock of the conv launches from the GRBM_GUI_ACTIVE pass (profiles/, see conv_traffic)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["conv_mfma"].get("effective_clock_ghz")
+    except Exception:
+        return None
+
+
 def cpu_baseline(seed):
     """The CPU oracle (a port of the reference's PyTorch-CPU path, pinned to it by
     tests/golden) timed on ONE pair at 512x512 on the host cores of this box."""
@@ -156,8 +188,10 @@ def main():
                 "frac_vs_dense_bf16": achieved / PEAK_BF16_DENSE_TF,
                 "launches": conv_launches, "kernel_ms_total": conv_ms,
                 "share_of_step_time": conv_ms * 1e-3 / dt, "traffic": conv_traffic(),
+                "effective_clock_ghz_pmc": conv_pmc(),
             },
         }
+        res["roofline_upfirdn2d"] = upfirdn2d_rate(B, dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(0)
         print(json.dumps(res))

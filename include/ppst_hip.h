@@ -265,6 +265,20 @@ int ppst_softmax_rows(void* x, int64_t rows, int cols, float div, void* stream);
 int ppst_unfold_patches(const void* x, void* y, int B, int C, int H, int W, int s, void* stream);
 int ppst_fold_patches(const void* x, void* y, int B, int C, int H, int W, int s, void* stream);
 
+/* -------------------------------------------------------- pre-process ---- */
+/* One pass of Pillow's 8-bit resample (Image.resize(..., BICUBIC): data/base_dataset.py:141-168
+ * __make_power_2 / __scale_shortside) over interleaved uint8 images x [B][in_h][in_w][C]:
+ * horizontal != 0 resizes the width to out_size, else the height.  bounds int32 [out_size][2] =
+ * (first input sample, count), coef int32 [out_size][ksize] = 22-bit fixed-point weights (host
+ * logic: Pillow's precompute_coeffs + normalize_coeffs_8bpc, ppst_amd/imageio.py).
+ * y = clip8((2^21 + sum in*coef) >> 22): integer arithmetic, bit-exact.  Pillow runs the
+ * horizontal pass first, then the vertical one, each rounding to uint8. */
+int ppst_resample_u8(const void* x, void* y, int B, int in_h, int in_w, int C, int out_size, int horizontal,
+                     const void* bounds, const void* coef, int ksize, void* stream);
+/* transforms.ToTensor + transforms.Normalize(mean, std) (base_dataset.py:133-138): uint8 HWC
+ * [B][H][W][C] -> fp32 NCHW, (v/255 - mean)/std in that operation order. */
+int ppst_u8_to_tensor(const void* x, void* y, int B, int H, int W, int C, float mean, float stdv, void* stream);
+
 /* ------------------------------------------------------- post-process ---- */
 /* util.tensor2im quantisation (util/util.py:98-131): NCHW fp32 [-1,1] ->
  * HWC uint8, ((x+1)/2*255) clipped and truncated. */

@@ -79,6 +79,8 @@ _SIGS = {
     "ppst_unfold_patches": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ppst_fold_patches": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ppst_tensor2im_u8": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ppst_resample_u8": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp]),
+    "ppst_u8_to_tensor": (i32, [vp, vp, i32, i32, i32, i32, f32, f32, vp]),
     "ppst_guided_filter_ws": (i64, [i32, i32, i32]),
     "ppst_guided_filter": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp]),
     "ppst_conv_wgrad_f32": (i32, [vp, vp, vp, vp, vp] + [i32] * 11 + [vp]),

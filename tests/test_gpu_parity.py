@@ -136,6 +136,42 @@ def test_swap_matches_reference_golden():
     assert np.abs(d.cpu().numpy() - g["D"]).max() <= 1e-3 * np.abs(g["D"]).max()
 
 
+def test_image_preprocessing_is_pillow_bit_exact():
+    """Device bicubic resample (two integer passes) + ToTensor/Normalize against the oracle
+    (oracle/resize_oracle.py, itself pinned to Pillow) and, when Pillow is importable, Pillow itself at
+    a full-size case (768x1024 -> short side 512 -> multiple of 16)."""
+    import numpy as np
+    import resize_oracle as R
+    from ppst_amd import imageio
+    rng = np.random.default_rng(11)
+    for (h, w), (oh, ow) in (((37, 53), (21, 29)), ((64, 48), (128, 96)), ((50, 50), (50, 31)), ((31, 77), (64, 77)), ((9, 200), (16, 16))):
+        a = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+        a[0, :3, :3] = 255; a[1, -3:, -3:] = 0
+        got = imageio.resize_bicubic_u8(torch.from_numpy(a).cuda(), oh, ow).cpu().numpy()
+        for b in range(2):
+            assert np.array_equal(got[b], R.resize_u8(a[b], oh, ow)), ((h, w), (oh, ow), b)
+    a = rng.integers(0, 256, (2, 90, 130, 3), dtype=np.uint8)
+    t = imageio.preprocess(torch.from_numpy(a).cuda(), 64).cpu().numpy()
+    for b in range(2):
+        assert np.array_equal(t[b], R.preprocess(a[b], 64))
+    assert imageio.resize_bicubic_u8(torch.zeros((0, 8, 8, 3), dtype=torch.uint8, device="cuda"), 4, 4).shape == (0, 4, 4, 3)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    yy, xx = np.mgrid[0:768, 0:1024]
+    big = np.stack([(xx * 255 // 1023), (yy * 255 // 767), ((xx * 7 + yy * 13) % 256)], -1).astype(np.uint8)
+    big = (big.astype(np.int32) + rng.integers(-20, 21, big.shape)).clip(0, 255).astype(np.uint8)
+    t = imageio.preprocess(torch.from_numpy(big[None]).cuda(), 512)[0].cpu().numpy()
+    w1, h1 = R.scale_shortside_size(1024, 768, 512)
+    im = Image.fromarray(big).resize((w1, h1), Image.BICUBIC)
+    w2, h2 = R.make_power_2_size(w1, h1)
+    if (w2, h2) != (w1, h1):
+        im = im.resize((w2, h2), Image.BICUBIC)
+    ref = (np.asarray(im).astype(np.float32) / np.float32(255) - np.float32(0.5)) / np.float32(0.5)
+    assert t.shape == (3, h2, w2) and np.array_equal(t, ref.transpose(2, 0, 1))
+
+
 def test_full_size_properties():
     """Size-independent properties at the BASELINE sizes (512x512, batch 8)."""
     from ppst_amd import ops
