@@ -86,37 +86,39 @@ __global__ __launch_bounds__(256) void upfirdn2d_planes(const float* __restrict_
 template <int KH, int KW, int DOWN, bool S2D>
 __global__ __launch_bounds__(256) void upfirdn2d_chan(const float4* __restrict__ x, float4* __restrict__ y, UfParams p, unsigned nwork,
                                                       FastDiv d_c, FastDiv d_xs, FastDiv d_oh) {
-  constexpr int PX = 4;
+  // One thread = PX x PY output pixels x 4 channels: the (PY-1+KH) x ((PX-1)*DOWN+KW) input patch is read once into
+  // registers (DOWN = 1: 4 x 6 loads for 8 outputs instead of 3 x 6 for 4).
+  constexpr int PX = 4, PY = (DOWN == 1) ? 2 : 1;
   const int c4n = p.minor >> 2;
   float kf[KH * KW];
 #pragma unroll
   for (int i = 0; i < KH * KW; ++i) kf[i] = p.k[KH * KW - 1 - i];
-  const int xs = (p.out_w + PX - 1) / PX;
-  (void)xs;
   // S2D: the padded extent (2*ceil(oh/2) x 2*ceil(ow/2)) is written in full, zeros beyond (oh, ow)
-  const int eh = S2D ? ((p.out_h + 1) & ~1) : p.out_h, ew = S2D ? ((p.out_w + 1) & ~1) : p.out_w;
+  const int ew = S2D ? ((p.out_w + 1) & ~1) : p.out_w;
   for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < nwork; t64 += (uint64_t)gridDim.x * 256) {
     unsigned c4u, sxu, oyu;
     unsigned r = fd_divmod((unsigned)t64, d_c, c4u);
     r = fd_divmod(r, d_xs, sxu);
-    const int m = (int)fd_divmod(r, d_oh, oyu);
-    const int c4 = (int)c4u, oy = (int)oyu;
+    const int m = (int)fd_divmod(r, d_oh, oyu);   // d_oh divides by the number of PY-row groups
+    const int c4 = (int)c4u, oy0 = (int)oyu * PY;
     int ox0 = (int)sxu * PX;
-    float4 acc[PX];
+    float4 acc[PY][PX];
 #pragma unroll
-    for (int i = 0; i < PX; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < PY; ++j)
+#pragma unroll
+      for (int i = 0; i < PX; ++i) acc[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 sa = make_float4(1.f, 1.f, 1.f, 1.f), sb = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.in_ss) {
       const float4* q = (const float4*)(p.in_ss + ((int64_t)m * p.minor + c4 * 4) * 2);
       float4 q0 = q[0], q1 = q[1];
       sa = make_float4(q0.x, q0.z, q1.x, q1.z); sb = make_float4(q0.y, q0.w, q1.y, q1.w);
     }
-    const bool row_ok = oy < p.out_h;
+    const bool any_row = oy0 < p.out_h;
 #pragma unroll
-    for (int ky = 0; ky < KH; ++ky) {
-      int iy = oy * DOWN + ky - p.pad_y0;
+    for (int ry = 0; ry < (PY - 1) * DOWN + KH; ++ry) {
+      int iy = oy0 * DOWN + ry - p.pad_y0;
       if (p.pad_mode == PPST_PAD_REFLECT) iy = uf_reflect(iy, p.in_h);
-      bool yok = row_ok && iy >= 0 && iy < p.in_h;
+      bool yok = any_row && iy >= 0 && iy < p.in_h;
       const float4* row = x + ((int64_t)m * p.in_h + (yok ? iy : 0)) * p.in_w * c4n + c4;
 #pragma unroll
       for (int j = 0; j < (PX - 1) * DOWN + KW; ++j) {
@@ -134,29 +136,41 @@ __global__ __launch_bounds__(256) void upfirdn2d_chan(const float4* __restrict__
           }
         }
 #pragma unroll
-        for (int i = 0; i < PX; ++i) {
-          int kx = j - i * DOWN;
-          if (kx >= 0 && kx < KW) {
-            float f = kf[ky * KW + kx];
-            acc[i].x += v.x * f; acc[i].y += v.y * f; acc[i].z += v.z * f; acc[i].w += v.w * f;
+        for (int py = 0; py < PY; ++py) {
+          const int ky = ry - py * DOWN;
+          if (ky < 0 || ky >= KH) continue;
+#pragma unroll
+          for (int i = 0; i < PX; ++i) {
+            int kx = j - i * DOWN;
+            if (kx >= 0 && kx < KW) {
+              float f = kf[ky * KW + kx];
+              acc[py][i].x += v.x * f; acc[py][i].y += v.y * f; acc[py][i].z += v.z * f; acc[py][i].w += v.w * f;
+            }
           }
         }
       }
     }
-    if (S2D) {
-      const int oh2 = (p.out_h + 1) >> 1, ow2 = (p.out_w + 1) >> 1;
 #pragma unroll
-      for (int i = 0; i < PX; ++i) {
-        int ox = ox0 + i;
-        if (ox < ew)
-          y[((((int64_t)m * oh2 + (oy >> 1)) * ow2 + (ox >> 1)) * 4 + (oy & 1) * 2 + (ox & 1)) * c4n + c4] =
-              (row_ok && ox < p.out_w) ? acc[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int py = 0; py < PY; ++py) {
+      const int oy = oy0 + py;
+      const bool row_ok = oy < p.out_h;
+      if (S2D) {
+        const int oh2 = (p.out_h + 1) >> 1, ow2 = (p.out_w + 1) >> 1;
+        if (oy >= 2 * oh2) continue;
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+          int ox = ox0 + i;
+          if (ox < ew)
+            y[((((int64_t)m * oh2 + (oy >> 1)) * ow2 + (ox >> 1)) * 4 + (oy & 1) * 2 + (ox & 1)) * c4n + c4] =
+                (row_ok && ox < p.out_w) ? acc[py][i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      } else {
+        if (!row_ok) continue;
+        float4* orow = y + ((int64_t)m * p.out_h + oy) * p.out_w * c4n + c4;
+#pragma unroll
+        for (int i = 0; i < PX; ++i)
+          if (ox0 + i < p.out_w) orow[(int64_t)(ox0 + i) * c4n] = acc[py][i];
       }
-    } else {
-      float4* orow = y + ((int64_t)m * p.out_h + oy) * p.out_w * c4n + c4;
-#pragma unroll
-      for (int i = 0; i < PX; ++i)
-        if (ox0 + i < p.out_w) orow[(int64_t)(ox0 + i) * c4n] = acc[i];
     }
   }
 }
@@ -190,12 +204,13 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic(const float* __restrict
 template <int KH, int KW>
 static int launch_chan(const float* x, float* y, const UfParams& p, int down, bool s2d, hipStream_t st) {
   const int eh = s2d ? ((p.out_h + 1) & ~1) : p.out_h, ew = s2d ? ((p.out_w + 1) & ~1) : p.out_w;
-  int64_t nwork = (int64_t)p.major * eh * cdiv(ew, 4) * (p.minor / 4);
+  const int rows = down == 1 ? cdiv(eh, 2) : eh;   // row groups: two output rows per thread when down == 1
+  int64_t nwork = (int64_t)p.major * rows * cdiv(ew, 4) * (p.minor / 4);
   if (nwork > PPST_IDX32_MAX) return PPST_EINVAL;
   int64_t blocks = cdiv64(nwork, 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
   dim3 g((unsigned)blocks), b(256);
-  const FastDiv d_c = make_fastdiv(p.minor / 4), d_xs = make_fastdiv(cdiv(ew, 4)), d_oh = make_fastdiv(eh);
+  const FastDiv d_c = make_fastdiv(p.minor / 4), d_xs = make_fastdiv(cdiv(ew, 4)), d_oh = make_fastdiv(rows);
   const unsigned nw = (unsigned)nwork;
   if (s2d) PPST_LAUNCH((upfirdn2d_chan<KH, KW, 1, true>), g, b, 0, st, (const float4*)x, (float4*)y, p, nw, d_c, d_xs, d_oh);
   else if (down == 2) PPST_LAUNCH((upfirdn2d_chan<KH, KW, 2, false>), g, b, 0, st, (const float4*)x, (float4*)y, p, nw, d_c, d_xs, d_oh);
