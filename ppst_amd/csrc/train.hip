@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     int4 d = steps[s0 + (t < T ? t : 0)];
     tdy[t] = d.y; tdx[t] = d.z;
   }
+  if (blockIdx.x * 128 + wave * 32 >= cout) return;   // waves beyond the last output channel (no barrier in this kernel)
   f32x16 acc[WG_MAXT];
 #pragma unroll
   for (int t = 0; t < WG_MAXT; ++t)
@@ -44,22 +45,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
   const int r_begin = blockIdx.z * rows_per_split;
   const int r_end = min(r_begin + rows_per_split, rows_total);
   const bool nok = n < cout;
+  const int nc = nok ? n : 0;
   for (int r = r_begin; r < r_end; ++r) {
     const int b = r / oh, y = r - b * oh;
-    const float* dyr = dy + ((int64_t)(b * oh + y) * ow) * dy_ld + n;
+    const float* dyr = dy + ((int64_t)(b * oh + y) * ow) * dy_ld + nc;
     const float* xb = x + (int64_t)b * in_h * in_w * in_ld + chan + li;
+    // per-row tap state: row pointer (clamped) and validity, so the pixel loop issues unconditional loads
+    // (select afterwards): the compiler can then hoist the loads of the next pixel pair above this pair's MFMAs
+    const float* rowp[WG_MAXT];
+    bool rowok[WG_MAXT];
+#pragma unroll
+    for (int t = 0; t < WG_MAXT; ++t) {
+      const int iy = y + tdy[t];
+      rowok[t] = t < T && iy >= 0 && iy < in_h;
+      rowp[t] = xb + (int64_t)(rowok[t] ? iy : 0) * in_w * in_ld;
+    }
+#pragma unroll 2
     for (int x0 = 0; x0 < ow; x0 += 2) {
       const int xx = x0 + lk;
-      const float av = (nok && xx < ow) ? dyr[(int64_t)xx * dy_ld] : 0.f;
+      const bool xok = xx < ow;
+      float av = dyr[(int64_t)(xok ? xx : 0) * dy_ld];
+      av = (nok && xok) ? av : 0.f;
+      float bv[WG_MAXT];
 #pragma unroll
       for (int t = 0; t < WG_MAXT; ++t) {
-        if (t < T) {
-          const int iy = y + tdy[t], ix = xx + tdx[t];
-          float bv = 0.f;
-          if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w && xx < ow) bv = xb[((int64_t)iy * in_w + ix) * in_ld];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-        }
+        const int ix = xx + tdx[t];
+        const bool ok = rowok[t] && xok && ix >= 0 && ix < in_w;
+        const float v = rowp[t][(int64_t)(ok ? ix : 0) * in_ld];
+        bv[t] = ok ? v : 0.f;
       }
+#pragma unroll
+      for (int t = 0; t < WG_MAXT; ++t)
+        if (t < T) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
     }
   }
   // D tile: col = lane&31 (k within the 32-channel chunk), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (n)
@@ -199,12 +216,52 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     __syncthreads();
   }
 }
+// 16-B-per-lane version (C % 4 == 0, ld % 4 == 0): lane = 4 columns, 4 rows in flight per thread
+__global__ __launch_bounds__(256) void colsum4_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t rows,
+                                                              int C, int ld, int64_t rows_per_block) {
+  __shared__ float4 sm[256];
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, rows);
+  const int c4n = C >> 2;
+  int lanes = 1;
+  while (lanes < c4n && lanes < 256) lanes <<= 1;
+  const int nrows = 256 / lanes, cl = threadIdx.x % lanes, pr = threadIdx.x / lanes;
+  for (int cb = 0; cb < c4n; cb += lanes) {
+    const int c = (cb + cl) * 4;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    if (c < C) {
+      int64_t r = r0 + pr;
+      for (; r + 3 * (int64_t)nrows < r1; r += 4 * (int64_t)nrows) {
+        const float4 v0 = *(const float4*)(x + r * ld + c), v1 = *(const float4*)(x + (r + nrows) * ld + c);
+        const float4 v2 = *(const float4*)(x + (r + 2 * nrows) * ld + c), v3 = *(const float4*)(x + (r + 3 * nrows) * ld + c);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+        a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+      }
+      for (; r < r1; r += nrows) {
+        const float4 v0 = *(const float4*)(x + r * ld + c);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      }
+    }
+    float4 a = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    if (pr == 0 && c < C) {
+      for (int q = 1; q < nrows; ++q) { float4 u = sm[q * lanes + cl]; a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
+      *(float4*)(partial + (int64_t)blockIdx.x * C + c) = a;
+    }
+    __syncthreads();
+  }
+}
 extern "C" int64_t ppst_colsum_ws(int64_t rows, int C) { return cdiv64(rows, 2048) * C * (int64_t)sizeof(float); }
 extern "C" int ppst_colsum(const void* x, void* out, void* ws, int64_t rows, int C, int ld, float scale, int accumulate, void* stream) {
   if (rows <= 0 || C <= 0 || ld < C) return PPST_EINVAL;
   if (!x || !out || !ws) return PPST_ENULL;
   int nblocks = (int)cdiv64(rows, 2048);
-  PPST_LAUNCH(colsum_partial_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), (const float*)x, (float*)ws, rows, C, ld, (int64_t)2048);
+  if (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)ws % 16) == 0)
+    PPST_LAUNCH(colsum4_partial_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), (const float*)x, (float*)ws, rows, C, ld, (int64_t)2048);
+  else
+    PPST_LAUNCH(colsum_partial_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), (const float*)x, (float*)ws, rows, C, ld, (int64_t)2048);
   int e = PPST_LAUNCH_CHECK();
   if (e) return e;
   PPST_LAUNCH(sum_blocks_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), (const float*)ws, (float*)out, nblocks, (int64_t)C,
