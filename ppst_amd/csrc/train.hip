@@ -19,7 +19,7 @@
 // grid = (cout/128 n-tiles, chunks, splits); block = 4 waves, wave w owns n = n0 + 32w .. +31;
 // one block handles ONE chunk = up to 9 consecutive steps that share chan_off (registers: 9 x 16).
 #define WG_MAXT 9
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const int4* __restrict__ steps, const int* __restrict__ chunk_start,
                                                          float* __restrict__ partial, int B, int in_h, int in_w, int in_ld,
                                                          int oh, int ow, int dy_ld, int cout, int nsteps, int rows_per_split) {
