@@ -234,6 +234,13 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   STAMP(t_setup)
 #define A_OFF(slot, dy, dx, mt) ((slot) * ABUF + g * PLANE + (((wm * 4 + (mt) + HALO + (dy)) * HW + HALO + (dx) + r16) * 16))
 
+#ifdef PPST_ABL_MFMA32
+  f32x16 acc32[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc32[i][j] = 0.f;
+#endif
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -314,6 +321,26 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
 #else
 #define ABL_BAR(x) x
 #endif
+#ifdef PPST_ABL_MFMA32
+// TIMING ONLY (results wrong): the same operand registers and accumulator count driven through
+// v_mfma_f32_32x32x16_bf16 (half the MFMA instructions for the same matrix-pipe time)
+#define ABL_MFMA_GROUP(bch, bcl, mt)                                                                  \
+  _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                     \
+    const int nb = ((mt) & 1) * 2 + q;                                                                \
+    acc32[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bch[nb], acc32[mt], 0, 0, 0);             \
+    acc32[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bcl[nb], acc32[mt], 0, 0, 0);             \
+    acc32[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bch[nb], acc32[mt], 0, 0, 0);             \
+  }
+#else
+#define ABL_MFMA_GROUP(bch, bcl, mt)                                                                  \
+  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                  \
+    if (X3) {                                                                                         \
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bch[nt], acc[mt][nt], 0, 0, 0);       \
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcl[nt], acc[mt][nt], 0, 0, 0);       \
+    }                                                                                                 \
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bch[nt], acc[mt][nt], 0, 0, 0);         \
+  }
+#endif
 #define CONV_STEP(bch, bcl, bnh, bnl, s, D2, D3)                                                      \
   {                                                                                                   \
     ST_A                                                                                              \
@@ -336,13 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
         nh = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0));                                         \
         if (X3) nl = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0) + 4 * PLANE);                     \
       }                                                                                               \
-      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                              \
-        if (X3) {                                                                                     \
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bch[nt], acc[mt][nt], 0, 0, 0);   \
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcl[nt], acc[mt][nt], 0, 0, 0);   \
-        }                                                                                             \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bch[nt], acc[mt][nt], 0, 0, 0);     \
-      }                                                                                               \
+      ABL_MFMA_GROUP(bch, bcl, mt)                                                                    \
       ah = nh;                                                                                        \
       if (X3) al = nl;                                                                                \
       /* convert + write the next chunk's tile while the last MFMA group executes: the VALU   */     \
@@ -380,6 +401,14 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   float* tw = (float*)smem + wave * EPI_TILE;            // main-loop buffers are dead: last barrier passed
   float* red = (float*)smem + (NT / 64) * EPI_TILE;      // [WM][BN][2]
   const int f8 = lane & 7, prow = lane >> 3;
+#ifdef PPST_ABL_MFMA32
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = acc32[i][j * 4 + e];
+#endif
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
