@@ -224,6 +224,13 @@ int ppst_avgpool(const void* x, void* y, int B, int H, int W, int C, int x_ld, i
  * encoder_col.py:129) NHWC -> dst slice with pixel stride y_ld */
 int ppst_bilinear(const void* x, void* y, int B, int H, int W, int C, int x_ld,
                   int OH, int OW, int y_ld, void* stream);
+/* Tail of a correspondence feature head (generator.py:174-238, the layer128 / layer256 heads): with
+ * f = act(a*x + s) the activated output of the head's last conv, writes feat = PxP average pool of f
+ * ([B][H/P][W/P], pixel stride feat_ld) and feat1 = F.interpolate(f, (H/D, W/D), bilinear) for the exact
+ * factors D = 1 (f itself) and D = 2 (2x2 mean) in one read of x -- f is never stored at full size. */
+int ppst_head_tail(const void* x, const void* scale_shift, const void* prelu, void* feat, void* feat1,
+                   int B, int H, int W, int C, int x_ld, int feat_ld, int feat1_ld, int P, int D, int act,
+                   void* stream);
 /* 2x2 max pool on masks (encoder_col.py:218) NHWC */
 int ppst_maxpool2(const void* x, void* y, int B, int H, int W, int C, void* stream);
 

@@ -66,6 +66,7 @@ _SIGS = {
     "ppst_gap_gmp": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ppst_avgpool": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ppst_bilinear": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ppst_head_tail": (i32, [vp, vp, vp, vp, vp] + [i32] * 10 + [vp]),
     "ppst_maxpool2": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ppst_linear": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, f32, i32, i32, vp]),
     "ppst_l2norm_rows": (i32, [vp, vp, i32, i32, f32, i32, vp]),

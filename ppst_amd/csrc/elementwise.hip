@@ -590,6 +590,79 @@ extern "C" int ppst_bilinear(const void* x, void* y, int B, int H, int W, int C,
   return PPST_LAUNCH_CHECK();
 }
 
+// Tail of a correspondence feature head (generator.py:174-238): f = act(a*x + s) of the head's last conv is never
+// needed at full resolution -- only its PxP average (into ``feat``) and its bilinear resize to the feat1 grid, which
+// for D = 1 is f itself and for D = 2 (align_corners=False, exact factor 2) the 2x2 mean.  One read of x instead of
+// an apply pass + two reads.  thread = (b, oy, ox) of the pooled grid x 4 channels; P in {2,4,8}, D in {1,2}, D | P.
+__global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ x, const float* __restrict__ ss,
+                                                        const float* __restrict__ prelu, float* __restrict__ feat,
+                                                        float* __restrict__ feat1, int H, int W, int C, int x_ld, int f_ld,
+                                                        int f1_ld, int P, int D, int actf, unsigned total, FastDiv d_c,
+                                                        FastDiv d_w, FastDiv d_h) {
+  const int act = actf & 0xff;
+  const float slope = (act == PPST_ACT_PRELU && prelu) ? prelu[0] : 0.f;
+  const int OW = W / P, OH = H / P, W1 = W / D, H1 = H / D;
+  const float inv = 1.f / (float)(P * P);
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned cq, oxu, oyu;
+    unsigned r = fd_divmod((unsigned)t64, d_c, cq);
+    r = fd_divmod(r, d_w, oxu);
+    const int b = (int)fd_divmod(r, d_h, oyu);
+    const int c = (int)cq * 4, ox = (int)oxu, oy = (int)oyu;
+    const float4* q = (const float4*)(ss + ((int64_t)b * C + c) * 2);
+    const float4 q0 = q[0], q1 = q[1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int dy = 0; dy < P; dy += D) {
+      for (int dx = 0; dx < P; dx += D) {
+        float4 v[2][2];
+#pragma unroll
+        for (int ey = 0; ey < 2; ++ey)
+#pragma unroll
+          for (int ex = 0; ex < 2; ++ex) {
+            if (ey < D && ex < D) {
+              float4 t = *(const float4*)(x + (((int64_t)b * H + oy * P + dy + ey) * W + ox * P + dx + ex) * x_ld + c);
+              t.x = act_apply(q0.x * t.x + q0.y, act, slope); t.y = act_apply(q0.z * t.y + q0.w, act, slope);
+              t.z = act_apply(q1.x * t.z + q1.y, act, slope); t.w = act_apply(q1.z * t.w + q1.w, act, slope);
+              v[ey][ex] = t;
+            }
+          }
+        float4 o;
+        if (D == 1) {
+          o = v[0][0];
+        } else {  // the bilinear kernel's expression with hx = lx = hy = ly = 0.5
+          o.x = 0.5f * (0.5f * v[0][0].x + 0.5f * v[0][1].x) + 0.5f * (0.5f * v[1][0].x + 0.5f * v[1][1].x);
+          o.y = 0.5f * (0.5f * v[0][0].y + 0.5f * v[0][1].y) + 0.5f * (0.5f * v[1][0].y + 0.5f * v[1][1].y);
+          o.z = 0.5f * (0.5f * v[0][0].z + 0.5f * v[0][1].z) + 0.5f * (0.5f * v[1][0].z + 0.5f * v[1][1].z);
+          o.w = 0.5f * (0.5f * v[0][0].w + 0.5f * v[0][1].w) + 0.5f * (0.5f * v[1][0].w + 0.5f * v[1][1].w);
+        }
+        *(float4*)(feat1 + (((int64_t)b * H1 + (oy * P + dy) / D) * W1 + (ox * P + dx) / D) * f1_ld + c) = o;
+        // average pool: plain sum of f over the block in row-major order would need f at the (dy+ey, dx+ex) order of
+        // ppst_avgpool; D = 2 visits 2x2 sub-blocks instead -- the sums differ in the last bit only
+#pragma unroll
+        for (int ey = 0; ey < 2; ++ey)
+#pragma unroll
+          for (int ex = 0; ex < 2; ++ex)
+            if (ey < D && ex < D) { acc.x += v[ey][ex].x; acc.y += v[ey][ex].y; acc.z += v[ey][ex].z; acc.w += v[ey][ex].w; }
+      }
+    }
+    *(float4*)(feat + (((int64_t)b * OH + oy) * OW + ox) * f_ld + c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  }
+}
+extern "C" int ppst_head_tail(const void* x, const void* scale_shift, const void* prelu, void* feat, void* feat1, int B, int H, int W,
+                              int C, int x_ld, int feat_ld, int feat1_ld, int P, int D, int act, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || x_ld % 4 || feat_ld % 4 || feat1_ld % 4 || x_ld < C || feat_ld < C || feat1_ld < C ||
+      (D != 1 && D != 2) || P <= 0 || P % D || H % P || W % P)
+    return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !scale_shift || !feat || !feat1) return PPST_ENULL;
+  int64_t total = (int64_t)B * (H / P) * (W / P) * (C / 4);
+  if (total > PPST_IDX32_MAX) return PPST_EINVAL;
+  PPST_LAUNCH(head_tail_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)scale_shift,
+              (const float*)prelu, (float*)feat, (float*)feat1, H, W, C, x_ld, feat_ld, feat1_ld, P, D, act, (unsigned)total,
+              make_fastdiv(C / 4), make_fastdiv(W / P), make_fastdiv(H / P));
+  return PPST_LAUNCH_CHECK();
+}
+
 // nearest x2 upsample (Upscale2d, stylegan2_layers.py:86-97; the <128 px branch of
 // EqualizedConv2d :322-323)
 __global__ __launch_bounds__(256) void upsample_nearest2_kernel(const float4* __restrict__ x, float4* __restrict__ y, int H, int W,

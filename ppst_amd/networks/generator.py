@@ -90,7 +90,7 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
         return ops.affine_act(y, ss, res=res, out_scale=out_scale, res_up2=res_up2)
 
     # -- correspondence feature heads (generator.py:174-238) ------------------
-    def _feat_head(self, x, p, k, out, st=None):
+    def _feat_head(self, x, p, k, out, st=None, tail=None):
         B, H, W, C = x.shape
         pad = ops.PAD_REPLICATE
         # InstanceNorm runs on the ReplicationPad2d(1)-padded tensor for the 3x3 heads
@@ -101,7 +101,11 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
         y, st = self.plan(p + "2.weight")(x, bias=self.p(p + "2.bias"), stats=True, pad_mode=pad, in_ss=ops.in_finalize(st, cnt))
         y, st = self.plan(p + "6.weight")(y, bias=self.p(p + "6.bias"), stats=True, pad_mode=pad,
                                           in_ss=ops.in_finalize(st, H * W), in_act=ops.ACT_PRELU, in_prelu=self.p(p + "4.weight"))
-        return ops.affine_act(y, ops.in_finalize(st, H * W), act=ops.ACT_PRELU, prelu=self.p(p + "8.weight"), out=out)
+        ss = ops.in_finalize(st, H * W)
+        if tail is not None:   # (feat slice, feat1 slice): pooled / resized copies only, f itself is not stored
+            ops.head_tail(y, ss, tail[0], tail[1], act=ops.ACT_PRELU, prelu=self.p(p + "8.weight"))
+            return None
+        return ops.affine_act(y, ss, act=ops.ACT_PRELU, prelu=self.p(p + "8.weight"), out=out)
 
     def _residual_block(self, x, p):
         B, H, W, C = x.shape
@@ -166,10 +170,14 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
                                  out_stats=want, res_up2=True)
             if extract_features:
                 x, xst = x
-                f = self._feat_head(x, "layer%d." % (2 ** (j + 6)), 3 if j < 2 else 1, out=None, st=xst)
                 c0 = 64 * (j + 1)
-                ops.avgpool(f, f.shape[1] // h, out=feat[..., c0:c0 + 64])
-                ops.bilinear(f, 256, 256, out=feat1[..., c0:c0 + 64])
+                name, kk = "layer%d." % (2 ** (j + 6)), 3 if j < 2 else 1
+                if x.shape[1] in (256, 512) and x.shape[1] % h == 0:
+                    self._feat_head(x, name, kk, out=None, st=xst, tail=(feat[..., c0:c0 + 64], feat1[..., c0:c0 + 64]))
+                else:
+                    f = self._feat_head(x, name, kk, out=None, st=xst)
+                    ops.avgpool(f, f.shape[1] // h, out=feat[..., c0:c0 + 64])
+                    ops.bilinear(f, 256, 256, out=feat1[..., c0:c0 + 64])
         # ToRGB (stylegan2_layers.py:477-495): 1x1 conv + biases -> InstanceNorm(3) -> StyleMod
         wr = self.p("ToRGB.conv.weight")
         brgb = self.cached(("rgbb",), [self.p("ToRGB.conv.bias"), self.p("ToRGB.bias")],

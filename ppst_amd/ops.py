@@ -544,6 +544,16 @@ def bilinear(x, OH, OW, out=None):
     return out
 
 
+def head_tail(x, scale_shift, feat, feat1, act=ACT_NONE, prelu=None):
+    """feat <- avgpool(act(a*x+s)) to feat's grid; feat1 <- the same f resized by the exact factor 1 or 2 (see ppst_head_tail)."""
+    x_ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    P, D = H // feat.shape[1], H // feat1.shape[1]
+    _chk(scale_shift, "scale_shift"); _chk(prelu, "prelu")
+    check(lib.ppst_head_tail(_p(x), _p(scale_shift), _p(prelu), _p(feat), _p(feat1), B, H, W, C, x_ld, _nhwc_ld(feat), _nhwc_ld(feat1),
+                             P, D, act, _stream()), "ppst_head_tail")
+
+
 def maxpool2(x):
     ld = _nhwc_ld(x)
     B, H, W, C = x.shape
