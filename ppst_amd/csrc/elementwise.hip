@@ -793,11 +793,73 @@ __global__ __launch_bounds__(256) void conv1x1_small_cout_kernel(const float* __
     }
   }
 }
+// Cout == 3 (ToRGB): 32 lanes x 8 pixels per iteration.  Each lane keeps 8 x 3 partial dot products over its
+// channel slice; the cross-lane sum is a transposing butterfly that halves the value count at offsets 16, 8, 4
+// (24 -> 12 -> 6 -> 3 values) and finishes with a 2-stage butterfly: 27 shuffles per 8 pixels instead of 15 per pixel.
+__global__ __launch_bounds__(256) void conv1x1_cout3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y,
+                                                            int64_t npix, int cin, float wscale) {
+  const int hl = threadIdx.x & 31;
+  const int64_t half_id = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
+  const int64_t nhalf = ((int64_t)gridDim.x * 256) >> 5;
+  const int b4 = (hl >> 4) & 1, b3 = (hl >> 3) & 1, b2 = (hl >> 2) & 1;
+  for (int64_t p0 = half_id * 8; p0 < npix; p0 += nhalf * 8) {
+    float v[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) v[i] = 0.f;
+    for (int c = hl * 4; c < cin; c += 128) {
+      const float4 w0 = *(const float4*)(w + c), w1 = *(const float4*)(w + (int64_t)cin + c), w2 = *(const float4*)(w + 2 * (int64_t)cin + c);
+      float4 xv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int64_t p = p0 + k < npix ? p0 + k : npix - 1;
+        xv[k] = *(const float4*)(x + p * cin + c);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[k * 3 + 0] += xv[k].x * w0.x + xv[k].y * w0.y + xv[k].z * w0.z + xv[k].w * w0.w;
+        v[k * 3 + 1] += xv[k].x * w1.x + xv[k].y * w1.y + xv[k].z * w1.z + xv[k].w * w1.w;
+        v[k * 3 + 2] += xv[k].x * w2.x + xv[k].y * w2.y + xv[k].z * w2.z + xv[k].w * w2.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {   // offset 16: pixels 0..3 stay on lanes with bit4 = 0, pixels 4..7 on bit4 = 1
+      const float keep = b4 ? v[12 + i] : v[i], send = b4 ? v[i] : v[12 + i];
+      v[i] = keep + __shfl_xor(send, 16, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const float keep = b3 ? v[6 + i] : v[i], send = b3 ? v[i] : v[6 + i];
+      v[i] = keep + __shfl_xor(send, 8, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float keep = b2 ? v[3 + i] : v[i], send = b2 ? v[i] : v[3 + i];
+      v[i] = keep + __shfl_xor(send, 4, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      v[i] += __shfl_xor(v[i], 2, 64);
+      v[i] += __shfl_xor(v[i], 1, 64);
+    }
+    const int k = b4 * 4 + b3 * 2 + b2, j = hl & 3;
+    if (j < 3 && p0 + k < npix) {
+      const float r = j == 0 ? v[0] : (j == 1 ? v[1] : v[2]);
+      y[(p0 + k) * 3 + j] = r * wscale + (bias ? bias[j] : 0.f);
+    }
+  }
+}
+
 extern "C" int ppst_conv1x1_small_cout(const void* x, const void* w, const void* bias, void* y, int64_t npix, int cin,
                                        int cout, float wscale, void* stream) {
   if (npix < 0 || cin <= 0 || cin % 4 || cout <= 0 || cout > 4) return PPST_EINVAL;
   if (npix == 0) return PPST_OK;
   if (!x || !w || !y) return PPST_ENULL;
+  if (cout == 3 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0) {
+    PPST_LAUNCH(conv1x1_cout3_kernel, dim3(grid_for(cdiv64(npix, 8) * 32)), dim3(256), 0, as_stream(stream), (const float*)x,
+                (const float*)w, (const float*)bias, (float*)y, npix, cin, wscale);
+    return PPST_LAUNCH_CHECK();
+  }
   PPST_LAUNCH(conv1x1_small_cout_kernel, dim3(grid_for(npix * 32)), dim3(256), 0, as_stream(stream),
                      (const float*)x, (const float*)w, (const float*)bias, (float*)y, npix, cin, cout, wscale);
   return PPST_LAUNCH_CHECK();
