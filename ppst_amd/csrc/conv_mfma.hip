@@ -311,10 +311,15 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
 #else
 #define ABL_B(c) (c)
 #endif
-#ifdef PPST_ABL_NOLDS
-#define ABL_L(c) false
+#if defined(PPST_ABL_NOLDS) || defined(PPST_ABL_NOLDS_A)
+#define ABL_LA(c) false
 #else
-#define ABL_L(c) (c)
+#define ABL_LA(c) (c)
+#endif
+#if defined(PPST_ABL_NOLDS) || defined(PPST_ABL_NOLDS_B)
+#define ABL_LB(c) false
+#else
+#define ABL_LB(c) (c)
 #endif
 #ifdef PPST_ABL_NOBAR
 #define ABL_BAR(x)
@@ -341,6 +346,14 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bch[nt], acc[mt][nt], 0, 0, 0);         \
   }
 #endif
+// Stagger (MI355X guide, "two waves that run the same program with one barrier per block"): the waves of the second
+// half of an 8-wave block (the SIMD partners of waves 0-3) do the step's non-MFMA head -- weight DMA issue, global
+// loads, next-step B fragment reads -- between their MFMA groups 1 and 2 instead of before group 0, so one partner's
+// head overlaps the other's MFMAs instead of both heads leaving the matrix pipe idle together.
+#define TOP_WORK(bnh, bnl, s, D2)                                                                     \
+  if (ABL_B(has2)) b_dma((s) + 2, (s) & 1);                                                           \
+  if (newA2) a_load(D2.x);                                                                            \
+  if (ABL_LB(has1)) ld_b(bnh, bnl, ((s) + 1) & 1);
 #define CONV_STEP(bch, bcl, bnh, bnl, s, D2, D3)                                                      \
   {                                                                                                   \
     ST_A                                                                                              \
@@ -349,12 +362,11 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     const bool newA2 = ABL_A(has2 && D2.w != 0);                                                      \
     int sl2 = sl1;                                                                                    \
     if (newA2) sl2 = (sl1 == NA - 1) ? 0 : sl1 + 1;                                                   \
-    if (ABL_B(has2)) b_dma((s) + 2, (s) & 1);                                                         \
-    if (newA2) a_load(D2.x);                                                                          \
-    if (ABL_L(has1)) ld_b(bnh, bnl, ((s) + 1) & 1);                                                   \
+    if (!late) { TOP_WORK(bnh, bnl, s, D2) }                                                          \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                \
       bf16x8 nh, nl;                                                                                  \
-      if (!ABL_L(true)) {                                                                             \
+      if (mt == 2 && late) { TOP_WORK(bnh, bnl, s, D2) }                                              \
+      if (!ABL_LA(true)) {                                                                            \
         nh = ah; nl = al;                                                                             \
       } else if (mt < 3) {                                                                            \
         nh = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1));                                    \
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
       if (X3) al = nl;                                                                                \
       /* convert + write the next chunk's tile while the last MFMA group executes: the VALU   */     \
       /* work of the staging store overlaps the matrix pipe instead of following it            */     \
-      if (mt == 2 && newA2) a_store(sl2);                                                             \
+      if (mt == (late ? 3 : 2) && newA2) a_store(sl2);                                                \
     }                                                                                                 \
     ST_B                                                                                              \
     ST_C                                                                                              \
@@ -381,11 +393,17 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     if (has2) { dy1 = D2.y; dx1 = D2.z; }                                                             \
     sl1 = sl2;                                                                                        \
   }
+#ifdef PPST_STAGGER
+  const bool late = (WM * WN == 8) && wave >= 4;
+#else
+  constexpr bool late = false;
+#endif
   for (int s = 0; s < a.nsteps; s += 2) {
     CONV_STEP(b0h, b0l, b1h, b1l, s, dE, dO)
     if (s + 1 < a.nsteps) CONV_STEP(b1h, b1l, b0h, b0l, s + 1, dO, dE)
   }
 #undef CONV_STEP
+#undef TOP_WORK
 #undef A_OFF
   STAMP(t_loop_end)
 
