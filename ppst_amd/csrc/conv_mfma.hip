@@ -118,6 +118,10 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   const int wn = wave % WN, wm = wave / WN;
   const int r16 = lane & 15, g = lane >> 4;
 
+#ifdef PPST_CONV_TRACE
+  unsigned long long tr_c0, tr_r0;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_c0), "=s"(tr_r0)::"memory");
+#endif
   STAMP(t_begin)
 #ifdef PPST_CONV_STAMP
   unsigned long long acc_top = 0, acc_mfma = 0, acc_store = 0, acc_bar = 0;
@@ -300,6 +304,29 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
 #define ST_C
 #define ST_D
 #endif
+// Diagnostic build -DPPST_CONV_TRACE: per-step timeline of every wave of the first blocks.  s_memtime results land
+// asynchronously in their own SGPR pairs and are only waited for after the step's barrier, so the stamps do not drain
+// the LDS pipeline the way STAMP() does.  dbg layout: [block < TR_BLOCKS][wave][step < TR_STEPS][8] cycle stamps
+// relative to the step start: 1 head issued, 2 MFMA groups 0-1 issued, 3 groups 2-3 issued, 4 staging store done,
+// 5 vmcnt wait done, 6 barrier passed; slot 0 = absolute start, 7 = newA2 flag.
+#ifdef PPST_CONV_TRACE
+#define TR_BLOCKS 8
+#define TR_STEPS 160
+#define TR(i) asm volatile("s_memtime %0" : "=s"(tr_[i])::"memory");
+#define TR_DECL unsigned long long tr_[7];
+#define TR_FLUSH(s, flag)                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+  if (a.dbg && blockIdx.x < TR_BLOCKS && (s) < TR_STEPS && lane == 0) {                               \
+    unsigned long long* o_ = a.dbg + ((((int64_t)blockIdx.x * (NT / 64) + wave) * TR_STEPS) + (s)) * 8; \
+    o_[0] = tr_[0];                                                                                   \
+    for (int q_ = 1; q_ < 7; ++q_) o_[q_] = tr_[q_] - tr_[0];                                         \
+    o_[7] = (flag) ? 1 : 0;                                                                           \
+  }
+#else
+#define TR(i)
+#define TR_DECL
+#define TR_FLUSH(s, flag)
+#endif
 // timing ablations (tests/conv_ablate.sh): results are WRONG with any of these defined
 #ifdef PPST_ABL_NOA
 #define ABL_A(c) false
@@ -354,15 +381,32 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   if (ABL_B(has2)) b_dma((s) + 2, (s) & 1);                                                           \
   if (newA2) a_load(D2.x);                                                                            \
   if (ABL_LB(has1)) ld_b(bnh, bnl, ((s) + 1) & 1);
+#define STEP_HEAD_IF(cond, bnh, bnl, s, D2, D3)                                                       \
+  if (cond) {                                                                                         \
+    if ((s) + 3 < a.nsteps) D3 = steps[(s) + 3];                                                      \
+    newA2 = ABL_A(has2 && D2.w != 0);                                                                 \
+    sl2 = sl1;                                                                                        \
+    if (newA2) sl2 = (sl1 == NA - 1) ? 0 : sl1 + 1;                                                   \
+    if (!late) { TOP_WORK(bnh, bnl, s, D2) }                                                          \
+  }
+// MFMA_FIRST (default): a step opens with the 12 MFMAs of its first M-tile group -- their operands were fetched
+// during the previous step -- and its non-MFMA head (descriptor, weight DMA issue, global loads, next-step B fragment
+// reads) follows while the matrix pipe runs them.  The in-kernel trace (-DPPST_CONV_TRACE) showed the pipe idle for
+// the ~365 cycles of the head of every step otherwise.  -DPPST_HEAD_FIRST restores the old order for A/B runs.
+#ifdef PPST_HEAD_FIRST
+#define MFMA_FIRST 0
+#else
+#define MFMA_FIRST 1
+#endif
 #define CONV_STEP(bch, bcl, bnh, bnl, s, D2, D3)                                                      \
   {                                                                                                   \
     ST_A                                                                                              \
+    TR_DECL TR(0)                                                                                     \
     const bool has1 = (s) + 1 < a.nsteps, has2 = (s) + 2 < a.nsteps;                                  \
-    if ((s) + 3 < a.nsteps) D3 = steps[(s) + 3];                                                      \
-    const bool newA2 = ABL_A(has2 && D2.w != 0);                                                      \
-    int sl2 = sl1;                                                                                    \
-    if (newA2) sl2 = (sl1 == NA - 1) ? 0 : sl1 + 1;                                                   \
-    if (!late) { TOP_WORK(bnh, bnl, s, D2) }                                                          \
+    bool newA2;                                                                                       \
+    int sl2;                                                                                          \
+    STEP_HEAD_IF(MFMA_FIRST == 0, bnh, bnl, s, D2, D3)                                                \
+    TR(1)                                                                                             \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                \
       bf16x8 nh, nl;                                                                                  \
       if (mt == 2 && late) { TOP_WORK(bnh, bnl, s, D2) }                                              \
@@ -376,6 +420,15 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
         if (X3) nl = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0) + 4 * PLANE);                     \
       }                                                                                               \
       ABL_MFMA_GROUP(bch, bcl, mt)                                                                    \
+      if (MFMA_FIRST && mt == 0) {                                                                    \
+        /* the matrix pipe is running the 12 MFMAs of group 0 (operands fetched during the previous */ \
+        /* step): the step's non-MFMA head goes here instead of in front of them                    */ \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        STEP_HEAD_IF(true, bnh, bnl, s, D2, D3)                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+      }                                                                                               \
+      if (mt == 1) { TR(2) }                                                                          \
+      if (mt == 3) { TR(3) }                                                                          \
       ah = nh;                                                                                        \
       if (X3) al = nl;                                                                                \
       /* convert + write the next chunk's tile while the last MFMA group executes: the VALU   */     \
@@ -383,11 +436,16 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
       if (mt == (late ? 3 : 2) && newA2) a_store(sl2);                                                \
     }                                                                                                 \
     ST_B                                                                                              \
+    TR(4)                                                                                             \
     ST_C                                                                                              \
     /* hipcc (ROCm 7.2) does NOT add vmcnt(0) for an in-flight LDS-DMA at this barrier (it only  */  \
     /* emits lgkmcnt(0)): without the explicit wait a slow (cold-cache) B copy lands after the   */  \
     /* next step has started reading the slot.                                                   */  \
-    ABL_BAR(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();)                        \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
+    TR(5)                                                                                             \
+    ABL_BAR(__syncthreads();)                                                                         \
+    TR(6)                                                                                             \
+    TR_FLUSH(s, newA2)                                                                                \
     ST_D                                                                                              \
     dy0 = dy1; dx0 = dx1; sl0 = sl1;                                                                  \
     if (has2) { dy1 = D2.y; dx1 = D2.z; }                                                             \
@@ -403,6 +461,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     if (s + 1 < a.nsteps) CONV_STEP(b1h, b1l, b0h, b0l, s + 1, dO, dE)
   }
 #undef CONV_STEP
+#undef STEP_HEAD_IF
 #undef TOP_WORK
 #undef A_OFF
   STAMP(t_loop_end)
@@ -501,6 +560,15 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
       }
     }
   }
+#ifdef PPST_CONV_TRACE
+  if (a.dbg && lane == 0 && wave == 0) {   // in-kernel clock: shader cycles / 100 MHz reference ticks over the whole block
+    unsigned long long c1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+    unsigned long long* o = a.dbg + (int64_t)TR_BLOCKS * (NT / 64) * TR_STEPS * 8 + (int64_t)blockIdx.x * 2;
+    o[0] = c1 - tr_c0;
+    o[1] = r1 - tr_r0;
+  }
+#endif
 #ifdef PPST_CONV_STAMP
   {
     STAMP(t_end)
@@ -671,8 +739,8 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   k.in_ss = (const float*)a->in_scale_shift; k.in_prelu = (const float*)a->in_prelu;
   k.in_c = a->in_c; k.in_act = a->in_act;
   k.dbg = nullptr;
-#ifdef PPST_CONV_STAMP
-  k.dbg = (unsigned long long*)a->prelu;  // stamp build: the (unused) prelu slot carries the debug buffer
+#if defined(PPST_CONV_STAMP) || defined(PPST_CONV_TRACE)
+  k.dbg = (unsigned long long*)a->prelu;  // diagnostic builds: the (unused) prelu slot carries the debug buffer
   k.prelu = nullptr;
 #endif
   int64_t blocks64 = (int64_t)a->n_groups * k.n_tiles * a->B * k.tiles_y * k.tiles_x;
