@@ -237,6 +237,39 @@ def gen_train(ns, size=128):
     print("train128.npz", len(out), {k: v for k, v in out.items() if k.startswith("loss.")})
 
 
+def gloss_inputs(B=2, size=512):
+    """Seeded inputs of the generator-loss fixture: smooth synthetic portraits + an integer label map -> one-hot mask."""
+    real = W.synthetic_images(21, B, size)
+    g = torch.Generator().manual_seed(77)
+    lab = torch.randint(0, 3, (B, size // 16, size // 16), generator=g)
+    lab = lab.repeat_interleave(16, 1).repeat_interleave(16, 2)
+    mask = torch.nn.functional.one_hot(lab, 3).permute(0, 3, 1, 2).float().contiguous()
+    return real, mask
+
+
+def gen_gloss(ns):
+    """compute_generator_losses of the reference itself (models/ppst_model.py:161-235) at B = 2, 512x512,
+    lambda_Cycwarp = 0 (lpips stubbed), noise weights 0 (the reference's init): every loss / metric value
+    and the NCE queues after the step's enqueues."""
+    opt = ref_loader.default_opt(lambda_Cycwarp=0.0)
+    m = ref_loader.build_reference_model(opt)
+    sd = W.make_state_dict(13, bias_std=0.1, noise_weight=0.0)
+    own = m.state_dict()
+    m.load_state_dict({k: sd[k] for k in own if k in sd}, strict=False)
+    m.eval()
+    real, mask = gloss_inputs()
+    with torch.no_grad():
+        losses, metrics = m.compute_generator_losses(real, None, None, mask)
+    out = {"loss." + k: np.array(float(v.mean())) for k, v in losses.items()}
+    out.update({"metric." + k: np.array(float(v.mean())) for k, v in metrics.items()})
+    for i in range(4):
+        q = getattr(m.criterionNCE, "queue_data_A%d" % i)
+        pack(out, "queue%d" % i, q)
+        out["queue_ptr%d" % i] = np.array(int(getattr(m.criterionNCE, "queue_ptr_A%d" % i)))
+    np.savez_compressed(os.path.join(GOLD, "gloss512.npz"), **out)
+    print("gloss512.npz", {k: float(v) for k, v in out.items() if k.startswith(("loss.", "metric."))})
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ns = ref_loader.load_reference()
@@ -247,6 +280,7 @@ def main():
     gen_cfg1(ns, m)
     gen_swap(ns, m)
     gen_train(ns)
+    gen_gloss(ns)
 
 
 if __name__ == "__main__":

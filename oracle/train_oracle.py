@@ -92,3 +92,66 @@ def adam_reference(params, grads, state, lr, beta1, beta2, eps=1e-8):
         denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
         out[k] = params[k] - (lr / bc1) * (m / denom)
     return out
+
+
+# ------------------------------------------------------------------ generator step, forward only
+def rscl_loss(feat_q, feat_k, feat_k0, queue, nce_T=0.07):
+    """rsclLoss.forward (networks/rscl.py:42-64): one positive, n current-batch logits (all -10, see below) and
+    the queue (+ feat_k0 columns) as negatives, cross entropy at temperature nce_T."""
+    import torch.nn.functional as F
+    l_pos = (feat_q * feat_k).sum(1, keepdim=True)
+    q = torch.cat((queue, feat_k0.t()), dim=1)
+    l_neg2 = feat_q @ q
+    n = feat_q.shape[0]
+    # quirk kept: after feat_q.view(1, -1, 2048) the reference builds eye(feat_q.size(0)) = eye(1), whose single True
+    # broadcasts in masked_fill_ over the whole (1, n, n) block -- every current-batch negative becomes -10 (rscl.py:57-60)
+    l_cur = torch.full((n, n), -10.0)
+    logits = torch.cat((l_pos, l_cur, l_neg2), dim=1)
+    return F.cross_entropy(logits / nce_T, torch.zeros(n, dtype=torch.long))
+
+
+def g_losses(sd, real, mask, noise=None, lambda_L1=3.0, lambda_GAN=1.0, lambda_StyleCon=1.0, lambda_Maskwarp=10.0, nce_T=0.07,
+             size=512):
+    """PPSTModel.compute_generator_losses (models/ppst_model.py:161-235), training_stage 2, forward values only,
+    lambda_Cycwarp = 0 (lpips is unpinned).  Returns (losses, metrics, queues after the enqueues)."""
+    l1 = torch.nn.functional.l1_loss
+    B = real.shape[0]
+    queues = [sd["criterionNCE.queue_data_A%d" % i].clone() for i in range(4)]
+    ptrs = [int(sd["criterionNCE.queue_ptr_A%d" % i]) for i in range(4)]
+    losses, metrics = {}, {}
+    with torch.no_grad():
+        sp = O.encoder_con(sd, real)
+        gl, _ = O.encoder_col(sd, real)
+        _, feas, feas1 = O.generator(sd, sp, gl, extract_features=True, noise=noise)
+        sps = torch.cat((feas, O.rselfcorr(feas1)), dim=1)
+        corr = O.corrm(sps, O.swap(sps))
+        corr_self = O.corrm(sps, sps)
+        _, gl = O.encoder_col(sd, real, corrmatrix=corr_self)
+        _, pro_ms, gl_w, pro_mw = O.encoder_col(sd, real, mask=mask, corrmatrix=corr)
+        mask_warp = O.model_warp(mask, corr)
+        losses["Mask_warp"] = l1(mask_warp, O.swap(mask)) * lambda_Maskwarp
+        rec = O.generator(sd, sp, gl, noise=noise)
+        losses["G_L1"] = l1(rec, real) * lambda_L1
+        mix = O.generator(sd, O.swap(sp), gl_w, noise=noise)
+        _, pro_3m, _, _ = O.encoder_col(sd, mix, mask=O.swap(mask))
+        _, pro_2m, _, _ = O.encoder_col(sd, rec, mask=mask)
+        sp_3 = O.encoder_con(sd, mix)
+        nz = None if noise is None else {k: v[:B // 2] for k, v in noise.items()}
+        cyc = O.generator(sd, O.swap(sp_3)[:B // 2], [g[:B // 2] for g in gl], noise=nz)
+        metrics["L1_dist"] = l1(cyc, real[:B // 2])
+        losses["G_L1_cyc"] = metrics["L1_dist"] * 3
+        s1 = s2 = 0.0
+        for lid in range(0, 12, 3):
+            li = lid // 3
+            key0, keyw = torch.cat(pro_ms[lid:lid + 3], 0), torch.cat(pro_mw[lid:lid + 3], 0)
+            query, query_r = torch.cat(pro_3m[lid:lid + 3], 0), torch.cat(pro_2m[lid:lid + 3], 0)
+            s1 = s1 + rscl_loss(query, keyw, key0, queues[li], nce_T)
+            s2 = s2 + rscl_loss(query_r, key0, keyw, queues[li], nce_T)
+            for keys in (key0[0:1], key0[1:2], key0[2:3], keyw[0:1], keyw[1:2], keyw[2:3]):   # dequeue_and_enqueue, batch 1
+                queues[li][:, ptrs[li]:ptrs[li] + 1] = keys.t()
+                ptrs[li] = (ptrs[li] + 1) % queues[li].shape[1]
+        losses["G_styleContmix"] = s1 * lambda_StyleCon
+        losses["G_styleContrec"] = s2 * lambda_StyleCon
+        losses["G_GAN_rec"] = O.gan_loss(O.discriminator(sd, rec, size), True) * (lambda_GAN * 0.5)
+        losses["G_GAN_mix"] = O.gan_loss(O.discriminator(sd, mix, size), True) * (lambda_GAN * 1.0)
+    return losses, metrics, queues

@@ -159,3 +159,29 @@ def test_train_step_oracle_vs_reference_autograd(golden_dir):
             assert float(v.abs().max()) == 0.0, k   # biases: no R1 gradient
         else:
             check_packed(g, name, v, rtol=2e-3)     # leaky-ReLU gate flips between two fp32 summation orders
+
+
+def gloss_inputs(B=2, size=512):
+    """The seeded inputs of oracle/gen_golden.py:gloss_inputs."""
+    real = W.synthetic_images(21, B, size)
+    g = torch.Generator().manual_seed(77)
+    lab = torch.randint(0, 3, (B, size // 16, size // 16), generator=g)
+    lab = lab.repeat_interleave(16, 1).repeat_interleave(16, 2)
+    mask = torch.nn.functional.one_hot(lab, 3).permute(0, 3, 1, 2).float().contiguous()
+    return real, mask
+
+
+def test_generator_losses_oracle_vs_reference(golden_dir):
+    """oracle/train_oracle.py:g_losses (forward values of compute_generator_losses incl. the rscl NCE terms and
+    the queue updates) against the reference's own method at B = 2, 512x512 (about 40 s of CPU)."""
+    import train_oracle as T
+    g = np.load(os.path.join(golden_dir, "gloss512.npz"))
+    sd = W.make_state_dict(13, bias_std=0.1, noise_weight=0.0)
+    real, mask = gloss_inputs()
+    losses, metrics, queues = T.g_losses(sd, real, mask)
+    for k, v in list(losses.items()) + [("L1_dist", metrics["L1_dist"])]:
+        key = ("metric." if k == "L1_dist" else "loss.") + k
+        ref = float(g[key])
+        assert abs(float(v) - ref) <= 2e-4 * max(1.0, abs(ref)), (k, float(v), ref)
+    for i in range(4):
+        check_packed(g, "queue%d" % i, queues[i], rtol=1e-4)
