@@ -325,6 +325,14 @@ int ppst_linear_wgrad(const void* dy, const void* x, void* dw, int B, int N, int
 int ppst_linear_dgrad(const void* dy, const void* w, void* dx, int B, int N, int K, float scale,
                       void* stream);
 /* LSGAN (models/networks/loss.py:11-18): loss = weight*mean((p-target)^2), grad = d loss / d p */
+/* torch.nn.L1Loss (mean |a-b|) times weight -> out[0]; ws >= ppst_l1_mean_ws(n) bytes (ppst_model.py:47,183,203). */
+int64_t ppst_l1_mean_ws(int64_t n);
+int ppst_l1_mean(const void* a, const void* b, void* out, void* ws, int64_t n, float weight, void* stream);
+/* rsclLoss.forward (networks/rscl.py:42-64): q, k [n][C] rows, k0 [n0][C] extra negatives, queue [C][K]; out[0] = mean
+ * cross entropy at temperature nce_T with the reference's quirk that all n current-batch logits are -10 (its eye(1)
+ * mask broadcasts).  n <= 64, K + n0 <= 512; ws >= n floats. */
+int ppst_rscl_loss(const void* q, const void* k, const void* k0, const void* queue, void* out, void* ws,
+                   int n, int n0, int C, int K, float nce_T, void* stream);
 int ppst_lsgan(const void* pred, void* loss, void* grad, int n, float target, float weight, void* stream);
 /* torch.optim.Adam step (ppst_optimizer.py:34-49), step counted from 1 */
 int ppst_adam_step(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1,

@@ -93,6 +93,9 @@ _SIGS = {
     "ppst_linear_wgrad": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, vp]),
     "ppst_linear_dgrad": (i32, [vp, vp, vp, i32, i32, i32, f32, vp]),
     "ppst_lsgan": (i32, [vp, vp, vp, i32, f32, f32, vp]),
+    "ppst_l1_mean_ws": (i64, [i64]),
+    "ppst_l1_mean": (i32, [vp, vp, vp, vp, i64, f32, vp]),
+    "ppst_rscl_loss": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "ppst_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]),
     "ppst_prof_enable": (i32, [i32]),
     "ppst_prof_collect": (i32, [ctypes.POINTER(f64), ctypes.POINTER(i64), ctypes.POINTER(f64)]),

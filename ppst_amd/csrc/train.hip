@@ -334,6 +334,85 @@ extern "C" int ppst_lsgan(const void* pred, void* loss, void* grad, int n, float
   return PPST_LAUNCH_CHECK();
 }
 
+// torch.nn.L1Loss() (mean |a - b|) * weight: block partial sums, then one double-precision finish.
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ partial,
+                                                         int64_t n) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += fabsf(a[i] - b[i]);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+extern "C" int64_t ppst_l1_mean_ws(int64_t n) { int64_t b = cdiv64(n, 256 * 16); return (b > 1024 ? 1024 : (b < 1 ? 1 : b)) * (int64_t)sizeof(float); }
+extern "C" int ppst_l1_mean(const void* a, const void* b, void* out, void* ws, int64_t n, float weight, void* stream) {
+  if (n <= 0) return PPST_EINVAL;
+  if (!a || !b || !out || !ws) return PPST_ENULL;
+  int nblocks = (int)(ppst_l1_mean_ws(n) / sizeof(float));
+  PPST_LAUNCH(l1_partial_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), (const float*)a, (const float*)b, (float*)ws, n);
+  int e = PPST_LAUNCH_CHECK();
+  if (e) return e;
+  PPST_LAUNCH(sum_blocks_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const float*)ws, (float*)out, nblocks, (int64_t)1,
+              weight / (float)n, 0);
+  return PPST_LAUNCH_CHECK();
+}
+
+// rsclLoss.forward (networks/rscl.py:42-64) for n <= 64 query rows of dimension C: row i's logits are
+// [ q_i . k_i | n current-batch entries, all -10 (the reference's eye(1) mask broadcasts over the whole block) |
+//   q_i . queue[:, j], j < K | q_i . k0_j, j < n0 ] / T ; loss = mean_i( logsumexp_i - logit_i0 ).
+// One block per row; thread j owns negative column j (queue is [C][K]: coalesced over j).
+__global__ __launch_bounds__(256) void rscl_rows_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ k0,
+                                                        const float* __restrict__ queue, float* __restrict__ row_loss, int n, int n0, int C,
+                                                        int K, float invT) {
+  __shared__ float red[256];
+  __shared__ float s_pos, s_max;
+  const int i = blockIdx.x, t = threadIdx.x;
+  const float* qi = q + (int64_t)i * C;
+  // positive
+  float p = 0.f;
+  for (int c = t; c < C; c += 256) p += qi[c] * k[(int64_t)i * C + c];
+  red[t] = p;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+  if (t == 0) s_pos = red[0] * invT;
+  __syncthreads();
+  // negatives owned by this thread (columns t, t+256, ... of [queue | k0])
+  float lmax = fmaxf(s_pos, -10.0f * invT), lsum = 0.f;
+  float mine[2];
+  int cnt = 0;
+  for (int j = t; j < K + n0 && cnt < 2; j += 256, ++cnt) {
+    float d = 0.f;
+    if (j < K) for (int c = 0; c < C; ++c) d += qi[c] * queue[(int64_t)c * K + j];
+    else { const float* kj = k0 + (int64_t)(j - K) * C; for (int c = 0; c < C; ++c) d += qi[c] * kj[c]; }
+    mine[cnt] = d * invT;
+    lmax = fmaxf(lmax, mine[cnt]);
+  }
+  red[t] = lmax;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] = fmaxf(red[t], red[t + o]); __syncthreads(); }
+  if (t == 0) s_max = red[0];
+  __syncthreads();
+  const float m = s_max;
+  for (int c2 = 0; c2 < cnt; ++c2) lsum += expf(mine[c2] - m);
+  if (t == 0) lsum += expf(s_pos - m) + (float)n * expf(-10.0f * invT - m);
+  red[t] = lsum;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+  if (t == 0) row_loss[i] = (logf(red[0]) + m) - s_pos;
+}
+extern "C" int ppst_rscl_loss(const void* q, const void* k, const void* k0, const void* queue, void* out, void* ws, int n, int n0, int C,
+                              int K, float nce_T, void* stream) {
+  if (n <= 0 || n > 64 || n0 < 0 || C <= 0 || K <= 0 || K + n0 > 512 || nce_T <= 0.f) return PPST_EINVAL;
+  if (!q || !k || !queue || !out || !ws || (n0 > 0 && !k0)) return PPST_ENULL;
+  PPST_LAUNCH(rscl_rows_kernel, dim3(n), dim3(256), 0, as_stream(stream), (const float*)q, (const float*)k, (const float*)k0,
+              (const float*)queue, (float*)ws, n, n0, C, K, 1.0f / nce_T);
+  int e = PPST_LAUNCH_CHECK();
+  if (e) return e;
+  PPST_LAUNCH(sum_blocks_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const float*)ws, (float*)out, n, (int64_t)1, 1.0f / (float)n, 0);
+  return PPST_LAUNCH_CHECK();
+}
+
 // torch.optim.Adam step (no weight decay / amsgrad): m, v updated in place, p <- p - lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, float lr, float b1, float b2, float eps, float bc1, float sqrt_bc2) {

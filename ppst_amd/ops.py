@@ -404,6 +404,31 @@ def lsgan(pred, target, weight):
     return loss, grad
 
 
+def l1_mean(a, b, weight=1.0):
+    """weight * mean|a - b| -> (1,) tensor (torch.nn.L1Loss)."""
+    _chk(a); _chk(b)
+    a, b = a.contiguous(), b.contiguous()
+    assert a.shape == b.shape
+    n = a.numel()
+    ws = torch.empty(lib.ppst_l1_mean_ws(n) // 4, device=a.device, dtype=torch.float32)
+    out = torch.empty((1,), device=a.device, dtype=torch.float32)
+    check(lib.ppst_l1_mean(_p(a), _p(b), _p(out), _p(ws), n, float(weight), _stream()), "ppst_l1_mean")
+    return out
+
+
+def rscl_loss(q, k, k0, queue, nce_T=0.07):
+    """rsclLoss.forward: q, k (n, C), k0 (n0, C), queue (C, K) -> (1,) mean NCE loss."""
+    for t in (q, k, k0, queue):
+        _chk(t)
+    q, k, k0, queue = q.contiguous(), k.contiguous(), k0.contiguous(), queue.contiguous()
+    n, C = q.shape
+    ws = torch.empty((n,), device=q.device, dtype=torch.float32)
+    out = torch.empty((1,), device=q.device, dtype=torch.float32)
+    check(lib.ppst_rscl_loss(_p(q), _p(k), _p(k0), _p(queue), _p(out), _p(ws), n, k0.shape[0], C, queue.shape[1], float(nce_T), _stream()),
+          "ppst_rscl_loss")
+    return out
+
+
 def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step):
     for t in (p, g, m, v):
         _chk(t)

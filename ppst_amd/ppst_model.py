@@ -23,15 +23,52 @@ class Options:
         d = dict(netE1="StyleGAN2Resnet", netE2="StyleGAN2Resnet", netG="StyleGAN2Resnet", netD="StyleGAN2",
                  spatial_code_ch=256, global_code_ch=2048, crop_size=512, lambda_GAN=1.0, match_kernel=1,
                  num_gpus=1, local_rank=1, isTrain=False, checkpoints_dir="./checkpoints", name="ppst",
-                 resume_iter="latest", pretrained_name=None)
+                 resume_iter="latest", pretrained_name=None, training_stage=2, lambda_R1=10.0, lambda_L1=3.0,
+                 lambda_StyleCon=1.0, lambda_Maskwarp=10.0, lambda_Cycwarp=0.0, nce_T=0.07)
         d.update(kw)
         self.__dict__.update(d)
 
 
+class RsclQueues(nn.Module):
+    """State + forward of rsclLoss (networks/rscl.py:17-90): four (2048, 128) key queues with their write pointers
+    (checkpoint keys ``criterionNCE.queue_data_A{i}`` / ``queue_ptr_A{i}``)."""
+
+    def __init__(self, opt, queue_size=128, dim=2048):
+        super().__init__()
+        self.opt, self.queue_size = opt, queue_size
+        for i in range(4):
+            q = torch.nn.functional.normalize(torch.randn(dim, queue_size), dim=0)
+            self.register_buffer("queue_data_A%d" % i, q)
+            self.register_buffer("queue_ptr_A%d" % i, torch.zeros(1, dtype=torch.long))
+
+    def forward(self, feat_q, feat_k, feat_k0=None, layer=-1):
+        queue = getattr(self, "queue_data_A%d" % layer)
+        if feat_k0 is None:
+            feat_k0 = feat_q[:0]
+        return ops.rscl_loss(feat_q, feat_k, feat_k0, queue, getattr(self.opt, "nce_T", 0.07))
+
+    def dequeue_and_enqueue(self, keys, layer=-1):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():      # concat_all_gather (rscl.py:9-15, 67-69)
+            parts = [torch.ones_like(keys) for _ in range(dist.get_world_size())]
+            dist.all_gather(parts, keys.contiguous())
+            parts[dist.get_rank()] = keys
+            keys = torch.cat(parts, dim=0)
+        bs = keys.size(0)
+        q, p = getattr(self, "queue_data_A%d" % layer), getattr(self, "queue_ptr_A%d" % layer)
+        ptr = int(p)
+        assert self.queue_size % bs == 0
+        q[:, ptr:ptr + bs] = keys.t()
+        p[0] = (ptr + bs) % self.queue_size
+
+
 class PPSTModel(nn.Module):
-    def __init__(self, opt=None, with_D=False):
+    def __init__(self, opt=None, with_D=False, with_nce=False):
         super().__init__()
         self.opt = opt or Options()
+        if with_nce:
+            self.criterionNCE = RsclQueues(self.opt)
+            self.register_buffer("num_discriminator_iters", torch.zeros(1, dtype=torch.long))
         self.E1 = create_network(self.opt, self.opt.netE1, "encoder_con")
         self.E2 = create_network(self.opt, self.opt.netE2, "encoder_col")
         self.G = create_network(self.opt, self.opt.netG, "generator")
@@ -173,16 +210,94 @@ class PPSTModel(nn.Module):
     def discriminate(self, x):
         return self.D(x)
 
+    # ---- train-step commands, forward values (models/ppst_model.py:68-235).  The parameter updates live in
+    # ppst_amd/train.py (discriminator + lazy R1); the generator/encoder backward is not built.
+    def compute_image_discriminator_losses(self, real, rec, mix, cyc=None):
+        lam = self.opt.lambda_GAN
+        if lam == 0.0:
+            return {}
+        losses = {"D_real": ops.lsgan(self.D(real), 1.0, lam)[0], "D_rec": ops.lsgan(self.D(rec), 0.0, 0.5 * lam)[0]}
+        if mix is not None:
+            losses["D_mix"] = ops.lsgan(self.D(mix), 0.0, 0.5 * lam)[0]
+        if cyc is not None:
+            losses["D_cyc"] = ops.lsgan(self.D(cyc), 0.0, 0.5 * lam)[0]
+        return losses
+
+    def compute_discriminator_losses(self, real, mask=None):
+        from .train import d_step_images
+        if hasattr(self, "num_discriminator_iters"):
+            self.num_discriminator_iters.add_(1)
+        rec, mix, sp, gl = d_step_images(self, real, getattr(self.opt, "lambda_StyleCon", 1.0), want_codes=True)
+        return self.compute_image_discriminator_losses(real, rec, mix), {}, sp, gl
+
+    def compute_R1_loss(self, real):
+        from .train import DiscriminatorTrainer
+        if getattr(self.opt, "lambda_R1", 10.0) <= 0.0:
+            return {"D_R1": 0.0}
+        tr = getattr(self, "_d_trainer", None)
+        if tr is None or tr.D is not self.D:
+            tr = DiscriminatorTrainer(self.D)
+            object.__setattr__(self, "_d_trainer", tr)
+        return {"D_R1": tr.r1_penalty(real, getattr(self.opt, "lambda_R1", 10.0))}
+
+    def compute_generator_losses(self, real, sp_ma, gl_ma, mask):
+        """Loss / metric VALUES of the generator iteration (ppst_model.py:161-235, training_stage 2,
+        lambda_Cycwarp = 0: lpips is not available) and the NCE queue updates.  No gradients."""
+        opt = self.opt
+        lam = lambda k, d: float(getattr(opt, k, d))
+        B = real.shape[0]
+        losses, metrics = {}, {}
+        sp = self.E1(real)
+        gl, _ = self.E2(real)
+        _, feas, feas1 = self.G(sp, gl, extract_features=True, noise=self.noise)
+        sps = torch.cat((feas, self.Rselfcorr(feas1)), dim=1)
+        corr = self.corrm(sps, self.swap(sps))
+        corr_self = self.corrm(sps, sps)
+        _, gl = self.E2(real, corrmatrix=corr_self)
+        _, pro_ms, gl_w, pro_mw = self.E2(real, mask=mask, corrmatrix=corr)
+        if lam("lambda_Maskwarp", 10.0) > 0.0:
+            losses["Mask_warp"] = ops.l1_mean(self.warp(mask, corr), self.swap(mask), lam("lambda_Maskwarp", 10.0))
+        rec = self.G(sp, gl, noise=self.noise)
+        if lam("lambda_L1", 3.0) > 0.0:
+            losses["G_L1"] = ops.l1_mean(rec, real, lam("lambda_L1", 3.0))
+        if lam("lambda_StyleCon", 1.0) > 0.0:
+            mix = self.G(self.swap(sp), gl_w, noise=self.noise)
+            _, pro_3m, _, _ = self.E2(mix, mask=self.swap(mask))
+            _, pro_2m, _, _ = self.E2(rec, mask=mask)
+            sp_3 = self.E1(mix)
+            nz = self.noise
+            if isinstance(nz, dict):
+                nz = {k: v[:B // 2] for k, v in nz.items()}
+            cyc = self.G(self.swap(sp_3)[:B // 2], [g[:B // 2] for g in gl], noise=nz)
+            metrics["L1_dist"] = ops.l1_mean(cyc, real[:B // 2].contiguous(), 1.0)
+            losses["G_L1_cyc"] = metrics["L1_dist"] * 3
+            s1 = s2 = 0.0
+            for lid in range(0, 12, 3):
+                li = lid // 3
+                key0, keyw = torch.cat(pro_ms[lid:lid + 3], 0), torch.cat(pro_mw[lid:lid + 3], 0)
+                query, query_r = torch.cat(pro_3m[lid:lid + 3], 0), torch.cat(pro_2m[lid:lid + 3], 0)
+                s1 = s1 + self.criterionNCE(query, keyw, key0, li)
+                s2 = s2 + self.criterionNCE(query_r, key0, keyw, li)
+                for keys in (key0[0:1], key0[1:2], key0[2:3], keyw[0:1], keyw[1:2], keyw[2:3]):
+                    self.criterionNCE.dequeue_and_enqueue(keys, li)
+            losses["G_styleContmix"] = s1 * lam("lambda_StyleCon", 1.0)
+            losses["G_styleContrec"] = s2 * lam("lambda_StyleCon", 1.0)
+        if lam("lambda_GAN", 1.0) > 0.0:
+            losses["G_GAN_rec"] = ops.lsgan(self.D(rec), 1.0, 0.5 * lam("lambda_GAN", 1.0))[0]
+            if lam("lambda_StyleCon", 1.0) > 0.0:
+                losses["G_GAN_mix"] = ops.lsgan(self.D(mix), 1.0, lam("lambda_GAN", 1.0))[0]
+        return losses, metrics
+
     def get_parameters_for_mode(self, mode):
         m = {"generator": "G", "contentencoder": "E1", "colorencoder": "E2", "discriminator": "D"}[mode]
         return list(getattr(self, m).parameters()) if hasattr(self, m) else []
 
 
-def create_model(opt=None, state_dict=None, seed=0, with_D=False, device="cuda"):
+def create_model(opt=None, state_dict=None, seed=0, with_D=False, device="cuda", with_nce=False):
     """models.create_model (models/__init__.py:57-72) without the DDP wrapper: inference
     is collective-free."""
-    m = PPSTModel(opt, with_D=with_D)
+    m = PPSTModel(opt, with_D=with_D, with_nce=with_nce)
     if state_dict is None:
-        state_dict = weights.make_state_dict(seed, with_D=with_D, with_nce=False)
+        state_dict = weights.make_state_dict(seed, with_D=with_D, with_nce=with_nce)
     m.load_weights(state_dict)
     return m.to(device)

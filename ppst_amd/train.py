@@ -193,6 +193,15 @@ class DiscriminatorTrainer:
             keep["d_img"] = ops.conv1x1_small_cout(g0, wt, None, wscale=sc0)
 
     # -------------------------------------------------------------- R1 penalty
+    def r1_penalty(self, real, lambda_R1=10.0):
+        """compute_R1_loss value only: per-sample 0.5*lambda*||d sum(D(x))/dx||^2 (forward + backward to the image)."""
+        pred, tape = self.forward(real)
+        keep = {}
+        self.backward(tape, torch.ones_like(pred), param_grads=False, keep=keep)
+        g_img = keep["d_img"]
+        part = ops.in_stats(g_img)
+        return torch.stack([ops.colsum(part[b].view(-1, 2), 0.5 * lambda_R1)[1] for b in range(pred.shape[0])])
+
     def r1_losses_and_grads(self, real, lambda_R1=10.0, R1_once_every=16):
         """Lazy R1 (ppst_model.py:140-159, ppst_optimizer.py:116-126): per-sample penalty
         0.5*lambda*||d sum(D(x)) / dx||^2 and d(mean(penalty) * R1_once_every)/d(theta_D) into self.grad.
@@ -303,7 +312,7 @@ def ddp_average_(flat_grad, world):
     return flat_grad
 
 
-def d_step_images(model, real, lambda_StyleCon=1.0):
+def d_step_images(model, real, lambda_StyleCon=1.0, want_codes=False):
     """rec (B/2) and mix (B) of compute_discriminator_losses (ppst_model.py:106-131), inference path."""
     from . import glue
     B = real.shape[0]
@@ -323,4 +332,6 @@ def d_step_images(model, real, lambda_StyleCon=1.0):
     if isinstance(nz, dict):
         nz = {k: v[:B // 2] for k, v in nz.items()}
     rec = model.G(sp[:B // 2], [g[:B // 2] for g in gl2], noise=nz)
+    if want_codes:
+        return rec, mix, sp, gl2
     return rec, mix

@@ -110,6 +110,39 @@ def test_train_step_matches_reference_golden():
     check("r1grad.", 2e-2, 1e-1)   # tolerance rationale: gpu_diag.t_train_r1
 
 
+def test_generator_loss_values_match_reference_golden():
+    """model(real, None, None, mask, command="compute_generator_losses") -- forward values of the generator
+    iteration on the HIP path (E1/E2 incl. mask heads, G x4, correspondence, mask warp, rscl NCE with queue
+    updates, D) -- against tests/golden/gloss512.npz, produced by the reference's own method."""
+    import numpy as np
+    from ppst_amd import weights as W
+    from ppst_amd.ppst_model import create_model
+    from test_oracle_golden import gloss_inputs, sample_idx
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gloss512.npz"))
+    sd = W.make_state_dict(13, bias_std=0.1, noise_weight=0.0)
+    m = create_model(state_dict=sd, with_D=True, with_nce=True)
+    real, mask = (t.cuda() for t in gloss_inputs())
+    with torch.no_grad():
+        losses, metrics = m(real, None, None, mask, command="compute_generator_losses")
+    assert set(losses) == {k[5:] for k in g.files if k.startswith("loss.")}
+    for k, v in list(losses.items()) + [("L1_dist", metrics["L1_dist"])]:
+        ref = float(g[("metric." if k == "L1_dist" else "loss.") + k])
+        tol = 5e-3 if "styleCont" in k else 1e-3      # NCE logits are divided by T = 0.07
+        assert abs(float(v) - ref) <= tol * max(1.0, abs(ref)), (k, float(v), ref)
+    for i in range(4):
+        q = getattr(m.criterionNCE, "queue_data_A%d" % i).double().cpu().numpy().reshape(-1)
+        name = "queue%d" % i
+        d = q[sample_idx(name, q.size)] - g[name + ".samples"]
+        assert np.abs(d).max() <= 1e-3 * float(g[name + ".stats"][2]), name
+        assert int(getattr(m.criterionNCE, "queue_ptr_A%d" % i)) == int(g["queue_ptr%d" % i])
+    # the other two train-step commands run and agree with the trainer path
+    with torch.no_grad():
+        dl, _, sp, gl = m(real, mask, command="compute_discriminator_losses")
+        r1 = m(real, command="compute_R1_loss")
+    assert set(dl) == {"D_real", "D_rec", "D_mix"} and all(torch.isfinite(v).all() for v in dl.values())
+    assert tuple(sp.shape) == (2, 256, 64, 64) and len(gl) == 4 and r1["D_R1"].shape == (2,) and (r1["D_R1"] >= 0).all()
+
+
 def test_swap_matches_reference_golden():
     """The HIP path against the fixtures produced by the *reference itself*
     (oracle/gen_golden.py): sampled activations of the full recipe."""
