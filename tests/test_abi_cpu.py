@@ -42,6 +42,18 @@ def test_argument_errors_need_no_gpu():
     assert lib.ppst_gemm_nt_f32(None, None, None, 1, 4, 4, 7, 1.0, None) == -1                      # K % 16
     assert lib.ppst_softmax_rows(None, 0, 4096, 0.01, None) == 0
     assert lib.ppst_conv_tiles(512, 512, 16) == 1024 and lib.ppst_conv_tiles(17, 16, 8) == 3
+    # entry points added later in the round: same contract
+    assert lib.ppst_blur_nhwc(None, None, None, 1, 8, 8, 4, 3, 1, 1, 0, 1, 0, None, 3, None) == -3      # null data
+    d = ctypes.c_void_p(16)   # a non-null token: validation happens before anything is dereferenced or launched
+    assert lib.ppst_blur_nhwc(d, d, d, 1, 8, 8, 4, 3, 1, 1, 0, 1, 0, None, 3, None) == -1               # in_act without a table
+    assert lib.ppst_blur_nhwc(d, d, d, 1, 8, 8, 6, 3, 1, 1, 0, 1, 0, None, 0, None) == -1               # C % 4
+    assert lib.ppst_resample_u8(None, None, 1, 8, 8, 3, 4, 1, None, None, 5, None) == -3
+    assert lib.ppst_resample_u8(None, None, 0, 8, 8, 3, 4, 1, None, None, 5, None) == 0                 # empty batch
+    assert lib.ppst_u8_to_tensor(d, d, 1, 8, 8, 3, 0.5, 0.0, None) == -1                               # std == 0
+    assert lib.ppst_head_tail(d, d, None, d, d, 1, 512, 512, 64, 64, 64, 64, 8, 3, 0, None) == -1       # D not in {1, 2}
+    assert lib.ppst_l1_mean(None, None, None, None, 16, 1.0, None) == -3 and lib.ppst_l1_mean_ws(1 << 20) == 256 * 4
+    assert lib.ppst_rscl_loss(d, d, d, d, d, d, 65, 0, 2048, 128, 0.07, None) == -1                     # n > 64
+    assert lib.ppst_rscl_loss(d, d, None, d, d, d, 6, 6, 2048, 128, 0.07, None) == -3                   # k0 missing
 
 
 def test_ops_refuse_cpu_tensors():
