@@ -45,19 +45,6 @@ struct ConvKArgs {
   unsigned long long* dbg;  // stamp build: [block][wave][8] cycle sums (else unused)
 };
 
-// Diagnostic build only (-DPPST_CONV_STAMP): s_memtime stamps around the phases of a K-step
-// (MI355X guide, "In-kernel stamps").  The product library is built without it.
-#ifdef PPST_CONV_STAMP
-__device__ __forceinline__ unsigned long long conv_stamp() {
-  unsigned long long t;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  return t;
-}
-#define STAMP(var) __builtin_amdgcn_sched_barrier(0); unsigned long long var = conv_stamp(); __builtin_amdgcn_sched_barrier(0);
-#else
-#define STAMP(var)
-#endif
-
 __device__ __forceinline__ int pad_index(int i, int n, int mode) {
   if (mode == PPST_PAD_REFLECT) {
     if (i < 0) i = -i;
@@ -87,10 +74,9 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   constexpr int B_IT = (B_ITEMS + NT - 1) / NT;
   static_assert(B_ITEMS % NT == 0, "B blob must split evenly");
 
-  // A ring slots (hazard note at the main loop).  The 8-row tile variants keep 2 slots so
-  // that two blocks fit one CU (2 x 80 KB); they require every chunk to span >= 2 steps
-  // (the host pads single-tap chunks with a zero-weight step).
-  constexpr int NA = NAS ? NAS : ((WM == 2 && HALO == 1) ? 2 : 3);
+  // A ring slots (hazard note at the main loop): 3 in general; NAS = 1 / 2 when the step table has no more chunks
+  // than that (smaller LDS footprint, two blocks per CU).
+  constexpr int NA = NAS ? NAS : 3;
   constexpr int EPI_TILE = 64 * 36;                              // floats per wave: 64 px x (32 ch + 4 pad)
   constexpr int EPI_BYTES = (NT / 64) * EPI_TILE * 4 + WM * BN * 2 * 4;  // transposition tiles + stats scratch
   constexpr int MAIN_BYTES = NA * ABUF + 2 * BBUF;
@@ -121,10 +107,6 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
 #ifdef PPST_CONV_TRACE
   unsigned long long tr_c0, tr_r0;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_c0), "=s"(tr_r0)::"memory");
-#endif
-  STAMP(t_begin)
-#ifdef PPST_CONV_STAMP
-  unsigned long long acc_top = 0, acc_mfma = 0, acc_store = 0, acc_bar = 0;
 #endif
   const int4* steps = a.steps + (int64_t)group * a.nsteps;
   const unsigned char* wblob = (const unsigned char*)a.wpack + ((int64_t)nidx * a.nsteps) * BBUF;
@@ -235,16 +217,8 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     }
   };
   // LDS byte offset of the A fragment (tile row mt) of a step with tap (dy, dx) in ring slot `slot`
-  STAMP(t_setup)
 #define A_OFF(slot, dy, dx, mt) ((slot) * ABUF + g * PLANE + (((wm * 4 + (mt) + HALO + (dy)) * HW + HALO + (dx) + r16) * 16))
 
-#ifdef PPST_ABL_MFMA32
-  f32x16 acc32[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc32[i][j] = 0.f;
-#endif
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -281,7 +255,6 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   if (a.nsteps > 2) dE = steps[2];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA of steps 0/1 (see the note at the loop barrier)
   __syncthreads();
-  STAMP(t_prologue)
 
   bf16x8 b0h[4], b0l[4], b1h[4], b1l[4];
   bf16x8 ah, al;
@@ -293,20 +266,9 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   // reads issued just before them)
   __builtin_amdgcn_s_waitcnt(0xC07F);
 
-#ifdef PPST_CONV_STAMP
-#define ST_A STAMP(t0_)
-#define ST_B STAMP(t1_)
-#define ST_C STAMP(t2_)
-#define ST_D STAMP(t3_) acc_mfma += t1_ - t0_; acc_store += t2_ - t1_; acc_bar += t3_ - t2_;
-#else
-#define ST_A
-#define ST_B
-#define ST_C
-#define ST_D
-#endif
 // Diagnostic build -DPPST_CONV_TRACE: per-step timeline of every wave of the first blocks.  s_memtime results land
 // asynchronously in their own SGPR pairs and are only waited for after the step's barrier, so the stamps do not drain
-// the LDS pipeline the way STAMP() does.  dbg layout: [block < TR_BLOCKS][wave][step < TR_STEPS][8] cycle stamps
+// the LDS pipeline.  dbg layout: [block < TR_BLOCKS][wave][step < TR_STEPS][8] cycle stamps
 // relative to the step start: 1 head issued, 2 MFMA groups 0-1 issued, 3 groups 2-3 issued, 4 staging store done,
 // 5 vmcnt wait done, 6 barrier passed; slot 0 = absolute start, 7 = newA2 flag.
 #ifdef PPST_CONV_TRACE
@@ -353,17 +315,6 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
 #else
 #define ABL_BAR(x) x
 #endif
-#ifdef PPST_ABL_MFMA32
-// TIMING ONLY (results wrong): the same operand registers and accumulator count driven through
-// v_mfma_f32_32x32x16_bf16 (half the MFMA instructions for the same matrix-pipe time)
-#define ABL_MFMA_GROUP(bch, bcl, mt)                                                                  \
-  _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                     \
-    const int nb = ((mt) & 1) * 2 + q;                                                                \
-    acc32[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bch[nb], acc32[mt], 0, 0, 0);             \
-    acc32[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bcl[nb], acc32[mt], 0, 0, 0);             \
-    acc32[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bch[nb], acc32[mt], 0, 0, 0);             \
-  }
-#else
 #define ABL_MFMA_GROUP(bch, bcl, mt)                                                                  \
   _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                  \
     if (X3) {                                                                                         \
@@ -372,11 +323,6 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     }                                                                                                 \
     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bch[nt], acc[mt][nt], 0, 0, 0);         \
   }
-#endif
-// Stagger (MI355X guide, "two waves that run the same program with one barrier per block"): the waves of the second
-// half of an 8-wave block (the SIMD partners of waves 0-3) do the step's non-MFMA head -- weight DMA issue, global
-// loads, next-step B fragment reads -- between their MFMA groups 1 and 2 instead of before group 0, so one partner's
-// head overlaps the other's MFMAs instead of both heads leaving the matrix pipe idle together.
 #define TOP_WORK(bnh, bnl, s, D2)                                                                     \
   if (ABL_B(has2)) b_dma((s) + 2, (s) & 1);                                                           \
   if (newA2) a_load(D2.x);                                                                            \
@@ -387,7 +333,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     newA2 = ABL_A(has2 && D2.w != 0);                                                                 \
     sl2 = sl1;                                                                                        \
     if (newA2) sl2 = (sl1 == NA - 1) ? 0 : sl1 + 1;                                                   \
-    if (!late) { TOP_WORK(bnh, bnl, s, D2) }                                                          \
+    TOP_WORK(bnh, bnl, s, D2)                                                                         \
   }
 // MFMA_FIRST (default): a step opens with the 12 MFMAs of its first M-tile group -- their operands were fetched
 // during the previous step -- and its non-MFMA head (descriptor, weight DMA issue, global loads, next-step B fragment
@@ -400,7 +346,6 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
 #endif
 #define CONV_STEP(bch, bcl, bnh, bnl, s, D2, D3)                                                      \
   {                                                                                                   \
-    ST_A                                                                                              \
     TR_DECL TR(0)                                                                                     \
     const bool has1 = (s) + 1 < a.nsteps, has2 = (s) + 2 < a.nsteps;                                  \
     bool newA2;                                                                                       \
@@ -409,7 +354,6 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     TR(1)                                                                                             \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                \
       bf16x8 nh, nl;                                                                                  \
-      if (mt == 2 && late) { TOP_WORK(bnh, bnl, s, D2) }                                              \
       if (!ABL_LA(true)) {                                                                            \
         nh = ah; nl = al;                                                                             \
       } else if (mt < 3) {                                                                            \
@@ -433,11 +377,9 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
       if (X3) al = nl;                                                                                \
       /* convert + write the next chunk's tile while the last MFMA group executes: the VALU   */     \
       /* work of the staging store overlaps the matrix pipe instead of following it            */     \
-      if (mt == (late ? 3 : 2) && newA2) a_store(sl2);                                                \
+      if (mt == 2 && newA2) a_store(sl2);                                                             \
     }                                                                                                 \
-    ST_B                                                                                              \
     TR(4)                                                                                             \
-    ST_C                                                                                              \
     /* hipcc (ROCm 7.2) does NOT add vmcnt(0) for an in-flight LDS-DMA at this barrier (it only  */  \
     /* emits lgkmcnt(0)): without the explicit wait a slow (cold-cache) B copy lands after the   */  \
     /* next step has started reading the slot.                                                   */  \
@@ -446,16 +388,10 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     ABL_BAR(__syncthreads();)                                                                         \
     TR(6)                                                                                             \
     TR_FLUSH(s, newA2)                                                                                \
-    ST_D                                                                                              \
     dy0 = dy1; dx0 = dx1; sl0 = sl1;                                                                  \
     if (has2) { dy1 = D2.y; dx1 = D2.z; }                                                             \
     sl1 = sl2;                                                                                        \
   }
-#ifdef PPST_STAGGER
-  const bool late = (WM * WN == 8) && wave >= 4;
-#else
-  constexpr bool late = false;
-#endif
   for (int s = 0; s < a.nsteps; s += 2) {
     CONV_STEP(b0h, b0l, b1h, b1l, s, dE, dO)
     if (s + 1 < a.nsteps) CONV_STEP(b1h, b1l, b0h, b0l, s + 1, dO, dE)
@@ -464,7 +400,6 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
 #undef STEP_HEAD_IF
 #undef TOP_WORK
 #undef A_OFF
-  STAMP(t_loop_end)
 
   // ---- epilogue: + bias + noise [+ residual] -> act -> * out_scale -> store, tile statistics.
   // The accumulators (lane = channel, registers = pixels) are transposed through a per-wave
@@ -478,14 +413,6 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   float* tw = (float*)smem + wave * EPI_TILE;            // main-loop buffers are dead: last barrier passed
   float* red = (float*)smem + (NT / 64) * EPI_TILE;      // [WM][BN][2]
   const int f8 = lane & 7, prow = lane >> 3;
-#ifdef PPST_ABL_MFMA32
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[i][j][e] = acc32[i][j * 4 + e];
-#endif
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -567,22 +494,6 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     unsigned long long* o = a.dbg + (int64_t)TR_BLOCKS * (NT / 64) * TR_STEPS * 8 + (int64_t)blockIdx.x * 2;
     o[0] = c1 - tr_c0;
     o[1] = r1 - tr_r0;
-  }
-#endif
-#ifdef PPST_CONV_STAMP
-  {
-    STAMP(t_end)
-    if (a.dbg && lane == 0) {
-      unsigned long long* o = a.dbg + ((int64_t)blockIdx.x * (NT / 64) + wave) * 8;
-      o[0] = t_setup - t_begin;         // index math
-      o[1] = t_prologue - t_setup;      // prologue staging (first loads + LDS stores + barrier)
-      o[2] = t_loop_end - t_prologue;   // main loop
-      o[3] = t_end - t_loop_end;        // epilogue
-      o[4] = acc_mfma;                  // barrier-exit -> MFMAs issued (incl. desc load, global-load issue, LDS reads)
-      o[5] = acc_store;                 // staging stores (waits for the global loads)
-      o[6] = acc_bar;                   // barrier wait
-      o[7] = acc_top;
-    }
   }
 #endif
 }
@@ -739,7 +650,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   k.in_ss = (const float*)a->in_scale_shift; k.in_prelu = (const float*)a->in_prelu;
   k.in_c = a->in_c; k.in_act = a->in_act;
   k.dbg = nullptr;
-#if defined(PPST_CONV_STAMP) || defined(PPST_CONV_TRACE)
+#ifdef PPST_CONV_TRACE
   k.dbg = (unsigned long long*)a->prelu;  // diagnostic builds: the (unused) prelu slot carries the debug buffer
   k.prelu = nullptr;
 #endif
