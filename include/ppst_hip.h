@@ -159,6 +159,10 @@ typedef struct ppst_conv_args {
                                     with bn = 64 the smaller footprint lets two blocks share a CU (small-K layers are
                                     latency/HBM-bound with one).  The caller owns this promise: the table is on the
                                     device and is not re-read by the host. */
+  int32_t early_a;               /* 1: every chunk of the step table spans >= 2 steps AND steps[i].w carries, besides bit 0
+                                    (step i opens a chunk), bit 1 = step i+1 opens a chunk and bits 8.. = that chunk's
+                                    channel offset: the kernel then requests a chunk's activations one step earlier
+                                    (HBM latency no longer stalls the staging store).  0: bits 1.. are ignored. */
 } ppst_conv_args;
 
 int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream);

@@ -42,6 +42,7 @@ struct ConvKArgs {
   const float* in_ss;     // optional [B][in_c][2] (scale, shift) applied to the input while staging
   const float* in_prelu;  // slope for in_act == PRELU
   int in_c, in_act;
+  int early_a;              // step table guarantees chunks of >= 2 steps: a chunk's global loads go out one step early
   unsigned long long* dbg;  // stamp build: [block][wave][8] cycle sums (else unused)
 };
 
@@ -108,13 +109,21 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   unsigned long long tr_c0, tr_r0;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_c0), "=s"(tr_r0)::"memory");
 #endif
-  const int4* steps = a.steps + (int64_t)group * a.nsteps;
+  // constant address space: the uniform-index descriptor reads become scalar loads (lgkmcnt), so using a descriptor
+  // never makes hipcc wait on vmcnt -- which would also drain an early activation load that is meant to stay in flight
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) int4* StepPtr;
+#else
+  typedef const int4* StepPtr;
+#endif
+  StepPtr steps = (StepPtr)(a.steps + (int64_t)group * a.nsteps);
   const unsigned char* wblob = (const unsigned char*)a.wpack + ((int64_t)nidx * a.nsteps) * BBUF;
   const float* xb = a.x + (int64_t)b * a.in_h * a.in_w * a.in_ld;
 
   constexpr int A_WCH = (HP + 7) / 8;                      // wave-chunks of 8 pixels x 8 float4
   constexpr int A_IT2 = (A_WCH * 64 + NT - 1) / NT;
   float4 ra[A_IT2];
+  constexpr int A_NLOADS = A_IT2 + (INSS ? 2 : 0);   // vector-memory operations of one a_load
 
   // A staging.  One wave-instruction covers 8 pixels x 128 B (fully coalesced global read);
   // inside it lane l -> plane g = l>>4, pixel (l>>1)&7, half h = l&1, so the 16 lanes of a
@@ -150,9 +159,10 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   auto a_load = [&](int chan_off) {
 #pragma unroll
     for (int it = 0; it < A_IT2; ++it) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (aoff[it] >= 0) v = *(const float4*)(xb + aoff[it] + chan_off);
-      ra[it] = v;
+      // always issued (padding lanes read element 0 and are zeroed in a_store): the count of outstanding
+      // vector-memory operations must be a compile-time constant for the counted vmcnt wait that lets an
+      // early load stay in flight across the step barrier
+      ra[it] = *(const float4*)(xb + (aoff[it] >= 0 ? aoff[it] : 0) + chan_off);
     }
     if (INSS) {
       const float4* p = (const float4*)(a.in_ss + ((int64_t)b * a.in_c + chan_off + q4lane * 4) * 2);
@@ -174,6 +184,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
       int pix = (i >> 6) * 8 + ((l >> 1) & 7);
       if (pix < HP) {
         float4 v = ra[it];
+        if (aoff[it] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (INSS && aoff[it] >= 0) {  // padding zeros stay zeros (they pad the normalised tensor)
           v.x = in_act(ras0.x * v.x + ras0.y); v.y = in_act(ras0.z * v.y + ras0.w);
           v.z = in_act(ras1.x * v.z + ras1.y); v.w = in_act(ras1.z * v.w + ras1.w);
@@ -246,10 +257,12 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   if (a.nsteps > 1) {
     d = steps[1];
     dy1 = d.y; dx1 = d.z;
-    sl1 = d.w != 0 ? 1 : 0;
+    sl1 = (d.w & 1) ? 1 : 0;
     b_dma(1, 1);
-    if (d.w != 0) a_load(d.x);
-    if (d.w != 0) a_store(sl1);
+    if (d.w & 1) a_load(d.x);
+    if (d.w & 1) a_store(sl1);
+    // early mode: the chunk opened by step 2 is staged during step 0 and must already be in registers
+    if (a.early_a && (d.w & 2)) a_load(d.w >> 8);
   }
   int4 dE = d, dO = d;                       // descriptor of step s+2, alternating register sets
   if (a.nsteps > 2) dE = steps[2];
@@ -325,12 +338,18 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   }
 #define TOP_WORK(bnh, bnl, s, D2)                                                                     \
   if (ABL_B(has2)) b_dma((s) + 2, (s) & 1);                                                           \
-  if (newA2) a_load(D2.x);                                                                            \
+  {   /* early mode: the chunk that step s+3 opens (stored during step s+1); else the chunk of step s+2 (stored   */ \
+      /* in this step).  ONE a_load call site: two would make hipcc merge their results with copies + vmcnt(0).    */ \
+    const bool ld_ = a.early_a ? ABL_A(has2 && (D2.w & 2)) : newA2;                                    \
+    const int ch_ = a.early_a ? (D2.w >> 8) : D2.x;                                                   \
+    if (ld_) { a_load(ch_); a_early = a.early_a != 0; }                                               \
+  }                                                                                                   \
   if (ABL_LB(has1)) ld_b(bnh, bnl, ((s) + 1) & 1);
 #define STEP_HEAD_IF(cond, bnh, bnl, s, D2, D3)                                                       \
   if (cond) {                                                                                         \
     if ((s) + 3 < a.nsteps) D3 = steps[(s) + 3];                                                      \
-    newA2 = ABL_A(has2 && D2.w != 0);                                                                 \
+    newA2 = ABL_A(has2 && (D2.w & 1));                                                                \
+    a_early = false;                                                                                  \
     sl2 = sl1;                                                                                        \
     if (newA2) sl2 = (sl1 == NA - 1) ? 0 : sl1 + 1;                                                   \
     TOP_WORK(bnh, bnl, s, D2)                                                                         \
@@ -348,7 +367,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   {                                                                                                   \
     TR_DECL TR(0)                                                                                     \
     const bool has1 = (s) + 1 < a.nsteps, has2 = (s) + 2 < a.nsteps;                                  \
-    bool newA2;                                                                                       \
+    bool newA2, a_early;                                                                              \
     int sl2;                                                                                          \
     STEP_HEAD_IF(MFMA_FIRST == 0, bnh, bnl, s, D2, D3)                                                \
     TR(1)                                                                                             \
@@ -383,9 +402,14 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     /* hipcc (ROCm 7.2) does NOT add vmcnt(0) for an in-flight LDS-DMA at this barrier (it only  */  \
     /* emits lgkmcnt(0)): without the explicit wait a slow (cold-cache) B copy lands after the   */  \
     /* next step has started reading the slot.                                                   */  \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
+    /* vmcnt counts in issue order: the B copy (older) must have landed; an early chunk load (younger,   */  \
+    /* A_NLOADS operations) may stay in flight across the barrier.                                       */  \
+    if (a_early) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_NLOADS) : "memory");                      \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
     TR(5)                                                                                             \
-    ABL_BAR(__syncthreads();)                                                                         \
+    /* raw barrier: __syncthreads() carries a fence for which hipcc drains vmcnt to 0 -- including the early    */  \
+    /* activation load.  LDS writes of this step (staging store) are drained here by hand.                      */  \
+    ABL_BAR(asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");)                          \
     TR(6)                                                                                             \
     TR_FLUSH(s, newA2)                                                                                \
     dy0 = dy1; dx0 = dx1; sl0 = sl1;                                                                  \
@@ -649,6 +673,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   k.n_tiles = cdiv(a->cout, a->bn);
   k.in_ss = (const float*)a->in_scale_shift; k.in_prelu = (const float*)a->in_prelu;
   k.in_c = a->in_c; k.in_act = a->in_act;
+  k.early_a = a->early_a ? 1 : 0;
   k.dbg = nullptr;
 #ifdef PPST_CONV_TRACE
   k.dbg = (unsigned long long*)a->prelu;  // diagnostic builds: the (unused) prelu slot carries the debug buffer

@@ -258,7 +258,18 @@ class ConvPlan:
         self.nsteps = len(steps) // self.n_groups
         self.flop_steps = sum(1 for t in src if t[0] >= 0) // self.n_groups
         dev = w.device
-        self.steps = torch.tensor(steps, dtype=torch.int32, device=dev).contiguous()
+        # flags: bit 0 = this step opens a chunk; bit 1 = the NEXT step of the group opens one, bits 8.. = its channel
+        # offset (lets the kernel request a chunk's activations a step early when every chunk spans >= 2 steps)
+        ns_ = self.nsteps
+        enc = []
+        for i, (c_, dy_, dx_, f_) in enumerate(steps):
+            nxt = steps[i + 1] if (i + 1) % ns_ != 0 else None
+            w_ = f_ | ((2 | (nxt[0] << 8)) if (nxt is not None and nxt[3]) else 0)
+            enc.append((c_, dy_, dx_, w_))
+        starts = [i for i, t in enumerate(steps) if t[3] == 1] + [len(steps)]
+        lens = [b_ - a_ for a_, b_ in zip(starts[:-1], starts[1:])]
+        self.early_a = 1 if (min(lens) >= 2 and ns_ >= 3) else 0
+        self.steps = torch.tensor(enc, dtype=torch.int32, device=dev).contiguous()
         s = torch.tensor(src, dtype=torch.int32, device=dev)
         src_c, src_ky, src_kx = s[:, 0].contiguous(), s[:, 1].contiguous(), s[:, 2].contiguous()
         self.src_dev = (src_c, src_ky, src_kx)
@@ -317,6 +328,7 @@ class ConvPlan:
         a.in_c = in_ss.shape[1] if in_ss is not None else 0
         a.flop_steps = self.flop_steps
         a.a_slots = min(3, self.chunks_per_group)
+        a.early_a = self.early_a
         check(lib.ppst_conv2d_mfma(ctypes.byref(a), _stream()), "ppst_conv2d_mfma")
         if stats:
             return out, st
