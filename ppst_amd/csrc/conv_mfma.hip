@@ -58,6 +58,15 @@ __device__ __forceinline__ int pad_index(int i, int n, int mode) {
 
 // NAS: activation-tile ring depth (0 = default rule below).  1 or 2 only when no group has more
 // chunks than that; those variants also ask for two waves per SIMD so two blocks share a CU.
+#ifdef PPST_CONV_CLOCK
+__device__ unsigned long long* g_clock_buf = nullptr;
+__device__ int g_clock_n = 1;
+extern "C" int ppst_conv_clock_buffer(void* buf, int n) {   // diagnostic build only (not in include/ppst_hip.h)
+  if (n <= 0) return PPST_EINVAL;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_clock_buf), &buf, sizeof(buf)) != hipSuccess) return PPST_EINVAL;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_clock_n), &n, sizeof(n)) == hipSuccess ? PPST_OK : PPST_EINVAL;
+}
+#endif
 template <int WM, int WN, int HALO, bool X3, bool INSS, int NAS = 0>
 __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(ConvKArgs a) {
   constexpr int NT = 64 * WM * WN;
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   const int wn = wave % WN, wm = wave / WN;
   const int r16 = lane & 15, g = lane >> 4;
 
-#ifdef PPST_CONV_TRACE
+#if defined(PPST_CONV_TRACE) || defined(PPST_CONV_CLOCK)
   unsigned long long tr_c0, tr_r0;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_c0), "=s"(tr_r0)::"memory");
 #endif
@@ -516,6 +525,17 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     unsigned long long c1, r1;
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
     unsigned long long* o = a.dbg + (int64_t)TR_BLOCKS * (NT / 64) * TR_STEPS * 8 + (int64_t)blockIdx.x * 2;
+    o[0] = c1 - tr_c0;
+    o[1] = r1 - tr_r0;
+  }
+#endif
+#ifdef PPST_CONV_CLOCK
+  // clock-only diagnostic build: two stamps per block (no per-step work), written to the buffer registered with
+  // ppst_conv_clock_buffer(); lets the in-kernel clock be sampled inside the real benchmark loop
+  if (g_clock_buf && lane == 0 && wave == 0) {
+    unsigned long long c1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+    unsigned long long* o = g_clock_buf + (int64_t)(blockIdx.x % g_clock_n) * 2;
     o[0] = c1 - tr_c0;
     o[1] = r1 - tr_r0;
   }
