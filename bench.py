@@ -127,7 +127,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PPST_BENCH_FORCE_DIST"):   # the override exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world)
 
