@@ -262,18 +262,22 @@ class DiscriminatorTrainer:
 
     # ------------------------------------------------------------------- step
     def losses_and_grads(self, real, rec, mix, lambda_GAN=1.0):
-        """LSGAN losses on real / rec / mix and d(sum of losses)/d(theta_D) into self.grad."""
+        """LSGAN losses on real / rec / mix and d(sum of losses)/d(theta_D) into self.grad.  The three image sets
+        go through D as ONE batch (the gradient is the sum over the sets either way): one forward, one backward,
+        a third of the launches, and the weight-gradient reduction runs over all images at once."""
         self.grad.zero_()
-        losses = {}
-        for name, img, target, wgt in (("D_real", real, 1.0, lambda_GAN), ("D_rec", rec, 0.0, 0.5 * lambda_GAN),
-                                       ("D_mix", mix, 0.0, 0.5 * lambda_GAN)):
-            if img is None:
-                continue
-            pred, tape = self.forward(img)
-            loss, dpred = ops.lsgan(pred, target, wgt)
+        sets = [(n, img, t, w) for n, img, t, w in (("D_real", real, 1.0, lambda_GAN), ("D_rec", rec, 0.0, 0.5 * lambda_GAN),
+                                                    ("D_mix", mix, 0.0, 0.5 * lambda_GAN)) if img is not None]
+        imgs = torch.cat([s_[1] for s_ in sets], dim=0) if len(sets) > 1 else sets[0][1]
+        pred, tape = self.forward(imgs)
+        losses, dparts, o = {}, [], 0
+        for name, img, target, wgt in sets:
+            nb = img.shape[0]
+            loss, dp = ops.lsgan(pred[o:o + nb].contiguous(), target, wgt)   # mean over this set's own batch
             losses[name] = loss
-            self.backward(tape, dpred)
-            del tape
+            dparts.append(dp)
+            o += nb
+        self.backward(tape, torch.cat(dparts, dim=0) if len(dparts) > 1 else dparts[0])
         return losses
 
     def all_reduce(self):
