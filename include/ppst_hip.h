@@ -124,7 +124,8 @@ int ppst_upscale_weight(const void* w, void* out, int cout, int cin, float scale
 typedef struct ppst_conv_args {
   const void* x;        /* NHWC fp32 input, pixel stride in_ld floats */
   const void* wpack;    /* from ppst_conv_pack */
-  const void* steps;    /* device array ppst_conv_step[n_groups*nsteps] */
+  const void* steps;    /* device array ppst_conv_step[n_groups*nsteps + 4]: 4 padding entries at the end (the kernel
+                           prefetches the descriptor of step s+3 without a bounds test; their content is ignored) */
   void* y;              /* NHWC fp32 output, pixel stride out_ld floats */
   const void* bias;     /* [cout] or NULL (sum of all per-channel biases) */
   const void* noise;    /* [B][out_h][out_w] or NULL (NoiseInjection, stylegan2_layers.py:376-399) */

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   if (ABL_LB(has1)) ld_b(bnh, bnl, ((s) + 1) & 1);
 #define STEP_HEAD_IF(cond, bnh, bnl, s, D2, D3)                                                       \
   if (cond) {                                                                                         \
-    if ((s) + 3 < a.nsteps) D3 = steps[(s) + 3];                                                      \
+    D3 = steps[(s) + 3];   /* the host pads the table: always in bounds, ignored past the end */       \
     newA2 = ABL_A(has2 && (D2.w & 1));                                                                \
     a_early = false;                                                                                  \
     sl2 = sl1;                                                                                        \
@@ -372,10 +372,10 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
 #else
 #define MFMA_FIRST 1
 #endif
-#define CONV_STEP(bch, bcl, bnh, bnl, s, D2, D3)                                                      \
+#define CONV_STEP(bch, bcl, bnh, bnl, s, D2, D3, H1, H2)                                              \
   {                                                                                                   \
     TR_DECL TR(0)                                                                                     \
-    const bool has1 = (s) + 1 < a.nsteps, has2 = (s) + 2 < a.nsteps;                                  \
+    const bool has1 = (H1), has2 = (H2);   /* steps s+1 / s+2 exist (compile-time true in the steady-state loop) */ \
     bool newA2, a_early;                                                                              \
     int sl2;                                                                                          \
     STEP_HEAD_IF(MFMA_FIRST == 0, bnh, bnl, s, D2, D3)                                                \
@@ -425,9 +425,16 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     if (has2) { dy1 = D2.y; dx1 = D2.z; }                                                             \
     sl1 = sl2;                                                                                        \
   }
-  for (int s = 0; s < a.nsteps; s += 2) {
-    CONV_STEP(b0h, b0l, b1h, b1l, s, dE, dO)
-    if (s + 1 < a.nsteps) CONV_STEP(b1h, b1l, b0h, b0l, s + 1, dO, dE)
+  // steady state: both steps of the unrolled pair have successors s+1 and s+2 (no existence tests / branches);
+  // the last <= 3 steps run the general form
+  int s = 0;
+  for (; s + 3 < a.nsteps; s += 2) {
+    CONV_STEP(b0h, b0l, b1h, b1l, s, dE, dO, true, true)
+    CONV_STEP(b1h, b1l, b0h, b0l, s + 1, dO, dE, true, true)
+  }
+  for (; s < a.nsteps; s += 2) {
+    CONV_STEP(b0h, b0l, b1h, b1l, s, dE, dO, s + 1 < a.nsteps, s + 2 < a.nsteps)
+    if (s + 1 < a.nsteps) CONV_STEP(b1h, b1l, b0h, b0l, s + 1, dO, dE, s + 2 < a.nsteps, s + 3 < a.nsteps)
   }
 #undef CONV_STEP
 #undef STEP_HEAD_IF

@@ -269,7 +269,8 @@ class ConvPlan:
         starts = [i for i, t in enumerate(steps) if t[3] == 1] + [len(steps)]
         lens = [b_ - a_ for a_, b_ in zip(starts[:-1], starts[1:])]
         self.early_a = 1 if (min(lens) >= 2 and ns_ >= 3) else 0
-        self.steps = torch.tensor(enc, dtype=torch.int32, device=dev).contiguous()
+        # 4 padding rows: the kernel prefetches the descriptor of step s+3 without a bounds test
+        self.steps = torch.tensor(enc + [(0, 0, 0, 0)] * 4, dtype=torch.int32, device=dev).contiguous()
         s = torch.tensor(src, dtype=torch.int32, device=dev)
         src_c, src_ky, src_kx = s[:, 0].contiguous(), s[:, 1].contiguous(), s[:, 2].contiguous()
         self.src_dev = (src_c, src_ky, src_kx)

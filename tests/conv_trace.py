@@ -10,6 +10,8 @@ TR_BLOCKS, TR_STEPS = 8, 160
 shapes = [(8, 256, 256, 256, 3, "conv"), (8, 128, 128, 512, 3, "conv")]
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in sys.argv[1:6]) + (sys.argv[6],)]
+if len(sys.argv) > 7:
+    ops.set_precision(int(sys.argv[7]))     # 1: single-pass bf16 (a probe of the non-MFMA floor of a step)
 for (B, ci, co, H, k, kind) in shapes:
     x = torch.randn(B, H, H, ci, device="cuda")
     w = torch.randn(co, ci, k, k, device="cuda") / math.sqrt(ci * k * k)
