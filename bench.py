@@ -92,21 +92,32 @@ def conv_pmc():
 
 
 def cpu_baseline(seed):
-    """The CPU oracle (a port of the reference's PyTorch-CPU path, pinned to it by
-    tests/golden) timed on ONE pair at 512x512 on the host cores of this box."""
+    """The CPU oracle (a port of the reference's PyTorch-CPU path, pinned to it by tests/golden) timed on the host
+    cores of this box, BASELINE.md section 4 protocol: torch.set_num_threads(nproc), fp32, one warm-up run
+    (the 256x256 encode/decode config: thread pool, allocator and oneDNN primitive caches), then 3 timed runs of
+    ONE pair of the same 512x512 recipe, median reported.  A batch-8 run costs the same per pair on the host
+    (the oracle's convs are already multi-threaded over pixels), so the batch-1 rate is the bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ppst_oracle as O
     from ppst_amd import weights as W
+    nproc = os.cpu_count() or 1
+    torch.set_num_threads(nproc)
     sd = W.make_state_dict(seed, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
     noise = W.make_noise(seed + 2, 1)
     imgs = W.synthetic_images(seed + 4, 2)
     orc = O.PPSTOracle(sd, noise=noise)
+    times = []
     with torch.no_grad():
-        t0 = time.time()
-        orc.simple_swap(imgs[0:1], imgs[1:2], alpha=1.0)
-        dt = time.time() - t0
+        small = W.synthetic_images(seed, 2, size=256)
+        O.generator(sd, O.encoder_con(sd, small[0:1]), O.encoder_col(sd, small[1:2])[0], noise=W.make_noise(seed, 1, S=32))
+        for _ in range(3):
+            t0 = time.time()
+            orc.simple_swap(imgs[0:1], imgs[1:2], alpha=1.0)
+            times.append(time.time() - t0)
+    dt = sorted(times)[1]
     return {"value": 1.0 / dt, "unit": "swaps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 pair (batch 1) of the same 512x512 recipe, fp32, %.1f s" % dt}
+            "sample": "1 warm-up (256x256 encode/decode) + 3 timed runs of 1 pair (batch 1) of the same 512x512 recipe, fp32, "
+                      "median %.1f s (runs: %s)" % (dt, ", ".join("%.1f" % t for t in times))}
 
 
 def main():

@@ -347,6 +347,8 @@ int ppst_adam_step(void* p, const void* g, void* m, void* v, int64_t n, float lr
  * Opt-in HIP-event timing of the conv launches (bench.py roofline): when
  * enabled every ppst_conv2d_mfma call is bracketed by events on its stream. */
 int ppst_prof_enable(int on);
+/* launches that were NOT bracketed since the last enable because the event pool was full */
+int ppst_prof_dropped(void);
 /* after a stream sync: total ms, launches, algorithmic flop of bracketed calls */
 int ppst_prof_collect(double* ms, int64_t* launches, double* flop);
 /* per-launch detail of bracketed call idx (before ppst_prof_collect resets the pool):

@@ -233,8 +233,8 @@ def gen_train(ns, size=128):
     (sum(v.mean() for v in r1.values()) * opt.R1_once_every).backward()
     for n, p in D.named_parameters():
         pack(out, "r1grad.D." + n, p.grad if p.grad is not None else torch.zeros_like(p))
-    np.savez_compressed(os.path.join(GOLD, "train128.npz"), **out)
-    print("train128.npz", len(out), {k: v for k, v in out.items() if k.startswith("loss.")})
+    np.savez_compressed(os.path.join(GOLD, "train%d.npz" % size), **out)
+    print("train%d.npz" % size, len(out), {k: v for k, v in out.items() if k.startswith("loss.")})
 
 
 def gloss_inputs(B=2, size=512):
@@ -270,9 +270,93 @@ def gen_gloss(ns):
     print("gloss512.npz", {k: float(v) for k, v in out.items() if k.startswith(("loss.", "metric."))})
 
 
+def gstep_inputs(B=2, size=512):
+    """Seeded inputs of the generator-update fixture: the gloss inputs + explicit noise (weights.make_noise)."""
+    real, mask = gloss_inputs(B, size)
+    return real, mask, W.make_noise(31, B, S=size // 8)
+
+
+def _noise_hooks(m, noise):
+    """NoiseInjection draws normal_() on every call (stylegan2_layers.py:388-390); a forward pre-hook installs the
+    fixture's rows [0:batch] as ``fixed_noise`` before each call (the reference file is not edited)."""
+    hs = []
+    for name, mod in m.G.named_modules():
+        if type(mod).__name__ == "NoiseInjection":
+            key = name[:-len(".noise")]
+
+            def pre(mod_, args, key=key):
+                mod_.fixed_noise = noise[key][:args[0].shape[0]]
+            hs.append(mod.register_forward_pre_hook(pre))
+    return hs
+
+
+def gen_gstep(ns, stage):
+    """The generator/encoder update of the reference itself: PPSTOptimizer.train_generator_one_step's
+    ``sum(v.mean()).backward()`` (optimizers/ppst_optimizer.py:73-94) over compute_generator_losses
+    (models/ppst_model.py:161-235) at B = 2, 512x512, lambda_Cycwarp = 0 (lpips stubbed), stress weights (non-zero
+    biases and noise weights, explicit noise).  stage 1: L1 + GAN on the reconstruction (lambda_StyleCon = 0);
+    stage 2: the full objective.  Stored: every loss, sampled gradients of every G / E1 / E2 parameter, and the
+    gradients at the network boundaries (d/d rec, d/d sp, d/d codes) as debugging checkpoints."""
+    over = dict(lambda_Cycwarp=0.0, training_stage=stage)
+    if stage == 1:
+        over["lambda_StyleCon"] = 0.0
+    opt = ref_loader.default_opt(**over)
+    m = ref_loader.build_reference_model(opt)
+    sd = W.make_state_dict(17, bias_std=0.1, noise_weight=0.1)
+    own = m.state_dict()
+    m.load_state_dict({k: sd[k] for k in own if k in sd}, strict=False)
+    m.train()
+    real, mask, noise = gstep_inputs()
+    hooks = _noise_hooks(m, noise)
+    taps = {"E1": [], "E2": [], "G": []}
+
+    def tap(tag):
+        def f(mod, args, out):
+            ts = []
+
+            def walk(o):
+                if torch.is_tensor(o):
+                    if o.requires_grad:
+                        o.retain_grad()
+                    ts.append(o)
+                elif isinstance(o, (list, tuple)):
+                    for v in o:
+                        walk(v)
+            walk(out)
+            taps[tag].append(ts)
+        return f
+    for tag in taps:
+        hooks.append(getattr(m, tag).register_forward_hook(tap(tag)))
+    for p in m.D.parameters():                      # set_requires_grad(self.Dparams, False)
+        p.requires_grad_(False)
+    for net in (m.G, m.E1, m.E2):
+        net.zero_grad()
+    losses, metrics = m.compute_generator_losses(real, None, None, mask)
+    sum(v.mean() for v in losses.values()).backward()
+    out = {"loss." + k: np.array(float(v.mean())) for k, v in losses.items()}
+    out.update({"metric." + k: np.array(float(v.mean())) for k, v in metrics.items()})
+    for pre, net in (("G.", m.G), ("E1.", m.E1), ("E2.", m.E2)):
+        for n, p in net.named_parameters():
+            pack(out, "grad." + pre + n, p.grad if p.grad is not None else torch.zeros_like(p))
+    for tag, calls in taps.items():
+        for ci, ts in enumerate(calls):
+            for ti, t in enumerate(ts):
+                if t.grad is not None:
+                    pack(out, "tapgrad.%s.%d.%d" % (tag, ci, ti), t.grad)
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(os.path.join(GOLD, "gstep512_s%d.npz" % stage), **out)
+    print("gstep512_s%d.npz" % stage, len(out), {k: float(v) for k, v in out.items() if k.startswith(("loss.", "metric."))})
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ns = ref_loader.load_reference()
+    if len(sys.argv) > 1:                        # e.g. `gen_golden.py gstep1 gstep2 train512`: only these fixtures
+        for a in sys.argv[1:]:
+            {"gstep1": lambda: gen_gstep(ns, 1), "gstep2": lambda: gen_gstep(ns, 2),
+             "train512": lambda: gen_train(ns, 512), "train128": lambda: gen_train(ns), "gloss": lambda: gen_gloss(ns)}[a]()
+        return
     m = ref_loader.build_reference_model()
     gen_keys(m)
     gen_glue(ns, m)
@@ -280,7 +364,10 @@ def main():
     gen_cfg1(ns, m)
     gen_swap(ns, m)
     gen_train(ns)
+    gen_train(ns, 512)
     gen_gloss(ns)
+    gen_gstep(ns, 1)
+    gen_gstep(ns, 2)
 
 
 if __name__ == "__main__":

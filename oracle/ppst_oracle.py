@@ -9,9 +9,9 @@ it; the product path never does (ppst_amd raises if its HIP library is
 missing instead of falling back to anything in here).
 
 Parity status: **pinned** against the reference's own Python (imported under the
-shims of oracle/ref_loader.py in the build container) by
-tests/test_oracle_vs_reference.py and by the fixtures that oracle/gen_golden.py
-produced from it (tests/golden/*.npz).  Two third-party pieces are *unpinned*
+shims of oracle/ref_loader.py in the build container) through the fixtures that
+oracle/gen_golden.py produced from it (tests/golden/*.npz), which
+tests/test_oracle_golden.py holds this file to.  Two third-party pieces are *unpinned*
 (SURVEY.md section 8c): cv2.ximgproc.guidedFilter (opencv-contrib 4.8.1.78,
 photo_gif.py:43) -- restated below from He et al. / the OpenCV contrib
 algorithm -- and lpips (ppst_model.py:48,178), which is left out.

@@ -98,6 +98,7 @@ _SIGS = {
     "ppst_rscl_loss": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "ppst_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]),
     "ppst_prof_enable": (i32, [i32]),
+    "ppst_prof_dropped": (i32, []),
     "ppst_prof_collect": (i32, [ctypes.POINTER(f64), ctypes.POINTER(i64), ctypes.POINTER(f64)]),
     "ppst_prof_detail": (i32, [i32, ctypes.POINTER(f64), ctypes.POINTER(f64), ctypes.POINTER(i32)]),
 }

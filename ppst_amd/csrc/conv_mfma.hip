@@ -347,6 +347,9 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   }
 #define TOP_WORK(bnh, bnl, s, D2)                                                                     \
   if (ABL_B(has2)) b_dma((s) + 2, (s) & 1);                                                           \
+  /* the counted vmcnt(A_NLOADS) at the step barrier assumes the weight DMA was ISSUED before the */  \
+  /* activation loads (vmcnt retires in issue order): pin that order                              */  \
+  __builtin_amdgcn_sched_barrier(0);                                                                  \
   {   /* early mode: the chunk that step s+3 opens (stored during step s+1); else the chunk of step s+2 (stored   */ \
       /* in this step).  ONE a_load call site: two would make hipcc merge their results with copies + vmcnt(0).    */ \
     const bool ld_ = a.early_a ? ABL_A(has2 && (D2.w & 2)) : newA2;                                    \
@@ -628,16 +631,19 @@ extern "C" int ppst_upscale_weight(const void* w, void* out, int cout, int cin, 
 }
 
 // --------------------------------------------------------------- profiling --
-#define PROF_MAX 4096
+#define PROF_MAX 16384
 static int g_prof_on = 0;
 static hipEvent_t g_ev[PROF_MAX][2];
 static double g_flop[PROF_MAX];
 static int g_info[PROF_MAX][8];
 static int g_ev_made = 0, g_ev_used = 0;
+static int g_prof_dropped = 0;   // launches not bracketed because PROF_MAX events were in use
+extern "C" int ppst_prof_dropped(void) { return g_prof_dropped; }
 
 extern "C" int ppst_prof_enable(int on) {
   g_prof_on = on;
   g_ev_used = 0;
+  if (on) g_prof_dropped = 0;
   return PPST_OK;
 }
 extern "C" int ppst_prof_collect(double* ms, int64_t* launches, double* flop) {
@@ -711,6 +717,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   int blocks = (int)blocks64;
   hipStream_t st = as_stream(stream);
   int slot = -1;
+  if (g_prof_on && g_ev_used >= PROF_MAX) ++g_prof_dropped;
   if (g_prof_on && g_ev_used < PROF_MAX) {
     while (g_ev_made <= g_ev_used) {
       if (hipEventCreate(&g_ev[g_ev_made][0]) != hipSuccess || hipEventCreate(&g_ev[g_ev_made][1]) != hipSuccess) return PPST_EINVAL;

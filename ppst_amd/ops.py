@@ -254,6 +254,7 @@ class ConvPlan:
         else:
             raise ValueError(kind)
         self.src = src
+        self.max_chan = max(t[0] for t in steps)      # highest first-channel of any step (input needs max_chan + 32)
         self.wstrides = (sn, sc, sy, sx)
         self.nsteps = len(steps) // self.n_groups
         self.flop_steps = sum(1 for t in src if t[0] >= 0) // self.n_groups
@@ -289,7 +290,15 @@ class ConvPlan:
                  residual=None, out=None, out_scale=1.0, pad_mode=PAD_ZERO, out_hw=None, res_after_act=False,
                  in_ss=None, in_act=ACT_NONE, in_prelu=None):
         in_ld = _nhwc_ld(x, "conv input")
-        B, H, W, _ = x.shape
+        B, H, W, xc = x.shape
+        # the step table lives on the device: the C ABI cannot check these, and the kernel indexes
+        # x[.. + chan + 32), in_ss[b][chan][2] and noise[(b*oh+oy)*ow+ox] blindly
+        need_c = self.max_chan + 32
+        if xc < need_c:
+            raise RuntimeError("conv input has %d channels (pixel stride %d); the %s plan reads %d" % (xc, in_ld, self.kind, need_c))
+        if in_ss is not None and (in_ss.dim() != 3 or in_ss.shape[0] != B or in_ss.shape[1] < need_c or in_ss.shape[2] != 2
+                                  or not in_ss.is_contiguous()):
+            raise RuntimeError("in_ss must be a contiguous (B=%d, >=%d, 2) table, got %s" % (B, need_c, tuple(in_ss.shape)))
         if self.kind == "convT":
             th, tw, oh, ow, osy = H, W, 2 * H, 2 * W, 2
         elif self.kind == "dgrad_s2d":
@@ -303,7 +312,12 @@ class ConvPlan:
         if out is None:
             out = torch.empty((B, oh, ow, self.cout), device=x.device, dtype=torch.float32)
         out_ld = _nhwc_ld(out, "conv output")
-        assert out.shape[0] == B and out.shape[1] == oh and out.shape[2] == ow and out.shape[3] == self.cout
+        if tuple(out.shape) != (B, oh, ow, self.cout):
+            raise RuntimeError("conv output must be %s, got %s" % ((B, oh, ow, self.cout), tuple(out.shape)))
+        if noise is not None and (noise.numel() != B * oh * ow or not noise.is_contiguous()):
+            raise RuntimeError("noise must be a contiguous (B,1,%d,%d) tensor with B = %d rows, got %s" % (oh, ow, B, tuple(noise.shape)))
+        if residual is not None and tuple(residual.shape) != (B, oh, ow, self.cout):
+            raise RuntimeError("residual must match the output shape %s, got %s" % ((B, oh, ow, self.cout), tuple(residual.shape)))
         for t, n in ((bias, "bias"), (noise, "noise"), (prelu, "prelu"), (residual, "residual")):
             _chk(t, n)
         rows = TILE_ROWS["value"]
@@ -744,8 +758,13 @@ def prof_enable(on):
 
 
 def prof_collect():
+    """(ms, launches, flop) of the bracketed conv launches.  Raises if the event pool overflowed (the totals
+    would silently miss launches)."""
     ms, n, fl = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
+    dropped = lib.ppst_prof_dropped()
     check(lib.ppst_prof_collect(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "ppst_prof_collect")
+    if dropped:
+        raise RuntimeError("conv profiling pool overflowed: %d launches were not timed (use fewer --steps)" % dropped)
     return ms.value, n.value, fl.value
 
 

@@ -74,7 +74,9 @@ class PPSTModel(nn.Module):
         self.G = create_network(self.opt, self.opt.netG, "generator")
         if with_D:
             self.D = create_network(self.opt, self.opt.netD, "discriminator")
-        self.noise = None  # dict of explicit noise tensors, 'random', or None
+        # 'random' draws N(0,1) per call like the reference's NoiseInjection (stylegan2_layers.py:388-390);
+        # a dict '<Block>.<conv>' -> (B,1,H,W) pins the noise (parity tests); None forbids non-zero noise weights
+        self.noise = "random"
 
     # BaseModel.forward (models/base_model.py:114-123)
     def forward(self, *args, command=None, **kwargs):
@@ -234,10 +236,9 @@ class PPSTModel(nn.Module):
         from .train import DiscriminatorTrainer
         if getattr(self.opt, "lambda_R1", 10.0) <= 0.0:
             return {"D_R1": 0.0}
-        tr = getattr(self, "_d_trainer", None)
-        if tr is None or tr.D is not self.D:
-            tr = DiscriminatorTrainer(self.D)
-            object.__setattr__(self, "_d_trainer", tr)
+        # ONE trainer per D: its constructor rebinds D's parameters into a flat buffer, so a second
+        # trainer would orphan the first one's flat / m / v (DiscriminatorTrainer.for_network)
+        tr = DiscriminatorTrainer.for_network(self.D)
         return {"D_R1": tr.r1_penalty(real, getattr(self.opt, "lambda_R1", 10.0))}
 
     def compute_generator_losses(self, real, sp_ma, gl_ma, mask):

@@ -35,8 +35,30 @@ def _lrelu_bwd(g, out, scale=1.0):
 class DiscriminatorTrainer:
     """Owns D's parameters (views into one flat buffer), their gradients and Adam state."""
 
+    @classmethod
+    def for_network(cls, D, **kw):
+        """The trainer that owns ``D`` (created on first use and kept on the network).  The constructor rebinds
+        every parameter of D into one flat buffer; a second trainer on the same D would leave the first with an
+        orphaned flat / m / v whose Adam step updates memory D no longer reads."""
+        tr = D.__dict__.get("_trainer")
+        if tr is None or not tr.owns_parameters():
+            tr = cls(D, **kw)
+        return tr
+
+    def owns_parameters(self):
+        """True while D's parameters still alias this trainer's flat buffer (``.to()`` / ``.cuda()`` or another
+        trainer's constructor break the aliasing)."""
+        params = [p for _, p in self.D.named_parameters()]
+        off = 0
+        for p, n in zip(params, self.sizes):
+            if p.data_ptr() != self.flat.data_ptr() + 4 * off:
+                return False
+            off += n
+        return True
+
     def __init__(self, D, lr=1e-3, beta1=0.0, beta2=0.99, R1_once_every=16, world=1):
         self.D = D
+        D.__dict__["_trainer"] = self
         self.size = D.size
         c = R1_once_every / (1 + R1_once_every)
         self.lr, self.b1, self.b2, self.eps = lr * c, beta1 ** c, beta2 ** c, 1e-8
@@ -285,6 +307,9 @@ class DiscriminatorTrainer:
         ddp_average_(self.grad, self.world)
 
     def adam(self):
+        if not self.owns_parameters():
+            raise RuntimeError("D's parameters no longer alias this trainer's flat buffer (a second trainer was built "
+                               "on the same network, or .to()/.cuda() moved it): the update would be lost")
         self.step_count += 1
         ops.adam_step_(self.flat, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, self.step_count)
         self.D._cache.clear()  # packed weights are stale

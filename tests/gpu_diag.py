@@ -437,6 +437,9 @@ def t_networks():
         smr = O.smooth(r["out"], imgs[0:1])
         d = ((sm.cpu() - smr).abs() * 127.5).round()
         print("decode+guided filter: max LSB diff %d, frac != %.4f" % (d.max().item(), (d > 0).float().mean().item()), flush=True)
+        # <= 1 uint8 LSB on a small fraction of pixels (fp32 rounding across a quantisation step of G's output);
+        # the oracle's filter itself is parity-unpinned vs OpenCV
+        RES.append(("decode + guided filter 512 within 1 LSB", bool(d.max().item() <= 1 and (d > 0).float().mean().item() < 0.02)))
     # cfg1: 256^2 encode/decode only, init-like weights
     sd0 = W.make_state_dict(0)
     im = W.synthetic_images(0, 2, size=256, smooth=False)
@@ -512,7 +515,9 @@ def t_configs():
         ops.set_precision(0)
         report("cfg5 1024^2 decode (single-pass bf16, max-norm tol 1e-1)", out1, outr, 1e-1)
         rms = ((out1.cpu() - outr).pow(2).mean().sqrt() / outr.pow(2).mean().sqrt()).item()
-        RES.append(("cfg5 bf16 rms", rms < 5e-2))  # sanity bound of the reduced-precision mode (2^-9 per operand over ~40 layers), not a parity claim; print("cfg5 single-pass bf16 relative RMS error %.3e" % rms, flush=True)
+        # sanity bound of the reduced-precision mode (2^-9 per operand over ~40 layers), not a parity claim
+        print("cfg5 single-pass bf16 relative RMS error %.3e" % rms, flush=True)
+        RES.append(("cfg5 bf16 rms", rms < 5e-2))
 
 
 def t_train_d():

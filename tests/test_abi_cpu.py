@@ -155,3 +155,46 @@ def test_two_rank_gloo_sharding(tmp_path):
     outs = [p.communicate(timeout=120) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert b"OK" in outs[0][0]
+
+
+def test_one_trainer_per_discriminator():
+    """A second DiscriminatorTrainer on the same D rebinds D's parameters and would orphan the first trainer's
+    flat / m / v (its Adam step would update memory D no longer reads).  for_network() keeps ONE trainer per D,
+    compute_R1_loss goes through it, and adam() refuses to run once the aliasing is broken."""
+    from ppst_amd.networks.discriminator import StyleGAN2Discriminator
+    from ppst_amd.train import DiscriminatorTrainer
+    D = StyleGAN2Discriminator(None, size=32)
+    tr = DiscriminatorTrainer.for_network(D)
+    assert DiscriminatorTrainer.for_network(D) is tr and tr.owns_parameters()
+    w = next(iter(D.parameters()))
+    tr.flat[0] = 123.0                       # the flat buffer IS the parameter storage
+    assert float(w.view(-1)[0]) == 123.0
+    other = DiscriminatorTrainer(D)          # what compute_R1_loss used to do
+    assert other.owns_parameters() and not tr.owns_parameters()
+    with pytest.raises(RuntimeError, match="no longer alias"):
+        tr.adam()
+    assert DiscriminatorTrainer.for_network(D) is other
+    D.double()                               # _apply() moves the storage: the trainer must notice
+    assert not other.owns_parameters()
+
+
+def test_conv_plan_shape_checks_need_no_gpu():
+    """ConvPlan.__call__ validates what the C ABI cannot see (the step table lives on the device)."""
+    from ppst_amd import ops
+    plan = ops.ConvPlan.__new__(ops.ConvPlan)
+    plan.kind, plan.max_chan, plan.cout, plan.cin, plan.k = "conv", 32, 64, 64, 3
+
+    class FakeCuda(torch.Tensor):
+        is_cuda = True
+    def fake(*shape):
+        return torch.zeros(*shape).as_subclass(FakeCuda)
+    with pytest.raises(RuntimeError, match="plan reads 64"):
+        plan(fake(1, 16, 16, 32))
+    with pytest.raises(RuntimeError, match="in_ss"):
+        plan(fake(1, 16, 16, 64), in_ss=fake(1, 32, 2))
+    with pytest.raises(RuntimeError, match="noise"):
+        plan(fake(2, 16, 16, 64), noise=fake(1, 1, 16, 16), out=fake(2, 16, 16, 64))
+    with pytest.raises(RuntimeError, match="residual"):
+        plan(fake(1, 16, 16, 64), residual=fake(1, 16, 16, 32), out=fake(1, 16, 16, 64))
+    with pytest.raises(RuntimeError, match="conv output must be"):
+        plan(fake(1, 16, 16, 64), out=fake(1, 16, 16, 32))

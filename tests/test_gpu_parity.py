@@ -169,6 +169,57 @@ def test_swap_matches_reference_golden():
     assert np.abs(d.cpu().numpy() - g["D"]).max() <= 1e-3 * np.abs(g["D"]).max()
 
 
+def test_bench_step_batch8_rows_match_oracle():
+    """bench.py's exact ``swap_step`` at the benchmarked shape (batch 8, 512x512, distinct images and noise per
+    row, non-zero noise weights): rows 0 and 7 against two CPU-oracle swaps at the 1e-3 bar.  Catches per-row
+    indexing mistakes (noise rows, [B][C][2] scale/shift tables, statistics tiles) that a batch-1 test cannot see."""
+    import ppst_oracle as O
+    import bench
+    from ppst_amd import glue, weights as W
+    from ppst_amd.ppst_model import create_model
+    B = 8
+    sd = W.make_state_dict(0, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
+    m = create_model(state_dict=sd)
+    noise = W.make_noise(2, B)
+    m.noise = {k: v.cuda() for k, v in noise.items()}
+    imgs = W.synthetic_images(4, 2 * B)
+    with torch.no_grad():
+        out = bench.swap_step(m, imgs[:B].cuda().contiguous(), imgs[B:].cuda().contiguous(), 1.0, glue).cpu()
+        for row in (0, 7):
+            orc = O.PPSTOracle(sd, noise={k: v[row:row + 1] for k, v in noise.items()})
+            ref = orc.simple_swap(imgs[row:row + 1], imgs[B + row:B + row + 1], alpha=1.0)["out"]
+            err = float((out[row:row + 1] - ref).abs().max() / ref.abs().max())
+            assert err < 1e-3, (row, err)
+    # rows must differ from each other (distinct inputs): a wrong-row read would often go unnoticed otherwise
+    assert float((out[0] - out[7]).abs().max()) > 1e-2
+
+
+def test_checkpoint_save_load_then_swap_matches_golden(tmp_path):
+    """SURVEY 8(f1) on the GPU: PPSTModel.save() -> a fresh model -> load() (the reference's file layout and key
+    walk, base_model.py:33-112) -> the swap recipe still matches the reference-generated golden."""
+    import numpy as np
+    import zlib
+    from ppst_amd import weights as W
+    from ppst_amd.evaluation import simple_swap
+    from ppst_amd.ppst_model import Options, PPSTModel, create_model
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "swap512.npz"))
+    sd = W.make_state_dict(1, bias_std=0.1, noise_weight=0.1)
+    opt = Options(checkpoints_dir=str(tmp_path), name="rt", isTrain=False)
+    m = create_model(opt, state_dict=sd, with_D=True)
+    path = m.save(50000)
+    assert os.path.basename(path) == "50k_checkpoint.pth" and os.path.islink(os.path.join(str(tmp_path), "rt", "latest_checkpoint.pth"))
+    m2 = PPSTModel(Options(checkpoints_dir=str(tmp_path), name="rt", isTrain=False), with_D=False).cuda()
+    assert m2.load(verbose=False)
+    m2.noise = {k: v.cuda() for k, v in W.make_noise(3, 1).items()}
+    imgs = W.synthetic_images(5, 2).cuda()
+    with torch.no_grad():
+        out = simple_swap(m2, imgs[0:1], imgs[1:2], alphas=(1.0,))
+    name = "out_a1.0"
+    a = out[1.0].cpu().contiguous().view(-1).double().numpy()
+    idx = np.random.default_rng([99, zlib.crc32(name.encode())]).integers(0, a.size, size=2048)
+    assert np.abs(a[idx] - g[name + ".samples"]).max() <= 1e-3 * g[name + ".stats"][2]
+
+
 def test_image_preprocessing_is_pillow_bit_exact():
     """Device bicubic resample (two integer passes) + ToTensor/Normalize against the oracle
     (oracle/resize_oracle.py, itself pinned to Pillow) and, when Pillow is importable, Pillow itself at
