@@ -100,8 +100,11 @@ def cpu_baseline(seed):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ppst_oracle as O
     from ppst_amd import weights as W
-    nproc = os.cpu_count() or 1
-    torch.set_num_threads(nproc)
+    try:
+        nproc = len(os.sched_getaffinity(0))     # the cores this process may run on (not the whole host's)
+    except AttributeError:
+        nproc = os.cpu_count() or 1
+    torch.set_num_threads(min(nproc, torch.get_num_threads()) if nproc < torch.get_num_threads() else torch.get_num_threads())
     sd = W.make_state_dict(seed, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
     noise = W.make_noise(seed + 2, 1)
     imgs = W.synthetic_images(seed + 4, 2)
@@ -114,6 +117,7 @@ def cpu_baseline(seed):
             t0 = time.time()
             orc.simple_swap(imgs[0:1], imgs[1:2], alpha=1.0)
             times.append(time.time() - t0)
+            print("[bench] cpu_baseline run %d: %.1f s on %d threads" % (len(times), times[-1], torch.get_num_threads()), file=sys.stderr, flush=True)
     dt = sorted(times)[1]
     return {"value": 1.0 / dt, "unit": "swaps/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "1 warm-up (256x256 encode/decode) + 3 timed runs of 1 pair (batch 1) of the same 512x512 recipe, fp32, "

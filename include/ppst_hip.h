@@ -343,6 +343,60 @@ int ppst_lsgan(const void* pred, void* loss, void* grad, int n, float target, fl
 int ppst_adam_step(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1,
                    float beta2, float eps, int step, void* stream);
 
+/* ---- generator / encoder update of the train step (optimizers/ppst_optimizer.py:73-94: g_loss.backward()
+ * through models/ppst_model.py:161-235).  These replace what torch autograd derives for the reference's
+ * InstanceNorm2d + StyleMod (stylegan2_layers.py:361-374, 414-437), F.pad(reflect / replicate), F.interpolate,
+ * adaptive avg / max pooling (encoder_col.py:150-251), F.normalize / util.normalize (util/util.py:18-22), L1Loss,
+ * softmax and PReLU.  Conv input / weight gradients reuse ppst_conv2d_mfma / ppst_conv_wgrad_f32 with other step
+ * tables. ---- */
+/* ppst_in_finalize that also returns mean_rstd [B][C][2] (needed by the backward of the norm) */
+int ppst_in_finalize_train(const void* partial, int n_partials, const void* style, int style_ld, const void* post_bias,
+                           void* scale_shift, void* mean_rstd, int B, int C, double count, float eps, void* stream);
+/* instance-norm backward, pass 1: partial [B][n][C][2] = (sum g', sum g'*y) over pixel chunks; g' = g, or with
+ * `gate` (the activation FOLLOWS the norm, ConvLayer norm='in') g * lrelu'(gate).  x == partial == NULL: size query. */
+int ppst_dual_stats(const void* g, const void* y, const void* gate, void* partial, int B, int64_t hw, int C, int g_ld, int y_ld,
+                    int gate_ld, int* n_partials, void* stream);
+/* pass 2: coef [B][C][4] = (k0, k1, k2, 0) with dy = k0*g' + k1*y + k2; dstyle [B][2C] = (sum g*n, sum g) when given
+ * (style = the StyleMod linear output [B][>=C], row stride style_ld; NULL = no modulation).  mean_rstd == NULL:
+ * no norm -- dstyle = (sum g*y, sum g) only (SpatialCodeModulation scale / shift gradient, generator.py:80-91). */
+int ppst_in_bwd_finalize(const void* partial, int n_partials, const void* mean_rstd, const void* style, int style_ld, void* coef,
+                         void* dstyle, int B, int C, double count, void* stream);
+/* pass 3: dx = post * (k0*g' + k1*y + k2); post = lrelu'(y) when post_gate (StyledConv: activation before the norm) */
+int ppst_in_bwd_apply(const void* g, const void* y, const void* gate, const void* coef, void* dx, int B, int64_t hw, int C, int g_ld,
+                      int y_ld, int gate_ld, int dx_ld, int post_gate, void* stream);
+/* PReLU backward over z = a*y + s [+ res]: gpre = g * (z >= 0 ? 1 : slope) (dense [.,C]); ws receives per-block partial
+ * sums of dslope = sum g*z*[z<0] (ppst_prelu_bwd_ws bytes; reduce with ppst_sum_partials) */
+int64_t ppst_prelu_bwd_ws(int64_t total_elements);
+int ppst_prelu_bwd(const void* g, const void* y, const void* scale_shift, const void* res, const void* prelu, void* gpre, void* ws,
+                   int B, int64_t hw, int C, int g_ld, int y_ld, int res_ld, void* stream);
+int ppst_sum_partials(const void* partial, void* out, int n, float scale, void* stream);
+/* F.pad (PPST_PAD_*) of an NHWC tensor and its adjoint (dx = sum of dy over the padded positions that read it) */
+int ppst_pad2d(const void* x, void* y, int B, int H, int W, int C, int x_ld, int py0, int py1, int px0, int px1, int mode,
+               void* stream);
+int ppst_pad2d_bwd(const void* dy, void* dx, int B, int H, int W, int C, int py0, int py1, int px0, int px1, int mode, void* stream);
+/* adjoints of ppst_bilinear (dx must be zero-initialised; float atomics), ppst_avgpool and ppst_gap_gmp
+ * (v = the forward's [B][2C] output, g = its gradient; accumulate != 0 adds into dx) */
+int ppst_bilinear_bwd(const void* dy, void* dx, int B, int H, int W, int C, int dx_ld, int OH, int OW, int dy_ld, void* stream);
+int ppst_avgpool_bwd(const void* dy, void* dx, int B, int H, int W, int C, int dx_ld, int f, int dy_ld, void* stream);
+int ppst_gap_gmp_bwd(const void* x, const void* mask, const void* v, const void* g, void* dx, int B, int64_t hw, int C, int ld,
+                     int accumulate, void* stream);
+/* backward of ppst_l2norm_rows (mode 0: util.normalize, 1: F.normalize), ppst_softmax_rows (in place on g) and
+ * ppst_corr_prep (ppst_model.py:343-356) */
+int ppst_l2norm_rows_bwd(const void* g, const void* x, void* dx, int B, int K, float eps, int mode, void* stream);
+int ppst_softmax_rows_bwd(const void* p, void* g, int64_t rows, int cols, float div, void* stream);
+int ppst_corr_prep_bwd(const void* g, const void* x, void* dx, int64_t rows, int C, int ncenter, float eps, void* stream);
+/* d(weight * mean|a-b|)/da */
+int ppst_l1_grad(const void* a, const void* b, void* da, int64_t n, float weight, void* stream);
+/* y = x * s[0], s a device scalar (chain rule through a scalar loss) */
+int ppst_scale_by(const void* x, const void* s, void* y, int64_t n, void* stream);
+/* NoiseInjection weight gradient: out[0] = sum dpre[p][c] * noise[p] (stylegan2_layers.py:376-399) */
+int64_t ppst_noise_wgrad_ws(int64_t npix);
+int ppst_noise_wgrad(const void* dpre, const void* noise, void* out, void* ws, int64_t npix, int C, int ld, void* stream);
+/* adjoint of ppst_upscale_weight: dw4 (Cin,Cout,4,4) -> dw (Cout,Cin,3,3) */
+int ppst_upscale_weight_bwd(const void* dw4, void* dw, int cout, int cin, float scale, void* stream);
+/* NHWC [B][H][W][C] -> space-to-depth [B][ceil(H/2)][ceil(W/2)][4C] (channel block (py*2+px)*C) */
+int ppst_space_to_depth(const void* x, void* y, int B, int H, int W, int C, int x_ld, void* stream);
+
 /* ---------------------------------------------------------- profiling ----
  * Opt-in HIP-event timing of the conv launches (bench.py roofline): when
  * enabled every ppst_conv2d_mfma call is bracketed by events on its stream. */

@@ -97,6 +97,27 @@ _SIGS = {
     "ppst_l1_mean": (i32, [vp, vp, vp, vp, i64, f32, vp]),
     "ppst_rscl_loss": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "ppst_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]),
+    "ppst_in_finalize_train": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, f64, f32, vp]),
+    "ppst_dual_stats": (i32, [vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, ctypes.POINTER(i32), vp]),
+    "ppst_in_bwd_finalize": (i32, [vp, i32, vp, vp, i32, vp, vp, i32, i32, f64, vp]),
+    "ppst_in_bwd_apply": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, i32, vp]),
+    "ppst_prelu_bwd_ws": (i64, [i64]),
+    "ppst_prelu_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]),
+    "ppst_sum_partials": (i32, [vp, vp, i32, f32, vp]),
+    "ppst_pad2d": (i32, [vp, vp] + [i32] * 10 + [vp]),
+    "ppst_pad2d_bwd": (i32, [vp, vp] + [i32] * 9 + [vp]),
+    "ppst_bilinear_bwd": (i32, [vp, vp] + [i32] * 8 + [vp]),
+    "ppst_avgpool_bwd": (i32, [vp, vp] + [i32] * 7 + [vp]),
+    "ppst_gap_gmp_bwd": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp]),
+    "ppst_l2norm_rows_bwd": (i32, [vp, vp, vp, i32, i32, f32, i32, vp]),
+    "ppst_softmax_rows_bwd": (i32, [vp, vp, i64, i32, f32, vp]),
+    "ppst_corr_prep_bwd": (i32, [vp, vp, vp, i64, i32, i32, f32, vp]),
+    "ppst_l1_grad": (i32, [vp, vp, vp, i64, f32, vp]),
+    "ppst_scale_by": (i32, [vp, vp, vp, i64, vp]),
+    "ppst_noise_wgrad_ws": (i64, [i64]),
+    "ppst_noise_wgrad": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
+    "ppst_upscale_weight_bwd": (i32, [vp, vp, i32, i32, f32, vp]),
+    "ppst_space_to_depth": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ppst_prof_enable": (i32, [i32]),
     "ppst_prof_dropped": (i32, []),
     "ppst_prof_collect": (i32, [ctypes.POINTER(f64), ctypes.POINTER(i64), ctypes.POINTER(f64)]),

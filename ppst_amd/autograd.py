@@ -1,0 +1,487 @@
+"""Differentiable building blocks of the generator / encoder update.
+
+Each class is a ``torch.autograd.Function`` whose forward AND backward are HIP kernels of
+libppst_hip.so (ppst_amd/ops.py); torch's autograd engine is used as the tape only -- what the
+reference gets from ``g_loss.backward()`` (optimizers/ppst_optimizer.py:88) through F.conv2d /
+F.conv_transpose2d / InstanceNorm2d / StyleMod / upfirdn2d / F.interpolate / pooling.  Activations
+are NHWC fp32 (B,H,W,C) like the inference path.  Views, cat and slicing between the blocks are
+torch memory operations.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+SQRT2 = math.sqrt(2.0)
+Z, REFLECT, REPLICATE = ops.PAD_ZERO, ops.PAD_REFLECT, ops.PAD_REPLICATE
+NONE, LRELU, PRELU = ops.ACT_NONE, ops.ACT_LRELU, ops.ACT_PRELU
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def lrelu_bwd(g, out, scale=1.0):
+    """d/d(pre-activation) of y = lrelu(x)*sqrt2 given d/dy, gated by the sign of the saved output
+    (fused_bias_act_kernel.cu:43)."""
+    return ops.fused_bias_act_raw(g, None, out, 3, 1, 0.2, SQRT2 * scale)
+
+
+def relu_gate(g, x):
+    """g * [x > 0] (backward of the projectors' leading nn.ReLU)."""
+    return ops.fused_bias_act_raw(g, None, x, 3, 1, 0.0, 1.0)
+
+
+def _conv_grads(net, wname, kind, scale, pad_mode, x, gpre, need_x, need_w, out_hw=None):
+    """(dx, dw) of a stride-1 'conv' plan given the gradient at its raw output."""
+    plan = net.plan(wname, kind, scale)
+    k = plan.k
+    dx = dw = None
+    if pad_mode == Z or k == 1:
+        if need_x:
+            dx = net.plan(wname, "dgrad", scale)(gpre)
+        if need_w:
+            dw = ops.conv_wgrad(plan, x, gpre)
+        return dx, dw
+    # reflection / replication padding: y = conv_valid(pad(x)).  On the padded canvas the same zero-padded kernels
+    # are exact: the gradient canvas is zero on the border, so border outputs / out-of-canvas taps contribute nothing.
+    gp = ops.pad2d(gpre, 1, 1, 1, 1, Z)
+    if need_x:
+        dx = ops.pad2d_bwd(net.plan(wname, "dgrad", scale)(gp), 1, 1, 1, 1, pad_mode)
+    if need_w:
+        dw = ops.conv_wgrad(plan, ops.pad2d(x, 1, 1, 1, 1, pad_mode), gp)
+    return dx, dw
+
+
+class ConvFn(Function):
+    """y = act(conv(x; w*scale) [+ noise_w*noise] [+ bias]) -> (y, tile statistics of y).
+    kind 'conv': k in {1,3}, stride 1, padding k//2 in ``pad_mode``; 'convT': the fused 4x4 stride-2 transposed conv
+    of EqualizedConv2d (stylegan2_layers.py:312-321)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, noise_w, noise, net, wname, kind, scale, pad_mode, act):
+        x = _c(x)
+        plan = net.plan(wname, kind, scale)
+        nw = float(noise_w) if noise_w is not None else 0.0
+        y, st = plan(x, bias=bias, noise=(noise if noise_w is not None else None), noise_weight=nw, act=act, pad_mode=pad_mode, stats=True)
+        ctx.save_for_backward(x, y if act != NONE else None, noise if noise_w is not None else None)
+        ctx.cfg = (net, wname, kind, scale, pad_mode, act, bias is not None, noise_w is not None)
+        ctx.mark_non_differentiable(st)
+        return y, st
+
+    @staticmethod
+    def backward(ctx, g, _gst):
+        x, y, noise = ctx.saved_tensors
+        net, wname, kind, scale, pad_mode, act, has_b, has_n = ctx.cfg
+        g = _c(g)
+        gpre = lrelu_bwd(g, y) if act == LRELU else g
+        C = gpre.shape[3]
+        db = ops.colsum(gpre.view(-1, C)) if (has_b and ctx.needs_input_grad[2]) else None
+        dnw = ops.noise_wgrad(gpre, noise) if (has_n and ctx.needs_input_grad[3]) else None
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if kind == "conv":
+            dx, dw = _conv_grads(net, wname, kind, scale, pad_mode, x, gpre, need_x, need_w)
+        else:  # convT: dX = stride-2 4x4 conv of dY (run over its space-to-depth copy); dW through the blurred 4x4 kernel
+            gs = ops.space_to_depth(gpre)
+            pl = net.plan(wname, "dgradT", scale)
+            dx = pl(gs) if need_x else None
+            dw = None
+            if need_w:
+                dw4 = ops.conv_wgrad(pl, gs, x)
+                dw = ops.upscale_weight_bwd(dw4, pl.cin, pl.cout, pl.fwd_scale)
+        return dx, dw, db, dnw, None, None, None, None, None, None, None
+
+
+def conv(x, w, net, wname, bias=None, kind="conv", scale=1.0, pad_mode=Z, act=NONE, noise_w=None, noise=None, stats=False):
+    y, st = ConvFn.apply(x, w, bias, noise_w, noise, net, wname, kind, scale, pad_mode, act)
+    return (y, st) if stats else y
+
+
+class BlurConvFn(Function):
+    """ConvLayer(downsample=True) of stylegan2_layers.py:497-555 for the 3x3 conv: Blur (upfirdn2d, zero or reflection
+    padding (p0, p1)) -> 3x3 stride-2 conv (no padding) [+ bias -> leaky-relu*sqrt2] -> (y, tile statistics)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, net, wname, kname, scale, p0, p1, pad_mode, act):
+        x = _c(x)
+        k = net.p(kname)
+        xb, bhw = ops.blur_nhwc(x, k, p0, p1, pad_mode, s2d=True)
+        ohw = ((bhw[0] - 3) // 2 + 1, (bhw[1] - 3) // 2 + 1)
+        y, st = net.plan(wname, "s2d", scale)(xb, bias=bias, act=act, out_hw=ohw, stats=True)
+        ctx.save_for_backward(xb, y if act != NONE else None)
+        ctx.cfg = (net, wname, kname, scale, p0, p1, pad_mode, act, bhw, bias is not None)
+        ctx.mark_non_differentiable(st)
+        return y, st
+
+    @staticmethod
+    def backward(ctx, g, _gst):
+        xb, y = ctx.saved_tensors
+        net, wname, kname, scale, p0, p1, pad_mode, act, bhw, has_b = ctx.cfg
+        g = _c(g)
+        gpre = lrelu_bwd(g, y) if act == LRELU else g
+        C = gpre.shape[3]
+        db = ops.colsum(gpre.view(-1, C)) if (has_b and ctx.needs_input_grad[2]) else None
+        dw = ops.conv_wgrad(net.plan(wname, "s2d", scale), xb, gpre) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            d_xb = net.plan(wname, "dgrad_s2d", scale)(gpre, out_hw=bhw)
+            k = net.p(kname)
+            ks = k.shape[0]
+            kf = torch.flip(k, [0, 1]).contiguous()
+            if pad_mode == Z:   # FIR with the flipped taps and g_pad = (ks-1-p0, ks-1-p1) (upfirdn2d.py:116-121)
+                dx, _ = ops.blur_nhwc(d_xb, kf, ks - 1 - p0, ks - 1 - p1, Z)
+            else:               # full correlation onto the padded extent, then the adjoint of the reflection padding
+                dpad, _ = ops.blur_nhwc(d_xb, kf, ks - 1, ks - 1, Z)
+                dx = ops.pad2d_bwd(dpad, p0, p1, p0, p1, pad_mode)
+        return dx, dw, db, None, None, None, None, None, None, None, None
+
+
+def blur_conv(x, w, net, wname, kname, bias=None, scale=1.0, p0=2, p1=2, pad_mode=Z, act=NONE, stats=False):
+    y, st = BlurConvFn.apply(x, w, bias, net, wname, kname, scale, p0, p1, pad_mode, act)
+    return (y, st) if stats else y
+
+
+class BlurDownFn(Function):
+    """Blur (zero padding (p0, p1)) keeping every second sample: the skip branch's Blur + stride-2 1x1 conv only reads
+    those (stylegan2_layers.py:566-568)."""
+
+    @staticmethod
+    def forward(ctx, x, net, kname, p0, p1):
+        x = _c(x)
+        k = net.p(kname)
+        y, _ = ops.blur_nhwc(x, k, p0, p1, Z, down=2)
+        ctx.cfg = (net, kname, p0, p1, x.shape[1], x.shape[2])
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        net, kname, p0, p1, H, W = ctx.cfg
+        k = net.p(kname)
+        ks = k.shape[0]
+        g = _c(g)
+        oh, ow = g.shape[1], g.shape[2]
+        # UpFirDn2dBackward (upfirdn2d.py:24-60): zero-insert x2, FIR with the flipped taps, g_pad
+        gp0 = ks - p0 - 1
+        dx = ops.upfirdn2d_raw(g, torch.flip(k, [0, 1]).contiguous(), 2, 2, 1, 1, gp0, W - 2 * ow + p0, gp0, H - 2 * oh + p0)
+        return dx, None, None, None, None
+
+
+class InstanceNormFn(Function):
+    """out = act(IN(y) * (s0 + 1) + s1 + post_bias): nn.InstanceNorm2d (eps 1e-5, biased variance) [+ StyleMod
+    (stylegan2_layers.py:361-374), style = its linear's (B, 2C) output] [+ the FusedLeakyReLU bias / activation that
+    follows the norm in ConvLayer(norm='in'), :542-549] [or PReLU (generator.py:10-32)].
+    ``st``: tile statistics of y from the producing kernel (None: computed here)."""
+
+    @staticmethod
+    def forward(ctx, y, st, style, post_bias, prelu, act, eps):
+        y = _c(y)
+        B, H, W, C = y.shape
+        if st is None:
+            st = ops.in_stats(y)
+        ss, mr = ops.in_finalize_train(st, H * W, style=style, post_bias=post_bias, eps=eps)
+        out = ops.affine_act(y, ss, act=act, prelu=prelu)
+        ctx.save_for_backward(y, out if act == LRELU else None, mr, style, ss if act == PRELU else None, prelu)
+        ctx.act = act
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, out, mr, style, ss, prelu = ctx.saved_tensors
+        g = _c(g)
+        B, H, W, C = y.shape
+        dprelu = None
+        gate = out if ctx.act == LRELU else None
+        if ctx.act == PRELU:
+            g, dprelu = ops.prelu_bwd(g, y, prelu, scale_shift=ss)
+        part = ops.dual_stats(g, y, gate)
+        want = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        coef, dstyle = ops.in_bwd_finalize(part, H * W, mr, style, want_dstyle=want)
+        dy = ops.in_bwd_apply(g, y, coef, gate=gate) if ctx.needs_input_grad[0] else None
+        dpb = ops.colsum(dstyle[:, C:]) if ctx.needs_input_grad[3] else None
+        return dy, None, (dstyle if ctx.needs_input_grad[2] else None), dpb, dprelu, None, None
+
+
+def instance_norm(y, st=None, style=None, post_bias=None, prelu=None, act=NONE, eps=1e-5):
+    return InstanceNormFn.apply(y, st, style, post_bias, prelu, act, eps)
+
+
+class AddScaleFn(Function):
+    """(a + b) * s  -- the resnet merge (skip + res) / sqrt2."""
+
+    @staticmethod
+    def forward(ctx, a, b, s):
+        ctx.s = s
+        return ops.affine_act(_c(a), None, res=_c(b), out_scale=s)
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = ops.affine_act(_c(g), None, out_scale=ctx.s)
+        return gs, gs, None
+
+
+class PReluResFn(Function):
+    """prelu(a + res) with the shared slope of generator.py:ResidualBlock (:28-31)."""
+
+    @staticmethod
+    def forward(ctx, a, res, prelu):
+        a, res = _c(a), _c(res)
+        ctx.save_for_backward(a, res, prelu)
+        return ops.affine_act(a, None, res=res, res_before_act=True, act=PRELU, prelu=prelu)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, res, prelu = ctx.saved_tensors
+        gpre, ds = ops.prelu_bwd(_c(g), a, prelu, res=res)
+        return gpre, gpre, ds
+
+
+class BilinearFn(Function):
+    """F.interpolate(mode='bilinear', align_corners=False) to (OH, OW)."""
+
+    @staticmethod
+    def forward(ctx, x, OH, OW):
+        x = _c(x)
+        ctx.hw = (x.shape[1], x.shape[2])
+        return ops.bilinear(x, OH, OW)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.bilinear_bwd(_c(g), *ctx.hw), None, None
+
+
+class AvgPoolFn(Function):
+    """adaptive_avg_pool2d by an integer factor."""
+
+    @staticmethod
+    def forward(ctx, x, f):
+        ctx.f = f
+        return ops.avgpool(_c(x), f)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.avgpool_bwd(_c(g), ctx.f), None
+
+
+class PadFn(Function):
+    @staticmethod
+    def forward(ctx, x, p, mode):
+        ctx.cfg = (p, mode)
+        return ops.pad2d(_c(x), p, p, p, p, mode)
+
+    @staticmethod
+    def backward(ctx, g):
+        p, mode = ctx.cfg
+        return ops.pad2d_bwd(_c(g), p, p, p, p, mode), None, None
+
+
+class GapGmpFn(Function):
+    """cat(AdaptiveAvgPool2d(1), AdaptiveMaxPool2d(1)) of x * mask (encoder_col.py:162-168, 217-245) -> (B, 2C)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        x = _c(x)
+        v = ops.gap_gmp(x, mask)
+        ctx.save_for_backward(x, mask, v)
+        return v
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mask, v = ctx.saved_tensors
+        return ops.gap_gmp_bwd(x, mask, v, _c(g)), None
+
+
+class LinearFn(Function):
+    """y = act(relu_in(x) @ (w*wscale)^T + b*bscale): EqualLinear / EqualizedLinear / nn.Linear behind nn.ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, wscale, bscale, relu_in, act):
+        x = _c(x)
+        y = ops.linear(x, w.reshape(w.shape[0], -1), b, wscale=wscale, bscale=bscale, relu_in=relu_in, act=act)
+        ctx.save_for_backward(x, w, y if act == LRELU else None)
+        ctx.cfg = (wscale, bscale, relu_in, act, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        wscale, bscale, relu_in, act, has_b = ctx.cfg
+        g = _c(g)
+        if act == LRELU:
+            g = lrelu_bwd(g, y)
+        w2 = w.reshape(w.shape[0], -1)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_dgrad(g, w2, wscale)
+            if relu_in:
+                dx = relu_gate(dx, x)
+        if ctx.needs_input_grad[1]:
+            xin = relu_gate(x, x) if relu_in else x      # relu(x) = x * [x > 0]
+            dw = ops.linear_wgrad(g, xin, wscale).view_as(w)
+        if has_b and ctx.needs_input_grad[2]:
+            db = ops.colsum(g, bscale)
+        return dx, dw, db, None, None, None, None
+
+
+def linear(x, w, b=None, wscale=1.0, bscale=1.0, relu_in=False, act=NONE):
+    return LinearFn.apply(x, w, b, wscale, bscale, relu_in, act)
+
+
+class L2NormFn(Function):
+    """mode 0: util.normalize (x * rsqrt(sum x^2 + 1e-8), util/util.py:18-22); mode 1: F.normalize (eps 1e-12)."""
+
+    @staticmethod
+    def forward(ctx, x, eps, mode):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        ctx.cfg = (eps, mode)
+        return ops.l2norm_rows(x, eps, mode)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.l2norm_rows_bwd(_c(g), x, *ctx.cfg), None, None
+
+
+class SpatialModFn(Function):
+    """GeneratorModulation (generator.py:80-91): sp * scale[b, c] + shift[b, c]."""
+
+    @staticmethod
+    def forward(ctx, sp, scale, shift):
+        sp, scale = _c(sp), _c(scale)
+        ctx.save_for_backward(sp, scale)
+        return ops.spatial_modulation(sp, scale, _c(shift))
+
+    @staticmethod
+    def backward(ctx, g):
+        sp, scale = ctx.saved_tensors
+        g = _c(g)
+        B, H, W, C = sp.shape
+        dsp = None
+        if ctx.needs_input_grad[0]:
+            ss = torch.stack((scale, torch.zeros_like(scale)), dim=2).contiguous()
+            dsp = ops.affine_act(g, ss)
+        _, d = ops.in_bwd_finalize(ops.dual_stats(g, sp), H * W)       # (sum g*sp, sum g) per (b, c)
+        return dsp, d[:, :C], d[:, C:]
+
+
+class FromRGBFn(Function):
+    """ConvLayer(3, C, 1): 1x1 conv (no conv bias) + FusedLeakyReLU (stylegan2_layers.py:497-555)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, scale):
+        x = _c(x)
+        y = ops.conv1x1_small_cin(x, w, b, scale, LRELU)
+        ctx.save_for_backward(x, w, y)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        g0 = lrelu_bwd(_c(g), y)
+        C = g0.shape[3]
+        db = ops.colsum(g0.view(-1, C)) if ctx.needs_input_grad[2] else None
+        dw = ops.wgrad_small_cin(x, g0, ctx.scale).view_as(w) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = w.reshape(w.shape[0], w.shape[1]).t().contiguous()
+            dx = ops.conv1x1_small_cout(g0, wt, None, wscale=ctx.scale)
+        return dx, dw, db, None
+
+
+class ToRGBConvFn(Function):
+    """EqualConv2d(C, 3, 1) + bias of ToRGB (stylegan2_layers.py:477-495)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, scale):
+        x = _c(x)
+        ctx.save_for_backward(x, w)
+        ctx.scale = scale
+        return ops.conv1x1_small_cout(x, w, b, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = _c(g)
+        cout, cin = w.shape[0], w.shape[1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv1x1_small_cin(g, w.reshape(cout, cin).t().contiguous(), None, ctx.scale, NONE)
+        if ctx.needs_input_grad[1]:
+            dw = ops.wgrad_small_cin(g, x, ctx.scale).t().contiguous().view_as(w)   # (cin, cout) -> (cout, cin, 1, 1)
+        if ctx.needs_input_grad[2]:
+            db = ops.colsum(g.view(-1, cout))
+        return dx, dw, db, None
+
+
+class ToNHWCFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.nchw_to_nhwc(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.nhwc_to_nchw(_c(g))
+
+
+class ToNCHWFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.nhwc_to_nchw(_c(x))
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.nchw_to_nhwc(_c(g))
+
+
+class L1LossFn(Function):
+    """weight * torch.nn.L1Loss()(a, b) -> (1,); gradient flows to ``a`` only (b is a target)."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight):
+        a, b = _c(a), _c(b)
+        ctx.save_for_backward(a, b)
+        ctx.w = weight
+        return ops.l1_mean(a, b, weight)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = ops.l1_grad(a, b, ctx.w)
+        return ops.scale_by(da, g), None, None
+
+
+class LsganFn(Function):
+    """weight * mean((pred - target)^2) (models/networks/loss.py:11-18)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, weight):
+        loss, grad = ops.lsgan(_c(pred), target, weight)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return ops.scale_by(grad, g), None, None
+
+
+class DiscriminatorLogitsFn(Function):
+    """D(img) for the generator iteration: D's parameters are frozen (set_requires_grad(Dparams, False),
+    ppst_optimizer.py:74), only d/d(img) is needed -- the taped forward / input-gradient backward of the
+    discriminator trainer (ppst_amd/train.py)."""
+
+    @staticmethod
+    def forward(ctx, img, trainer):
+        pred, tape = trainer.forward(img)
+        ctx.tape, ctx.trainer = tape, trainer
+        return pred
+
+    @staticmethod
+    def backward(ctx, g):
+        keep = {}
+        ctx.trainer.backward(ctx.tape, _c(g), param_grads=False, keep=keep)
+        ctx.tape = None
+        return ops.nhwc_to_nchw(keep["d_img"]), None

@@ -300,7 +300,7 @@ extern "C" int ppst_in_stats(const void* x, void* partial, int B, int H, int W, 
 __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ partial, int n_partials,
                                                           const float* __restrict__ style, int style_ld,
                                                           const float* __restrict__ post_bias, float* __restrict__ ss, int B,
-                                                          int C, double count, float eps) {
+                                                          int C, double count, float eps, float* __restrict__ mr) {
   __shared__ double sm[8][32][2];
   const int cgroups = (C + 31) / 32;
   const int b = blockIdx.x / cgroups, c0 = (blockIdx.x % cgroups) * 32;
@@ -334,6 +334,10 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restric
     if (post_bias) sh += (double)post_bias[c];  // FusedLeakyReLU bias that follows the norm (ConvLayer norm='in')
     ss[((int64_t)b * C + c) * 2] = (float)a;
     ss[((int64_t)b * C + c) * 2 + 1] = (float)sh;
+    if (mr) {   // training: the backward of the norm needs (mean, rstd) themselves (ppst_in_bwd_finalize)
+      mr[((int64_t)b * C + c) * 2] = (float)mean;
+      mr[((int64_t)b * C + c) * 2 + 1] = (float)rstd;
+    }
   }
 }
 extern "C" int ppst_in_finalize(const void* partial, int n_partials, const void* style, int style_ld, const void* post_bias,
@@ -343,7 +347,18 @@ extern "C" int ppst_in_finalize(const void* partial, int n_partials, const void*
   if (!partial || !scale_shift) return PPST_ENULL;
   PPST_LAUNCH(in_finalize_kernel, dim3(B * cdiv(C, 32)), dim3(256), 0, as_stream(stream),
                      (const float*)partial, n_partials, (const float*)style, style_ld, (const float*)post_bias,
-                     (float*)scale_shift, B, C, count, eps);
+                     (float*)scale_shift, B, C, count, eps, (float*)nullptr);
+  return PPST_LAUNCH_CHECK();
+}
+// ppst_in_finalize that also returns mean_rstd [B][C][2] for the backward pass
+extern "C" int ppst_in_finalize_train(const void* partial, int n_partials, const void* style, int style_ld, const void* post_bias,
+                                      void* scale_shift, void* mean_rstd, int B, int C, double count, float eps, void* stream) {
+  if (B < 0 || C <= 0 || n_partials <= 0 || count <= 0 || (style && style_ld < 2 * C)) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!partial || !scale_shift || !mean_rstd) return PPST_ENULL;
+  PPST_LAUNCH(in_finalize_kernel, dim3(B * cdiv(C, 32)), dim3(256), 0, as_stream(stream),
+                     (const float*)partial, n_partials, (const float*)style, style_ld, (const float*)post_bias,
+                     (float*)scale_shift, B, C, count, eps, (float*)mean_rstd);
   return PPST_LAUNCH_CHECK();
 }
 

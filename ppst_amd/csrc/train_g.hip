@@ -1,0 +1,615 @@
+// Backward kernels of the generator / encoder update of the GAN train step (SURVEY.md section 8 a14;
+// reference: optimizers/ppst_optimizer.py:73-94 `g_loss.backward()` through
+// models/ppst_model.py:161-235, i.e. torch autograd of InstanceNorm2d + StyleMod
+// (stylegan2_layers.py:361-374, 414-437), ReflectionPad2d / ReplicationPad2d, F.interpolate(bilinear),
+// adaptive avg / max pooling (encoder_col.py:150-251), F.normalize / util.normalize, L1Loss, softmax, PReLU).
+// All HBM-bound, NHWC fp32, one pass each; the conv input / weight gradients are the MFMA kernels of
+// conv_mfma.hip / train.hip driven by other step tables.
+#include "common.h"
+
+#define TG_GRID_CAP (256 * 16)
+static inline unsigned tg_grid(int64_t work, int threads = 256) {
+  int64_t b = cdiv64(work, threads);
+  if (b > TG_GRID_CAP) b = TG_GRID_CAP;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+__device__ __forceinline__ float lrelu_gate(float ref) { return (ref > 0.f ? 1.f : 0.2f) * 1.41421356237309515f; }
+
+static inline int tg_pix_chunk(int B, int64_t hw) {
+  int chunk = 1024;
+  while (chunk > 64 && (int64_t)B * cdiv64(hw, chunk) < 2048) chunk >>= 1;
+  return chunk;
+}
+
+// ---------------------------------------------------- instance norm backward --
+// out = n * A + s1,  n = (y - mean) * rstd  (A = style s0 + 1 or 1).  With g = dL/dout:
+//   dy = rstd*A * (g - mean(g) - n * mean(g*n)),  ds0 = sum g*n,  ds1 = sum g.
+// Pass 1 (this kernel): per-(b, c) partial sums (sum g', sum g'*y) over pixel chunks, g' = g or, with `gate`
+// (ConvLayer norm='in': the norm precedes the activation), g * lrelu'(gate).
+__global__ __launch_bounds__(256) void dual_stats_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                         const float* __restrict__ gate, float* __restrict__ partial, int P, int C,
+                                                         int g_ld, int y_ld, int gate_ld, int nchunks, int PIX_CHUNK) {
+  __shared__ float s0[256], s1[256];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int pbeg = chunk * PIX_CHUNK;
+  const int pend = (pbeg + PIX_CHUNK < P) ? pbeg + PIX_CHUNK : P;
+  int lanesC = 1;
+  while (lanesC < C && lanesC < 256) lanesC <<= 1;
+  const int rows = 256 / lanesC;
+  const int cl = threadIdx.x % lanesC, pr = threadIdx.x / lanesC;
+  for (int cbase = 0; cbase < C; cbase += lanesC) {
+    const int c = cbase + cl;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C) {
+      for (int p = pbeg + pr; p < pend; p += rows) {
+        const int64_t bp = (int64_t)b * P + p;
+        float gv = g[bp * g_ld + c];
+        const float yv = y[bp * y_ld + c];
+        if (gate) gv *= lrelu_gate(gate[bp * gate_ld + c]);
+        a0 += gv;
+        a1 += gv * yv;
+      }
+    }
+    s0[threadIdx.x] = a0;
+    s1[threadIdx.x] = a1;
+    __syncthreads();
+    if (pr == 0 && c < C) {
+      for (int r = 1; r < rows; ++r) { a0 += s0[r * lanesC + cl]; a1 += s1[r * lanesC + cl]; }
+      float* o = partial + (((int64_t)b * nchunks + chunk) * C + c) * 2;
+      o[0] = a0;
+      o[1] = a1;
+    }
+    __syncthreads();
+  }
+}
+extern "C" int ppst_dual_stats(const void* g, const void* y, const void* gate, void* partial, int B, int64_t hw, int C, int g_ld,
+                               int y_ld, int gate_ld, int* n_partials, void* stream) {
+  if (B < 0 || hw <= 0 || hw > 0x7fffffffll || C <= 0 || g_ld < C || y_ld < C || (gate && gate_ld < C)) return PPST_EINVAL;
+  const int chunk = tg_pix_chunk(B, hw);
+  const int nchunks = (int)cdiv64(hw, chunk);
+  if (n_partials) *n_partials = nchunks;
+  if (!g && !partial) return PPST_OK;  // size query
+  if (B == 0) return PPST_OK;
+  if (!g || !y || !partial) return PPST_ENULL;
+  PPST_LAUNCH(dual_stats_kernel, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)g, (const float*)y,
+              (const float*)gate, (float*)partial, (int)hw, C, g_ld, y_ld, gate_ld, nchunks, chunk);
+  return PPST_LAUNCH_CHECK();
+}
+
+// Pass 2: reduce the partials (double accumulation) -> coef[b][c] = (k0, k1, k2) with dy = k0*g' + k1*y + k2 and,
+// with `style`, dstyle[b] = (ds0[0..C), ds1[0..C)) (gradient of the StyleMod linear's output, stylegan2_layers.py:368-374).
+// mean_rstd[b][c] = (mean, rstd) of the forward (ppst_in_finalize_train).  Without a norm (mean_rstd == null) the
+// partials are plain per-channel sums: coef is not written and dstyle = (sum g*y, sum g) -- the gradient of the
+// SpatialCodeModulation scale / shift (generator.py:80-91).
+__global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const float* __restrict__ partial, int n_partials,
+                                                              const float* __restrict__ mean_rstd, const float* __restrict__ style,
+                                                              int style_ld, float* __restrict__ coef, float* __restrict__ dstyle,
+                                                              int B, int C, double count) {
+  __shared__ double sm[8][32][2];
+  const int cgroups = (C + 31) / 32;
+  const int b = blockIdx.x / cgroups, c0 = (blockIdx.x % cgroups) * 32;
+  const int cl = threadIdx.x & 31, kk = threadIdx.x >> 5;
+  const int c = c0 + cl;
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+    const float2* p = (const float2*)partial + ((int64_t)b * n_partials * C + c);
+    for (int k = kk; k < n_partials; k += 8) {
+      float2 v = p[(int64_t)k * C];
+      s += (double)v.x;
+      q += (double)v.y;
+    }
+  }
+  sm[kk][cl][0] = s;
+  sm[kk][cl][1] = q;
+  __syncthreads();
+  if (kk == 0 && c < C) {
+    for (int r = 1; r < 8; ++r) { s += sm[r][cl][0]; q += sm[r][cl][1]; }
+    if (!mean_rstd) {
+      if (dstyle) {
+        dstyle[(int64_t)b * 2 * C + c] = (float)q;
+        dstyle[(int64_t)b * 2 * C + C + c] = (float)s;
+      }
+      return;
+    }
+    const double mean = (double)mean_rstd[((int64_t)b * C + c) * 2], rstd = (double)mean_rstd[((int64_t)b * C + c) * 2 + 1];
+    const double A = style ? (double)style[(int64_t)b * style_ld + c] + 1.0 : 1.0;
+    const double m1 = s / count, m2 = q / count;
+    const double qn = rstd * (m2 - mean * m1);          // mean(g * n)
+    const double k0 = rstd * A;
+    float* o = coef + ((int64_t)b * C + c) * 4;
+    o[0] = (float)k0;
+    o[1] = (float)(-k0 * rstd * qn);
+    o[2] = (float)(k0 * (mean * rstd * qn - m1));
+    o[3] = 0.f;
+    if (dstyle) {
+      dstyle[(int64_t)b * 2 * C + c] = (float)(qn * count);
+      dstyle[(int64_t)b * 2 * C + C + c] = (float)s;
+    }
+  }
+}
+extern "C" int ppst_in_bwd_finalize(const void* partial, int n_partials, const void* mean_rstd, const void* style, int style_ld,
+                                    void* coef, void* dstyle, int B, int C, double count, void* stream) {
+  if (B < 0 || C <= 0 || n_partials <= 0 || count <= 0 || (style && style_ld < C)) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!partial || (mean_rstd && !coef) || (!mean_rstd && !dstyle)) return PPST_ENULL;
+  PPST_LAUNCH(in_bwd_finalize_kernel, dim3(B * cdiv(C, 32)), dim3(256), 0, as_stream(stream), (const float*)partial, n_partials,
+              (const float*)mean_rstd, (const float*)style, style_ld, (float*)coef, (float*)dstyle, B, C, count);
+  return PPST_LAUNCH_CHECK();
+}
+
+// Pass 3: dx = post * (k0 * g' + k1 * y + k2);  g' = g * lrelu'(gate) if gate (norm before activation);
+// post = lrelu'(y) if post_gate (StyledConv: the activation precedes the norm, so y is its output) else 1.
+__global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                           const float* __restrict__ gate, const float* __restrict__ coef,
+                                                           float* __restrict__ dx, unsigned hw, int C, int g_ld, int y_ld, int gate_ld,
+                                                           int dx_ld, int post_gate, unsigned total, FastDiv d_c, FastDiv d_hw) {
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned cq;
+    const unsigned bpu = fd_divmod((unsigned)t64, d_c, cq);
+    const int c = (int)cq;
+    const int b = (int)fd_div(bpu, d_hw);
+    const int64_t bp = bpu;
+    const float* k = coef + ((int64_t)b * C + c) * 4;
+    float gv = g[bp * g_ld + c];
+    const float yv = y[bp * y_ld + c];
+    if (gate) gv *= lrelu_gate(gate[bp * gate_ld + c]);
+    float o = k[0] * gv + k[1] * yv + k[2];
+    if (post_gate) o *= lrelu_gate(yv);
+    dx[bp * dx_ld + c] = o;
+  }
+}
+extern "C" int ppst_in_bwd_apply(const void* g, const void* y, const void* gate, const void* coef, void* dx, int B, int64_t hw, int C,
+                                 int g_ld, int y_ld, int gate_ld, int dx_ld, int post_gate, void* stream) {
+  if (B < 0 || hw <= 0 || C <= 0 || g_ld < C || y_ld < C || dx_ld < C || (gate && gate_ld < C)) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!g || !y || !coef || !dx) return PPST_ENULL;
+  const int64_t total = (int64_t)B * hw * C;
+  if (total > PPST_IDX32_MAX) return PPST_EINVAL;
+  PPST_LAUNCH(in_bwd_apply_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)g, (const float*)y,
+              (const float*)gate, (const float*)coef, (float*)dx, (unsigned)hw, C, g_ld, y_ld, gate_ld, dx_ld, post_gate,
+              (unsigned)total, make_fastdiv((unsigned)C), make_fastdiv((unsigned)hw));
+  return PPST_LAUNCH_CHECK();
+}
+
+// PReLU (single slope, nn.PReLU()) applied to a normalised tensor: out = prelu(a*y + s) (feature heads,
+// generator.py:10-32,174-238).  Given g = dL/dout: gpre = g * (z >= 0 ? 1 : slope), z = a*y + s;
+// dslope partial = sum g * z * [z < 0].  Writes gpre and per-block partial sums of dslope.
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                        const float* __restrict__ ss, const float* __restrict__ res,
+                                                        const float* __restrict__ prelu, float* __restrict__ gpre,
+                                                        float* __restrict__ dslope_partial, unsigned hw, int C, int g_ld, int y_ld,
+                                                        int res_ld, unsigned total, FastDiv d_c, FastDiv d_hw) {
+  __shared__ float red[4];
+  const float slope = prelu[0];
+  float acc = 0.f;
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned cq;
+    const unsigned bpu = fd_divmod((unsigned)t64, d_c, cq);
+    const int c = (int)cq;
+    const int b = (int)fd_div(bpu, d_hw);
+    const int64_t bp = bpu;
+    float z = y[bp * y_ld + c];
+    if (ss) z = ss[((int64_t)b * C + c) * 2] * z + ss[((int64_t)b * C + c) * 2 + 1];
+    if (res) z += res[bp * res_ld + c];       // residual joins before the activation (ResidualBlock, generator.py:28-31)
+    const float gv = g[bp * g_ld + c];
+    gpre[bp * C + c] = z >= 0.f ? gv : gv * slope;
+    if (z < 0.f) acc += gv * z;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) dslope_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+extern "C" int64_t ppst_prelu_bwd_ws(int64_t total) { return (int64_t)tg_grid(total) * (int64_t)sizeof(float); }
+extern "C" int ppst_prelu_bwd(const void* g, const void* y, const void* scale_shift, const void* res, const void* prelu, void* gpre,
+                              void* ws, int B, int64_t hw, int C, int g_ld, int y_ld, int res_ld, void* stream) {
+  if (B < 0 || hw <= 0 || C <= 0 || g_ld < C || y_ld < C || (res && res_ld < C)) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!g || !y || !prelu || !gpre || !ws) return PPST_ENULL;
+  const int64_t total = (int64_t)B * hw * C;
+  if (total > PPST_IDX32_MAX) return PPST_EINVAL;
+  PPST_LAUNCH(prelu_bwd_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)g, (const float*)y,
+              (const float*)scale_shift, (const float*)res, (const float*)prelu, (float*)gpre, (float*)ws, (unsigned)hw, C, g_ld,
+              y_ld, res_ld, (unsigned)total, make_fastdiv((unsigned)C), make_fastdiv((unsigned)hw));
+  return PPST_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------ padding --
+__device__ __forceinline__ int pad_src(int t, int n, int mode) {   // padded coordinate (origin at the unpadded tensor) -> source
+  if (t >= 0 && t < n) return t;
+  if (mode == PPST_PAD_ZERO) return -1;
+  if (mode == PPST_PAD_REFLECT) {
+    if (t < 0) t = -t;
+    if (t >= n) t = 2 * (n - 1) - t;
+    return (t >= 0 && t < n) ? t : -1;
+  }
+  return t < 0 ? 0 : n - 1;
+}
+// y[b][ty][tx][c] = x[b][src(ty - py0)][src(tx - px0)][c]  (F.pad zero / reflect / replicate)
+__global__ __launch_bounds__(256) void pad2d_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int x_ld,
+                                                    int OH, int OW, int py0, int px0, int mode, unsigned total, FastDiv d_c,
+                                                    FastDiv d_ow, FastDiv d_oh) {
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned c, tx, ty;
+    unsigned r = fd_divmod((unsigned)t64, d_c, c);
+    r = fd_divmod(r, d_ow, tx);
+    const unsigned b = fd_divmod(r, d_oh, ty);
+    const int sy = pad_src((int)ty - py0, H, mode), sx = pad_src((int)tx - px0, W, mode);
+    float v = 0.f;
+    if (sy >= 0 && sx >= 0) v = x[(((int64_t)b * H + sy) * W + sx) * x_ld + c];
+    y[t64] = v;
+  }
+}
+extern "C" int ppst_pad2d(const void* x, void* y, int B, int H, int W, int C, int x_ld, int py0, int py1, int px0, int px1, int mode,
+                          void* stream) {
+  const int OH = H + py0 + py1, OW = W + px0 + px1;
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || x_ld < C || OH <= 0 || OW <= 0 || mode < 0 || mode > 2) return PPST_EINVAL;
+  if (mode == PPST_PAD_REFLECT && (py0 >= H || py1 >= H || px0 >= W || px1 >= W)) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !y) return PPST_ENULL;
+  const int64_t total = (int64_t)B * OH * OW * C;
+  if (total > PPST_IDX32_MAX) return PPST_EINVAL;
+  PPST_LAUNCH(pad2d_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, H, W, C, x_ld, OH, OW,
+              py0, px0, mode, (unsigned)total, make_fastdiv((unsigned)C), make_fastdiv((unsigned)OW), make_fastdiv((unsigned)OH));
+  return PPST_LAUNCH_CHECK();
+}
+// adjoint of ppst_pad2d: dx[b][y][x][c] = sum of dy over every padded position whose source is (y, x).
+// Candidates per axis: the interior copy plus the (py0 + py1) border positions -- tested, not enumerated in closed form.
+__global__ __launch_bounds__(256) void pad2d_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int C,
+                                                        int OH, int OW, int py0, int py1, int px0, int px1, int mode, unsigned total,
+                                                        FastDiv d_c, FastDiv d_w, FastDiv d_h) {
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned c, xx, yy;
+    unsigned r = fd_divmod((unsigned)t64, d_c, c);
+    r = fd_divmod(r, d_w, xx);
+    const unsigned b = fd_divmod(r, d_h, yy);
+    const float* base = dy + (int64_t)b * OH * OW * C + c;
+    float acc = 0.f;
+    const int ny = 1 + (py0 > 0 ? py0 : 0) + (py1 > 0 ? py1 : 0), nx = 1 + (px0 > 0 ? px0 : 0) + (px1 > 0 ? px1 : 0);
+    for (int iy = 0; iy < ny; ++iy) {
+      // candidate padded row (coordinates relative to the unpadded origin): itself, the top border rows, the bottom ones
+      int ty = iy == 0 ? (int)yy : (iy <= (py0 > 0 ? py0 : 0) ? -iy : H - 1 + (iy - (py0 > 0 ? py0 : 0)));
+      if (ty + py0 < 0 || ty + py0 >= OH) continue;       // cropped away (negative pad)
+      if (pad_src(ty, H, mode) != (int)yy) continue;
+      for (int ix = 0; ix < nx; ++ix) {
+        int tx = ix == 0 ? (int)xx : (ix <= (px0 > 0 ? px0 : 0) ? -ix : W - 1 + (ix - (px0 > 0 ? px0 : 0)));
+        if (tx + px0 < 0 || tx + px0 >= OW) continue;
+        if (pad_src(tx, W, mode) != (int)xx) continue;
+        acc += base[((int64_t)(ty + py0) * OW + (tx + px0)) * C];
+      }
+    }
+    dx[t64] = acc;
+  }
+}
+extern "C" int ppst_pad2d_bwd(const void* dy, void* dx, int B, int H, int W, int C, int py0, int py1, int px0, int px1, int mode,
+                              void* stream) {
+  const int OH = H + py0 + py1, OW = W + px0 + px1;
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || mode < 0 || mode > 2) return PPST_EINVAL;
+  if (mode == PPST_PAD_REFLECT && (py0 >= H || py1 >= H || px0 >= W || px1 >= W)) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!dy || !dx) return PPST_ENULL;
+  const int64_t total = (int64_t)B * H * W * C;
+  if (total > PPST_IDX32_MAX || (int64_t)B * OH * OW * C > PPST_IDX32_MAX) return PPST_EINVAL;
+  PPST_LAUNCH(pad2d_bwd_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)dy, (float*)dx, H, W, C, OH, OW,
+              py0, py1, px0, px1, mode, (unsigned)total, make_fastdiv((unsigned)C), make_fastdiv((unsigned)W),
+              make_fastdiv((unsigned)H));
+  return PPST_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------- resize / pooling adjoints --
+// adjoint of ppst_bilinear (F.interpolate bilinear, align_corners=False): dx (zero-initialised by the caller)
+// += weights * dy.  Scatter with float atomics (memory-side adds on gfx950; two contributions commute).
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int C,
+                                                           int OH, int OW, int dy_ld, int dx_ld, float sy, float sx, unsigned total,
+                                                           FastDiv d_c, FastDiv d_ow, FastDiv d_oh) {
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned c, ox, oy;
+    unsigned r = fd_divmod((unsigned)t64, d_c, c);
+    r = fd_divmod(r, d_ow, ox);
+    const unsigned b = fd_divmod(r, d_oh, oy);
+    const float fy = fmaxf(((float)oy + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf(((float)ox + 0.5f) * sx - 0.5f, 0.f);
+    const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
+    const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float gv = dy[(((int64_t)b * OH + oy) * OW + ox) * dy_ld + c];
+    float* base = dx + (int64_t)b * H * W * dx_ld + c;
+    atomicAdd(base + ((int64_t)y0 * W + x0) * dx_ld, hy * hx * gv);
+    atomicAdd(base + ((int64_t)y0 * W + x1) * dx_ld, hy * lx * gv);
+    atomicAdd(base + ((int64_t)y1 * W + x0) * dx_ld, ly * hx * gv);
+    atomicAdd(base + ((int64_t)y1 * W + x1) * dx_ld, ly * lx * gv);
+  }
+}
+extern "C" int ppst_bilinear_bwd(const void* dy, void* dx, int B, int H, int W, int C, int dx_ld, int OH, int OW, int dy_ld,
+                                 void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || dx_ld < C || dy_ld < C) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!dy || !dx) return PPST_ENULL;
+  const int64_t total = (int64_t)B * OH * OW * C;
+  if (total > PPST_IDX32_MAX) return PPST_EINVAL;
+  PPST_LAUNCH(bilinear_bwd_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)dy, (float*)dx, H, W, C, OH, OW,
+              dy_ld, dx_ld, (float)H / (float)OH, (float)W / (float)OW, (unsigned)total, make_fastdiv((unsigned)C),
+              make_fastdiv((unsigned)OW), make_fastdiv((unsigned)OH));
+  return PPST_LAUNCH_CHECK();
+}
+
+// adjoint of ppst_avgpool (adaptive_avg_pool2d with an integer factor f): dx[y][x] = dy[y/f][x/f] / f^2
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int C,
+                                                          int f, int dy_ld, int dx_ld, unsigned total, FastDiv d_c, FastDiv d_w,
+                                                          FastDiv d_h, FastDiv d_f) {
+  const float inv = 1.f / (float)(f * f);
+  const int oh = H / f, ow = W / f;
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned c, xx, yy;
+    unsigned r = fd_divmod((unsigned)t64, d_c, c);
+    r = fd_divmod(r, d_w, xx);
+    const unsigned b = fd_divmod(r, d_h, yy);
+    const unsigned oy = fd_div(yy, d_f), ox = fd_div(xx, d_f);
+    dx[(((int64_t)b * H + yy) * W + xx) * dx_ld + c] = dy[(((int64_t)b * oh + oy) * ow + ox) * dy_ld + c] * inv;
+  }
+}
+extern "C" int ppst_avgpool_bwd(const void* dy, void* dx, int B, int H, int W, int C, int dx_ld, int f, int dy_ld, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || f <= 0 || H % f || W % f || dx_ld < C || dy_ld < C) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!dy || !dx) return PPST_ENULL;
+  const int64_t total = (int64_t)B * H * W * C;
+  if (total > PPST_IDX32_MAX) return PPST_EINVAL;
+  PPST_LAUNCH(avgpool_bwd_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)dy, (float*)dx, H, W, C, f, dy_ld,
+              dx_ld, (unsigned)total, make_fastdiv((unsigned)C), make_fastdiv((unsigned)W), make_fastdiv((unsigned)H),
+              make_fastdiv((unsigned)f));
+  return PPST_LAUNCH_CHECK();
+}
+
+// adjoint of ppst_gap_gmp: v = cat(mean_p(m*x), max_p(m*x));  dx[p][c] = m[p] * (g_mean[c] / P + g_max[c] * [m*x == vmax[c]])
+// (accumulate != 0: dx += ...; several heads pool the same feature map, encoder_col.py:162-245)
+__global__ __launch_bounds__(256) void gap_gmp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                          const float* __restrict__ v, const float* __restrict__ g,
+                                                          float* __restrict__ dx, unsigned hw, int C, int ld, int accumulate,
+                                                          unsigned total, FastDiv d_c, FastDiv d_hw) {
+  const float invP = 1.f / (float)hw;
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned c;
+    const unsigned bpu = fd_divmod((unsigned)t64, d_c, c);
+    const unsigned b = fd_div(bpu, d_hw);
+    const float m = mask ? mask[bpu] : 1.f;
+    const float xv = x[(int64_t)bpu * ld + c] * m;
+    const float vmax = v[(int64_t)b * 2 * C + C + c];
+    float o = m * (g[(int64_t)b * 2 * C + c] * invP + (xv == vmax ? g[(int64_t)b * 2 * C + C + c] : 0.f));
+    float* d = dx + (int64_t)bpu * C + c;
+    *d = accumulate ? *d + o : o;
+  }
+}
+extern "C" int ppst_gap_gmp_bwd(const void* x, const void* mask, const void* v, const void* g, void* dx, int B, int64_t hw, int C,
+                                int ld, int accumulate, void* stream) {
+  if (B < 0 || hw <= 0 || C <= 0 || ld < C) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !v || !g || !dx) return PPST_ENULL;
+  const int64_t total = (int64_t)B * hw * C;
+  if (total > PPST_IDX32_MAX) return PPST_EINVAL;
+  PPST_LAUNCH(gap_gmp_bwd_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)mask,
+              (const float*)v, (const float*)g, (float*)dx, (unsigned)hw, C, ld, accumulate, (unsigned)total,
+              make_fastdiv((unsigned)C), make_fastdiv((unsigned)hw));
+  return PPST_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------ row-wise ops ----
+// y = x * s, s = rsqrt(sum x^2 + eps) (mode 0, util.normalize) or 1 / max(||x||, eps) (mode 1, F.normalize):
+// dx = s * (g - y * sum(g*y))   (mode 1 with ||x|| < eps: dx = g / eps)
+__global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                              float* __restrict__ dx, int K, float eps, int mode) {
+  __shared__ float red[2][4];
+  const float* xr = x + (int64_t)blockIdx.x * K;
+  const float* gr = g + (int64_t)blockIdx.x * K;
+  float ss = 0.f, gx = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) { ss += xr[k] * xr[k]; gx += gr[k] * xr[k]; }
+  ss = wave_sum(ss); gx = wave_sum(gx);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ss; red[1][threadIdx.x >> 6] = gx; }
+  __syncthreads();
+  ss = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  gx = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  float s, proj;
+  if (mode == 0) { s = rsqrtf(ss + eps); proj = s * s * s * gx; }
+  else {
+    const float nrm = sqrtf(ss);
+    if (nrm < eps) { s = 1.f / eps; proj = 0.f; } else { s = 1.f / nrm; proj = s * s * s * gx; }
+  }
+  for (int k = threadIdx.x; k < K; k += 256) dx[(int64_t)blockIdx.x * K + k] = s * gr[k] - proj * xr[k];
+}
+extern "C" int ppst_l2norm_rows_bwd(const void* g, const void* x, void* dx, int B, int K, float eps, int mode, void* stream) {
+  if (B < 0 || K <= 0 || mode < 0 || mode > 1) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!g || !x || !dx) return PPST_ENULL;
+  PPST_LAUNCH(l2norm_rows_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), (const float*)g, (const float*)x, (float*)dx, K, eps, mode);
+  return PPST_LAUNCH_CHECK();
+}
+
+// softmax(x / div) backward, in place on g: g <- p * (g - sum(g*p)) / div   (rows of the correspondence matrix)
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ p, float* __restrict__ g, int cols, float inv_div) {
+  __shared__ float red[4];
+  const float* pr = p + (int64_t)blockIdx.x * cols;
+  float* gr = g + (int64_t)blockIdx.x * cols;
+  float d = 0.f;
+  for (int k = threadIdx.x; k < cols; k += 256) d += pr[k] * gr[k];
+  d = wave_sum(d);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+  __syncthreads();
+  d = red[0] + red[1] + red[2] + red[3];
+  for (int k = threadIdx.x; k < cols; k += 256) gr[k] = pr[k] * (gr[k] - d) * inv_div;
+}
+extern "C" int ppst_softmax_rows_bwd(const void* p, void* g, int64_t rows, int cols, float div, void* stream) {
+  if (rows < 0 || cols <= 0 || div == 0.f || rows > 0x7fffffffll) return PPST_EINVAL;
+  if (rows == 0) return PPST_OK;
+  if (!p || !g) return PPST_ENULL;
+  PPST_LAUNCH(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, as_stream(stream), (const float*)p, (float*)g, cols, 1.f / div);
+  return PPST_LAUNCH_CHECK();
+}
+
+// correspondence feature preparation backward (ppst_model.py:343-356): per row (pixel) x (C values)
+//   z = x with the first `ncenter` channels mean-centred over those channels;  y = z / (||z||_2 + eps)
+// dz = (g - y * sum(g*y)) / (||z|| + eps);  dx = dz with the first ncenter entries re-centred.
+__global__ __launch_bounds__(256) void corr_prep_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                            float* __restrict__ dx, int64_t rows, int C, int ncenter, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * C;
+  const float* gr = g + row * C;
+  float m = 0.f;
+  for (int k = lane; k < ncenter; k += 64) m += xr[k];
+  m = ncenter > 0 ? wave_sum(m) / (float)ncenter : 0.f;
+  float ss = 0.f, gz = 0.f;
+  for (int k = lane; k < C; k += 64) {
+    const float z = xr[k] - (k < ncenter ? m : 0.f);
+    ss += z * z;
+    gz += gr[k] * z;
+  }
+  ss = wave_sum(ss); gz = wave_sum(gz);
+  const float nrm = sqrtf(ss), inv = 1.f / (nrm + eps);
+  // y = z*inv;  d||z||/dz = z/||z||  ->  dz = inv*g - inv^2 * (g.z) * z/||z||
+  const float k2 = nrm > 0.f ? inv * inv * gz / nrm : 0.f;
+  float dsum = 0.f;
+  for (int k = lane; k < ncenter; k += 64) dsum += inv * gr[k] - k2 * (xr[k] - m);
+  dsum = ncenter > 0 ? wave_sum(dsum) / (float)ncenter : 0.f;
+  for (int k = lane; k < C; k += 64) {
+    const float z = xr[k] - (k < ncenter ? m : 0.f);
+    dx[row * C + k] = inv * gr[k] - k2 * z - (k < ncenter ? dsum : 0.f);
+  }
+}
+extern "C" int ppst_corr_prep_bwd(const void* g, const void* x, void* dx, int64_t rows, int C, int ncenter, float eps, void* stream) {
+  if (rows < 0 || C <= 0 || ncenter < 0 || ncenter > C) return PPST_EINVAL;
+  if (rows == 0) return PPST_OK;
+  if (!g || !x || !dx) return PPST_ENULL;
+  PPST_LAUNCH(corr_prep_bwd_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, as_stream(stream), (const float*)g, (const float*)x,
+              (float*)dx, rows, C, ncenter, eps);
+  return PPST_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------- losses ---
+// d(weight * mean|a - b|)/da = weight / n * sign(a - b)   (torch: sign(0) = 0)
+__global__ __launch_bounds__(256) void l1_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ da,
+                                                      int64_t n, float w) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float d = a[i] - b[i];
+    da[i] = d > 0.f ? w : (d < 0.f ? -w : 0.f);
+  }
+}
+extern "C" int ppst_l1_grad(const void* a, const void* b, void* da, int64_t n, float weight, void* stream) {
+  if (n < 0) return PPST_EINVAL;
+  if (n == 0) return PPST_OK;
+  if (!a || !b || !da) return PPST_ENULL;
+  PPST_LAUNCH(l1_grad_kernel, dim3(tg_grid(n)), dim3(256), 0, as_stream(stream), (const float*)a, (const float*)b, (float*)da, n,
+              weight / (float)n);
+  return PPST_LAUNCH_CHECK();
+}
+
+// NoiseInjection weight gradient (stylegan2_layers.py:376-399): d/dw sum over (b,p,c) of dpre[b][p][c] * noise[b][p]
+__global__ __launch_bounds__(256) void noise_wgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ noise,
+                                                          float* __restrict__ partial, int64_t npix, int C, int ld) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  // one wave per pixel at a time: lanes stride the channels (coalesced), then the pixel's noise value multiplies the row sum
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int64_t p = (int64_t)blockIdx.x * 4 + wave; p < npix; p += (int64_t)gridDim.x * 4) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += dpre[p * ld + c];
+    acc += s * noise[p];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int n, float scale) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) * scale;
+}
+extern "C" int64_t ppst_noise_wgrad_ws(int64_t npix) {
+  int64_t b = cdiv64(npix, 4);
+  if (b > 2048) b = 2048;
+  return (b < 1 ? 1 : b) * (int64_t)sizeof(float);
+}
+extern "C" int ppst_noise_wgrad(const void* dpre, const void* noise, void* out, void* ws, int64_t npix, int C, int ld, void* stream) {
+  if (npix < 0 || C <= 0 || ld < C) return PPST_EINVAL;
+  if (!out) return PPST_ENULL;
+  if (npix == 0) return (int)hipMemsetAsync(out, 0, sizeof(float), as_stream(stream));
+  if (!dpre || !noise || !ws) return PPST_ENULL;
+  const int blocks = (int)(ppst_noise_wgrad_ws(npix) / (int64_t)sizeof(float));
+  PPST_LAUNCH(noise_wgrad_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)dpre, (const float*)noise, (float*)ws,
+              npix, C, ld);
+  PPST_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const float*)ws, (float*)out, blocks, 1.f);
+  return PPST_LAUNCH_CHECK();
+}
+// sum of a small float vector times scale -> out[0] (PReLU slope gradient from ppst_prelu_bwd's partials)
+extern "C" int ppst_sum_partials(const void* partial, void* out, int n, float scale, void* stream) {
+  if (n <= 0) return PPST_EINVAL;
+  if (!partial || !out) return PPST_ENULL;
+  PPST_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const float*)partial, (float*)out, n, scale);
+  return PPST_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------- weight-space adjoint --
+// adjoint of ppst_upscale_weight: w4[c][n][ky][kx] = scale * (w[n][c][ky][kx] + w[ky-1][kx] + w[ky][kx-1] + w[ky-1][kx-1])
+// -> dw[n][c][y][x] = scale * (dw4[c][n][y][x] + dw4[y+1][x] + dw4[y][x+1] + dw4[y+1][x+1])
+__global__ __launch_bounds__(256) void upscale_weight_bwd_kernel(const float* __restrict__ dw4, float* __restrict__ dw, int cout, int cin,
+                                                                 float scale, int64_t total) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int xk = (int)(t % 3), yk = (int)((t / 3) % 3);
+    const int64_t r = t / 9;
+    const int c = (int)(r % cin), n = (int)(r / cin);
+    const float* p = dw4 + ((int64_t)c * cout + n) * 16;
+    dw[t] = scale * (p[yk * 4 + xk] + p[(yk + 1) * 4 + xk] + p[yk * 4 + xk + 1] + p[(yk + 1) * 4 + xk + 1]);
+  }
+}
+extern "C" int ppst_upscale_weight_bwd(const void* dw4, void* dw, int cout, int cin, float scale, void* stream) {
+  if (cout <= 0 || cin <= 0) return PPST_EINVAL;
+  if (!dw4 || !dw) return PPST_ENULL;
+  const int64_t total = (int64_t)cout * cin * 9;
+  PPST_LAUNCH(upscale_weight_bwd_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)dw4, (float*)dw, cout, cin,
+              scale, total);
+  return PPST_LAUNCH_CHECK();
+}
+
+// space-to-depth copy: x [B][H][W][C] -> y [B][ceil(H/2)][ceil(W/2)][4C], channel block (py*2+px)*C (zeros beyond the edge):
+// the layout the stride-2 step tables read (input gradient of the fused transposed conv = a stride-2 4x4 conv of dY)
+__global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int x_ld,
+                                                  int H2, int W2, unsigned total, FastDiv d_c, FastDiv d_4, FastDiv d_w2, FastDiv d_h2) {
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned c, ph, qx, qy;
+    unsigned r = fd_divmod((unsigned)t64, d_c, c);
+    r = fd_divmod(r, d_4, ph);
+    r = fd_divmod(r, d_w2, qx);
+    const unsigned b = fd_divmod(r, d_h2, qy);
+    const int iy = (int)qy * 2 + (int)(ph >> 1), ix = (int)qx * 2 + (int)(ph & 1);
+    y[t64] = (iy < H && ix < W) ? x[(((int64_t)b * H + iy) * W + ix) * x_ld + c] : 0.f;
+  }
+}
+extern "C" int ppst_space_to_depth(const void* x, void* y, int B, int H, int W, int C, int x_ld, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || x_ld < C) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !y) return PPST_ENULL;
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  const int64_t total = (int64_t)B * H2 * W2 * 4 * C;
+  if (total > PPST_IDX32_MAX) return PPST_EINVAL;
+  PPST_LAUNCH(s2d_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, H, W, C, x_ld, H2, W2,
+              (unsigned)total, make_fastdiv((unsigned)C), make_fastdiv(4u), make_fastdiv((unsigned)W2), make_fastdiv((unsigned)H2));
+  return PPST_LAUNCH_CHECK();
+}
+
+// y = x * s[0] (s on the device): chain rule through a scalar loss without a host round trip
+__global__ __launch_bounds__(256) void scale_by_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ y,
+                                                       int64_t n) {
+  const float f = s[0];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = x[i] * f;
+}
+extern "C" int ppst_scale_by(const void* x, const void* s, void* y, int64_t n, void* stream) {
+  if (n < 0) return PPST_EINVAL;
+  if (n == 0) return PPST_OK;
+  if (!x || !s || !y) return PPST_ENULL;
+  PPST_LAUNCH(scale_by_kernel, dim3(tg_grid(n)), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)s, (float*)y, n);
+  return PPST_LAUNCH_CHECK();
+}

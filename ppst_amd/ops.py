@@ -251,6 +251,32 @@ class ConvPlan:
             self.cout, self.cin = cin, cout
             cout, cin = cin, cout
             self.bn = 128 if cout >= 128 else 64
+        elif kind == "dgradT":
+            # input gradient of the fused 4x4 stride-2 transposed conv (kind 'convT'): a stride-2 4x4 conv (pad 1) of
+            # dY, run over the space-to-depth copy of dY:  oy = 2*iy - 1 + ky  ->  (dq, phase, ky) per axis in
+            # {(-1,1,0), (0,0,1), (0,1,2), (+1,0,3)}.  ``weight`` is the FORWARD (Cout,Cin,3,3) parameter.
+            assert k == 3 and cout % 32 == 0
+            self.n_groups = 1
+            self.halo = 1
+            wsrc = torch.empty((cin, cout, 4, 4), device=w.device, dtype=torch.float32)
+            check(lib.ppst_upscale_weight(_p(w), _p(wsrc), cout, cin, float(scale), _stream()), "ppst_upscale_weight")
+            self.fwd_scale = float(scale)
+            scale = 1.0
+            taps = {0: [(0, 1), (1, 3)], 1: [(-1, 0), (0, 2)]}
+            for py in range(2):
+                for px in range(2):
+                    for c in range(cout // 32):
+                        first = True
+                        for dqy, ky in taps[py]:
+                            for dqx, kx in taps[px]:
+                                steps.append(((py * 2 + px) * cout + 32 * c, dqy, dqx, 1 if first else 0))
+                                src.append((32 * c, ky, kx))
+                                first = False
+            sn, sc, sy, sx = cout * 16, 16, 4, 1      # w4[c][n][ky][kx]: output channel = c, reduction = n
+            self.w4_shape = (cin, cout, 4, 4)
+            self.cout, self.cin = cin, cout
+            cout, cin = cin, cout
+            self.bn = 128 if cout >= 128 else 64
         else:
             raise ValueError(kind)
         self.src = src
@@ -355,7 +381,7 @@ def conv_wgrad(plan, x, dy, splits=None):
     x = the tensor the forward conv read (NHWC, or the space-to-depth tensor for 's2d'),
     dy = gradient w.r.t. the conv output (before bias/activation).  Returns dW shaped
     (Cout, Cin, k, k), already multiplied by the plan's weight scale (EqualConv2d)."""
-    assert plan.kind in ("conv", "s2d")
+    assert plan.kind in ("conv", "s2d", "dgradT")
     in_ld = _nhwc_ld(x, "x")
     dy_ld = _nhwc_ld(dy, "dy")
     B, H, W, _ = x.shape
@@ -368,7 +394,9 @@ def conv_wgrad(plan, x, dy, splits=None):
     partial = torch.empty((splits, plan.nsteps, cout, 32), device=x.device, dtype=torch.float32)
     check(lib.ppst_conv_wgrad_f32(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), B, H, W, in_ld, oh, ow, dy_ld,
                                   cout, plan.nsteps, nchunks, splits, _stream()), "ppst_conv_wgrad_f32")
-    dw = torch.zeros((plan.cout, plan.cin, plan.k, plan.k), device=x.device, dtype=torch.float32)
+    # 'dgradT': the plan's "weights" are the blurred 4x4 kernel (Cin,Cout,4,4) of the transposed conv
+    shape = plan.w4_shape if plan.kind == "dgradT" else (plan.cout, plan.cin, plan.k, plan.k)
+    dw = torch.zeros(shape, device=x.device, dtype=torch.float32)
     sn, sc, sy, sx = plan.wstrides
     c_, ky_, kx_ = plan.src_dev
     check(lib.ppst_wgrad_scatter(_p(partial), _p(c_), _p(ky_), _p(kx_), _p(dw), sn, sc, sy, sx, cout, plan.nsteps, splits,
@@ -487,6 +515,22 @@ def conv1x1_small_cout(x, w, bias, wscale):
     return y
 
 
+def upscale_weight_bwd(dw4, cout, cin, scale=1.0):
+    """adjoint of the fused-upscale weight blur (stylegan2_layers.py:314-319): dw4 (Cin,Cout,4,4) -> (Cout,Cin,3,3)."""
+    _chk(dw4)
+    dw = torch.empty((cout, cin, 3, 3), device=dw4.device, dtype=torch.float32)
+    check(lib.ppst_upscale_weight_bwd(_p(dw4.contiguous()), _p(dw), cout, cin, float(scale), _stream()), "ppst_upscale_weight_bwd")
+    return dw
+
+
+def space_to_depth(x):
+    ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    y = torch.empty((B, (H + 1) // 2, (W + 1) // 2, 4 * C), device=x.device, dtype=torch.float32)
+    check(lib.ppst_space_to_depth(_p(x), _p(y), B, H, W, C, ld, _stream()), "ppst_space_to_depth")
+    return y
+
+
 # ------------------------------------------------- instance norm / affine ----
 def in_stats(x, rep_pad=False):
     ld = _nhwc_ld(x)
@@ -513,6 +557,179 @@ def in_finalize(partial, count, style=None, post_bias=None, eps=1e-5):
     check(lib.ppst_in_finalize(_p(partial), n, _p(style), style_ld, _p(post_bias), _p(ss), B, C, float(count), float(eps),
                                _stream()), "ppst_in_finalize")
     return ss
+
+
+def in_finalize_train(partial, count, style=None, post_bias=None, eps=1e-5):
+    """in_finalize that also returns mean_rstd (B, C, 2) for the backward of the norm."""
+    _chk(partial); _chk(style, "style"); _chk(post_bias, "post_bias")
+    B, n, C, _ = partial.shape
+    style_ld = 0
+    if style is not None:
+        assert style.shape == (B, 2 * C) and style.stride(1) == 1
+        style_ld = style.stride(0) if B > 1 else max(style.stride(0), 2 * C)
+    ss = torch.empty((B, C, 2), device=partial.device, dtype=torch.float32)
+    mr = torch.empty((B, C, 2), device=partial.device, dtype=torch.float32)
+    check(lib.ppst_in_finalize_train(_p(partial), n, _p(style), style_ld, _p(post_bias), _p(ss), _p(mr), B, C, float(count), float(eps),
+                                     _stream()), "ppst_in_finalize_train")
+    return ss, mr
+
+
+def dual_stats(g, y, gate=None):
+    """per-(b, c) partial sums (sum g', sum g'*y), g' = g * lrelu'(gate) when gate is given."""
+    g_ld, y_ld = _nhwc_ld(g, "g"), _nhwc_ld(y, "y")
+    gate_ld = _nhwc_ld(gate, "gate") if gate is not None else 0
+    B, H, W, C = g.shape
+    assert y.shape == g.shape
+    n = ctypes.c_int(0)
+    check(lib.ppst_dual_stats(None, None, None, None, B, H * W, C, g_ld, y_ld, gate_ld, ctypes.byref(n), None), "ppst_dual_stats(size)")
+    part = torch.empty((B, n.value, C, 2), device=g.device, dtype=torch.float32)
+    check(lib.ppst_dual_stats(_p(g), _p(y), _p(gate), _p(part), B, H * W, C, g_ld, y_ld, gate_ld, ctypes.byref(n), _stream()),
+          "ppst_dual_stats")
+    return part
+
+
+def in_bwd_finalize(partial, count, mean_rstd=None, style=None, want_dstyle=False):
+    """-> (coef (B,C,4) or None, dstyle (B,2C) or None); see ppst_in_bwd_finalize."""
+    _chk(partial); _chk(mean_rstd); _chk(style)
+    B, n, C, _ = partial.shape
+    style_ld = 0
+    if style is not None:
+        assert style.shape[0] == B and style.shape[1] >= C and style.stride(1) == 1
+        style_ld = style.stride(0) if B > 1 else max(style.stride(0), C)
+    coef = torch.empty((B, C, 4), device=partial.device, dtype=torch.float32) if mean_rstd is not None else None
+    dstyle = torch.empty((B, 2 * C), device=partial.device, dtype=torch.float32) if (want_dstyle or mean_rstd is None) else None
+    check(lib.ppst_in_bwd_finalize(_p(partial), n, _p(mean_rstd), _p(style), style_ld, _p(coef), _p(dstyle), B, C, float(count),
+                                   _stream()), "ppst_in_bwd_finalize")
+    return coef, dstyle
+
+
+def in_bwd_apply(g, y, coef, gate=None, post_gate=False):
+    g_ld, y_ld = _nhwc_ld(g, "g"), _nhwc_ld(y, "y")
+    gate_ld = _nhwc_ld(gate, "gate") if gate is not None else 0
+    B, H, W, C = g.shape
+    dx = torch.empty((B, H, W, C), device=g.device, dtype=torch.float32)
+    check(lib.ppst_in_bwd_apply(_p(g), _p(y), _p(gate), _p(coef), _p(dx), B, H * W, C, g_ld, y_ld, gate_ld, C, 1 if post_gate else 0,
+                                _stream()), "ppst_in_bwd_apply")
+    return dx
+
+
+def prelu_bwd(g, y, prelu, scale_shift=None, res=None):
+    """z = a*y + s [+ res]; returns (g * prelu'(z) dense, dslope (1,))."""
+    g_ld, y_ld = _nhwc_ld(g, "g"), _nhwc_ld(y, "y")
+    res_ld = _nhwc_ld(res, "res") if res is not None else 0
+    _chk(prelu); _chk(scale_shift)
+    B, H, W, C = g.shape
+    total = B * H * W * C
+    ws = torch.empty(lib.ppst_prelu_bwd_ws(total) // 4, device=g.device, dtype=torch.float32)
+    gpre = torch.empty((B, H, W, C), device=g.device, dtype=torch.float32)
+    check(lib.ppst_prelu_bwd(_p(g), _p(y), _p(scale_shift), _p(res), _p(prelu), _p(gpre), _p(ws), B, H * W, C, g_ld, y_ld, res_ld,
+                             _stream()), "ppst_prelu_bwd")
+    ds = torch.empty((1,), device=g.device, dtype=torch.float32)
+    check(lib.ppst_sum_partials(_p(ws), _p(ds), ws.numel(), 1.0, _stream()), "ppst_sum_partials")
+    return gpre, ds
+
+
+def pad2d(x, py0, py1, px0, px1, mode):
+    ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    y = torch.empty((B, H + py0 + py1, W + px0 + px1, C), device=x.device, dtype=torch.float32)
+    check(lib.ppst_pad2d(_p(x), _p(y), B, H, W, C, ld, py0, py1, px0, px1, mode, _stream()), "ppst_pad2d")
+    return y
+
+
+def pad2d_bwd(dy, py0, py1, px0, px1, mode):
+    _chk(dy)
+    dy = dy.contiguous()
+    B, OH, OW, C = dy.shape
+    H, W = OH - py0 - py1, OW - px0 - px1
+    dx = torch.empty((B, H, W, C), device=dy.device, dtype=torch.float32)
+    check(lib.ppst_pad2d_bwd(_p(dy), _p(dx), B, H, W, C, py0, py1, px0, px1, mode, _stream()), "ppst_pad2d_bwd")
+    return dx
+
+
+def bilinear_bwd(dy, H, W):
+    dy_ld = _nhwc_ld(dy)
+    B, OH, OW, C = dy.shape
+    dx = torch.zeros((B, H, W, C), device=dy.device, dtype=torch.float32)
+    check(lib.ppst_bilinear_bwd(_p(dy), _p(dx), B, H, W, C, C, OH, OW, dy_ld, _stream()), "ppst_bilinear_bwd")
+    return dx
+
+
+def avgpool_bwd(dy, f):
+    dy_ld = _nhwc_ld(dy)
+    B, oh, ow, C = dy.shape
+    dx = torch.empty((B, oh * f, ow * f, C), device=dy.device, dtype=torch.float32)
+    check(lib.ppst_avgpool_bwd(_p(dy), _p(dx), B, oh * f, ow * f, C, C, f, dy_ld, _stream()), "ppst_avgpool_bwd")
+    return dx
+
+
+def gap_gmp_bwd(x, mask, v, g, out=None):
+    """adjoint of gap_gmp; out given -> accumulate into it."""
+    ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    _chk(mask); _chk(v); _chk(g)
+    acc = out is not None
+    if out is None:
+        out = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+    check(lib.ppst_gap_gmp_bwd(_p(x), _p(mask), _p(v.contiguous()), _p(g.contiguous()), _p(out), B, H * W, C, ld, 1 if acc else 0,
+                               _stream()), "ppst_gap_gmp_bwd")
+    return out
+
+
+def l2norm_rows_bwd(g, x, eps, mode):
+    _chk(g); _chk(x)
+    g, x = g.contiguous(), x.contiguous()
+    B, K = x.shape
+    dx = torch.empty_like(x)
+    check(lib.ppst_l2norm_rows_bwd(_p(g), _p(x), _p(dx), B, K, float(eps), mode, _stream()), "ppst_l2norm_rows_bwd")
+    return dx
+
+
+def softmax_rows_bwd_(p, g, div=1.0):
+    """in place on g: g <- p * (g - sum(g*p)) / div."""
+    _chk(p); _chk(g)
+    assert p.is_contiguous() and g.is_contiguous() and p.shape == g.shape
+    cols = p.shape[-1]
+    check(lib.ppst_softmax_rows_bwd(_p(p), _p(g), p.numel() // cols, cols, float(div), _stream()), "ppst_softmax_rows_bwd")
+    return g
+
+
+def corr_prep_bwd(g, x, ncenter=256):
+    _chk(g); _chk(x)
+    g, x = g.contiguous(), x.contiguous()
+    B, P, C = x.shape
+    dx = torch.empty_like(x)
+    check(lib.ppst_corr_prep_bwd(_p(g), _p(x), _p(dx), B * P, C, ncenter, 2.220446049250313e-16, _stream()), "ppst_corr_prep_bwd")
+    return dx
+
+
+def l1_grad(a, b, weight=1.0):
+    _chk(a); _chk(b)
+    a, b = a.contiguous(), b.contiguous()
+    da = torch.empty_like(a)
+    check(lib.ppst_l1_grad(_p(a), _p(b), _p(da), a.numel(), float(weight), _stream()), "ppst_l1_grad")
+    return da
+
+
+def scale_by(x, s):
+    """x * s[0] with s a (1,) device tensor."""
+    _chk(x); _chk(s)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(lib.ppst_scale_by(_p(x), _p(s.contiguous()), _p(y), x.numel(), _stream()), "ppst_scale_by")
+    return y
+
+
+def noise_wgrad(dpre, noise):
+    ld = _nhwc_ld(dpre)
+    B, H, W, C = dpre.shape
+    _chk(noise)
+    noise = noise.contiguous()
+    assert noise.numel() == B * H * W
+    ws = torch.empty(lib.ppst_noise_wgrad_ws(B * H * W) // 4, device=dpre.device, dtype=torch.float32)
+    out = torch.empty((1,), device=dpre.device, dtype=torch.float32)
+    check(lib.ppst_noise_wgrad(_p(dpre), _p(noise), _p(out), _p(ws), B * H * W, C, ld, _stream()), "ppst_noise_wgrad")
+    return out
 
 
 def affine_act(x, scale_shift=None, res=None, act=ACT_NONE, prelu=None, out_scale=1.0, res_before_act=False, out=None,

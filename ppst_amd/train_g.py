@@ -1,0 +1,367 @@
+"""Generator / encoder update of the GAN train step on HIP kernels.
+
+Reference: PPSTOptimizer.train_generator_one_step (optimizers/ppst_optimizer.py:73-94) ->
+PPSTModel.compute_generator_losses (models/ppst_model.py:161-235): ``sum(v.mean()).backward()`` through E1, E2, G
+(D frozen: only d/d(image) flows through it), then three Adam optimisers (lr 1e-3, betas (0, 0.99)).
+
+The differentiable forward below is the training-mode twin of ppst_amd/networks/*: the same kernels, unfused where
+the backward needs the intermediate (the inference path merges norms into the consumer's loads).  Every block is an
+autograd Function over HIP kernels (ppst_amd/autograd.py); parameters of each network live in ONE flat buffer so
+the data-parallel gradient average is one all-reduce per network and Adam one launch.
+"""
+import math
+
+import torch
+
+from . import autograd as A
+from . import glue, ops
+from .networks.base_network import to_nhwc
+from .train import DiscriminatorTrainer, ddp_average_
+
+SQRT2 = math.sqrt(2.0)
+INV_SQRT2 = 1.0 / SQRT2
+HEAD_CH = [(256, 256), (256, 256), (256, 384), (384, 512)]
+UP = [(16, 512, 512), (32, 512, 256), (64, 256, 128)]
+TAGS = ["9", "0", "1", "2"]
+CH = [32, 64, 128, 256]
+
+
+class FlatParams:
+    """Parameters of one network as views into a flat buffer, with flat gradient and Adam state."""
+
+    def __init__(self, net, lr, beta1, beta2):
+        self.net = net
+        self.names = [n for n, _ in net.named_parameters()]
+        params = [p for _, p in net.named_parameters()]
+        self.params = params
+        self.sizes = [p.numel() for p in params]
+        flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+        self.flat, self.grad = flat, torch.zeros_like(flat)
+        self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
+        self.offsets, off = {}, 0
+        for n_, p, sz in zip(self.names, params, self.sizes):
+            p.data = flat[off:off + sz].view_as(p)
+            p.requires_grad_(True)
+            p.grad = self.grad[off:off + sz].view_as(p)     # autograd accumulates in place into the flat gradient
+            self.offsets[n_] = (off, sz)
+            off += sz
+        net._flat.clear(); net._cache.clear()
+        self.lr, self.b1, self.b2, self.eps, self.step_count = lr, beta1, beta2, 1e-8, 0
+
+    def g(self, name):
+        off, sz = self.offsets[name]
+        return self.grad[off:off + sz]
+
+    def owns_parameters(self):
+        off = 0
+        for p, n in zip(self.params, self.sizes):
+            if p.data_ptr() != self.flat.data_ptr() + 4 * off or p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                return False
+            off += n
+        return True
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def adam(self):
+        if not self.owns_parameters():
+            raise RuntimeError("parameters / gradients no longer alias the flat buffers of this trainer")
+        self.step_count += 1
+        ops.adam_step_(self.flat, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, self.step_count)
+        self.net._cache.clear()      # packed weights are stale
+
+
+class GeneratorTrainer:
+    """Differentiable E1 / E2 / G forward + the generator iteration of PPSTOptimizer."""
+
+    def __init__(self, model, lr=1e-3, beta1=0.0, beta2=0.99, world=1):
+        self.model = model
+        self.opt = model.opt
+        self.world = world
+        self.G, self.E1, self.E2 = model.G, model.E1, model.E2
+        self.fp = {"G": FlatParams(model.G, lr, beta1, beta2), "E2": FlatParams(model.E2, lr, beta1, beta2),
+                   "E1": FlatParams(model.E1, lr, beta1, beta2)}
+        self.d_trainer = DiscriminatorTrainer.for_network(model.D) if hasattr(model, "D") else None
+
+    # ------------------------------------------------------------ ConvLayer / ResBlock (stylegan2_layers.py:497-579)
+    def _res_block(self, net, x, p, norm):
+        P = net.p
+        cin = x.shape[3]
+        ks = P(p + "conv2.Blur.kernel").shape[0]
+        sc1, scs = 1.0 / math.sqrt(cin * 9), 1.0 / math.sqrt(cin)
+        pad_c, pad_s = (ks - 2) + 2, (ks - 2) + 0
+        w1, w2, ws = p + "conv1.Conv.weight", p + "conv2.Conv.weight", p + "skip.Conv.weight"
+        xs = A.BlurDownFn.apply(x, net, p + "skip.Blur.kernel", (pad_s + 1) // 2, pad_s // 2)
+        if not norm:
+            y1 = A.conv(x, P(w1), net, w1, bias=P(p + "conv1.Act.bias"), scale=sc1, pad_mode=A.REFLECT, act=A.LRELU)
+            a2 = A.blur_conv(y1, P(w2), net, w2, p + "conv2.Blur.kernel", bias=P(p + "conv2.Act.bias"), scale=sc1,
+                             p0=(pad_c + 1) // 2, p1=pad_c // 2, pad_mode=A.REFLECT, act=A.LRELU)
+            skip = A.conv(xs, P(ws), net, ws, scale=scs)
+            return A.AddScaleFn.apply(a2, skip, INV_SQRT2)
+        y1, st1 = A.conv(x, P(w1), net, w1, scale=sc1, pad_mode=A.REFLECT, stats=True)
+        a1 = A.instance_norm(y1, st1, post_bias=P(p + "conv1.Act.bias"), act=A.LRELU)
+        y2, st2 = A.blur_conv(a1, P(w2), net, w2, p + "conv2.Blur.kernel", scale=sc1, p0=(pad_c + 1) // 2, p1=pad_c // 2,
+                              pad_mode=A.REFLECT, stats=True)
+        a2 = A.instance_norm(y2, st2, post_bias=P(p + "conv2.Act.bias"), act=A.LRELU)
+        ys, sts = A.conv(xs, P(ws), net, ws, scale=scs, stats=True)
+        return A.AddScaleFn.apply(a2, A.instance_norm(ys, sts), INV_SQRT2)
+
+    def _from_rgb(self, net, img, p):
+        x = A.ToNHWCFn.apply(img) if img.requires_grad else to_nhwc(img)     # img is NCHW like the reference's
+        x = x if x.is_contiguous() else x.contiguous()
+        w = net.p(p + "Conv.weight")
+        return A.FromRGBFn.apply(x, w, net.p(p + "Act.bias"), 1.0 / math.sqrt(w.shape[1]))
+
+    # ------------------------------------------------------------ E1 (encoder_con.py:82-92)
+    def encoder_con(self, img):
+        """img NCHW -> sp NHWC (B, H/8, W/8, 256)."""
+        net, P = self.E1, self.E1.p
+        x = self._from_rgb(net, img, "FromRGB.")
+        for i in range(3):
+            x = self._res_block(net, x, "DownToSpatialCode.ResBlockDownBy%d." % (2 ** i), norm=True)
+        sc = 1.0 / math.sqrt(x.shape[3])
+        n0, n1 = "ToSpatialCode.0.Conv.weight", "ToSpatialCode.1.Conv.weight"
+        y, st = A.conv(x, P(n0), net, n0, scale=sc, stats=True)
+        x = A.instance_norm(y, st, post_bias=P("ToSpatialCode.0.Act.bias"), act=A.LRELU)
+        y, st = A.conv(x, P(n1), net, n1, bias=P("ToSpatialCode.1.Conv.bias"), scale=sc, stats=True)
+        return A.instance_norm(y, st)
+
+    # ------------------------------------------------------------ E2 (encoder_col.py:150-251)
+    def _e2_head(self, tag, x, mask=None):
+        P = self.E2.p
+        v = A.GapGmpFn.apply(x, mask)
+        v = A.linear(v, P("conv1x1_%s.weight" % tag), P("conv1x1_%s.bias" % tag))
+        q = "projector%s." % tag
+        for i in (1, 3, 5):
+            v = A.linear(v, P(q + "%d.weight" % i), P(q + "%d.bias" % i), relu_in=True)
+        return A.L2NormFn.apply(v, 1e-12, 1)
+
+    def encoder_col(self, img, mask=None, corrmatrix=None):
+        net = self.E2
+        feats = [self._from_rgb(net, img, "FromRGB.")]
+        for i in range(3):
+            feats.append(self._res_block(net, feats[-1], "DownToGlobalCode1.ResBlockDownBy%d." % (2 ** i), norm=False))
+        vectors = [self._e2_head(t, f) for t, f in zip(TAGS, feats)]
+        vectors_w, pm, pmw, warped = [], [], [], None
+        if corrmatrix is not None:
+            warped = self._warp_levels(feats, corrmatrix)
+            vectors_w = [self._e2_head(t, f) for t, f in zip(TAGS, warped)]
+        if mask is not None:
+            levels = net._mask_planes(mask)
+            sw = net._mask_planes(glue.swap(mask)) if warped is not None else None
+            for lvl, (t, f) in enumerate(zip(TAGS, feats)):
+                for i in range(3):
+                    pm.append(self._e2_head(t, f, levels[lvl][..., i].contiguous()))
+                    if warped is not None:
+                        pmw.append(self._e2_head(t, warped[lvl], sw[lvl][..., i].contiguous()))
+            return vectors, pm, vectors_w, pmw
+        return vectors, vectors_w
+
+    def _warp_levels(self, feats, corr):
+        """E2.warp (encoder_col.py:100-138) for the four levels with one GEMM; the correspondence matrix receives a
+        gradient through the first level only (the others use corrmatrix.detach(), :197)."""
+        B = feats[0].shape[0]
+        pooled = [f if f.shape[1] == 64 else A.AvgPoolFn.apply(f, f.shape[1] // 64) for f in feats]
+        V = torch.cat(pooled, dim=3).reshape(B, 4096, sum(CH))
+        Wv = A.WarpGemmFn.apply(corr, V, CH[0]).view(B, 64, 64, sum(CH))
+        out, off = [], 0
+        for f, c in zip(feats, CH):
+            sl = Wv[..., off:off + c]
+            out.append(sl if f.shape[1] == 64 else A.BilinearFn.apply(sl, f.shape[1], f.shape[2]))
+            off += c
+        return out
+
+    # ------------------------------------------------------------ G (generator.py:244-281)
+    def _styled_conv(self, x, p, code, key, noise, upsample=False):
+        net, P = self.G, self.G.p
+        bias = P(p + "conv.bias") + P(p + "bias").reshape(-1) + P(p + "activate.bias")   # three biases of StyledConv collapse
+        kind = "conv"
+        if upsample:
+            if min(x.shape[1], x.shape[2]) * 2 < 128:
+                raise NotImplementedError("training below 64x64 feature maps (the nearest-upsample branch) is not on the path")
+            kind = "convT"
+        nz = noise[key] if isinstance(noise, dict) else None
+        if nz is None:
+            B, H, W = x.shape[0], x.shape[1] * (2 if upsample else 1), x.shape[2] * (2 if upsample else 1)
+            nz = torch.randn(B, 1, H, W, device=x.device)          # NoiseInjection draws N(0,1) (stylegan2_layers.py:388-390)
+        wn = p + "conv.weight"
+        a, st = A.conv(x, P(wn), net, wn, bias=bias, kind=kind, act=A.LRELU, noise_w=P(p + "noise.weight"), noise=nz.contiguous(), stats=True)
+        wl = P(p + "epi1.style_mod.lin.weight")
+        style = A.linear(code, wl, P(p + "epi1.style_mod.lin.bias"), wscale=wl.shape[1] ** -0.5)
+        return A.instance_norm(a, st, style=style)
+
+    def generator(self, sp, global_codes, noise=None, extract_features=False):
+        """sp NHWC (B,h,w,256), codes 4 x (B,2048) -> rgb NCHW (B,3,8h,8w) [, feat NHWC, feat1 NHWC]."""
+        net, P = self.G, self.G.p
+        codes = [A.L2NormFn.apply(c, 1e-8, 0) for c in global_codes]
+        g = codes[-1]
+        ws = P("SpatialCodeModulation.scale.weight")
+        inv = 1.0 / math.sqrt(ws.shape[1])
+        scale = A.linear(g, ws, P("SpatialCodeModulation.scale.bias"), wscale=inv)
+        shift = A.linear(g, P("SpatialCodeModulation.bias.weight"), P("SpatialCodeModulation.bias.bias"), wscale=inv)
+        x = A.SpatialModFn.apply(sp, scale, shift)
+        for i, (ci, co) in enumerate(HEAD_CH):
+            q = "HeadResnetBlock%d." % i
+            sw = q + "skip.Conv.weight"
+            skip = x if ci == co else A.conv(x, P(sw), net, sw, scale=1.0 / math.sqrt(ci))
+            r = self._styled_conv(x, q + "conv1.", g, "HeadResnetBlock%d.conv1" % i, noise)
+            r = self._styled_conv(r, q + "conv2.", g, "HeadResnetBlock%d.conv2" % i, noise)
+            x = A.AddScaleFn.apply(skip, r, INV_SQRT2)
+        feas = []
+        if extract_features:
+            feas.append(self._feat_head(x.detach(), "layer32.", 3))
+        for j, (key, ci, co) in enumerate(UP):
+            q = "UpsamplingResBlock%d." % key
+            g = codes[-2 - j]
+            if ci == co:
+                skip = x
+            else:
+                sw = q + "skip.Conv.weight"
+                skip = A.conv(x, P(sw), net, sw, bias=P(q + "skip.Act.bias"), scale=1.0 / math.sqrt(ci), act=A.LRELU)
+            skip = A.BilinearFn.apply(skip, 2 * skip.shape[1], 2 * skip.shape[2])
+            r = self._styled_conv(x, q + "conv1.", g, "UpsamplingResBlock%d.conv1" % key, noise, upsample=True)
+            r = self._styled_conv(r, q + "conv2.", g, "UpsamplingResBlock%d.conv2" % key, noise)
+            x = A.AddScaleFn.apply(skip, r, INV_SQRT2)
+            if extract_features:
+                feas.append(self._feat_head(x.detach(), "layer%d." % (2 ** (j + 6)), 3 if j < 2 else 1))
+        wr = P("ToRGB.conv.weight")
+        brgb = P("ToRGB.conv.bias") + P("ToRGB.bias").reshape(-1)
+        y = A.ToRGBConvFn.apply(x, wr, brgb, 1.0 / math.sqrt(wr.shape[1]))
+        wl = P("ToRGB.epi1.style_mod.lin.weight")
+        style = A.linear(codes[0], wl, P("ToRGB.epi1.style_mod.lin.bias"), wscale=wl.shape[1] ** -0.5)
+        rgb = A.ToNCHWFn.apply(A.instance_norm(y, None, style=style))
+        if not extract_features:
+            return rgb
+        h = feas[0].shape[1]
+        feat = torch.cat([feas[0]] + [A.AvgPoolFn.apply(f, f.shape[1] // h) for f in feas[1:]], dim=3)
+        feat1 = torch.cat([f if f.shape[1] == 256 else A.BilinearFn.apply(f, 256, 256) for f in feas], dim=3)
+        for i in range(3):
+            feat = self._residual_block(feat, "layert.%d." % i)
+        feat1 = self._residual_block(feat1, "layert1.0.")
+        feat1 = A.conv(feat1, P("layert1.1.weight"), net, "layert1.1.weight", bias=P("layert1.1.bias"))
+        return rgb, feat, feat1
+
+    # correspondence feature heads (generator.py:174-238): IN on the ReplicationPad2d(1)-padded tensor, conv, IN, PReLU, ...
+    def _feat_head(self, x, p, k):
+        net, P = self.G, self.G.p
+        if k == 3:
+            # InstanceNorm runs on the padded tensor (quirk of the reference); the conv then needs no padding:
+            # run the zero-padded kernel on the padded canvas and crop its border
+            xp = A.PadFn.apply(x, 1, A.REPLICATE)
+            n = A.instance_norm(xp)
+            y = A.PadFn.apply(A.conv(n, P(p + "2.weight"), net, p + "2.weight", bias=P(p + "2.bias")), -1, A.Z)
+        else:
+            y = A.conv(A.instance_norm(x), P(p + "2.weight"), net, p + "2.weight", bias=P(p + "2.bias"))
+        y = A.instance_norm(y, prelu=P(p + "4.weight"), act=A.PRELU)
+        y = A.conv(y, P(p + "6.weight"), net, p + "6.weight", bias=P(p + "6.bias"), pad_mode=A.REPLICATE if k == 3 else A.Z)
+        return A.instance_norm(y, prelu=P(p + "8.weight"), act=A.PRELU)
+
+    def _residual_block(self, x, p):
+        net, P = self.G, self.G.p
+        a = P(p + "prelu.weight")
+        y, st = A.conv(x, P(p + "conv1.weight"), net, p + "conv1.weight", bias=P(p + "conv1.bias"), pad_mode=A.REPLICATE, stats=True)
+        y = A.instance_norm(y, st, prelu=a, act=A.PRELU)
+        y, st = A.conv(y, P(p + "conv2.weight"), net, p + "conv2.weight", bias=P(p + "conv2.bias"), pad_mode=A.REPLICATE, stats=True)
+        return A.PReluResFn.apply(A.instance_norm(y, st), x, a)
+
+    # ------------------------------------------------------------ correspondence (ppst_model.py:330-387)
+    def rselfcorr(self, fea1):
+        return A.RSelfCorrFn.apply(fea1)
+
+    def corrm(self, fea, fea0):
+        """fea (keys) / fea0 (queries): NHWC (B,64,64,512) -> (B,4096,4096)."""
+        return A.CorrMFn.apply(fea, fea0)
+
+    def warp_mask(self, mask, corr):
+        """PPSTModel.warp of the one-hot mask (no gradient to the mask)."""
+        s = int(((mask.shape[2] * mask.shape[3]) / corr.shape[1]) ** 0.5)
+        patches = ops.unfold_patches(mask, s)
+        b, c, h, w = mask.shape
+        return A.FoldFn.apply(A.GemmConstBFn.apply(corr, patches), c, h, w, s)
+
+    # ------------------------------------------------------------ losses (ppst_model.py:161-235)
+    def gan_logits(self, img):
+        return A.DiscriminatorLogitsFn.apply(img, self.d_trainer)
+
+    def compute_generator_losses(self, real, mask=None):
+        opt, m = self.opt, self.model
+        lam = lambda k, d: float(getattr(opt, k, d))
+        stage = int(getattr(opt, "training_stage", 2))
+        B = real.shape[0]
+        noise = m.noise if isinstance(m.noise, dict) else None
+        losses, metrics = {}, {}
+        sp = self.encoder_con(real)
+        gl, _ = self.encoder_col(real)
+        if stage == 2:
+            _, feas, feas1 = self.generator(sp, gl, noise, extract_features=True)
+            sps = torch.cat((feas, self.rselfcorr(feas1)), dim=3)
+            corr = self.corrm(sps, glue.swap(sps))
+            corr_self = self.corrm(sps, sps)
+            _, gl = self.encoder_col(real, corrmatrix=corr_self)
+            if lam("lambda_StyleCon", 1.0) > 0.0:
+                _, pro_ms, gl_w, pro_mw = self.encoder_col(real, mask=mask, corrmatrix=corr)
+            if lam("lambda_Maskwarp", 10.0) > 0.0:
+                losses["Mask_warp"] = A.L1LossFn.apply(self.warp_mask(mask, corr), glue.swap(mask), lam("lambda_Maskwarp", 10.0))
+        rec = self.generator(sp, gl, noise)
+        if lam("lambda_L1", 3.0) > 0.0:
+            losses["G_L1"] = A.L1LossFn.apply(rec, real, lam("lambda_L1", 3.0))
+        if lam("lambda_StyleCon", 1.0) > 0.0:
+            mix = self.generator(glue.swap(sp), gl_w, noise)
+            _, pro_3m, _, _ = self.encoder_col(mix, mask=glue.swap(mask))
+            _, pro_2m, _, _ = self.encoder_col(rec, mask=mask)
+            sp_3 = self.encoder_con(mix)
+            nz = {k: v[:B // 2] for k, v in noise.items()} if noise is not None else None
+            cyc = self.generator(glue.swap(sp_3)[:B // 2], [g[:B // 2] for g in gl], nz)
+            metrics["L1_dist"] = A.L1LossFn.apply(cyc, real[:B // 2].contiguous(), 1.0)
+            losses["G_L1_cyc"] = A.L1LossFn.apply(cyc, real[:B // 2].contiguous(), 3.0)
+            s1 = s2 = None
+            for lid in range(0, 12, 3):
+                li = lid // 3
+                key0 = torch.cat(pro_ms[lid:lid + 3], 0).detach()
+                keyw = torch.cat(pro_mw[lid:lid + 3], 0).detach()
+                query, query_r = torch.cat(pro_3m[lid:lid + 3], 0), torch.cat(pro_2m[lid:lid + 3], 0)
+                queue = getattr(m.criterionNCE, "queue_data_A%d" % li)
+                a = A.RsclLossFn.apply(query, keyw, key0, queue, lam("nce_T", 0.07))
+                b = A.RsclLossFn.apply(query_r, key0, keyw, queue, lam("nce_T", 0.07))
+                s1 = a if s1 is None else s1 + a
+                s2 = b if s2 is None else s2 + b
+                m.criterionNCE.enqueue_many(torch.cat((key0[0:3], keyw[0:3]), 0), li)
+            lsc = lam("lambda_StyleCon", 1.0)
+            losses["G_styleContmix"] = s1 if lsc == 1.0 else s1 * lsc
+            losses["G_styleContrec"] = s2 if lsc == 1.0 else s2 * lsc
+        if lam("lambda_GAN", 1.0) > 0.0:
+            losses["G_GAN_rec"] = A.LsganFn.apply(self.gan_logits(rec), 1.0, 0.5 * lam("lambda_GAN", 1.0))
+            if lam("lambda_StyleCon", 1.0) > 0.0:
+                losses["G_GAN_mix"] = A.LsganFn.apply(self.gan_logits(mix), 1.0, lam("lambda_GAN", 1.0))
+        return losses, metrics
+
+    # ------------------------------------------------------------ one generator iteration
+    def zero_grad(self):
+        for f in self.fp.values():
+            f.zero_grad()
+
+    def losses_and_grads(self, real, mask=None):
+        self.zero_grad()
+        with torch.enable_grad():
+            losses, metrics = self.compute_generator_losses(real, mask)
+            total = None
+            for v in losses.values():
+                total = v if total is None else total + v
+            total.backward()
+        out = {k: v.detach() for k, v in losses.items()}
+        out.update({k: v.detach() for k, v in metrics.items()})
+        return out
+
+    def all_reduce(self):
+        for f in self.fp.values():
+            ddp_average_(f.grad, self.world)
+
+    def adam(self):
+        for k in ("G", "E2", "E1"):          # optimizer_G.step(); optimizer_E2.step(); optimizer_E1.step()
+            self.fp[k].adam()
+
+    def train_step(self, real, mask=None):
+        losses = self.losses_and_grads(real, mask)
+        self.all_reduce()
+        self.adam()
+        return losses

@@ -1,0 +1,333 @@
+"""GPU diagnostic for the generator / encoder update: every autograd block (ppst_amd/autograd.py) against torch
+autograd of the CPU oracle's ops in float64, then the full generator iteration against the fixtures the reference's
+own compute_generator_losses + backward produced (tests/golden/gstep512_s{1,2}.npz).
+Usage (GPU box):  python tests/gstep_diag.py [blocks|s1|s2|all]
+The pytest -m gpu tests (tests/test_gpu_gstep.py) assert the same comparisons."""
+import math
+import os
+import sys
+import traceback
+import zlib
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import ppst_oracle as O  # noqa: E402
+from ppst_amd import autograd as A, ops, weights as W  # noqa: E402
+
+dev = "cuda"
+RES = []
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def report(name, a, b, tol):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    if a.shape != b.shape:
+        RES.append((name, False))
+        print("%-52s FAIL shape %s vs %s" % (name, tuple(a.shape), tuple(b.shape)), flush=True)
+        return
+    d = (a - b).abs().max().item()
+    r = d / (b.abs().max().item() + 1e-30)
+    ok = r <= tol
+    RES.append((name, ok))
+    print("%-52s %s rel %.3e (tol %.0e) maxabs %.3e refmax %.3e" % (name, "ok  " if ok else "FAIL", r, tol, d, b.abs().max().item()), flush=True)
+
+
+class MiniNet:
+    """what the autograd blocks need from a network: parameters by name and cached conv plans."""
+
+    def __init__(self, **params):
+        self.params = {k: v.to(dev) for k, v in params.items()}
+        self._cache = {}
+
+    def p(self, n):
+        return self.params[n]
+
+    def plan(self, wname, kind="conv", scale=1.0):
+        key = (wname, kind)
+        if key not in self._cache:
+            self._cache[key] = ops.ConvPlan(self.params[wname], kind=kind, scale=scale)
+        return self._cache[key]
+
+
+def grads_gpu(out, ins, gout):
+    gs = torch.autograd.grad(out, ins, gout, allow_unused=True)
+    return gs
+
+
+def check_block(name, gpu_fn, ref_fn, inputs, tol=3e-5, layouts=None):
+    """inputs: dict name -> CPU float32 tensor (NCHW for 4-D activations listed in ``layouts``).  gpu_fn / ref_fn take the
+    dict (GPU fp32 NHWC / CPU fp64 NCHW, requires_grad set) and return the output (NHWC / NCHW)."""
+    layouts = layouts or {}
+    torch.manual_seed(zlib.crc32(name.encode()))
+    gi = {k: (nhwc(v) if layouts.get(k) == "act" else v).to(dev).requires_grad_(v.is_floating_point()) for k, v in inputs.items()}
+    ri = {k: v.double().requires_grad_(v.is_floating_point()) for k, v in inputs.items()}
+    yo = gpu_fn(gi)
+    yr = ref_fn(ri)
+    out_act = yr.dim() == 4
+    report(name + " fwd", nchw(yo) if out_act else yo, yr, tol)
+    gr = torch.randn_like(yr)
+    gg = (nhwc(gr) if out_act else gr).float().to(dev)
+    keys = [k for k in inputs if inputs[k].is_floating_point()]
+    g_gpu = torch.autograd.grad(yo, [gi[k] for k in keys], gg, allow_unused=True)
+    g_ref = torch.autograd.grad(yr, [ri[k] for k in keys], gr, allow_unused=True)
+    for k, a, b in zip(keys, g_gpu, g_ref):
+        if b is None:
+            continue
+        if a is None:
+            RES.append((name + " d" + k, False))
+            print("%-52s FAIL no gradient" % (name + " d" + k), flush=True)
+            continue
+        report(name + " d/d" + k, nchw(a) if layouts.get(k) == "act" else a, b, tol)
+
+
+def refpad(x, mode, p=1):
+    if mode == A.Z:
+        return F.pad(x, (p, p, p, p))
+    return F.pad(x, (p, p, p, p), mode="reflect" if mode == A.REFLECT else "replicate")
+
+
+def t_blocks():
+    rn = torch.randn
+    # ---- ConvFn: 3x3 with each padding mode, bias + noise + lrelu, 1x1, convT
+    for mode, tag in ((A.Z, "zero"), (A.REFLECT, "reflect"), (A.REPLICATE, "replicate")):
+        w = rn(64, 32, 3, 3) * 0.1
+        net = MiniNet(w=w)
+        ins = dict(x=rn(2, 32, 20, 24), w=w, b=rn(64) * 0.1, nw=torch.tensor([0.3]))
+        noise = rn(2, 1, 20, 24)
+
+        def gpu(i, mode=mode, net=net, noise=noise):
+            net.params["w"] = i["w"]; net._cache.clear()
+            return A.conv(i["x"], i["w"], net, "w", bias=i["b"], scale=0.7, pad_mode=mode, act=A.LRELU, noise_w=i["nw"], noise=noise.to(dev))
+
+        def ref(i, mode=mode, noise=noise):
+            y = F.conv2d(refpad(i["x"], mode), i["w"] * 0.7) + i["nw"] * noise.double()
+            return O.fused_leaky_relu(y, i["b"])
+        check_block("ConvFn 3x3 %s +bias+noise+lrelu" % tag, gpu, ref, ins, layouts={"x": "act"})
+    w = rn(128, 64, 1, 1) * 0.1
+    net = MiniNet(w=w)
+
+    def gpu(i, net=net):
+        net.params["w"] = i["w"]; net._cache.clear()
+        return A.conv(i["x"], i["w"], net, "w", scale=0.5)
+    check_block("ConvFn 1x1", gpu, lambda i: F.conv2d(i["x"], i["w"] * 0.5), dict(x=rn(2, 64, 16, 16), w=w), layouts={"x": "act"})
+    w = rn(64, 32, 3, 3) * 0.1
+    net = MiniNet(w=w)
+
+    def gpu(i, net=net):
+        net.params["w"] = i["w"]; net._cache.clear()
+        return A.conv(i["x"], i["w"], net, "w", bias=i["b"], kind="convT", act=A.LRELU)
+
+    def ref(i):
+        y = F.conv_transpose2d(i["x"], O.upscale_weight(i["w"]), stride=2, padding=1)
+        return O.fused_leaky_relu(y, i["b"])
+    check_block("ConvFn convT (fused 4x4 s2 upscale)", gpu, ref, dict(x=rn(2, 32, 64, 64), w=w, b=rn(64) * 0.1), layouts={"x": "act"})
+    # ---- BlurConvFn (zero pad 4-tap as in D, reflect 3-tap as in E1/E2), BlurDownFn
+    for (taps, p0, p1, mode, tag) in (((1, 3, 3, 1), 2, 2, A.Z, "D"), ((1, 2, 1), 2, 1, A.REFLECT, "E")):
+        k = O.make_kernel(list(taps))
+        w = rn(64, 32, 3, 3) * 0.1
+        net = MiniNet(w=w, k=k)
+
+        def gpu(i, net=net, p0=p0, p1=p1, mode=mode):
+            net.params["w"] = i["w"]; net._cache.clear()
+            return A.blur_conv(i["x"], i["w"], net, "w", "k", bias=i["b"], scale=0.6, p0=p0, p1=p1, pad_mode=mode, act=A.LRELU)
+
+        def ref(i, k=k, p0=p0, p1=p1, mode=mode):
+            x = i["x"]
+            if mode == A.REFLECT:
+                x = O.upfirdn2d(F.pad(x, (p0, p1, p0, p1), mode="reflect"), k.double(), pad=(0, 0))
+            else:
+                x = O.upfirdn2d(x, k.double(), pad=(p0, p1))
+            return O.fused_leaky_relu(F.conv2d(x, i["w"] * 0.6, stride=2), i["b"])
+        check_block("BlurConvFn %s" % tag, gpu, ref, dict(x=rn(2, 32, 32, 40), w=w, b=rn(64) * 0.1), layouts={"x": "act"})
+        ps = (len(taps) - 2)
+        q0, q1 = (ps + 1) // 2, ps // 2
+
+        def gpu(i, net=net, q0=q0, q1=q1):
+            return A.BlurDownFn.apply(i["x"], net, "k", q0, q1)
+
+        def ref(i, k=k, q0=q0, q1=q1):
+            return O.upfirdn2d(i["x"], k.double(), pad=(q0, q1))[:, :, ::2, ::2]
+        check_block("BlurDownFn %s" % tag, gpu, ref, dict(x=rn(2, 32, 32, 40)), layouts={"x": "act"}, tol=5e-6)
+    # ---- InstanceNormFn variants
+    ins = dict(y=rn(2, 32, 24, 20) * 2 + 0.5, style=rn(2, 64) * 0.5, pb=rn(32) * 0.2, a=torch.tensor([0.25]))
+
+    def refin(i, style=False, pb=False, act=A.NONE):
+        n = O.instance_norm(i["y"])
+        if style:
+            s = i["style"].view(2, 2, 32, 1, 1)
+            n = n * (s[:, 0] + 1) + s[:, 1]
+        if act == A.LRELU:
+            return O.fused_leaky_relu(n, i["pb"] if pb else None)
+        if pb:
+            n = n + i["pb"].view(1, -1, 1, 1)
+        return O.prelu(n, i["a"]) if act == A.PRELU else n
+    check_block("InstanceNormFn + StyleMod", lambda i: A.instance_norm(i["y"], None, style=i["style"]),
+                lambda i: refin(i, style=True), {k: ins[k] for k in ("y", "style")}, layouts={"y": "act"}, tol=2e-5)
+    check_block("InstanceNormFn + bias + lrelu", lambda i: A.instance_norm(i["y"], None, post_bias=i["pb"], act=A.LRELU),
+                lambda i: refin(i, pb=True, act=A.LRELU), {k: ins[k] for k in ("y", "pb")}, layouts={"y": "act"}, tol=2e-5)
+    check_block("InstanceNormFn plain", lambda i: A.instance_norm(i["y"]), lambda i: refin(i), dict(y=ins["y"]), layouts={"y": "act"}, tol=2e-5)
+    check_block("InstanceNormFn + PReLU", lambda i: A.instance_norm(i["y"], None, prelu=i["a"], act=A.PRELU),
+                lambda i: refin(i, act=A.PRELU), {k: ins[k] for k in ("y", "a")}, layouts={"y": "act"}, tol=2e-5)
+    y3 = rn(2, 3, 32, 32)
+    check_block("InstanceNormFn C=3 + StyleMod", lambda i: A.instance_norm(i["y"], None, style=i["style"]),
+                lambda i: O.instance_norm(i["y"]) * (i["style"].view(2, 2, 3, 1, 1)[:, 0] + 1) + i["style"].view(2, 2, 3, 1, 1)[:, 1],
+                dict(y=y3, style=rn(2, 6) * 0.5), layouts={"y": "act"}, tol=2e-5)
+    # ---- elementwise / resize / pooling
+    a, b = rn(2, 32, 16, 16), rn(2, 32, 16, 16)
+    check_block("AddScaleFn", lambda i: A.AddScaleFn.apply(i["a"], i["b"], 0.7), lambda i: (i["a"] + i["b"]) * 0.7, dict(a=a, b=b),
+                layouts={"a": "act", "b": "act"}, tol=2e-6)
+    check_block("PReluResFn", lambda i: A.PReluResFn.apply(i["a"], i["b"], i["s"]), lambda i: O.prelu(i["a"] + i["b"], i["s"]),
+                dict(a=a, b=b, s=torch.tensor([0.25])), layouts={"a": "act", "b": "act"}, tol=2e-6)
+    for (ih, oh) in ((16, 32), (8, 64), (32, 16), (16, 16)):
+        x = rn(2, 8, ih, ih)
+        check_block("BilinearFn %d->%d" % (ih, oh), lambda i, oh=oh: A.BilinearFn.apply(i["x"], oh, oh),
+                    lambda i, oh=oh: F.interpolate(i["x"], (oh, oh), mode="bilinear", align_corners=False), dict(x=x), layouts={"x": "act"}, tol=5e-6)
+    check_block("AvgPoolFn /4", lambda i: A.AvgPoolFn.apply(i["x"], 4), lambda i: F.adaptive_avg_pool2d(i["x"], (4, 4)), dict(x=a), layouts={"x": "act"}, tol=2e-6)
+    for mode, tag in ((A.REFLECT, "reflect"), (A.REPLICATE, "replicate"), (A.Z, "zero")):
+        check_block("PadFn %s" % tag, lambda i, mode=mode: A.PadFn.apply(i["x"], 1, mode), lambda i, mode=mode: refpad(i["x"], mode), dict(x=a), layouts={"x": "act"}, tol=1e-6)
+    check_block("PadFn crop", lambda i: A.PadFn.apply(i["x"], -1, A.Z), lambda i: i["x"][:, :, 1:-1, 1:-1], dict(x=a), layouts={"x": "act"}, tol=1e-6)
+    mask = (torch.rand(2, 16, 16) > 0.5).float()
+
+    def refgg(i, mask=None):
+        x = i["x"] if mask is None else i["x"] * mask.double()[:, None]
+        return torch.cat([x.mean((2, 3)), x.amax((2, 3))], 1)
+    check_block("GapGmpFn", lambda i: A.GapGmpFn.apply(i["x"], None), lambda i: refgg(i), dict(x=a), layouts={"x": "act"}, tol=2e-6)
+    check_block("GapGmpFn masked", lambda i: A.GapGmpFn.apply(i["x"], mask.to(dev)), lambda i: refgg(i, mask), dict(x=a), layouts={"x": "act"}, tol=2e-6)
+    # ---- vectors
+    xv, wv, bv = rn(3, 256), rn(128, 256) * 0.1, rn(128) * 0.1
+    check_block("LinearFn relu_in", lambda i: A.linear(i["x"], i["w"], i["b"], wscale=0.5, bscale=2.0, relu_in=True),
+                lambda i: F.linear(F.relu(i["x"]), i["w"] * 0.5, i["b"] * 2.0), dict(x=xv, w=wv, b=bv), tol=2e-6)
+    check_block("LinearFn lrelu", lambda i: A.linear(i["x"], i["w"], i["b"], wscale=0.5, act=A.LRELU),
+                lambda i: O.fused_leaky_relu(F.linear(i["x"], i["w"] * 0.5), i["b"]), dict(x=xv, w=wv, b=bv), tol=2e-6)
+    check_block("L2NormFn util.normalize", lambda i: A.L2NormFn.apply(i["x"], 1e-8, 0), lambda i: O.normalize(i["x"]), dict(x=xv), tol=2e-6)
+    check_block("L2NormFn F.normalize", lambda i: A.L2NormFn.apply(i["x"], 1e-12, 1), lambda i: F.normalize(i["x"]), dict(x=xv), tol=2e-6)
+    sp, sc, sh = rn(2, 32, 16, 16), rn(2, 32), rn(2, 32)
+    check_block("SpatialModFn", lambda i: A.SpatialModFn.apply(i["sp"], i["sc"], i["sh"]),
+                lambda i: i["sp"] * i["sc"][:, :, None, None] + i["sh"][:, :, None, None], dict(sp=sp, sc=sc, sh=sh), layouts={"sp": "act"}, tol=5e-6)
+    img, w0, b0 = rn(2, 3, 32, 32), rn(32, 3, 1, 1), rn(32) * 0.1
+    check_block("FromRGBFn", lambda i: A.FromRGBFn.apply(i["x"], i["w"], i["b"], 0.5),
+                lambda i: O.fused_leaky_relu(F.conv2d(i["x"], i["w"] * 0.5), i["b"]), dict(x=img, w=w0, b=b0), layouts={"x": "act"}, tol=5e-6)
+    xr, wr, br = rn(2, 128, 32, 32), rn(3, 128, 1, 1), rn(3) * 0.1
+    check_block("ToRGBConvFn", lambda i: A.ToRGBConvFn.apply(i["x"], i["w"], i["b"], 0.1),
+                lambda i: F.conv2d(i["x"], i["w"] * 0.1, i["b"]), dict(x=xr, w=wr, b=br), layouts={"x": "act"}, tol=5e-6)
+    # ---- losses
+    check_block("L1LossFn", lambda i: A.L1LossFn.apply(i["a"], b.to(dev), 3.0), lambda i: (3.0 * (i["a"] - b.double()).abs().mean()).view(1), dict(a=a), tol=5e-6)
+    pr = rn(4, 1)
+    check_block("LsganFn", lambda i: A.LsganFn.apply(i["p"], 1.0, 0.5), lambda i: (0.5 * ((i["p"] - 1) ** 2).mean()).view(1), dict(p=pr), tol=5e-6)
+
+
+# ---------------------------------------------------------------------------------------- full generator iteration
+def sample_idx(name, numel, n=2048):
+    rng = np.random.default_rng([99, zlib.crc32(name.encode())])
+    return rng.integers(0, numel, size=min(n, numel))
+
+
+def gstep_inputs(B=2, size=512):
+    real = W.synthetic_images(21, B, size)
+    g = torch.Generator().manual_seed(77)
+    lab = torch.randint(0, 3, (B, size // 16, size // 16), generator=g)
+    lab = lab.repeat_interleave(16, 1).repeat_interleave(16, 2)
+    mask = torch.nn.functional.one_hot(lab, 3).permute(0, 3, 1, 2).float().contiguous()
+    return real, mask, W.make_noise(31, B, S=size // 8)
+
+
+def compare_gstep(stage, tol_max=5e-3, tol_l2=5e-3, verbose=True):
+    """-> list of (name, ok).  Losses <= 1e-3; every parameter gradient: max|d| <= tol_max * max|ref| over the
+    reference's sampled entries and ||d||_2 <= tol_l2 * ||ref||_2."""
+    from ppst_amd.ppst_model import Options, create_model
+    from ppst_amd.train_g import GeneratorTrainer
+    g = np.load(os.path.join(GOLD, "gstep512_s%d.npz" % stage))
+    over = dict(training_stage=stage, lambda_Cycwarp=0.0)
+    if stage == 1:
+        over["lambda_StyleCon"] = 0.0
+    sd = W.make_state_dict(17, bias_std=0.1, noise_weight=0.1)
+    m = create_model(Options(**over), state_dict=sd, with_D=True, with_nce=True)
+    real, mask, noise = gstep_inputs()
+    m.noise = {k: v.to(dev) for k, v in noise.items()}
+    tr = GeneratorTrainer(m)
+    out = tr.losses_and_grads(real.to(dev), mask.to(dev))
+    torch.cuda.synchronize()
+    res = []
+    for k in [f[5:] for f in g.files if f.startswith("loss.")]:
+        ref = float(g["loss." + k])
+        got = float(out[k])
+        tol = 5e-3 if "styleCont" in k else 1e-3
+        ok = abs(got - ref) <= tol * max(1.0, abs(ref))
+        res.append(("loss " + k, ok))
+        if verbose:
+            print("loss %-20s %s got %.6f ref %.6f" % (k, "ok  " if ok else "FAIL", got, ref), flush=True)
+    worst = []
+    for net in ("G", "E1", "E2"):
+        fp = tr.fp[net]
+        for name in fp.names:
+            key = "grad.%s.%s" % (net, name)
+            got = fp.g(name).double().cpu().numpy()
+            ref = g[key + ".samples"].astype(np.float64)
+            scale = float(g[key + ".stats"][2])
+            d = got[sample_idx(key, got.size)] - ref
+            if scale == 0.0:
+                ok = float(np.abs(got).max()) == 0.0
+                e_max = e_l2 = float(np.abs(got).max())
+            else:
+                e_max = float(np.abs(d).max() / scale)
+                e_l2 = float(np.linalg.norm(d) / (np.linalg.norm(ref) + 1e-30))
+                ok = e_max <= tol_max and e_l2 <= tol_l2
+            res.append((key, ok))
+            worst.append((e_max, e_l2, key, ok, scale))
+    worst.sort(reverse=True)
+    if verbose:
+        nbad = sum(1 for w_ in worst if not w_[3])
+        print("stage %d: %d parameter gradients, %d outside the bar (max %.0e, l2 %.0e); worst:" % (stage, len(worst), nbad, tol_max, tol_l2), flush=True)
+        for e_max, e_l2, key, ok, scale in worst[:25]:
+            print("  %-64s %s max %.3e l2 %.3e (ref absmax %.3e)" % (key, "ok  " if ok else "FAIL", e_max, e_l2, scale), flush=True)
+    return res
+
+
+def t_s1():
+    RES.extend(compare_gstep(1))
+
+
+def t_s2():
+    RES.extend(compare_gstep(2))
+
+
+def run(fn):
+    try:
+        fn()
+    except Exception:
+        RES.append((fn.__name__, False))
+        print("EXC in %s\n%s" % (fn.__name__, traceback.format_exc()), flush=True)
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("blocks", "all"):
+        run(t_blocks)
+    if what in ("s1", "all"):
+        run(t_s1)
+    if what in ("s2", "all"):
+        run(t_s2)
+    bad = [n for n, ok in RES if not ok]
+    print("SUMMARY: %d checks, %d failed" % (len(RES), len(bad)))
+    for n in bad[:60]:
+        print("  FAILED:", n)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
