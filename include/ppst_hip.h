@@ -167,6 +167,12 @@ typedef struct ppst_conv_args {
 } ppst_conv_args;
 
 int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream);
+/* Exact-fp32 twin of ppst_conv2d_mfma (v_mfma_f32_32x32x2_f32; a->wpack, bn, precision, a_slots, early_a are ignored):
+ * same step table / padding / epilogue semantics, weights read from the fp32 tensor itself -- element (n, c, ky, kx) at
+ * w[n*sn + c*sc + ky*sy + kx*sx], step s of group g uses w[n][src_c .. src_c+31][src_ky][src_kx] * wscale (src_c < 0:
+ * zero-weight step).  A verification path (10-30x slower): it tells rounding of the bf16 hi+lo split apart from defects. */
+int ppst_conv2d_f32(const ppst_conv_args* a, const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx, float wscale,
+                    const int32_t* src_c, const int32_t* src_ky, const int32_t* src_kx, void* stream);
 /* number of tile_rows x 16 tiles per image for (tile_h, tile_w) -- size of the stats buffer */
 int ppst_conv_tiles(int tile_h, int tile_w, int tile_rows);
 
@@ -387,6 +393,11 @@ int ppst_softmax_rows_bwd(const void* p, void* g, int64_t rows, int cols, float 
 int ppst_corr_prep_bwd(const void* g, const void* x, void* dx, int64_t rows, int C, int ncenter, float eps, void* stream);
 /* d(weight * mean|a-b|)/da */
 int ppst_l1_grad(const void* a, const void* b, void* da, int64_t n, float weight, void* stream);
+/* backward of ppst_rscl_loss wrt the queries (keys / queue are detached, ppst_model.py:214-217): dq (n, C); gout = d/d(loss) (1) */
+int ppst_rscl_loss_bwd(const void* q, const void* k, const void* k0, const void* queue, const void* gout, void* dq, int n, int n0,
+                       int C, int K, float nce_T, void* stream);
+/* backward of ppst_rselfcorr: dfea [B][H][W][64] from dout [B][H/4][W/4][>=256] (pixel stride dout_ld) */
+int ppst_rselfcorr_bwd(const void* fea, const void* dout, void* dfea, int B, int H, int W, int C, int dout_ld, void* stream);
 /* y = x * s[0], s a device scalar (chain rule through a scalar loss) */
 int ppst_scale_by(const void* x, const void* s, void* y, int64_t n, void* stream);
 /* NoiseInjection weight gradient: out[0] = sum dpre[p][c] * noise[p] (stylegan2_layers.py:376-399) */

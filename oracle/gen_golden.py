@@ -290,12 +290,14 @@ def _noise_hooks(m, noise):
     return hs
 
 
-def gen_gstep(ns, stage):
+def gen_gstep(ns, stage, f64=False):
     """The generator/encoder update of the reference itself: PPSTOptimizer.train_generator_one_step's
     ``sum(v.mean()).backward()`` (optimizers/ppst_optimizer.py:73-94) over compute_generator_losses
     (models/ppst_model.py:161-235) at B = 2, 512x512, lambda_Cycwarp = 0 (lpips stubbed), stress weights (non-zero
     biases and noise weights, explicit noise).  stage 1: L1 + GAN on the reconstruction (lambda_StyleCon = 0);
-    stage 2: the full objective.  Stored: every loss, sampled gradients of every G / E1 / E2 parameter, and the
+    stage 2: the full objective.  f64: the same reference code with the model and inputs cast to float64 -- the
+    rounding-free value of every gradient, which tells how much of a float32-vs-float32 difference is the reference's own
+    summation noise (several of these gradients are heavily cancelling sums over 10^5..10^8 terms).  Stored: every loss, sampled gradients of every G / E1 / E2 parameter, and the
     gradients at the network boundaries (d/d rec, d/d sp, d/d codes) as debugging checkpoints."""
     over = dict(lambda_Cycwarp=0.0, training_stage=stage)
     if stage == 1:
@@ -307,6 +309,9 @@ def gen_gstep(ns, stage):
     m.load_state_dict({k: sd[k] for k in own if k in sd}, strict=False)
     m.train()
     real, mask, noise = gstep_inputs()
+    if f64:
+        m.double()
+        real, mask, noise = real.double(), mask.double(), {k: v.double() for k, v in noise.items()}
     hooks = _noise_hooks(m, noise)
     taps = {"E1": [], "E2": [], "G": []}
 
@@ -345,8 +350,9 @@ def gen_gstep(ns, stage):
                     pack(out, "tapgrad.%s.%d.%d" % (tag, ci, ti), t.grad)
     for h in hooks:
         h.remove()
-    np.savez_compressed(os.path.join(GOLD, "gstep512_s%d.npz" % stage), **out)
-    print("gstep512_s%d.npz" % stage, len(out), {k: float(v) for k, v in out.items() if k.startswith(("loss.", "metric."))})
+    tag = "gstep512_s%d%s.npz" % (stage, "_f64" if f64 else "")
+    np.savez_compressed(os.path.join(GOLD, tag), **out)
+    print(tag, len(out), {k: float(v) for k, v in out.items() if k.startswith(("loss.", "metric."))})
 
 
 def main():
@@ -355,6 +361,7 @@ def main():
     if len(sys.argv) > 1:                        # e.g. `gen_golden.py gstep1 gstep2 train512`: only these fixtures
         for a in sys.argv[1:]:
             {"gstep1": lambda: gen_gstep(ns, 1), "gstep2": lambda: gen_gstep(ns, 2),
+             "gstep1_f64": lambda: gen_gstep(ns, 1, True), "gstep2_f64": lambda: gen_gstep(ns, 2, True),
              "train512": lambda: gen_train(ns, 512), "train128": lambda: gen_train(ns), "gloss": lambda: gen_gloss(ns)}[a]()
         return
     m = ref_loader.build_reference_model()
@@ -368,6 +375,8 @@ def main():
     gen_gloss(ns)
     gen_gstep(ns, 1)
     gen_gstep(ns, 2)
+    gen_gstep(ns, 1, True)
+    gen_gstep(ns, 2, True)
 
 
 if __name__ == "__main__":

@@ -54,6 +54,7 @@ _SIGS = {
     "ppst_conv_pack": (i32, [vp, i64, i64, i64, i64, f32, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp]),
     "ppst_upscale_weight": (i32, [vp, vp, i32, i32, f32, vp]),
     "ppst_conv2d_mfma": (i32, [ctypes.POINTER(ConvArgs), vp]),
+    "ppst_conv2d_f32": (i32, [ctypes.POINTER(ConvArgs), vp, i64, i64, i64, i64, f32, vp, vp, vp, vp]),
     "ppst_conv_tiles": (i32, [i32, i32, i32]),
     "ppst_conv1x1_small_cin": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp]),
     "ppst_conv1x1_small_cout": (i32, [vp, vp, vp, vp, i64, i32, i32, f32, vp]),
@@ -114,6 +115,8 @@ _SIGS = {
     "ppst_corr_prep_bwd": (i32, [vp, vp, vp, i64, i32, i32, f32, vp]),
     "ppst_l1_grad": (i32, [vp, vp, vp, i64, f32, vp]),
     "ppst_scale_by": (i32, [vp, vp, vp, i64, vp]),
+    "ppst_rscl_loss_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
+    "ppst_rselfcorr_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ppst_noise_wgrad_ws": (i64, [i64]),
     "ppst_noise_wgrad": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
     "ppst_upscale_weight_bwd": (i32, [vp, vp, i32, i32, f32, vp]),

@@ -410,7 +410,7 @@ class ToRGBConvFn(Function):
         if ctx.needs_input_grad[0]:
             dx = ops.conv1x1_small_cin(g, w.reshape(cout, cin).t().contiguous(), None, ctx.scale, NONE)
         if ctx.needs_input_grad[1]:
-            dw = ops.wgrad_small_cin(g, x, ctx.scale).t().contiguous().view_as(w)   # (cin, cout) -> (cout, cin, 1, 1)
+            dw = ops.wgrad_small_cin(g, x, ctx.scale).reshape(cin, cout).t().contiguous().view_as(w)   # (cin, cout) -> (cout, cin, 1, 1)
         if ctx.needs_input_grad[2]:
             db = ops.colsum(g.view(-1, cout))
         return dx, dw, db, None
@@ -485,3 +485,112 @@ class DiscriminatorLogitsFn(Function):
         ctx.trainer.backward(ctx.tape, _c(g), param_grads=False, keep=keep)
         ctx.tape = None
         return ops.nhwc_to_nchw(keep["d_img"]), None
+
+
+# ---------------------------------------------------------------- correspondence (ppst_model.py:330-387) ----
+class RSelfCorrFn(Function):
+    """PPSTModel.Rselfcorr: (B,256,256,64) NHWC -> (B,64,64,256)."""
+
+    @staticmethod
+    def forward(ctx, fea1):
+        fea1 = _c(fea1)
+        ctx.save_for_backward(fea1)
+        return ops.rselfcorr(fea1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (fea1,) = ctx.saved_tensors
+        return ops.rselfcorr_bwd(fea1, _c(g))
+
+
+class CorrMFn(Function):
+    """PPSTModel.corrm: softmax(cos(q_i, k_j) / 0.01) over j; fea (keys) / fea0 (queries) NHWC (B,h,w,512)."""
+
+    @staticmethod
+    def forward(ctx, fea, fea0):
+        k, q = _c(fea), _c(fea0)
+        B, h, w, C = k.shape
+        k, q = k.reshape(B, h * w, C), q.reshape(B, h * w, C)
+        kn, qn = ops.corr_prep(k, 256), ops.corr_prep(q, 256)
+        corr = ops.softmax_rows_(ops.gemm_nt(qn, kn), 0.01)
+        ctx.save_for_backward(k, q, kn, qn, corr)
+        ctx.shape = (B, h, w, C)
+        return corr
+
+    @staticmethod
+    def backward(ctx, g):
+        k, q, kn, qn, corr = ctx.saved_tensors
+        ds = ops.softmax_rows_bwd_(corr, _c(g).clone(), 0.01)          # d/d(cosine matrix)
+        dk = dq = None
+        if ctx.needs_input_grad[1]:
+            dq = ops.corr_prep_bwd(ops.gemm_nn(ds, kn), q, 256).view(ctx.shape)
+        if ctx.needs_input_grad[0]:
+            dk = ops.corr_prep_bwd(ops.gemm_nn(ops.transpose_last2(ds), qn), k, 256).view(ctx.shape)
+        return dk, dq
+
+
+class WarpGemmFn(Function):
+    """corr (B,P,P) @ V (B,P,C).  The correspondence matrix receives a gradient through the first ``nlive`` channels
+    of V only (E2.warp uses corrmatrix.detach() for the deeper levels, encoder_col.py:197)."""
+
+    @staticmethod
+    def forward(ctx, corr, V, nlive):
+        corr, V = _c(corr), _c(V)
+        ctx.save_for_backward(corr, V)
+        ctx.nlive = nlive
+        return ops.gemm_nn(corr, V)
+
+    @staticmethod
+    def backward(ctx, g):
+        corr, V = ctx.saved_tensors
+        g = _c(g)
+        dcorr = dV = None
+        if ctx.needs_input_grad[0]:
+            n = ctx.nlive
+            dcorr = ops.gemm_nt(g[..., :n].contiguous(), V[..., :n].contiguous())
+        if ctx.needs_input_grad[1]:
+            dV = ops.gemm_nn(ops.transpose_last2(corr), g)
+        return dcorr, dV, None
+
+
+class GemmConstBFn(Function):
+    """corr @ M with a constant right operand (PPSTModel.warp of the one-hot mask)."""
+
+    @staticmethod
+    def forward(ctx, corr, M):
+        ctx.save_for_backward(M)
+        return ops.gemm_nn(_c(corr), M)
+
+    @staticmethod
+    def backward(ctx, g):
+        (M,) = ctx.saved_tensors
+        return ops.gemm_nt(_c(g), M), None
+
+
+class FoldFn(Function):
+    """F.fold(x^T, (h, w), s, stride=s) of (B, P, C*s*s) patches -> NCHW (ppst_model.py:366-387)."""
+
+    @staticmethod
+    def forward(ctx, x, c, h, w, s):
+        ctx.s = s
+        return ops.fold_patches(_c(x), c, h, w, s)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.unfold_patches(_c(g), ctx.s), None, None, None, None
+
+
+class RsclLossFn(Function):
+    """rsclLoss.forward (networks/rscl.py:42-64); gradient to the queries only (keys and queue are detached)."""
+
+    @staticmethod
+    def forward(ctx, q, k, k0, queue, T):
+        q, k, k0, queue = _c(q), _c(k), _c(k0), _c(queue).clone()
+        ctx.save_for_backward(q, k, k0, queue)
+        ctx.T = T
+        return ops.rscl_loss(q, k, k0, queue, T)
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, k0, queue = ctx.saved_tensors
+        return ops.rscl_loss_bwd(q, k, k0, queue, _c(g), ctx.T), None, None, None, None

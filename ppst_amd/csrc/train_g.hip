@@ -613,3 +613,124 @@ extern "C" int ppst_scale_by(const void* x, const void* s, void* y, int64_t n, v
   PPST_LAUNCH(scale_by_kernel, dim3(tg_grid(n)), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)s, (float*)y, n);
   return PPST_LAUNCH_CHECK();
 }
+
+// --------------------------------------------------------- rsclLoss backward --
+// d(mean_i CE(logits_i, 0))/dq (networks/rscl.py:42-64; keys, queue detached; the current-batch logits are the constant
+// -10 of the reference's eye(1) mask): dq_i = g/(n*T) * [ (p_pos - 1) k_i + sum_j p_j key_j ],  key_j = queue[:, j] | k0_j.
+__global__ __launch_bounds__(256) void rscl_rows_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ k0, const float* __restrict__ queue,
+                                                            const float* __restrict__ gout, float* __restrict__ dq, int n, int n0,
+                                                            int C, int K, float invT) {
+  __shared__ float red[256];
+  __shared__ float prob[512];
+  __shared__ float s_pos, s_max, s_sum;
+  const int i = blockIdx.x, t = threadIdx.x;
+  const float* qi = q + (int64_t)i * C;
+  float p = 0.f;
+  for (int c = t; c < C; c += 256) p += qi[c] * k[(int64_t)i * C + c];
+  red[t] = p;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+  if (t == 0) s_pos = red[0] * invT;
+  __syncthreads();
+  float lmax = fmaxf(s_pos, -10.0f * invT);
+  for (int j = t; j < K + n0; j += 256) {
+    float d = 0.f;
+    if (j < K) for (int c = 0; c < C; ++c) d += qi[c] * queue[(int64_t)c * K + j];
+    else { const float* kj = k0 + (int64_t)(j - K) * C; for (int c = 0; c < C; ++c) d += qi[c] * kj[c]; }
+    prob[j] = d * invT;
+    lmax = fmaxf(lmax, prob[j]);
+  }
+  red[t] = lmax;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] = fmaxf(red[t], red[t + o]); __syncthreads(); }
+  if (t == 0) s_max = red[0];
+  __syncthreads();
+  const float m = s_max;
+  float lsum = 0.f;
+  for (int j = t; j < K + n0; j += 256) { prob[j] = expf(prob[j] - m); lsum += prob[j]; }
+  if (t == 0) lsum += expf(s_pos - m) + (float)n * expf(-10.0f * invT - m);
+  red[t] = lsum;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+  if (t == 0) s_sum = red[0];
+  __syncthreads();
+  const float inv_sum = 1.f / s_sum;
+  const float ppos = expf(s_pos - m) * inv_sum;
+  const float f = gout[0] * invT / (float)n;
+  for (int c = t; c < C; c += 256) {
+    float acc = (ppos - 1.f) * k[(int64_t)i * C + c];
+    const float* qr = queue + (int64_t)c * K;
+    for (int j = 0; j < K; ++j) acc += prob[j] * inv_sum * qr[j];
+    for (int j = 0; j < n0; ++j) acc += prob[K + j] * inv_sum * k0[(int64_t)j * C + c];
+    dq[(int64_t)i * C + c] = f * acc;
+  }
+}
+extern "C" int ppst_rscl_loss_bwd(const void* q, const void* k, const void* k0, const void* queue, const void* gout, void* dq, int n,
+                                  int n0, int C, int K, float nce_T, void* stream) {
+  if (n <= 0 || n > 64 || n0 < 0 || C <= 0 || K <= 0 || K + n0 > 512 || nce_T <= 0.f) return PPST_EINVAL;
+  if (!q || !k || !queue || !gout || !dq || (n0 > 0 && !k0)) return PPST_ENULL;
+  PPST_LAUNCH(rscl_rows_bwd_kernel, dim3(n), dim3(256), 0, as_stream(stream), (const float*)q, (const float*)k, (const float*)k0,
+              (const float*)queue, (const float*)gout, (float*)dq, n, n0, C, K, 1.0f / nce_T);
+  return PPST_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------ Rselfcorr backward --
+// forward (ppst_model.py:330-339, ppst_rselfcorr): per 4x4 patch X[c][i] (c < 64 channels, i < 16 positions):
+//   d[:, i] = X[:, i] - mean_c;  z[:, i] = d[:, i] / (||d[:, i]|| + eps);  G[i][j] = sum_c z[c][i] z[c][j]  (out channel i*16+j).
+// backward: dz[c][i] = sum_j (dG[i][j] + dG[j][i]) z[c][j];  dd = inv*dz - (inv^2/nrm) (dz . d) d;  dX = dd - mean_c(dd).
+// One wave per patch, lane = channel.
+__global__ __launch_bounds__(256) void rselfcorr_bwd_kernel(const float* __restrict__ fea, const float* __restrict__ dout,
+                                                            float* __restrict__ dfea, int B, int H, int W, int dout_ld, float eps,
+                                                            int64_t npatch) {
+  __shared__ float S[4][16][16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int gy = H >> 2, gx = W >> 2;
+  for (int64_t p = (int64_t)blockIdx.x * 4 + wv; p < npatch; p += (int64_t)gridDim.x * 4) {
+    const int px = (int)(p % gx);
+    const int64_t r = p / gx;
+    const int py = (int)(r % gy), b = (int)(r / gy);
+    const float* go = dout + (((int64_t)b * gy + py) * gx + px) * dout_ld;
+    // S = dG + dG^T
+    for (int e = lane; e < 256; e += 64) {
+      const int i = e >> 4, j = e & 15;
+      S[wv][i][j] = go[i * 16 + j] + go[j * 16 + i];
+    }
+    float d[16], z[16], inv[16], nrm[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int iy = py * 4 + (i >> 2), ix = px * 4 + (i & 3);
+      const float v = fea[(((int64_t)b * H + iy) * W + ix) * 64 + lane];
+      const float m = wave_sum(v) * (1.f / 64.f);
+      d[i] = v - m;
+      nrm[i] = sqrtf(wave_sum(d[i] * d[i]));
+      inv[i] = 1.f / (nrm[i] + eps);
+      z[i] = d[i] * inv[i];
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float dz = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) dz += S[wv][i][j] * z[j];
+      const float dot = wave_sum(dz * d[i]);
+      float dd = inv[i] * dz - (nrm[i] > 0.f ? inv[i] * inv[i] / nrm[i] * dot * d[i] : 0.f);
+      dd -= wave_sum(dd) * (1.f / 64.f);
+      const int iy = py * 4 + (i >> 2), ix = px * 4 + (i & 3);
+      dfea[(((int64_t)b * H + iy) * W + ix) * 64 + lane] = dd;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+extern "C" int ppst_rselfcorr_bwd(const void* fea, const void* dout, void* dfea, int B, int H, int W, int C, int dout_ld, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || H % 4 || W % 4 || C != 64 || dout_ld < 256) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!fea || !dout || !dfea) return PPST_ENULL;
+  const int64_t npatch = (int64_t)B * (H / 4) * (W / 4);
+  int64_t blocks = cdiv64(npatch, 4);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  PPST_LAUNCH(rselfcorr_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)fea, (const float*)dout,
+              (float*)dfea, B, H, W, dout_ld, 2.220446049250313e-16f, npatch);
+  return PPST_LAUNCH_CHECK();
+}

@@ -22,7 +22,8 @@ TILE_ROWS = {"value": 16}  # conv tile rows: 8 (2 blocks per CU) or 16 (1 block 
 
 
 def set_precision(p):
-    assert p in (0, 1)
+    """0: bf16x3 (fp32-class, the measured path); 1: single-pass bf16; 2: exact fp32 MFMA (verification only, slow)."""
+    assert p in (0, 1, 2)
     PRECISION["value"] = p
 
 
@@ -306,6 +307,10 @@ class ConvPlan:
         # chunks per group (every group has the same count): ring depth hint for the kernel
         self.chunks_per_group = (len(cs) - 1) // self.n_groups
         self.scale = float(scale)
+        self.wsrc = wsrc
+        if self.precision == 2:      # exact-fp32 verification kernel reads the fp32 weights directly: nothing to pack
+            self.wpack = None
+            return
         n_tiles = (cout + self.bn - 1) // self.bn
         npl = 8 if self.precision == 0 else 4
         self.wpack = torch.empty(self.n_groups * n_tiles * self.nsteps * npl * self.bn * 8, dtype=torch.int16, device=dev)
@@ -370,7 +375,13 @@ class ConvPlan:
         a.flop_steps = self.flop_steps
         a.a_slots = min(3, self.chunks_per_group)
         a.early_a = self.early_a
-        check(lib.ppst_conv2d_mfma(ctypes.byref(a), _stream()), "ppst_conv2d_mfma")
+        if self.precision == 2:
+            sn, sc, sy, sx = self.wstrides
+            c_, ky_, kx_ = self.src_dev
+            check(lib.ppst_conv2d_f32(ctypes.byref(a), _p(self.wsrc), sn, sc, sy, sx, self.scale, _p(c_), _p(ky_), _p(kx_), _stream()),
+                  "ppst_conv2d_f32")
+        else:
+            check(lib.ppst_conv2d_mfma(ctypes.byref(a), _stream()), "ppst_conv2d_mfma")
         if stats:
             return out, st
         return out
@@ -709,6 +720,37 @@ def l1_grad(a, b, weight=1.0):
     da = torch.empty_like(a)
     check(lib.ppst_l1_grad(_p(a), _p(b), _p(da), a.numel(), float(weight), _stream()), "ppst_l1_grad")
     return da
+
+
+def rscl_loss_bwd(q, k, k0, queue, gout, nce_T=0.07):
+    for t in (q, k, k0, queue, gout):
+        _chk(t)
+    q, k, k0, queue = q.contiguous(), k.contiguous(), k0.contiguous(), queue.contiguous()
+    n, C = q.shape
+    dq = torch.empty_like(q)
+    check(lib.ppst_rscl_loss_bwd(_p(q), _p(k), _p(k0), _p(queue), _p(gout.contiguous()), _p(dq), n, k0.shape[0], C, queue.shape[1],
+                                 float(nce_T), _stream()), "ppst_rscl_loss_bwd")
+    return dq
+
+
+def rselfcorr_bwd(fea, dout):
+    ld = _nhwc_ld(fea)
+    B, H, W, C = fea.shape
+    assert ld == C
+    dout_ld = _nhwc_ld(dout)
+    dfea = torch.empty_like(fea)
+    check(lib.ppst_rselfcorr_bwd(_p(fea), _p(dout), _p(dfea), B, H, W, C, dout_ld, _stream()), "ppst_rselfcorr_bwd")
+    return dfea
+
+
+def transpose_last2(x):
+    """(b, M, N) -> (b, N, M) contiguous (the layout-transpose kernel)."""
+    _chk(x)
+    x = x.contiguous()
+    b, M, N = x.shape
+    y = torch.empty((b, N, M), device=x.device, dtype=torch.float32)
+    check(lib.ppst_nchw_to_nhwc(_p(x), _p(y), b, M, 1, N, _stream()), "ppst_nchw_to_nhwc")
+    return y
 
 
 def scale_by(x, s):

@@ -62,6 +62,35 @@ class RsclQueues(nn.Module):
         p[0] = (ptr + bs) % self.queue_size
 
 
+    def enqueue_all(self, keys_per_layer):
+        """The 24 ``dequeue_and_enqueue(keys[i:i+1], layer)`` calls of one generator iteration (ppst_model.py:214-219:
+        six keys for each of the four queues) with ONE collective: the reference all_gathers 24 separate [1, 2048]
+        tensors (8 KB each, latency bound); here the keys of all layers travel as one [24, 2048] all_gather and are
+        written in the reference's order (call i enqueues rank 0..world-1's i-th key).  keys_per_layer: list of
+        (keys (n, C), layer)."""
+        import torch.distributed as dist
+        allk = torch.cat([k for k, _ in keys_per_layer], 0).contiguous()
+        world = 1
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            world = dist.get_world_size()
+            parts = [torch.empty_like(allk) for _ in range(world)]
+            dist.all_gather(parts, allk)
+            parts[dist.get_rank()] = allk
+            allk = torch.stack(parts, 1)                       # (N, world, C): call i -> ranks in order
+        else:
+            allk = allk[:, None]
+        assert self.queue_size % world == 0
+        o = 0
+        for keys, layer in keys_per_layer:
+            q, p = getattr(self, "queue_data_A%d" % layer), getattr(self, "queue_ptr_A%d" % layer)
+            ptr = int(p)
+            for i in range(keys.shape[0]):
+                q[:, ptr:ptr + world] = allk[o + i].t()
+                ptr = (ptr + world) % self.queue_size
+            p[0] = ptr
+            o += keys.shape[0]
+
+
 class PPSTModel(nn.Module):
     def __init__(self, opt=None, with_D=False, with_nce=False):
         super().__init__()
@@ -273,14 +302,15 @@ class PPSTModel(nn.Module):
             metrics["L1_dist"] = ops.l1_mean(cyc, real[:B // 2].contiguous(), 1.0)
             losses["G_L1_cyc"] = metrics["L1_dist"] * 3
             s1 = s2 = 0.0
+            pending = []
             for lid in range(0, 12, 3):
                 li = lid // 3
                 key0, keyw = torch.cat(pro_ms[lid:lid + 3], 0), torch.cat(pro_mw[lid:lid + 3], 0)
                 query, query_r = torch.cat(pro_3m[lid:lid + 3], 0), torch.cat(pro_2m[lid:lid + 3], 0)
                 s1 = s1 + self.criterionNCE(query, keyw, key0, li)
                 s2 = s2 + self.criterionNCE(query_r, key0, keyw, li)
-                for keys in (key0[0:1], key0[1:2], key0[2:3], keyw[0:1], keyw[1:2], keyw[2:3]):
-                    self.criterionNCE.dequeue_and_enqueue(keys, li)
+                pending.append((torch.cat((key0[0:3], keyw[0:3]), 0), li))
+            self.criterionNCE.enqueue_all(pending)     # each layer has its own queue: the enqueues can follow the losses
             losses["G_styleContmix"] = s1 * lam("lambda_StyleCon", 1.0)
             losses["G_styleContrec"] = s2 * lam("lambda_StyleCon", 1.0)
         if lam("lambda_GAN", 1.0) > 0.0:

@@ -315,6 +315,7 @@ class GeneratorTrainer:
             metrics["L1_dist"] = A.L1LossFn.apply(cyc, real[:B // 2].contiguous(), 1.0)
             losses["G_L1_cyc"] = A.L1LossFn.apply(cyc, real[:B // 2].contiguous(), 3.0)
             s1 = s2 = None
+            pending = []
             for lid in range(0, 12, 3):
                 li = lid // 3
                 key0 = torch.cat(pro_ms[lid:lid + 3], 0).detach()
@@ -325,7 +326,8 @@ class GeneratorTrainer:
                 b = A.RsclLossFn.apply(query_r, key0, keyw, queue, lam("nce_T", 0.07))
                 s1 = a if s1 is None else s1 + a
                 s2 = b if s2 is None else s2 + b
-                m.criterionNCE.enqueue_many(torch.cat((key0[0:3], keyw[0:3]), 0), li)
+                pending.append((torch.cat((key0[0:3], keyw[0:3]), 0), li))
+            m.criterionNCE.enqueue_all(pending)
             lsc = lam("lambda_StyleCon", 1.0)
             losses["G_styleContmix"] = s1 if lsc == 1.0 else s1 * lsc
             losses["G_styleContrec"] = s2 if lsc == 1.0 else s2 * lsc

@@ -77,7 +77,13 @@ def check_block(name, gpu_fn, ref_fn, inputs, tol=3e-5, layouts=None):
     gi = {k: (nhwc(v) if layouts.get(k) == "act" else v).to(dev).requires_grad_(v.is_floating_point()) for k, v in inputs.items()}
     ri = {k: v.double().requires_grad_(v.is_floating_point()) for k, v in inputs.items()}
     yo = gpu_fn(gi)
-    yr = ref_fn(ri)
+    # leaky-relu gates: a pre-activation within rounding of 0 takes the other slope on the two sides and changes that
+    # element's gradient by a factor 5 -- ref functions that take ``gate`` use the sign of the GPU's own output
+    import inspect
+    if "gate" in inspect.signature(ref_fn).parameters:
+        yr = ref_fn(ri, gate=(nchw(yo) if yo.dim() == 4 else yo).detach().double().cpu())
+    else:
+        yr = ref_fn(ri)
     out_act = yr.dim() == 4
     report(name + " fwd", nchw(yo) if out_act else yo, yr, tol)
     gr = torch.randn_like(yr)
@@ -93,6 +99,12 @@ def check_block(name, gpu_fn, ref_fn, inputs, tol=3e-5, layouts=None):
             print("%-52s FAIL no gradient" % (name + " d" + k), flush=True)
             continue
         report(name + " d/d" + k, nchw(a) if layouts.get(k) == "act" else a, b, tol)
+
+
+def lrelu_gated(z, bias, gate):
+    """fused_leaky_relu with the slope chosen by the sign of ``gate`` (= the other side's output)."""
+    z = z + bias.view(1, -1, 1, 1)
+    return torch.where(gate > 0, z, z * 0.2) * math.sqrt(2.0)
 
 
 def refpad(x, mode, p=1):
@@ -114,9 +126,9 @@ def t_blocks():
             net.params["w"] = i["w"]; net._cache.clear()
             return A.conv(i["x"], i["w"], net, "w", bias=i["b"], scale=0.7, pad_mode=mode, act=A.LRELU, noise_w=i["nw"], noise=noise.to(dev))
 
-        def ref(i, mode=mode, noise=noise):
+        def ref(i, gate, mode=mode, noise=noise):
             y = F.conv2d(refpad(i["x"], mode), i["w"] * 0.7) + i["nw"] * noise.double()
-            return O.fused_leaky_relu(y, i["b"])
+            return lrelu_gated(y, i["b"], gate)
         check_block("ConvFn 3x3 %s +bias+noise+lrelu" % tag, gpu, ref, ins, layouts={"x": "act"})
     w = rn(128, 64, 1, 1) * 0.1
     net = MiniNet(w=w)
@@ -132,9 +144,9 @@ def t_blocks():
         net.params["w"] = i["w"]; net._cache.clear()
         return A.conv(i["x"], i["w"], net, "w", bias=i["b"], kind="convT", act=A.LRELU)
 
-    def ref(i):
+    def ref(i, gate):
         y = F.conv_transpose2d(i["x"], O.upscale_weight(i["w"]), stride=2, padding=1)
-        return O.fused_leaky_relu(y, i["b"])
+        return lrelu_gated(y, i["b"], gate)
     check_block("ConvFn convT (fused 4x4 s2 upscale)", gpu, ref, dict(x=rn(2, 32, 64, 64), w=w, b=rn(64) * 0.1), layouts={"x": "act"})
     # ---- BlurConvFn (zero pad 4-tap as in D, reflect 3-tap as in E1/E2), BlurDownFn
     for (taps, p0, p1, mode, tag) in (((1, 3, 3, 1), 2, 2, A.Z, "D"), ((1, 2, 1), 2, 1, A.REFLECT, "E")):
@@ -146,13 +158,13 @@ def t_blocks():
             net.params["w"] = i["w"]; net._cache.clear()
             return A.blur_conv(i["x"], i["w"], net, "w", "k", bias=i["b"], scale=0.6, p0=p0, p1=p1, pad_mode=mode, act=A.LRELU)
 
-        def ref(i, k=k, p0=p0, p1=p1, mode=mode):
+        def ref(i, gate, k=k, p0=p0, p1=p1, mode=mode):
             x = i["x"]
             if mode == A.REFLECT:
                 x = O.upfirdn2d(F.pad(x, (p0, p1, p0, p1), mode="reflect"), k.double(), pad=(0, 0))
             else:
                 x = O.upfirdn2d(x, k.double(), pad=(p0, p1))
-            return O.fused_leaky_relu(F.conv2d(x, i["w"] * 0.6, stride=2), i["b"])
+            return lrelu_gated(F.conv2d(x, i["w"] * 0.6, stride=2), i["b"], gate)
         check_block("BlurConvFn %s" % tag, gpu, ref, dict(x=rn(2, 32, 32, 40), w=w, b=rn(64) * 0.1), layouts={"x": "act"})
         ps = (len(taps) - 2)
         q0, q1 = (ps + 1) // 2, ps // 2
@@ -231,6 +243,49 @@ def t_blocks():
     check_block("LsganFn", lambda i: A.LsganFn.apply(i["p"], 1.0, 0.5), lambda i: (0.5 * ((i["p"] - 1) ** 2).mean()).view(1), dict(p=pr), tol=5e-6)
 
 
+def t_blocks2():
+    """correspondence / NCE blocks of training stage 2."""
+    import train_oracle as TO
+    rn = torch.randn
+    f1 = rn(1, 64, 32, 32)
+    check_block("RSelfCorrFn", lambda i: A.RSelfCorrFn.apply(i["x"]), lambda i: _rself_ref(i["x"]),
+                dict(x=f1), layouts={"x": "act"}, tol=2e-5)
+    # corrm on a smooth-ish feature field so the T = 0.01 softmax is not a pure arg-max
+    fk = rn(1, 512, 8, 8) + 2.0 * rn(1, 512, 1, 1)
+    fq = fk + 0.3 * rn(1, 512, 8, 8)
+    check_block("CorrMFn", lambda i: A.CorrMFn.apply(i["k"], i["q"]), lambda i: O.corrm(i["k"], i["q"]), dict(k=fk, q=fq),
+                layouts={"k": "act", "q": "act"}, tol=5e-4)
+    corr = torch.softmax(rn(2, 64, 64) * 2, -1)
+    V = rn(2, 64, 96)
+
+    def refwarp(i):
+        full = torch.matmul(i["c"], i["v"])
+        det = torch.matmul(i["c"].detach(), i["v"])
+        return torch.cat((full[..., :32], det[..., 32:]), -1)
+    check_block("WarpGemmFn (corr live on 32 ch)", lambda i: A.WarpGemmFn.apply(i["c"], i["v"], 32), refwarp, dict(c=corr, v=V), tol=5e-6)
+    mask = (torch.rand(2, 3, 32, 32) > 0.5).float()
+    corr16 = torch.softmax(rn(2, 16, 16) * 2, -1)
+
+    def gpuw(i):
+        patches = ops.unfold_patches(mask.to(dev), 8)
+        return nhwc(A.FoldFn.apply(A.GemmConstBFn.apply(i["c"], patches), 3, 32, 32, 8))   # NCHW -> the harness's NHWC
+    check_block("mask warp (GemmConstB + Fold)", gpuw, lambda i: O.model_warp(mask.double(), i["c"]), dict(c=corr16), tol=5e-6)
+    q, k, k0 = (F.normalize(rn(6, 2048)) for _ in range(3))
+    queue = F.normalize(rn(2048, 128), dim=0)
+    check_block("RsclLossFn", lambda i: A.RsclLossFn.apply(i["q"], k.to(dev), k0.to(dev), queue.to(dev), 0.07),
+                lambda i: TO.rscl_loss(i["q"], k.double(), k0.double(), queue.double(), 0.07).view(1), dict(q=q), tol=2e-5)
+
+
+def _rself_ref(fea):
+    """PPSTModel.Rselfcorr (ppst_model.py:330-339) for any H, W divisible by 4."""
+    B, C, H, W = fea.shape
+    f = F.unfold(fea, kernel_size=4, stride=4).permute(0, 2, 1).reshape(B, -1, C, 16).permute(0, 2, 1, 3)
+    f = f - f.mean(dim=1, keepdim=True)
+    f = f / (torch.norm(f, 2, 1, keepdim=True) + sys.float_info.epsilon)
+    corr = torch.sum(torch.matmul(f.unsqueeze(4), f.unsqueeze(4).permute(0, 1, 2, 4, 3)).reshape(B, C, f.shape[2], 256), dim=1)
+    return corr.permute(0, 2, 1).reshape(B, 256, H // 4, W // 4)
+
+
 # ---------------------------------------------------------------------------------------- full generator iteration
 def sample_idx(name, numel, n=2048):
     rng = np.random.default_rng([99, zlib.crc32(name.encode())])
@@ -246,7 +301,7 @@ def gstep_inputs(B=2, size=512):
     return real, mask, W.make_noise(31, B, S=size // 8)
 
 
-def compare_gstep(stage, tol_max=5e-3, tol_l2=5e-3, verbose=True):
+def compare_gstep(stage, tol_max=5e-3, tol_l2=5e-3, verbose=True, precision=0):
     """-> list of (name, ok).  Losses <= 1e-3; every parameter gradient: max|d| <= tol_max * max|ref| over the
     reference's sampled entries and ||d||_2 <= tol_l2 * ||ref||_2."""
     from ppst_amd.ppst_model import Options, create_model
@@ -256,12 +311,20 @@ def compare_gstep(stage, tol_max=5e-3, tol_l2=5e-3, verbose=True):
     if stage == 1:
         over["lambda_StyleCon"] = 0.0
     sd = W.make_state_dict(17, bias_std=0.1, noise_weight=0.1)
+    ops.set_precision(precision)     # 0: the production bf16x3 convs; 2: the exact-fp32 verification kernel
+    if verbose:
+        print("---- generator iteration, stage %d, conv precision %s" % (stage, {0: "bf16x3", 2: "exact fp32"}[precision]), flush=True)
     m = create_model(Options(**over), state_dict=sd, with_D=True, with_nce=True)
     real, mask, noise = gstep_inputs()
     m.noise = {k: v.to(dev) for k, v in noise.items()}
     tr = GeneratorTrainer(m)
+    import time
+    t0 = time.time()
     out = tr.losses_and_grads(real.to(dev), mask.to(dev))
     torch.cuda.synchronize()
+    ops.set_precision(0)
+    if verbose:
+        print("forward + backward: %.1f s" % (time.time() - t0), flush=True)
     res = []
     for k in [f[5:] for f in g.files if f.startswith("loss.")]:
         ref = float(g["loss." + k])
@@ -271,30 +334,47 @@ def compare_gstep(stage, tol_max=5e-3, tol_l2=5e-3, verbose=True):
         res.append(("loss " + k, ok))
         if verbose:
             print("loss %-20s %s got %.6f ref %.6f" % (k, "ok  " if ok else "FAIL", got, ref), flush=True)
+    # float64 run of the same reference code, when the fixture is there: the rounding-free gradients.  Many of these
+    # gradients are heavily cancelling sums (bias / noise-weight gradients over 10^5..10^8 terms), and the reference's own
+    # float32 values differ from the float64 ones -- and from each other where it computes the same quantity three
+    # times (StyledConv's conv.bias / bias / activate.bias) -- by more than 5e-3.  The bar per tensor:
+    #   err(ours vs f64) <= max(5e-3, 2 * err(reference f32 vs f64)),  error = max|d| / max|ref| and l2-relative.
+    p64 = os.path.join(GOLD, "gstep512_s%d_f64.npz" % stage)
+    g64 = np.load(p64) if os.path.exists(p64) else None
     worst = []
     for net in ("G", "E1", "E2"):
         fp = tr.fp[net]
         for name in fp.names:
             key = "grad.%s.%s" % (net, name)
             got = fp.g(name).double().cpu().numpy()
-            ref = g[key + ".samples"].astype(np.float64)
-            scale = float(g[key + ".stats"][2])
-            d = got[sample_idx(key, got.size)] - ref
-            if scale == 0.0:
-                ok = float(np.abs(got).max()) == 0.0
+            idx = sample_idx(key, got.size)
+            ref32 = g[key + ".samples"].astype(np.float64)
+            truth = g64[key + ".samples"].astype(np.float64) if g64 is not None else ref32
+            scale = float((g64 if g64 is not None else g)[key + ".stats"][2])
+            d = got[idx] - truth
+            if scale < 1e-6:
+                # a bias in front of an instance norm (ToRGB.bias, ToSpatialCode.1.Conv.bias ...) or an unused parameter:
+                # the exact gradient is 0 and the reference's value is rounding noise -- ours must be noise-sized too
+                ok = float(np.abs(got).max()) <= 1e-5
                 e_max = e_l2 = float(np.abs(got).max())
+                floor_max = floor_l2 = 0.0
             else:
                 e_max = float(np.abs(d).max() / scale)
-                e_l2 = float(np.linalg.norm(d) / (np.linalg.norm(ref) + 1e-30))
-                ok = e_max <= tol_max and e_l2 <= tol_l2
+                e_l2 = float(np.linalg.norm(d) / (np.linalg.norm(truth) + 1e-30))
+                dr = ref32 - truth
+                floor_max = float(np.abs(dr).max() / scale)
+                floor_l2 = float(np.linalg.norm(dr) / (np.linalg.norm(truth) + 1e-30))
+                ok = e_max <= max(tol_max, 2 * floor_max) and e_l2 <= max(tol_l2, 2 * floor_l2)
             res.append((key, ok))
-            worst.append((e_max, e_l2, key, ok, scale))
+            worst.append((e_max, e_l2, key, ok, scale, floor_max, floor_l2))
     worst.sort(reverse=True)
     if verbose:
         nbad = sum(1 for w_ in worst if not w_[3])
-        print("stage %d: %d parameter gradients, %d outside the bar (max %.0e, l2 %.0e); worst:" % (stage, len(worst), nbad, tol_max, tol_l2), flush=True)
-        for e_max, e_l2, key, ok, scale in worst[:25]:
-            print("  %-64s %s max %.3e l2 %.3e (ref absmax %.3e)" % (key, "ok  " if ok else "FAIL", e_max, e_l2, scale), flush=True)
+        print("stage %d: %d parameter gradients, %d outside the bar (max %.0e, l2 %.0e; truth = %s); worst 25 and every failure:" % (
+            stage, len(worst), nbad, tol_max, tol_l2, "reference in float64" if g64 is not None else "reference in float32"), flush=True)
+        for n_, (e_max, e_l2, key, ok, scale, fm, fl) in enumerate(worst):
+            if n_ < 25 or not ok:
+                print("  %-62s %s max %.2e l2 %.2e | ref32-vs-f64 max %.2e l2 %.2e | absmax %.2e" % (key, "ok  " if ok else "FAIL", e_max, e_l2, fm, fl, scale), flush=True)
     return res
 
 
@@ -304,6 +384,14 @@ def t_s1():
 
 def t_s2():
     RES.extend(compare_gstep(2))
+
+
+def t_s1x():
+    RES.extend(compare_gstep(1, precision=2))
+
+
+def t_s2x():
+    RES.extend(compare_gstep(2, precision=2))
 
 
 def run(fn):
@@ -318,10 +406,16 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("blocks", "all"):
         run(t_blocks)
+    if what in ("blocks", "blocks2", "all"):
+        run(t_blocks2)
     if what in ("s1", "all"):
         run(t_s1)
     if what in ("s2", "all"):
         run(t_s2)
+    if what in ("s1x", "exact"):
+        run(t_s1x)
+    if what in ("s2x", "exact"):
+        run(t_s2x)
     bad = [n for n, ok in RES if not ok]
     print("SUMMARY: %d checks, %d failed" % (len(RES), len(bad)))
     for n in bad[:60]:
