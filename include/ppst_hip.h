@@ -111,7 +111,7 @@ typedef struct ppst_conv_step {
  *  scale    multiplied in (EqualConv2d runtime scale, stylegan2_layers.py:177)
  *  src_*    DEVICE int32 arrays [n_groups*nsteps]: the K-slice of step s of group g is
  *           w[n][src_c .. src_c+31][src_ky][src_kx]
- *  bn       64 or 128 = N tile of the kernel variant that will consume the blob
+ *  bn       64, 128 or 256 = N tile of the kernel variant that will consume the blob
  *  out      n_groups * ceil(cout/bn) * nsteps * (precision==0 ? 8 : 4) * bn * 8 bf16 */
 int ppst_conv_pack(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx,
                    float scale, int cout, int bn,
@@ -164,6 +164,10 @@ typedef struct ppst_conv_args {
                                     (step i opens a chunk), bit 1 = step i+1 opens a chunk and bits 8.. = that chunk's
                                     channel offset: the kernel then requests a chunk's activations one step earlier
                                     (HBM latency no longer stalls the staging store).  0: bits 1.. are ignored. */
+  int32_t variant;               /* 0: the 8-wave kernel (512 threads, wave tile 64 px x 64 ch; bn 64 / 128).
+                                    1: the fat-wave kernel (conv_mfma2.hip: 256 threads = one wave per SIMD, wave tile
+                                    128 px x 64 / 128 ch; bn 128 / 256; precision 0 only).  Its activation ring has two
+                                    slots: every chunk of the step table must span >= 2 steps (the early_a promise). */
 } ppst_conv_args;
 
 int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream);

@@ -40,7 +40,7 @@ class ConvArgs(ctypes.Structure):
         ("in_off_y", i32), ("in_off_x", i32), ("out_sy", i32), ("out_sx", i32),
         ("act", i32), ("precision", i32), ("res_ld", i32), ("tile_h", i32), ("tile_w", i32),
         ("halo", i32), ("bn", i32), ("in_scale_shift", vp), ("in_prelu", vp), ("in_c", i32), ("in_act", i32),
-        ("flop_steps", i32), ("tile_rows", i32), ("a_slots", i32), ("early_a", i32),
+        ("flop_steps", i32), ("tile_rows", i32), ("a_slots", i32), ("early_a", i32), ("variant", i32),
     ]
 
 

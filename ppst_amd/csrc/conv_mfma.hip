@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict_
 extern "C" int ppst_conv_pack(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx, float scale, int cout, int bn,
                               const int32_t* src_c, const int32_t* src_ky, const int32_t* src_kx, int nsteps, int n_groups,
                               int precision, void* out, void* stream) {
-  if (cout <= 0 || (bn != 64 && bn != 128) || nsteps <= 0 || (n_groups != 1 && n_groups != 4) || precision < 0 || precision > 1)
+  if (cout <= 0 || (bn != 64 && bn != 128 && bn != 256) || nsteps <= 0 || (n_groups != 1 && n_groups != 4) || precision < 0 || precision > 1)
     return PPST_EINVAL;
   if (!w || !src_c || !src_ky || !src_kx || !out) return PPST_ENULL;
   int n_tiles = (cout + bn - 1) / bn;
@@ -673,6 +673,8 @@ extern "C" int ppst_prof_detail(int idx, double* ms, double* flop, int32_t* info
   return PPST_OK;
 }
 
+int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int tiles_x, hipStream_t st);   // conv_mfma2.hip
+
 extern "C" int ppst_conv_tiles(int tile_h, int tile_w, int tile_rows) { return cdiv(tile_h, tile_rows) * cdiv(tile_w, 16); }
 
 template <int WM, int WN, int HALO, bool X3, int NAS = 0>
@@ -686,7 +688,9 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   if (a->B < 0 || a->in_h <= 0 || a->in_w <= 0 || a->in_ld <= 0 || a->in_ld % 4 || a->out_h <= 0 || a->out_w <= 0 ||
       a->out_ld < a->cout || a->cout <= 0 || a->cout % 4 || a->out_ld % 4 || (a->residual && a->res_ld % 4) || a->nsteps <= 0 || (a->n_groups != 1 && a->n_groups != 4) || a->pad_mode < 0 ||
       a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 || a->precision < 0 ||
-      a->precision > 1 || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128) || (a->residual && a->res_ld < a->cout) ||
+      a->precision > 1 || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128 && a->bn != 256) || (a->residual && a->res_ld < a->cout) ||
+      a->variant < 0 || a->variant > 1 || (a->variant == 0 && a->bn == 256) ||
+      (a->variant == 1 && (a->precision != 0 || a->bn == 64 || !a->early_a)) ||
       (a->tile_rows != 16) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
     return PPST_EINVAL;
   // the scattered output must reach into the output tensor (elements beyond it are dropped)
@@ -728,6 +732,11 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
     int inf[8] = {a->B, a->tile_h, a->tile_w, a->nsteps, a->cout, a->n_groups, a->halo, a->bn};
     for (int i = 0; i < 8; ++i) g_info[slot][i] = inf[i];
     (void)hipEventRecord(g_ev[slot][0], st);
+  }
+  if (a->variant == 1) {
+    int e2 = ppst_conv2d_mfma2_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st);
+    if (slot >= 0) (void)hipEventRecord(g_ev[slot][1], st);
+    return e2;
   }
   const bool x3 = a->precision == 0;
 #define DISPATCH(WM_, WN_)                                                                                         \

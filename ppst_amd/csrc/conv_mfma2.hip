@@ -1,0 +1,399 @@
+// Fused implicit-GEMM convolution, "one fat wave per SIMD" variant (round 2).
+//
+// Same operation, step tables, weight blobs' meaning, padding modes, normalise-on-load and epilogue as conv_mfma.hip
+// (the StyledConv / EqualConv2d conv of stylegan2_layers.py:184-193, 305-347, 467-475) -- a different decomposition:
+//
+//   conv_mfma.hip : 512 threads = 8 waves (2 per SIMD), wave tile 64 px x 64 ch  (4 x 4 MFMA tiles, 48 MFMAs / K-step)
+//   this file     : 256 threads = 4 waves (1 per SIMD), wave tile 128 px x 16*NT ch (8 x NT tiles, NT = 4 or 8:
+//                   96 / 192 MFMAs per wave and K-step), block tile 16x16 px x (128 | 256) channels, up to 512 VGPRs.
+//
+// Why (profiles/r01_conv_trace.txt): the 8-wave kernel's K-step took ~2450 cycles for the 1536 its
+// MFMAs need.  v_mfma_f32_16x16x32_bf16 holds its SIMD's issue port for 8 of its 16 cycles, so a step leaves 768 issue
+// cycles for everything else, and the two co-resident waves needed ~2 x 100 non-MFMA instructions (LDS fragment reads,
+// address arithmetic, descriptor handling, DMA issue, waits) ~ 800-1000 cycles: issue-bound, not matrix-bound.  Per
+// K-step the non-MFMA work of a wave is almost independent of its tile, so doubling / quadrupling the MFMAs per wave
+// (and halving the wave count) puts the same overhead beside 2-4x the matrix work: 24 or 32 ds_read_b128 for 96 or
+// 192 MFMAs (0.25 / 0.17 per MFMA instead of 0.33).  The 256-channel tile also halves the number of times an
+// activation tile is fetched on the 256/512-channel layers (PMC showed reads at 2.0x the algorithmic bytes).
+//
+// LDS: activation ring of 2 slots (43 KB each; legal because every chunk of the step table spans >= 2 steps -- the
+// host only selects this kernel for such tables) + weight ring of 2 slots (16 / 32 KB) = 118 / 151 KB, one block per CU.
+#include "common.h"
+
+struct Conv2KArgs {
+  const float* x;
+  const unsigned short* wpack;
+  const int4* steps;
+  float* y;
+  const float* bias;
+  const float* noise;
+  const float* prelu;
+  float* stats;
+  const float* residual;
+  float noise_weight, out_scale;
+  int B, in_h, in_w, in_ld, out_h, out_w, out_ld, cout;
+  int nsteps, n_groups, pad_mode, in_off_y, in_off_x, out_sy, out_sx, act, res_ld, tile_h, tile_w;
+  int tiles_y, tiles_x, n_tiles;
+  const float* in_ss;
+  const float* in_prelu;
+  int in_c, in_act;
+  int early_a;
+};
+
+__device__ __forceinline__ int pad_index2(int i, int n, int mode) {
+  if (mode == PPST_PAD_REFLECT) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+  }
+  return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+
+template <int NT, int HALO, bool INSS>
+__global__ __launch_bounds__(256, 1) void conv_mfma2_kernel(Conv2KArgs a) {
+  constexpr int NTH = 256;
+  constexpr int MT = 8;                                   // m-tiles (16-pixel rows) per wave
+  constexpr int TH = 16, TW = 16;
+  constexpr int HH = TH + 2 * HALO, HW = TW + 2 * HALO, HP = HH * HW;
+  constexpr int PLANE = ((HP * 16 + 255) / 256) * 256;    // bytes
+  constexpr int ABUF = 8 * PLANE;                         // hi g0..3, lo g0..3
+  constexpr int BN = 2 * 16 * NT;                         // 2 N-waves
+  constexpr int BPLANE = BN * 16;
+  constexpr int BBUF = 8 * BPLANE;
+  constexpr int NA = 2;
+  constexpr int EPI_TILE = 64 * 36;
+  constexpr int EPI_BYTES = 4 * EPI_TILE * 4 + 2 * BN * 2 * 4;
+  constexpr int MAIN_BYTES = NA * ABUF + 2 * BBUF;
+  __shared__ __attribute__((aligned(256))) unsigned char smem[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
+  unsigned char* smA = smem;
+  unsigned char* smB = smem + NA * ABUF;
+
+  // XCD-aware block -> (n index, m tile) map (bijective remap, N-major order): as conv_mfma.hip
+  const int nwg = gridDim.x;
+  int wid;
+  {
+    int id = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int m_count = a.B * a.tiles_y * a.tiles_x;
+  const int nidx = wid / m_count;
+  int midx = wid - nidx * m_count;
+  const int group = nidx / a.n_tiles, ntile = nidx - group * a.n_tiles;
+  const int b = midx / (a.tiles_y * a.tiles_x);
+  midx -= b * a.tiles_y * a.tiles_x;
+  const int tyi = midx / a.tiles_x, txi = midx - tyi * a.tiles_x;
+  const int ty0 = tyi * TH, tx0 = txi * TW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wm = wave >> 1;
+  const int r16 = lane & 15, g = lane >> 4;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) int4* StepPtr;
+#else
+  typedef const int4* StepPtr;
+#endif
+  StepPtr steps = (StepPtr)(a.steps + (int64_t)group * a.nsteps);
+  const unsigned char* wblob = (const unsigned char*)a.wpack + ((int64_t)nidx * a.nsteps) * BBUF;
+  const float* xb = a.x + (int64_t)b * a.in_h * a.in_w * a.in_ld;
+
+  // ---- A staging (as conv_mfma.hip: one wave-instruction = 8 pixels x 128 B; fp32 -> bf16 hi/lo planes)
+  constexpr int A_WCH = (HP + 7) / 8;
+  constexpr int A_IT2 = (A_WCH * 64 + NTH - 1) / NTH;
+  float4 ra[A_IT2];
+  constexpr int A_NLOADS = A_IT2 + (INSS ? 2 : 0);
+  int aoff[A_IT2];
+#pragma unroll
+  for (int it = 0; it < A_IT2; ++it) {
+    int i = tid + it * NTH;
+    int l = i & 63;
+    int pix = (i >> 6) * 8 + ((l >> 1) & 7), q4 = (l >> 4) * 2 + (l & 1);
+    int o = -1;
+    if (pix < HP) {
+      int hy = pix / HW, hx = pix - hy * HW;
+      int iy = ty0 + hy - HALO + a.in_off_y, ix = tx0 + hx - HALO + a.in_off_x;
+      bool inb = iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w;
+      if (inb || a.pad_mode != PPST_PAD_ZERO) {
+        iy = pad_index2(iy, a.in_h, a.pad_mode);
+        ix = pad_index2(ix, a.in_w, a.pad_mode);
+        o = (iy * a.in_w + ix) * a.in_ld + q4 * 4;
+      }
+    }
+    aoff[it] = o;
+  }
+  float4 ras0 = make_float4(1.f, 0.f, 1.f, 0.f), ras1 = ras0;
+  const int q4lane = ((tid & 63) >> 4) * 2 + (tid & 1);
+  const float in_slope = (INSS && a.in_act == PPST_ACT_PRELU && a.in_prelu) ? a.in_prelu[0] : 0.f;
+  auto a_load = [&](int chan_off) {
+#pragma unroll
+    for (int it = 0; it < A_IT2; ++it) ra[it] = *(const float4*)(xb + (aoff[it] >= 0 ? aoff[it] : 0) + chan_off);
+    if (INSS) {
+      const float4* p = (const float4*)(a.in_ss + ((int64_t)b * a.in_c + chan_off + q4lane * 4) * 2);
+      ras0 = p[0];
+      ras1 = p[1];
+    }
+  };
+  auto in_act = [&](float t) -> float {
+    if (a.in_act == PPST_ACT_LRELU) return (t > 0.f ? t : t * 0.2f) * 1.41421356237309515f;
+    if (a.in_act == PPST_ACT_PRELU) return t >= 0.f ? t : t * in_slope;
+    return t;
+  };
+  auto a_store = [&](int slot) {
+    unsigned char* base = smA + slot * ABUF;
+#pragma unroll
+    for (int it = 0; it < A_IT2; ++it) {
+      int i = tid + it * NTH;
+      int l = i & 63;
+      int pix = (i >> 6) * 8 + ((l >> 1) & 7);
+      if (pix < HP) {
+        float4 v = ra[it];
+        if (aoff[it] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (INSS && aoff[it] >= 0) {
+          v.x = in_act(ras0.x * v.x + ras0.y); v.y = in_act(ras0.z * v.y + ras0.w);
+          v.z = in_act(ras1.x * v.z + ras1.y); v.w = in_act(ras1.z * v.w + ras1.w);
+        }
+        unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
+        split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
+        int off = (l >> 4) * PLANE + pix * 16 + (l & 1) * 8;
+        *(uint2*)(base + off) = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
+        *(uint2*)(base + 4 * PLANE + off) = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+      }
+    }
+  };
+  // ---- B staging: LDS-DMA of the pre-packed step blob (global_load_lds_dwordx4, 1 KB per wave-instruction)
+  constexpr int B_WI = BBUF / 1024;
+  constexpr int B_PER_WAVE = B_WI / 4;
+  auto b_dma = [&](int s, int slot) {
+    const unsigned char* src = wblob + (int64_t)s * BBUF + lane * 16;
+    unsigned char* dst = smB + slot * BBUF;
+#pragma unroll
+    for (int it = 0; it < B_PER_WAVE; ++it) {
+      const int wi = it * 4 + wave;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + wi * 1024),
+                                       (void __attribute__((address_space(3)))*)(dst + wi * 1024), 16, 0, 0);
+    }
+  };
+  // fragment addresses
+#define B_ADDR(slot, nt) (smB + (slot) * BBUF + g * BPLANE + ((wn * NT + (nt)) * 16 + r16) * 16)
+#define A_OFF(slot, dy, dx, mt) ((slot) * ABUF + g * PLANE + (((wm * MT + (mt) + HALO + (dy)) * HW + HALO + (dx) + r16) * 16))
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: steps 0 and 1 staged, descriptors of step 2 fetched
+  int4 d = steps[0];
+  int dy0 = d.y, dx0 = d.z, sl0 = 0;
+  int dy1 = d.y, dx1 = d.z, sl1 = 0;
+  a_load(d.x);
+  b_dma(0, 0);
+  a_store(0);
+  if (a.nsteps > 1) {
+    d = steps[1];
+    dy1 = d.y; dx1 = d.z;
+    sl1 = (d.w & 1) ? 1 : 0;
+    b_dma(1, 1);
+    if (d.w & 1) a_load(d.x);
+    if (d.w & 1) a_store(sl1);
+    if (a.early_a && (d.w & 2)) a_load(d.w >> 8);
+  }
+  int4 dE = d, dO = d;
+  if (a.nsteps > 2) dE = steps[2];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  bf16x8 b0h[NT], b0l[NT], b1h[NT], b1l[NT];
+  bf16x8 ah, al;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    b0h[nt] = *(const bf16x8*)B_ADDR(0, nt);
+    b0l[nt] = *(const bf16x8*)(B_ADDR(0, nt) + 4 * BPLANE);
+  }
+  ah = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, 0));
+  al = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, 0) + 4 * PLANE);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+
+  // One K-step.  bc* = this step's weight fragments (read during the previous step); bn* receive the next step's:
+  // one n-tile pair per m-tile group, so the 2*NT reads are spread over the step.  The next A fragment (m-tile mt+1, or
+  // m-tile 0 of step s+1) is read one group ahead.  The non-MFMA head (descriptor, weight DMA, activation loads) follows
+  // the first group's MFMAs; the staging store of a new chunk sits under the second-to-last group.
+#define STEP2(bch, bcl, bnh, bnl, s, D2, D3, H1, H2)                                                        \
+  {                                                                                                           \
+    const bool has1 = (H1), has2 = (H2);                                                                      \
+    bool newA2 = false, a_early = false;                                                                      \
+    int sl2 = sl1;                                                                                            \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                       \
+      bf16x8 nh, nl;                                                                                          \
+      if (mt < MT - 1) {                                                                                      \
+        nh = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1));                                            \
+        nl = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1) + 4 * PLANE);                                \
+      } else if (has1) {                                                                                      \
+        nh = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0));                                                 \
+        nl = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0) + 4 * PLANE);                                     \
+      }                                                                                                       \
+      if (has1 && mt >= 1 && mt - 1 < NT) {   /* next step's B fragment pair nt = mt - 1 */                   \
+        bnh[mt - 1] = *(const bf16x8*)B_ADDR(((s) + 1) & 1, mt - 1);                                          \
+        bnl[mt - 1] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, mt - 1) + 4 * BPLANE);                           \
+      }                                                                                                       \
+      if (NT == 8 && has1 && mt == MT - 1) {                                                                  \
+        bnh[NT - 1] = *(const bf16x8*)B_ADDR(((s) + 1) & 1, NT - 1);                                          \
+        bnl[NT - 1] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, NT - 1) + 4 * BPLANE);                           \
+      }                                                                                                       \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                     \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bch[nt], acc[mt][nt], 0, 0, 0);             \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcl[nt], acc[mt][nt], 0, 0, 0);             \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bch[nt], acc[mt][nt], 0, 0, 0);             \
+      }                                                                                                       \
+      if (mt == 0) {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        D3 = steps[(s) + 3];                                                                                  \
+        newA2 = has2 && (D2.w & 1);                                                                           \
+        if (newA2) sl2 = sl1 ^ 1;                                                                             \
+        if (has2) b_dma((s) + 2, (s) & 1);                                                                    \
+        __builtin_amdgcn_sched_barrier(0);   /* DMA issued before the activation loads: counted vmcnt below */ \
+        {                                                                                                     \
+          const bool ld_ = a.early_a ? (has2 && (D2.w & 2)) : newA2;                                          \
+          const int ch_ = a.early_a ? (D2.w >> 8) : D2.x;                                                     \
+          if (ld_) { a_load(ch_); a_early = a.early_a != 0; }                                                 \
+        }                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+      }                                                                                                       \
+      ah = nh;                                                                                                \
+      al = nl;                                                                                                \
+      if (mt == MT - 2 && newA2) a_store(sl2);                                                                \
+    }                                                                                                         \
+    if (a_early) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_NLOADS) : "memory");                              \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                           \
+    dy0 = dy1; dx0 = dx1; sl0 = sl1;                                                                          \
+    if (has2) { dy1 = D2.y; dx1 = D2.z; }                                                                     \
+    sl1 = sl2;                                                                                                \
+  }
+  int s = 0;
+  for (; s + 3 < a.nsteps; s += 2) {
+    STEP2(b0h, b0l, b1h, b1l, s, dE, dO, true, true)
+    STEP2(b1h, b1l, b0h, b0l, s + 1, dO, dE, true, true)
+  }
+  for (; s < a.nsteps; s += 2) {
+    STEP2(b0h, b0l, b1h, b1l, s, dE, dO, s + 1 < a.nsteps, s + 2 < a.nsteps)
+    if (s + 1 < a.nsteps) STEP2(b1h, b1l, b0h, b0l, s + 1, dO, dE, s + 2 < a.nsteps, s + 3 < a.nsteps)
+  }
+#undef STEP2
+#undef A_OFF
+#undef B_ADDR
+
+  // ---- epilogue (as conv_mfma.hip): per wave, passes of 64 pixels x 32 channels through an LDS transposition tile
+  const int gy = group >> 1, gx = group & 1;
+  const int act = a.act & 0xff;
+  const bool res_after = (a.act >> 8) & 1;
+  const float slope = (act == PPST_ACT_PRELU && a.prelu) ? a.prelu[0] : 0.f;
+  float* tw = (float*)smem + wave * EPI_TILE;
+  float* red = (float*)smem + 4 * EPI_TILE;            // [2 (wm)][BN][2]
+  const int f8 = lane & 7, prow = lane >> 3;
+  float4 s1a[NT / 2], s2a[NT / 2];
+#pragma unroll
+  for (int i = 0; i < NT / 2; ++i) { s1a[i] = make_float4(0.f, 0.f, 0.f, 0.f); s2a[i] = s1a[i]; }
+#pragma unroll
+  for (int mh = 0; mh < MT / 4; ++mh) {
+#pragma unroll
+    for (int pass = 0; pass < NT / 2; ++pass) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int ntl = 0; ntl < 2; ++ntl)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) tw[(mt * 16 + g * 4 + j) * 36 + ntl * 16 + r16] = acc[mh * 4 + mt][pass * 2 + ntl][j];
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_wave_barrier();
+      const int nl0 = wn * (16 * NT) + pass * 32 + f8 * 4;
+      const int n0 = ntile * BN + nl0;
+      const bool nok = n0 < a.cout;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (nok && a.bias) bv = *(const float4*)(a.bias + n0);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int p = it * 8 + prow;
+        const int ty = ty0 + wm * MT + mh * 4 + (p >> 4), tx = tx0 + (p & 15);
+        float4 v = *(const float4*)(tw + p * 36 + f8 * 4);
+        if (nok && ty < a.tile_h && tx < a.tile_w) {
+          const int oy = ty * a.out_sy + (a.n_groups > 1 ? gy : 0), ox = tx * a.out_sx + (a.n_groups > 1 ? gx : 0);
+          if (oy >= a.out_h || ox >= a.out_w) continue;
+          const int64_t opix = ((int64_t)b * a.out_h + oy) * a.out_w + ox;
+          float nz = a.noise ? a.noise_weight * a.noise[opix] : 0.f;
+          float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a.residual) rv = *(const float4*)(a.residual + opix * a.res_ld + n0);
+          float o[4] = {v.x + bv.x + nz, v.y + bv.y + nz, v.z + bv.z + nz, v.w + bv.w + nz};
+          const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float t = o[c];
+            if (!res_after) t += r4[c];
+            if (act == PPST_ACT_LRELU) t = (t > 0.f ? t : t * 0.2f) * 1.41421356237309515f;
+            else if (act == PPST_ACT_PRELU) t = t >= 0.f ? t : t * slope;
+            if (res_after) t += r4[c];
+            o[c] = t * a.out_scale;
+          }
+          *(float4*)(a.y + opix * a.out_ld + n0) = make_float4(o[0], o[1], o[2], o[3]);
+          s1a[pass].x += o[0]; s1a[pass].y += o[1]; s1a[pass].z += o[2]; s1a[pass].w += o[3];
+          s2a[pass].x += o[0] * o[0]; s2a[pass].y += o[1] * o[1]; s2a[pass].z += o[2] * o[2]; s2a[pass].w += o[3] * o[3];
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (a.stats) {
+    __syncthreads();     // the transposition tiles are done: `red` lies behind them, but other waves may still be in their last pass
+#pragma unroll
+    for (int pass = 0; pass < NT / 2; ++pass) {
+      float4 s1 = s1a[pass], s2 = s2a[pass];
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64); s1.z += __shfl_xor(s1.z, o, 64); s1.w += __shfl_xor(s1.w, o, 64);
+        s2.x += __shfl_xor(s2.x, o, 64); s2.y += __shfl_xor(s2.y, o, 64); s2.z += __shfl_xor(s2.z, o, 64); s2.w += __shfl_xor(s2.w, o, 64);
+      }
+      if (prow == 0) {
+        float* r = red + (wm * BN + wn * (16 * NT) + pass * 32 + f8 * 4) * 2;
+        r[0] = s1.x; r[1] = s2.x; r[2] = s1.y; r[3] = s2.y; r[4] = s1.z; r[5] = s2.z; r[6] = s1.w; r[7] = s2.w;
+      }
+    }
+    __syncthreads();
+    const int tiles = a.tiles_y * a.tiles_x;
+    for (int nl = tid; nl < BN; nl += NTH) {
+      int n = ntile * BN + nl;
+      if (n < a.cout) {
+        float* o = a.stats + ((((int64_t)b * a.n_groups + group) * tiles + tyi * a.tiles_x + txi) * a.cout + n) * 2;
+        o[0] = red[nl * 2] + red[(BN + nl) * 2];
+        o[1] = red[nl * 2 + 1] + red[(BN + nl) * 2 + 1];
+      }
+    }
+  }
+}
+
+// Entry used by ppst_conv2d_mfma (conv_mfma.hip) when a->bn is 256, or 128 with the fat-wave variant requested.
+int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int tiles_x, hipStream_t st) {
+  Conv2KArgs k;
+  k.x = (const float*)a->x; k.wpack = (const unsigned short*)a->wpack; k.steps = (const int4*)a->steps; k.y = (float*)a->y;
+  k.bias = (const float*)a->bias; k.noise = (const float*)a->noise; k.prelu = (const float*)a->prelu;
+  k.stats = (float*)a->stats; k.residual = (const float*)a->residual;
+  k.noise_weight = a->noise_weight; k.out_scale = a->out_scale;
+  k.B = a->B; k.in_h = a->in_h; k.in_w = a->in_w; k.in_ld = a->in_ld; k.out_h = a->out_h; k.out_w = a->out_w;
+  k.out_ld = a->out_ld; k.cout = a->cout; k.nsteps = a->nsteps; k.n_groups = a->n_groups; k.pad_mode = a->pad_mode;
+  k.in_off_y = a->in_off_y; k.in_off_x = a->in_off_x; k.out_sy = a->out_sy; k.out_sx = a->out_sx; k.act = a->act;
+  k.res_ld = a->res_ld; k.tile_h = a->tile_h; k.tile_w = a->tile_w;
+  k.tiles_y = tiles_y; k.tiles_x = tiles_x; k.n_tiles = n_tiles;
+  k.in_ss = (const float*)a->in_scale_shift; k.in_prelu = (const float*)a->in_prelu;
+  k.in_c = a->in_c; k.in_act = a->in_act;
+  k.early_a = a->early_a ? 1 : 0;
+  const int blocks = a->n_groups * n_tiles * a->B * tiles_y * tiles_x;
+#define L2(NT_, HALO_)                                                                                          \
+  do {                                                                                                          \
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<NT_, HALO_, true>), dim3(blocks), dim3(256), 0, st, k);         \
+    else PPST_LAUNCH((conv_mfma2_kernel<NT_, HALO_, false>), dim3(blocks), dim3(256), 0, st, k);                \
+  } while (0)
+  if (a->bn == 256) { if (a->halo) L2(8, 1); else L2(8, 0); }
+  else { if (a->halo) L2(4, 1); else L2(4, 0); }
+#undef L2
+  return PPST_LAUNCH_CHECK();
+}

@@ -19,6 +19,13 @@ RES_BEFORE_ACT = 1 << 8
 
 PRECISION = {"value": 0}  # 0 = bf16x3 (fp32-class), 1 = single-pass bf16
 TILE_ROWS = {"value": 16}  # conv tile rows: 8 (2 blocks per CU) or 16 (1 block per CU)
+# 1: layers whose step table allows it run on the fat-wave kernel (conv_mfma2.hip: 4 waves, 128-px x 64/128-ch wave
+# tiles, N tile 128 or 256); 0 (default): everything on the 8-wave kernel.  Measured on MI355X (round 2, same process
+# class of runs, tests/conv_table.py): the fat-wave kernel is bit-identical but SLOWER -- 256->256@256^2 395 vs 417 TF/s
+# with the 256-channel tile, 128->128@512^2 261 vs 356 with the 128-channel tile; whole step 284-294 vs 330 TF/s: one
+# in-order wave per SIMD exposes its own LDS / wait latency, which two co-resident waves hide for each other.
+CONV_VARIANT = {"value": 0}
+FAT_MIN_BLOCKS = 384        # prefer the 256-channel tile only when the launch still has >= this many blocks
 
 
 def set_precision(p):
@@ -311,11 +318,24 @@ class ConvPlan:
         if self.precision == 2:      # exact-fp32 verification kernel reads the fp32 weights directly: nothing to pack
             self.wpack = None
             return
-        n_tiles = (cout + self.bn - 1) // self.bn
+        self._packs = {}
+        self.wpack = self.pack_for(self.bn)
+
+    def pack_for(self, bn):
+        """packed weight blob for N tile ``bn`` (built on first use: the fat-wave kernel wants 128 / 256)."""
+        hit = self._packs.get(bn)
+        if hit is not None:
+            return hit
+        cout = self.cout
+        sn, sc, sy, sx = self.wstrides
+        src_c, src_ky, src_kx = self.src_dev
+        n_tiles = (cout + bn - 1) // bn
         npl = 8 if self.precision == 0 else 4
-        self.wpack = torch.empty(self.n_groups * n_tiles * self.nsteps * npl * self.bn * 8, dtype=torch.int16, device=dev)
-        check(lib.ppst_conv_pack(_p(wsrc), sn, sc, sy, sx, float(scale), cout, self.bn, _p(src_c), _p(src_ky), _p(src_kx),
-                                 self.nsteps, self.n_groups, self.precision, _p(self.wpack), _stream()), "ppst_conv_pack")
+        wpack = torch.empty(self.n_groups * n_tiles * self.nsteps * npl * bn * 8, dtype=torch.int16, device=self.steps.device)
+        check(lib.ppst_conv_pack(_p(self.wsrc), sn, sc, sy, sx, float(self.scale), cout, bn, _p(src_c), _p(src_ky), _p(src_kx),
+                                 self.nsteps, self.n_groups, self.precision, _p(wpack), _stream()), "ppst_conv_pack")
+        self._packs[bn] = wpack
+        return wpack
 
     def __call__(self, x, bias=None, noise=None, noise_weight=0.0, act=ACT_NONE, prelu=None, stats=False,
                  residual=None, out=None, out_scale=1.0, pad_mode=PAD_ZERO, out_hw=None, res_after_act=False,
@@ -356,8 +376,16 @@ class ConvPlan:
         if stats:
             tiles = lib.ppst_conv_tiles(th, tw, rows)
             st = torch.empty((B, self.n_groups * tiles, self.cout, 2), device=x.device, dtype=torch.float32)
+        # kernel variant / N tile: the fat-wave kernel needs chunks of >= 2 steps (3x3, transposed, stride-2 tables) and
+        # pays off from 128 output channels; its 256-channel tile only when the grid still covers the chip
+        variant, bn = 0, self.bn
+        if CONV_VARIANT["value"] == 1 and self.precision == 0 and self.early_a and self.cout >= 128:
+            variant = 1
+            tiles16 = ((th + 15) // 16) * ((tw + 15) // 16) * B * self.n_groups
+            bn = 256 if (self.cout % 256 == 0 and tiles16 * (self.cout // 256) >= FAT_MIN_BLOCKS) else 128
         a = _lib.ConvArgs()
-        a.x, a.wpack, a.steps, a.y = _p(x), _p(self.wpack), _p(self.steps), _p(out)
+        a.x, a.wpack, a.steps, a.y = _p(x), _p(self.pack_for(bn) if self.precision != 2 else None), _p(self.steps), _p(out)
+        a.variant = variant
         a.bias, a.noise, a.prelu, a.stats = _p(bias), _p(noise), _p(prelu), _p(st)
         a.residual = _p(residual)
         a.res_ld = _nhwc_ld(residual, "residual") if residual is not None else 0
@@ -368,7 +396,7 @@ class ConvPlan:
         a.in_off_y = a.in_off_x = 0
         a.out_sy = a.out_sx = osy
         a.act, a.precision = act | (0x100 if res_after_act else 0), self.precision
-        a.tile_h, a.tile_w, a.halo, a.bn, a.tile_rows = th, tw, self.halo, self.bn, rows
+        a.tile_h, a.tile_w, a.halo, a.bn, a.tile_rows = th, tw, self.halo, bn, rows
         _chk(in_ss, "in_ss"); _chk(in_prelu, "in_prelu")
         a.in_scale_shift, a.in_prelu, a.in_act = _p(in_ss), _p(in_prelu), in_act
         a.in_c = in_ss.shape[1] if in_ss is not None else 0

@@ -348,6 +348,10 @@ def d_step_images(model, real, lambda_StyleCon=1.0, want_codes=False):
     assert B % 2 == 0, "Batch size must be even on each GPU."
     sp = model.E1(real)
     gl, _ = model.E2(real)
+    nzh = {k: v[:B // 2] for k, v in model.noise.items()} if isinstance(model.noise, dict) else model.noise
+    if int(getattr(model.opt, "training_stage", 2)) == 1:      # ppst_model.py:109-112, 128-131
+        rec = model.G(sp[:B // 2], [g[:B // 2] for g in gl], noise=nzh)
+        return (rec, None, sp, gl) if want_codes else (rec, None)
     _, feas, feas1 = model.G(sp, gl, extract_features=True, noise=model.noise)
     sps = torch.cat((feas, model.Rselfcorr(feas1)), dim=1)
     corrms = model.corrm(sps, glue.swap(sps))

@@ -367,3 +367,59 @@ class GeneratorTrainer:
         self.all_reduce()
         self.adam()
         return losses
+
+
+class PPSTOptimizer:
+    """optimizers/ppst_optimizer.py:PPSTOptimizer on the HIP path: the D / G alternation of ``train_one_step``
+    (:60-71 -- the first call is a discriminator iteration, the mode names are swapped in the reference), Adam for G, E1,
+    E2 (lr, betas) and for D (lazy-regularisation corrected lr / betas, :46-49), the lazy R1 penalty every
+    ``R1_once_every`` discriminator iterations (:116-126) and ``D_total`` (:127).  ``data_i`` = {"real_A": (B,3,H,W),
+    "mask_A": (B,3,H,W) one-hot}.  Gradients are averaged over ranks with one flat all-reduce per network (RCCL)."""
+
+    def __init__(self, model, lr=1e-3, beta1=0.0, beta2=0.99, R1_once_every=16, world=1):
+        self.model, self.opt = model, model.opt
+        self.train_mode_counter = 0
+        self.R1_once_every = R1_once_every
+        self.gen = GeneratorTrainer(model, lr, beta1, beta2, world)
+        self.dis = self.gen.d_trainer
+        if self.dis is not None:
+            c = R1_once_every / (1 + R1_once_every)
+            self.dis.lr, self.dis.b1, self.dis.b2 = lr * c, beta1 ** c, beta2 ** c
+            self.dis.R1_once_every, self.dis.world = R1_once_every, world
+
+    def prepare_images(self, data_i):
+        return data_i["real_A"], data_i["mask_A"]
+
+    def toggle_training_mode(self):
+        modes = ["discriminator", "generator"]
+        self.train_mode_counter = (self.train_mode_counter + 1) % len(modes)
+        return modes[self.train_mode_counter]
+
+    def train_one_step(self, data_i, total_steps_so_far=0):
+        images, mask = self.prepare_images(data_i)
+        if self.toggle_training_mode() == "generator":
+            losses = self.train_discriminator_one_step(images, mask)
+        else:
+            losses = self.train_generator_one_step(images, mask)
+        return {k: float(v.float().mean()) for k, v in losses.items()}      # util.to_numpy
+
+    def train_generator_one_step(self, images, mask):
+        return self.gen.train_step(images, mask)
+
+    def train_discriminator_one_step(self, images, mask):
+        if float(getattr(self.opt, "lambda_GAN", 1.0)) == 0.0 or self.dis is None:
+            return {}
+        with torch.no_grad():
+            losses = self.dis.train_step(self.model, images, float(getattr(self.opt, "lambda_StyleCon", 1.0)),
+                                         float(getattr(self.opt, "lambda_R1", 10.0)))
+        if hasattr(self.model, "num_discriminator_iters"):
+            self.model.num_discriminator_iters.add_(1)
+        total = None
+        for v in losses.values():
+            m_ = v.float().mean()
+            total = m_ if total is None else total + m_
+        losses["D_total"] = total
+        return losses
+
+    def save(self, total_steps_so_far):
+        return self.model.save(total_steps_so_far)

@@ -9,12 +9,17 @@ from bench import swap_step
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 prec = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 ops.set_precision(prec)
+if len(sys.argv) > 3:
+    ops.CONV_VARIANT["value"] = int(sys.argv[3])        # 0: 8-wave kernel everywhere; 1: fat-wave kernel where eligible
+if len(sys.argv) > 4:
+    ops.FAT_MIN_BLOCKS = int(sys.argv[4])
 dev = torch.device("cuda", 0)
 sd = W.make_state_dict(0, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
 m = create_model(state_dict=sd, device=dev)
 m.noise = {k: v.to(dev) for k, v in W.make_noise(2, B).items()}
 imgs = W.synthetic_images(4, 2 * B).to(dev)
 with torch.no_grad():
+    swap_step(m, imgs[:B], imgs[B:], 1.0, glue)
     swap_step(m, imgs[:B], imgs[B:], 1.0, glue)
     torch.cuda.synchronize()
     ops.prof_enable(True)

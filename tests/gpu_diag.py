@@ -289,6 +289,51 @@ def t_conv():
     report("conv1x1 small cout (ToRGB)", nchw(y.cpu()), O.equal_conv2d(x, w, b), 3e-6)
 
 
+def t_conv_variants():
+    """The fat-wave kernel (conv_mfma2.hip, N tile 128 and 256) against the 8-wave kernel on the same plans: same MFMA
+    sequence per output element, so outputs must be bit-identical; tile statistics to rounding (other summation tree)."""
+    torch.manual_seed(5)
+    nz_ = torch.randn
+    cases = [
+        # name, B, Cin, Cout, H, W, kind, pad_mode, features
+        ("3x3 zero 64->128 48x40 bias+noise+lrelu+stats", 2, 64, 128, 48, 40, "conv", 0, "full"),
+        ("3x3 reflect 32->256 33x47", 2, 32, 256, 33, 47, "conv", 1, "plain"),
+        ("3x3 replicate 128->512 16x16 in_ss+prelu", 1, 128, 512, 16, 16, "conv", 2, "inss"),
+        ("3x3 zero 256->384 24x24 residual", 1, 256, 384, 24, 24, "conv", 0, "res"),
+        ("convT 64->256 20x12", 2, 64, 256, 20, 12, "convT", 0, "full"),
+        ("convT 128->128 16x16", 1, 128, 128, 16, 16, "convT", 0, "plain"),
+        ("dgrad 3x3 (128<-64) 32x32", 2, 64, 128, 32, 32, "dgrad", 0, "plain"),
+        ("dgradT (256->64 fwd) 16x16", 1, 64, 256, 16, 16, "dgradT", 0, "plain"),
+    ]
+    for name, B, ci, co, H, Wd, kind, pm, feat in cases:
+        w = g(nz_(co, ci, 3, 3) / math.sqrt(ci * 9))
+        outs = {}
+        for variant, minb in ((0, 384), (1, 1 << 30), (1, 0)):      # 8-wave; fat N=128; fat N=256 where Cout % 256 == 0
+            ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = variant, minb
+            plan = ops.ConvPlan(w, kind=kind)
+            cin_eff = plan.max_chan + 32
+            torch.manual_seed(11)
+            x = g(nz_(B, H, Wd, cin_eff))
+            kw = {}
+            oh, ow = (2 * H, 2 * Wd) if kind == "convT" else (H, Wd)
+            if feat == "full":
+                kw = dict(bias=g(nz_(plan.cout)), noise=g(nz_(B, 1, oh, ow)), noise_weight=0.3, act=ops.ACT_LRELU)
+            elif feat == "inss":
+                kw = dict(in_ss=g(torch.rand(B, cin_eff, 2) + 0.5), in_act=ops.ACT_PRELU, in_prelu=g(torch.tensor([0.25])),
+                          act=ops.ACT_PRELU, prelu=g(torch.tensor([0.1])))
+            elif feat == "res":
+                kw = dict(residual=g(nz_(B, oh, ow, plan.cout)), res_after_act=True, act=ops.ACT_LRELU, out_scale=0.7)
+            y, st = plan(x, pad_mode=pm, stats=True, **kw)
+            outs[(variant, minb)] = (y.cpu(), st.sum(1).cpu())
+        ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = 0, 384
+        y0, s0 = outs[(0, 384)]
+        for key, tag in (((1, 1 << 30), "N=128"), ((1, 0), "N=256|128")):
+            y1, s1 = outs[key]
+            RES.append(("fat conv %s %s bit-identical" % (tag, name), bool(torch.equal(y0, y1))))
+            print("fat conv %-9s %-52s %s max diff %.3e" % (tag, name, "ok  " if torch.equal(y0, y1) else "FAIL", (y0 - y1).abs().max().item()), flush=True)
+            report("fat conv %s %s stats" % (tag, name), s1, s0, 1e-5)
+
+
 def t_norm_pool():
     torch.manual_seed(3)
     for (B, C, H, Wd) in [(2, 64, 40, 40), (1, 3, 64, 64), (2, 512, 16, 16), (1, 128, 70, 30)]:
@@ -644,13 +689,15 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     print("device:", torch.cuda.get_device_name(0), flush=True)
     if which in ("ops", "all"):
-        for fn in (t_upfirdn2d, t_fused_act, t_layout_misc, t_conv, t_norm_pool, t_corr, t_guided):
+        for fn in (t_upfirdn2d, t_fused_act, t_layout_misc, t_conv, t_conv_variants, t_norm_pool, t_corr, t_guided):
             print("== " + fn.__name__, flush=True)
             run(fn)
             torch.cuda.synchronize()
     if which in ("nets", "all"):
         print("== t_networks", flush=True)
         run(t_networks)
+    if which == "convv":
+        run(t_conv_variants)
     if which == "trainops":
         run(t_train_ops)
     if which in ("train", "all"):
