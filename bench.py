@@ -124,14 +124,94 @@ def cpu_baseline(seed):
                       "median %.1f s (runs: %s)" % (dt, ", ".join("%.1f" % t for t in times))}
 
 
+DTYPE_NOTE = {"bf16x3": "bf16x3 (fp32 split into hi+lo bf16, 3 MFMA passes, fp32 accumulate)",
+              "bf16": "bf16 (single MFMA pass, fp32 accumulate / statistics / modulation)",
+              "fp16": "fp16 (single MFMA pass, fp32 accumulate / statistics / modulation)"}
+FLOP_PER_IMAGE_PASS = (23.7 + 22.7 + 753.9) * 1e9     # E1 + E2 + G with feature heads
+FLOP_PER_PAIR_PASS = (17.2 + 38.8 + 486.2) * 1e9      # corrm + E2 with warp + G decode
+
+
+def bench_grid(args, rank, world, dev, barrier, max_over_ranks):
+    """BASELINE configs[2]: swapping_grid over an 8 x 8 folder at 512x512 with the guided-filter post-process
+    (content_style_grid_generation_evaluator.py:36-99).  One step = the whole grid: 16 per-image passes + one exchange
+    + 64 pair passes, images and pairs sharded over the ranks (strong scaling: the grid is fixed as N grows)."""
+    from ppst_amd import weights as W
+    from ppst_amd.evaluation import swapping_grid
+    from ppst_amd.ppst_model import create_model
+    sd = W.make_state_dict(0, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
+    model = create_model(state_dict=sd, device=dev)
+    model.noise = {k: v.to(dev) for k, v in W.make_noise(2, 1).items()}      # one fixed row for every batch row
+    contents, styles = W.synthetic_images(4, 8).to(dev), W.synthetic_images(5, 8).to(dev)
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = swapping_grid(model, contents, styles, rank, world, smooth=True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = swapping_grid(model, contents, styles, rank, world, smooth=True)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+    assert all(torch.isfinite(v).all() for v in out.values())
+    pairs = 64 * args.steps
+    flop = args.steps * (16 * FLOP_PER_IMAGE_PASS + 64 * FLOP_PER_PAIR_PASS)
+    return {"metric": "512x512 grid swaps/sec (8x8 folder, guided filter on)", "value": pairs / dt, "unit": "swaps/s (all GPUs)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE_NOTE[args.precision], "data": "synthetic",
+            "config": {"workload": "swapping_grid 8x8 folder at 512 (BASELINE configs[2]): 16 image passes + 64 pair passes + guided filter",
+                       "sharding": "images k mod N, one all_gather of sp | fea||Rselfcorr (12.6 MB per image), pairs (i*8+j) mod N"},
+            "algorithmic_tflops_whole_job": flop / dt / 1e12}
+
+
+def bench_train(args, rank, world, dev, barrier, max_over_ranks):
+    """BASELINE configs[3]: CelebAMaskHQ_default train step at 512x512, batch 2 per GPU (the reference's default), random
+    init, synthetic images + label maps.  One step = one discriminator iteration (with the lazy R1 pass every 16th) and
+    one generator iteration (PPSTOptimizer.train_one_step twice), data parallel: flat gradient all-reduce per network."""
+    from ppst_amd import weights as W
+    from ppst_amd.ppst_model import Options, create_model
+    from ppst_amd.train_g import PPSTOptimizer
+    B = 2
+    sd = W.make_state_dict(0, bias_std=0.1, noise_weight=0.1)
+    model = create_model(Options(training_stage=2, lambda_Cycwarp=0.0), state_dict=sd, with_D=True, with_nce=True, device=dev)
+    model.noise = "random"
+    real = W.synthetic_images(40 + rank, B).to(dev)
+    g = torch.Generator().manual_seed(7 + rank)
+    lab = torch.randint(0, 3, (B, 32, 32), generator=g).repeat_interleave(16, 1).repeat_interleave(16, 2)
+    mask = torch.nn.functional.one_hot(lab, 3).permute(0, 3, 1, 2).float().contiguous().to(dev)
+    opt = PPSTOptimizer(model, world=world)
+    data = {"real_A": real, "mask_A": mask}
+    for _ in range(args.warmup):
+        opt.train_one_step(data, 0); opt.train_one_step(data, 0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dl = opt.train_one_step(data, 0)
+        gl = opt.train_one_step(data, 0)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    assert all(v == v for v in list(dl.values()) + list(gl.values())), "NaN loss"
+    imgs = world * B * args.steps
+    return {"metric": "512x512 train images/sec (one D + one G iteration per step)", "value": imgs / dt, "unit": "images/s (all GPUs)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NOTE[args.precision], "data": "synthetic",
+            "config": {"workload": "CelebAMaskHQ_default train step 512x512, batch 2 per GPU, training stage 2, lambda_Cycwarp 0 "
+                                   "(lpips unavailable), random init (BASELINE configs[3])",
+                       "collectives": "flat gradient all-reduce per network (D 29.0 M, G 42.5 M, E2 27.0 M, E1 0.83 M fp32) + one "
+                                      "[24, 2048] all_gather of the NCE keys"},
+            "losses": {**dl, **gl}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="swap", choices=["swap", "grid", "train"],
+                    help="swap: BASELINE configs[1] (the headline line); grid: configs[2], 8x8 folder at 512 with the guided filter, "
+                         "images and pairs sharded over the ranks; train: configs[3], one D (+ lazy R1) and one G iteration per step")
+    ap.add_argument("--conv-variant", type=int, default=None, help="0: 8-wave conv kernel (default); 1: fat-wave kernel where eligible")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -148,7 +228,29 @@ def main():
 
     from ppst_amd import glue, ops, weights as W
     from ppst_amd.ppst_model import create_model
-    ops.set_precision(0 if args.precision == "bf16x3" else 1)
+    ops.set_precision({"bf16x3": 0, "bf16": 1, "fp16": 3}[args.precision])
+    if args.conv_variant is not None:
+        ops.CONV_VARIANT["value"] = args.conv_variant
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(dt):
+        if dist is None:
+            return dt
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    if args.workload != "swap":
+        res = (bench_grid if args.workload == "grid" else bench_train)(args, rank, world, dev, barrier, max_over_ranks)
+        if rank == 0:
+            print(json.dumps(res))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     B = args.batch
     sd = W.make_state_dict(0, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
@@ -156,11 +258,6 @@ def main():
     model.noise = {k: v.to(dev) for k, v in W.make_noise(2 + rank, B).items()}
     imgs = W.synthetic_images(4 + rank, 2 * B).to(dev)
     content, style = imgs[:B].contiguous(), imgs[B:].contiguous()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -176,10 +273,7 @@ def main():
         ops.prof_enable(False)
     assert torch.isfinite(out).all()
 
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt)
 
     if rank == 0:
         swaps = world * B * args.steps
@@ -190,7 +284,7 @@ def main():
             "metric": "512x512 portrait swaps/sec/GPU", "value": swaps / dt, "unit": "swaps/s (all GPUs)",
             "per_gpu": swaps / dt / world, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3 (fp32 split into hi+lo bf16, 3 MFMA passes, fp32 accumulate)" if passes == 3 else "bf16",
+            "dtype": DTYPE_NOTE[args.precision],
             "data": "synthetic",
             "config": {"workload": "simple_swapping 512x512 batch=%d per GPU, generator+encoders forward only (BASELINE configs[1])" % B,
                        "recipe": "encode + 2x extract_feat_from_image + 2x Rselfcorr + corrm + encode2 + decode",

@@ -67,7 +67,12 @@ extern "C" int ppst_conv_clock_buffer(void* buf, int n) {   // diagnostic build 
   return hipMemcpyToSymbol(HIP_SYMBOL(g_clock_n), &n, sizeof(n)) == hipSuccess ? PPST_OK : PPST_EINVAL;
 }
 #endif
-template <int WM, int WN, int HALO, bool X3, bool INSS, int NAS = 0>
+// F16 (single-pass builds only): operands are IEEE half instead of bfloat16 (v_mfma_f32_16x16x32_f16): 11 significant
+// bits instead of 8 at the same MFMA rate -- the "fp16 generator" mode of BASELINE configs[4]; accumulation, instance-norm
+// statistics and StyleMod stay fp32 as in every mode.
+typedef _Float16 __attribute__((ext_vector_type(8))) half8;
+__device__ __forceinline__ unsigned short f2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+template <int WM, int WN, int HALO, bool X3, bool INSS, int NAS = 0, bool F16 = false>
 __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(ConvKArgs a) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TH = 4 * WM, TW = 16;
@@ -199,7 +204,8 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
           v.z = in_act(ras1.x * v.z + ras1.y); v.w = in_act(ras1.z * v.w + ras1.w);
         }
         unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
-        split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
+        if (F16) { h0 = f2h(v.x); h1 = f2h(v.y); h2 = f2h(v.z); h3 = f2h(v.w); l0 = l1 = l2 = l3 = 0; }
+        else { split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3); }
         int off = (l >> 4) * PLANE + pix * 16 + (l & 1) * 8;
         uint2 hv = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
         *(uint2*)(base + off) = hv;
@@ -343,7 +349,8 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
       acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bch[nt], acc[mt][nt], 0, 0, 0);       \
       acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcl[nt], acc[mt][nt], 0, 0, 0);       \
     }                                                                                                 \
-    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bch[nt], acc[mt][nt], 0, 0, 0);         \
+    if (F16) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah), __builtin_bit_cast(half8, bch[nt]), acc[mt][nt], 0, 0, 0); \
+    else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bch[nt], acc[mt][nt], 0, 0, 0);    \
   }
 #define TOP_WORK(bnh, bnl, s, D2)                                                                     \
   if (ABL_B(has2)) b_dma((s) + 2, (s) & 1);                                                           \
@@ -558,7 +565,7 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict_
                                                         int64_t sx, float scale, int cout, int bn,
                                                         const int* __restrict__ src_c, const int* __restrict__ src_ky,
                                                         const int* __restrict__ src_kx, int nsteps, int n_groups, int x3,
-                                                        unsigned short* __restrict__ out, int64_t total) {
+                                                        unsigned short* __restrict__ out, int64_t total, int f16) {
   const int n_tiles = (cout + bn - 1) / bn;
   const int npl = x3 ? 8 : 4;
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
@@ -576,7 +583,8 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict_
     for (int j = 0; j < 8; ++j) {
       float v = 0.f;
       if (n < cout && src_c[gs] >= 0) v = w[n * sn + (int64_t)(c0 + j) * sc + ky * sy + kx * sx] * scale;  // src_c < 0: zero-weight pad step
-      split_bf16(v, hi[j], lo[j]);
+      if (f16) { hi[j] = __builtin_bit_cast(unsigned short, (_Float16)v); lo[j] = 0; }
+      else split_bf16(v, hi[j], lo[j]);
     }
     int64_t blob = (((int64_t)group * n_tiles + ntile) * nsteps + s) * ((int64_t)npl * bn * 8);
     unsigned short* oh = out + blob + ((int64_t)g * bn + nl) * 8;
@@ -593,7 +601,8 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict_
 extern "C" int ppst_conv_pack(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx, float scale, int cout, int bn,
                               const int32_t* src_c, const int32_t* src_ky, const int32_t* src_kx, int nsteps, int n_groups,
                               int precision, void* out, void* stream) {
-  if (cout <= 0 || (bn != 64 && bn != 128 && bn != 256) || nsteps <= 0 || (n_groups != 1 && n_groups != 4) || precision < 0 || precision > 1)
+  if (cout <= 0 || (bn != 64 && bn != 128 && bn != 256) || nsteps <= 0 || (n_groups != 1 && n_groups != 4) ||
+      (precision != 0 && precision != 1 && precision != 3))
     return PPST_EINVAL;
   if (!w || !src_c || !src_ky || !src_kx || !out) return PPST_ENULL;
   int n_tiles = (cout + bn - 1) / bn;
@@ -601,7 +610,8 @@ extern "C" int ppst_conv_pack(const void* w, int64_t sn, int64_t sc, int64_t sy,
   int64_t blocks = cdiv64(total, 256);
   if (blocks > 4096) blocks = 4096;
   PPST_LAUNCH(conv_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)w, sn, sc, sy, sx,
-                     scale, cout, bn, src_c, src_ky, src_kx, nsteps, n_groups, precision == 0 ? 1 : 0, (unsigned short*)out, total);
+                     scale, cout, bn, src_c, src_ky, src_kx, nsteps, n_groups, precision == 0 ? 1 : 0, (unsigned short*)out, total,
+                     precision == 3 ? 1 : 0);
   return PPST_LAUNCH_CHECK();
 }
 
@@ -677,18 +687,18 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
 
 extern "C" int ppst_conv_tiles(int tile_h, int tile_w, int tile_rows) { return cdiv(tile_h, tile_rows) * cdiv(tile_w, 16); }
 
-template <int WM, int WN, int HALO, bool X3, int NAS = 0>
+template <int WM, int WN, int HALO, bool X3, int NAS = 0, bool F16 = false>
 static void launch_conv(const ConvKArgs& k, int blocks, hipStream_t st) {
-  if (k.in_ss) PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, true, NAS>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
-  else PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, false, NAS>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
+  if (k.in_ss) PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, true, NAS, F16>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
+  else PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, false, NAS, F16>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
 }
 
 extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   if (!a) return PPST_ENULL;
   if (a->B < 0 || a->in_h <= 0 || a->in_w <= 0 || a->in_ld <= 0 || a->in_ld % 4 || a->out_h <= 0 || a->out_w <= 0 ||
       a->out_ld < a->cout || a->cout <= 0 || a->cout % 4 || a->out_ld % 4 || (a->residual && a->res_ld % 4) || a->nsteps <= 0 || (a->n_groups != 1 && a->n_groups != 4) || a->pad_mode < 0 ||
-      a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 || a->precision < 0 ||
-      a->precision > 1 || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128 && a->bn != 256) || (a->residual && a->res_ld < a->cout) ||
+      a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 ||
+      (a->precision != 0 && a->precision != 1 && a->precision != 3) || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128 && a->bn != 256) || (a->residual && a->res_ld < a->cout) ||
       a->variant < 0 || a->variant > 1 || (a->variant == 0 && a->bn == 256) ||
       (a->variant == 1 && (a->precision != 0 || a->bn == 64 || !a->early_a)) ||
       (a->tile_rows != 16) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
@@ -739,10 +749,11 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
     return e2;
   }
   const bool x3 = a->precision == 0;
+  const bool f16 = a->precision == 3;
 #define DISPATCH(WM_, WN_)                                                                                         \
   do {                                                                                                             \
-    if (a->halo) { if (x3) launch_conv<WM_, WN_, 1, true>(k, blocks, st); else launch_conv<WM_, WN_, 1, false>(k, blocks, st); } \
-    else         { if (x3) launch_conv<WM_, WN_, 0, true>(k, blocks, st); else launch_conv<WM_, WN_, 0, false>(k, blocks, st); } \
+    if (a->halo) { if (x3) launch_conv<WM_, WN_, 1, true>(k, blocks, st); else if (f16) launch_conv<WM_, WN_, 1, false, 0, true>(k, blocks, st); else launch_conv<WM_, WN_, 1, false>(k, blocks, st); } \
+    else         { if (x3) launch_conv<WM_, WN_, 0, true>(k, blocks, st); else if (f16) launch_conv<WM_, WN_, 0, false, 0, true>(k, blocks, st); else launch_conv<WM_, WN_, 0, false>(k, blocks, st); } \
   } while (0)
   // (8-row tiles -- two 80-KB blocks per CU -- were measured 35 % slower than one 16-row block
   //  per CU on MI355X and are not instantiated; tile_rows == 8 is rejected above.)

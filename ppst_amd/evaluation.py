@@ -3,11 +3,13 @@
 * ``simple_swap``  = evaluation/simple_swapping_evaluator.py:38-76 (one content, one
   style, list of mix alphas) -- batched: B pairs at once.
 * ``swapping_grid`` = evaluation/content_style_grid_generation_evaluator.py:36-99
-  (N contents x M styles, guided-filter post-process with the content as guide) with the
-  per-image passes (encode, extract_feat_from_image, Rselfcorr) computed once per image
-  instead of once per pair, and the (content, style) pairs sharded over ranks:
-  pair (i, j) belongs to rank ((i * M + j) mod world) -- image-parallel, no collective on
-  the data path.
+  (N contents x M styles, guided-filter post-process with the content as guide) in two phases:
+    1. per-IMAGE passes (encode, extract_feat, Rselfcorr), computed once per image instead of once per pair and
+       sharded over ranks by image (image k of the N + M belongs to rank k mod world), batched;
+    2. ONE exchange: all_gather of the spatial codes (4.2 MB per content image) and of fea || Rselfcorr (8.4 MB per
+       image) -- RCCL on the GPU, the only data-path collective of inference (SURVEY.md section 8e);
+    3. per-PAIR passes (corrm, encode2, decode + guided filter), pair (i, j) on rank ((i * M + j) mod world), batched.
+  An 8 x 8 grid on 8 ranks costs each rank 2 image passes + 8 pair passes (~5.9 TFLOP) against 16 + 64 on one GPU.
 Image file I/O (PIL decode/resize/PNG) is left to the caller: tensors in, tensors out.
 """
 import torch
@@ -43,29 +45,89 @@ def shard_pairs(n_content, n_style, rank=0, world=1):
     return [(i, j) for i in range(n_content) for j in range(n_style) if (i * n_style + j) % world == rank]
 
 
-def swapping_grid(model, contents, styles, rank=0, world=1, smooth=True, pair_batch=8):
-    """contents (N,3,H,W), styles (M,3,H,W) on this rank's GPU (every rank holds all images:
-    they are small; only the pair work is sharded).  Returns {(i, j): image (3,H,W)} for the
-    pairs this rank owns."""
+def shard_images(n_content, n_style, rank=0, world=1):
+    """Images owned by ``rank``: image k (contents first, then styles) belongs to rank k mod world.
+    Returns (content indices, style indices)."""
+    own = [k for k in range(n_content + n_style) if k % world == rank]
+    return [k for k in own if k < n_content], [k - n_content for k in own if k >= n_content]
+
+
+def grid_image_pass(model, contents, styles, rank=0, world=1, image_batch=8):
+    """Phase 1: the per-image passes of this rank's images, batched.  Returns
+    (ci, sp (len(ci),256,h,w), fc (len(ci),512,h,w)), (si, fs (len(si),512,h,w)) -- NCHW-shaped like the commands return."""
+    ci, si = shard_images(contents.shape[0], styles.shape[0], rank, world)
+
+    def feats(imgs, want_sp):
+        sps, fs = [], []
+        for k in range(0, imgs.shape[0], image_batch):
+            img = imgs[k:k + image_batch]
+            sp, gl = model(img, command="encode")
+            f0, f1 = model(sp, gl, command="extract_feat")[1:]
+            fs.append(torch.cat((f0, model(f1, command="Rselfcorr")), dim=1).contiguous())
+            if want_sp:
+                sps.append(sp.contiguous())
+        return (torch.cat(sps, 0) if sps else None), (torch.cat(fs, 0) if fs else None)
+    sp_c, f_c = feats(contents[ci], True) if ci else (None, None)
+    _, f_s = feats(styles[si], False) if si else (None, None)
+    return (ci, sp_c, f_c), (si, f_s)
+
+
+def _gather_rows(local, idx, total, world, like):
+    """all_gather of per-image rows: ``local`` (len(idx), ...) of this rank -> (total, ...) table on every rank.
+    One padded all_gather_into_tensor (RCCL when the tensors live on the GPU, gloo on the CPU)."""
+    import torch.distributed as dist
+    per = (total + world - 1) // world
+    shape = tuple(like)
+    buf = torch.zeros((per,) + shape[1:], device=shape[0], dtype=torch.float32)
+    if local is not None:
+        buf[:local.shape[0]] = local
+    out = torch.empty((world * per,) + shape[1:], device=shape[0], dtype=torch.float32)
+    dist.all_gather_into_tensor(out, buf)
+    return out.view((world, per) + shape[1:])
+
+
+def grid_exchange(local_c, local_s, n_content, n_style, world, gathered=None):
+    """Phase 2: assemble the full tables {content i: (sp, fc)}, {style j: fs} from every rank's phase-1 output.
+    ``gathered``: list over ranks of phase-1 outputs (single-process simulation of N ranks); otherwise the live
+    process group is used.  Tensors keep the commands' NCHW shape; the storage layout is plain contiguous."""
+    table_c, table_s = {}, {}
+    if gathered is not None:
+        for (ci, sp_c, f_c), (si, f_s) in gathered:
+            for n, i in enumerate(ci):
+                table_c[i] = (sp_c[n:n + 1], f_c[n:n + 1])
+            for n, j in enumerate(si):
+                table_s[j] = f_s[n:n + 1]
+        return table_c, table_s
+    (ci, sp_c, f_c), (si, f_s) = local_c, local_s
+    if world == 1:
+        return grid_exchange(None, None, n_content, n_style, 1, gathered=[(local_c, local_s)])
+    ref = sp_c if sp_c is not None else (f_c if f_c is not None else f_s)
+    dev, h, w = ref.device, ref.shape[2], ref.shape[3]
+    # rows of one rank: its contents' (sp | fc) = 768 channels, its styles' fs = 512 channels
+    nc_max = (n_content + world - 1) // world + 1
+    ns_max = (n_style + world - 1) // world + 1
+    pack_c = torch.cat((sp_c, f_c), 1) if ci else None
+    g_c = _gather_rows(pack_c, ci, nc_max * world, world, (dev, 768, h, w))
+    g_s = _gather_rows(f_s, si, ns_max * world, world, (dev, 512, h, w))
+    for r in range(world):
+        rc, rs = shard_images(n_content, n_style, r, world)
+        for n, i in enumerate(rc):
+            table_c[i] = (g_c[r, n:n + 1, :256], g_c[r, n:n + 1, 256:])
+        for n, j in enumerate(rs):
+            table_s[j] = g_s[r, n:n + 1]
+    return table_c, table_s
+
+
+def grid_pair_pass(model, contents, styles, table_c, table_s, rank=0, world=1, smooth=True, pair_batch=8):
+    """Phase 3: this rank's (content, style) pairs, batched: corrm -> encode2 -> decode (+ guided filter with the content
+    as guide, content_style_grid_generation_evaluator.py:81-93)."""
     pairs = shard_pairs(contents.shape[0], styles.shape[0], rank, world)
-    need_c = sorted({i for i, _ in pairs})
-    need_s = sorted({j for _, j in pairs})
-    cache_c, cache_s = {}, {}
-    for i in need_c:
-        img = contents[i:i + 1]
-        sp, _ = model(img, command="encode")
-        f0, f1 = model(img, command="extract_feat_from_image")
-        cache_c[i] = (sp, torch.cat((f0, model(f1, command="Rselfcorr")), dim=1))
-    for j in need_s:
-        img = styles[j:j + 1]
-        f0, f1 = model(img, command="extract_feat_from_image")
-        cache_s[j] = torch.cat((f0, model(f1, command="Rselfcorr")), dim=1)
     out = {}
     for k in range(0, len(pairs), pair_batch):
         chunk = pairs[k:k + pair_batch]
-        sp = torch.cat([cache_c[i][0] for i, _ in chunk], 0)
-        fc = torch.cat([cache_c[i][1] for i, _ in chunk], 0)
-        fs = torch.cat([cache_s[j] for _, j in chunk], 0)
+        sp = torch.cat([table_c[i][0] for i, _ in chunk], 0)
+        fc = torch.cat([table_c[i][1] for i, _ in chunk], 0)
+        fs = torch.cat([table_s[j] for _, j in chunk], 0)
         st = torch.cat([styles[j:j + 1] for _, j in chunk], 0)
         ct = torch.cat([contents[i:i + 1] for i, _ in chunk], 0)
         corr = model(fs, fc, command="corrm")
@@ -74,3 +136,11 @@ def swapping_grid(model, contents, styles, rank=0, world=1, smooth=True, pair_ba
         for n, (i, j) in enumerate(chunk):
             out[(i, j)] = img[n]
     return out
+
+
+def swapping_grid(model, contents, styles, rank=0, world=1, smooth=True, pair_batch=8, image_batch=8):
+    """contents (N,3,H,W), styles (M,3,H,W) on this rank's GPU (every rank holds all images: they are small; the image
+    passes and the pair passes are sharded).  Returns {(i, j): image (3,H,W)} for the pairs this rank owns."""
+    local_c, local_s = grid_image_pass(model, contents, styles, rank, world, image_batch)
+    table_c, table_s = grid_exchange(local_c, local_s, contents.shape[0], styles.shape[0], world)
+    return grid_pair_pass(model, contents, styles, table_c, table_s, rank, world, smooth, pair_batch)

@@ -79,7 +79,10 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
         if nw != 0.0:
             if noise is None:
                 raise RuntimeError("noise weight of %s is non-zero: pass noise tensors (or noise='random')" % p)
-            nz = noise[key].contiguous()
+            nz = noise[key]
+            if nz.shape[0] == 1 and B > 1:      # one fixed row applies to the whole batch, like NoiseInjection.fixed_noise
+                nz = nz.expand(B, *nz.shape[1:])
+            nz = nz.contiguous()
         y, st = self.plan(p + "conv.weight", kind)(x, bias=bias, noise=nz, noise_weight=nw, act=ops.ACT_LRELU, stats=True,
                                                    in_ss=in_ss)
         ss = ops.in_finalize(st, y.shape[1] * y.shape[2], style=style[p])

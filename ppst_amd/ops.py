@@ -29,8 +29,9 @@ FAT_MIN_BLOCKS = 384        # prefer the 256-channel tile only when the launch s
 
 
 def set_precision(p):
-    """0: bf16x3 (fp32-class, the measured path); 1: single-pass bf16; 2: exact fp32 MFMA (verification only, slow)."""
-    assert p in (0, 1, 2)
+    """0: bf16x3 (fp32-class, the measured path); 1: single-pass bf16; 2: exact fp32 MFMA (verification only, slow);
+    3: single-pass fp16 (the "fp16 generator" of BASELINE configs[4]; fp32 accumulate / statistics / StyleMod)."""
+    assert p in (0, 1, 2, 3)
     PRECISION["value"] = p
 
 

@@ -204,6 +204,8 @@ def t_conv():
         plan1 = ops.ConvPlan(g(w), kind=kind, precision=1)
         y1 = plan1(g(nhwc(x)), pad_mode=pm)
         report("conv bf16x1 " + name, nchw(y1.cpu()), ref, 2e-2)
+        plan3 = ops.ConvPlan(g(w), kind=kind, precision=3)      # single-pass fp16 (11 significant bits per operand)
+        report("conv fp16x1 " + name, nchw(plan3(g(nhwc(x)), pad_mode=pm).cpu()), ref, 3e-3)
         plan2 = ops.ConvPlan(g(w), kind=kind, precision=2)      # exact-fp32 verification kernel (conv_f32.hip)
         st_ = plan2(g(nhwc(x)), pad_mode=pm, stats=True)
         report("conv fp32  " + name, nchw(st_[0].cpu()), ref, 2e-6)
@@ -531,12 +533,20 @@ def t_configs():
         for (i, j) in [(0, 1), (1, 0)]:
             r = orc.simple_swap(cs[i:i + 1], ss_[j:j + 1], alpha=1.0)
             ref[(i, j)] = (r["out"], O.smooth(r["out"], cs[i:i + 1]))
+        # the image passes and the pair passes of two simulated ranks (phase 1 -> exchange -> phase 3), then the same grid
+        # on one rank: the sharded run must reproduce it bit for bit (kernels are batch-composition invariant)
+        from ppst_amd.evaluation import grid_exchange, grid_image_pass, grid_pair_pass
+        m.noise = {k: v.to(dev) for k, v in W.make_noise(3, 1).items()}      # one row: applies to every batch row
+        outs = [grid_image_pass(m, g(cs), g(ss_), r, 2) for r in range(2)]
+        tc, ts = grid_exchange(None, None, 2, 2, 2, gathered=outs)
         got = {}
         for rank in range(2):
-            # noise tensors are per batch row: rebuild for the pair batch of this rank
-            nb = len(shard_pairs(2, 2, rank, 2))
-            m.noise = {k: v.to(dev).repeat(nb, 1, 1, 1) for k, v in W.make_noise(3, 1).items()}
-            got.update(swapping_grid(m, g(cs), g(ss_), rank=rank, world=2, smooth=True))
+            got.update(grid_pair_pass(m, g(cs), g(ss_), tc, ts, rank, 2, smooth=True))
+        one = swapping_grid(m, g(cs), g(ss_), rank=0, world=1, smooth=True)
+        same = all(torch.equal(one[k_], got[k_]) for k_ in one)
+        RES.append(("grid: 2 simulated ranks == 1 rank bit for bit", bool(same and sorted(one) == sorted(got))))
+        print("grid: 2 simulated ranks vs 1 rank: %s (max diff %.3e)" % ("identical" if same else "DIFFERENT",
+              max((one[k_] - got[k_]).abs().max().item() for k_ in one)), flush=True)
         assert sorted(got) == [(0, 0), (0, 1), (1, 0), (1, 1)]
     for key, (raw, sm) in ref.items():
         d = ((got[key].cpu() - sm[0]).abs() * 127.5).round()
@@ -567,6 +577,48 @@ def t_configs():
         # sanity bound of the reduced-precision mode (2^-9 per operand over ~40 layers), not a parity claim
         print("cfg5 single-pass bf16 relative RMS error %.3e" % rms, flush=True)
         RES.append(("cfg5 bf16 rms", rms < 5e-2))
+
+
+def t_precision():
+    """Reduced-precision modes of BASELINE configs[3]/[4] against the fp32 oracle.  Tolerances stated BEFORE measuring
+    (tests/test_gpu_parity.py:test_reduced_precision_modes docstring): relative RMS and max-norm of the output image."""
+    from ppst_amd.ppst_model import create_model
+    from ppst_amd.evaluation import simple_swap
+    bars = {3: ("fp16", 5e-3, 3e-2, 2e-2, 1e-1), 1: ("bf16", 5e-2, 2e-1, 1e-1, 5e-1)}   # (tag, rms 1024 enc/dec, max, rms 512 swap, max)
+    sd0 = W.make_state_dict(0, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
+    im = W.synthetic_images(13, 2, size=1024)
+    nz1024 = W.make_noise(5, 1, S=128)
+    with torch.no_grad():
+        ref1024 = O.generator(sd0, O.encoder_con(sd0, im[0:1]), O.encoder_col(sd0, im[1:2])[0], noise=nz1024)
+    sd = W.make_state_dict(1, bias_std=0.1, noise_weight=0.1)
+    imgs = W.synthetic_images(5, 2)
+    nz = W.make_noise(3, 1)
+    with torch.no_grad():
+        ref512 = O.PPSTOracle(sd, noise=nz).simple_swap(imgs[0:1], imgs[1:2], alpha=1.0)["out"]
+
+    def errs(a, b):
+        a, b = a.double().cpu(), b.double()
+        return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item(), ((a - b).abs().max() / b.abs().max()).item()
+    for prec, (tag, r1, m1, r2, m2) in bars.items():
+        ops.set_precision(prec)
+        try:
+            with torch.no_grad():
+                m = create_model(state_dict=sd0)
+                m.noise = {k: v.to(dev) for k, v in nz1024.items()}
+                sp, _ = m(g(im[0:1]), command="encode"); _, gl = m(g(im[1:2]), command="encode")
+                rms, mx = errs(m(sp, gl, command="decode"), ref1024)
+                ok = rms <= r1 and mx <= m1
+                RES.append(("cfg4 1024^2 encode/decode %s" % tag, ok))
+                print("cfg4 1024^2 encode/decode %-5s %s rel RMS %.3e (bar %.0e) max-norm %.3e (bar %.0e)" % (tag, "ok  " if ok else "FAIL", rms, r1, mx, m1), flush=True)
+                m2_ = create_model(state_dict=sd, with_D=False)
+                m2_.noise = {k: v.to(dev) for k, v in nz.items()}
+                out = simple_swap(m2_, g(imgs[0:1]), g(imgs[1:2]), alphas=(1.0,))[1.0]
+                rms, mx = errs(out, ref512)
+                ok = rms <= r2 and mx <= m2
+                RES.append(("512^2 swap %s" % tag, ok))
+                print("512^2 full swap recipe     %-5s %s rel RMS %.3e (bar %.0e) max-norm %.3e (bar %.0e)" % (tag, "ok  " if ok else "FAIL", rms, r2, mx, m2), flush=True)
+        finally:
+            ops.set_precision(0)
 
 
 def t_train_d():
@@ -696,6 +748,8 @@ def main():
     if which in ("nets", "all"):
         print("== t_networks", flush=True)
         run(t_networks)
+    if which == "prec":
+        run(t_precision)
     if which == "convv":
         run(t_conv_variants)
     if which == "trainops":

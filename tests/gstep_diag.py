@@ -401,6 +401,46 @@ def _within_class_bar(key, numel, e_max, e_l2, floor_max, floor_l2, precision):
     return e_max <= max(3e-2, 2 * floor_max) and e_l2 <= max(1.5e-2, 2 * floor_l2)
 
 
+def t_train_precision():
+    """BASELINE configs[3] names bf16 compute with fp32 master weights: the same generator iteration with single-pass
+    bf16 (and fp16) convs for forward / input gradients (weight gradients stay exact fp32, parameters / Adam fp32).
+    Bars stated before measuring: losses within 2e-2 (bf16) / 3e-3 (fp16) relative (NCE terms 5e-2 / 1e-2); cosine between
+    our gradient and the reference's, over the sampled entries of each network: >= 0.98 (bf16) / 0.999 (fp16)."""
+    from ppst_amd.ppst_model import Options, create_model
+    from ppst_amd.train_g import GeneratorTrainer
+    g = np.load(os.path.join(GOLD, "gstep512_s2.npz"))
+    real, mask, noise = gstep_inputs()
+    for prec, tag, ltol, ntol, cmin in ((1, "bf16", 2e-2, 5e-2, 0.98), (3, "fp16", 3e-3, 1e-2, 0.999)):
+        ops.set_precision(prec)
+        try:
+            sd = W.make_state_dict(17, bias_std=0.1, noise_weight=0.1)
+            m = create_model(Options(training_stage=2, lambda_Cycwarp=0.0), state_dict=sd, with_D=True, with_nce=True)
+            m.noise = {k: v.to(dev) for k, v in noise.items()}
+            tr = GeneratorTrainer(m)
+            out = tr.losses_and_grads(real.to(dev), mask.to(dev))
+            torch.cuda.synchronize()
+        finally:
+            ops.set_precision(0)
+        for k in [f[5:] for f in g.files if f.startswith("loss.")]:
+            ref, got = float(g["loss." + k]), float(out[k])
+            tol = ntol if "styleCont" in k else ltol
+            ok = abs(got - ref) <= tol * max(1.0, abs(ref))
+            RES.append(("train %s loss %s" % (tag, k), ok))
+            print("train %s loss %-18s %s got %.5f ref %.5f" % (tag, k, "ok  " if ok else "FAIL", got, ref), flush=True)
+        for net in ("G", "E1", "E2"):
+            fp = tr.fp[net]
+            a, b = [], []
+            for name in fp.names:
+                key = "grad.%s.%s" % (net, name)
+                gg = fp.g(name).double().cpu().numpy()
+                a.append(gg[sample_idx(key, gg.size)]); b.append(g[key + ".samples"].astype(np.float64))
+            a, b = np.concatenate(a), np.concatenate(b)
+            cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+            ok = cos >= cmin
+            RES.append(("train %s grad cosine %s" % (tag, net), ok))
+            print("train %s gradient cosine vs reference, %-2s: %.5f (bar %.3f) %s" % (tag, net, cos, cmin, "ok" if ok else "FAIL"), flush=True)
+
+
 def t_s1():
     RES.extend(compare_gstep(1))
 
@@ -435,6 +475,8 @@ def main():
         run(t_s1)
     if what in ("s2", "all"):
         run(t_s2)
+    if what in ("tprec",):
+        run(t_train_precision)
     if what in ("s1x", "exact"):
         run(t_s1x)
     if what in ("s2x", "exact"):

@@ -57,6 +57,11 @@ def test_generator_update_matches_reference_gradients(stage, precision):
     assert not bad, "outside the bar: %s" % bad[:20]
 
 
+def test_train_step_reduced_precision():
+    """bf16 / fp16 compute with fp32 master weights (BASELINE configs[3]); bars in gstep_diag.t_train_precision."""
+    _run_blocks("t_train_precision")
+
+
 def test_generator_adam_step_and_alternation():
     """PPSTOptimizer mirror: first call = discriminator iteration (+ D_total), second = generator iteration; the
     parameter update equals torch.optim.Adam(lr 1e-3, betas (0, 0.99)) applied to the gradients of that step."""

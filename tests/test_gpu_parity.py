@@ -55,6 +55,16 @@ def test_grid_1024_and_mask_configs_vs_oracle():
     _run("t_configs")
 
 
+def test_reduced_precision_modes():
+    """fp16 / bf16 single-pass convs (fp32 accumulate, instance-norm statistics and StyleMod in every mode) against the
+    fp32 oracle.  Bars, written before the first measurement (relative RMS / max-norm of the output image):
+      fp16 (11 significant bits): 1024^2 encode-decode 5e-3 / 3e-2;  512^2 full swap recipe 2e-2 / 1e-1
+      bf16 ( 8 significant bits): 1024^2 encode-decode 5e-2 / 2e-1;  512^2 full swap recipe 1e-1 / 5e-1
+    (the swap recipe adds the T = 0.01 correspondence softmax, which turns feature rounding into shifted matches; the
+    correspondence GEMMs themselves stay exact fp32 in every mode)."""
+    _run("t_precision")
+
+
 def test_discriminator_train_step_vs_autograd_oracle():
     """LSGAN losses, all D parameter gradients (conv wgrad/dgrad, blur, lrelu, linear) and one Adam
     step against oracle/train_oracle.py (CPU autograd, pinned to the reference's own backward)."""
