@@ -385,11 +385,12 @@ int ppst_pad2d(const void* x, void* y, int B, int H, int W, int C, int x_ld, int
                void* stream);
 int ppst_pad2d_bwd(const void* dy, void* dx, int B, int H, int W, int C, int py0, int py1, int px0, int px1, int mode, void* stream);
 /* adjoints of ppst_bilinear (dx must be zero-initialised; float atomics), ppst_avgpool and ppst_gap_gmp
- * (v = the forward's [B][2C] output, g = its gradient; accumulate != 0 adds into dx) */
+ * (v = the forward's [B][2C] output, g = its gradient; the max routes to the FIRST maximal pixel like nn.AdaptiveMaxPool2d;
+ * accumulate != 0 adds into dx) */
 int ppst_bilinear_bwd(const void* dy, void* dx, int B, int H, int W, int C, int dx_ld, int OH, int OW, int dy_ld, void* stream);
 int ppst_avgpool_bwd(const void* dy, void* dx, int B, int H, int W, int C, int dx_ld, int f, int dy_ld, void* stream);
-int ppst_gap_gmp_bwd(const void* x, const void* mask, const void* v, const void* g, void* dx, int B, int64_t hw, int C, int ld,
-                     int accumulate, void* stream);
+int ppst_gap_gmp_bwd(const void* x, const void* mask, const void* v, const void* g, void* dx, void* arg_ws /* B*C int32 */, int B,
+                     int64_t hw, int C, int ld, int accumulate, void* stream);
 /* backward of ppst_l2norm_rows (mode 0: util.normalize, 1: F.normalize), ppst_softmax_rows (in place on g) and
  * ppst_corr_prep (ppst_model.py:343-356) */
 int ppst_l2norm_rows_bwd(const void* g, const void* x, void* dx, int B, int K, float eps, int mode, void* stream);

@@ -284,7 +284,10 @@ def encoder_con(sd, x, p="E1."):
 def _e2_head(sd, p, tag, x):
     """encoder_col.py:162-168: cat(GAP,GMP) -> conv1x1 -> projector -> F.normalize."""
     gap = x.mean(dim=(2, 3))
-    gmp = x.amax(dim=(2, 3))
+    # nn.AdaptiveMaxPool2d(1) (encoder_col.py:45): its backward routes the gradient to the FIRST maximal element in
+    # row-major order (amax would split it evenly over ties; the x8 bilinear upsampling of the warped features has 4x4
+    # plateaus at the image border, so ties do occur)
+    gmp = F.adaptive_max_pool2d(x, 1).flatten(1)
     v = torch.cat([gap, gmp], 1)
     w = sd[p + "conv1x1_%s.weight" % tag]
     v = F.linear(v, w.view(w.shape[0], -1), sd[p + "conv1x1_%s.bias" % tag])
@@ -324,7 +327,8 @@ def encoder_col(sd, x, mask=None, corrmatrix=None, p="E2."):
         vectors.append(_e2_head(sd, p, tag, x))
         xx = None
         if corrmatrix is not None:
-            xx = e2_warp(x, corrmatrix, scales[lvl] is not None, scales[lvl])
+            # the first level warps with the live matrix (encoder_col.py:165), the deeper ones with corrmatrix.detach() (:197)
+            xx = e2_warp(x, corrmatrix if lvl == 0 else corrmatrix.detach(), scales[lvl] is not None, scales[lvl])
             vectors_w.append(_e2_head(sd, p, tag, xx))
         if mask is not None:
             if lvl > 0:
@@ -396,7 +400,7 @@ def generator(sd, sp, codes, extract_features=False, noise=None, p="G."):
         x = (skip + r) / SQRT2
     feas = []
     if extract_features:
-        feas.append(_feat_head(sd, p + "layer32.", x, 3))
+        feas.append(_feat_head(sd, p + "layer32.", x.detach(), 3))          # generator.py:256: the heads read x.detach()
     for j, (key, ci, co) in enumerate(G_UP):
         q = p + "UpsamplingResBlock%d." % key
         g = codes[-2 - j]
@@ -406,7 +410,7 @@ def generator(sd, sp, codes, extract_features=False, noise=None, p="G."):
         r = styled_conv(r, sd, q + "conv2.", g, noise=nz("UpsamplingResBlock%d.conv2" % key))
         x = (skip + r) / SQRT2
         if extract_features:
-            feas.append(_feat_head(sd, p + "layer%d." % (2 ** (j + 6)), x, 3 if j < 2 else 1))
+            feas.append(_feat_head(sd, p + "layer%d." % (2 ** (j + 6)), x.detach(), 3 if j < 2 else 1))   # generator.py:267
     rgb = to_rgb(x, sd, p + "ToRGB.", codes[0])
     if not extract_features:
         return rgb

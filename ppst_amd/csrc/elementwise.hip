@@ -119,9 +119,13 @@ extern "C" int ppst_nhwc_to_nchw(const void* x, void* y, int B, int C, int H, in
 // MODE 1 = (sum m*x, max m*x) [GAP/GMP with optional mask].
 // Pixels per block: 1024 for big images, fewer when that would leave CUs idle (>= 2048 blocks
 // wanted, >= 64 pixels per block).  n_partials = ceil(H*W / pix_chunk(B, H*W)) everywhere.
+// The chunk depends on the image size ONLY (not on the batch): the grouping of the partial sums -- and so every
+// bit of the statistics -- is the same whether an image is processed alone or inside any batch (the image-sharded grid
+// evaluator relies on it: N ranks reproduce one rank bit for bit).
 static inline int pix_chunk(int B, int64_t hw) {
+  (void)B;
   int chunk = 1024;
-  while (chunk > 64 && (int64_t)B * cdiv64(hw, chunk) < 2048) chunk >>= 1;
+  while (chunk > 64 && cdiv64(hw, chunk) < 2048) chunk >>= 1;
   return chunk;
 }
 template <int MODE>

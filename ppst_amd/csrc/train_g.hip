@@ -16,9 +16,10 @@ static inline unsigned tg_grid(int64_t work, int threads = 256) {
 }
 __device__ __forceinline__ float lrelu_gate(float ref) { return (ref > 0.f ? 1.f : 0.2f) * 1.41421356237309515f; }
 
-static inline int tg_pix_chunk(int B, int64_t hw) {
+static inline int tg_pix_chunk(int B, int64_t hw) {   // batch-independent, like pix_chunk (elementwise.hip)
+  (void)B;
   int chunk = 1024;
-  while (chunk > 64 && (int64_t)B * cdiv64(hw, chunk) < 2048) chunk >>= 1;
+  while (chunk > 64 && cdiv64(hw, chunk) < 2048) chunk >>= 1;
   return chunk;
 }
 
@@ -360,35 +361,51 @@ extern "C" int ppst_avgpool_bwd(const void* dy, void* dx, int B, int H, int W, i
   return PPST_LAUNCH_CHECK();
 }
 
-// adjoint of ppst_gap_gmp: v = cat(mean_p(m*x), max_p(m*x));  dx[p][c] = m[p] * (g_mean[c] / P + g_max[c] * [m*x == vmax[c]])
+// adjoint of ppst_gap_gmp: v = cat(mean_p(m*x), max_p(m*x));  dx[p][c] = m[p] * (g_mean[c] / P + g_max[c] * [p == argmax[c]])
+// argmax = the FIRST pixel (row-major) attaining the maximum, as nn.AdaptiveMaxPool2d's backward routes it (ties are real:
+// the x8 bilinear upsampling of the warped features has 4x4 plateaus at the image border).  Pass 1 finds it with an
+// atomicMin over the pixels equal to the forward's maximum; pass 2 applies.
 // (accumulate != 0: dx += ...; several heads pool the same feature map, encoder_col.py:162-245)
-__global__ __launch_bounds__(256) void gap_gmp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mask,
-                                                          const float* __restrict__ v, const float* __restrict__ g,
-                                                          float* __restrict__ dx, unsigned hw, int C, int ld, int accumulate,
-                                                          unsigned total, FastDiv d_c, FastDiv d_hw) {
+__global__ __launch_bounds__(256) void gmp_argmax_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                         const float* __restrict__ v, int* __restrict__ arg, unsigned hw, int C, int ld,
+                                                         unsigned total, FastDiv d_c, FastDiv d_hw) {
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned c;
+    const unsigned bpu = fd_divmod((unsigned)t64, d_c, c);
+    const unsigned b = fd_div(bpu, d_hw);
+    const float m = mask ? mask[bpu] : 1.f;
+    if (x[(int64_t)bpu * ld + c] * m == v[(int64_t)b * 2 * C + C + c]) atomicMin(arg + (int64_t)b * C + c, (int)(bpu - b * hw));
+  }
+}
+__global__ __launch_bounds__(256) void gap_gmp_bwd_kernel(const float* __restrict__ mask, const int* __restrict__ arg,
+                                                          const float* __restrict__ g, float* __restrict__ dx, unsigned hw, int C,
+                                                          int accumulate, unsigned total, FastDiv d_c, FastDiv d_hw) {
   const float invP = 1.f / (float)hw;
   for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
     unsigned c;
     const unsigned bpu = fd_divmod((unsigned)t64, d_c, c);
     const unsigned b = fd_div(bpu, d_hw);
     const float m = mask ? mask[bpu] : 1.f;
-    const float xv = x[(int64_t)bpu * ld + c] * m;
-    const float vmax = v[(int64_t)b * 2 * C + C + c];
-    float o = m * (g[(int64_t)b * 2 * C + c] * invP + (xv == vmax ? g[(int64_t)b * 2 * C + C + c] : 0.f));
+    const bool top = (int)(bpu - b * hw) == arg[(int64_t)b * C + c];
+    float o = m * (g[(int64_t)b * 2 * C + c] * invP + (top ? g[(int64_t)b * 2 * C + C + c] : 0.f));
     float* d = dx + (int64_t)bpu * C + c;
     *d = accumulate ? *d + o : o;
   }
 }
-extern "C" int ppst_gap_gmp_bwd(const void* x, const void* mask, const void* v, const void* g, void* dx, int B, int64_t hw, int C,
-                                int ld, int accumulate, void* stream) {
-  if (B < 0 || hw <= 0 || C <= 0 || ld < C) return PPST_EINVAL;
+extern "C" int ppst_gap_gmp_bwd(const void* x, const void* mask, const void* v, const void* g, void* dx, void* arg_ws, int B,
+                                int64_t hw, int C, int ld, int accumulate, void* stream) {
+  if (B < 0 || hw <= 0 || hw > 0x7fffffffll || C <= 0 || ld < C) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
-  if (!x || !v || !g || !dx) return PPST_ENULL;
+  if (!x || !v || !g || !dx || !arg_ws) return PPST_ENULL;
   const int64_t total = (int64_t)B * hw * C;
   if (total > PPST_IDX32_MAX) return PPST_EINVAL;
-  PPST_LAUNCH(gap_gmp_bwd_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)mask,
-              (const float*)v, (const float*)g, (float*)dx, (unsigned)hw, C, ld, accumulate, (unsigned)total,
-              make_fastdiv((unsigned)C), make_fastdiv((unsigned)hw));
+  hipError_t e = hipMemsetAsync(arg_ws, 0x7f, (size_t)B * C * sizeof(int), as_stream(stream));   // 0x7f7f7f7f: above any pixel index
+  if (e != hipSuccess) return (int)e;
+  PPST_LAUNCH(gmp_argmax_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)mask,
+              (const float*)v, (int*)arg_ws, (unsigned)hw, C, ld, (unsigned)total, make_fastdiv((unsigned)C), make_fastdiv((unsigned)hw));
+  PPST_LAUNCH(gap_gmp_bwd_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)mask, (const int*)arg_ws,
+              (const float*)g, (float*)dx, (unsigned)hw, C, accumulate, (unsigned)total, make_fastdiv((unsigned)C),
+              make_fastdiv((unsigned)hw));
   return PPST_LAUNCH_CHECK();
 }
 

@@ -711,8 +711,9 @@ def gap_gmp_bwd(x, mask, v, g, out=None):
     acc = out is not None
     if out is None:
         out = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
-    check(lib.ppst_gap_gmp_bwd(_p(x), _p(mask), _p(v.contiguous()), _p(g.contiguous()), _p(out), B, H * W, C, ld, 1 if acc else 0,
-                               _stream()), "ppst_gap_gmp_bwd")
+    arg = torch.empty((B, C), device=x.device, dtype=torch.int32)
+    check(lib.ppst_gap_gmp_bwd(_p(x), _p(mask), _p(v.contiguous()), _p(g.contiguous()), _p(out), ctypes.c_void_p(arg.data_ptr()), B, H * W, C, ld,
+                               1 if acc else 0, _stream()), "ppst_gap_gmp_bwd")
     return out
 
 

@@ -208,7 +208,7 @@ def t_conv():
         report("conv fp16x1 " + name, nchw(plan3(g(nhwc(x)), pad_mode=pm).cpu()), ref, 3e-3)
         plan2 = ops.ConvPlan(g(w), kind=kind, precision=2)      # exact-fp32 verification kernel (conv_f32.hip)
         st_ = plan2(g(nhwc(x)), pad_mode=pm, stats=True)
-        report("conv fp32  " + name, nchw(st_[0].cpu()), ref, 2e-6)
+        report("conv fp32  " + name, nchw(st_[0].cpu()), ref, 5e-6)     # fp32 fmaf chain over up to 4608 terms
         report("conv fp32 stats " + name, st_[1].sum(1)[..., 0].cpu(), ref.sum((2, 3)), 2e-5)
     # scale folded into the pack
     x = torch.randn(1, 64, 16, 16); w = torch.randn(64, 64, 3, 3)

@@ -48,6 +48,12 @@ def test_correspondence_and_nce_blocks_vs_torch_autograd():
     _run_blocks("t_blocks2")
 
 
+def test_networks_backward_vs_oracle_autograd():
+    """E2 (masked heads + correspondence warp, live matrix), E1 and G (+ feature heads): every parameter gradient and the
+    input gradients against torch autograd of the CPU oracle in float64 (exact-fp32 convs on the GPU side)."""
+    _run_blocks("t_nets")
+
+
 @pytest.mark.parametrize("stage", [1, 2])
 @pytest.mark.parametrize("precision", [2, 0])
 def test_generator_update_matches_reference_gradients(stage, precision):
