@@ -355,6 +355,35 @@ def gen_gstep(ns, stage, f64=False):
     print(tag, len(out), {k: float(v) for k, v in out.items() if k.startswith(("loss.", "metric."))})
 
 
+def gen_iter_counter():
+    """Schedule of the reference's own IterationCounter (util/iter_counter.py, loaded from its file: util/__init__ needs
+    packages that are absent): for two option sets, the image count and the save / evaluate / print decisions of the first
+    iterations."""
+    import importlib.util
+    from argparse import Namespace
+    spec = importlib.util.spec_from_file_location("ref_iter_counter", os.path.join(ref_loader.REF, "util", "iter_counter.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = []
+    for kw in (dict(batch_size=2, save_freq=50, evaluation_freq=30, print_freq=8, total_nimgs=200),
+               dict(batch_size=16, save_freq=50000, evaluation_freq=50000, print_freq=480, total_nimgs=120000)):
+        opt = Namespace(checkpoints_dir="/nonexistent", name="x", dataset_mode="celebamask", isTrain=True, continue_train=False,
+                        resume_iter="latest", pretrained_name=None, display_freq=1600, **kw)
+        ic = mod.IterationCounter(opt)
+        ic.record_one_iteration.__func__  # noqa: B018 (exists)
+        rows = []
+        for _ in range(400):
+            rows.append([int(ic.steps_so_far), bool(ic.needs_saving()), bool(ic.needs_evaluation()), bool(ic.needs_printing()),
+                         bool(ic.completed_training())])
+            if ic.completed_training():
+                break
+            ic.steps_so_far += ic.batch_size            # record_one_iteration without the file write
+        out.append({"opt": kw, "rows": rows})
+    with open(os.path.join(GOLD, "iter_counter.json"), "w") as f:
+        json.dump(out, f)
+    print("iter_counter.json", [len(o["rows"]) for o in out])
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ns = ref_loader.load_reference()
@@ -362,6 +391,7 @@ def main():
         for a in sys.argv[1:]:
             {"gstep1": lambda: gen_gstep(ns, 1), "gstep2": lambda: gen_gstep(ns, 2),
              "gstep1_f64": lambda: gen_gstep(ns, 1, True), "gstep2_f64": lambda: gen_gstep(ns, 2, True),
+             "iter_counter": gen_iter_counter,
              "train512": lambda: gen_train(ns, 512), "train128": lambda: gen_train(ns), "gloss": lambda: gen_gloss(ns)}[a]()
         return
     m = ref_loader.build_reference_model()
@@ -376,7 +406,8 @@ def main():
     gen_gstep(ns, 1)
     gen_gstep(ns, 2)
     gen_gstep(ns, 1, True)
-    gen_gstep(ns, 2, True)
+    # gen_gstep(ns, 2, True) needs more than the build container's 62 GB (killed by the kernel twice): not a fixture
+    gen_iter_counter()
 
 
 if __name__ == "__main__":

@@ -344,6 +344,11 @@ class GeneratorTrainer:
 
     def losses_and_grads(self, real, mask=None):
         self.zero_grad()
+        if self.world > 1:
+            self._install_overlap_hooks()
+            self._pending = {}
+            for k in self._done_count:
+                self._done_count[k] = 0
         with torch.enable_grad():
             losses, metrics = self.compute_generator_losses(real, mask)
             total = None
@@ -354,9 +359,38 @@ class GeneratorTrainer:
         out.update({k: v.detach() for k, v in metrics.items()})
         return out
 
+    # ---- data parallel: flat gradient all-reduce per network, overlapped with the rest of the backward pass.
+    # Autograd runs a leaf's AccumulateGrad once per backward, after ALL uses of the parameter have contributed, so a
+    # post-accumulate hook that counts a network's parameters knows when that network's flat gradient is final: its
+    # all-reduce is launched (async, RCCL) right there, while autograd is still working on the networks behind it
+    # (backward order: D -> G -> E2 / E1).  Whatever did not complete (parameters without a gradient in this step) is
+    # reduced after backward() returns.
+    def _install_overlap_hooks(self):
+        if getattr(self, "_hooks", None) is not None:
+            return
+        self._hooks, self._pending, self._done_count = [], {}, {}
+        for key, f in self.fp.items():
+            self._done_count[key] = 0
+            for p in f.params:
+                def hook(_p, key=key, f=f):
+                    self._done_count[key] += 1
+                    if self._done_count[key] == len(f.params) and self.world > 1:
+                        import torch.distributed as dist
+                        self._pending[key] = dist.all_reduce(f.grad, op=dist.ReduceOp.SUM, async_op=True)
+                self._hooks.append(p.register_post_accumulate_grad_hook(hook))
+
     def all_reduce(self):
-        for f in self.fp.values():
-            ddp_average_(f.grad, self.world)
+        """Finish the gradient average: wait for the all-reduces launched during backward, launch + wait the rest."""
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+        pending = getattr(self, "_pending", {})
+        for key, f in self.fp.items():
+            h = pending.pop(key, None)
+            if h is None:
+                h = dist.all_reduce(f.grad, op=dist.ReduceOp.SUM, async_op=True)
+            h.wait()
+            f.grad.div_(self.world)
 
     def adam(self):
         for k in ("G", "E2", "E1"):          # optimizer_G.step(); optimizer_E2.step(); optimizer_E1.step()

@@ -707,17 +707,24 @@ def t_train_r1():
     import train_oracle as T
     from ppst_amd.networks.discriminator import StyleGAN2Discriminator
     from ppst_amd.train import DiscriminatorTrainer
-    for size, B in ((128, 2), (256, 2)):
+    for size, B, prec in ((128, 2, 0), (256, 2, 0), (128, 2, 2), (256, 2, 2)):
+        # prec 2 = exact-fp32 verification convs: the forward then rounds like the oracle's and the tight bar must hold --
+        # what remains at prec 0 is gate flips caused by the rounding of the bf16 hi+lo split, not a defect
         sd = W.make_state_dict(3, size=size, with_nce=False, bias_std=0.1)
         D = StyleGAN2Discriminator(None, size=size)
         D.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith("D.")}, strict=True)
         D = D.to(dev)
+        ops.set_precision(prec)
         tr = DiscriminatorTrainer(D)
         torch.manual_seed(size + 1)
         real = torch.rand(B, 3, size, size) * 2 - 1
         pen, gr = T.r1_step_grads(sd, real, size=size)
-        losses = tr.r1_losses_and_grads(g(real))
-        report("R1 %d per-sample penalty" % size, losses["D_R1"], pen, 1e-3)
+        try:
+            losses = tr.r1_losses_and_grads(g(real))
+            torch.cuda.synchronize()
+        finally:
+            ops.set_precision(0)
+        report("R1 %d per-sample penalty (precision %d)" % (size, prec), losses["D_R1"], pen, 1e-3)
         worst, worst_k, worst_max = 0.0, "", 0.0
         for k, gref in gr.items():
             got = tr.g(k[2:]).view_as(gref).cpu()
@@ -731,10 +738,10 @@ def t_train_r1():
             worst_max = max(worst_max, rmax)
             if r > worst:
                 worst, worst_k = r, k
-        ok = worst <= 2e-2 and worst_max <= 1e-1
-        RES.append(("R1 %d gradients" % size, ok))
-        print("R1 %d: worst L2-relative gradient error %.3e (%s), worst max-relative %.3e over %d tensors %s"
-              % (size, worst, worst_k, worst_max, len(gr), "ok" if ok else "FAIL"), flush=True)
+        ok = (worst <= 5e-3 and worst_max <= 2e-2) if prec == 2 else (worst <= 2e-2 and worst_max <= 1e-1)
+        RES.append(("R1 %d gradients (precision %d)" % (size, prec), ok))
+        print("R1 %d precision %d: worst L2-relative gradient error %.3e (%s), worst max-relative %.3e over %d tensors %s"
+              % (size, prec, worst, worst_k, worst_max, len(gr), "ok" if ok else "FAIL"), flush=True)
 
 
 def main():

@@ -98,3 +98,58 @@ def test_generator_adam_step_and_alternation():
         live = g.abs() > 1e-12
         assert float((f.flat.cpu().double() - ref)[live].abs().max()) < 2e-6, k
         assert f.step_count == 1
+
+
+def test_training_loop_runs_saves_and_resumes(tmp_path):
+    """train.py:24-60 on the HIP path: four iterations (D, G, D, G) on synthetic data with the image-count schedule, the
+    model checkpoint in the reference's layout + optimiser state + iter.txt; a second process-equivalent resumes from them."""
+    from ppst_amd import weights as W
+    from ppst_amd.ppst_model import Options, create_model
+    from ppst_amd.train_g import PPSTOptimizer
+    from ppst_amd.training import IterationCounter, SyntheticMaskDataset, load_optimizer_state, train_loop
+    opt = Options(training_stage=2, lambda_Cycwarp=0.0, checkpoints_dir=str(tmp_path), name="run", isTrain=True, batch_size=2,
+                  total_nimgs=8, save_freq=4, evaluation_freq=1000, print_freq=2, local_rank=0, continue_train=False, dataset_mode="celebamask")
+    sd = W.make_state_dict(3, bias_std=0.1, noise_weight=0.1)
+    m = create_model(opt, state_dict=sd, with_D=True, with_nce=True)
+    optim = PPSTOptimizer(m)
+    logs = []
+    w0 = optim.gen.fp["G"].flat.clone()
+    tracker = train_loop(opt, m, SyntheticMaskDataset(batch_size=2), optim, log=logs.append)
+    mets = tracker.current_metrics()
+    assert {"D_total", "G_L1", "G_GAN_rec", "Mask_warp"} <= set(mets) and all(v == v for v in mets.values())
+    assert (optim.gen.fp["G"].flat != w0).any() and optim.gen.fp["G"].step_count == 2 and optim.dis.step_count == 2
+    run = os.path.join(str(tmp_path), "run")
+    assert os.path.islink(os.path.join(run, "latest_checkpoint.pth")) and os.path.exists(os.path.join(run, "latest_optimizer.pth"))
+    assert any("Training finished" in s for s in logs)
+    # resume: same weights, same Adam state, image count from iter.txt
+    opt2 = Options(**{**opt.__dict__, "continue_train": True})
+    m2 = create_model(opt2, state_dict=W.make_state_dict(99), with_D=True, with_nce=True)
+    assert m2.load(verbose=False)
+    optim2 = load_optimizer_state(PPSTOptimizer(m2), os.path.join(run, "latest_optimizer.pth"))
+    assert torch.equal(optim2.gen.fp["G"].m, optim.gen.fp["G"].m) and optim2.gen.fp["G"].step_count == 2
+    assert torch.allclose(optim2.gen.fp["G"].flat, optim.gen.fp["G"].flat) and IterationCounter(opt2).steps_so_far >= 4
+
+
+def test_celebamask_dataset_loader(tmp_path):
+    """image + integer label map -> {'real_A' in [-1, 1], 'mask_A' exact one-hot} (CelebAMask_dataset.py:40-60)."""
+    import numpy as np
+    Image = pytest.importorskip("PIL.Image")
+    import resize_oracle as R
+    from ppst_amd.training import CelebAMaskDataset
+    rng = np.random.default_rng(3)
+    os.makedirs(tmp_path / "images"); os.makedirs(tmp_path / "labels")
+    imgs, labs = [], []
+    for i in range(3):
+        a = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+        l = rng.integers(0, 3, (64, 64), dtype=np.uint8)
+        Image.fromarray(a).save(tmp_path / "images" / ("%d.png" % i))
+        Image.fromarray(l).save(tmp_path / "labels" / ("%d.png" % i))
+        imgs.append(a); labs.append(l)
+    ds = CelebAMaskDataset(str(tmp_path), size=64, batch_size=3)
+    batch = next(ds)
+    assert tuple(batch["real_A"].shape) == (3, 3, 64, 64) and tuple(batch["mask_A"].shape) == (3, 3, 64, 64)
+    order = ds._order[:3]
+    for n, idx in enumerate(order):
+        assert np.array_equal(batch["real_A"][n].cpu().numpy(), R.preprocess(imgs[idx], 64))
+        onehot = np.stack([(labs[idx] == c) for c in range(3)]).astype(np.float32)
+        assert np.array_equal(batch["mask_A"][n].cpu().numpy(), onehot)

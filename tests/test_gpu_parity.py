@@ -82,21 +82,24 @@ def test_lazy_r1_penalty_vs_double_backward_oracle():
     _run("t_train_r1")
 
 
-def test_train_step_matches_reference_golden():
-    """The HIP D iteration + lazy R1 against tests/golden/train128.npz, which holds what the
-    reference's own compute_image_discriminator_losses / compute_R1_loss + autograd produced."""
+@pytest.mark.parametrize("size,precision", [(128, 0), (512, 0), (512, 2)])
+def test_train_step_matches_reference_golden(size, precision):
+    """The HIP D iteration + lazy R1 against tests/golden/train{128,512}.npz, which hold what the reference's own
+    compute_image_discriminator_losses / compute_R1_loss + autograd produced (512x512, batch 2 = BASELINE configs[3]'s
+    shape).  precision 2 = the exact-fp32 verification convs: tells rounding of the bf16 hi+lo split from defects."""
     import numpy as np
-    from ppst_amd import weights as W
+    from ppst_amd import ops, weights as W
     from ppst_amd.networks.discriminator import StyleGAN2Discriminator
     from ppst_amd.train import DiscriminatorTrainer
     from test_oracle_golden import sample_idx, train_inputs
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train128.npz"))
-    size = 128
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train%d.npz" % size))
     sd = W.make_state_dict(11, size=size, with_nce=False, bias_std=0.1)
     D = StyleGAN2Discriminator(None, size=size)
     D.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith("D.")}, strict=True)
+    ops.set_precision(precision)
     tr = DiscriminatorTrainer(D.cuda())
     real, rec, mix = (t.cuda() for t in train_inputs(size))
+    worst = {}
 
     def check(prefix, tol_l2, tol_max):
         for name in tr.names:
@@ -108,16 +111,27 @@ def test_train_step_matches_reference_golden():
             if scale == 0.0:
                 assert np.abs(got).max() == 0.0, key
                 continue
-            assert np.abs(d).max() <= tol_max * scale, (key, np.abs(d).max(), scale)
-            assert np.linalg.norm(d) <= tol_l2 * np.linalg.norm(ref) + 1e-12, (key, np.linalg.norm(d), np.linalg.norm(ref))
+            w_ = worst.setdefault(prefix, [0.0, 0.0, ""])
+            e_max, e_l2 = np.abs(d).max() / scale, np.linalg.norm(d) / (np.linalg.norm(ref) + 1e-30)
+            if e_max > w_[0]:
+                w_[0], w_[2] = e_max, key
+            w_[1] = max(w_[1], e_l2)
+            assert e_max <= tol_max, (key, e_max, scale)
+            assert e_l2 <= tol_l2, (key, e_l2)
 
-    losses = tr.losses_and_grads(real, rec, mix)
-    for k in ("D_real", "D_rec", "D_mix"):
-        assert abs(float(losses[k]) - float(g["loss." + k])) <= 1e-4 * max(1.0, abs(float(g["loss." + k]))), k
-    check("dgrad.", 5e-3, 5e-3)
-    r1 = tr.r1_losses_and_grads(real)
-    assert np.allclose(r1["D_R1"].cpu().numpy(), g["loss.D_R1"], rtol=1e-3)
-    check("r1grad.", 2e-2, 1e-1)   # tolerance rationale: gpu_diag.t_train_r1
+    try:
+        losses = tr.losses_and_grads(real, rec, mix)
+        for k in ("D_real", "D_rec", "D_mix"):
+            assert abs(float(losses[k]) - float(g["loss." + k])) <= 1e-4 * max(1.0, abs(float(g["loss." + k]))), k
+        check("dgrad.", 5e-3, 5e-3)
+        r1 = tr.r1_losses_and_grads(real)
+        assert np.allclose(r1["D_R1"].cpu().numpy(), g["loss.D_R1"], rtol=1e-3)
+        # second-order (R1) gradients at the same 5e-3 bar as the first-order ones (measured, round 2: worst 1.4e-3 at
+        # 512x512 with the production convs, 6.7e-4 with the exact-fp32 convs; round 1 had accepted 2e-2 / 1e-1 here)
+        check("r1grad.", 5e-3, 5e-3)
+    finally:
+        ops.set_precision(0)
+        print("D step %d precision %d: worst (max, l2, key) %s" % (size, precision, worst))
 
 
 def test_generator_loss_values_match_reference_golden():
