@@ -337,7 +337,9 @@ int ppst_colsum(const void* x, void* out, void* ws, int64_t rows, int C, int ld,
 /* F.linear gradients: dW[n][k] (+)= scale*sum_b dY[b][n] X[b][k];  dX[b][k] = scale*sum_n dY[b][n] W[n][k] */
 int ppst_linear_wgrad(const void* dy, const void* x, void* dw, int B, int N, int K, float scale,
                       int accumulate, void* stream);
-int ppst_linear_dgrad(const void* dy, const void* w, void* dx, int B, int N, int K, float scale,
+/* ws: ppst_linear_dgrad_ws(B, N, K) bytes of scratch (partial sums over row slices, reduced in a fixed order) */
+int64_t ppst_linear_dgrad_ws(int B, int N, int K);
+int ppst_linear_dgrad(const void* dy, const void* w, void* dx, void* ws, int B, int N, int K, float scale,
                       void* stream);
 /* LSGAN (models/networks/loss.py:11-18): loss = weight*mean((p-target)^2), grad = d loss / d p */
 /* torch.nn.L1Loss (mean |a-b|) times weight -> out[0]; ws >= ppst_l1_mean_ws(n) bytes (ppst_model.py:47,183,203). */

@@ -93,6 +93,97 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
   }
 }
 
+// LDS-staged variant (round 2): the block stages a 2 x 32-pixel tile of dY (64 px x 128 n, 32 KB) and the matching
+// (2+2) x (32+2)-pixel halo tile of the 32-channel input chunk (17 KB) with 16-B loads, then every k-pair costs one
+// conflict-free ds_read_b32 per operand instead of an L1/L2 round trip per lane.  Same arithmetic (exact fp32 MFMA), same
+// step tables; the round-1 kernel above was latency bound (26 TFLOP/s = 17 % of the fp32 MFMA peak: two waves per SIMD
+// each waiting ~500 cycles per operand fetch).  49 KB of LDS, 3 blocks per CU: one block's staging overlaps the
+// others' MFMAs.
+#define WG_TR 2
+#define WG_TC 32
+__global__ __launch_bounds__(256, 3) void conv_wgrad_lds_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              const int4* __restrict__ steps, const int* __restrict__ chunk_start,
+                                                              float* __restrict__ partial, int B, int in_h, int in_w, int in_ld,
+                                                              int oh, int ow, int dy_ld, int cout, int nsteps, int tiles_x,
+                                                              int tiles_per_image, int tiles_total, int tiles_per_split) {
+  constexpr int XH = WG_TR + 2, XW = WG_TC + 2;
+  __shared__ __attribute__((aligned(16))) float sdy[WG_TR * WG_TC][128];
+  __shared__ __attribute__((aligned(16))) float sx[XH * XW][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const int n0 = blockIdx.x * 128;
+  const int s0 = chunk_start[blockIdx.y], s1 = chunk_start[blockIdx.y + 1];
+  const int T = s1 - s0;
+  const int chan = steps[s0].x;
+  int tdy[WG_MAXT], tdx[WG_MAXT];
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t) {
+    int4 d = steps[s0 + (t < T ? t : 0)];
+    tdy[t] = d.y; tdx[t] = d.z;
+  }
+  f32x16 acc[WG_MAXT];
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  const int t_begin = blockIdx.z * tiles_per_split;
+  const int t_end = min(t_begin + tiles_per_split, tiles_total);
+  const bool wave_live = n0 + wave * 32 < cout;          // waves beyond the last output channel only help staging
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int b = tile / tiles_per_image;
+    const int r = tile - b * tiles_per_image;
+    const int ty0 = (r / tiles_x) * WG_TR, tx0 = (r - (r / tiles_x) * tiles_x) * WG_TC;
+    __syncthreads();                                       // previous tile's reads are done
+    // dY tile: 64 px x 128 n (zeros outside the image / beyond cout)
+    for (int i = tid; i < WG_TR * WG_TC * 32; i += 256) {
+      const int q = i & 31, p = i >> 5;                    // float4 index within the pixel, pixel
+      const int y = ty0 + p / WG_TC, xx = tx0 + p % WG_TC;
+      const int n = n0 + q * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (y < oh && xx < ow && n < cout) {                 // cout % 4 == 0 (host check)
+        v = *(const float4*)(dy + (((int64_t)b * oh + y) * ow + xx) * dy_ld + n);
+      }
+      *(float4*)&sdy[p][q * 4] = v;
+    }
+    // input halo tile: (TR + 2) x (TC + 2) px x 32 channels, zero outside the image
+    for (int i = tid; i < XH * XW * 8; i += 256) {
+      const int q = i & 7, p = i >> 3;
+      const int iy = ty0 - 1 + p / XW, ix = tx0 - 1 + p % XW;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w)
+        v = *(const float4*)(x + (((int64_t)b * in_h + iy) * in_w + ix) * in_ld + chan + q * 4);
+      *(float4*)&sx[p][q * 4] = v;
+    }
+    __syncthreads();
+    if (wave_live) {
+#pragma unroll 4
+      for (int kp = 0; kp < WG_TR * WG_TC; kp += 2) {
+        const int p = kp + lk;
+        const int py = p / WG_TC, px = p % WG_TC;
+        const float av = sdy[p][wave * 32 + li];
+        float bv[WG_MAXT];
+#pragma unroll
+        for (int t = 0; t < WG_MAXT; ++t) bv[t] = sx[(py + 1 + tdy[t]) * XW + px + 1 + tdx[t]][li];
+#pragma unroll
+        for (int t = 0; t < WG_MAXT; ++t)
+          if (t < T) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  if (!wave_live) return;
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t) {
+    if (t < T) {
+      float* o = partial + (((int64_t)blockIdx.z * nsteps + s0 + t) * cout) * 32;
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        int nn = n0 + wave * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * lk;
+        if (nn < cout) o[(int64_t)nn * 32 + li] = acc[t][rg];
+      }
+    }
+  }
+}
+
 extern "C" int ppst_conv_wgrad_f32(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial,
                                    int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
                                    int nchunks, int splits, void* stream) {
@@ -101,6 +192,19 @@ extern "C" int ppst_conv_wgrad_f32(const void* x, const void* dy, const void* st
     return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!x || !dy || !steps || !chunk_start || !partial) return PPST_ENULL;
+  // the LDS-staged kernel needs 16-B aligned rows (every caller on the train path has them); else the direct one
+  const bool lds_ok = cout % 4 == 0 && dy_ld % 4 == 0 && in_ld % 4 == 0 && ((uintptr_t)x | (uintptr_t)dy) % 16 == 0;
+  if (lds_ok) {
+    const int tiles_x = cdiv(ow, WG_TC), tiles_per_image = cdiv(oh, WG_TR) * tiles_x;
+    const int tiles_total = B * tiles_per_image;
+    const int tps = cdiv(tiles_total, splits);
+    // every split block must write its partial (the scatter sums all `splits` of them): an empty split writes zeros
+    dim3 grid(cdiv(cout, 128), nchunks, splits);
+    PPST_LAUNCH(conv_wgrad_lds_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (const int4*)steps,
+                (const int*)chunk_start, (float*)partial, B, in_h, in_w, in_ld, oh, ow, dy_ld, cout, nsteps, tiles_x, tiles_per_image,
+                tiles_total, tps);
+    return PPST_LAUNCH_CHECK();
+  }
   int rows_total = B * oh;
   int rps = cdiv(rows_total, splits);
   dim3 grid(cdiv(cout, 128), nchunks, splits);
@@ -280,12 +384,36 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     dw[t] = accumulate ? dw[t] + s * scale : s * scale;
   }
 }
-__global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
-                                                           int B, int N, int K, float scale, int64_t total) {
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    int k = (int)(t % K), b = (int)(t / K);
+// dX = dY W streams the weight matrix once (4*N*K bytes): block (kx, ns) owns 256 columns k and the LDG_ROWS rows
+// n of its slice, accumulates every batch row in registers (dY[b][n] is a wave-uniform broadcast) and writes a partial;
+// a second launch sums the slices in a fixed order (deterministic).  (Round 1's version ran one thread per output with a
+// sequential loop over n: 16 blocks, latency bound -- 17 % of the train step.)
+#define LDG_ROWS 32
+#define LDG_BMAX 16
+__global__ __launch_bounds__(256) void linear_dgrad_partial_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                   float* __restrict__ partial, int B, int N, int K, int b0) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int n0 = blockIdx.y * LDG_ROWS, n1 = min(n0 + LDG_ROWS, N);
+  float acc[LDG_BMAX];
+#pragma unroll
+  for (int b = 0; b < LDG_BMAX; ++b) acc[b] = 0.f;
+  if (k < K) {
+    for (int n = n0; n < n1; ++n) {
+      const float wv = w[(int64_t)n * K + k];
+#pragma unroll
+      for (int b = 0; b < LDG_BMAX; ++b)
+        if (b0 + b < B) acc[b] += dy[(int64_t)(b0 + b) * N + n] * wv;
+    }
+#pragma unroll
+    for (int b = 0; b < LDG_BMAX; ++b)
+      if (b0 + b < B) partial[((int64_t)blockIdx.y * B + b0 + b) * K + k] = acc[b];
+  }
+}
+__global__ __launch_bounds__(256) void linear_dgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dx, int nsplit,
+                                                                  int64_t bk, float scale) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < bk; t += (int64_t)gridDim.x * 256) {
     float s = 0.f;
-    for (int n = 0; n < N; ++n) s += dy[(int64_t)b * N + n] * w[(int64_t)n * K + k];
+    for (int i = 0; i < nsplit; ++i) s += partial[(int64_t)i * bk + t];
     dx[t] = s * scale;
   }
 }
@@ -298,13 +426,18 @@ extern "C" int ppst_linear_wgrad(const void* dy, const void* x, void* dw, int B,
               K, scale, accumulate, total);
   return PPST_LAUNCH_CHECK();
 }
-extern "C" int ppst_linear_dgrad(const void* dy, const void* w, void* dx, int B, int N, int K, float scale, void* stream) {
+extern "C" int64_t ppst_linear_dgrad_ws(int B, int N, int K) { return (int64_t)cdiv(N, LDG_ROWS) * B * K * (int64_t)sizeof(float); }
+extern "C" int ppst_linear_dgrad(const void* dy, const void* w, void* dx, void* ws, int B, int N, int K, float scale, void* stream) {
   if (B <= 0 || N <= 0 || K <= 0) return PPST_EINVAL;
-  if (!dy || !w || !dx) return PPST_ENULL;
-  int64_t total = (int64_t)B * K, blocks = cdiv64(total, 256);
+  if (!dy || !w || !dx || !ws) return PPST_ENULL;
+  const int nsplit = cdiv(N, LDG_ROWS);
+  for (int b0 = 0; b0 < B; b0 += LDG_BMAX)
+    PPST_LAUNCH(linear_dgrad_partial_kernel, dim3(cdiv(K, 256), nsplit), dim3(256), 0, as_stream(stream), (const float*)dy, (const float*)w,
+                (float*)ws, B, N, K, b0);
+  const int64_t bk = (int64_t)B * K;
+  int64_t blocks = cdiv64(bk, 256);
   if (blocks > 4096) blocks = 4096;
-  PPST_LAUNCH(linear_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)dy, (const float*)w, (float*)dx, B, N, K,
-              scale, total);
+  PPST_LAUNCH(linear_dgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)ws, (float*)dx, nsplit, bk, scale);
   return PPST_LAUNCH_CHECK();
 }
 

@@ -485,7 +485,8 @@ def linear_dgrad(dy, w, scale=1.0):
     B, N = dy.shape
     K = w.shape[1]
     dx = torch.empty((B, K), device=dy.device, dtype=torch.float32)
-    check(lib.ppst_linear_dgrad(_p(dy), _p(w), _p(dx), B, N, K, float(scale), _stream()), "ppst_linear_dgrad")
+    ws = torch.empty(lib.ppst_linear_dgrad_ws(B, N, K) // 4, device=dy.device, dtype=torch.float32)
+    check(lib.ppst_linear_dgrad(_p(dy), _p(w), _p(dx), _p(ws), B, N, K, float(scale), _stream()), "ppst_linear_dgrad")
     return dx
 
 

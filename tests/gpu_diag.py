@@ -738,7 +738,9 @@ def t_train_r1():
             worst_max = max(worst_max, rmax)
             if r > worst:
                 worst, worst_k = r, k
-        ok = (worst <= 5e-3 and worst_max <= 2e-2) if prec == 2 else (worst <= 2e-2 and worst_max <= 1e-1)
+        # measured (round 2): exact convs 6e-5 / 3.5e-4 (the second-order sweep itself is exact); production convs
+        # 2.5e-3 / 3.5e-2 on uniform-noise images, where the rounding of the bf16 hi+lo split flips a few leaky-ReLU gates
+        ok = (worst <= 5e-4 and worst_max <= 2e-3) if prec == 2 else (worst <= 5e-3 and worst_max <= 5e-2)
         RES.append(("R1 %d gradients (precision %d)" % (size, prec), ok))
         print("R1 %d precision %d: worst L2-relative gradient error %.3e (%s), worst max-relative %.3e over %d tensors %s"
               % (size, prec, worst, worst_k, worst_max, len(gr), "ok" if ok else "FAIL"), flush=True)
