@@ -47,16 +47,34 @@ def swap_step(model, content, style, alpha, glue):
     return model(sp, code, target=None, command="decode")
 
 
-def conv_traffic():
-    """HBM bytes per conv launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
-    rocprofv3 --pmc runs of this same command; summary committed under profiles/).  PMC
-    counters cannot be read from inside the process, so the committed measurement is quoted;
-    None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def _pmc_file():
+    """Newest committed PMC summary (profiles/rNN_pmc_traffic.json).  PMC counters cannot be read from inside the process:
+    the roofline quotes the committed measurement and says which commit / command it was taken at."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
     try:
-        return json.load(open(path))["conv_mfma"]["hbm_bytes_per_launch"]
+        return json.load(open(files[-1])), os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
+def conv_traffic():
+    """HBM bytes per conv launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of this
+    same command; summary committed under profiles/); None if absent."""
+    d, _ = _pmc_file()
+    try:
+        return d["conv_mfma"]["hbm_bytes_per_launch"]
     except Exception:
         return None
+
+
+def conv_traffic_source():
+    d, name = _pmc_file()
+    if d is None:
+        return None
+    return {"file": "profiles/" + name, "measured_at_commit": d.get("commit"), "command": d.get("command")}
 
 
 def upfirdn2d_rate(B, dev):
@@ -85,8 +103,9 @@ def upfirdn2d_rate(B, dev):
 
 def conv_pmc():
     """Effective clock of the conv launches from the GRBM_GUI_ACTIVE pass (profiles/, see conv_traffic)."""
+    d, _ = _pmc_file()
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["conv_mfma"].get("effective_clock_ghz")
+        return d["conv_mfma"].get("effective_clock_ghz")
     except Exception:
         return None
 
@@ -126,7 +145,8 @@ def cpu_baseline(seed):
 
 DTYPE_NOTE = {"bf16x3": "bf16x3 (fp32 split into hi+lo bf16, 3 MFMA passes, fp32 accumulate)",
               "bf16": "bf16 (single MFMA pass, fp32 accumulate / statistics / modulation)",
-              "fp16": "fp16 (single MFMA pass, fp32 accumulate / statistics / modulation)"}
+              "fp16": "fp16 (single MFMA pass, fp32 accumulate / statistics / modulation)",
+              "fp16x2": "fp16x2 (activation fp16 hi+lo, weight fp16: 2 MFMA passes, fp32 accumulate) -- measured experiment"}
 FLOP_PER_IMAGE_PASS = (23.7 + 22.7 + 753.9) * 1e9     # E1 + E2 + G with feature heads
 FLOP_PER_PAIR_PASS = (17.2 + 38.8 + 486.2) * 1e9      # corrm + E2 with warp + G decode
 
@@ -206,7 +226,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp16"])
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp16", "fp16x2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="swap", choices=["swap", "grid", "train"],
                     help="swap: BASELINE configs[1] (the headline line); grid: configs[2], 8x8 folder at 512 with the guided filter, "
@@ -228,7 +248,7 @@ def main():
 
     from ppst_amd import glue, ops, weights as W
     from ppst_amd.ppst_model import create_model
-    ops.set_precision({"bf16x3": 0, "bf16": 1, "fp16": 3}[args.precision])
+    ops.set_precision({"bf16x3": 0, "bf16": 1, "fp16": 3, "fp16x2": 4}[args.precision])
     if args.conv_variant is not None:
         ops.CONV_VARIANT["value"] = args.conv_variant
 
@@ -277,7 +297,7 @@ def main():
 
     if rank == 0:
         swaps = world * B * args.steps
-        passes = 3 if args.precision == "bf16x3" else 1
+        passes = {"bf16x3": 3, "fp16x2": 2}.get(args.precision, 1)
         achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         peak = PEAK_BF16_DENSE_TF / passes
         res = {
@@ -296,7 +316,7 @@ def main():
                 "peak_note": "bf16 dense MFMA 2500 TF / %d MFMA passes per algorithmic MAC" % passes,
                 "frac_vs_dense_bf16": achieved / PEAK_BF16_DENSE_TF,
                 "launches": conv_launches, "kernel_ms_total": conv_ms,
-                "share_of_step_time": conv_ms * 1e-3 / dt, "traffic": conv_traffic(),
+                "share_of_step_time": conv_ms * 1e-3 / dt, "traffic": conv_traffic(), "traffic_source": conv_traffic_source(),
                 "effective_clock_ghz_pmc": conv_pmc(),
             },
         }

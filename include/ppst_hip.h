@@ -141,7 +141,8 @@ typedef struct ppst_conv_args {
   int32_t in_off_y, in_off_x;    /* input pixel = tile pixel + tap + in_off (e.g. -pad) */
   int32_t out_sy, out_sx;        /* output pixel stride (2 for the transposed conv) ... */
   int32_t act;                   /* PPST_ACT_* | 0x100: residual joins AFTER the activation */
-  int32_t precision;             /* 0 bf16x3 (fp32-class), 1 bf16 single pass, 3 fp16 single pass (ppst_conv_pack with the same value) */
+  int32_t precision;             /* 0 bf16x3 (fp32-class), 1 bf16 single pass, 3 fp16 single pass, 4 fp16 two-pass
+                                    (activation hi + lo, weight fp16); ppst_conv_pack with the same value */
   int32_t res_ld;
   int32_t tile_h, tile_w;        /* logical (pre-scatter) output extent tiled by 16x16 */
   int32_t halo;                  /* 0: every tap is (0,0) (1x1 conv); 1: taps in [-1,1]^2 */

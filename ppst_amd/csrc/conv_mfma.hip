@@ -72,17 +72,27 @@ extern "C" int ppst_conv_clock_buffer(void* buf, int n) {   // diagnostic build 
 // statistics and StyleMod stay fp32 as in every mode.
 typedef _Float16 __attribute__((ext_vector_type(8))) half8;
 __device__ __forceinline__ unsigned short f2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
-template <int WM, int WN, int HALO, bool X3, bool INSS, int NAS = 0, bool F16 = false>
+// x = hi + lo with hi, lo IEEE half: 22 significant bits while |x| stays inside the half range (activations do)
+__device__ __forceinline__ void split_f16(float x, unsigned short& hi, unsigned short& lo) {
+  const _Float16 h = (_Float16)x;
+  hi = __builtin_bit_cast(unsigned short, h);
+  lo = __builtin_bit_cast(unsigned short, (_Float16)(x - (float)h));
+}
+// X2 (with F16, !X3): two passes -- the activation as fp16 hi + lo (22 significant bits), the weight rounded once to
+// fp16 (11 bits): al*b + ah*b.  A measured experiment: 2/3 of the MFMAs of the fp32-class mode.
+template <int WM, int WN, int HALO, bool X3, bool INSS, int NAS = 0, bool F16 = false, bool X2 = false>
 __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(ConvKArgs a) {
+  constexpr bool ALO = X3 || X2;                         // the activation tile has lo planes
   constexpr int NT = 64 * WM * WN;
   constexpr int TH = 4 * WM, TW = 16;
   constexpr int HH = TH + 2 * HALO, HW = TW + 2 * HALO, HP = HH * HW;
   constexpr int PLANE = ((HP * 16 + 255) / 256) * 256;  // bytes
-  constexpr int NPL = X3 ? 8 : 4;                        // planes per A buffer (hi g0..3, lo g0..3)
+  constexpr int NPL = ALO ? 8 : 4;                       // planes per A buffer (hi g0..3, lo g0..3)
+  constexpr int NPLB = X3 ? 8 : 4;                       // planes per weight blob
   constexpr int ABUF = NPL * PLANE;
   constexpr int BN = 64 * WN;
   constexpr int BPLANE = BN * 16;
-  constexpr int BBUF = NPL * BPLANE;
+  constexpr int BBUF = NPLB * BPLANE;
   constexpr int A_ITEMS = HP * 8;                        // float4 items per chunk
   constexpr int A_IT = (A_ITEMS + NT - 1) / NT;
   constexpr int B_ITEMS = BBUF / 16;
@@ -204,12 +214,13 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
           v.z = in_act(ras1.x * v.z + ras1.y); v.w = in_act(ras1.z * v.w + ras1.w);
         }
         unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
-        if (F16) { h0 = f2h(v.x); h1 = f2h(v.y); h2 = f2h(v.z); h3 = f2h(v.w); l0 = l1 = l2 = l3 = 0; }
+        if (F16 && X2) { split_f16(v.x, h0, l0); split_f16(v.y, h1, l1); split_f16(v.z, h2, l2); split_f16(v.w, h3, l3); }
+        else if (F16) { h0 = f2h(v.x); h1 = f2h(v.y); h2 = f2h(v.z); h3 = f2h(v.w); l0 = l1 = l2 = l3 = 0; }
         else { split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3); }
         int off = (l >> 4) * PLANE + pix * 16 + (l & 1) * 8;
         uint2 hv = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
         *(uint2*)(base + off) = hv;
-        if (X3) {
+        if (ALO) {
           uint2 lv = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
           *(uint2*)(base + 4 * PLANE + off) = lv;
         }
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   bf16x8 ah, al;
   ld_b(b0h, b0l, 0);
   ah = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, 0));
-  if (X3) al = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, 0) + 4 * PLANE);
+  if (ALO) al = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, 0) + 4 * PLANE);
   // drain the prologue's LDS reads so both edges into the loop header carry an empty LDS
   // scoreboard (otherwise hipcc makes the first MFMAs of every step wait for the prefetch
   // reads issued just before them)
@@ -349,6 +360,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
       acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bch[nt], acc[mt][nt], 0, 0, 0);       \
       acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcl[nt], acc[mt][nt], 0, 0, 0);       \
     }                                                                                                 \
+    if (X2) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, al), __builtin_bit_cast(half8, bch[nt]), acc[mt][nt], 0, 0, 0); \
     if (F16) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah), __builtin_bit_cast(half8, bch[nt]), acc[mt][nt], 0, 0, 0); \
     else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bch[nt], acc[mt][nt], 0, 0, 0);    \
   }
@@ -396,10 +408,10 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
         nh = ah; nl = al;                                                                             \
       } else if (mt < 3) {                                                                            \
         nh = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1));                                    \
-        if (X3) nl = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1) + 4 * PLANE);                \
+        if (ALO) nl = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1) + 4 * PLANE);               \
       } else if (has1) {                                                                              \
         nh = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0));                                         \
-        if (X3) nl = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0) + 4 * PLANE);                     \
+        if (ALO) nl = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0) + 4 * PLANE);                    \
       }                                                                                               \
       ABL_MFMA_GROUP(bch, bcl, mt)                                                                    \
       if (MFMA_FIRST && mt == 0) {                                                                    \
@@ -412,7 +424,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
       if (mt == 1) { TR(2) }                                                                          \
       if (mt == 3) { TR(3) }                                                                          \
       ah = nh;                                                                                        \
-      if (X3) al = nl;                                                                                \
+      if (ALO) al = nl;                                                                               \
       /* convert + write the next chunk's tile while the last MFMA group executes: the VALU   */     \
       /* work of the staging store overlaps the matrix pipe instead of following it            */     \
       if (mt == 2 && newA2) a_store(sl2);                                                             \
@@ -602,7 +614,7 @@ extern "C" int ppst_conv_pack(const void* w, int64_t sn, int64_t sc, int64_t sy,
                               const int32_t* src_c, const int32_t* src_ky, const int32_t* src_kx, int nsteps, int n_groups,
                               int precision, void* out, void* stream) {
   if (cout <= 0 || (bn != 64 && bn != 128 && bn != 256) || nsteps <= 0 || (n_groups != 1 && n_groups != 4) ||
-      (precision != 0 && precision != 1 && precision != 3))
+      (precision != 0 && precision != 1 && precision != 3 && precision != 4))
     return PPST_EINVAL;
   if (!w || !src_c || !src_ky || !src_kx || !out) return PPST_ENULL;
   int n_tiles = (cout + bn - 1) / bn;
@@ -611,7 +623,7 @@ extern "C" int ppst_conv_pack(const void* w, int64_t sn, int64_t sc, int64_t sy,
   if (blocks > 4096) blocks = 4096;
   PPST_LAUNCH(conv_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)w, sn, sc, sy, sx,
                      scale, cout, bn, src_c, src_ky, src_kx, nsteps, n_groups, precision == 0 ? 1 : 0, (unsigned short*)out, total,
-                     precision == 3 ? 1 : 0);
+                     (precision == 3 || precision == 4) ? 1 : 0);
   return PPST_LAUNCH_CHECK();
 }
 
@@ -687,10 +699,10 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
 
 extern "C" int ppst_conv_tiles(int tile_h, int tile_w, int tile_rows) { return cdiv(tile_h, tile_rows) * cdiv(tile_w, 16); }
 
-template <int WM, int WN, int HALO, bool X3, int NAS = 0, bool F16 = false>
+template <int WM, int WN, int HALO, bool X3, int NAS = 0, bool F16 = false, bool X2 = false>
 static void launch_conv(const ConvKArgs& k, int blocks, hipStream_t st) {
-  if (k.in_ss) PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, true, NAS, F16>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
-  else PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, false, NAS, F16>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
+  if (k.in_ss) PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, true, NAS, F16, X2>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
+  else PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, false, NAS, F16, X2>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
 }
 
 extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
@@ -698,7 +710,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   if (a->B < 0 || a->in_h <= 0 || a->in_w <= 0 || a->in_ld <= 0 || a->in_ld % 4 || a->out_h <= 0 || a->out_w <= 0 ||
       a->out_ld < a->cout || a->cout <= 0 || a->cout % 4 || a->out_ld % 4 || (a->residual && a->res_ld % 4) || a->nsteps <= 0 || (a->n_groups != 1 && a->n_groups != 4) || a->pad_mode < 0 ||
       a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 ||
-      (a->precision != 0 && a->precision != 1 && a->precision != 3) || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128 && a->bn != 256) || (a->residual && a->res_ld < a->cout) ||
+      (a->precision != 0 && a->precision != 1 && a->precision != 3 && a->precision != 4) || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128 && a->bn != 256) || (a->residual && a->res_ld < a->cout) ||
       a->variant < 0 || a->variant > 1 || (a->variant == 0 && a->bn == 256) ||
       (a->variant == 1 && (a->precision != 0 || a->bn == 64 || !a->early_a)) ||
       (a->tile_rows != 16) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
@@ -749,11 +761,11 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
     return e2;
   }
   const bool x3 = a->precision == 0;
-  const bool f16 = a->precision == 3;
+  const bool f16 = a->precision == 3, x2 = a->precision == 4;
 #define DISPATCH(WM_, WN_)                                                                                         \
   do {                                                                                                             \
-    if (a->halo) { if (x3) launch_conv<WM_, WN_, 1, true>(k, blocks, st); else if (f16) launch_conv<WM_, WN_, 1, false, 0, true>(k, blocks, st); else launch_conv<WM_, WN_, 1, false>(k, blocks, st); } \
-    else         { if (x3) launch_conv<WM_, WN_, 0, true>(k, blocks, st); else if (f16) launch_conv<WM_, WN_, 0, false, 0, true>(k, blocks, st); else launch_conv<WM_, WN_, 0, false>(k, blocks, st); } \
+    if (a->halo) { if (x3) launch_conv<WM_, WN_, 1, true>(k, blocks, st); else if (x2) launch_conv<WM_, WN_, 1, false, 0, true, true>(k, blocks, st); else if (f16) launch_conv<WM_, WN_, 1, false, 0, true>(k, blocks, st); else launch_conv<WM_, WN_, 1, false>(k, blocks, st); } \
+    else         { if (x3) launch_conv<WM_, WN_, 0, true>(k, blocks, st); else if (x2) launch_conv<WM_, WN_, 0, false, 0, true, true>(k, blocks, st); else if (f16) launch_conv<WM_, WN_, 0, false, 0, true>(k, blocks, st); else launch_conv<WM_, WN_, 0, false>(k, blocks, st); } \
   } while (0)
   // (8-row tiles -- two 80-KB blocks per CU -- were measured 35 % slower than one 16-row block
   //  per CU on MI355X and are not instantiated; tile_rows == 8 is rejected above.)

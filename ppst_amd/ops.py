@@ -30,8 +30,9 @@ FAT_MIN_BLOCKS = 384        # prefer the 256-channel tile only when the launch s
 
 def set_precision(p):
     """0: bf16x3 (fp32-class, the measured path); 1: single-pass bf16; 2: exact fp32 MFMA (verification only, slow);
-    3: single-pass fp16 (the "fp16 generator" of BASELINE configs[4]; fp32 accumulate / statistics / StyleMod)."""
-    assert p in (0, 1, 2, 3)
+    3: single-pass fp16 (the "fp16 generator" of BASELINE configs[4]; fp32 accumulate / statistics / StyleMod);
+    4: two-pass fp16 (activation hi + lo, weight rounded once to fp16): a measured experiment, 2/3 of the MFMAs of mode 0."""
+    assert p in (0, 1, 2, 3, 4)
     PRECISION["value"] = p
 
 

@@ -206,6 +206,8 @@ def t_conv():
         report("conv bf16x1 " + name, nchw(y1.cpu()), ref, 2e-2)
         plan3 = ops.ConvPlan(g(w), kind=kind, precision=3)      # single-pass fp16 (11 significant bits per operand)
         report("conv fp16x1 " + name, nchw(plan3(g(nhwc(x)), pad_mode=pm).cpu()), ref, 3e-3)
+        plan4 = ops.ConvPlan(g(w), kind=kind, precision=4)      # two-pass fp16: activation hi + lo, weight rounded to fp16
+        report("conv fp16x2 " + name, nchw(plan4(g(nhwc(x)), pad_mode=pm).cpu()), ref, 3e-4)
         plan2 = ops.ConvPlan(g(w), kind=kind, precision=2)      # exact-fp32 verification kernel (conv_f32.hip)
         st_ = plan2(g(nhwc(x)), pad_mode=pm, stats=True)
         report("conv fp32  " + name, nchw(st_[0].cpu()), ref, 5e-6)     # fp32 fmaf chain over up to 4608 terms
@@ -584,7 +586,12 @@ def t_precision():
     (tests/test_gpu_parity.py:test_reduced_precision_modes docstring): relative RMS and max-norm of the output image."""
     from ppst_amd.ppst_model import create_model
     from ppst_amd.evaluation import simple_swap
-    bars = {3: ("fp16", 5e-3, 3e-2, 2e-2, 1e-1), 1: ("bf16", 5e-2, 2e-1, 1e-1, 5e-1)}   # (tag, rms 1024 enc/dec, max, rms 512 swap, max)
+    # (tag, rms 1024 enc/dec, max, rms 512 swap, max).  fp16x2 = the two-pass experiment: it must pass the fp32 gate itself
+    # (1e-3 max-norm on the generator output, BASELINE north_star) to count as an fp32-class mode
+    # MEASURED (round 2): fp16x2 is 2.0-2.5e-4 per layer (the fp16 rounding of the weights) and 2.7e-3 RMS / 3.1e-3 max-norm
+    # over the whole recipe -- three times OUTSIDE the fp32 gate, for +8 % swaps/s.  It therefore is not an fp32-class
+    # mode; the bars below only keep it from regressing (the first-stated bars 5e-4 / 1e-3 are the gate it failed).
+    bars = {3: ("fp16", 5e-3, 3e-2, 2e-2, 1e-1), 1: ("bf16", 5e-2, 2e-1, 1e-1, 5e-1), 4: ("fp16x2", 5e-3, 1e-2, 5e-3, 1e-2)}
     sd0 = W.make_state_dict(0, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
     im = W.synthetic_images(13, 2, size=1024)
     nz1024 = W.make_noise(5, 1, S=128)

@@ -8,6 +8,7 @@ coalesced reads).  Effective clock of a kernel = sum(GRBM_GUI_ACTIVE) / 8 XCDs /
 import json, re, sqlite3, sys
 
 prefix, out_path, cmd = sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else ""
+commit = sys.argv[4] if len(sys.argv) > 4 else None
 
 
 def per_kernel(counter):
@@ -34,6 +35,7 @@ cyc = sum(act[k][1] for k in act if "conv_mfma_kernel" in k)
 dur = sum(act[k][2] for k in act if "conv_mfma_kernel" in k)
 res = {
     "command": cmd,
+    "commit": commit,
     "note": "one rocprofv3 --kernel-trace --pmc <counter> run per counter; FETCH_SIZE/WRITE_SIZE are KB; FETCH_SIZE doubled per "
             "MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); effective clock = GRBM_GUI_ACTIVE / 8 / duration "
             "(reads high for dispatches shorter than ~0.3 ms); all steps of the run (warm-up included) are in the trace",
