@@ -95,7 +95,15 @@ __global__ __launch_bounds__(256) void upfirdn2d_chan(const float4* __restrict__
   for (int i = 0; i < KH * KW; ++i) kf[i] = p.k[KH * KW - 1 - i];
   // S2D: the padded extent (2*ceil(oh/2) x 2*ceil(ow/2)) is written in full, zeros beyond (oh, ow)
   const int ew = S2D ? ((p.out_w + 1) & ~1) : p.out_w;
-  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < nwork; t64 += (uint64_t)gridDim.x * 256) {
+  // XCD-aware order (round 2): blocks are dealt round-robin over the 8 XCDs, so with a plain linear order the two
+  // blocks that share halo rows (consecutive row pairs) sit on different XCDs and each XCD's L2 fetches those rows from
+  // HBM itself -- the 1.4x over-fetch of round 1's PMC pass.  Virtual block v works on chunk
+  // (v % 8) * ceil(T / 8) + v / 8: every XCD walks a contiguous band of rows (about one image at batch 8) in order.
+  const unsigned nblk = (nwork + 255u) >> 8, per = (nblk + 7u) >> 3;
+  for (unsigned v = blockIdx.x; v < per * 8u; v += gridDim.x) {
+    const unsigned wblk = (v & 7u) * per + (v >> 3);
+    const uint64_t t64 = (uint64_t)wblk * 256 + threadIdx.x;
+    if (wblk >= nblk || t64 >= nwork) continue;
     unsigned c4u, sxu, oyu;
     unsigned r = fd_divmod((unsigned)t64, d_c, c4u);
     r = fd_divmod(r, d_xs, sxu);
@@ -207,7 +215,7 @@ static int launch_chan(const float* x, float* y, const UfParams& p, int down, bo
   const int rows = down == 1 ? cdiv(eh, 2) : eh;   // row groups: two output rows per thread when down == 1
   int64_t nwork = (int64_t)p.major * rows * cdiv(ew, 4) * (p.minor / 4);
   if (nwork > PPST_IDX32_MAX) return PPST_EINVAL;
-  int64_t blocks = cdiv64(nwork, 256);
+  int64_t blocks = cdiv64(cdiv64(nwork, 256), 8) * 8;      // a multiple of 8: v % 8 is the XCD slot in every stride iteration
   if (blocks > 256 * 16) blocks = 256 * 16;
   dim3 g((unsigned)blocks), b(256);
   const FastDiv d_c = make_fastdiv(p.minor / 4), d_xs = make_fastdiv(cdiv(ew, 4)), d_oh = make_fastdiv(rows);

@@ -430,8 +430,12 @@ def conv_wgrad(plan, x, dy, splits=None):
     assert cout == plan.cout
     nchunks = plan.chunk_start.numel() - 1
     if splits is None:
-        splits = max(1, min(64, (2048 + nchunks * ((cout + 127) // 128) - 1) // (nchunks * ((cout + 127) // 128))))
-        splits = min(splits, B * oh)
+        # blocks = n-tiles x chunks x splits; the LDS-staged kernel runs 3 blocks per CU (768 slots): aim for ~2 rounds, keep
+        # >= 2 pixel tiles (2 x 32 px) per block.  (Round 1 capped splits at 64: the 512x512 layers with few channels ran on
+        # 64-256 blocks, a third of the chip or less.)
+        per = nchunks * ((cout + 127) // 128)
+        tiles_total = B * ((oh + 1) // 2) * ((ow + 31) // 32)
+        splits = max(1, min((1536 + per - 1) // per, max(1, tiles_total // 2), 2048))
     partial = torch.empty((splits, plan.nsteps, cout, 32), device=x.device, dtype=torch.float32)
     check(lib.ppst_conv_wgrad_f32(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), B, H, W, in_ld, oh, ow, dy_ld,
                                   cout, plan.nsteps, nchunks, splits, _stream()), "ppst_conv_wgrad_f32")
