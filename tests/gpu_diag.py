@@ -21,6 +21,18 @@ from ppst_amd.networks.base_network import to_nhwc  # noqa: E402
 
 dev = "cuda"
 RES = []
+_ORACLE_SWAPS = {}
+
+
+def oracle_swap512():
+    """The 512x512 oracle swap of t_networks / t_precision (same weights, images, noise): computed once per process --
+    CPU oracle time dominates the GPU suite."""
+    if "s" not in _ORACLE_SWAPS:
+        sd = W.make_state_dict(1, bias_std=0.1, noise_weight=0.1)
+        imgs = W.synthetic_images(5, 2)
+        with torch.no_grad():
+            _ORACLE_SWAPS["s"] = O.PPSTOracle(sd, noise=W.make_noise(3, 1)).simple_swap(imgs[0:1], imgs[1:2], alpha=1.0)
+    return _ORACLE_SWAPS["s"]
 
 
 def rel(a, b):
@@ -444,9 +456,8 @@ def t_networks():
     noise = W.make_noise(3, 1)
     imgs = W.synthetic_images(5, 2)
     t0 = time.time()
-    orc = O.PPSTOracle(sd, noise=noise)
     with torch.no_grad():
-        r = orc.simple_swap(imgs[0:1], imgs[1:2], alpha=1.0)
+        r = oracle_swap512()
         d_ref = O.discriminator(sd, imgs)
     print("oracle swap %.1fs" % (time.time() - t0), flush=True)
     m = create_model(state_dict=sd, with_D=True)
@@ -532,7 +543,7 @@ def t_configs():
     orc = O.PPSTOracle(sd, noise=W.make_noise(3, 1))
     with torch.no_grad():
         ref = {}
-        for (i, j) in [(0, 1), (1, 0)]:
+        for (i, j) in [(0, 1)]:                  # one pair against the CPU oracle; all four go through the sharding checks
             r = orc.simple_swap(cs[i:i + 1], ss_[j:j + 1], alpha=1.0)
             ref[(i, j)] = (r["out"], O.smooth(r["out"], cs[i:i + 1]))
         # the image passes and the pair passes of two simulated ranks (phase 1 -> exchange -> phase 3), then the same grid
@@ -600,8 +611,7 @@ def t_precision():
     sd = W.make_state_dict(1, bias_std=0.1, noise_weight=0.1)
     imgs = W.synthetic_images(5, 2)
     nz = W.make_noise(3, 1)
-    with torch.no_grad():
-        ref512 = O.PPSTOracle(sd, noise=nz).simple_swap(imgs[0:1], imgs[1:2], alpha=1.0)["out"]
+    ref512 = oracle_swap512()["out"]
 
     def errs(a, b):
         a, b = a.double().cpu(), b.double()
@@ -634,7 +644,9 @@ def t_train_d():
     import train_oracle as T
     from ppst_amd.networks.discriminator import StyleGAN2Discriminator
     from ppst_amd.train import DiscriminatorTrainer
-    for size, B in ((128, 2), (256, 2)):
+    # (the 256x256 leg of round 1 went when tests/golden/train512.npz -- the reference's own step at 512x512 -- arrived:
+    #  CPU autograd oracle time dominates the GPU suite)
+    for size, B in ((128, 2),):
         sd = W.make_state_dict(2, size=size, with_nce=False, bias_std=0.1)
         D = StyleGAN2Discriminator(None, size=size)
         D.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith("D.")}, strict=True)
@@ -714,7 +726,8 @@ def t_train_r1():
     import train_oracle as T
     from ppst_amd.networks.discriminator import StyleGAN2Discriminator
     from ppst_amd.train import DiscriminatorTrainer
-    for size, B, prec in ((128, 2, 0), (256, 2, 0), (128, 2, 2), (256, 2, 2)):
+    oracle_cache = {}
+    for size, B, prec in ((128, 2, 0), (128, 2, 2)):      # larger: the reference-generated R1 gradients at 512x512 (train512.npz)
         # prec 2 = exact-fp32 verification convs: the forward then rounds like the oracle's and the tight bar must hold --
         # what remains at prec 0 is gate flips caused by the rounding of the bf16 hi+lo split, not a defect
         sd = W.make_state_dict(3, size=size, with_nce=False, bias_std=0.1)
@@ -725,7 +738,9 @@ def t_train_r1():
         tr = DiscriminatorTrainer(D)
         torch.manual_seed(size + 1)
         real = torch.rand(B, 3, size, size) * 2 - 1
-        pen, gr = T.r1_step_grads(sd, real, size=size)
+        if size not in oracle_cache:
+            oracle_cache[size] = T.r1_step_grads(sd, real, size=size)      # CPU double backward: once per size
+        pen, gr = oracle_cache[size]
         try:
             losses = tr.r1_losses_and_grads(g(real))
             torch.cuda.synchronize()

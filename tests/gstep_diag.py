@@ -5,6 +5,7 @@ Usage (GPU box):  python tests/gstep_diag.py [blocks|s1|s2|all]
 The pytest -m gpu tests (tests/test_gpu_gstep.py) assert the same comparisons."""
 import math
 import os
+import re
 import sys
 import traceback
 import zlib
@@ -415,7 +416,7 @@ def _within_class_bar(key, numel, e_max, e_l2, floor_max, floor_l2, precision, t
 def _net_grad_check(tag, trainer, fp, sd64, outs_gpu, outs_ref, extra_gpu=(), extra_ref=(), tol=5e-3, prefix=""):
     """random cotangents on every output; parameter (and extra input) gradients of the HIP network vs the oracle's autograd."""
     torch.manual_seed(123)
-    cots = [torch.randn(o.shape, dtype=torch.float64) for o in outs_ref]
+    cots = [torch.randn(o.shape, dtype=torch.float64).to(o.dtype) for o in outs_ref]
     for net in trainer.fp.values():
         net.zero_grad()
     loss = None
@@ -428,14 +429,15 @@ def _net_grad_check(tag, trainer, fp, sd64, outs_gpu, outs_ref, extra_gpu=(), ex
     names = [n for n in fp.names if sd64[prefix + n].requires_grad]
     gr = torch.autograd.grad(lr, [sd64[prefix + n] for n in names] + list(extra_ref), allow_unused=True)
     worst = []
-    gscale = max(float(r.abs().max()) for r in gr[:len(names)] if r is not None)      # largest gradient entry of the network
+    gscale = max(float(r.abs().max()) for r in gr[:len(names)] if r is not None)      # (exact zeros in float64, ~1e-7 relative in float32)      # largest gradient entry of the network
     for n, r in zip(names, gr[:len(names)]):
         if r is None:
             continue
         a = fp.g(n).double().cpu().view(-1)
-        r = r.detach().reshape(-1)
+        r = r.detach().double().reshape(-1)
         sc = r.abs().max().item()
-        if sc < 1e-9 * gscale:      # exact zero in float64 (a bias in front of an instance norm): ours must be rounding-sized
+        null = sc < 1e-9 * gscale or re.match(r"^(layer(32|64|128|256)\.(2|6)\.bias|layert1?\.\d\.conv[12]\.bias|ToRGB\.(conv\.)?bias|ToSpatialCode\.1\.Conv\.bias)$", n)
+        if null:                    # a bias in front of an instance norm: exact gradient 0 (rounding noise in float32); ours must be noise-sized
             if a.abs().max().item() > 1e-5 * gscale:
                 worst.append((float("inf"), float("inf"), n + " (null direction, ours %.2e of %.2e)" % (a.abs().max().item(), gscale)))
             continue
@@ -445,13 +447,13 @@ def _net_grad_check(tag, trainer, fp, sd64, outs_gpu, outs_ref, extra_gpu=(), ex
     # moves single entries, so the max-norm is reported and held to 5e-2 only), 5e-2 for the scalar cancelling sums
     nbad = sum(1 for w_ in worst if (w_[1] > (5e-2 if w_[3] == 1 else (1.5e-2 if cancelling_sum("grad." + prefix + w_[2]) else tol))) or w_[0] > 5e-2)
     RES.append((tag + " parameter gradients", nbad == 0))
-    print("%s: %d parameter gradients vs oracle autograd (float64), %d outside the bar (l2 %.0e, max 5e-2); worst:" % (tag, len(worst), nbad, tol), flush=True)
+    print("%s: %d parameter gradients vs oracle autograd, %d outside the bar (l2 %.0e, max 5e-2); worst:" % (tag, len(worst), nbad, tol), flush=True)
     for i_, w_ in enumerate(worst):
         if i_ < 12:
             print("   %-58s max %.2e l2 %.2e" % (w_[2], w_[0], w_[1]), flush=True)
     for i, (a, r) in enumerate(zip(gin, gr[len(names):])):
         if r is not None and a is not None:
-            a = a.detach().double().cpu()
+            a, r = a.detach().double().cpu(), r.detach().double()
             if a.dim() == 4 and a.shape != r.shape:
                 a = nchw(a)
             l2 = ((a - r).norm() / r.norm()).item()
@@ -463,7 +465,7 @@ def _net_grad_check(tag, trainer, fp, sd64, outs_gpu, outs_ref, extra_gpu=(), ex
 
 def t_nets():
     """E2 (mask + correspondence warp heads), E1 and G (+ feature heads) of the training path against torch autograd of
-    the CPU oracle in float64, conv precision = exact fp32 (rounding of the production convs is bounded in compare_gstep)."""
+    the CPU oracle (float32), conv precision = exact fp32 (rounding of the production convs is bounded in compare_gstep)."""
     from ppst_amd.ppst_model import Options, create_model
     from ppst_amd.train_g import GeneratorTrainer
     ops.set_precision(2)
@@ -471,19 +473,20 @@ def t_nets():
         sd = W.make_state_dict(17, bias_std=0.1, noise_weight=0.1)
         m = create_model(Options(training_stage=2, lambda_Cycwarp=0.0), state_dict=sd, with_D=True, with_nce=True)
         tr = GeneratorTrainer(m)
-        sd64 = {k: v.double().requires_grad_(v.is_floating_point() and not k.endswith("kernel")) for k, v in sd.items()}
+        # the oracle side runs in float32 (float64 autograd of the three networks took 80 s of the GPU suite; bars are 5e-3)
+        sd64 = {k: v.float().requires_grad_(v.is_floating_point() and not k.endswith("kernel")) for k, v in sd.items()}
         real, mask, noise = gstep_inputs()
         # ---- E2 with mask and a live correspondence matrix
         torch.manual_seed(5)
         corr = torch.softmax(torch.randn(2, 4096, 4096) * 3, -1)
         cg = corr.to(dev).requires_grad_(True)
-        cr = corr.double().requires_grad_(True)
+        cr = corr.clone().requires_grad_(True)
         v, pm, vw, pmw = tr.encoder_col(real.to(dev), mask=mask.to(dev), corrmatrix=cg)
-        rv, rpm, rvw, rpmw = O.encoder_col(sd64, real.double(), mask=mask.double(), corrmatrix=cr)
+        rv, rpm, rvw, rpmw = O.encoder_col(sd64, real, mask=mask, corrmatrix=cr)
         _net_grad_check("E2 (mask, corr)", tr, tr.fp["E2"], sd64, v + pm + vw + pmw, rv + rpm + rvw + rpmw, (cg,), (cr,), prefix="E2.")
         # ---- E1
         xg = real.to(dev).requires_grad_(True)
-        xr = real.double().requires_grad_(True)
+        xr = real.clone().requires_grad_(True)
         sp = tr.encoder_con(xg)
         spr = O.encoder_con(sd64, xr)
         _net_grad_check("E1", tr, tr.fp["E1"], sd64, [nchw(sp)], [spr], (xg,), (xr,), prefix="E1.")
@@ -494,11 +497,13 @@ def t_nets():
         nz1 = {k: v[:1] for k, v in noise.items()}
         sg = nhwc(sp1).to(dev).requires_grad_(True)
         cgl = [c.to(dev).requires_grad_(True) for c in codes]
-        sr = sp1.double().requires_grad_(True)
-        crl = [c.double().requires_grad_(True) for c in codes]
+        # (the oracle side of G runs in float32: its float64 autograd alone took 50 s of the GPU suite; the bars are 5e-3)
+        sd32 = sd64
+        sr = sp1.clone().requires_grad_(True)
+        crl = [c.clone().requires_grad_(True) for c in codes]
         rgb, feat, feat1 = tr.generator(sg, cgl, {k: v.to(dev) for k, v in nz1.items()}, extract_features=True)
-        rrgb, rfeat, rfeat1 = O.generator(sd64, sr, crl, extract_features=True, noise={k: v.double() for k, v in nz1.items()})
-        _net_grad_check("G (+ feature heads)", tr, tr.fp["G"], sd64, [rgb, nchw(feat), nchw(feat1)], [rrgb, rfeat, rfeat1],
+        rrgb, rfeat, rfeat1 = O.generator(sd32, sr, crl, extract_features=True, noise=nz1)
+        _net_grad_check("G (+ feature heads)", tr, tr.fp["G"], sd32, [rgb, nchw(feat), nchw(feat1)], [rrgb, rfeat, rfeat1],
                         [sg] + cgl, [sr] + crl, prefix="G.")
     finally:
         ops.set_precision(0)
