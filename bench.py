@@ -231,7 +231,7 @@ def main():
     ap.add_argument("--workload", default="swap", choices=["swap", "grid", "train"],
                     help="swap: BASELINE configs[1] (the headline line); grid: configs[2], 8x8 folder at 512 with the guided filter, "
                          "images and pairs sharded over the ranks; train: configs[3], one D (+ lazy R1) and one G iteration per step")
-    ap.add_argument("--conv-variant", type=int, default=None, help="0: 8-wave conv kernel (default); 1: fat-wave kernel where eligible")
+    ap.add_argument("--conv-variant", type=int, default=None, help="2 (default): N-256 / 128x64-wave-tile kernel where eligible; 0: the 64x64-wave-tile kernel everywhere; 1: one-wave-per-SIMD experiment")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -711,8 +711,8 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       a->out_ld < a->cout || a->cout <= 0 || a->cout % 4 || a->out_ld % 4 || (a->residual && a->res_ld % 4) || a->nsteps <= 0 || (a->n_groups != 1 && a->n_groups != 4) || a->pad_mode < 0 ||
       a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 ||
       (a->precision != 0 && a->precision != 1 && a->precision != 3 && a->precision != 4) || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128 && a->bn != 256) || (a->residual && a->res_ld < a->cout) ||
-      a->variant < 0 || a->variant > 1 || (a->variant == 0 && a->bn == 256) ||
-      (a->variant == 1 && (a->precision != 0 || a->bn == 64 || !a->early_a)) ||
+      a->variant < 0 || a->variant > 2 || (a->variant == 0 && a->bn == 256) ||
+      (a->variant >= 1 && (a->precision != 0 || a->bn == 64 || !a->early_a)) || (a->variant == 2 && a->bn != 256) ||
       (a->tile_rows != 16) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
     return PPST_EINVAL;
   // the scattered output must reach into the output tensor (elements beyond it are dropped)
@@ -755,7 +755,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
     for (int i = 0; i < 8; ++i) g_info[slot][i] = inf[i];
     (void)hipEventRecord(g_ev[slot][0], st);
   }
-  if (a->variant == 1) {
+  if (a->variant >= 1) {
     int e2 = ppst_conv2d_mfma2_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st);
     if (slot >= 0) (void)hipEventRecord(g_ev[slot][1], st);
     return e2;

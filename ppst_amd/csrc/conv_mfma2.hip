@@ -48,20 +48,24 @@ __device__ __forceinline__ int pad_index2(int i, int n, int mode) {
   return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
 
-template <int NT, int HALO, bool INSS>
-__global__ __launch_bounds__(256, 1) void conv_mfma2_kernel(Conv2KArgs a) {
-  constexpr int NTH = 256;
+// WNW: waves along N (2: one wave per SIMD, 256 threads; 4: two waves per SIMD, 512 threads, wave tile 128 px x 64 ch,
+// block tile 16x16 px x 256 ch -- the "8-phase template" geometry of the CDNA GEMM guide).  BDB: weight fragments of the
+// next step double-buffered in registers (WNW = 2) or reloaded at the end of the step (WNW = 4: 256 registers per wave).
+template <int NT, int HALO, bool INSS, int WNW = 2, bool BDB = true>
+__global__ __launch_bounds__(128 * WNW, WNW == 4 ? 2 : 1) void conv_mfma2_kernel(Conv2KArgs a) {
+  constexpr int NWV = 2 * WNW;                            // waves per block (2 along M)
+  constexpr int NTH = 64 * NWV;
   constexpr int MT = 8;                                   // m-tiles (16-pixel rows) per wave
   constexpr int TH = 16, TW = 16;
   constexpr int HH = TH + 2 * HALO, HW = TW + 2 * HALO, HP = HH * HW;
   constexpr int PLANE = ((HP * 16 + 255) / 256) * 256;    // bytes
   constexpr int ABUF = 8 * PLANE;                         // hi g0..3, lo g0..3
-  constexpr int BN = 2 * 16 * NT;                         // 2 N-waves
+  constexpr int BN = WNW * 16 * NT;                       // WNW N-waves
   constexpr int BPLANE = BN * 16;
   constexpr int BBUF = 8 * BPLANE;
   constexpr int NA = 2;
   constexpr int EPI_TILE = 64 * 36;
-  constexpr int EPI_BYTES = 4 * EPI_TILE * 4 + 2 * BN * 2 * 4;
+  constexpr int EPI_BYTES = NWV * EPI_TILE * 4 + 2 * BN * 2 * 4;
   constexpr int MAIN_BYTES = NA * ABUF + 2 * BBUF;
   __shared__ __attribute__((aligned(256))) unsigned char smem[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
   unsigned char* smA = smem;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma2_kernel(Conv2KArgs a) {
   const int ty0 = tyi * TH, tx0 = txi * TW;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave & 1, wm = wave >> 1;
+  const int wn = wave % WNW, wm = wave / WNW;
   const int r16 = lane & 15, g = lane >> 4;
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -161,13 +165,14 @@ __global__ __launch_bounds__(256, 1) void conv_mfma2_kernel(Conv2KArgs a) {
   };
   // ---- B staging: LDS-DMA of the pre-packed step blob (global_load_lds_dwordx4, 1 KB per wave-instruction)
   constexpr int B_WI = BBUF / 1024;
-  constexpr int B_PER_WAVE = B_WI / 4;
+  constexpr int B_PER_WAVE = B_WI / NWV;
+  static_assert(B_WI % NWV == 0, "weight blob must split evenly over the waves");
   auto b_dma = [&](int s, int slot) {
     const unsigned char* src = wblob + (int64_t)s * BBUF + lane * 16;
     unsigned char* dst = smB + slot * BBUF;
 #pragma unroll
     for (int it = 0; it < B_PER_WAVE; ++it) {
-      const int wi = it * 4 + wave;
+      const int wi = it * NWV + wave;
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + wi * 1024),
                                        (void __attribute__((address_space(3)))*)(dst + wi * 1024), 16, 0, 0);
     }
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma2_kernel(Conv2KArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  bf16x8 b0h[NT], b0l[NT], b1h[NT], b1l[NT];
+  bf16x8 b0h[NT], b0l[NT], b1h[BDB ? NT : 1], b1l[BDB ? NT : 1];
   bf16x8 ah, al;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -232,11 +237,11 @@ __global__ __launch_bounds__(256, 1) void conv_mfma2_kernel(Conv2KArgs a) {
         nh = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0));                                                 \
         nl = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0) + 4 * PLANE);                                     \
       }                                                                                                       \
-      if (has1 && mt >= 1 && mt - 1 < NT) {   /* next step's B fragment pair nt = mt - 1 */                   \
+      if (BDB && has1 && mt >= 1 && mt - 1 < NT) {   /* next step's B fragment pair nt = mt - 1 */            \
         bnh[mt - 1] = *(const bf16x8*)B_ADDR(((s) + 1) & 1, mt - 1);                                          \
         bnl[mt - 1] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, mt - 1) + 4 * BPLANE);                           \
       }                                                                                                       \
-      if (NT == 8 && has1 && mt == MT - 1) {                                                                  \
+      if (BDB && NT == 8 && has1 && mt == MT - 1) {                                                           \
         bnh[NT - 1] = *(const bf16x8*)B_ADDR(((s) + 1) & 1, NT - 1);                                          \
         bnl[NT - 1] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, NT - 1) + 4 * BPLANE);                           \
       }                                                                                                       \
@@ -263,6 +268,12 @@ __global__ __launch_bounds__(256, 1) void conv_mfma2_kernel(Conv2KArgs a) {
       al = nl;                                                                                                \
       if (mt == MT - 2 && newA2) a_store(sl2);                                                                \
     }                                                                                                         \
+    if (!BDB && has1) {   /* single register set: the next step's weight fragments replace this step's, now dead */ \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                     \
+        bnh[nt] = *(const bf16x8*)B_ADDR(((s) + 1) & 1, nt);                                                  \
+        bnl[nt] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, nt) + 4 * BPLANE);                                   \
+      }                                                                                                       \
+    }                                                                                                         \
     if (a_early) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_NLOADS) : "memory");                              \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                           \
@@ -271,13 +282,24 @@ __global__ __launch_bounds__(256, 1) void conv_mfma2_kernel(Conv2KArgs a) {
     sl1 = sl2;                                                                                                \
   }
   int s = 0;
-  for (; s + 3 < a.nsteps; s += 2) {
-    STEP2(b0h, b0l, b1h, b1l, s, dE, dO, true, true)
-    STEP2(b1h, b1l, b0h, b0l, s + 1, dO, dE, true, true)
-  }
-  for (; s < a.nsteps; s += 2) {
-    STEP2(b0h, b0l, b1h, b1l, s, dE, dO, s + 1 < a.nsteps, s + 2 < a.nsteps)
-    if (s + 1 < a.nsteps) STEP2(b1h, b1l, b0h, b0l, s + 1, dO, dE, s + 2 < a.nsteps, s + 3 < a.nsteps)
+  if (BDB) {
+    for (; s + 3 < a.nsteps; s += 2) {
+      STEP2(b0h, b0l, b1h, b1l, s, dE, dO, true, true)
+      STEP2(b1h, b1l, b0h, b0l, s + 1, dO, dE, true, true)
+    }
+    for (; s < a.nsteps; s += 2) {
+      STEP2(b0h, b0l, b1h, b1l, s, dE, dO, s + 1 < a.nsteps, s + 2 < a.nsteps)
+      if (s + 1 < a.nsteps) STEP2(b1h, b1l, b0h, b0l, s + 1, dO, dE, s + 2 < a.nsteps, s + 3 < a.nsteps)
+    }
+  } else {
+    for (; s + 3 < a.nsteps; s += 2) {
+      STEP2(b0h, b0l, b0h, b0l, s, dE, dO, true, true)
+      STEP2(b0h, b0l, b0h, b0l, s + 1, dO, dE, true, true)
+    }
+    for (; s < a.nsteps; s += 2) {
+      STEP2(b0h, b0l, b0h, b0l, s, dE, dO, s + 1 < a.nsteps, s + 2 < a.nsteps)
+      if (s + 1 < a.nsteps) STEP2(b0h, b0l, b0h, b0l, s + 1, dO, dE, s + 2 < a.nsteps, s + 3 < a.nsteps)
+    }
   }
 #undef STEP2
 #undef A_OFF
@@ -289,7 +311,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma2_kernel(Conv2KArgs a) {
   const bool res_after = (a.act >> 8) & 1;
   const float slope = (act == PPST_ACT_PRELU && a.prelu) ? a.prelu[0] : 0.f;
   float* tw = (float*)smem + wave * EPI_TILE;
-  float* red = (float*)smem + 4 * EPI_TILE;            // [2 (wm)][BN][2]
+  float* red = (float*)smem + NWV * EPI_TILE;          // [2 (wm)][BN][2]
   const int f8 = lane & 7, prow = lane >> 3;
   float4 s1a[NT / 2], s2a[NT / 2];
 #pragma unroll
@@ -387,13 +409,15 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
   k.in_c = a->in_c; k.in_act = a->in_act;
   k.early_a = a->early_a ? 1 : 0;
   const int blocks = a->n_groups * n_tiles * a->B * tiles_y * tiles_x;
-#define L2(NT_, HALO_)                                                                                          \
+#define L2(NT_, HALO_, WNW_, BDB_)                                                                              \
   do {                                                                                                          \
-    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<NT_, HALO_, true>), dim3(blocks), dim3(256), 0, st, k);         \
-    else PPST_LAUNCH((conv_mfma2_kernel<NT_, HALO_, false>), dim3(blocks), dim3(256), 0, st, k);                \
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<NT_, HALO_, true, WNW_, BDB_>), dim3(blocks), dim3(128 * WNW_), 0, st, k);  \
+    else PPST_LAUNCH((conv_mfma2_kernel<NT_, HALO_, false, WNW_, BDB_>), dim3(blocks), dim3(128 * WNW_), 0, st, k);         \
   } while (0)
-  if (a->bn == 256) { if (a->halo) L2(8, 1); else L2(8, 0); }
-  else { if (a->halo) L2(4, 1); else L2(4, 0); }
+  if (a->variant == 2) {                 // 8 waves, wave tile 128 px x 64 ch, N tile 256
+    if (a->halo) L2(4, 1, 4, false); else L2(4, 0, 4, false);
+  } else if (a->bn == 256) { if (a->halo) L2(8, 1, 2, true); else L2(8, 0, 2, true); }
+  else { if (a->halo) L2(4, 1, 2, true); else L2(4, 0, 2, true); }
 #undef L2
   return PPST_LAUNCH_CHECK();
 }

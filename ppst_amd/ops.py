@@ -24,8 +24,11 @@ TILE_ROWS = {"value": 16}  # conv tile rows: 8 (2 blocks per CU) or 16 (1 block 
 # class of runs, tests/conv_table.py): the fat-wave kernel is bit-identical but SLOWER -- 256->256@256^2 395 vs 417 TF/s
 # with the 256-channel tile, 128->128@512^2 261 vs 356 with the 128-channel tile; whole step 284-294 vs 330 TF/s: one
 # in-order wave per SIMD exposes its own LDS / wait latency, which two co-resident waves hide for each other.
-CONV_VARIANT = {"value": 0}
-FAT_MIN_BLOCKS = 384        # prefer the 256-channel tile only when the launch still has >= this many blocks
+# 2 (default since round 2): layers with Cout % 256 == 0 whose grid still covers the chip run on the 8-wave kernel with
+# 128 px x 64 ch wave tiles and a 256-channel N tile (conv_mfma2.hip, WNW = 4): bit-identical to the 64x64-wave-tile kernel
+# and 10-16 % faster on those layers (256->256 @256^2 459 vs 417 TFLOP/s, 512->512 @128^2 494 vs 440).
+CONV_VARIANT = {"value": 2}
+FAT_MIN_BLOCKS = 256        # take the 256-channel tile only when the launch still has >= one block per CU
 
 
 def set_precision(p):
@@ -381,10 +384,13 @@ class ConvPlan:
         # kernel variant / N tile: the fat-wave kernel needs chunks of >= 2 steps (3x3, transposed, stride-2 tables) and
         # pays off from 128 output channels; its 256-channel tile only when the grid still covers the chip
         variant, bn = 0, self.bn
+        tiles16 = ((th + 15) // 16) * ((tw + 15) // 16) * B * self.n_groups
         if CONV_VARIANT["value"] == 1 and self.precision == 0 and self.early_a and self.cout >= 128:
             variant = 1
-            tiles16 = ((th + 15) // 16) * ((tw + 15) // 16) * B * self.n_groups
             bn = 256 if (self.cout % 256 == 0 and tiles16 * (self.cout // 256) >= FAT_MIN_BLOCKS) else 128
+        elif (CONV_VARIANT["value"] == 2 and self.precision == 0 and self.early_a and self.cout % 256 == 0
+              and tiles16 * (self.cout // 256) >= FAT_MIN_BLOCKS):
+            variant, bn = 2, 256        # 8 waves x (128 px x 64 ch), N tile 256 (conv_mfma2.hip, WNW = 4)
         a = _lib.ConvArgs()
         a.x, a.wpack, a.steps, a.y = _p(x), _p(self.pack_for(bn) if self.precision != 2 else None), _p(self.steps), _p(out)
         a.variant = variant

@@ -324,7 +324,7 @@ def t_conv_variants():
     for name, B, ci, co, H, Wd, kind, pm, feat in cases:
         w = g(nz_(co, ci, 3, 3) / math.sqrt(ci * 9))
         outs = {}
-        for variant, minb in ((0, 384), (1, 1 << 30), (1, 0)):      # 8-wave; fat N=128; fat N=256 where Cout % 256 == 0
+        for variant, minb in ((0, 384), (1, 1 << 30), (1, 0), (2, 0)):   # 8-wave; fat N=128; fat N=256; 8-wave 128x64 tiles N=256
             ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = variant, minb
             plan = ops.ConvPlan(w, kind=kind)
             cin_eff = plan.max_chan + 32
@@ -341,9 +341,9 @@ def t_conv_variants():
                 kw = dict(residual=g(nz_(B, oh, ow, plan.cout)), res_after_act=True, act=ops.ACT_LRELU, out_scale=0.7)
             y, st = plan(x, pad_mode=pm, stats=True, **kw)
             outs[(variant, minb)] = (y.cpu(), st.sum(1).cpu())
-        ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = 0, 384
+        ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = 2, 256
         y0, s0 = outs[(0, 384)]
-        for key, tag in (((1, 1 << 30), "N=128"), ((1, 0), "N=256|128")):
+        for key, tag in (((1, 1 << 30), "N=128"), ((1, 0), "N=256|128"), ((2, 0), "8w N=256")):
             y1, s1 = outs[key]
             RES.append(("fat conv %s %s bit-identical" % (tag, name), bool(torch.equal(y0, y1))))
             print("fat conv %-9s %-52s %s max diff %.3e" % (tag, name, "ok  " if torch.equal(y0, y1) else "FAIL", (y0 - y1).abs().max().item()), flush=True)
