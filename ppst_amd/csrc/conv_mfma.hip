@@ -556,6 +556,8 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     unsigned long long* o = a.dbg + (int64_t)TR_BLOCKS * (NT / 64) * TR_STEPS * 8 + (int64_t)blockIdx.x * 2;
     o[0] = c1 - tr_c0;
     o[1] = r1 - tr_r0;
+    // absolute start stamp of the traced blocks (prologue = first step's stamp - this), behind the per-block pairs
+    if (blockIdx.x < TR_BLOCKS) a.dbg[(int64_t)TR_BLOCKS * (NT / 64) * TR_STEPS * 8 + (int64_t)gridDim.x * 2 + blockIdx.x] = tr_c0;
   }
 #endif
 #ifdef PPST_CONV_CLOCK
@@ -711,8 +713,8 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       a->out_ld < a->cout || a->cout <= 0 || a->cout % 4 || a->out_ld % 4 || (a->residual && a->res_ld % 4) || a->nsteps <= 0 || (a->n_groups != 1 && a->n_groups != 4) || a->pad_mode < 0 ||
       a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 ||
       (a->precision != 0 && a->precision != 1 && a->precision != 3 && a->precision != 4) || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128 && a->bn != 256) || (a->residual && a->res_ld < a->cout) ||
-      a->variant < 0 || a->variant > 2 || (a->variant == 0 && a->bn == 256) ||
-      (a->variant >= 1 && (a->precision != 0 || a->bn == 64 || !a->early_a)) || (a->variant == 2 && a->bn != 256) ||
+      a->variant < 0 || a->variant > 3 || (a->variant == 0 && a->bn == 256) ||
+      (a->variant >= 1 && (a->precision != 0 || a->bn == 64 || !a->early_a)) || (a->variant == 2 && a->bn != 256) || (a->variant == 3 && a->bn != 128) ||
       (a->tile_rows != 16) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
     return PPST_EINVAL;
   // the scattered output must reach into the output tensor (elements beyond it are dropped)

@@ -51,8 +51,11 @@ __device__ __forceinline__ int pad_index2(int i, int n, int mode) {
 // WNW: waves along N (2: one wave per SIMD, 256 threads; 4: two waves per SIMD, 512 threads, wave tile 128 px x 64 ch,
 // block tile 16x16 px x 256 ch -- the "8-phase template" geometry of the CDNA GEMM guide).  BDB: weight fragments of the
 // next step double-buffered in registers (WNW = 2) or reloaded at the end of the step (WNW = 4: 256 registers per wave).
-template <int NT, int HALO, bool INSS, int WNW = 2, bool BDB = true>
-__global__ __launch_bounds__(128 * WNW, WNW == 4 ? 2 : 1) void conv_mfma2_kernel(Conv2KArgs a) {
+// NA_: activation ring slots.  1 (with WNW = 2, NT = 4, BDB = false): 75 KB of LDS and <= 256 registers, so TWO 4-wave blocks
+// share a CU -- the 128 px x 64 ch wave tile for layers whose Cout is only 128.  With one slot a new chunk is stored at the
+// END of the step before it is used, between two barriers; the CU's other block fills that bubble.
+template <int NT, int HALO, bool INSS, int WNW = 2, bool BDB = true, int NA_ = 2>
+__global__ __launch_bounds__(128 * WNW, (WNW == 4 || NA_ == 1) ? 2 : 1) void conv_mfma2_kernel(Conv2KArgs a) {
   constexpr int NWV = 2 * WNW;                            // waves per block (2 along M)
   constexpr int NTH = 64 * NWV;
   constexpr int MT = 8;                                   // m-tiles (16-pixel rows) per wave
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(128 * WNW, WNW == 4 ? 2 : 1) void conv_mfma2_kernel
   constexpr int BN = WNW * 16 * NT;                       // WNW N-waves
   constexpr int BPLANE = BN * 16;
   constexpr int BBUF = 8 * BPLANE;
-  constexpr int NA = 2;
+  constexpr int NA = NA_;
   constexpr int EPI_TILE = 64 * 36;
   constexpr int EPI_BYTES = NWV * EPI_TILE * 4 + 2 * BN * 2 * 4;
   constexpr int MAIN_BYTES = NA * ABUF + 2 * BBUF;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(128 * WNW, WNW == 4 ? 2 : 1) void conv_mfma2_kernel
     b_dma(1, 1);
     if (d.w & 1) a_load(d.x);
     if (d.w & 1) a_store(sl1);
-    if (a.early_a && (d.w & 2)) a_load(d.w >> 8);
+    if (NA > 1 && a.early_a && (d.w & 2)) a_load(d.w >> 8);
   }
   int4 dE = d, dO = d;
   if (a.nsteps > 2) dE = steps[2];
@@ -228,12 +231,17 @@ __global__ __launch_bounds__(128 * WNW, WNW == 4 ? 2 : 1) void conv_mfma2_kernel
     const bool has1 = (H1), has2 = (H2);                                                                      \
     bool newA2 = false, a_early = false;                                                                      \
     int sl2 = sl1;                                                                                            \
+    if (NA == 1 && freshA) {   /* this step's chunk was stored at the end of the previous step */             \
+      ah = *(const bf16x8*)(smA + A_OFF(0, dy0, dx0, 0));                                                     \
+      al = *(const bf16x8*)(smA + A_OFF(0, dy0, dx0, 0) + 4 * PLANE);                                         \
+    }                                                                                                         \
+    const bool storeA = NA == 1 && pendA;   /* the next step opens a chunk: store it at the end of this one */ \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                       \
       bf16x8 nh, nl;                                                                                          \
       if (mt < MT - 1) {                                                                                      \
         nh = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1));                                            \
         nl = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1) + 4 * PLANE);                                \
-      } else if (has1) {                                                                                      \
+      } else if (has1 && !storeA) {                                                                           \
         nh = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0));                                                 \
         nl = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0) + 4 * PLANE);                                     \
       }                                                                                                       \
@@ -254,19 +262,25 @@ __global__ __launch_bounds__(128 * WNW, WNW == 4 ? 2 : 1) void conv_mfma2_kernel
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         D3 = steps[(s) + 3];                                                                                  \
         newA2 = has2 && (D2.w & 1);                                                                           \
-        if (newA2) sl2 = sl1 ^ 1;                                                                             \
+        if (NA > 1 && newA2) sl2 = sl1 ^ 1;                                                                   \
         if (has2) b_dma((s) + 2, (s) & 1);                                                                    \
         __builtin_amdgcn_sched_barrier(0);   /* DMA issued before the activation loads: counted vmcnt below */ \
         {                                                                                                     \
-          const bool ld_ = a.early_a ? (has2 && (D2.w & 2)) : newA2;                                          \
-          const int ch_ = a.early_a ? (D2.w >> 8) : D2.x;                                                     \
-          if (ld_) { a_load(ch_); a_early = a.early_a != 0; }                                                 \
+          const bool early_ = NA > 1 && a.early_a;                                                            \
+          const bool ld_ = early_ ? (has2 && (D2.w & 2)) : newA2;                                             \
+          const int ch_ = early_ ? (D2.w >> 8) : D2.x;                                                        \
+          if (ld_) { a_load(ch_); a_early = NA == 1 || early_; }                                              \
         }                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
       }                                                                                                       \
       ah = nh;                                                                                                \
       al = nl;                                                                                                \
-      if (mt == MT - 2 && newA2) a_store(sl2);                                                                \
+      if (NA > 1 && mt == MT - 2 && newA2) a_store(sl2);                                                      \
+    }                                                                                                         \
+    if (storeA) {   /* every wave has read the old chunk -> overwrite the only slot */                        \
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                         \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+      a_store(0);                                                                                             \
     }                                                                                                         \
     if (!BDB && has1) {   /* single register set: the next step's weight fragments replace this step's, now dead */ \
       _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                     \
@@ -277,11 +291,13 @@ __global__ __launch_bounds__(128 * WNW, WNW == 4 ? 2 : 1) void conv_mfma2_kernel
     if (a_early) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_NLOADS) : "memory");                              \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                           \
+    freshA = storeA; pendA = newA2;                                                                           \
     dy0 = dy1; dx0 = dx1; sl0 = sl1;                                                                          \
     if (has2) { dy1 = D2.y; dx1 = D2.z; }                                                                     \
     sl1 = sl2;                                                                                                \
   }
   int s = 0;
+  bool freshA = false, pendA = false;
   if (BDB) {
     for (; s + 3 < a.nsteps; s += 2) {
       STEP2(b0h, b0l, b1h, b1l, s, dE, dO, true, true)
@@ -409,15 +425,17 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
   k.in_c = a->in_c; k.in_act = a->in_act;
   k.early_a = a->early_a ? 1 : 0;
   const int blocks = a->n_groups * n_tiles * a->B * tiles_y * tiles_x;
-#define L2(NT_, HALO_, WNW_, BDB_)                                                                              \
+#define L2(NT_, HALO_, WNW_, BDB_, NA_)                                                                         \
   do {                                                                                                          \
-    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<NT_, HALO_, true, WNW_, BDB_>), dim3(blocks), dim3(128 * WNW_), 0, st, k);  \
-    else PPST_LAUNCH((conv_mfma2_kernel<NT_, HALO_, false, WNW_, BDB_>), dim3(blocks), dim3(128 * WNW_), 0, st, k);         \
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<NT_, HALO_, true, WNW_, BDB_, NA_>), dim3(blocks), dim3(128 * WNW_), 0, st, k);  \
+    else PPST_LAUNCH((conv_mfma2_kernel<NT_, HALO_, false, WNW_, BDB_, NA_>), dim3(blocks), dim3(128 * WNW_), 0, st, k);         \
   } while (0)
   if (a->variant == 2) {                 // 8 waves, wave tile 128 px x 64 ch, N tile 256
-    if (a->halo) L2(4, 1, 4, false); else L2(4, 0, 4, false);
-  } else if (a->bn == 256) { if (a->halo) L2(8, 1, 2, true); else L2(8, 0, 2, true); }
-  else { if (a->halo) L2(4, 1, 2, true); else L2(4, 0, 2, true); }
+    if (a->halo) L2(4, 1, 4, false, 2); else L2(4, 0, 4, false, 2);
+  } else if (a->variant == 3) {          // two 4-wave blocks per CU, wave tile 128 px x 64 ch, N tile 128, one activation slot
+    if (a->halo) L2(4, 1, 2, false, 1); else L2(4, 0, 2, false, 1);
+  } else if (a->bn == 256) { if (a->halo) L2(8, 1, 2, true, 2); else L2(8, 0, 2, true, 2); }
+  else { if (a->halo) L2(4, 1, 2, true, 2); else L2(4, 0, 2, true, 2); }
 #undef L2
   return PPST_LAUNCH_CHECK();
 }

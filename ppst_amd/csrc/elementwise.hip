@@ -299,21 +299,34 @@ extern "C" int ppst_in_stats(const void* x, void* partial, int B, int H, int W, 
   return PPST_LAUNCH_CHECK();
 }
 
-// One block per (image b, 32-channel group): 8 partial rows are in flight per step (each a
-// 256-B coalesced read of 32 (sum, sumsq) pairs), double accumulation, LDS tree at the end.
+// One block per (image b, 8-channel group): 32 partial rows x 4 (unrolled) are in flight per step (64-B segments of
+// 8 (sum, sumsq) pairs), double accumulation in a fixed order, LDS tree at the end.  (Round 1 used 32 channels x 8 rows:
+// B*C/32 blocks -- 32 for a 128-channel map -- each walking up to 256 dependent-latency steps took 16 us per call, 118
+// calls per swap step.)
+#define FIN_CH 8
+#define FIN_ROWS 32
 __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ partial, int n_partials,
                                                           const float* __restrict__ style, int style_ld,
                                                           const float* __restrict__ post_bias, float* __restrict__ ss, int B,
                                                           int C, double count, float eps, float* __restrict__ mr) {
-  __shared__ double sm[8][32][2];
-  const int cgroups = (C + 31) / 32;
-  const int b = blockIdx.x / cgroups, c0 = (blockIdx.x % cgroups) * 32;
-  const int cl = threadIdx.x & 31, kk = threadIdx.x >> 5;
+  __shared__ double sm[FIN_ROWS][FIN_CH][2];
+  const int cgroups = (C + FIN_CH - 1) / FIN_CH;
+  const int b = blockIdx.x / cgroups, c0 = (blockIdx.x % cgroups) * FIN_CH;
+  const int cl = threadIdx.x & (FIN_CH - 1), kk = threadIdx.x / FIN_CH;
   const int c = c0 + cl;
   double s = 0.0, q = 0.0;
   if (c < C) {
     const float2* p = (const float2*)partial + ((int64_t)b * n_partials * C + c);
-    for (int k = kk; k < n_partials; k += 8) {
+    int k = kk;
+    for (; k + 3 * FIN_ROWS < n_partials; k += 4 * FIN_ROWS) {
+      float2 v0 = p[(int64_t)k * C], v1 = p[(int64_t)(k + FIN_ROWS) * C], v2 = p[(int64_t)(k + 2 * FIN_ROWS) * C],
+             v3 = p[(int64_t)(k + 3 * FIN_ROWS) * C];
+      s += (double)v0.x; q += (double)v0.y;
+      s += (double)v1.x; q += (double)v1.y;
+      s += (double)v2.x; q += (double)v2.y;
+      s += (double)v3.x; q += (double)v3.y;
+    }
+    for (; k < n_partials; k += FIN_ROWS) {
       float2 v = p[(int64_t)k * C];
       s += (double)v.x;
       q += (double)v.y;
@@ -323,7 +336,7 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restric
   sm[kk][cl][1] = q;
   __syncthreads();
   if (kk == 0 && c < C) {
-    for (int r = 1; r < 8; ++r) { s += sm[r][cl][0]; q += sm[r][cl][1]; }
+    for (int r = 1; r < FIN_ROWS; ++r) { s += sm[r][cl][0]; q += sm[r][cl][1]; }
     double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -349,7 +362,7 @@ extern "C" int ppst_in_finalize(const void* partial, int n_partials, const void*
   if (B < 0 || C <= 0 || n_partials <= 0 || count <= 0 || (style && style_ld < 2 * C)) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!partial || !scale_shift) return PPST_ENULL;
-  PPST_LAUNCH(in_finalize_kernel, dim3(B * cdiv(C, 32)), dim3(256), 0, as_stream(stream),
+  PPST_LAUNCH(in_finalize_kernel, dim3(B * cdiv(C, FIN_CH)), dim3(256), 0, as_stream(stream),
                      (const float*)partial, n_partials, (const float*)style, style_ld, (const float*)post_bias,
                      (float*)scale_shift, B, C, count, eps, (float*)nullptr);
   return PPST_LAUNCH_CHECK();
@@ -360,7 +373,7 @@ extern "C" int ppst_in_finalize_train(const void* partial, int n_partials, const
   if (B < 0 || C <= 0 || n_partials <= 0 || count <= 0 || (style && style_ld < 2 * C)) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!partial || !scale_shift || !mean_rstd) return PPST_ENULL;
-  PPST_LAUNCH(in_finalize_kernel, dim3(B * cdiv(C, 32)), dim3(256), 0, as_stream(stream),
+  PPST_LAUNCH(in_finalize_kernel, dim3(B * cdiv(C, FIN_CH)), dim3(256), 0, as_stream(stream),
                      (const float*)partial, n_partials, (const float*)style, style_ld, (const float*)post_bias,
                      (float*)scale_shift, B, C, count, eps, (float*)mean_rstd);
   return PPST_LAUNCH_CHECK();
@@ -477,21 +490,28 @@ extern "C" int ppst_affine_act_stats(const void* x, const void* scale_shift, con
 }
 
 // ---------------------------------------------------------------- GAP/GMP --
-// One block per (image b, 32-channel group), 8 partial rows in flight (256-B coalesced reads of
-// 32 (sum, max) pairs), double accumulation of the sums in a fixed order, LDS tree at the end.
+// One block per (image b, 8-channel group), 32 partial rows x 4 in flight (as in_finalize_kernel), double accumulation
+// of the sums in a fixed order, LDS tree at the end.
 __global__ __launch_bounds__(256) void gap_gmp_finalize_kernel(const float* __restrict__ partial, int n_partials,
                                                                float* __restrict__ out, int B, int C, double count) {
-  __shared__ double ss[8][32];
-  __shared__ float sm[8][32];
-  const int cgroups = (C + 31) / 32;
-  const int b = blockIdx.x / cgroups, c0 = (blockIdx.x % cgroups) * 32;
-  const int cl = threadIdx.x & 31, kk = threadIdx.x >> 5;
+  __shared__ double ss[FIN_ROWS][FIN_CH];
+  __shared__ float sm[FIN_ROWS][FIN_CH];
+  const int cgroups = (C + FIN_CH - 1) / FIN_CH;
+  const int b = blockIdx.x / cgroups, c0 = (blockIdx.x % cgroups) * FIN_CH;
+  const int cl = threadIdx.x & (FIN_CH - 1), kk = threadIdx.x / FIN_CH;
   const int c = c0 + cl;
   double s = 0.0;
   float m = -INFINITY;
   if (c < C) {
     const float2* p = (const float2*)partial + ((int64_t)b * n_partials * C + c);
-    for (int k = kk; k < n_partials; k += 8) {
+    int k = kk;
+    for (; k + 3 * FIN_ROWS < n_partials; k += 4 * FIN_ROWS) {
+      float2 v0 = p[(int64_t)k * C], v1 = p[(int64_t)(k + FIN_ROWS) * C], v2 = p[(int64_t)(k + 2 * FIN_ROWS) * C],
+             v3 = p[(int64_t)(k + 3 * FIN_ROWS) * C];
+      s += (double)v0.x; s += (double)v1.x; s += (double)v2.x; s += (double)v3.x;
+      m = fmaxf(fmaxf(m, v0.y), fmaxf(v1.y, fmaxf(v2.y, v3.y)));
+    }
+    for (; k < n_partials; k += FIN_ROWS) {
       float2 v = p[(int64_t)k * C];
       s += (double)v.x;
       m = fmaxf(m, v.y);
@@ -501,7 +521,7 @@ __global__ __launch_bounds__(256) void gap_gmp_finalize_kernel(const float* __re
   sm[kk][cl] = m;
   __syncthreads();
   if (kk == 0 && c < C) {
-    for (int r = 1; r < 8; ++r) { s += ss[r][cl]; m = fmaxf(m, sm[r][cl]); }
+    for (int r = 1; r < FIN_ROWS; ++r) { s += ss[r][cl]; m = fmaxf(m, sm[r][cl]); }
     out[(int64_t)b * 2 * C + c] = (float)(s / count);
     out[(int64_t)b * 2 * C + C + c] = m;
   }
@@ -528,7 +548,7 @@ extern "C" int ppst_gap_gmp(const void* x, const void* mask, void* out, void* ws
   }
   int e = PPST_LAUNCH_CHECK();
   if (e) return e;
-  PPST_LAUNCH(gap_gmp_finalize_kernel, dim3(B * cdiv(C, 32)), dim3(256), 0, as_stream(stream),
+  PPST_LAUNCH(gap_gmp_finalize_kernel, dim3(B * cdiv(C, FIN_CH)), dim3(256), 0, as_stream(stream),
                      (const float*)ws, nchunks, (float*)out, B, C, (double)H * W);
   return PPST_LAUNCH_CHECK();
 }

@@ -28,7 +28,8 @@ TILE_ROWS = {"value": 16}  # conv tile rows: 8 (2 blocks per CU) or 16 (1 block 
 # 128 px x 64 ch wave tiles and a 256-channel N tile (conv_mfma2.hip, WNW = 4): bit-identical to the 64x64-wave-tile kernel
 # and 10-16 % faster on those layers (256->256 @256^2 459 vs 417 TFLOP/s, 512->512 @128^2 494 vs 440).
 CONV_VARIANT = {"value": 2}
-FAT_MIN_BLOCKS = 256        # take the 256-channel tile only when the launch still has >= one block per CU
+TWO_BLOCK_128 = {"value": False}   # experiment: variant 3 (see __call__) for the Cout = 128-class layers
+FAT_MIN_BLOCKS = 32         # take the 256-channel tile only when ONE image still gives >= this many blocks (B = 8: one per CU)
 
 
 def set_precision(p):
@@ -384,13 +385,20 @@ class ConvPlan:
         # kernel variant / N tile: the fat-wave kernel needs chunks of >= 2 steps (3x3, transposed, stride-2 tables) and
         # pays off from 128 output channels; its 256-channel tile only when the grid still covers the chip
         variant, bn = 0, self.bn
-        tiles16 = ((th + 15) // 16) * ((tw + 15) // 16) * B * self.n_groups
+        # blocks PER IMAGE: the choice must not depend on the batch size -- the variants give bit-identical outputs but
+        # their tile statistics differ in the last bit (other summation tree), and a shard of a batch has to reproduce the
+        # whole batch bit for bit (evaluation.grid_exchange, tests: "2 simulated ranks == 1 rank")
+        tiles16 = ((th + 15) // 16) * ((tw + 15) // 16) * self.n_groups
         if CONV_VARIANT["value"] == 1 and self.precision == 0 and self.early_a and self.cout >= 128:
             variant = 1
             bn = 256 if (self.cout % 256 == 0 and tiles16 * (self.cout // 256) >= FAT_MIN_BLOCKS) else 128
-        elif (CONV_VARIANT["value"] == 2 and self.precision == 0 and self.early_a and self.cout % 256 == 0
-              and tiles16 * (self.cout // 256) >= FAT_MIN_BLOCKS):
-            variant, bn = 2, 256        # 8 waves x (128 px x 64 ch), N tile 256 (conv_mfma2.hip, WNW = 4)
+        elif CONV_VARIANT["value"] in (2, 3) and self.precision == 0 and self.early_a:
+            force3 = CONV_VARIANT["value"] == 3          # (tests) every eligible plan on the two-block kernel
+            if not force3 and self.cout % 256 == 0 and tiles16 * (self.cout // 256) >= FAT_MIN_BLOCKS:
+                variant, bn = 2, 256    # 8 waves x (128 px x 64 ch), N tile 256 (conv_mfma2.hip, WNW = 4)
+            elif self.bn == 128 and (force3 or (TWO_BLOCK_128["value"] and
+                                                tiles16 * ((self.cout + 127) // 128) >= 2 * FAT_MIN_BLOCKS)):
+                variant = 3             # two 4-wave blocks per CU, 128 px x 64 ch wave tiles, N tile 128 (NA_ = 1)
         a = _lib.ConvArgs()
         a.x, a.wpack, a.steps, a.y = _p(x), _p(self.pack_for(bn) if self.precision != 2 else None), _p(self.steps), _p(out)
         a.variant = variant

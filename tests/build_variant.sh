@@ -6,6 +6,6 @@ name=$1; shift
 cd "$(dirname "$0")/.."
 obj=ppst_amd/csrc/_obj/conv_mfma_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result "$@" -c ppst_amd/csrc/conv_mfma.hip -o $obj
-others=$(ls ppst_amd/csrc/_obj/*.o | grep -v conv_mfma)
+others=$(ls ppst_amd/csrc/_obj/*.o | grep -v "conv_mfma_\|conv_mfma\.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ppst_amd/libppst_hip_$name.so $obj $others
 echo built ppst_amd/libppst_hip_$name.so

@@ -13,6 +13,8 @@ if len(sys.argv) > 3:
     ops.CONV_VARIANT["value"] = int(sys.argv[3])        # 0: 8-wave kernel everywhere; 1: fat-wave kernel where eligible
 if len(sys.argv) > 4:
     ops.FAT_MIN_BLOCKS = int(sys.argv[4])
+if len(sys.argv) > 5:
+    ops.TWO_BLOCK_128["value"] = bool(int(sys.argv[5]))
 dev = torch.device("cuda", 0)
 sd = W.make_state_dict(0, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
 m = create_model(state_dict=sd, device=dev)

@@ -13,12 +13,16 @@ if len(sys.argv) > 1:
 if len(sys.argv) > 7:
     ops.set_precision(int(sys.argv[7]))     # 1: single-pass bf16 (a probe of the non-MFMA floor of a step)
 for (B, ci, co, H, k, kind) in shapes:
-    x = torch.randn(B, H, H, ci, device="cuda")
+    # s2d: H is the OUTPUT size, x the space-to-depth copy of the (2H+1)^2 blurred map
+    x = torch.randn(B, H + 1, H + 1, 4 * ci, device="cuda") if kind == "s2d" else torch.randn(B, H, H, ci, device="cuda")
     w = torch.randn(co, ci, k, k, device="cuda") / math.sqrt(ci * k * k)
-    plan = ops.ConvPlan(w, kind=kind)
+    plan_ = ops.ConvPlan(w, kind=kind)
+    plan = (lambda x_, **kw: plan_(x_, out_hw=(H, H), **kw)) if kind == "s2d" else plan_
+    for at in ("bn", "n_groups", "nsteps"):
+        setattr(plan, at, getattr(plan_, at)) if kind == "s2d" else None
     nw = 8 if plan.bn == 128 else 4
     n_blocks = plan.n_groups * ((co + plan.bn - 1) // plan.bn) * B * ((H + 15) // 16) ** 2
-    dbg = torch.zeros(TR_BLOCKS * nw * TR_STEPS * 8 + 2 * n_blocks, dtype=torch.int64, device="cuda")
+    dbg = torch.zeros(TR_BLOCKS * nw * TR_STEPS * 8 + 2 * n_blocks + TR_BLOCKS, dtype=torch.int64, device="cuda")
     import time
     t0 = time.time()
     while time.time() - t0 < 2.0:        # steady-state clock: >= 2 s of back-to-back launches on random data
@@ -35,7 +39,7 @@ for (B, ci, co, H, k, kind) in shapes:
     torch.cuda.synchronize()
     kms = e0.elapsed_time(e1)
     ns = min(plan.nsteps, TR_STEPS)
-    clk = dbg[TR_BLOCKS * nw * TR_STEPS * 8:].view(n_blocks, 2).cpu().numpy().astype(np.float64)
+    clk = dbg[TR_BLOCKS * nw * TR_STEPS * 8:TR_BLOCKS * nw * TR_STEPS * 8 + 2 * n_blocks].view(n_blocks, 2).cpu().numpy().astype(np.float64)
     ghz = clk[:, 0] / np.maximum(clk[:, 1], 1) * 0.1          # cycles per 10-ns reference tick
     print("in-kernel clock (s_memtime / s_memrealtime over each block): median %.3f GHz  p10 %.3f  p90 %.3f;  block lifetime median %.1f us"
           % (np.median(ghz), np.percentile(ghz, 10), np.percentile(ghz, 90), np.median(clk[:, 1]) * 0.01))
@@ -44,6 +48,14 @@ for (B, ci, co, H, k, kind) in shapes:
     n_tiles = plan.n_groups * ((co + plan.bn - 1) // plan.bn) * B * ((H + 15) // 16) ** 2
     print("kernel %.3f ms for %d tiles (%.1f per CU); main loop of a traced tile: median %.0f ticks -> if tiles ran back to back "
           "a tick is <= %.3f ns" % (kms, n_tiles, n_tiles / 256.0, np.median(span), kms * 1e6 / (n_tiles / 256.0) / np.median(span)))
+    life = np.median(clk[:, 0])
+    print("block lifetime median %.0f cycles; main loop %.0f cycles; prologue + epilogue %.0f cycles" % (life, np.median(span), life - np.median(span)))
+    start = dbg[TR_BLOCKS * nw * TR_STEPS * 8 + 2 * n_blocks:].cpu().numpy().astype(np.int64)
+    pro = (d[:, 0, 0, 0] - start).astype(np.float64)
+    tl = clk[:TR_BLOCKS, 0]
+    print("traced blocks: prologue %s  main loop %s  epilogue %s cycles" % (pro.astype(int).tolist(), span.astype(int).tolist(), (tl - pro - span).astype(int).tolist()))
+    if plan.nsteps < 8:
+        continue
     names = ["head issued", "MFMA g0-1 issued", "MFMA g2-3 issued", "staging done", "vmcnt done", "barrier passed"]
     print("\n%s %d->%d @%d k%d  nsteps %d  (cycles from step start; median over blocks 1..7, all waves)" % (kind, ci, co, H, k, plan.nsteps))
     for label, sel in (("plain steps", d[..., 7] == 0), ("chunk-staging steps", d[..., 7] == 1)):

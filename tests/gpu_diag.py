@@ -305,6 +305,9 @@ def t_conv():
     report("conv1x1 small cout (ToRGB)", nchw(y.cpu()), O.equal_conv2d(x, w, b), 3e-6)
 
 
+CONV_DEFAULTS = (ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS)
+
+
 def t_conv_variants():
     """The fat-wave kernel (conv_mfma2.hip, N tile 128 and 256) against the 8-wave kernel on the same plans: same MFMA
     sequence per output element, so outputs must be bit-identical; tile statistics to rounding (other summation tree)."""
@@ -324,7 +327,8 @@ def t_conv_variants():
     for name, B, ci, co, H, Wd, kind, pm, feat in cases:
         w = g(nz_(co, ci, 3, 3) / math.sqrt(ci * 9))
         outs = {}
-        for variant, minb in ((0, 384), (1, 1 << 30), (1, 0), (2, 0)):   # 8-wave; fat N=128; fat N=256; 8-wave 128x64 tiles N=256
+        # 8-wave; fat N=128; fat N=256; 8-wave 128x64 tiles N=256; two 4-wave blocks per CU, 128x64 tiles, N=128
+        for variant, minb in ((0, 384), (1, 1 << 30), (1, 0), (2, 0), (3, 0)):
             ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = variant, minb
             plan = ops.ConvPlan(w, kind=kind)
             cin_eff = plan.max_chan + 32
@@ -341,9 +345,9 @@ def t_conv_variants():
                 kw = dict(residual=g(nz_(B, oh, ow, plan.cout)), res_after_act=True, act=ops.ACT_LRELU, out_scale=0.7)
             y, st = plan(x, pad_mode=pm, stats=True, **kw)
             outs[(variant, minb)] = (y.cpu(), st.sum(1).cpu())
-        ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = 2, 256
+        ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = CONV_DEFAULTS
         y0, s0 = outs[(0, 384)]
-        for key, tag in (((1, 1 << 30), "N=128"), ((1, 0), "N=256|128"), ((2, 0), "8w N=256")):
+        for key, tag in (((1, 1 << 30), "N=128"), ((1, 0), "N=256|128"), ((2, 0), "8w N=256"), ((3, 0), "2blk N=128")):
             y1, s1 = outs[key]
             RES.append(("fat conv %s %s bit-identical" % (tag, name), bool(torch.equal(y0, y1))))
             print("fat conv %-9s %-52s %s max diff %.3e" % (tag, name, "ok  " if torch.equal(y0, y1) else "FAIL", (y0 - y1).abs().max().item()), flush=True)
