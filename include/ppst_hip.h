@@ -313,6 +313,15 @@ int64_t ppst_guided_filter_ws(int B, int H, int W);
 int ppst_guided_filter(const void* guide_u8, const void* src_u8, void* out, void* out_u8,
                        int B, int H, int W, int r, float eps, void* work, void* stream);
 
+/* local-affine photo smoothing (smooth_filter.py:332-378 smooth_local_affine and its three NVRTC kernels :149-321):
+ * output (stylised), input (content = guide), result: planar fp32 [B][3][H][W]; model_ws: >= ppst_smooth_local_affine_ws()
+ * bytes, 16-B aligned (the per-pixel 3x4 maps); filtered_model: optional [B][H*W][12] fp32 (the smoothed maps), or NULL.
+ * patch_radius = (patch - 1) / 2, filter_radius = f_r, sigma1 = f_r / 3, sigma2 = f_e as the reference's driver sets them. */
+int64_t ppst_smooth_local_affine_ws(int B, int H, int W);
+int ppst_smooth_local_affine(const void* output, const void* input, void* result, void* model_ws, void* filtered_model,
+                             int B, int H, int W, int patch_radius, int filter_radius, float sigma1, float sigma2,
+                             void* stream);
+
 /* ------------------------------------------------- train step (backward) ---
  * Gradients of the discriminator update (optimizers/ppst_optimizer.py:96-130; torch autograd
  * of F.conv2d / F.linear in stylegan2_layers.py).  The conv INPUT gradient is

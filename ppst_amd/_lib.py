@@ -85,6 +85,8 @@ _SIGS = {
     "ppst_u8_to_tensor": (i32, [vp, vp, i32, i32, i32, i32, f32, f32, vp]),
     "ppst_guided_filter_ws": (i64, [i32, i32, i32]),
     "ppst_guided_filter": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp]),
+    "ppst_smooth_local_affine_ws": (i64, [i32, i32, i32]),
+    "ppst_smooth_local_affine": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp]),
     "ppst_conv_wgrad_f32": (i32, [vp, vp, vp, vp, vp] + [i32] * 11 + [vp]),
     "ppst_wgrad_scatter": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, f32, i32, vp]),
     "ppst_wgrad_small_cin_ws": (i64, [i64, i32, i32]),

@@ -348,3 +348,68 @@ def test_edge_cases():
     # non-float input is rejected
     with pytest.raises(RuntimeError):
         upfirdn2d(torch.zeros(1, 1, 8, 8, device=dev, dtype=torch.float16), k)
+
+
+def test_smooth_filter_local_affine_vs_oracle():
+    """SURVEY section 8 f4 (smooth_filter.py:149-378): the two HIP launches against the numpy restatement of the three
+    reference kernels -- per-pixel affine model, smoothed model and reconstructed image; r = 15 (LDS-tiled path), a small
+    radius, and r = 17 (global-memory path); a ragged size that does not divide the 16 x 16 tile; batch of 2 == 2 singles.
+    Bars (images in [0, 1]): model / filtered model 1e-6 relative to the largest coefficient (fp64 inverse of an
+    fp32-product normal matrix; the oracle and the kernel order the cofactor sums differently), result 1e-6 absolute
+    (first run measured 6e-8 / 8e-8 / 1.8e-7; the bars before it were 2e-5 / 2e-6) + agreement of the uint8 image up to
+    1 LSB on <= 0.1 % of the samples.
+    Property (no oracle): a stylised image that IS a global affine map of the content comes back unchanged up to the 1e-3
+    regulariser."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import smooth_filter_oracle as SO
+    from ppst_amd import smooth_filter as SF
+    rng = np.random.default_rng(3)
+    H, W = 45, 52
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    base = np.stack([0.5 + 0.4 * np.sin(xx / 7 + c) * np.cos(yy / 9 - c) for c in range(3)]).astype(np.float32)
+    inp = np.clip(base + 0.05 * rng.standard_normal((3, H, W)).astype(np.float32), 0, 1).astype(np.float32)
+    out = np.clip(0.8 * inp[::-1] ** 1.3 + 0.1 + 0.03 * rng.standard_normal((3, H, W)).astype(np.float32), 0, 1).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    o_t, i_t = torch.from_numpy(out).to(dev), torch.from_numpy(inp).to(dev)
+    for f_r, f_e in ((15, 0.1), (3, 0.05), (17, 0.1)):
+        res, filt, model = SF.smooth_local_affine_tensor(o_t, i_t, 3, f_r, f_e, return_model=True)
+        m_ref = SO.best_local_affine(out, inp, 1)
+        f_ref = SO.bilateral_smooth(m_ref, inp, f_r, f_r / 3, f_e)
+        r_ref = SO.reconstruction(inp, f_ref)
+        em = np.abs(model[0].cpu().numpy() - m_ref).max() / np.abs(m_ref).max()
+        ef = np.abs(filt.cpu().numpy() - f_ref).max() / np.abs(f_ref).max()
+        er = np.abs(res.cpu().numpy() - r_ref).max()
+        print("smooth_filter f_r=%d: model %.2e  filtered %.2e  result %.2e" % (f_r, em, ef, er))
+        assert em < 1e-6 and ef < 1e-6 and er < 1e-6, (f_r, em, ef, er)
+        u_hip = np.uint8(np.clip(res.cpu().numpy() * 255., 0, 255.))
+        u_ref = np.uint8(np.clip(r_ref * 255., 0, 255.))
+        d = np.abs(u_hip.astype(int) - u_ref.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() <= 1e-3
+    # numpy front end of the reference's signature == tensor entry
+    r_np = SF.smooth_local_affine(out, inp, 1e-7, 3, H, W, 15, 0.1)
+    assert np.array_equal(r_np, SF.smooth_local_affine_tensor(o_t, i_t, 3, 15, 0.1).cpu().numpy())
+    # batch == singles, bit for bit
+    o2 = torch.stack([o_t, o_t.flip(2)]); i2 = torch.stack([i_t, i_t.flip(2)])
+    rb = SF.smooth_local_affine_tensor(o2, i2, 3, 15, 0.1)
+    assert torch.equal(rb[0], SF.smooth_local_affine_tensor(o_t, i_t, 3, 15, 0.1))
+    assert torch.equal(rb[1], SF.smooth_local_affine_tensor(o_t.flip(2), i_t.flip(2), 3, 15, 0.1))
+    # global affine map is a fixed point (channel order reversed by the kernels' indexing, smooth_filter.py:296-317)
+    # (a textured content image: on smooth patches the 3x3 normal matrix is near-singular and the regulariser dominates)
+    M = rng.standard_normal((3, 3)) * 0.2 + np.eye(3)
+    tex = rng.random((3, H, W)).astype(np.float32)
+    aff = (np.einsum("ij,jhw->ihw", M, tex) + 0.05).astype(np.float32)
+    ra = SF.smooth_local_affine_tensor(torch.from_numpy(aff).to(dev), torch.from_numpy(tex).to(dev), 3, 15, 0.1).cpu().numpy()
+    assert np.abs(ra - aff[::-1]).max() < 1e-2
+    # full-size run (512 x 512, r = 15): finite, and a constant stylised image stays constant
+    big_i = torch.rand(1, 3, 512, 512, device=dev)
+    big_o = torch.full_like(big_i, 0.25)
+    rbig = SF.smooth_local_affine_tensor(big_o, big_i, 3, 15, 0.1)
+    assert torch.isfinite(rbig).all() and (rbig - 0.25).abs().max().item() < 1e-3
+    # PIL front end (smooth_filter.py:381-405) == oracle on the same uint8 arrays up to 1 LSB
+    from PIL import Image
+    a8 = np.uint8(np.clip(out.transpose(1, 2, 0) * 255, 0, 255)); c8 = np.uint8(np.clip(inp.transpose(1, 2, 0) * 255, 0, 255))
+    pil = np.asarray(SF.smooth_filter(Image.fromarray(a8), Image.fromarray(c8)))
+    ref8 = SO.smooth_filter_arrays(a8, c8)
+    d = np.abs(pil.astype(int) - ref8.astype(int))
+    assert pil.shape == ref8.shape and d.max() <= 1 and (d > 0).mean() <= 1e-3

@@ -185,3 +185,30 @@ def test_generator_losses_oracle_vs_reference(golden_dir):
         assert abs(float(v) - ref) <= 2e-4 * max(1.0, abs(ref)), (k, float(v), ref)
     for i in range(4):
         check_packed(g, "queue%d" % i, queues[i], rtol=1e-4)
+
+
+def test_smooth_filter_oracle_properties():
+    """oracle/smooth_filter_oracle.py (parity unpinned: no reference fixture exists, smooth_filter.py needs cupy + NVRTC):
+    properties of the restated algorithm itself -- 4x4 inverse, a global affine map is a fixed point (with the kernels'
+    channel reversal), a constant stylised image stays constant, uint8 front end truncates."""
+    import smooth_filter_oracle as SO
+    rng = np.random.default_rng(0)
+    m = rng.standard_normal((6, 4, 4)) + 3 * np.eye(4)
+    inv, ok = SO._inverse4x4(m)
+    assert ok.all() and np.abs(inv - np.linalg.inv(m)).max() < 1e-12
+    sing = np.zeros((1, 4, 4))
+    inv0, ok0 = SO._inverse4x4(sing)
+    assert not ok0[0] and not inv0.any()
+    H, W = 20, 24
+    inp = rng.random((3, H, W)).astype(np.float32)
+    M = rng.standard_normal((3, 3)) * 0.3 + np.eye(3)
+    out = (np.einsum("ij,jhw->ihw", M, inp) + 0.1).astype(np.float32)
+    r = SO.smooth_local_affine(out, inp, 1e-7, 3, H, W, 5, 0.1)
+    assert np.abs(r - out[::-1]).max() < 2e-2
+    const = np.full((3, H, W), 0.25, np.float32)
+    rc = SO.smooth_local_affine(const, inp, 1e-7, 3, H, W, 5, 0.1)
+    assert np.abs(rc - 0.25).max() < 1e-3
+    a8 = (rng.random((H, W, 3)) * 255).astype(np.uint8)
+    c8 = (inp.transpose(1, 2, 0) * 255).astype(np.uint8)
+    u = SO.smooth_filter_arrays(a8, c8, f_radius=4)
+    assert u.dtype == np.uint8 and u.shape == (H, W, 3)
