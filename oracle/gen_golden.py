@@ -290,6 +290,29 @@ def _noise_hooks(m, noise):
     return hs
 
 
+def _noise_scale_hooks(m, acc):
+    """The noise-weight gradient is  sum_p noise[p] * (sum_c dL/dz[c, p])  -- a sum of ~10^5..10^6 zero-mean terms whose
+    total can come out far smaller than its own random-walk magnitude (UpsamplingResBlock64.conv2 at stage 2: 5e-4 against
+    1e-3), so "relative to the reference's value" is not a meaningful scale for it: a handful of leaky-ReLU gates that fall
+    the other way within float32 rounding move it by tens of percent.  This hook records the natural scale
+    sqrt(sum_p term[p]^2) of every NoiseInjection over all its calls of the step; the parity bar for these scalars is taken
+    relative to max(|gradient|, that scale) (tests/gstep_diag.py)."""
+    hs = []
+    for name, mod in m.G.named_modules():
+        if type(mod).__name__ == "NoiseInjection":
+            def fwd(mod_, args, out, name=name):
+                if not (torch.is_tensor(out) and out.requires_grad):
+                    return
+                nz = mod_.fixed_noise.detach()
+
+                def on_grad(g, nz=nz, name=name):
+                    t = (g.detach().sum(1, keepdim=True) * nz).double()
+                    acc[name] = acc.get(name, 0.0) + float((t * t).sum())
+                out.register_hook(on_grad)
+            hs.append(mod.register_forward_hook(fwd))
+    return hs
+
+
 def gen_gstep(ns, stage, f64=False):
     """The generator/encoder update of the reference itself: PPSTOptimizer.train_generator_one_step's
     ``sum(v.mean()).backward()`` (optimizers/ppst_optimizer.py:73-94) over compute_generator_losses
@@ -313,6 +336,8 @@ def gen_gstep(ns, stage, f64=False):
         m.double()
         real, mask, noise = real.double(), mask.double(), {k: v.double() for k, v in noise.items()}
     hooks = _noise_hooks(m, noise)
+    nscale = {}
+    hooks += _noise_scale_hooks(m, nscale)
     taps = {"E1": [], "E2": [], "G": []}
 
     def tap(tag):
@@ -348,6 +373,8 @@ def gen_gstep(ns, stage, f64=False):
             for ti, t in enumerate(ts):
                 if t.grad is not None:
                     pack(out, "tapgrad.%s.%d.%d" % (tag, ci, ti), t.grad)
+    for name, v in nscale.items():
+        out["nscale.G." + name + ".weight"] = np.array(np.sqrt(v))
     for h in hooks:
         h.remove()
     tag = "gstep512_s%d%s.npz" % (stage, "_f64" if f64 else "")

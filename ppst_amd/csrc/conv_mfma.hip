@@ -698,6 +698,9 @@ extern "C" int ppst_prof_detail(int idx, double* ms, double* flop, int32_t* info
 }
 
 int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int tiles_x, hipStream_t st);   // conv_mfma2.hip
+int ppst_conv1x1_stream_launch(const ppst_conv_args* a, int n_tiles, int tiles, hipStream_t st);                     // conv1x1.hip
+int ppst_conv_direct_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int tiles_x, hipStream_t st);         // conv1x1.hip
+int ppst_conv3x3_direct_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int tiles_x, hipStream_t st);      // conv1x1.hip
 
 extern "C" int ppst_conv_tiles(int tile_h, int tile_w, int tile_rows) { return cdiv(tile_h, tile_rows) * cdiv(tile_w, 16); }
 
@@ -713,8 +716,17 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       a->out_ld < a->cout || a->cout <= 0 || a->cout % 4 || a->out_ld % 4 || (a->residual && a->res_ld % 4) || a->nsteps <= 0 || (a->n_groups != 1 && a->n_groups != 4) || a->pad_mode < 0 ||
       a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 ||
       (a->precision != 0 && a->precision != 1 && a->precision != 3 && a->precision != 4) || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128 && a->bn != 256) || (a->residual && a->res_ld < a->cout) ||
-      a->variant < 0 || a->variant > 3 || (a->variant == 0 && a->bn == 256) ||
-      (a->variant >= 1 && (a->precision != 0 || a->bn == 64 || !a->early_a)) || (a->variant == 2 && a->bn != 256) || (a->variant == 3 && a->bn != 128) ||
+      a->variant < 0 || a->variant > 6 || (a->variant == 0 && a->bn == 256) ||
+      (a->variant >= 1 && a->variant <= 3 && (a->precision != 0 || a->bn == 64 || !a->early_a)) ||
+      (a->variant == 2 && a->bn != 256) || (a->variant == 3 && a->bn != 128) ||
+      // variant 4 = the 1x1 streaming kernel (conv1x1.hip): all taps (0,0), one group, unit strides, bf16x3, 64-wide blobs
+      (a->variant == 4 && (a->precision != 0 || a->bn != 64 || a->halo != 0 || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
+                           a->in_off_y != 0 || a->in_off_x != 0 || a->tile_h != a->out_h || a->tile_w != a->out_w ||
+                           a->in_h != a->out_h || a->in_w != a->out_w)) ||
+      // variant 5 = the direct form of the same kernel for thin layers with taps (one group, unit output stride)
+      // (6: its register-reuse form for plain 3x3 stride-1 tables: the CALLER promises the (chunk, dy, dx) step order)
+      ((a->variant == 5 || a->variant == 6) && (a->precision != 0 || a->bn != 64 || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
+                           a->in_off_y != 0 || a->in_off_x != 0 || a->tile_h != a->out_h || a->tile_w != a->out_w)) ||
       (a->tile_rows != 16) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
     return PPST_EINVAL;
   // the scattered output must reach into the output tensor (elements beyond it are dropped)
@@ -758,7 +770,10 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
     (void)hipEventRecord(g_ev[slot][0], st);
   }
   if (a->variant >= 1) {
-    int e2 = ppst_conv2d_mfma2_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st);
+    int e2 = a->variant == 4   ? ppst_conv1x1_stream_launch(a, k.n_tiles, k.tiles_y * k.tiles_x, st)
+             : a->variant == 5 ? ppst_conv_direct_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st)
+             : a->variant == 6 ? ppst_conv3x3_direct_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st)
+                               : ppst_conv2d_mfma2_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st);
     if (slot >= 0) (void)hipEventRecord(g_ev[slot][1], st);
     return e2;
   }

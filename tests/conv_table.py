@@ -15,6 +15,10 @@ if len(sys.argv) > 4:
     ops.FAT_MIN_BLOCKS = int(sys.argv[4])
 if len(sys.argv) > 5:
     ops.TWO_BLOCK_128["value"] = bool(int(sys.argv[5]))
+if len(sys.argv) > 6:
+    ops.DIRECT_MAX["cout"] = int(sys.argv[6])
+if len(sys.argv) > 7:
+    ops.DIRECT_MAX["nsteps"] = int(sys.argv[7])
 dev = torch.device("cuda", 0)
 sd = W.make_state_dict(0, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
 m = create_model(state_dict=sd, device=dev)

@@ -354,6 +354,67 @@ def t_conv_variants():
             report("fat conv %s %s stats" % (tag, name), s1, s0, 1e-5)
 
 
+def t_conv1x1_stream():
+    """conv1x1.hip (streaming 1x1 kernel and its direct form for thin 3x3 / stride-2 layers; operands swapped) against
+    conv_mfma.hip on the same plans: bit-identical outputs, statistics to rounding; every epilogue / normalise-on-load
+    option, the three padding modes, ragged sizes, Cout not a multiple of 64 (and <= 32: the 2-tile build), > 8 steps."""
+    torch.manual_seed(6)
+    nz_ = torch.randn
+    cases = [
+        # name, B, Cin, Cout, H, W, kind, k, pad_mode, features
+        ("1x1 64->64 48x40 bias+noise+lrelu", 2, 64, 64, 48, 40, "conv", 1, 0, "full"),
+        ("1x1 32->384 33x47 plain", 2, 32, 384, 33, 47, "conv", 1, 0, "plain"),
+        ("1x1 512->256 16x16 in_ss+prelu (16 steps)", 1, 512, 256, 16, 16, "conv", 1, 0, "inss"),
+        ("1x1 128->64 24x24 residual", 3, 128, 64, 24, 24, "conv", 1, 0, "res"),
+        ("1x1 256->36 17x9 bias", 1, 256, 36, 17, 9, "conv", 1, 0, "bias"),
+        ("1x1 dgrad (64<-128) 32x32", 2, 64, 128, 32, 32, "dgrad", 1, 0, "plain"),
+        ("3x3 zero 32->32 48x40 bias+noise+lrelu", 2, 32, 32, 48, 40, "conv", 3, 0, "full"),
+        ("3x3 reflect 64->64 33x47 plain", 2, 64, 64, 33, 47, "conv", 3, 1, "plain"),
+        ("3x3 replicate 32->48 19x21 in_ss+prelu", 1, 32, 48, 19, 21, "conv", 3, 2, "inss"),
+        ("3x3 zero 128->64 24x24 residual (36 steps)", 2, 128, 64, 24, 24, "conv", 3, 0, "res"),
+        ("3x3 zero in_ss 64->20 17x9", 1, 64, 20, 17, 9, "conv", 3, 0, "inss"),
+        ("s2d 32->64 -> 20x23 residual", 2, 32, 64, 20, 23, "s2d", 3, 0, "res"),
+        ("dgrad 3x3 (32<-64) 32x32", 2, 32, 64, 32, 32, "dgrad", 3, 0, "plain"),
+        # full-size launches: > 512 tiles, so the single-chunk 3x3 kernel runs its persistent loop with resident weights
+        ("3x3 reflect 32->32 512x512 bias+noise+lrelu (persistent)", 2, 32, 32, 512, 512, "conv", 3, 1, "full"),
+        ("3x3 zero 64->64 400x512 in_ss (2 chunks)", 2, 64, 64, 400, 512, "conv", 3, 0, "inss"),
+        ("1x1 128->64 512x512 residual", 2, 128, 64, 512, 512, "conv", 1, 0, "res"),
+        ("s2d 32->64 -> 256x256", 2, 32, 64, 256, 256, "s2d", 3, 0, "plain"),
+    ]
+    dmax = dict(ops.DIRECT_MAX)
+    for name, B, ci, co, H, Wd, kind, k, pm, feat in cases:
+        w = g(nz_(co, ci, k, k) / math.sqrt(ci * k * k))
+        outs = {}
+        for stream in (False, True):
+            ops.STREAM_1X1["value"] = stream
+            ops.DIRECT_MAX["cout"] = dmax["cout"] if stream else 0
+            plan = ops.ConvPlan(w, kind=kind)
+            cin_eff = plan.max_chan + 32
+            torch.manual_seed(12)
+            x = g(nz_(B, H + 1, Wd + 1, cin_eff)) if kind == "s2d" else g(nz_(B, H, Wd, cin_eff))
+            kw = dict(out_hw=(H, Wd)) if kind == "s2d" else {}
+            if feat == "full":
+                kw.update(bias=g(nz_(plan.cout)), noise=g(nz_(B, 1, H, Wd)), noise_weight=0.3, act=ops.ACT_LRELU)
+            elif feat == "bias":
+                kw.update(bias=g(nz_(plan.cout)))
+            elif feat == "inss":
+                kw.update(in_ss=g(torch.rand(B, cin_eff, 2) + 0.5), in_act=ops.ACT_PRELU, in_prelu=g(torch.tensor([0.25])),
+                          act=ops.ACT_PRELU, prelu=g(torch.tensor([0.1])))
+            elif feat == "res":
+                kw.update(residual=g(nz_(B, H, Wd, plan.cout)), res_after_act=True, act=ops.ACT_LRELU, out_scale=0.7)
+            y, st = plan(x, stats=True, pad_mode=pm, **kw)
+            outs[stream] = (y.cpu(), st.sum(1).cpu())
+        ops.STREAM_1X1["value"] = STREAM_DEFAULT
+        ops.DIRECT_MAX.update(dmax)
+        (y0, s0), (y1, s1) = outs[False], outs[True]
+        RES.append(("stream/direct %s bit-identical" % name, bool(torch.equal(y0, y1))))
+        print("stream/direct %-46s %s max diff %.3e" % (name, "ok  " if torch.equal(y0, y1) else "FAIL", (y0 - y1).abs().max().item()), flush=True)
+        report("stream/direct %s stats" % name, s1, s0, 1e-5)
+
+
+STREAM_DEFAULT = ops.STREAM_1X1["value"]
+
+
 def t_norm_pool():
     torch.manual_seed(3)
     for (B, C, H, Wd) in [(2, 64, 40, 40), (1, 3, 64, 64), (2, 512, 16, 16), (1, 128, 70, 30)]:
@@ -776,7 +837,7 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     print("device:", torch.cuda.get_device_name(0), flush=True)
     if which in ("ops", "all"):
-        for fn in (t_upfirdn2d, t_fused_act, t_layout_misc, t_conv, t_conv_variants, t_norm_pool, t_corr, t_guided):
+        for fn in (t_upfirdn2d, t_fused_act, t_layout_misc, t_conv, t_conv_variants, t_conv1x1_stream, t_norm_pool, t_corr, t_guided):
             print("== " + fn.__name__, flush=True)
             run(fn)
             torch.cuda.synchronize()
@@ -787,6 +848,7 @@ def main():
         run(t_precision)
     if which == "convv":
         run(t_conv_variants)
+        run(t_conv1x1_stream)
     if which == "trainops":
         run(t_train_ops)
     if which in ("train", "all"):

@@ -354,6 +354,13 @@ def compare_gstep(stage, tol_max=5e-3, tol_l2=5e-3, verbose=True, precision=0, a
             ref32 = g[key + ".samples"].astype(np.float64)
             truth = g64[key + ".samples"].astype(np.float64) if g64 is not None else ref32
             scale = float((g64 if g64 is not None else g)[key + ".stats"][2])
+            # noise-weight gradients: sum_p noise[p] * sum_c dz[c, p], a sum of ~10^6 zero-mean terms that can land far below
+            # its own random-walk magnitude sqrt(sum term^2) (recorded by the fixture generator from the reference's
+            # backward, oracle/gen_golden.py:_noise_scale_hooks).  A few leaky-ReLU gates that fall the other way within
+            # float32 rounding move such a sum by a multiple of one term, whatever its total: the error of these scalars is
+            # measured against max(|gradient|, natural scale), not against a total that happens to be small.
+            nkey = "nscale." + key[len("grad."):]
+            nat = float(g[nkey]) if nkey in g.files else 0.0
             d = got[idx] - truth
             if scale < 1e-6 or key in NULL_DIRECTIONS:
                 # a bias in front of an instance norm (ToRGB.bias, ToSpatialCode.1.Conv.bias ...) or an unused parameter:
@@ -362,11 +369,14 @@ def compare_gstep(stage, tol_max=5e-3, tol_l2=5e-3, verbose=True, precision=0, a
                 e_max = e_l2 = float(np.abs(got).max())
                 floor_max = floor_l2 = 0.0
             else:
+                l2ref = float(np.linalg.norm(truth)) + 1e-30
+                if nat > scale:
+                    scale = l2ref = nat
                 e_max = float(np.abs(d).max() / scale)
-                e_l2 = float(np.linalg.norm(d) / (np.linalg.norm(truth) + 1e-30))
+                e_l2 = float(np.linalg.norm(d) / l2ref)
                 dr = ref32 - truth
                 floor_max = float(np.abs(dr).max() / scale)
-                floor_l2 = float(np.linalg.norm(dr) / (np.linalg.norm(truth) + 1e-30))
+                floor_l2 = float(np.linalg.norm(dr) / l2ref)
                 ok = e_max <= max(tol_max, 2 * floor_max) and e_l2 <= max(tol_l2, 2 * floor_l2)
                 if assert_mode and not ok:
                     ok = _within_class_bar(key, got.size, e_max, e_l2, floor_max, floor_l2, precision, truth64=g64 is not None)
