@@ -311,7 +311,8 @@ def main():
                        "image_parallel": "1 batch per rank, no data-path collective"},
             "algorithmic_tflops_whole_job": swaps * FLOP_PER_SWAP / dt / 1e12,
             "roofline": {
-                "kernel": "conv_mfma_kernel (StyledConv / EqualConv2d / nn.Conv2d implicit GEMM, all launches)",
+                "kernel": "ppst_conv2d_mfma: conv_mfma_kernel + conv_mfma2_kernel + conv1x1_stream_kernel + conv3x3_direct_kernel "
+                          "(StyledConv / EqualConv2d / nn.Conv2d implicit GEMM, all launches)",
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "peak_note": "bf16 dense MFMA 2500 TF / %d MFMA passes per algorithmic MAC" % passes,
                 "frac_vs_dense_bf16": achieved / PEAK_BF16_DENSE_TF,

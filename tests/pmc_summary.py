@@ -28,11 +28,13 @@ for k in fetch:
         e["kernel_ms_in_clock_pass"] = act[k][2] / 1e6
     kernels[k] = e
 kernels = dict(sorted(kernels.items(), key=lambda kv: -(kv[1]["fetch_bytes_corrected"] + kv[1]["write_bytes"])))
-conv = [v for k, v in kernels.items() if "conv_mfma_kernel" in k]
+CONV = ("conv_mfma_kernel", "conv_mfma2_kernel", "conv1x1_stream_kernel", "conv3x3_direct_kernel")   # every ppst_conv2d_mfma variant
+is_conv = lambda k: any(c in k for c in CONV)
+conv = [v for k, v in kernels.items() if is_conv(k)]
 n = sum(v["launches"] for v in conv)
 fb, wb = sum(v["fetch_bytes_corrected"] for v in conv), sum(v["write_bytes"] for v in conv)
-cyc = sum(act[k][1] for k in act if "conv_mfma_kernel" in k)
-dur = sum(act[k][2] for k in act if "conv_mfma_kernel" in k)
+cyc = sum(act[k][1] for k in act if is_conv(k))
+dur = sum(act[k][2] for k in act if is_conv(k))
 res = {
     "command": cmd,
     "commit": commit,
