@@ -130,7 +130,9 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
                 out["UpsamplingResBlock%d.%s" % (key, c)] = torch.randn(B, 1, s, s, device=device)
         return out
 
-    def forward(self, spatial_code, global_codes, extract_features=False, noise=None):
+    def forward(self, spatial_code, global_codes, extract_features=False, noise=None, want_rgb=True):
+        """want_rgb=False (only with extract_features): skip ToRGB -- `extract_feat_from_image` (ppst_model.py:255-262)
+        throws the image of its feature passes away; the reference computes it all the same.  Returns (None, feat, feat1)."""
         sp = to_nhwc(spatial_code)
         B, S = sp.shape[0], sp.shape[1]
         if isinstance(noise, str) and noise == "random":
@@ -182,6 +184,12 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
                     ops.avgpool(f, f.shape[1] // h, out=feat[..., c0:c0 + 64])
                     ops.bilinear(f, 256, 256, out=feat1[..., c0:c0 + 64])
         # ToRGB (stylegan2_layers.py:477-495): 1x1 conv + biases -> InstanceNorm(3) -> StyleMod
+        if extract_features and not want_rgb:
+            for i in range(3):
+                feat = self._residual_block(feat, "layert.%d." % i)
+            feat1 = self._residual_block(feat1, "layert1.0.")
+            feat1 = self.plan("layert1.1.weight")(feat1, bias=self.p("layert1.1.bias"))
+            return None, as_nchw(feat), as_nchw(feat1)
         wr = self.p("ToRGB.conv.weight")
         brgb = self.cached(("rgbb",), [self.p("ToRGB.conv.bias"), self.p("ToRGB.bias")],
                            lambda: (self.p("ToRGB.conv.bias") + self.p("ToRGB.bias").reshape(-1)).contiguous())

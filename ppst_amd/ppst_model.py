@@ -200,7 +200,7 @@ class PPSTModel(nn.Module):
     def extract_feat_from_image(self, img):
         sp = self.E1(img)
         gl = self.E2(img)[0]
-        _, fea, fea1 = self.G(sp, gl, extract_features=True, noise=self.noise)
+        _, fea, fea1 = self.G(sp, gl, extract_features=True, noise=self.noise, want_rgb=False)
         return fea, fea1
 
     def Rselfcorr(self, fea):
@@ -279,7 +279,7 @@ class PPSTModel(nn.Module):
         losses, metrics = {}, {}
         sp = self.E1(real)
         gl, _ = self.E2(real)
-        _, feas, feas1 = self.G(sp, gl, extract_features=True, noise=self.noise)
+        _, feas, feas1 = self.G(sp, gl, extract_features=True, noise=self.noise, want_rgb=False)
         sps = torch.cat((feas, self.Rselfcorr(feas1)), dim=1)
         corr = self.corrm(sps, self.swap(sps))
         corr_self = self.corrm(sps, sps)
