@@ -283,15 +283,39 @@ def main():
         for _ in range(args.warmup):
             out = swap_step(model, content, style, 1.0, glue)
         barrier()
+        # which of the bracketed conv launches belong to StyledConv (the "modulated_conv2d" of BASELINE's metric (ii)): every
+        # ConvPlan call is one ppst_conv2d_mfma launch, counted in order; those issued inside Generator.styled_conv are tagged
+        tag = {"n": 0, "depth": 0, "styled": set()}
+        plan_call, g_cls = ops.ConvPlan.__call__, type(model.G)
+        styled_conv = g_cls.styled_conv
+
+        def counted_call(self, *a, **k):
+            if tag["depth"]:
+                tag["styled"].add(tag["n"])
+            tag["n"] += 1
+            return plan_call(self, *a, **k)
+
+        def tagged_styled_conv(self, *a, **k):
+            tag["depth"] += 1
+            try:
+                return styled_conv(self, *a, **k)
+            finally:
+                tag["depth"] -= 1
+        ops.ConvPlan.__call__, g_cls.styled_conv = counted_call, tagged_styled_conv
         ops.prof_enable(True)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = swap_step(model, content, style, 1.0, glue)
         barrier()
         dt = time.perf_counter() - t0
+        ops.ConvPlan.__call__, g_cls.styled_conv = plan_call, styled_conv
+        detail = ops.prof_detail()
         conv_ms, conv_launches, conv_flop = ops.prof_collect()
         ops.prof_enable(False)
     assert torch.isfinite(out).all()
+    assert len(detail) == tag["n"] == conv_launches, (len(detail), tag["n"], conv_launches)
+    st_ms = sum(detail[i][0] for i in tag["styled"])
+    st_flop = sum(detail[i][1] for i in tag["styled"])
 
     dt = max_over_ranks(dt)
 
@@ -321,6 +345,13 @@ def main():
                 "effective_clock_ghz_pmc": conv_pmc(),
             },
         }
+        st_ach = st_flop / (st_ms * 1e-3) / 1e12 if st_ms > 0 else 0.0
+        res["roofline_modulated_conv2d"] = {
+            "kernel": "the same kernels, only the launches issued by StyledConv (stylegan2_layers.py:439-475: the generator's 3x3 and "
+                      "fused-upscale convs with noise / bias / leaky-ReLU epilogue and instance-norm statistics) -- BASELINE metric (ii)",
+            "bound": "mfma", "achieved": st_ach, "peak": peak, "unit": "TFLOP/s", "frac": st_ach / peak,
+            "frac_vs_dense_bf16": st_ach / PEAK_BF16_DENSE_TF, "launches": len(tag["styled"]), "kernel_ms_total": st_ms,
+            "share_of_step_time": st_ms * 1e-3 / dt}
         res["roofline_upfirdn2d"] = upfirdn2d_rate(B, dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(0)

@@ -53,7 +53,7 @@ __device__ __forceinline__ int c1_pad(int i, int n, int mode) {
 // Epilogue shared by the kernels of this file: lane = pixel r16 of each m-tile, channels n0 + 4g .. 4g+3 of each n-tile
 // (operands swapped in the MFMAs), everything a 16-B access straight from the accumulators; tile statistics through `red`.
 template <int MT, int NT, bool TAPS>
-__device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT], float (&red)[8][64][2], int b, int mblk,
+__device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT], float (&red)[8][NT > 4 ? 128 : 64][2], int b, int mblk,
                                             int ntile, int pbase, int oy0, int ox, int tid, int wave, int r16, int g) {
   const int act = a.act & 0xff;
   const bool res_after = (a.act >> 8) & 1;
@@ -69,7 +69,7 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT
     const float nz = a.noise ? a.noise_weight * a.noise[opix] : 0.f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int n0 = ntile * 64 + nt * 16 + g * 4;
+      const int n0 = ntile * (NT > 4 ? 128 : 64) + nt * 16 + g * 4;
       if (n0 >= a.cout) continue;
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), rv = bv;
       if (a.bias) bv = *(const float4*)(a.bias + n0);
@@ -112,8 +112,8 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT
       }
     }
     __syncthreads();
-    if (tid < 64) {
-      const int n = ntile * 64 + tid;
+    if (tid < (NT > 4 ? 128 : 64)) {
+      const int n = ntile * (NT > 4 ? 128 : 64) + tid;
       if (n < a.cout) {
         float t0 = 0.f, t1 = 0.f;
 #pragma unroll
@@ -283,11 +283,15 @@ __device__ __forceinline__ bf16x8 c3_shift(bf16x8 edge, bf16x8 centre) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
+// NT_ = 8 (Cout = 65..128, blobs packed for bn = 128): wave tile 32 px x 128 ch, 256 registers, one block per CU (152 KB of
+// LDS) -- the generator's 128 -> 128 @512^2 StyledConv, which the tile kernel ran at 0.43 of the ceiling (36-step tiles
+// pay 20 % for their serial prologue + epilogue): here the two waves of a SIMD overlap one's conversions with the other's MFMAs.
 template <bool INSS, int NT_>
-__global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(C1Args a) {
+__global__ __launch_bounds__(512, NT_ > 4 ? 2 : 4) void conv3x3_direct_kernel(C1Args a) {
   constexpr int MT = 2, NT = NT_;
-  __shared__ uint4 sB[C3_GROUP * C1_BLOB / 16];
-  __shared__ float red[8][64][2];
+  constexpr int BLOB = NT > 4 ? 16384 : C1_BLOB;          // bytes per step blob (8 planes x bn x 16 B)
+  __shared__ uint4 sB[C3_GROUP * BLOB / 16];
+  __shared__ float red[8][NT > 4 ? 128 : 64][2];
   // persistent blocks (the launch caps the grid at two per CU): block i walks the contiguous range of work ids
   // [i * per, (i + 1) * per) -- neighbouring tiles share their halo rows in this XCD's L2 -- and, when the layer has a single
   // 32-channel chunk and one N tile, copies the 9 weight blobs to LDS once for all its tiles.
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(C1Args a) {
   const int tyi = mblk / a.tiles_x, txi = mblk - tyi * a.tiles_x;
   const int oy0 = tyi * 16 + wave * 2, ox = txi * 16 + r16;
   const float* xb = a.x + (int64_t)b * a.in_h * a.in_w * a.in_ld;
-  const unsigned char* wblob = a.wpack + (int64_t)ntile * a.nsteps * C1_BLOB;
+  const unsigned char* wblob = a.wpack + (int64_t)ntile * a.nsteps * BLOB;
   if (wid > w_beg) __syncthreads();            // `red` and (unless kept) the weight blobs of the previous tile are free
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef const __attribute__((address_space(4))) int4* StepPtr;
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(C1Args a) {
   for (int c = 0; c < nchunks; ++c) {
     if (!keep_b || wid == w_beg) {
       if (c) __syncthreads();                  // every wave has finished reading the previous chunk's blobs
-      for (int i = tid; i < C3_GROUP * (C1_BLOB / 16); i += 512) sB[i] = ((const uint4*)(wblob + (int64_t)c * C3_GROUP * C1_BLOB))[i];
+      for (int i = tid; i < C3_GROUP * (BLOB / 16); i += 512) sB[i] = ((const uint4*)(wblob + (int64_t)c * C3_GROUP * BLOB))[i];
       __syncthreads();
     }
     const int chan_next = c + 1 < nchunks ? steps[(c + 1) * 9].x : chan;
@@ -396,11 +400,11 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(C1Args a) {
         for (int mt = 0; mt < MT; ++mt) {
           const int dyi = r - mt;                                            // dy + 1
           if (dyi < 0 || dyi > 2) continue;
-          const unsigned char* bs = (const unsigned char*)sB + (dyi * 3 + dxi) * C1_BLOB + g * 1024 + r16 * 16;
+          const unsigned char* bs = (const unsigned char*)sB + (dyi * 3 + dxi) * BLOB + g * (BLOB / 8) + r16 * 16;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const bf16x8 bh = *(const bf16x8*)(bs + nt * 256);
-            const bf16x8 bl = *(const bf16x8*)(bs + nt * 256 + 4096);
+            const bf16x8 bl = *(const bf16x8*)(bs + nt * 256 + BLOB / 2);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, fl, acc[mt][nt], 0, 0, 0);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, fh, acc[mt][nt], 0, 0, 0);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, fh, acc[mt][nt], 0, 0, 0);
@@ -474,10 +478,11 @@ int ppst_conv3x3_direct_launch(const ppst_conv_args* a, int n_tiles, int tiles_y
   if (blocks > 0x7fffffff) return PPST_EINVAL;
   // single-chunk layers: persistent blocks (two 8-wave blocks per CU, 72 KB of LDS each) that keep the weights resident
   if (a->nsteps == 9 && n_tiles == 1 && blocks > 512) blocks = 512;
-  const bool nt2 = a->cout <= 32;
+  const bool nt2 = a->cout <= 32, nt8 = a->bn == 128;
 #define LD3(INSS_)                                                                                                   \
   do {                                                                                                               \
-    if (nt2) PPST_LAUNCH((conv3x3_direct_kernel<INSS_, 2>), dim3((unsigned)blocks), dim3(512), 0, st, k);             \
+    if (nt8) PPST_LAUNCH((conv3x3_direct_kernel<INSS_, 8>), dim3((unsigned)blocks), dim3(512), 0, st, k);             \
+    else if (nt2) PPST_LAUNCH((conv3x3_direct_kernel<INSS_, 2>), dim3((unsigned)blocks), dim3(512), 0, st, k);        \
     else PPST_LAUNCH((conv3x3_direct_kernel<INSS_, 4>), dim3((unsigned)blocks), dim3(512), 0, st, k);                 \
   } while (0)
   if (k.in_ss) LD3(true); else LD3(false);

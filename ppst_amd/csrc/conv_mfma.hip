@@ -725,7 +725,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
                            a->in_h != a->out_h || a->in_w != a->out_w)) ||
       // variant 5 = the direct form of the same kernel for thin layers with taps (one group, unit output stride)
       // (6: its register-reuse form for plain 3x3 stride-1 tables: the CALLER promises the (chunk, dy, dx) step order)
-      ((a->variant == 5 || a->variant == 6) && (a->precision != 0 || a->bn != 64 || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
+      ((a->variant == 5 || a->variant == 6) && (a->precision != 0 || (a->bn != 64 && !(a->variant == 6 && a->bn == 128)) || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
                            a->in_off_y != 0 || a->in_off_x != 0 || a->tile_h != a->out_h || a->tile_w != a->out_w)) ||
       (a->tile_rows != 16) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
     return PPST_EINVAL;

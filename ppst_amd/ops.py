@@ -28,7 +28,8 @@ TILE_ROWS = {"value": 16}  # conv tile rows: 8 (2 blocks per CU) or 16 (1 block 
 # 128 px x 64 ch wave tiles and a 256-channel N tile (conv_mfma2.hip, WNW = 4): bit-identical to the 64x64-wave-tile kernel
 # and 10-16 % faster on those layers (256->256 @256^2 459 vs 417 TFLOP/s, 512->512 @128^2 494 vs 440).
 CONV_VARIANT = {"value": 2}
-DIRECT_MAX = {"cout": 64, "nsteps": 40}   # thin layers (few channels in and out) on the direct form of that kernel
+DIRECT_MAX = {"cout": 64, "nsteps": 40, "cout3x3": 64}   # cout3x3 = 128 was measured: 128->128 @512^2 230 vs 357 TFLOP/s
+# thin layers (few channels in and out) on the direct form of that kernel
 STREAM_1X1 = {"value": True}       # 1x1 convs (halo 0) on the streaming kernel of conv1x1.hip
 TWO_BLOCK_128 = {"value": False}   # experiment: variant 3 (see __call__) for the Cout = 128-class layers
 FAT_MIN_BLOCKS = 32         # take the 256-channel tile only when ONE image still gives >= this many blocks (B = 8: one per CU)
@@ -409,6 +410,9 @@ class ConvPlan:
             # thin layers: direct form of the streaming kernel; plain 3x3 stride-1 tables (order (chunk, dy, dx)) on its
             # register-reuse form
             variant, bn = (6 if (self.kind in ("conv", "dgrad") and self.k == 3) else 5), 64
+        elif (self.precision == 0 and self.kind in ("conv", "dgrad") and self.k == 3 and 64 < self.cout <= DIRECT_MAX["cout3x3"]
+              and (th, tw) == (oh, ow)):
+            variant, bn = 6, 128        # 3x3 layers with 65..128 output channels: the register-reuse kernel, 32 px x 128 ch waves
         a = _lib.ConvArgs()
         a.x, a.wpack, a.steps, a.y = _p(x), _p(self.pack_for(bn) if self.precision != 2 else None), _p(self.steps), _p(out)
         a.variant = variant

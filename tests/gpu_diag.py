@@ -375,6 +375,12 @@ def t_conv1x1_stream():
         ("3x3 zero in_ss 64->20 17x9", 1, 64, 20, 17, 9, "conv", 3, 0, "inss"),
         ("s2d 32->64 -> 20x23 residual", 2, 32, 64, 20, 23, "s2d", 3, 0, "res"),
         ("dgrad 3x3 (32<-64) 32x32", 2, 32, 64, 32, 32, "dgrad", 3, 0, "plain"),
+        # 65..128 output channels: the 32 px x 128 ch form of the 3x3 kernel (blobs packed for bn = 128)
+        ("3x3 zero 128->128 48x40 bias+noise+lrelu", 2, 128, 128, 48, 40, "conv", 3, 0, "full"),
+        ("3x3 reflect 64->96 33x47 in_ss+prelu", 2, 64, 96, 33, 47, "conv", 3, 1, "inss"),
+        ("3x3 replicate 256->128 19x21 residual (72 steps)", 1, 256, 128, 19, 21, "conv", 3, 2, "res"),
+        ("dgrad 3x3 (128<-128) 32x32", 2, 128, 128, 32, 32, "dgrad", 3, 0, "plain"),
+        ("3x3 zero 128->128 512x512 bias+noise+lrelu", 2, 128, 128, 512, 512, "conv", 3, 0, "full"),
         # full-size launches: > 512 tiles, so the single-chunk 3x3 kernel runs its persistent loop with resident weights
         ("3x3 reflect 32->32 512x512 bias+noise+lrelu (persistent)", 2, 32, 32, 512, 512, "conv", 3, 1, "full"),
         ("3x3 zero 64->64 400x512 in_ss (2 chunks)", 2, 64, 64, 400, 512, "conv", 3, 0, "inss"),
@@ -388,6 +394,7 @@ def t_conv1x1_stream():
         for stream in (False, True):
             ops.STREAM_1X1["value"] = stream
             ops.DIRECT_MAX["cout"] = dmax["cout"] if stream else 0
+            ops.DIRECT_MAX["cout3x3"] = 128 if stream else 0      # (off by default: measured slower; kept bit-identical)
             plan = ops.ConvPlan(w, kind=kind)
             cin_eff = plan.max_chan + 32
             torch.manual_seed(12)
