@@ -256,13 +256,21 @@ __global__ __launch_bounds__(256) void wgrad_small_cin_kernel(const float* __res
   for (int nb = 0; nb < cout; nb += 64) {
     const int n = nb + lane;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
-    if (n < cout)
-      for (int64_t p = p0 + w; p < p1; p += 4) {
+    if (n < cout) {
+      int64_t p = p0 + w;
+      for (; p + 12 < p1; p += 16) {            // four pixels in flight per wave (independent loads)
+        const float g0 = dy[p * cout + n], g1 = dy[(p + 4) * cout + n], g2 = dy[(p + 8) * cout + n], g3 = dy[(p + 12) * cout + n];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < cin) a[c] += (g0 * x[p * in_ld + c] + g1 * x[(p + 4) * in_ld + c]) + (g2 * x[(p + 8) * in_ld + c] + g3 * x[(p + 12) * in_ld + c]);
+      }
+      for (; p < p1; p += 4) {
         float g = dy[p * cout + n];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
           if (c < cin) a[c] += g * x[p * in_ld + c];
       }
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) sm[w][lane][c] = a[c];
     __syncthreads();
@@ -273,27 +281,46 @@ __global__ __launch_bounds__(256) void wgrad_small_cin_kernel(const float* __res
     __syncthreads();
   }
 }
+// out[i] (+)= scale * sum_b partial[b][i]: a block owns 32 consecutive outputs, its 8 thread groups walk the partial rows
+// 8 apart with 4 loads in flight each (double accumulation, fixed order).  (The one-thread-per-output form walked
+// `nblocks` dependent loads per thread: 0.1-0.3 ms for the 128-1280 partial rows of the FromRGB / bias gradients.)
 __global__ __launch_bounds__(256) void sum_blocks_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblocks,
                                                          int64_t n, float scale, int accumulate) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  __shared__ double sm[8][32];
+  const int il = threadIdx.x & 31, kk = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + il;
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += (double)partial[(int64_t)b * n + i];
-  float v = (float)s * scale;
-  out[i] = accumulate ? out[i] + v : v;
+  if (i < n) {
+    int b = kk;
+    for (; b + 24 < nblocks; b += 32) {
+      const float v0 = partial[(int64_t)b * n + i], v1 = partial[(int64_t)(b + 8) * n + i], v2 = partial[(int64_t)(b + 16) * n + i],
+                  v3 = partial[(int64_t)(b + 24) * n + i];
+      s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+    }
+    for (; b < nblocks; b += 8) s += (double)partial[(int64_t)b * n + i];
+  }
+  sm[kk][il] = s;
+  __syncthreads();
+  if (kk == 0 && i < n) {
+#pragma unroll
+    for (int r = 1; r < 8; ++r) s += sm[r][il];
+    float v = (float)s * scale;
+    out[i] = accumulate ? out[i] + v : v;
+  }
 }
-extern "C" int64_t ppst_wgrad_small_cin_ws(int64_t npix, int cin, int cout) { return cdiv64(npix, 4096) * cout * cin * (int64_t)sizeof(float); }
+#define WSC_PIX 1024    // pixels per block of the FromRGB weight gradient (4096 left half the chip idle at 2 x 512^2 pixels)
+extern "C" int64_t ppst_wgrad_small_cin_ws(int64_t npix, int cin, int cout) { return cdiv64(npix, WSC_PIX) * cout * cin * (int64_t)sizeof(float); }
 extern "C" int ppst_wgrad_small_cin(const void* x, const void* dy, void* dw, void* ws, int64_t npix, int cin, int in_ld, int cout,
                                     float scale, int accumulate, void* stream) {
   if (npix <= 0 || cin <= 0 || cin > 4 || in_ld < cin || cout <= 0) return PPST_EINVAL;
   if (!x || !dy || !dw || !ws) return PPST_ENULL;
-  int nblocks = (int)cdiv64(npix, 4096);
+  int nblocks = (int)cdiv64(npix, WSC_PIX);
   PPST_LAUNCH(wgrad_small_cin_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (float*)ws,
-              npix, cin, in_ld, cout, (int64_t)4096);
+              npix, cin, in_ld, cout, (int64_t)WSC_PIX);
   int e = PPST_LAUNCH_CHECK();
   if (e) return e;
   int64_t n = (int64_t)cout * cin;
-  PPST_LAUNCH(sum_blocks_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, as_stream(stream), (const float*)ws, (float*)dw, nblocks,
+  PPST_LAUNCH(sum_blocks_kernel, dim3((unsigned)cdiv64(n, 32)), dim3(256), 0, as_stream(stream), (const float*)ws, (float*)dw, nblocks,
               n, scale, accumulate);
   return PPST_LAUNCH_CHECK();
 }
@@ -368,7 +395,7 @@ extern "C" int ppst_colsum(const void* x, void* out, void* ws, int64_t rows, int
     PPST_LAUNCH(colsum_partial_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), (const float*)x, (float*)ws, rows, C, ld, (int64_t)2048);
   int e = PPST_LAUNCH_CHECK();
   if (e) return e;
-  PPST_LAUNCH(sum_blocks_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), (const float*)ws, (float*)out, nblocks, (int64_t)C,
+  PPST_LAUNCH(sum_blocks_kernel, dim3(cdiv(C, 32)), dim3(256), 0, as_stream(stream), (const float*)ws, (float*)out, nblocks, (int64_t)C,
               scale, accumulate);
   return PPST_LAUNCH_CHECK();
 }
@@ -494,51 +521,23 @@ extern "C" int ppst_l1_mean(const void* a, const void* b, void* out, void* ws, i
 // rsclLoss.forward (networks/rscl.py:42-64) for n <= 64 query rows of dimension C: row i's logits are
 // [ q_i . k_i | n current-batch entries, all -10 (the reference's eye(1) mask broadcasts over the whole block) |
 //   q_i . queue[:, j], j < K | q_i . k0_j, j < n0 ] / T ; loss = mean_i( logsumexp_i - logit_i0 ).
-// One block per row; thread j owns negative column j (queue is [C][K]: coalesced over j).
-__global__ __launch_bounds__(256) void rscl_rows_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ k0,
-                                                        const float* __restrict__ queue, float* __restrict__ row_loss, int n, int n0, int C,
-                                                        int K, float invT) {
-  __shared__ float red[256];
-  __shared__ float s_pos, s_max;
+// One 1024-thread block per row (rscl_common.h): thread = (negative column j, quarter of the C reduction), four
+// independent accumulators -- round 1/2's 256-thread form walked 2048 dependent L2 loads per thread (0.5-0.7 ms per row).
+#include "rscl_common.h"
+__global__ __launch_bounds__(RS_T) void rscl_rows_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ k0,
+                                                         const float* __restrict__ queue, float* __restrict__ row_loss, int n, int n0, int C,
+                                                         int K, float invT) {
+  __shared__ RsclShared sh;
   const int i = blockIdx.x, t = threadIdx.x;
-  const float* qi = q + (int64_t)i * C;
-  // positive
-  float p = 0.f;
-  for (int c = t; c < C; c += 256) p += qi[c] * k[(int64_t)i * C + c];
-  red[t] = p;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
-  if (t == 0) s_pos = red[0] * invT;
-  __syncthreads();
-  // negatives owned by this thread (columns t, t+256, ... of [queue | k0])
-  float lmax = fmaxf(s_pos, -10.0f * invT), lsum = 0.f;
-  float mine[2];
-  int cnt = 0;
-  for (int j = t; j < K + n0 && cnt < 2; j += 256, ++cnt) {
-    float d = 0.f;
-    if (j < K) for (int c = 0; c < C; ++c) d += qi[c] * queue[(int64_t)c * K + j];
-    else { const float* kj = k0 + (int64_t)(j - K) * C; for (int c = 0; c < C; ++c) d += qi[c] * kj[c]; }
-    mine[cnt] = d * invT;
-    lmax = fmaxf(lmax, mine[cnt]);
-  }
-  red[t] = lmax;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] = fmaxf(red[t], red[t + o]); __syncthreads(); }
-  if (t == 0) s_max = red[0];
-  __syncthreads();
-  const float m = s_max;
-  for (int c2 = 0; c2 < cnt; ++c2) lsum += expf(mine[c2] - m);
-  if (t == 0) lsum += expf(s_pos - m) + (float)n * expf(-10.0f * invT - m);
-  red[t] = lsum;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
-  if (t == 0) row_loss[i] = (logf(red[0]) + m) - s_pos;
+  float s_pos, m, ssum;
+  rscl_logits(q + (int64_t)i * C, k + (int64_t)i * C, k0, queue, n, n0, C, K, invT, sh, s_pos, m, ssum);
+  if (t == 0) row_loss[i] = (logf(ssum) + m) - s_pos;
 }
 extern "C" int ppst_rscl_loss(const void* q, const void* k, const void* k0, const void* queue, void* out, void* ws, int n, int n0, int C,
                               int K, float nce_T, void* stream) {
   if (n <= 0 || n > 64 || n0 < 0 || C <= 0 || K <= 0 || K + n0 > 512 || nce_T <= 0.f) return PPST_EINVAL;
   if (!q || !k || !queue || !out || !ws || (n0 > 0 && !k0)) return PPST_ENULL;
-  PPST_LAUNCH(rscl_rows_kernel, dim3(n), dim3(256), 0, as_stream(stream), (const float*)q, (const float*)k, (const float*)k0,
+  PPST_LAUNCH(rscl_rows_kernel, dim3(n), dim3(RS_T), 0, as_stream(stream), (const float*)q, (const float*)k, (const float*)k0,
               (const float*)queue, (float*)ws, n, n0, C, K, 1.0f / nce_T);
   int e = PPST_LAUNCH_CHECK();
   if (e) return e;

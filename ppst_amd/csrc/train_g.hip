@@ -321,11 +321,64 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
     atomicAdd(base + ((int64_t)y1 * W + x1) * dx_ld, ly * lx * gv);
   }
 }
+// Gather form (C % 4 == 0, 16-B aligned rows): one thread = 4 channels of one INPUT pixel; it walks the output pixels whose
+// 2x2 footprint can touch it (a generous index window; each tap re-derives the forward's (y0, y1, ly) and takes the weight
+// that lands on this pixel), in a fixed order: no atomics, bit-reproducible, and the 4 x over-read of dy stays in L2.
+// (The scatter form above cost 0.3 ms per launch on the x8 / x4 upsamplings of the train step.)
+__global__ __launch_bounds__(256) void bilinear_bwd_gather_kernel(const float4* __restrict__ dy, float4* __restrict__ dx, int H, int W,
+                                                                  int C4, int OH, int OW, int dy_ld4, int dx_ld4, float sy, float sx,
+                                                                  unsigned total, FastDiv d_c, FastDiv d_w, FastDiv d_h) {
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned c4, xx, yy;
+    unsigned r = fd_divmod((unsigned)t64, d_c, c4);
+    r = fd_divmod(r, d_w, xx);
+    const unsigned b = fd_divmod(r, d_h, yy);
+    const int y = (int)yy, x = (int)xx;
+    // output rows / columns whose source coordinate lies in (y - 1, y + 1): o in ((y - 0.5) / s - 0.5, (y + 1.5) / s - 0.5)
+    int oy_lo = (int)floorf(((float)y - 0.5f) / sy - 0.5f) - 1, oy_hi = (int)ceilf(((float)y + 1.5f) / sy - 0.5f) + 1;
+    int ox_lo = (int)floorf(((float)x - 0.5f) / sx - 0.5f) - 1, ox_hi = (int)ceilf(((float)x + 1.5f) / sx - 0.5f) + 1;
+    if (y == 0) oy_lo = 0;                       // the clamp fy = max(., 0) sends every row above to y0 = 0
+    if (x == 0) ox_lo = 0;
+    oy_lo = max(oy_lo, 0); ox_lo = max(ox_lo, 0); oy_hi = min(oy_hi, OH - 1); ox_hi = min(ox_hi, OW - 1);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      const float fy = fmaxf(((float)oy + 0.5f) * sy - 0.5f, 0.f);
+      const int y0 = min((int)fy, H - 1), y1 = y0 + (y0 < H - 1);
+      const float ly = fy - (float)y0;
+      const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+      if (wy == 0.f) continue;
+      const float4* row = dy + (((int64_t)b * OH + oy) * OW) * dy_ld4 + c4;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const float fx = fmaxf(((float)ox + 0.5f) * sx - 0.5f, 0.f);
+        const int x0 = min((int)fx, W - 1), x1 = x0 + (x0 < W - 1);
+        const float lx = fx - (float)x0;
+        const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+        if (wx == 0.f) continue;
+        const float4 g = row[(int64_t)ox * dy_ld4];
+        // the forward's four products hy*hx, hy*lx, ly*hx, ly*lx: when both corners of an axis clamp onto this pixel their
+        // weights add (1 - l) + l; the scatter form adds the two products separately -- equal to rounding
+        const float w = wy * wx;
+        acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
+      }
+    }
+    float4* d = dx + (((int64_t)b * H + y) * W + x) * dx_ld4 + c4;
+    const float4 p = *d;
+    *d = make_float4(p.x + acc.x, p.y + acc.y, p.z + acc.z, p.w + acc.w);
+  }
+}
 extern "C" int ppst_bilinear_bwd(const void* dy, void* dx, int B, int H, int W, int C, int dx_ld, int OH, int OW, int dy_ld,
                                  void* stream) {
   if (B < 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || dx_ld < C || dy_ld < C) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!dy || !dx) return PPST_ENULL;
+  if (C % 4 == 0 && dx_ld % 4 == 0 && dy_ld % 4 == 0 && (((uintptr_t)dy | (uintptr_t)dx) % 16) == 0 &&
+      (int64_t)B * H * W * (C / 4) <= PPST_IDX32_MAX) {
+    const int64_t t4 = (int64_t)B * H * W * (C / 4);
+    PPST_LAUNCH(bilinear_bwd_gather_kernel, dim3(tg_grid(t4)), dim3(256), 0, as_stream(stream), (const float4*)dy, (float4*)dx, H, W,
+                C / 4, OH, OW, dy_ld / 4, dx_ld / 4, (float)H / (float)OH, (float)W / (float)OW, (unsigned)t4,
+                make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)W), make_fastdiv((unsigned)H));
+    return PPST_LAUNCH_CHECK();
+  }
   const int64_t total = (int64_t)B * OH * OW * C;
   if (total > PPST_IDX32_MAX) return PPST_EINVAL;
   PPST_LAUNCH(bilinear_bwd_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)dy, (float*)dx, H, W, C, OH, OW,
@@ -392,6 +445,46 @@ __global__ __launch_bounds__(256) void gap_gmp_bwd_kernel(const float* __restric
     *d = accumulate ? *d + o : o;
   }
 }
+// 16-B forms of the two passes (C % 4 == 0, 16-B aligned rows): one thread = 4 channels of one pixel
+__global__ __launch_bounds__(256) void gmp_argmax4_kernel(const float4* __restrict__ x, const float* __restrict__ mask,
+                                                          const float* __restrict__ v, int* __restrict__ arg, unsigned hw, int C, int ld4,
+                                                          unsigned total, FastDiv d_c4, FastDiv d_hw) {
+  const int c4n = C >> 2;
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned c4;
+    const unsigned bpu = fd_divmod((unsigned)t64, d_c4, c4);
+    const unsigned b = fd_div(bpu, d_hw);
+    const float m = mask ? mask[bpu] : 1.f;
+    const float4 xv = x[(int64_t)bpu * ld4 + c4];
+    const float4 mv = *(const float4*)(v + (int64_t)b * 2 * C + C + c4 * 4);
+    int* ap = arg + (int64_t)b * C + c4 * 4;
+    const int pix = (int)(bpu - b * hw);
+    if (xv.x * m == mv.x) atomicMin(ap, pix);
+    if (xv.y * m == mv.y) atomicMin(ap + 1, pix);
+    if (xv.z * m == mv.z) atomicMin(ap + 2, pix);
+    if (xv.w * m == mv.w) atomicMin(ap + 3, pix);
+    (void)c4n;
+  }
+}
+__global__ __launch_bounds__(256) void gap_gmp_bwd4_kernel(const float* __restrict__ mask, const int* __restrict__ arg,
+                                                           const float* __restrict__ g, float4* __restrict__ dx, unsigned hw, int C,
+                                                           int accumulate, unsigned total, FastDiv d_c4, FastDiv d_hw) {
+  const float invP = 1.f / (float)hw;
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned c4;
+    const unsigned bpu = fd_divmod((unsigned)t64, d_c4, c4);
+    const unsigned b = fd_div(bpu, d_hw);
+    const float m = mask ? mask[bpu] : 1.f;
+    const int pix = (int)(bpu - b * hw);
+    const int4 ar = *(const int4*)(arg + (int64_t)b * C + c4 * 4);
+    const float4 ga = *(const float4*)(g + (int64_t)b * 2 * C + c4 * 4), gm = *(const float4*)(g + (int64_t)b * 2 * C + C + c4 * 4);
+    float4 o = make_float4(m * (ga.x * invP + (pix == ar.x ? gm.x : 0.f)), m * (ga.y * invP + (pix == ar.y ? gm.y : 0.f)),
+                           m * (ga.z * invP + (pix == ar.z ? gm.z : 0.f)), m * (ga.w * invP + (pix == ar.w ? gm.w : 0.f)));
+    float4* d = dx + (int64_t)bpu * (C >> 2) + c4;
+    if (accumulate) { const float4 p = *d; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+    *d = o;
+  }
+}
 extern "C" int ppst_gap_gmp_bwd(const void* x, const void* mask, const void* v, const void* g, void* dx, void* arg_ws, int B,
                                 int64_t hw, int C, int ld, int accumulate, void* stream) {
   if (B < 0 || hw <= 0 || hw > 0x7fffffffll || C <= 0 || ld < C) return PPST_EINVAL;
@@ -401,6 +494,15 @@ extern "C" int ppst_gap_gmp_bwd(const void* x, const void* mask, const void* v, 
   if (total > PPST_IDX32_MAX) return PPST_EINVAL;
   hipError_t e = hipMemsetAsync(arg_ws, 0x7f, (size_t)B * C * sizeof(int), as_stream(stream));   // 0x7f7f7f7f: above any pixel index
   if (e != hipSuccess) return (int)e;
+  if (C % 4 == 0 && ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)v | (uintptr_t)g | (uintptr_t)dx | (uintptr_t)arg_ws) % 16) == 0) {
+    const int64_t t4 = total / 4;
+    PPST_LAUNCH(gmp_argmax4_kernel, dim3(tg_grid(t4)), dim3(256), 0, as_stream(stream), (const float4*)x, (const float*)mask,
+                (const float*)v, (int*)arg_ws, (unsigned)hw, C, ld / 4, (unsigned)t4, make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)hw));
+    PPST_LAUNCH(gap_gmp_bwd4_kernel, dim3(tg_grid(t4)), dim3(256), 0, as_stream(stream), (const float*)mask, (const int*)arg_ws,
+                (const float*)g, (float4*)dx, (unsigned)hw, C, accumulate, (unsigned)t4, make_fastdiv((unsigned)(C / 4)),
+                make_fastdiv((unsigned)hw));
+    return PPST_LAUNCH_CHECK();
+  }
   PPST_LAUNCH(gmp_argmax_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)mask,
               (const float*)v, (int*)arg_ws, (unsigned)hw, C, ld, (unsigned)total, make_fastdiv((unsigned)C), make_fastdiv((unsigned)hw));
   PPST_LAUNCH(gap_gmp_bwd_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)mask, (const int*)arg_ws,
@@ -634,60 +736,35 @@ extern "C" int ppst_scale_by(const void* x, const void* s, void* y, int64_t n, v
 // --------------------------------------------------------- rsclLoss backward --
 // d(mean_i CE(logits_i, 0))/dq (networks/rscl.py:42-64; keys, queue detached; the current-batch logits are the constant
 // -10 of the reference's eye(1) mask): dq_i = g/(n*T) * [ (p_pos - 1) k_i + sum_j p_j key_j ],  key_j = queue[:, j] | k0_j.
-__global__ __launch_bounds__(256) void rscl_rows_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                            const float* __restrict__ k0, const float* __restrict__ queue,
-                                                            const float* __restrict__ gout, float* __restrict__ dq, int n, int n0,
-                                                            int C, int K, float invT) {
-  __shared__ float red[256];
-  __shared__ float prob[512];
-  __shared__ float s_pos, s_max, s_sum;
+#include "rscl_common.h"
+__global__ __launch_bounds__(RS_T) void rscl_rows_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                             const float* __restrict__ k0, const float* __restrict__ queue,
+                                                             const float* __restrict__ gout, float* __restrict__ dq, int n, int n0,
+                                                             int C, int K, float invT) {
+  __shared__ RsclShared sh;
   const int i = blockIdx.x, t = threadIdx.x;
-  const float* qi = q + (int64_t)i * C;
-  float p = 0.f;
-  for (int c = t; c < C; c += 256) p += qi[c] * k[(int64_t)i * C + c];
-  red[t] = p;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
-  if (t == 0) s_pos = red[0] * invT;
-  __syncthreads();
-  float lmax = fmaxf(s_pos, -10.0f * invT);
-  for (int j = t; j < K + n0; j += 256) {
-    float d = 0.f;
-    if (j < K) for (int c = 0; c < C; ++c) d += qi[c] * queue[(int64_t)c * K + j];
-    else { const float* kj = k0 + (int64_t)(j - K) * C; for (int c = 0; c < C; ++c) d += qi[c] * kj[c]; }
-    prob[j] = d * invT;
-    lmax = fmaxf(lmax, prob[j]);
-  }
-  red[t] = lmax;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] = fmaxf(red[t], red[t + o]); __syncthreads(); }
-  if (t == 0) s_max = red[0];
-  __syncthreads();
-  const float m = s_max;
-  float lsum = 0.f;
-  for (int j = t; j < K + n0; j += 256) { prob[j] = expf(prob[j] - m); lsum += prob[j]; }
-  if (t == 0) lsum += expf(s_pos - m) + (float)n * expf(-10.0f * invT - m);
-  red[t] = lsum;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
-  if (t == 0) s_sum = red[0];
-  __syncthreads();
-  const float inv_sum = 1.f / s_sum;
+  float s_pos, m, ssum;
+  rscl_logits(q + (int64_t)i * C, k + (int64_t)i * C, k0, queue, n, n0, C, K, invT, sh, s_pos, m, ssum);
+  const float inv_sum = 1.f / ssum;
   const float ppos = expf(s_pos - m) * inv_sum;
   const float f = gout[0] * invT / (float)n;
-  for (int c = t; c < C; c += 256) {
-    float acc = (ppos - 1.f) * k[(int64_t)i * C + c];
+  for (int c = t; c < C; c += RS_T) {           // thread = channel: its queue row is contiguous (K floats)
     const float* qr = queue + (int64_t)c * K;
-    for (int j = 0; j < K; ++j) acc += prob[j] * inv_sum * qr[j];
-    for (int j = 0; j < n0; ++j) acc += prob[K + j] * inv_sum * k0[(int64_t)j * C + c];
-    dq[(int64_t)i * C + c] = f * acc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int j = 0;
+    for (; j + 3 < K; j += 4) {
+      a0 += sh.prob[j] * qr[j]; a1 += sh.prob[j + 1] * qr[j + 1]; a2 += sh.prob[j + 2] * qr[j + 2]; a3 += sh.prob[j + 3] * qr[j + 3];
+    }
+    for (; j < K; ++j) a0 += sh.prob[j] * qr[j];
+    for (int j2 = 0; j2 < n0; ++j2) a1 += sh.prob[K + j2] * k0[(int64_t)j2 * C + c];
+    dq[(int64_t)i * C + c] = f * ((ppos - 1.f) * k[(int64_t)i * C + c] + ((a0 + a1) + (a2 + a3)) * inv_sum);
   }
 }
 extern "C" int ppst_rscl_loss_bwd(const void* q, const void* k, const void* k0, const void* queue, const void* gout, void* dq, int n,
                                   int n0, int C, int K, float nce_T, void* stream) {
   if (n <= 0 || n > 64 || n0 < 0 || C <= 0 || K <= 0 || K + n0 > 512 || nce_T <= 0.f) return PPST_EINVAL;
   if (!q || !k || !queue || !gout || !dq || (n0 > 0 && !k0)) return PPST_ENULL;
-  PPST_LAUNCH(rscl_rows_bwd_kernel, dim3(n), dim3(256), 0, as_stream(stream), (const float*)q, (const float*)k, (const float*)k0,
+  PPST_LAUNCH(rscl_rows_bwd_kernel, dim3(n), dim3(RS_T), 0, as_stream(stream), (const float*)q, (const float*)k, (const float*)k0,
               (const float*)queue, (const float*)gout, (float*)dq, n, n0, C, K, 1.0f / nce_T);
   return PPST_LAUNCH_CHECK();
 }

@@ -209,6 +209,36 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic(const float* __restrict
   }
 }
 
+// ---- up2: minor % 4 == 0, up == 2, down == 1 (the adjoint of the decimating blur: zero-insert x2, FIR, crop) ------------
+// One thread = 4 channels of one output pixel; only the taps whose upsampled coordinate is even touch an input sample
+// (at most ceil(K/2)^2 of them).  32-bit index math with multiplier division (the generic kernel's int64 % and / cost
+// ~100 instructions per element: 0.11 ms per launch in the train step).
+__global__ __launch_bounds__(256) void upfirdn2d_up2_chan(const float4* __restrict__ x, float4* __restrict__ y, UfParams p, unsigned total,
+                                                          FastDiv d_c, FastDiv d_w, FastDiv d_h) {
+  const int c4n = p.minor >> 2;
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned c4, oxu, oyu;
+    unsigned r = fd_divmod((unsigned)t64, d_c, c4);
+    r = fd_divmod(r, d_w, oxu);
+    const int m = (int)fd_divmod(r, d_h, oyu);
+    const int ox = (int)oxu, oy = (int)oyu;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ky = 0; ky < p.kh; ++ky) {
+      const int Y = oy + ky - p.pad_y0;
+      if (Y < 0 || (Y & 1) || (Y >> 1) >= p.in_h) continue;
+      const float4* row = x + ((int64_t)m * p.in_h + (Y >> 1)) * p.in_w * c4n + c4;
+      for (int kx = 0; kx < p.kw; ++kx) {
+        const int X = ox + kx - p.pad_x0;
+        if (X < 0 || (X & 1) || (X >> 1) >= p.in_w) continue;
+        const float4 v = row[(int64_t)(X >> 1) * c4n];
+        const float f = p.k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+        acc.x += v.x * f; acc.y += v.y * f; acc.z += v.z * f; acc.w += v.w * f;
+      }
+    }
+    y[(((int64_t)m * p.out_h + oy) * p.out_w + ox) * c4n + c4] = acc;
+  }
+}
+
 template <int KH, int KW>
 static int launch_chan(const float* x, float* y, const UfParams& p, int down, bool s2d, hipStream_t st) {
   const int eh = s2d ? ((p.out_h + 1) & ~1) : p.out_h, ew = s2d ? ((p.out_w + 1) & ~1) : p.out_w;
@@ -265,6 +295,14 @@ extern "C" int ppst_upfirdn2d(const void* x, const void* k, void* y, int major, 
   if (down2 && kh == 3) return launch_chan<3, 3>(xf, yf, p, 2, false, st);
   if (down2 && kh == 4) return launch_chan<4, 4>(xf, yf, p, 2, false, st);
   int64_t n = (int64_t)major * p.out_h * p.out_w * minor;
+  if (up_x == 2 && up_y == 2 && down_x == 1 && down_y == 1 && minor % 4 == 0 && n / 4 <= PPST_IDX32_MAX &&
+      (((uintptr_t)x | (uintptr_t)y) % 16) == 0) {
+    int64_t b4 = cdiv64(n / 4, 256);
+    if (b4 > 256 * 32) b4 = 256 * 32;
+    PPST_LAUNCH(upfirdn2d_up2_chan, dim3((unsigned)b4), dim3(256), 0, st, (const float4*)xf, (float4*)yf, p, (unsigned)(n / 4),
+                make_fastdiv((unsigned)(minor / 4)), make_fastdiv((unsigned)p.out_w), make_fastdiv((unsigned)p.out_h));
+    return PPST_LAUNCH_CHECK();
+  }
   int64_t blocks = cdiv64(n, 256);
   if (blocks > 256 * 32) blocks = 256 * 32;
   PPST_LAUNCH(upfirdn2d_generic, dim3((unsigned)blocks), dim3(256), 0, st, xf, yf, p, n);
