@@ -332,6 +332,11 @@ int ppst_smooth_local_affine(const void* output, const void* input, void* result
 int ppst_conv_wgrad_f32(const void* x, const void* dy, const void* steps, const void* chunk_start,
                         void* partial, int B, int in_h, int in_w, int in_ld, int oh, int ow,
                         int dy_ld, int cout, int nsteps, int nchunks, int splits, void* stream);
+/* the same gradient on the bf16 matrix pipe, fp32-class through the hi/lo split of both operands (the production path;
+ * ppst_conv_wgrad_f32 stays the exact verification path).  Same arguments; rows must be 16-B aligned, taps in [-1,1]^2. */
+int ppst_conv_wgrad_bf16x3(const void* x, const void* dy, const void* steps, const void* chunk_start,
+                           void* partial, int B, int in_h, int in_w, int in_ld, int oh, int ow,
+                           int dy_ld, int cout, int nsteps, int nchunks, int splits, void* stream);
 /* dw[n*sn + (src_c+k)*sc + ky*sy + kx*sx] (+)= scale * sum_splits partial[.][step][n][k] */
 int ppst_wgrad_scatter(const void* partial, const void* src_c, const void* src_ky, const void* src_kx,
                        void* dw, int64_t sn, int64_t sc, int64_t sy, int64_t sx, int cout, int nsteps,

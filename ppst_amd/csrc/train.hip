@@ -184,6 +184,153 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_lds_kernel(const float* __r
   }
 }
 
+// bf16x3 weight gradient (round 2): the same partial layout, step tables and tiling as conv_wgrad_lds_kernel, on the bf16
+// matrix pipe (v_mfma_f32_32x32x16_bf16: 5.3x the fp32 MFMA's rate after the three passes of the hi/lo split).  The
+// reduction index of this GEMM is the PIXEL, so an MFMA operand lane needs 8 consecutive pixels of one channel: the staging
+// pass converts fp32 -> bf16 hi / lo and packs PIXEL PAIRS (x even, x odd) of one channel into a dword, laid out
+// [pair][channel]; a fragment is then 4 conflict-free ds_read_b32.  The input tile is kept twice -- pairs starting at an odd
+// and at an even column -- so that the dx = -1 / 0 / +1 taps all find their pixel pairs aligned.  67 KB of LDS, two blocks per
+// CU.  Rounding: every product carries the 2^-17 relative error of the split, the sums are the MFMA's fp32 accumulation as
+// before (the discriminator / generator gradient bars of tests/ are 5e-3).
+#define WX_ROWS (WG_TR + 2)
+#define WX_PAIRS (WG_TC / 2 + 1)
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const int4* __restrict__ steps, const int* __restrict__ chunk_start,
+                                                             float* __restrict__ partial, int B, int in_h, int in_w, int in_ld,
+                                                             int oh, int ow, int dy_ld, int cout, int nsteps, int tiles_x,
+                                                             int tiles_per_image, int tiles_total, int tiles_per_split) {
+  // [hi | lo][pixel pair][channel]
+  __shared__ __attribute__((aligned(16))) unsigned sdy[2][WG_TR * WG_TC / 2][128];
+  __shared__ __attribute__((aligned(16))) unsigned sx[2][2][WX_ROWS * WX_PAIRS][32];     // [hi|lo][copy A (odd start) | B (even start)]
+  typedef unsigned __attribute__((ext_vector_type(4))) u4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, kb = lane >> 5;
+  const int n0 = blockIdx.x * 128;
+  const int s0 = chunk_start[blockIdx.y], s1 = chunk_start[blockIdx.y + 1];
+  const int T = s1 - s0;
+  const int chan = steps[s0].x;
+  int tdy[WG_MAXT], tdx[WG_MAXT];
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t) {
+    int4 d = steps[s0 + (t < T ? t : 0)];
+    tdy[t] = d.y; tdx[t] = d.z;
+  }
+  f32x16 acc[WG_MAXT];
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  const int t_begin = blockIdx.z * tiles_per_split;
+  const int t_end = min(t_begin + tiles_per_split, tiles_total);
+  const bool wave_live = n0 + wave * 32 < cout;
+  auto pack2 = [](float a, float b, unsigned& hi, unsigned& lo) {
+    unsigned short ah, al, bh, bl;
+    split_bf16(a, ah, al);
+    split_bf16(b, bh, bl);
+    hi = (unsigned)ah | ((unsigned)bh << 16);
+    lo = (unsigned)al | ((unsigned)bl << 16);
+  };
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int b = tile / tiles_per_image;
+    const int r = tile - b * tiles_per_image;
+    const int ty0 = (r / tiles_x) * WG_TR, tx0 = (r - (r / tiles_x) * tiles_x) * WG_TC;
+    __syncthreads();                                       // previous tile's reads are done
+    // dY: pairs (x, x+1), x even, of the 2 x 32-pixel tile; 4 channels per thread-item
+    for (int i = tid; i < (WG_TR * WG_TC / 2) * 32; i += 256) {
+      const int q = i & 31, pr = i >> 5;
+      const int y = ty0 + pr / (WG_TC / 2), xx = tx0 + (pr % (WG_TC / 2)) * 2;
+      const int n = n0 + q * 4;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (y < oh && n < cout) {
+        const float* p = dy + (((int64_t)b * oh + y) * ow + xx) * dy_ld + n;
+        if (xx < ow) v0 = *(const float4*)p;
+        if (xx + 1 < ow) v1 = *(const float4*)(p + dy_ld);
+      }
+      unsigned h[4], l[4];
+      pack2(v0.x, v1.x, h[0], l[0]); pack2(v0.y, v1.y, h[1], l[1]); pack2(v0.z, v1.z, h[2], l[2]); pack2(v0.w, v1.w, h[3], l[3]);
+      *(u4*)&sdy[0][pr][q * 4] = (u4){h[0], h[1], h[2], h[3]};
+      *(u4*)&sdy[1][pr][q * 4] = (u4){l[0], l[1], l[2], l[3]};
+    }
+    // input halo tile, rows ty0 - 1 .. ty0 + 2: copy A pairs (tx0 + 2j - 1, tx0 + 2j), copy B pairs (tx0 + 2j, tx0 + 2j + 1)
+    for (int i = tid; i < 2 * WX_ROWS * WX_PAIRS * 8; i += 256) {
+      const int q = i & 7;
+      int rest = i >> 3;
+      const int j = rest % WX_PAIRS; rest /= WX_PAIRS;
+      const int row = rest % WX_ROWS, copy = rest / WX_ROWS;
+      const int iy = ty0 - 1 + row, ix = tx0 + 2 * j - (copy == 0 ? 1 : 0);
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (iy >= 0 && iy < in_h) {
+        const float* p = x + (((int64_t)b * in_h + iy) * in_w + ix) * in_ld + chan + q * 4;
+        if (ix >= 0 && ix < in_w) v0 = *(const float4*)p;
+        if (ix + 1 >= 0 && ix + 1 < in_w) v1 = *(const float4*)(p + in_ld);
+      }
+      unsigned h[4], l[4];
+      pack2(v0.x, v1.x, h[0], l[0]); pack2(v0.y, v1.y, h[1], l[1]); pack2(v0.z, v1.z, h[2], l[2]); pack2(v0.w, v1.w, h[3], l[3]);
+      *(u4*)&sx[0][copy][row * WX_PAIRS + j][q * 4] = (u4){h[0], h[1], h[2], h[3]};
+      *(u4*)&sx[1][copy][row * WX_PAIRS + j][q * 4] = (u4){l[0], l[1], l[2], l[3]};
+    }
+    __syncthreads();
+    if (wave_live) {
+#pragma unroll
+      for (int ks = 0; ks < WG_TR * WG_TC / 16; ++ks) {      // 16 pixels of one tile row per MFMA
+        const int row = ks / (WG_TC / 16), xh = (ks % (WG_TC / 16)) * 16;
+        const int pa = row * (WG_TC / 2) + xh / 2 + kb * 4;
+        u4 ah, al;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ah[e] = sdy[0][pa + e][wave * 32 + li]; al[e] = sdy[1][pa + e][wave * 32 + li]; }
+        const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah), a_l = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+        for (int t = 0; t < WG_MAXT; ++t) {
+          if (t < T) {
+            const int copy = tdx[t] == 0 ? 1 : 0;
+            const int pj = (row + 1 + tdy[t]) * WX_PAIRS + xh / 2 + kb * 4 + (tdx[t] == 1 ? 1 : 0);
+            u4 bh, bl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bh[e] = sx[0][copy][pj + e][li]; bl[e] = sx[1][copy][pj + e][li]; }
+            const bf16x8 b_h = __builtin_bit_cast(bf16x8, bh), b_l = __builtin_bit_cast(bf16x8, bl);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b_h, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_l, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_h, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  if (!wave_live) return;
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t) {
+    if (t < T) {
+      float* o = partial + (((int64_t)blockIdx.z * nsteps + s0 + t) * cout) * 32;
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        int nn = n0 + wave * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kb;
+        if (nn < cout) o[(int64_t)nn * 32 + li] = acc[t][rg];
+      }
+    }
+  }
+}
+
+// same contract as ppst_conv_wgrad_f32 (which stays the exact-fp32 path of precision 2); needs the 16-B aligned rows every
+// caller on the train path has, taps in [-1, 1]^2 (every step table of the path)
+extern "C" int ppst_conv_wgrad_bf16x3(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial,
+                                      int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
+                                      int nchunks, int splits, void* stream) {
+  if (B < 0 || in_h <= 0 || in_w <= 0 || in_ld <= 0 || oh <= 0 || ow <= 0 || dy_ld < cout || cout <= 0 || nsteps <= 0 ||
+      nchunks <= 0 || splits <= 0)
+    return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !dy || !steps || !chunk_start || !partial) return PPST_ENULL;
+  if (cout % 4 || dy_ld % 4 || in_ld % 4 || ((uintptr_t)x | (uintptr_t)dy) % 16) return PPST_EINVAL;
+  const int tiles_x = cdiv(ow, WG_TC), tiles_per_image = cdiv(oh, WG_TR) * tiles_x;
+  const int tiles_total = B * tiles_per_image;
+  const int tps = cdiv(tiles_total, splits);
+  dim3 grid(cdiv(cout, 128), nchunks, splits);
+  PPST_LAUNCH(conv_wgrad_x3_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (const int4*)steps,
+              (const int*)chunk_start, (float*)partial, B, in_h, in_w, in_ld, oh, ow, dy_ld, cout, nsteps, tiles_x, tiles_per_image,
+              tiles_total, tps);
+  return PPST_LAUNCH_CHECK();
+}
+
 extern "C" int ppst_conv_wgrad_f32(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial,
                                    int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
                                    int nchunks, int splits, void* stream) {

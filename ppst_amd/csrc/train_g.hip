@@ -427,7 +427,9 @@ __global__ __launch_bounds__(256) void gmp_argmax_kernel(const float* __restrict
     const unsigned bpu = fd_divmod((unsigned)t64, d_c, c);
     const unsigned b = fd_div(bpu, d_hw);
     const float m = mask ? mask[bpu] : 1.f;
-    if (x[(int64_t)bpu * ld + c] * m == v[(int64_t)b * 2 * C + C + c]) atomicMin(arg + (int64_t)b * C + c, (int)(bpu - b * hw));
+    int* ap = arg + (int64_t)b * C + c;
+    const int pix = (int)(bpu - b * hw);
+    if (x[(int64_t)bpu * ld + c] * m == v[(int64_t)b * 2 * C + C + c] && pix < *(const volatile int*)ap) atomicMin(ap, pix);
   }
 }
 __global__ __launch_bounds__(256) void gap_gmp_bwd_kernel(const float* __restrict__ mask, const int* __restrict__ arg,
@@ -459,10 +461,14 @@ __global__ __launch_bounds__(256) void gmp_argmax4_kernel(const float4* __restri
     const float4 mv = *(const float4*)(v + (int64_t)b * 2 * C + C + c4 * 4);
     int* ap = arg + (int64_t)b * C + c4 * 4;
     const int pix = (int)(bpu - b * hw);
-    if (xv.x * m == mv.x) atomicMin(ap, pix);
-    if (xv.y * m == mv.y) atomicMin(ap + 1, pix);
-    if (xv.z * m == mv.z) atomicMin(ap + 2, pix);
-    if (xv.w * m == mv.w) atomicMin(ap + 3, pix);
+    // masked pooling makes ties massive (every masked-out pixel is 0 = the maximum of an all-negative channel): read the
+    // current winner first -- a stale value is only larger, so at worst an unnecessary atomic -- instead of 10^5 atomics on
+    // one address
+    const volatile int* cur = ap;
+    if (xv.x * m == mv.x && pix < cur[0]) atomicMin(ap, pix);
+    if (xv.y * m == mv.y && pix < cur[1]) atomicMin(ap + 1, pix);
+    if (xv.z * m == mv.z && pix < cur[2]) atomicMin(ap + 2, pix);
+    if (xv.w * m == mv.w && pix < cur[3]) atomicMin(ap + 3, pix);
     (void)c4n;
   }
 }

@@ -30,6 +30,7 @@ TILE_ROWS = {"value": 16}  # conv tile rows: 8 (2 blocks per CU) or 16 (1 block 
 CONV_VARIANT = {"value": 2}
 DIRECT_MAX = {"cout": 64, "nsteps": 40, "cout3x3": 64}   # cout3x3 = 128 was measured: 128->128 @512^2 230 vs 357 TFLOP/s
 # thin layers (few channels in and out) on the direct form of that kernel
+WGRAD_X3 = {"value": True}         # conv weight gradients on the bf16 matrix pipe (hi/lo split), exact fp32 with precision 2
 STREAM_1X1 = {"value": True}       # 1x1 convs (halo 0) on the streaming kernel of conv1x1.hip
 TWO_BLOCK_128 = {"value": False}   # experiment: variant 3 (see __call__) for the Cout = 128-class layers
 FAT_MIN_BLOCKS = 32         # take the 256-channel tile only when ONE image still gives >= this many blocks (B = 8: one per CU)
@@ -465,8 +466,12 @@ def conv_wgrad(plan, x, dy, splits=None):
         tiles_total = B * ((oh + 1) // 2) * ((ow + 31) // 32)
         splits = max(1, min((1536 + per - 1) // per, max(1, tiles_total // 2), 2048))
     partial = torch.empty((splits, plan.nsteps, cout, 32), device=x.device, dtype=torch.float32)
-    check(lib.ppst_conv_wgrad_f32(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), B, H, W, in_ld, oh, ow, dy_ld,
-                                  cout, plan.nsteps, nchunks, splits, _stream()), "ppst_conv_wgrad_f32")
+    # production: bf16x3 on the bf16 matrix pipe; precision 2 (verification): the exact fp32 MFMA
+    aligned = cout % 4 == 0 and dy_ld % 4 == 0 and in_ld % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
+    fn, name = ((lib.ppst_conv_wgrad_bf16x3, "ppst_conv_wgrad_bf16x3") if (WGRAD_X3["value"] and plan.precision != 2 and aligned)
+                else (lib.ppst_conv_wgrad_f32, "ppst_conv_wgrad_f32"))
+    check(fn(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), B, H, W, in_ld, oh, ow, dy_ld,
+             cout, plan.nsteps, nchunks, splits, _stream()), name)
     # 'dgradT': the plan's "weights" are the blurred 4x4 kernel (Cin,Cout,4,4) of the transposed conv
     shape = plan.w4_shape if plan.kind == "dgradT" else (plan.cout, plan.cin, plan.k, plan.k)
     dw = torch.zeros(shape, device=x.device, dtype=torch.float32)
