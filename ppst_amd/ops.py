@@ -30,6 +30,7 @@ TILE_ROWS = {"value": 16}  # conv tile rows: 8 (2 blocks per CU) or 16 (1 block 
 CONV_VARIANT = {"value": 2}
 DIRECT_MAX = {"cout": 64, "nsteps": 40, "cout3x3": 64}   # cout3x3 = 128 was measured: 128->128 @512^2 230 vs 357 TFLOP/s
 # thin layers (few channels in and out) on the direct form of that kernel
+WGRAD_SPLIT = {"blocks": 1024, "min_tiles": 4}   # conv_wgrad: target block count of a launch, fewest pixel tiles per block
 WGRAD_X3 = {"value": True}         # conv weight gradients on the bf16 matrix pipe (hi/lo split), exact fp32 with precision 2
 STREAM_1X1 = {"value": True}       # 1x1 convs (halo 0) on the streaming kernel of conv1x1.hip
 TWO_BLOCK_128 = {"value": False}   # experiment: variant 3 (see __call__) for the Cout = 128-class layers
@@ -464,7 +465,7 @@ def conv_wgrad(plan, x, dy, splits=None):
         # 64-256 blocks, a third of the chip or less.)
         per = nchunks * ((cout + 127) // 128)
         tiles_total = B * ((oh + 1) // 2) * ((ow + 31) // 32)
-        splits = max(1, min((1536 + per - 1) // per, max(1, tiles_total // 2), 2048))
+        splits = max(1, min((WGRAD_SPLIT["blocks"] + per - 1) // per, max(1, tiles_total // WGRAD_SPLIT["min_tiles"]), 2048))
     partial = torch.empty((splits, plan.nsteps, cout, 32), device=x.device, dtype=torch.float32)
     # production: bf16x3 on the bf16 matrix pipe; precision 2 (verification): the exact fp32 MFMA
     aligned = cout % 4 == 0 and dy_ld % 4 == 0 and in_ld % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
