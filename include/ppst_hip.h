@@ -168,7 +168,19 @@ typedef struct ppst_conv_args {
   int32_t variant;               /* 0: the 8-wave kernel (512 threads, wave tile 64 px x 64 ch; bn 64 / 128).
                                     1: the fat-wave kernel (conv_mfma2.hip: 256 threads = one wave per SIMD, wave tile
                                     128 px x 64 / 128 ch; bn 128 / 256; precision 0 only).  Its activation ring has two
-                                    slots: every chunk of the step table must span >= 2 steps (the early_a promise). */
+                                    slots: every chunk of the step table must span >= 2 steps (the early_a promise).
+                                    2: 8 waves x (128 px x 64 ch), bn = 256 (the production kernel for Cout % 256 == 0);
+                                    3: two 4-wave blocks per CU, bn = 128, one activation slot (experiment) -- both with
+                                    the early_a promise, precision 0.
+                                    4 / 5 / 6 (conv1x1.hip, precision 0, one group, unit output stride, no in_off):
+                                    4: all taps (0,0) (halo 0), bn = 64, in and out extents equal;
+                                    5: any taps in [-1,1]^2, bn = 64;
+                                    6: plain 3x3 stride-1 tables only -- nsteps = 9 * chunks and step 9c + 3(dy+1) + (dx+1)
+                                       is tap (dy, dx) of chunk c; bn = 64, or 128 for Cout in 65..128.  The table lives on
+                                       the device and is not re-read: the CALLER owns this promise (as with a_slots).
+                                    Every variant gives bit-identical outputs; the per-tile statistics differ in the last
+                                    bit between variants (other summation tree).  The library returns PPST_EINVAL for a
+                                    variant whose shape conditions do not hold. */
 } ppst_conv_args;
 
 int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream);
