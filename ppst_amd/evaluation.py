@@ -10,7 +10,10 @@
        image) -- RCCL on the GPU, the only data-path collective of inference (SURVEY.md section 8e);
     3. per-PAIR passes (corrm, encode2, decode + guided filter), pair (i, j) on rank ((i * M + j) mod world), batched.
   An 8 x 8 grid on 8 ranks costs each rank 2 image passes + 8 pair passes (~5.9 TFLOP) against 16 + 64 on one GPU.
-Image file I/O (PIL decode/resize/PNG) is left to the caller: tensors in, tensors out.
+The recipes take and return tensors.  The folder-level front ends at the end of this file (``evaluate_swap_files``,
+``evaluate_grid_folder``) add what the reference's evaluators do around them: decode (PIL, a thread pool), resize + normalise
+on the device (ppst_amd/imageio.py, Pillow-exact), the uint8 quantisation on the device (glue.tensor2im), PNG encode in the
+thread pool (zlib releases the GIL: the encode of one batch overlaps the next batch's kernels), the reference's file names.
 """
 import torch
 
@@ -144,3 +147,91 @@ def swapping_grid(model, contents, styles, rank=0, world=1, smooth=True, pair_ba
     local_c, local_s = grid_image_pass(model, contents, styles, rank, world, image_batch)
     table_c, table_s = grid_exchange(local_c, local_s, contents.shape[0], styles.shape[0], world)
     return grid_pair_pass(model, contents, styles, table_c, table_s, rank, world, smooth, pair_batch)
+
+
+# ------------------------------------------------------------------------------------------------- file front ends
+_IMG_EXT = (".jpg", ".jpeg", ".png", ".bmp", ".webp")
+
+
+def _decode(path):
+    from PIL import Image
+    import numpy as np
+    return np.array(Image.open(path).convert("RGB"))
+
+
+def load_images(paths, load_size=512, device="cuda", pool=None):
+    """data/base_dataset.py:85-171 (scale_shortside + make_power_2 + ToTensor + Normalize) for a list of files: decode on
+    host threads, everything else on the device.  Returns a list of (1,3,H,W) tensors (sizes may differ per file)."""
+    from . import imageio
+    arrs = list(pool.map(_decode, paths)) if pool is not None else [_decode(p) for p in paths]
+    return [imageio.preprocess(torch.from_numpy(a[None]).to(device), load_size) for a in arrs]
+
+
+def _save_png(args):
+    from PIL import Image
+    arr, path = args
+    Image.fromarray(arr).save(path)
+    return path
+
+
+def save_images(images, paths, pool=None):
+    """images: (B,3,H,W) in [-1,1] on the device -> PNG files.  util.tensor2im quantisation (util/util.py:98-131) on the
+    device, one device-to-host copy of the uint8 batch, encode on the pool's threads (returns the futures when a pool is
+    given: the caller overlaps them with the next batch and joins at the end)."""
+    u8 = glue.tensor2im(images).cpu().numpy()
+    jobs = [(u8[i], p) for i, p in enumerate(paths)]
+    if pool is None:
+        return [_save_png(j) for j in jobs]
+    return [pool.submit(_save_png, j) for j in jobs]
+
+
+def evaluate_swap_files(model, structure_path, texture_path, out_dir, alphas=(1.0,), load_size=512, device="cuda"):
+    """evaluation/simple_swapping_evaluator.py:38-76: one structure image, one texture image, one output per mix alpha named
+    <structure>_<texture>_<alpha %.2f>.png (ToPILImage quantisation of the clamped image, :61-62).  Returns the paths."""
+    import os
+    from PIL import Image
+    os.makedirs(out_dir, exist_ok=True)
+    c, s_ = load_images([os.path.expanduser(structure_path), os.path.expanduser(texture_path)], load_size, device)
+    outs = simple_swap(model, c, s_, alphas)
+    stem = lambda p: os.path.splitext(os.path.basename(p))[0]
+    paths = []
+    for alpha in alphas:
+        path = os.path.join(out_dir, "%s_%s_%.2f.png" % (stem(structure_path), stem(texture_path), alpha))
+        Image.fromarray(to_uint8_image(outs[alpha])[0].cpu().numpy()).save(path)
+        paths.append(path)
+    return paths
+
+
+def evaluate_grid_folder(model, dataroot, out_dir, rank=0, world=1, smooth=True, load_size=512, device="cuda", workers=8,
+                         pair_batch=8, image_batch=8):
+    """evaluation/content_style_grid_generation_evaluator.py:36-99 over <dataroot>/content/* and <dataroot>/style/*: every
+    (content, style) pair, guided-filter post-process with the content as guide; files land in <out_dir>/images/ under the
+    reference's names (<content>_<style>.png, the inputs as <name>.png; util/html.py:51-75 -- the HTML index itself is not
+    written).  All images must come out of the preprocessing at one size (the reference batches them the same way).
+    Multi-GPU: every rank reads all inputs (they are small), computes its share (swapping_grid) and writes its own files."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    cdir, sdir = os.path.join(dataroot, "content"), os.path.join(dataroot, "style")
+    ls = lambda d: sorted(os.path.join(d, f) for f in os.listdir(d) if f.lower().endswith(_IMG_EXT))
+    cpaths, spaths = ls(cdir), ls(sdir)
+    if not cpaths or not spaths:
+        raise RuntimeError("need images under %s and %s" % (cdir, sdir))
+    img_dir = os.path.join(out_dir, "images")
+    os.makedirs(img_dir, exist_ok=True)
+    stem = lambda p: os.path.splitext(os.path.basename(p))[0]
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        imgs = load_images(cpaths + spaths, load_size, device, pool)
+        if len({tuple(t.shape) for t in imgs}) != 1:
+            raise RuntimeError("images of different sizes after preprocessing: %s" % sorted({tuple(t.shape[2:]) for t in imgs}))
+        contents, styles = torch.cat(imgs[:len(cpaths)], 0), torch.cat(imgs[len(cpaths):], 0)
+        futures = []
+        if rank == 0:   # the top row / first column of the reference's page: the inputs themselves
+            futures += save_images(torch.cat((contents, styles), 0), [os.path.join(img_dir, stem(p) + ".png") for p in cpaths + spaths], pool)
+        out = swapping_grid(model, contents, styles, rank, world, smooth, pair_batch, image_batch)
+        keys = sorted(out)
+        for k in range(0, len(keys), pair_batch):
+            chunk = keys[k:k + pair_batch]
+            names = [os.path.join(img_dir, "%s_%s.png" % (stem(cpaths[i]), stem(spaths[j]))) for i, j in chunk]
+            futures += save_images(torch.stack([out[ij] for ij in chunk], 0), names, pool)
+        written = [f.result() for f in futures]
+    return written

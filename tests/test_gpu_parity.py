@@ -413,3 +413,47 @@ def test_smooth_filter_local_affine_vs_oracle():
     ref8 = SO.smooth_filter_arrays(a8, c8)
     d = np.abs(pil.astype(int) - ref8.astype(int))
     assert pil.shape == ref8.shape and d.max() <= 1 and (d > 0).mean() <= 1e-3
+
+
+def test_evaluator_folder_front_ends(tmp_path):
+    """The file-level front ends (evaluation.evaluate_grid_folder / evaluate_swap_files): folder layout and file names of the
+    reference's evaluators, threaded PNG I/O; the files decode to exactly the uint8 images the tensor-level recipes give."""
+    import numpy as np
+    from PIL import Image
+    from ppst_amd import evaluation as EV, glue, imageio, weights as W
+    from ppst_amd.ppst_model import create_model
+    dev = torch.device("cuda", 0)
+    root = tmp_path / "data"
+    (root / "content").mkdir(parents=True); (root / "style").mkdir()
+    base = W.synthetic_images(21, 4, size=512)                       # (4,3,512,512) in [-1,1]
+    u8 = ((base.clamp(-1, 1) + 1) * 127.5).to(torch.uint8).permute(0, 2, 3, 1).numpy()
+    names = [("content", "c0.png"), ("content", "c1.jpg"), ("style", "s0.png"), ("style", "s1.png")]
+    for (sub, fn), a in zip(names, u8):
+        Image.fromarray(a).resize((600, 600), Image.BICUBIC).save(str(root / sub / fn))       # not 512: exercises the device resize
+        # (square: the correspondence path of the reference itself only closes at 512 x 512, SURVEY.md section 0)
+    sd = W.make_state_dict(3, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.0)
+    model = create_model(state_dict=sd, device=dev)
+    out_dir = tmp_path / "out"
+    with torch.no_grad():
+        written = EV.evaluate_grid_folder(model, str(root), str(out_dir), load_size=512, workers=4)
+    files = sorted(os.listdir(str(out_dir / "images")))
+    assert files == sorted(["c0.png", "c1.png", "s0.png", "s1.png", "c0_s0.png", "c0_s1.png", "c1_s0.png", "c1_s1.png"]), files
+    assert len(written) == 8
+    # the same pair through the tensor-level recipe
+    cp = [str(root / "content" / "c0.png"), str(root / "content" / "c1.jpg")]
+    sp_ = [str(root / "style" / "s0.png"), str(root / "style" / "s1.png")]
+    with torch.no_grad():
+        imgs = EV.load_images(cp + sp_, 512, dev)
+        contents, styles = torch.cat(imgs[:2], 0), torch.cat(imgs[2:], 0)
+        ref = EV.swapping_grid(model, contents, styles)
+    got = np.asarray(Image.open(str(out_dir / "images" / "c1_s0.png")))
+    want = glue.tensor2im(ref[(1, 0)][None])[0].cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert np.array_equal(np.asarray(Image.open(str(out_dir / "images" / "c0.png"))), glue.tensor2im(contents[0:1])[0].cpu().numpy())
+    # simple_swapping front end: names <structure>_<texture>_<alpha>.png
+    with torch.no_grad():
+        paths = EV.evaluate_swap_files(model, cp[0], sp_[1], str(tmp_path / "swap"), alphas=(0.5, 1.0))
+    assert [os.path.basename(p) for p in paths] == ["c0_s1_0.50.png", "c0_s1_1.00.png"]
+    with torch.no_grad():
+        o = EV.simple_swap(model, imgs[0], imgs[3], (1.0,))[1.0]
+    assert np.array_equal(np.asarray(Image.open(paths[1])), EV.to_uint8_image(o)[0].cpu().numpy())
