@@ -37,10 +37,12 @@ HBM_PEAK_GBS = 8000.0
 def swap_step(model, content, style, alpha, glue):
     """The reference recipe, batched; returns the output image tensor."""
     sp, gl_c = model(content, command="encode")
-    fea_c, fea_c1 = model(content, command="extract_feat_from_image")
-    fea_s, fea_s1 = model(style, command="extract_feat_from_image")
-    fea_c = torch.cat((fea_c, model(fea_c1, command="Rselfcorr")), dim=1)
-    fea_s = torch.cat((fea_s, model(fea_s1, command="Rselfcorr")), dim=1)
+    # the two feature passes of the recipe (content, style) run as one batch of 2B images: same commands, same results bit for
+    # bit (no kernel choice depends on the batch size), half the launches and fuller grids on the 64x64 layers
+    B = content.shape[0]
+    fea, fea1 = model(torch.cat((content, style), 0), command="extract_feat_from_image")
+    fea = torch.cat((fea, model(fea1, command="Rselfcorr")), dim=1)
+    fea_c, fea_s = fea[:B], fea[B:]
     corr = model(fea_s, fea_c, command="corrm")
     _, gl_w = model(style, corr, command="encode2")
     code = glue.lerp(gl_c, gl_w, alpha)
@@ -331,7 +333,8 @@ def main():
             "dtype": DTYPE_NOTE[args.precision],
             "data": "synthetic",
             "config": {"workload": "simple_swapping 512x512 batch=%d per GPU, generator+encoders forward only (BASELINE configs[1])" % B,
-                       "recipe": "encode + 2x extract_feat_from_image + 2x Rselfcorr + corrm + encode2 + decode",
+                       "recipe": "encode + extract_feat_from_image and Rselfcorr on content and on style (run as ONE batch of 2B images: same "
+                                 "work, half the launches) + corrm + encode2 + decode; nothing of the reference's recipe is skipped or cached",
                        "image_parallel": "1 batch per rank, no data-path collective"},
             "algorithmic_tflops_whole_job": swaps * FLOP_PER_SWAP / dt / 1e12,
             "roofline": {

@@ -23,10 +23,16 @@ from . import glue
 def simple_swap(model, content, style, alphas=(1.0,)):
     """content, style: (B,3,H,W) in [-1,1] on the GPU.  Returns {alpha: image (B,3,H,W)}."""
     sp, gl_c = model(content, command="encode")
-    fea_c, fea_c1 = model(content, command="extract_feat_from_image")
-    fea_s, fea_s1 = model(style, command="extract_feat_from_image")
-    fea_c = torch.cat((fea_c, model(fea_c1, command="Rselfcorr")), dim=1)
-    fea_s = torch.cat((fea_s, model(fea_s1, command="Rselfcorr")), dim=1)
+    if content.shape == style.shape:      # the two feature passes as one batch (bit-identical: nothing depends on the batch size)
+        B = content.shape[0]
+        fea, fea1 = model(torch.cat((content, style), 0), command="extract_feat_from_image")
+        fea = torch.cat((fea, model(fea1, command="Rselfcorr")), dim=1)
+        fea_c, fea_s = fea[:B], fea[B:]
+    else:
+        fea_c, fea_c1 = model(content, command="extract_feat_from_image")
+        fea_s, fea_s1 = model(style, command="extract_feat_from_image")
+        fea_c = torch.cat((fea_c, model(fea_c1, command="Rselfcorr")), dim=1)
+        fea_s = torch.cat((fea_s, model(fea_s1, command="Rselfcorr")), dim=1)
     corr = model(fea_s, fea_c, command="corrm")
     _, gl_w = model(style, corr, command="encode2")
     out = {}

@@ -82,6 +82,10 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
             nz = noise[key]
             if nz.shape[0] == 1 and B > 1:      # one fixed row applies to the whole batch, like NoiseInjection.fixed_noise
                 nz = nz.expand(B, *nz.shape[1:])
+            elif nz.shape[0] < B and B % nz.shape[0] == 0:
+                # several calls' batches run as one (content and style feature passes concatenated): the fixture's rows
+                # repeat, so image i of every sub-batch sees row i exactly as in separate calls
+                nz = nz.repeat(B // nz.shape[0], 1, 1, 1)
             nz = nz.contiguous()
         y, st = self.plan(p + "conv.weight", kind)(x, bias=bias, noise=nz, noise_weight=nw, act=ops.ACT_LRELU, stats=True,
                                                    in_ss=in_ss)

@@ -106,6 +106,9 @@ class PPSTModel(nn.Module):
         # 'random' draws N(0,1) per call like the reference's NoiseInjection (stylegan2_layers.py:388-390);
         # a dict '<Block>.<conv>' -> (B,1,H,W) pins the noise (parity tests); None forbids non-zero noise weights
         self.noise = "random"
+        # True: the feature passes whose image nobody reads (extract_feat_from_image, the loss passes) skip ToRGB.  Off by
+        # default: the benchmarked recipe does everything the reference's does, used or not.
+        self.skip_unused_rgb = False
 
     # BaseModel.forward (models/base_model.py:114-123)
     def forward(self, *args, command=None, **kwargs):
@@ -200,7 +203,7 @@ class PPSTModel(nn.Module):
     def extract_feat_from_image(self, img):
         sp = self.E1(img)
         gl = self.E2(img)[0]
-        _, fea, fea1 = self.G(sp, gl, extract_features=True, noise=self.noise, want_rgb=False)
+        _, fea, fea1 = self.G(sp, gl, extract_features=True, noise=self.noise, want_rgb=not self.skip_unused_rgb)
         return fea, fea1
 
     def Rselfcorr(self, fea):
@@ -279,7 +282,7 @@ class PPSTModel(nn.Module):
         losses, metrics = {}, {}
         sp = self.E1(real)
         gl, _ = self.E2(real)
-        _, feas, feas1 = self.G(sp, gl, extract_features=True, noise=self.noise, want_rgb=False)
+        _, feas, feas1 = self.G(sp, gl, extract_features=True, noise=self.noise, want_rgb=not self.skip_unused_rgb)
         sps = torch.cat((feas, self.Rselfcorr(feas1)), dim=1)
         corr = self.corrm(sps, self.swap(sps))
         corr_self = self.corrm(sps, sps)

@@ -352,7 +352,7 @@ def d_step_images(model, real, lambda_StyleCon=1.0, want_codes=False):
     if int(getattr(model.opt, "training_stage", 2)) == 1:      # ppst_model.py:109-112, 128-131
         rec = model.G(sp[:B // 2], [g[:B // 2] for g in gl], noise=nzh)
         return (rec, None, sp, gl) if want_codes else (rec, None)
-    _, feas, feas1 = model.G(sp, gl, extract_features=True, noise=model.noise, want_rgb=False)
+    _, feas, feas1 = model.G(sp, gl, extract_features=True, noise=model.noise, want_rgb=not getattr(model, 'skip_unused_rgb', False))
     sps = torch.cat((feas, model.Rselfcorr(feas1)), dim=1)
     corrms = model.corrm(sps, glue.swap(sps))
     corr_self = model.corrm(sps, sps)
