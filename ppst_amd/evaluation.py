@@ -22,13 +22,17 @@ from . import glue
 
 def simple_swap(model, content, style, alphas=(1.0,)):
     """content, style: (B,3,H,W) in [-1,1] on the GPU.  Returns {alpha: image (B,3,H,W)}."""
-    sp, gl_c = model(content, command="encode")
-    if content.shape == style.shape:      # the two feature passes as one batch (bit-identical: nothing depends on the batch size)
+    if content.shape == style.shape:
+        # the encoder passes of the recipe (encode(content) + the E1 / E2 inside the two extract_feat_from_image) as one batch of
+        # 3B images, the two generator feature passes as one of 2B: the same work, bit-identical (nothing depends on the batch size)
         B = content.shape[0]
-        fea, fea1 = model(torch.cat((content, style), 0), command="extract_feat_from_image")
+        sp3, gl3 = model(torch.cat((content, content, style), 0), command="encode")
+        sp, gl_c = sp3[:B], [g[:B] for g in gl3]
+        _, fea, fea1 = model(sp3[B:], [g[B:] for g in gl3], command="extract_feat")
         fea = torch.cat((fea, model(fea1, command="Rselfcorr")), dim=1)
         fea_c, fea_s = fea[:B], fea[B:]
     else:
+        sp, gl_c = model(content, command="encode")
         fea_c, fea_c1 = model(content, command="extract_feat_from_image")
         fea_s, fea_s1 = model(style, command="extract_feat_from_image")
         fea_c = torch.cat((fea_c, model(fea_c1, command="Rselfcorr")), dim=1)
