@@ -14,6 +14,8 @@ typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+template <int V> struct EpiC { static constexpr int value = V; };   // compile-time tag for the specialised conv epilogues
+
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -61,6 +61,10 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT
   float4 s1[NT], s2[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { s1[nt] = make_float4(0.f, 0.f, 0.f, 0.f); s2[nt] = s1[nt]; }
+  // instantiated per (activation, residual mode), as in conv_mfma.hip / conv_mfma2.hip (same arithmetic, no FMA contraction)
+  auto epi_passes = [&](auto act_c, auto res_c) {
+#pragma clang fp contract(off)
+    constexpr int ACT = decltype(act_c)::value, RES = decltype(res_c)::value;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int p = pbase + mt * 16 + r16;
@@ -73,22 +77,36 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT
       if (n0 >= a.cout) continue;
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), rv = bv;
       if (a.bias) bv = *(const float4*)(a.bias + n0);
-      if (a.residual) rv = *(const float4*)(a.residual + opix * a.res_ld + n0);
+      if (RES) rv = *(const float4*)(a.residual + opix * a.res_ld + n0);
       float o[4] = {acc[mt][nt][0] + bv.x + nz, acc[mt][nt][1] + bv.y + nz, acc[mt][nt][2] + bv.z + nz, acc[mt][nt][3] + bv.w + nz};
       const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         float t = o[c];
-        if (!res_after) t += r4[c];
-        if (act == PPST_ACT_LRELU) t = (t > 0.f ? t : t * 0.2f) * 1.41421356237309515f;
-        else if (act == PPST_ACT_PRELU) t = t >= 0.f ? t : t * slope;
-        if (res_after) t += r4[c];
+        if (RES == 1) t += r4[c];
+        if (ACT == PPST_ACT_LRELU) t = (t > 0.f ? t : t * 0.2f) * 1.41421356237309515f;
+        else if (ACT == PPST_ACT_PRELU) t = t >= 0.f ? t : t * slope;
+        if (RES == 2) t += r4[c];
         o[c] = t * a.out_scale;
       }
       *(float4*)(a.y + opix * a.out_ld + n0) = make_float4(o[0], o[1], o[2], o[3]);
       s1[nt].x += o[0]; s1[nt].y += o[1]; s1[nt].z += o[2]; s1[nt].w += o[3];
       s2[nt].x += o[0] * o[0]; s2[nt].y += o[1] * o[1]; s2[nt].z += o[2] * o[2]; s2[nt].w += o[3] * o[3];
     }
+  }
+  };
+  {
+    const int resm = a.residual ? (res_after ? 2 : 1) : 0;
+#define EPI_GO(A_)                                                                                    \
+  do {                                                                                                \
+    if (resm == 0) epi_passes(EpiC<A_>{}, EpiC<0>{});                                                 \
+    else if (resm == 1) epi_passes(EpiC<A_>{}, EpiC<1>{});                                            \
+    else epi_passes(EpiC<A_>{}, EpiC<2>{});                                                           \
+  } while (0)
+    if (act == PPST_ACT_LRELU) EPI_GO(PPST_ACT_LRELU);
+    else if (act == PPST_ACT_PRELU) EPI_GO(PPST_ACT_PRELU);
+    else EPI_GO(PPST_ACT_NONE);
+#undef EPI_GO
   }
   if (a.stats) {
 #pragma unroll

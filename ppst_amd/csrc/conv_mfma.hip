@@ -475,6 +475,11 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   float* tw = (float*)smem + wave * EPI_TILE;            // main-loop buffers are dead: last barrier passed
   float* red = (float*)smem + (NT / 64) * EPI_TILE;      // [WM][BN][2]
   const int f8 = lane & 7, prow = lane >> 3;
+  // The passes are instantiated per (activation, residual mode): as run-time values they cost ~30 VALU instructions per element
+  // (both activation branches evaluated and selected), ~10 when specialised (conv_mfma2.hip).
+  auto epi_passes = [&](auto act_c, auto res_c) {
+#pragma clang fp contract(off)   // no fused multiply-add here: every kernel family's epilogue must round like the others'
+    constexpr int ACT = decltype(act_c)::value, RES = decltype(res_c)::value;   // RES: 0 none, 1 joins before the activation, 2 after
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -502,16 +507,16 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
         const int64_t opix = ((int64_t)b * a.out_h + oy) * a.out_w + ox;
         float nz = a.noise ? a.noise_weight * a.noise[opix] : 0.f;
         float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.residual) rv = *(const float4*)(a.residual + opix * a.res_ld + n0);
+        if (RES) rv = *(const float4*)(a.residual + opix * a.res_ld + n0);
         float o[4] = {v.x + bv.x + nz, v.y + bv.y + nz, v.z + bv.z + nz, v.w + bv.w + nz};
         const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           float t = o[c];
-          if (!res_after) t += r4[c];
-          if (act == PPST_ACT_LRELU) t = (t > 0.f ? t : t * 0.2f) * 1.41421356237309515f;
-          else if (act == PPST_ACT_PRELU) t = t >= 0.f ? t : t * slope;
-          if (res_after) t += r4[c];
+          if (RES == 1) t += r4[c];
+          if (ACT == PPST_ACT_LRELU) t = (t > 0.f ? t : t * 0.2f) * 1.41421356237309515f;
+          else if (ACT == PPST_ACT_PRELU) t = t >= 0.f ? t : t * slope;
+          if (RES == 2) t += r4[c];
           o[c] = t * a.out_scale;
         }
         *(float4*)(a.y + opix * a.out_ld + n0) = make_float4(o[0], o[1], o[2], o[3]);
@@ -533,6 +538,20 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();  // tile reads done before the next pass overwrites it
+  }
+  };
+  {
+    const int resm = a.residual ? (res_after ? 2 : 1) : 0;
+#define EPI_GO(A_)                                                                                    \
+  do {                                                                                                \
+    if (resm == 0) epi_passes(EpiC<A_>{}, EpiC<0>{});                                                 \
+    else if (resm == 1) epi_passes(EpiC<A_>{}, EpiC<1>{});                                            \
+    else epi_passes(EpiC<A_>{}, EpiC<2>{});                                                           \
+  } while (0)
+    if (act == PPST_ACT_LRELU) EPI_GO(PPST_ACT_LRELU);
+    else if (act == PPST_ACT_PRELU) EPI_GO(PPST_ACT_PRELU);
+    else EPI_GO(PPST_ACT_NONE);
+#undef EPI_GO
   }
   if (a.stats) {
     __syncthreads();

@@ -38,7 +38,28 @@ struct Conv2KArgs {
   const float* in_prelu;
   int in_c, in_act;
   int early_a;
+  unsigned long long* dbg;   // -DPPST_CONV_TRACE builds only
 };
+
+// Diagnostic build -DPPST_CONV_TRACE (tests/build_variant.sh): the per-step timeline of conv_mfma.hip's trace, same buffer
+// layout [block < 8][wave][step < 160][8]: 0 absolute start; relative: 1 head (descriptor, DMA, activation loads) issued,
+// 2 m-tiles 0-3 issued, 3 all m-tiles issued, 4 weight-fragment reload issued, 5 vmcnt wait done, 6 barrier passed; 7 newA2.
+#ifdef PPST_CONV_TRACE
+#define TR2(i) asm volatile("s_memtime %0" : "=s"(tr_[i])::"memory");
+#define TR2_DECL unsigned long long tr_[7];
+#define TR2_FLUSH(s, flag)                                                                            \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+  if (a.dbg && blockIdx.x < 8 && (s) < 160 && lane == 0) {                                            \
+    unsigned long long* o_ = a.dbg + ((((int64_t)blockIdx.x * NWV + wave) * 160) + (s)) * 8;          \
+    o_[0] = tr_[0];                                                                                   \
+    for (int q_ = 1; q_ < 7; ++q_) o_[q_] = tr_[q_] - tr_[0];                                         \
+    o_[7] = (flag) ? 1 : 0;                                                                           \
+  }
+#else
+#define TR2(i)
+#define TR2_DECL
+#define TR2_FLUSH(s, flag)
+#endif
 
 __device__ __forceinline__ int pad_index2(int i, int n, int mode) {
   if (mode == PPST_PAD_REFLECT) {
@@ -73,6 +94,10 @@ __global__ __launch_bounds__(128 * WNW, (WNW == 4 || NA_ == 1) ? 2 : 1) void con
   __shared__ __attribute__((aligned(256))) unsigned char smem[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
   unsigned char* smA = smem;
   unsigned char* smB = smem + NA * ABUF;
+#ifdef PPST_CONV_TRACE
+  unsigned long long tr_c0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_c0)::"memory");
+#endif
 
   // XCD-aware block -> (n index, m tile) map (bijective remap, N-major order): as conv_mfma.hip
   const int nwg = gridDim.x;
@@ -229,6 +254,7 @@ __global__ __launch_bounds__(128 * WNW, (WNW == 4 || NA_ == 1) ? 2 : 1) void con
 #define STEP2(bch, bcl, bnh, bnl, s, D2, D3, H1, H2)                                                        \
   {                                                                                                           \
     const bool has1 = (H1), has2 = (H2);                                                                      \
+    TR2_DECL TR2(0)                                                                                           \
     bool newA2 = false, a_early = false;                                                                      \
     int sl2 = sl1;                                                                                            \
     if (NA == 1 && freshA) {   /* this step's chunk was stored at the end of the previous step */             \
@@ -272,11 +298,14 @@ __global__ __launch_bounds__(128 * WNW, (WNW == 4 || NA_ == 1) ? 2 : 1) void con
           if (ld_) { a_load(ch_); a_early = NA == 1 || early_; }                                              \
         }                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
+        TR2(1)                                                                                                \
       }                                                                                                       \
+      if (mt == 3) { TR2(2) }                                                                                 \
       ah = nh;                                                                                                \
       al = nl;                                                                                                \
       if (NA > 1 && mt == MT - 2 && newA2) a_store(sl2);                                                      \
     }                                                                                                         \
+    TR2(3)                                                                                                    \
     if (storeA) {   /* every wave has read the old chunk -> overwrite the only slot */                        \
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                         \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
@@ -288,9 +317,13 @@ __global__ __launch_bounds__(128 * WNW, (WNW == 4 || NA_ == 1) ? 2 : 1) void con
         bnl[nt] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, nt) + 4 * BPLANE);                                   \
       }                                                                                                       \
     }                                                                                                         \
+    TR2(4)                                                                                                    \
     if (a_early) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_NLOADS) : "memory");                              \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+    TR2(5)                                                                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                           \
+    TR2(6)                                                                                                    \
+    TR2_FLUSH(s, newA2)                                                                                       \
     freshA = storeA; pendA = newA2;                                                                           \
     dy0 = dy1; dx0 = dx1; sl0 = sl1;                                                                          \
     if (has2) { dy1 = D2.y; dx1 = D2.z; }                                                                     \
@@ -332,6 +365,12 @@ __global__ __launch_bounds__(128 * WNW, (WNW == 4 || NA_ == 1) ? 2 : 1) void con
   float4 s1a[NT / 2], s2a[NT / 2];
 #pragma unroll
   for (int i = 0; i < NT / 2; ++i) { s1a[i] = make_float4(0.f, 0.f, 0.f, 0.f); s2a[i] = s1a[i]; }
+  // The pass loops are instantiated per (activation, residual mode): with both as run-time values hipcc evaluated the
+  // leaky-ReLU AND the PReLU branch of every element and selected (~30 VALU instructions per element, 27.7 k cycles per tile
+  // = 9 % of a 72-step tile, profiles/r02_conv_trace_v2.txt); a specialised pass needs ~10.
+  auto epi_passes = [&](auto act_c, auto res_c) {
+#pragma clang fp contract(off)   // no fused multiply-add here: every kernel family's epilogue must round like the others'
+    constexpr int ACT = decltype(act_c)::value, RES = decltype(res_c)::value;   // RES: 0 none, 1 joins before the activation, 2 after
 #pragma unroll
   for (int mh = 0; mh < MT / 4; ++mh) {
 #pragma unroll
@@ -360,16 +399,16 @@ __global__ __launch_bounds__(128 * WNW, (WNW == 4 || NA_ == 1) ? 2 : 1) void con
           const int64_t opix = ((int64_t)b * a.out_h + oy) * a.out_w + ox;
           float nz = a.noise ? a.noise_weight * a.noise[opix] : 0.f;
           float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (a.residual) rv = *(const float4*)(a.residual + opix * a.res_ld + n0);
+          if (RES) rv = *(const float4*)(a.residual + opix * a.res_ld + n0);
           float o[4] = {v.x + bv.x + nz, v.y + bv.y + nz, v.z + bv.z + nz, v.w + bv.w + nz};
           const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             float t = o[c];
-            if (!res_after) t += r4[c];
-            if (act == PPST_ACT_LRELU) t = (t > 0.f ? t : t * 0.2f) * 1.41421356237309515f;
-            else if (act == PPST_ACT_PRELU) t = t >= 0.f ? t : t * slope;
-            if (res_after) t += r4[c];
+            if (RES == 1) t += r4[c];
+            if (ACT == PPST_ACT_LRELU) t = (t > 0.f ? t : t * 0.2f) * 1.41421356237309515f;
+            else if (ACT == PPST_ACT_PRELU) t = t >= 0.f ? t : t * slope;
+            if (RES == 2) t += r4[c];
             o[c] = t * a.out_scale;
           }
           *(float4*)(a.y + opix * a.out_ld + n0) = make_float4(o[0], o[1], o[2], o[3]);
@@ -380,6 +419,20 @@ __global__ __launch_bounds__(128 * WNW, (WNW == 4 || NA_ == 1) ? 2 : 1) void con
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_wave_barrier();
     }
+  }
+  };
+  {
+    const int resm = a.residual ? (res_after ? 2 : 1) : 0;
+#define EPI_GO(A_)                                                                                    \
+  do {                                                                                                \
+    if (resm == 0) epi_passes(EpiC<A_>{}, EpiC<0>{});                                                 \
+    else if (resm == 1) epi_passes(EpiC<A_>{}, EpiC<1>{});                                            \
+    else epi_passes(EpiC<A_>{}, EpiC<2>{});                                                           \
+  } while (0)
+    if (act == PPST_ACT_LRELU) EPI_GO(PPST_ACT_LRELU);
+    else if (act == PPST_ACT_PRELU) EPI_GO(PPST_ACT_PRELU);
+    else EPI_GO(PPST_ACT_NONE);
+#undef EPI_GO
   }
   if (a.stats) {
     __syncthreads();     // the transposition tiles are done: `red` lies behind them, but other waves may still be in their last pass
@@ -407,6 +460,14 @@ __global__ __launch_bounds__(128 * WNW, (WNW == 4 || NA_ == 1) ? 2 : 1) void con
       }
     }
   }
+#ifdef PPST_CONV_TRACE
+  if (a.dbg && blockIdx.x < 8 && tid == 0) {   // block start / end stamps behind the step records: [8 blocks][2]
+    unsigned long long c1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1)::"memory");
+    a.dbg[(int64_t)8 * NWV * 160 * 8 + blockIdx.x * 2] = tr_c0;
+    a.dbg[(int64_t)8 * NWV * 160 * 8 + blockIdx.x * 2 + 1] = c1;
+  }
+#endif
 }
 
 // Entry used by ppst_conv2d_mfma (conv_mfma.hip) when a->bn is 256, or 128 with the fat-wave variant requested.
@@ -424,6 +485,11 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
   k.in_ss = (const float*)a->in_scale_shift; k.in_prelu = (const float*)a->in_prelu;
   k.in_c = a->in_c; k.in_act = a->in_act;
   k.early_a = a->early_a ? 1 : 0;
+  k.dbg = nullptr;
+#ifdef PPST_CONV_TRACE
+  k.dbg = (unsigned long long*)a->prelu;   // diagnostic builds: the (unused) prelu slot carries the debug buffer
+  k.prelu = nullptr;
+#endif
   const int blocks = a->n_groups * n_tiles * a->B * tiles_y * tiles_x;
 #define L2(NT_, HALO_, WNW_, BDB_, NA_)                                                                         \
   do {                                                                                                          \
