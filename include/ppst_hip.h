@@ -153,7 +153,7 @@ typedef struct ppst_conv_args {
   const void* in_prelu;          /* [1] slope when in_act == PPST_ACT_PRELU */
   int32_t in_c, in_act;          /* channel count of the in_scale_shift table; PPST_ACT_* */
   int32_t flop_steps;            /* steps that carry real weights (profiling only; 0 = nsteps) */
-  int32_t tile_rows;             /* 16: 16x16-pixel tiles, 512- (bn 128) / 256-thread blocks, 1 block per CU;
+  int32_t tile_rows;             /* (32 only with variant 7) 16: 16x16-pixel tiles, 512- (bn 128) / 256-thread blocks, 1 block per CU;
                                     8:  8x16-pixel tiles, 256- / 128-thread blocks, 2 blocks per CU -- with halo=1
                                     every chunk of the step table must then span >= 2 steps */
   int32_t a_slots;               /* depth of the activation-tile ring in LDS: 0 = default (3).  1 or 2 may be given when
@@ -178,6 +178,8 @@ typedef struct ppst_conv_args {
                                     6: plain 3x3 stride-1 tables only -- nsteps = 9 * chunks and step 9c + 3(dy+1) + (dx+1)
                                        is tap (dy, dx) of chunk c; bn = 64, or 128 for Cout in 65..128.  The table lives on
                                        the device and is not re-read: the CALLER owns this promise (as with a_slots).
+                                    7: conv_mfma2.hip with 8 waves as 4 (M) x 2 (N): block tile 32 x 16 px x 128 ch, one
+                                       activation slot; bn = 128, tile_rows = 32, the early_a promise (experiment, measured slower).
                                     Every variant gives bit-identical outputs; the per-tile statistics differ in the last
                                     bit between variants (other summation tree).  The library returns PPST_EINVAL for a
                                     variant whose shape conditions do not hold. */

@@ -735,8 +735,9 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       a->out_ld < a->cout || a->cout <= 0 || a->cout % 4 || a->out_ld % 4 || (a->residual && a->res_ld % 4) || a->nsteps <= 0 || (a->n_groups != 1 && a->n_groups != 4) || a->pad_mode < 0 ||
       a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 ||
       (a->precision != 0 && a->precision != 1 && a->precision != 3 && a->precision != 4) || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128 && a->bn != 256) || (a->residual && a->res_ld < a->cout) ||
-      a->variant < 0 || a->variant > 6 || (a->variant == 0 && a->bn == 256) ||
-      (a->variant >= 1 && a->variant <= 3 && (a->precision != 0 || a->bn == 64 || !a->early_a)) ||
+      a->variant < 0 || a->variant > 7 || (a->variant == 0 && a->bn == 256) ||
+      ((a->variant >= 1 && a->variant <= 3 || a->variant == 7) && (a->precision != 0 || a->bn == 64 || !a->early_a)) ||
+      (a->variant == 7 && (a->bn != 128 || a->tile_rows != 32)) ||
       (a->variant == 2 && a->bn != 256) || (a->variant == 3 && a->bn != 128) ||
       // variant 4 = the 1x1 streaming kernel (conv1x1.hip): all taps (0,0), one group, unit strides, bf16x3, 64-wide blobs
       (a->variant == 4 && (a->precision != 0 || a->bn != 64 || a->halo != 0 || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
@@ -746,7 +747,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       // (6: its register-reuse form for plain 3x3 stride-1 tables: the CALLER promises the (chunk, dy, dx) step order)
       ((a->variant == 5 || a->variant == 6) && (a->precision != 0 || (a->bn != 64 && !(a->variant == 6 && a->bn == 128)) || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
                            a->in_off_y != 0 || a->in_off_x != 0 || a->tile_h != a->out_h || a->tile_w != a->out_w)) ||
-      (a->tile_rows != 16) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
+      (a->tile_rows != 16 && !(a->variant == 7 && a->tile_rows == 32)) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
     return PPST_EINVAL;
   // the scattered output must reach into the output tensor (elements beyond it are dropped)
   if ((a->tile_h - 1) * a->out_sy >= a->out_h || (a->tile_w - 1) * a->out_sx >= a->out_w) return PPST_EINVAL;

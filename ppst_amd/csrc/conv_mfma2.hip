@@ -75,12 +75,15 @@ __device__ __forceinline__ int pad_index2(int i, int n, int mode) {
 // NA_: activation ring slots.  1 (with WNW = 2, NT = 4, BDB = false): 75 KB of LDS and <= 256 registers, so TWO 4-wave blocks
 // share a CU -- the 128 px x 64 ch wave tile for layers whose Cout is only 128.  With one slot a new chunk is stored at the
 // END of the step before it is used, between two barriers; the CU's other block fills that bubble.
-template <int NT, int HALO, bool INSS, int WNW = 2, bool BDB = true, int NA_ = 2>
-__global__ __launch_bounds__(128 * WNW, (WNW == 4 || NA_ == 1) ? 2 : 1) void conv_mfma2_kernel(Conv2KArgs a) {
-  constexpr int NWV = 2 * WNW;                            // waves per block (2 along M)
+// WMW: waves along M (8 tile rows each).  4 (with WNW = 2, NT = 4, BDB = false, NA_ = 1): block tile 32 x 16 px x 128 ch --
+// the 128 px x 64 ch wave tile, two waves per SIMD, for layers whose Cout is only 128 (variant 7).  Its activation slot is
+// 78 KB, so there is one, and a new chunk is stored at the end of the step before it is used (the NA_ = 1 path).
+template <int NT, int HALO, bool INSS, int WNW = 2, bool BDB = true, int NA_ = 2, int WMW = 2>
+__global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 1) void conv_mfma2_kernel(Conv2KArgs a) {
+  constexpr int NWV = WMW * WNW;                          // waves per block
   constexpr int NTH = 64 * NWV;
   constexpr int MT = 8;                                   // m-tiles (16-pixel rows) per wave
-  constexpr int TH = 16, TW = 16;
+  constexpr int TH = 8 * WMW, TW = 16;
   constexpr int HH = TH + 2 * HALO, HW = TW + 2 * HALO, HP = HH * HW;
   constexpr int PLANE = ((HP * 16 + 255) / 256) * 256;    // bytes
   constexpr int ABUF = 8 * PLANE;                         // hi g0..3, lo g0..3
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(128 * WNW, (WNW == 4 || NA_ == 1) ? 2 : 1) void con
   constexpr int BBUF = 8 * BPLANE;
   constexpr int NA = NA_;
   constexpr int EPI_TILE = 64 * 36;
-  constexpr int EPI_BYTES = NWV * EPI_TILE * 4 + 2 * BN * 2 * 4;
+  constexpr int EPI_BYTES = NWV * EPI_TILE * 4 + WMW * BN * 2 * 4;
   constexpr int MAIN_BYTES = NA * ABUF + 2 * BBUF;
   __shared__ __attribute__((aligned(256))) unsigned char smem[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
   unsigned char* smA = smem;
@@ -455,8 +458,11 @@ __global__ __launch_bounds__(128 * WNW, (WNW == 4 || NA_ == 1) ? 2 : 1) void con
       int n = ntile * BN + nl;
       if (n < a.cout) {
         float* o = a.stats + ((((int64_t)b * a.n_groups + group) * tiles + tyi * a.tiles_x + txi) * a.cout + n) * 2;
-        o[0] = red[nl * 2] + red[(BN + nl) * 2];
-        o[1] = red[nl * 2 + 1] + red[(BN + nl) * 2 + 1];
+        float t0 = red[nl * 2], t1 = red[nl * 2 + 1];
+#pragma unroll
+        for (int w = 1; w < WMW; ++w) { t0 += red[(w * BN + nl) * 2]; t1 += red[(w * BN + nl) * 2 + 1]; }
+        o[0] = t0;
+        o[1] = t1;
       }
     }
   }
@@ -496,7 +502,14 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
     if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<NT_, HALO_, true, WNW_, BDB_, NA_>), dim3(blocks), dim3(128 * WNW_), 0, st, k);  \
     else PPST_LAUNCH((conv_mfma2_kernel<NT_, HALO_, false, WNW_, BDB_, NA_>), dim3(blocks), dim3(128 * WNW_), 0, st, k);         \
   } while (0)
-  if (a->variant == 2) {                 // 8 waves, wave tile 128 px x 64 ch, N tile 256
+#define L7(HALO_)                                                                                               \
+  do {                                                                                                          \
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 1, 4>), dim3(blocks), dim3(512), 0, st, k);   \
+    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 1, 4>), dim3(blocks), dim3(512), 0, st, k);          \
+  } while (0)
+  if (a->variant == 7) {                 // 8 waves = 4 (M) x 2 (N), wave tile 128 px x 64 ch, block 32 x 16 px x 128 ch, one slot
+    if (a->halo) L7(1); else L7(0);
+  } else if (a->variant == 2) {          // 8 waves, wave tile 128 px x 64 ch, N tile 256
     if (a->halo) L2(4, 1, 4, false, 2); else L2(4, 0, 4, false, 2);
   } else if (a->variant == 3) {          // two 4-wave blocks per CU, wave tile 128 px x 64 ch, N tile 128, one activation slot
     if (a->halo) L2(4, 1, 2, false, 1); else L2(4, 0, 2, false, 1);

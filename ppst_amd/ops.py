@@ -33,6 +33,9 @@ DIRECT_MAX = {"cout": 64, "nsteps": 40, "cout3x3": 64}   # cout3x3 = 128 was mea
 WGRAD_SPLIT = {"blocks": 1024, "min_tiles": 4}   # conv_wgrad: target block count of a launch, fewest pixel tiles per block
 WGRAD_X3 = {"value": True}         # conv weight gradients on the bf16 matrix pipe (hi/lo split), exact fp32 with precision 2
 STREAM_1X1 = {"value": True}       # 1x1 convs (halo 0) on the streaming kernel of conv1x1.hip
+# variant 7 (32 x 16 px x 128 ch blocks, conv_mfma2.hip WMW = 4) when one image gives >= min_blocks: measured 3-5 % SLOWER than
+# the tile kernel on the Cout = 128 layers (one activation slot: the chunk store sits between two barriers; 33-44 spills) -- off
+TALL_TILE_128 = {"value": False, "min_blocks": 32}
 TWO_BLOCK_128 = {"value": False}   # experiment: variant 3 (see __call__) for the Cout = 128-class layers
 FAT_MIN_BLOCKS = 32         # take the 256-channel tile only when ONE image still gives >= this many blocks (B = 8: one per CU)
 
@@ -383,10 +386,6 @@ class ConvPlan:
         for t, n in ((bias, "bias"), (noise, "noise"), (prelu, "prelu"), (residual, "residual")):
             _chk(t, n)
         rows = TILE_ROWS["value"]
-        st = None
-        if stats:
-            tiles = lib.ppst_conv_tiles(th, tw, rows)
-            st = torch.empty((B, self.n_groups * tiles, self.cout, 2), device=x.device, dtype=torch.float32)
         # kernel variant / N tile: the fat-wave kernel needs chunks of >= 2 steps (3x3, transposed, stride-2 tables) and
         # pays off from 128 output channels; its 256-channel tile only when the grid still covers the chip
         variant, bn = 0, self.bn
@@ -404,6 +403,11 @@ class ConvPlan:
             elif self.bn == 128 and (force3 or (TWO_BLOCK_128["value"] and
                                                 tiles16 * ((self.cout + 127) // 128) >= 2 * FAT_MIN_BLOCKS)):
                 variant = 3             # two 4-wave blocks per CU, 128 px x 64 ch wave tiles, N tile 128 (NA_ = 1)
+            elif (self.bn == 128 and TALL_TILE_128["value"] and
+                  ((th + 31) // 32) * ((tw + 15) // 16) * self.n_groups * ((self.cout + 127) // 128) >= TALL_TILE_128["min_blocks"]):
+                # Cout in 65..255 (and the 128-wide remainder classes): 8 waves = 4 (M) x 2 (N) of 128 px x 64 ch, block tile
+                # 32 x 16 px x 128 ch, one activation slot (conv_mfma2.hip, WMW = 4)
+                variant, rows = 7, 32
         if (STREAM_1X1["value"] and self.precision == 0 and self.halo == 0 and self.n_groups == 1 and osy == 1
                 and (th, tw) == (oh, ow) == (H, W)):
             variant, bn = 4, 64         # 1x1 convs: streaming kernel, no activation staging (conv1x1.hip)
@@ -415,6 +419,12 @@ class ConvPlan:
         elif (self.precision == 0 and self.kind in ("conv", "dgrad") and self.k == 3 and 64 < self.cout <= DIRECT_MAX["cout3x3"]
               and (th, tw) == (oh, ow)):
             variant, bn = 6, 128        # 3x3 layers with 65..128 output channels: the register-reuse kernel, 32 px x 128 ch waves
+        if variant != 7:
+            rows = TILE_ROWS["value"]           # (a later choice -- stream / direct kernels -- replaced the tall-tile variant)
+        st = None
+        if stats:
+            tiles = lib.ppst_conv_tiles(th, tw, rows)
+            st = torch.empty((B, self.n_groups * tiles, self.cout, 2), device=x.device, dtype=torch.float32)
         a = _lib.ConvArgs()
         a.x, a.wpack, a.steps, a.y = _p(x), _p(self.pack_for(bn) if self.precision != 2 else None), _p(self.steps), _p(out)
         a.variant = variant

@@ -328,8 +328,12 @@ def t_conv_variants():
         w = g(nz_(co, ci, 3, 3) / math.sqrt(ci * 9))
         outs = {}
         # 8-wave; fat N=128; fat N=256; 8-wave 128x64 tiles N=256; two 4-wave blocks per CU, 128x64 tiles, N=128
-        for variant, minb in ((0, 384), (1, 1 << 30), (1, 0), (2, 0), (3, 0)):
+        tall = dict(ops.TALL_TILE_128)
+        for variant, minb in ((0, 384), (1, 1 << 30), (1, 0), (2, 0), (3, 0), (7, 0)):
             ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = variant, minb
+            ops.TALL_TILE_128.update(value=variant == 7, min_blocks=0)
+            if variant == 7:      # the 32 x 16-pixel-tile kernel on every 128-wide plan (the N-256 tile switched off)
+                ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = 2, 1 << 30
             plan = ops.ConvPlan(w, kind=kind)
             cin_eff = plan.max_chan + 32
             torch.manual_seed(11)
@@ -346,8 +350,9 @@ def t_conv_variants():
             y, st = plan(x, pad_mode=pm, stats=True, **kw)
             outs[(variant, minb)] = (y.cpu(), st.sum(1).cpu())
         ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = CONV_DEFAULTS
+        ops.TALL_TILE_128.update(tall)
         y0, s0 = outs[(0, 384)]
-        for key, tag in (((1, 1 << 30), "N=128"), ((1, 0), "N=256|128"), ((2, 0), "8w N=256"), ((3, 0), "2blk N=128")):
+        for key, tag in (((1, 1 << 30), "N=128"), ((1, 0), "N=256|128"), ((2, 0), "8w N=256"), ((3, 0), "2blk N=128"), ((7, 0), "32x16 N=128")):
             y1, s1 = outs[key]
             RES.append(("fat conv %s %s bit-identical" % (tag, name), bool(torch.equal(y0, y1))))
             print("fat conv %-9s %-52s %s max diff %.3e" % (tag, name, "ok  " if torch.equal(y0, y1) else "FAIL", (y0 - y1).abs().max().item()), flush=True)
