@@ -61,10 +61,11 @@ class ConvFn(Function):
     of EqualizedConv2d (stylegan2_layers.py:312-321)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, noise_w, noise, net, wname, kind, scale, pad_mode, act):
+    def forward(ctx, x, w, bias, noise_w, noise, net, wname, kind, scale, pad_mode, act, noise_w_host=None):
         x = _c(x)
         plan = net.plan(wname, kind, scale)
-        nw = float(noise_w) if noise_w is not None else 0.0
+        # the kernel takes the noise weight by value: the caller's cached host copy, or (a stream sync) the tensor itself
+        nw = (noise_w_host if noise_w_host is not None else float(noise_w)) if noise_w is not None else 0.0
         y, st = plan(x, bias=bias, noise=(noise if noise_w is not None else None), noise_weight=nw, act=act, pad_mode=pad_mode, stats=True)
         ctx.save_for_backward(x, y if act != NONE else None, noise if noise_w is not None else None)
         ctx.cfg = (net, wname, kind, scale, pad_mode, act, bias is not None, noise_w is not None)
@@ -91,11 +92,12 @@ class ConvFn(Function):
             if need_w:
                 dw4 = ops.conv_wgrad(pl, gs, x)
                 dw = ops.upscale_weight_bwd(dw4, pl.cin, pl.cout, pl.fwd_scale)
-        return dx, dw, db, dnw, None, None, None, None, None, None, None
+        return dx, dw, db, dnw, None, None, None, None, None, None, None, None
 
 
-def conv(x, w, net, wname, bias=None, kind="conv", scale=1.0, pad_mode=Z, act=NONE, noise_w=None, noise=None, stats=False):
-    y, st = ConvFn.apply(x, w, bias, noise_w, noise, net, wname, kind, scale, pad_mode, act)
+def conv(x, w, net, wname, bias=None, kind="conv", scale=1.0, pad_mode=Z, act=NONE, noise_w=None, noise=None, stats=False,
+         noise_w_host=None):
+    y, st = ConvFn.apply(x, w, bias, noise_w, noise, net, wname, kind, scale, pad_mode, act, noise_w_host)
     return (y, st) if stats else y
 
 

@@ -52,6 +52,19 @@ class FlatParams:
         off, sz = self.offsets[name]
         return self.grad[off:off + sz]
 
+    def scalar(self, name):
+        """Host value of a one-element parameter (the 14 NoiseInjection weights: the conv kernel takes them by value).  All
+        of them come over in ONE device-to-host copy per parameter update -- `float(param)` per StyledConv call was a
+        stream synchronisation each (50-80 per train step, each draining the launch queue)."""
+        key = (self.step_count, self.flat._version)
+        if getattr(self, "_scalar_key", None) != key:
+            names = [n_ for n_, sz in zip(self.names, self.sizes) if sz == 1]
+            if not hasattr(self, "_scalar_idx"):
+                self._scalar_idx = torch.tensor([self.offsets[n_][0] for n_ in names], dtype=torch.long, device=self.flat.device)
+            vals = self.flat.index_select(0, self._scalar_idx).cpu().tolist() if names else []
+            self._scalars, self._scalar_key = dict(zip(names, vals)), key
+        return self._scalars[name]
+
     def owns_parameters(self):
         off = 0
         for p, n in zip(self.params, self.sizes):
@@ -185,7 +198,8 @@ class GeneratorTrainer:
             B, H, W = x.shape[0], x.shape[1] * (2 if upsample else 1), x.shape[2] * (2 if upsample else 1)
             nz = torch.randn(B, 1, H, W, device=x.device)          # NoiseInjection draws N(0,1) (stylegan2_layers.py:388-390)
         wn = p + "conv.weight"
-        a, st = A.conv(x, P(wn), net, wn, bias=bias, kind=kind, act=A.LRELU, noise_w=P(p + "noise.weight"), noise=nz.contiguous(), stats=True)
+        a, st = A.conv(x, P(wn), net, wn, bias=bias, kind=kind, act=A.LRELU, noise_w=P(p + "noise.weight"), noise=nz.contiguous(), stats=True,
+                       noise_w_host=self.fp["G"].scalar(p + "noise.weight"))
         wl = P(p + "epi1.style_mod.lin.weight")
         style = A.linear(code, wl, P(p + "epi1.style_mod.lin.bias"), wscale=wl.shape[1] ** -0.5)
         return A.instance_norm(a, st, style=style)
