@@ -25,13 +25,15 @@ def _hipcc():
     return "hipcc"
 
 
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "rscl_common.h"), os.path.join(HERE, "..", "include", "ppst_hip.h")]
+
+
+def _stale(target, deps):
+    return not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"),
-                                                        os.path.join(HERE, "..", "include", "ppst_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
 
 
 def build(force=False, verbose=True):
@@ -42,15 +44,19 @@ def build(force=False, verbose=True):
 
     def cc(src):
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        if not force and not _stale(obj, [os.path.join(CSRC, src)] + HEADERS):
+            return obj                                   # this object is current: only what changed is recompiled
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))
         return obj
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(cc, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    # the three conv files dominate (minutes each): start them first, all files in parallel
+    order = sorted(SOURCES, key=lambda f: 0 if f.startswith("conv") else 1)
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = dict(zip(order, ex.map(cc, order)))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [objs[s_] for s_ in SOURCES]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stderr)

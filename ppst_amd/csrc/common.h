@@ -14,7 +14,10 @@ typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-template <int V> struct EpiC { static constexpr int value = V; };   // compile-time tag for the specialised conv epilogues
+// Tags for the conv epilogues' (activation, residual mode): EpiC = compile-time (the production kernels: the pass loops are
+// instantiated per combination), EpiR = run-time (experiment / reduced-precision kernels: one generic instance, shorter build).
+template <int V> struct EpiC { static constexpr int value = V; };
+struct EpiR { int value; };
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 

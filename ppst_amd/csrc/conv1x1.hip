@@ -64,7 +64,7 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT
   // instantiated per (activation, residual mode), as in conv_mfma.hip / conv_mfma2.hip (same arithmetic, no FMA contraction)
   auto epi_passes = [&](auto act_c, auto res_c) {
 #pragma clang fp contract(off)
-    constexpr int ACT = decltype(act_c)::value, RES = decltype(res_c)::value;
+    const int ACT = act_c.value, RES = res_c.value;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int p = pbase + mt * 16 + r16;

@@ -479,7 +479,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   // (both activation branches evaluated and selected), ~10 when specialised (conv_mfma2.hip).
   auto epi_passes = [&](auto act_c, auto res_c) {
 #pragma clang fp contract(off)   // no fused multiply-add here: every kernel family's epilogue must round like the others'
-    constexpr int ACT = decltype(act_c)::value, RES = decltype(res_c)::value;   // RES: 0 none, 1 joins before the activation, 2 after
+    const int ACT = act_c.value, RES = res_c.value;   // RES: 0 none, 1 joins before the activation, 2 after
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -548,7 +548,8 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     else if (resm == 1) epi_passes(EpiC<A_>{}, EpiC<1>{});                                            \
     else epi_passes(EpiC<A_>{}, EpiC<2>{});                                                           \
   } while (0)
-    if (act == PPST_ACT_LRELU) EPI_GO(PPST_ACT_LRELU);
+    if (!X3) epi_passes(EpiR{act}, EpiR{resm});        // reduced-precision kernels: one generic instance
+    else if (act == PPST_ACT_LRELU) EPI_GO(PPST_ACT_LRELU);
     else if (act == PPST_ACT_PRELU) EPI_GO(PPST_ACT_PRELU);
     else EPI_GO(PPST_ACT_NONE);
 #undef EPI_GO

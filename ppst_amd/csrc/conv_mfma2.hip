@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 
   // = 9 % of a 72-step tile, profiles/r02_conv_trace_v2.txt); a specialised pass needs ~10.
   auto epi_passes = [&](auto act_c, auto res_c) {
 #pragma clang fp contract(off)   // no fused multiply-add here: every kernel family's epilogue must round like the others'
-    constexpr int ACT = decltype(act_c)::value, RES = decltype(res_c)::value;   // RES: 0 none, 1 joins before the activation, 2 after
+    const int ACT = act_c.value, RES = res_c.value;   // RES: 0 none, 1 joins before the activation, 2 after
 #pragma unroll
   for (int mh = 0; mh < MT / 4; ++mh) {
 #pragma unroll
@@ -432,7 +432,8 @@ __global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 
     else if (resm == 1) epi_passes(EpiC<A_>{}, EpiC<1>{});                                            \
     else epi_passes(EpiC<A_>{}, EpiC<2>{});                                                           \
   } while (0)
-    if (act == PPST_ACT_LRELU) EPI_GO(PPST_ACT_LRELU);
+    if (!(WNW == 4 && NA_ == 2)) epi_passes(EpiR{act}, EpiR{resm});   // the measured experiments: one generic instance
+    else if (act == PPST_ACT_LRELU) EPI_GO(PPST_ACT_LRELU);
     else if (act == PPST_ACT_PRELU) EPI_GO(PPST_ACT_PRELU);
     else EPI_GO(PPST_ACT_NONE);
 #undef EPI_GO
