@@ -737,7 +737,8 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 ||
       (a->precision != 0 && a->precision != 1 && a->precision != 3 && a->precision != 4) || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128 && a->bn != 256) || (a->residual && a->res_ld < a->cout) ||
       a->variant < 0 || a->variant > 7 || (a->variant == 0 && a->bn == 256) ||
-      ((a->variant >= 1 && a->variant <= 3 || a->variant == 7) && (a->precision != 0 || a->bn == 64 || !a->early_a)) ||
+      ((a->variant >= 1 && a->variant <= 3 || a->variant == 7) &&
+       ((a->precision != 0 && !(a->variant == 2 && (a->precision == 1 || a->precision == 3))) || a->bn == 64 || !a->early_a)) ||
       (a->variant == 7 && (a->bn != 128 || a->tile_rows != 32)) ||
       (a->variant == 2 && a->bn != 256) || (a->variant == 3 && a->bn != 128) ||
       // variant 4 = the 1x1 streaming kernel (conv1x1.hip): all taps (0,0), one group, unit strides, bf16x3, 64-wide blobs

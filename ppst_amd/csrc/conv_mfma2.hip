@@ -78,18 +78,23 @@ __device__ __forceinline__ int pad_index2(int i, int n, int mode) {
 // WMW: waves along M (8 tile rows each).  4 (with WNW = 2, NT = 4, BDB = false, NA_ = 1): block tile 32 x 16 px x 128 ch --
 // the 128 px x 64 ch wave tile, two waves per SIMD, for layers whose Cout is only 128 (variant 7).  Its activation slot is
 // 78 KB, so there is one, and a new chunk is stored at the end of the step before it is used (the NA_ = 1 path).
-template <int NT, int HALO, bool INSS, int WNW = 2, bool BDB = true, int NA_ = 2, int WMW = 2>
+// PREC: 0 the fp32-class bf16 hi+lo form (three MFMAs per product); 1 / 3 single-pass bf16 / fp16 (the reduced-precision modes
+// of ops.set_precision: one plane set in LDS, one MFMA) -- instantiated for the production geometry (variant 2) only.
+typedef _Float16 __attribute__((ext_vector_type(8))) half8_2;
+__device__ __forceinline__ unsigned short f2h_2(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+template <int NT, int HALO, bool INSS, int WNW = 2, bool BDB = true, int NA_ = 2, int WMW = 2, int PREC = 0>
 __global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 1) void conv_mfma2_kernel(Conv2KArgs a) {
+  constexpr bool X3 = PREC == 0;
   constexpr int NWV = WMW * WNW;                          // waves per block
   constexpr int NTH = 64 * NWV;
   constexpr int MT = 8;                                   // m-tiles (16-pixel rows) per wave
   constexpr int TH = 8 * WMW, TW = 16;
   constexpr int HH = TH + 2 * HALO, HW = TW + 2 * HALO, HP = HH * HW;
   constexpr int PLANE = ((HP * 16 + 255) / 256) * 256;    // bytes
-  constexpr int ABUF = 8 * PLANE;                         // hi g0..3, lo g0..3
+  constexpr int ABUF = (X3 ? 8 : 4) * PLANE;              // hi g0..3 [, lo g0..3]
   constexpr int BN = WNW * 16 * NT;                       // WNW N-waves
   constexpr int BPLANE = BN * 16;
-  constexpr int BBUF = 8 * BPLANE;
+  constexpr int BBUF = (X3 ? 8 : 4) * BPLANE;
   constexpr int NA = NA_;
   constexpr int EPI_TILE = 64 * 36;
   constexpr int EPI_BYTES = NWV * EPI_TILE * 4 + WMW * BN * 2 * 4;
@@ -186,11 +191,13 @@ __global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 
           v.x = in_act(ras0.x * v.x + ras0.y); v.y = in_act(ras0.z * v.y + ras0.w);
           v.z = in_act(ras1.x * v.z + ras1.y); v.w = in_act(ras1.z * v.w + ras1.w);
         }
-        unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
-        split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
+        unsigned short h0, h1, h2, h3, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+        if (X3) { split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3); }
+        else if (PREC == 3) { h0 = f2h_2(v.x); h1 = f2h_2(v.y); h2 = f2h_2(v.z); h3 = f2h_2(v.w); }
+        else { h0 = f2bf(v.x); h1 = f2bf(v.y); h2 = f2bf(v.z); h3 = f2bf(v.w); }
         int off = (l >> 4) * PLANE + pix * 16 + (l & 1) * 8;
         *(uint2*)(base + off) = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
-        *(uint2*)(base + 4 * PLANE + off) = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+        if (X3) *(uint2*)(base + 4 * PLANE + off) = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
       }
     }
   };
@@ -244,10 +251,10 @@ __global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     b0h[nt] = *(const bf16x8*)B_ADDR(0, nt);
-    b0l[nt] = *(const bf16x8*)(B_ADDR(0, nt) + 4 * BPLANE);
+    if (X3) b0l[nt] = *(const bf16x8*)(B_ADDR(0, nt) + 4 * BPLANE);
   }
   ah = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, 0));
-  al = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, 0) + 4 * PLANE);
+  if (X3) al = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, 0) + 4 * PLANE);
   __builtin_amdgcn_s_waitcnt(0xC07F);
 
   // One K-step.  bc* = this step's weight fragments (read during the previous step); bn* receive the next step's:
@@ -262,30 +269,35 @@ __global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 
     int sl2 = sl1;                                                                                            \
     if (NA == 1 && freshA) {   /* this step's chunk was stored at the end of the previous step */             \
       ah = *(const bf16x8*)(smA + A_OFF(0, dy0, dx0, 0));                                                     \
-      al = *(const bf16x8*)(smA + A_OFF(0, dy0, dx0, 0) + 4 * PLANE);                                         \
+      if (X3) al = *(const bf16x8*)(smA + A_OFF(0, dy0, dx0, 0) + 4 * PLANE);                                         \
     }                                                                                                         \
     const bool storeA = NA == 1 && pendA;   /* the next step opens a chunk: store it at the end of this one */ \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                       \
       bf16x8 nh, nl;                                                                                          \
       if (mt < MT - 1) {                                                                                      \
         nh = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1));                                            \
-        nl = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1) + 4 * PLANE);                                \
+        if (X3) nl = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1) + 4 * PLANE);                                \
       } else if (has1 && !storeA) {                                                                           \
         nh = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0));                                                 \
-        nl = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0) + 4 * PLANE);                                     \
+        if (X3) nl = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0) + 4 * PLANE);                                     \
       }                                                                                                       \
       if (BDB && has1 && mt >= 1 && mt - 1 < NT) {   /* next step's B fragment pair nt = mt - 1 */            \
         bnh[mt - 1] = *(const bf16x8*)B_ADDR(((s) + 1) & 1, mt - 1);                                          \
-        bnl[mt - 1] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, mt - 1) + 4 * BPLANE);                           \
+        if (X3) bnl[mt - 1] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, mt - 1) + 4 * BPLANE);                           \
       }                                                                                                       \
       if (BDB && NT == 8 && has1 && mt == MT - 1) {                                                           \
         bnh[NT - 1] = *(const bf16x8*)B_ADDR(((s) + 1) & 1, NT - 1);                                          \
-        bnl[NT - 1] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, NT - 1) + 4 * BPLANE);                           \
+        if (X3) bnl[NT - 1] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, NT - 1) + 4 * BPLANE);                           \
       }                                                                                                       \
       _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                     \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bch[nt], acc[mt][nt], 0, 0, 0);             \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcl[nt], acc[mt][nt], 0, 0, 0);             \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bch[nt], acc[mt][nt], 0, 0, 0);             \
+        if (X3) {                                                                                             \
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bch[nt], acc[mt][nt], 0, 0, 0);           \
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcl[nt], acc[mt][nt], 0, 0, 0);           \
+        }                                                                                                     \
+        if (PREC == 3)                                                                                        \
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_2, ah), __builtin_bit_cast(half8_2, bch[nt]), acc[mt][nt], 0, 0, 0); \
+        else                                                                                                  \
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bch[nt], acc[mt][nt], 0, 0, 0);           \
       }                                                                                                       \
       if (mt == 0) {                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -317,7 +329,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 
     if (!BDB && has1) {   /* single register set: the next step's weight fragments replace this step's, now dead */ \
       _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                     \
         bnh[nt] = *(const bf16x8*)B_ADDR(((s) + 1) & 1, nt);                                                  \
-        bnl[nt] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, nt) + 4 * BPLANE);                                   \
+        if (X3) bnl[nt] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, nt) + 4 * BPLANE);                                   \
       }                                                                                                       \
     }                                                                                                         \
     TR2(4)                                                                                                    \
@@ -432,7 +444,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 
     else if (resm == 1) epi_passes(EpiC<A_>{}, EpiC<1>{});                                            \
     else epi_passes(EpiC<A_>{}, EpiC<2>{});                                                           \
   } while (0)
-    if (!(WNW == 4 && NA_ == 2)) epi_passes(EpiR{act}, EpiR{resm});   // the measured experiments: one generic instance
+    if (!(WNW == 4 && NA_ == 2 && X3)) epi_passes(EpiR{act}, EpiR{resm});   // experiments / reduced precision: one generic instance
     else if (act == PPST_ACT_LRELU) EPI_GO(PPST_ACT_LRELU);
     else if (act == PPST_ACT_PRELU) EPI_GO(PPST_ACT_PRELU);
     else EPI_GO(PPST_ACT_NONE);
@@ -508,7 +520,14 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
     if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 1, 4>), dim3(blocks), dim3(512), 0, st, k);   \
     else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 1, 4>), dim3(blocks), dim3(512), 0, st, k);          \
   } while (0)
-  if (a->variant == 7) {                 // 8 waves = 4 (M) x 2 (N), wave tile 128 px x 64 ch, block 32 x 16 px x 128 ch, one slot
+#define L2P(HALO_, PREC_)                                                                                       \
+  do {                                                                                                          \
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 4, false, 2, 2, PREC_>), dim3(blocks), dim3(512), 0, st, k);   \
+    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 4, false, 2, 2, PREC_>), dim3(blocks), dim3(512), 0, st, k);          \
+  } while (0)
+  if (a->variant == 2 && a->precision == 1) { if (a->halo) L2P(1, 1); else L2P(0, 1); }
+  else if (a->variant == 2 && a->precision == 3) { if (a->halo) L2P(1, 3); else L2P(0, 3); }
+  else if (a->variant == 7) {                 // 8 waves = 4 (M) x 2 (N), wave tile 128 px x 64 ch, block 32 x 16 px x 128 ch, one slot
     if (a->halo) L7(1); else L7(0);
   } else if (a->variant == 2) {          // 8 waves, wave tile 128 px x 64 ch, N tile 256
     if (a->halo) L2(4, 1, 4, false, 2); else L2(4, 0, 4, false, 2);

@@ -396,9 +396,11 @@ class ConvPlan:
         if CONV_VARIANT["value"] == 1 and self.precision == 0 and self.early_a and self.cout >= 128:
             variant = 1
             bn = 256 if (self.cout % 256 == 0 and tiles16 * (self.cout // 256) >= FAT_MIN_BLOCKS) else 128
-        elif CONV_VARIANT["value"] in (2, 3) and self.precision == 0 and self.early_a:
+        elif CONV_VARIANT["value"] in (2, 3) and self.precision in (0, 1, 3) and self.early_a:
             force3 = CONV_VARIANT["value"] == 3          # (tests) every eligible plan on the two-block kernel
-            if not force3 and self.cout % 256 == 0 and tiles16 * (self.cout // 256) >= FAT_MIN_BLOCKS:
+            if self.precision != 0 and not (not force3 and self.cout % 256 == 0 and tiles16 * (self.cout // 256) >= FAT_MIN_BLOCKS):
+                pass                    # single-pass modes: only the N-256 geometry is built for them
+            elif not force3 and self.cout % 256 == 0 and tiles16 * (self.cout // 256) >= FAT_MIN_BLOCKS:
                 variant, bn = 2, 256    # 8 waves x (128 px x 64 ch), N tile 256 (conv_mfma2.hip, WNW = 4)
             elif self.bn == 128 and (force3 or (TWO_BLOCK_128["value"] and
                                                 tiles16 * ((self.cout + 127) // 128) >= 2 * FAT_MIN_BLOCKS)):

@@ -359,6 +359,30 @@ def t_conv_variants():
             report("fat conv %s %s stats" % (tag, name), s1, s0, 1e-5)
 
 
+def t_conv_variants_single_pass():
+    """The N-256 kernel in the single-pass modes (bf16, fp16) against the tile kernel in the same mode: bit-identical."""
+    torch.manual_seed(8)
+    nz_ = torch.randn
+    cd = (ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS)
+    for prec in (1, 3):
+        for name, B, ci, co, H, Wd, kind, pm in (("3x3 reflect 64->256 33x47", 2, 64, 256, 33, 47, "conv", 1),
+                                                  ("convT 64->512 20x12", 2, 64, 512, 20, 12, "convT", 0),
+                                                  ("3x3 zero 256->256 256x256", 1, 256, 256, 256, 256, "conv", 0)):
+            w = g(nz_(co, ci, 3, 3) / math.sqrt(ci * 9))
+            x = g(nz_(B, H, Wd, ci))
+            outs = []
+            for variant in (0, 2):
+                ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = variant, 0
+                plan = ops.ConvPlan(w, kind=kind, precision=prec)
+                y, st = plan(x, pad_mode=pm, stats=True, bias=g(torch.arange(co, dtype=torch.float32) * 0.01), act=ops.ACT_LRELU)
+                outs.append((y.cpu(), st.sum(1).cpu()))
+            ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = cd
+            ok = bool(torch.equal(outs[0][0], outs[1][0]))
+            RES.append(("single-pass precision %d N=256 %s bit-identical" % (prec, name), ok))
+            print("single-pass prec %d %-30s %s max diff %.3e" % (prec, name, "ok  " if ok else "FAIL", (outs[0][0] - outs[1][0]).abs().max().item()), flush=True)
+            report("single-pass prec %d %s stats" % (prec, name), outs[1][1], outs[0][1], 1e-5)
+
+
 def t_conv1x1_stream():
     """conv1x1.hip (streaming 1x1 kernel and its direct form for thin 3x3 / stride-2 layers; operands swapped) against
     conv_mfma.hip on the same plans: bit-identical outputs, statistics to rounding; every epilogue / normalise-on-load
@@ -849,7 +873,7 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     print("device:", torch.cuda.get_device_name(0), flush=True)
     if which in ("ops", "all"):
-        for fn in (t_upfirdn2d, t_fused_act, t_layout_misc, t_conv, t_conv_variants, t_conv1x1_stream, t_norm_pool, t_corr, t_guided):
+        for fn in (t_upfirdn2d, t_fused_act, t_layout_misc, t_conv, t_conv_variants, t_conv_variants_single_pass, t_conv1x1_stream, t_norm_pool, t_corr, t_guided):
             print("== " + fn.__name__, flush=True)
             run(fn)
             torch.cuda.synchronize()
@@ -860,6 +884,7 @@ def main():
         run(t_precision)
     if which == "convv":
         run(t_conv_variants)
+        run(t_conv_variants_single_pass)
         run(t_conv1x1_stream)
     if which == "trainops":
         run(t_train_ops)
