@@ -42,6 +42,26 @@ struct C1Args {
 #define C1_GROUP 8          // step blobs resident in LDS at a time
 #define C1_BLOB 8192        // bytes per step blob (bn = 64: 8 planes x 64 n x 16 B)
 
+// PREC of the kernels below: 0 = bf16 hi + lo on both sides (fp32-class, three MFMAs per product); 1 / 3 = single-pass bf16 /
+// fp16 (ops.set_precision(1 | 3): one plane set per blob, one MFMA).
+typedef _Float16 __attribute__((ext_vector_type(8))) c1_half8;
+template <int PREC>
+__device__ __forceinline__ void c1_cvt(float v, unsigned short& h, unsigned short& l) {
+  if (PREC == 0) split_bf16(v, h, l);
+  else if (PREC == 3) { h = __builtin_bit_cast(unsigned short, (_Float16)v); l = 0; }
+  else { h = f2bf(v); l = 0; }
+}
+template <int PREC>
+__device__ __forceinline__ f32x4 c1_mfma(bf16x8 bh, bf16x8 bl, bf16x8 xh, bf16x8 xl, f32x4 acc) {
+  if (PREC == 0) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, xl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, xh, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, xh, acc, 0, 0, 0);
+  }
+  if (PREC == 3) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(c1_half8, bh), __builtin_bit_cast(c1_half8, xh), acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, xh, acc, 0, 0, 0);
+}
+
 __device__ __forceinline__ int c1_pad(int i, int n, int mode) {
   if (mode == PPST_PAD_REFLECT) {
     if (i < 0) i = -i;
@@ -52,7 +72,7 @@ __device__ __forceinline__ int c1_pad(int i, int n, int mode) {
 
 // Epilogue shared by the kernels of this file: lane = pixel r16 of each m-tile, channels n0 + 4g .. 4g+3 of each n-tile
 // (operands swapped in the MFMAs), everything a 16-B access straight from the accumulators; tile statistics through `red`.
-template <int MT, int NT, bool TAPS>
+template <int MT, int NT, bool TAPS, bool SPEC = true>
 __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT], float (&red)[8][NT > 4 ? 128 : 64][2], int b, int mblk,
                                             int ntile, int pbase, int oy0, int ox, int tid, int wave, int r16, int g) {
   const int act = a.act & 0xff;
@@ -103,7 +123,8 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT
     else if (resm == 1) epi_passes(EpiC<A_>{}, EpiC<1>{});                                            \
     else epi_passes(EpiC<A_>{}, EpiC<2>{});                                                           \
   } while (0)
-    if (act == PPST_ACT_LRELU) EPI_GO(PPST_ACT_LRELU);
+    if (!SPEC) epi_passes(EpiR{act}, EpiR{resm});      // reduced-precision / experiment kernels: one generic instance
+    else if (act == PPST_ACT_LRELU) EPI_GO(PPST_ACT_LRELU);
     else if (act == PPST_ACT_PRELU) EPI_GO(PPST_ACT_PRELU);
     else EPI_GO(PPST_ACT_NONE);
 #undef EPI_GO
@@ -153,10 +174,12 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT
 //               HBM-bound layers have to spare, and removes the tile's serial prologue (load -> split -> LDS -> barrier) and
 //               the per-step barriers that left these layers at 0.10-0.25 of the MFMA ceiling.
 // NT_: 16-channel tiles per wave (2 when Cout <= 32).
-template <bool INSS, bool TAPS = false, int NT_ = 4>
+template <bool INSS, bool TAPS = false, int NT_ = 4, int PREC = 0>
 __global__ __launch_bounds__(512, 4) void conv1x1_stream_kernel(C1Args a) {
   constexpr int MT = 2, NT = NT_;
-  __shared__ uint4 sB[C1_GROUP * C1_BLOB / 16];
+  constexpr bool X3 = PREC == 0;
+  constexpr int BLOB1 = X3 ? C1_BLOB : C1_BLOB / 2;      // single-pass blobs carry the hi planes only
+  __shared__ uint4 sB[C1_GROUP * BLOB1 / 16];
   __shared__ float red[8][64][2];
 
   // XCD-aware order: each XCD gets a contiguous range of work ids; inside it the N tiles of one pixel block are adjacent
@@ -176,7 +199,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_stream_kernel(C1Args a) {
   const int tyi = TAPS ? mblk / a.tiles_x : 0, txi = TAPS ? mblk - tyi * a.tiles_x : 0;
   const int oy0 = tyi * 16 + wave * 2, ox = txi * 16 + r16;       // TAPS: output pixel of m-tile mt = (oy0 + mt, ox)
   const float* xb = a.x + (int64_t)b * (TAPS ? a.in_h * a.in_w : a.hw) * a.in_ld;
-  const unsigned char* wblob = a.wpack + (int64_t)ntile * a.nsteps * C1_BLOB;
+  const unsigned char* wblob = a.wpack + (int64_t)ntile * a.nsteps * BLOB1;
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef const __attribute__((address_space(4))) int4* StepPtr;
 #else
@@ -237,7 +260,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_stream_kernel(C1Args a) {
   for (int s0 = 0; s0 < a.nsteps; s0 += C1_GROUP) {
     const int ng = a.nsteps - s0 < C1_GROUP ? a.nsteps - s0 : C1_GROUP;
     if (s0) __syncthreads();                    // every wave has finished reading the previous group's blobs
-    for (int i = tid; i < ng * (C1_BLOB / 16); i += 512) sB[i] = ((const uint4*)(wblob + (int64_t)s0 * C1_BLOB))[i];
+    for (int i = tid; i < ng * (BLOB1 / 16); i += 512) sB[i] = ((const uint4*)(wblob + (int64_t)s0 * BLOB1))[i];
     __syncthreads();
     for (int sl = 0; sl < ng; ++sl) {
       const int s = s0 + sl;
@@ -259,28 +282,25 @@ __global__ __launch_bounds__(512, 4) void conv1x1_stream_kernel(C1Args a) {
         for (int j = 0; j < 8; ++j) {
           if (!vok[mt]) v[j] = 0.f;
           unsigned short h, l;
-          split_bf16(v[j], h, l);
+          c1_cvt<PREC>(v[j], h, l);
           ah[mt][j] = (short)h;
           al[mt][j] = (short)l;
         }
       }
       if (s + 1 < a.nsteps) a_load(steps[s + 1]);            // in flight while the matrix pipe works on this step
-      const unsigned char* bs = (const unsigned char*)sB + sl * C1_BLOB + g * 1024 + r16 * 16;
+      const unsigned char* bs = (const unsigned char*)sB + sl * BLOB1 + g * 1024 + r16 * 16;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const bf16x8 bh = *(const bf16x8*)(bs + nt * 256);
-        const bf16x8 bl = *(const bf16x8*)(bs + nt * 256 + 4096);
+        bf16x8 bl = bh;
+        if (X3) bl = *(const bf16x8*)(bs + nt * 256 + 4096);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[mt], acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[mt], acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[mt], acc[mt][nt], 0, 0, 0);
-        }
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = c1_mfma<PREC>(bh, bl, ah[mt], al[mt], acc[mt][nt]);
       }
     }
   }
 
-  c1_epilogue<MT, NT, TAPS>(a, acc, red, b, mblk, ntile, pbase, oy0, ox, tid, wave, r16, g);
+  c1_epilogue<MT, NT, TAPS, X3>(a, acc, red, b, mblk, ntile, pbase, oy0, ox, tid, wave, r16, g);
 }
 
 // Plain 3x3 stride-1 layers with few channels (variant 6): the direct form above re-reads every pixel 9 times through
@@ -304,10 +324,12 @@ __device__ __forceinline__ bf16x8 c3_shift(bf16x8 edge, bf16x8 centre) {
 // NT_ = 8 (Cout = 65..128, blobs packed for bn = 128): wave tile 32 px x 128 ch, 256 registers, one block per CU (152 KB of
 // LDS) -- the generator's 128 -> 128 @512^2 StyledConv, which the tile kernel ran at 0.43 of the ceiling (36-step tiles
 // pay 20 % for their serial prologue + epilogue): here the two waves of a SIMD overlap one's conversions with the other's MFMAs.
-template <bool INSS, int NT_>
+template <bool INSS, int NT_, int PREC = 0>
 __global__ __launch_bounds__(512, NT_ > 4 ? 2 : 4) void conv3x3_direct_kernel(C1Args a) {
   constexpr int MT = 2, NT = NT_;
-  constexpr int BLOB = NT > 4 ? 16384 : C1_BLOB;          // bytes per step blob (8 planes x bn x 16 B)
+  constexpr bool X3 = PREC == 0;
+  constexpr int PSTR = (NT > 4 ? 128 : 64) * 16;          // bytes per plane of a step blob (bn x 16 B)
+  constexpr int BLOB = (X3 ? 8 : 4) * PSTR;               // hi planes g0..3 [, lo planes]
   __shared__ uint4 sB[C3_GROUP * BLOB / 16];
   __shared__ float red[8][NT > 4 ? 128 : 64][2];
   // persistent blocks (the launch caps the grid at two per CU): block i walks the contiguous range of work ids
@@ -385,7 +407,7 @@ __global__ __launch_bounds__(512, NT_ > 4 ? 2 : 4) void conv3x3_direct_kernel(C1
     for (int j = 0; j < 8; ++j) {
       if (!ok) v[j] = 0.f;
       unsigned short h, l;
-      split_bf16(v[j], h, l);
+      c1_cvt<PREC>(v[j], h, l);
       hi[j] = (short)h;
       lo[j] = (short)l;
     }
@@ -418,14 +440,13 @@ __global__ __launch_bounds__(512, NT_ > 4 ? 2 : 4) void conv3x3_direct_kernel(C1
         for (int mt = 0; mt < MT; ++mt) {
           const int dyi = r - mt;                                            // dy + 1
           if (dyi < 0 || dyi > 2) continue;
-          const unsigned char* bs = (const unsigned char*)sB + (dyi * 3 + dxi) * BLOB + g * (BLOB / 8) + r16 * 16;
+          const unsigned char* bs = (const unsigned char*)sB + (dyi * 3 + dxi) * BLOB + g * PSTR + r16 * 16;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const bf16x8 bh = *(const bf16x8*)(bs + nt * 256);
-            const bf16x8 bl = *(const bf16x8*)(bs + nt * 256 + BLOB / 2);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, fl, acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, fh, acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, fh, acc[mt][nt], 0, 0, 0);
+            bf16x8 bl = bh;
+            if (X3) bl = *(const bf16x8*)(bs + nt * 256 + 4 * PSTR);
+            acc[mt][nt] = c1_mfma<PREC>(bh, bl, fh, fl, acc[mt][nt]);
           }
         }
         __builtin_amdgcn_sched_barrier(0);     // keep the weight-fragment reads of later taps from being hoisted (registers)
@@ -433,7 +454,7 @@ __global__ __launch_bounds__(512, NT_ > 4 ? 2 : 4) void conv3x3_direct_kernel(C1
     }
     chan = chan_next;
   }
-  c1_epilogue<MT, NT, true>(a, acc, red, b, mblk, ntile, 0, oy0, ox, tid, wave, r16, g);
+  c1_epilogue<MT, NT, true, (X3 && NT <= 4)>(a, acc, red, b, mblk, ntile, 0, oy0, ox, tid, wave, r16, g);
   }
 }
 
@@ -451,8 +472,13 @@ int ppst_conv1x1_stream_launch(const ppst_conv_args* a, int n_tiles, int tiles, 
   if ((int64_t)tiles * 256 < k.hw) return PPST_EINVAL;
   const int64_t blocks = (int64_t)a->B * tiles * n_tiles;
   if (blocks > 0x7fffffff) return PPST_EINVAL;
-  if (k.in_ss) PPST_LAUNCH(conv1x1_stream_kernel<true>, dim3((unsigned)blocks), dim3(512), 0, st, k);
-  else PPST_LAUNCH(conv1x1_stream_kernel<false>, dim3((unsigned)blocks), dim3(512), 0, st, k);
+#define LS(PREC_)                                                                                                     \
+  do {                                                                                                                \
+    if (k.in_ss) PPST_LAUNCH((conv1x1_stream_kernel<true, false, 4, PREC_>), dim3((unsigned)blocks), dim3(512), 0, st, k);   \
+    else PPST_LAUNCH((conv1x1_stream_kernel<false, false, 4, PREC_>), dim3((unsigned)blocks), dim3(512), 0, st, k);          \
+  } while (0)
+  if (a->precision == 1) LS(1); else if (a->precision == 3) LS(3); else LS(0);
+#undef LS
   return PPST_LAUNCH_CHECK();
 }
 
@@ -470,12 +496,14 @@ int ppst_conv_direct_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, i
   const int64_t blocks = (int64_t)a->B * k.tiles * n_tiles;
   if (blocks > 0x7fffffff) return PPST_EINVAL;
   const bool nt2 = a->cout <= 32;
-#define LD(INSS_)                                                                                                    \
+#define LD(INSS_, PREC_)                                                                                             \
   do {                                                                                                               \
-    if (nt2) PPST_LAUNCH((conv1x1_stream_kernel<INSS_, true, 2>), dim3((unsigned)blocks), dim3(512), 0, st, k);       \
-    else PPST_LAUNCH((conv1x1_stream_kernel<INSS_, true, 4>), dim3((unsigned)blocks), dim3(512), 0, st, k);           \
+    if (nt2) PPST_LAUNCH((conv1x1_stream_kernel<INSS_, true, 2, PREC_>), dim3((unsigned)blocks), dim3(512), 0, st, k);       \
+    else PPST_LAUNCH((conv1x1_stream_kernel<INSS_, true, 4, PREC_>), dim3((unsigned)blocks), dim3(512), 0, st, k);           \
   } while (0)
-  if (k.in_ss) LD(true); else LD(false);
+#define LDP(PREC_) do { if (k.in_ss) LD(true, PREC_); else LD(false, PREC_); } while (0)
+  if (a->precision == 1) LDP(1); else if (a->precision == 3) LDP(3); else LDP(0);
+#undef LDP
 #undef LD
   return PPST_LAUNCH_CHECK();
 }
@@ -497,13 +525,16 @@ int ppst_conv3x3_direct_launch(const ppst_conv_args* a, int n_tiles, int tiles_y
   // single-chunk layers: persistent blocks (two 8-wave blocks per CU, 72 KB of LDS each) that keep the weights resident
   if (a->nsteps == 9 && n_tiles == 1 && blocks > 512) blocks = 512;
   const bool nt2 = a->cout <= 32, nt8 = a->bn == 128;
-#define LD3(INSS_)                                                                                                   \
+#define LD3(INSS_, PREC_)                                                                                            \
   do {                                                                                                               \
-    if (nt8) PPST_LAUNCH((conv3x3_direct_kernel<INSS_, 8>), dim3((unsigned)blocks), dim3(512), 0, st, k);             \
-    else if (nt2) PPST_LAUNCH((conv3x3_direct_kernel<INSS_, 2>), dim3((unsigned)blocks), dim3(512), 0, st, k);        \
-    else PPST_LAUNCH((conv3x3_direct_kernel<INSS_, 4>), dim3((unsigned)blocks), dim3(512), 0, st, k);                 \
+    if (nt8 && PREC_ == 0) PPST_LAUNCH((conv3x3_direct_kernel<INSS_, 8, 0>), dim3((unsigned)blocks), dim3(512), 0, st, k);   \
+    else if (nt8) return PPST_EUNSUPPORTED;                                                                          \
+    else if (nt2) PPST_LAUNCH((conv3x3_direct_kernel<INSS_, 2, PREC_>), dim3((unsigned)blocks), dim3(512), 0, st, k); \
+    else PPST_LAUNCH((conv3x3_direct_kernel<INSS_, 4, PREC_>), dim3((unsigned)blocks), dim3(512), 0, st, k);          \
   } while (0)
-  if (k.in_ss) LD3(true); else LD3(false);
+#define LD3P(PREC_) do { if (k.in_ss) LD3(true, PREC_); else LD3(false, PREC_); } while (0)
+  if (a->precision == 1) LD3P(1); else if (a->precision == 3) LD3P(3); else LD3P(0);
+#undef LD3P
 #undef LD3
   return PPST_LAUNCH_CHECK();
 }

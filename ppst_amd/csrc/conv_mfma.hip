@@ -742,12 +742,13 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       (a->variant == 7 && (a->bn != 128 || a->tile_rows != 32)) ||
       (a->variant == 2 && a->bn != 256) || (a->variant == 3 && a->bn != 128) ||
       // variant 4 = the 1x1 streaming kernel (conv1x1.hip): all taps (0,0), one group, unit strides, bf16x3, 64-wide blobs
-      (a->variant == 4 && (a->precision != 0 || a->bn != 64 || a->halo != 0 || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
+      (a->variant == 4 && ((a->precision != 0 && a->precision != 1 && a->precision != 3) || a->bn != 64 || a->halo != 0 || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
                            a->in_off_y != 0 || a->in_off_x != 0 || a->tile_h != a->out_h || a->tile_w != a->out_w ||
                            a->in_h != a->out_h || a->in_w != a->out_w)) ||
       // variant 5 = the direct form of the same kernel for thin layers with taps (one group, unit output stride)
       // (6: its register-reuse form for plain 3x3 stride-1 tables: the CALLER promises the (chunk, dy, dx) step order)
-      ((a->variant == 5 || a->variant == 6) && (a->precision != 0 || (a->bn != 64 && !(a->variant == 6 && a->bn == 128)) || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
+      ((a->variant == 5 || a->variant == 6) && ((a->precision != 0 && a->precision != 1 && a->precision != 3) ||
+                                                (a->bn != 64 && !(a->variant == 6 && a->bn == 128 && a->precision == 0)) || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
                            a->in_off_y != 0 || a->in_off_x != 0 || a->tile_h != a->out_h || a->tile_w != a->out_w)) ||
       (a->tile_rows != 16 && !(a->variant == 7 && a->tile_rows == 32)) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
     return PPST_EINVAL;

@@ -410,10 +410,10 @@ class ConvPlan:
                 # Cout in 65..255 (and the 128-wide remainder classes): 8 waves = 4 (M) x 2 (N) of 128 px x 64 ch, block tile
                 # 32 x 16 px x 128 ch, one activation slot (conv_mfma2.hip, WMW = 4)
                 variant, rows = 7, 32
-        if (STREAM_1X1["value"] and self.precision == 0 and self.halo == 0 and self.n_groups == 1 and osy == 1
+        if (STREAM_1X1["value"] and self.precision in (0, 1, 3) and self.halo == 0 and self.n_groups == 1 and osy == 1
                 and (th, tw) == (oh, ow) == (H, W)):
             variant, bn = 4, 64         # 1x1 convs: streaming kernel, no activation staging (conv1x1.hip)
-        elif (self.precision == 0 and self.halo == 1 and self.n_groups == 1 and osy == 1 and (th, tw) == (oh, ow)
+        elif (self.precision in (0, 1, 3) and self.halo == 1 and self.n_groups == 1 and osy == 1 and (th, tw) == (oh, ow)
               and self.cout <= DIRECT_MAX["cout"] and self.nsteps <= DIRECT_MAX["nsteps"]):
             # thin layers: direct form of the streaming kernel; plain 3x3 stride-1 tables (order (chunk, dy, dx)) on its
             # register-reuse form

@@ -381,6 +381,29 @@ def t_conv_variants_single_pass():
             RES.append(("single-pass precision %d N=256 %s bit-identical" % (prec, name), ok))
             print("single-pass prec %d %-30s %s max diff %.3e" % (prec, name, "ok  " if ok else "FAIL", (outs[0][0] - outs[1][0]).abs().max().item()), flush=True)
             report("single-pass prec %d %s stats" % (prec, name), outs[1][1], outs[0][1], 1e-5)
+        # the streaming kernels (1x1, thin stride-2, thin 3x3) in the same mode
+        dmax, st1 = dict(ops.DIRECT_MAX), ops.STREAM_1X1["value"]
+        for name, B, ci, co, H, Wd, kind, k, pm in (("1x1 128->64 40x48", 2, 128, 64, 40, 48, "conv", 1, 0),
+                                                     ("3x3 reflect 32->32 33x47", 2, 32, 32, 33, 47, "conv", 3, 1),
+                                                     ("3x3 zero 64->64 256x256", 1, 64, 64, 256, 256, "conv", 3, 0),
+                                                     ("s2d 32->64 -> 20x23", 2, 32, 64, 20, 23, "s2d", 3, 0)):
+            w = g(nz_(co, ci, k, k) / math.sqrt(ci * k * k))
+            outs = []
+            for stream in (False, True):
+                ops.STREAM_1X1["value"] = stream
+                ops.DIRECT_MAX["cout"] = dmax["cout"] if stream else 0
+                plan = ops.ConvPlan(w, kind=kind, precision=prec)
+                torch.manual_seed(13)
+                x = g(nz_(B, H + 1, Wd + 1, plan.max_chan + 32)) if kind == "s2d" else g(nz_(B, H, Wd, plan.max_chan + 32))
+                kw = dict(out_hw=(H, Wd)) if kind == "s2d" else {}
+                y, st = plan(x, pad_mode=pm, stats=True, bias=g(torch.arange(co, dtype=torch.float32) * 0.01), act=ops.ACT_LRELU, **kw)
+                outs.append((y.cpu(), st.sum(1).cpu()))
+            ops.STREAM_1X1["value"] = st1
+            ops.DIRECT_MAX.update(dmax)
+            ok = bool(torch.equal(outs[0][0], outs[1][0]))
+            RES.append(("single-pass precision %d stream/direct %s bit-identical" % (prec, name), ok))
+            print("single-pass prec %d %-30s %s max diff %.3e" % (prec, name, "ok  " if ok else "FAIL", (outs[0][0] - outs[1][0]).abs().max().item()), flush=True)
+            report("single-pass prec %d %s stats" % (prec, name), outs[1][1], outs[0][1], 1e-5)
 
 
 def t_conv1x1_stream():
