@@ -351,6 +351,48 @@ class ConvPlan:
         self._packs[bn] = wpack
         return wpack
 
+    def choose_kernel(self, th, tw, oh, ow, H, W, osy):
+        """(variant, N tile, tile rows) of ppst_conv_args for one launch of this plan -- a function of the plan and of ONE
+        image's geometry only.  The batch size is deliberately not an argument: every variant gives bit-identical outputs,
+        but their tile statistics differ in the last bit (other summation tree), and a shard of a batch has to reproduce the
+        whole batch bit for bit (evaluation.grid_exchange; "2 simulated ranks == 1 rank"; tests/test_abi_cpu.py).
+          0  tile kernel (64 px x 64 ch waves), bn 64 / 128;      2  its N-256 form (128 px x 64 ch waves) for Cout % 256 == 0
+          4  1x1 streaming kernel;   5  direct form for thin stride-2 tables;   6  3x3 register-reuse form (thin layers)
+          1 / 3 / 7 and variant 6 with bn 128: measured experiments, off unless a test switches them on."""
+        rows = TILE_ROWS["value"]
+        variant, bn = 0, self.bn
+        single = self.precision in (1, 3)
+        if self.precision not in (0, 1, 3):
+            return variant, bn, rows                     # fp16x2 experiment / exact-fp32 verification: the tile kernel only
+        tiles16 = ((th + 15) // 16) * ((tw + 15) // 16) * self.n_groups          # blocks PER IMAGE per N tile
+        cv = CONV_VARIANT["value"]
+        n256_ok = self.cout % 256 == 0 and tiles16 * (self.cout // 256) >= FAT_MIN_BLOCKS
+        if cv == 1 and not single and self.early_a and self.cout >= 128:
+            variant, bn = 1, (256 if n256_ok else 128)
+        elif cv in (2, 3) and self.early_a:
+            force3 = cv == 3                             # (tests) every eligible plan on the two-block kernel
+            if n256_ok and not force3:
+                variant, bn = 2, 256                     # 8 waves x (128 px x 64 ch), N tile 256 (conv_mfma2.hip, WNW = 4)
+            elif single:
+                pass                                     # single-pass modes: only the N-256 geometry is built for them
+            elif self.bn == 128 and (force3 or (TWO_BLOCK_128["value"] and
+                                                tiles16 * ((self.cout + 127) // 128) >= 2 * FAT_MIN_BLOCKS)):
+                variant = 3                              # two 4-wave blocks per CU, N tile 128, one activation slot
+            elif (self.bn == 128 and TALL_TILE_128["value"] and
+                  ((th + 31) // 32) * ((tw + 15) // 16) * self.n_groups * ((self.cout + 127) // 128) >= TALL_TILE_128["min_blocks"]):
+                variant, rows = 7, 32                    # block tile 32 x 16 px x 128 ch, one activation slot (WMW = 4)
+        same = (th, tw) == (oh, ow)
+        if STREAM_1X1["value"] and self.halo == 0 and self.n_groups == 1 and osy == 1 and same and (oh, ow) == (H, W):
+            variant, bn, rows = 4, 64, TILE_ROWS["value"]            # 1x1 convs: streaming kernel, no activation staging
+        elif (self.halo == 1 and self.n_groups == 1 and osy == 1 and same and self.cout <= DIRECT_MAX["cout"]
+              and self.nsteps <= DIRECT_MAX["nsteps"]):
+            # thin layers: direct form of the streaming kernel; plain 3x3 stride-1 tables (order (chunk, dy, dx)) on its
+            # register-reuse form
+            variant, bn, rows = (6 if (self.kind in ("conv", "dgrad") and self.k == 3) else 5), 64, TILE_ROWS["value"]
+        elif (not single and self.kind in ("conv", "dgrad") and self.k == 3 and 64 < self.cout <= DIRECT_MAX["cout3x3"] and same):
+            variant, bn, rows = 6, 128, TILE_ROWS["value"]           # (experiment) 32 px x 128 ch waves for Cout in 65..128
+        return variant, bn, rows
+
     def __call__(self, x, bias=None, noise=None, noise_weight=0.0, act=ACT_NONE, prelu=None, stats=False,
                  residual=None, out=None, out_scale=1.0, pad_mode=PAD_ZERO, out_hw=None, res_after_act=False,
                  in_ss=None, in_act=ACT_NONE, in_prelu=None):
@@ -385,44 +427,7 @@ class ConvPlan:
             raise RuntimeError("residual must match the output shape %s, got %s" % ((B, oh, ow, self.cout), tuple(residual.shape)))
         for t, n in ((bias, "bias"), (noise, "noise"), (prelu, "prelu"), (residual, "residual")):
             _chk(t, n)
-        rows = TILE_ROWS["value"]
-        # kernel variant / N tile: the fat-wave kernel needs chunks of >= 2 steps (3x3, transposed, stride-2 tables) and
-        # pays off from 128 output channels; its 256-channel tile only when the grid still covers the chip
-        variant, bn = 0, self.bn
-        # blocks PER IMAGE: the choice must not depend on the batch size -- the variants give bit-identical outputs but
-        # their tile statistics differ in the last bit (other summation tree), and a shard of a batch has to reproduce the
-        # whole batch bit for bit (evaluation.grid_exchange, tests: "2 simulated ranks == 1 rank")
-        tiles16 = ((th + 15) // 16) * ((tw + 15) // 16) * self.n_groups
-        if CONV_VARIANT["value"] == 1 and self.precision == 0 and self.early_a and self.cout >= 128:
-            variant = 1
-            bn = 256 if (self.cout % 256 == 0 and tiles16 * (self.cout // 256) >= FAT_MIN_BLOCKS) else 128
-        elif CONV_VARIANT["value"] in (2, 3) and self.precision in (0, 1, 3) and self.early_a:
-            force3 = CONV_VARIANT["value"] == 3          # (tests) every eligible plan on the two-block kernel
-            if self.precision != 0 and not (not force3 and self.cout % 256 == 0 and tiles16 * (self.cout // 256) >= FAT_MIN_BLOCKS):
-                pass                    # single-pass modes: only the N-256 geometry is built for them
-            elif not force3 and self.cout % 256 == 0 and tiles16 * (self.cout // 256) >= FAT_MIN_BLOCKS:
-                variant, bn = 2, 256    # 8 waves x (128 px x 64 ch), N tile 256 (conv_mfma2.hip, WNW = 4)
-            elif self.bn == 128 and (force3 or (TWO_BLOCK_128["value"] and
-                                                tiles16 * ((self.cout + 127) // 128) >= 2 * FAT_MIN_BLOCKS)):
-                variant = 3             # two 4-wave blocks per CU, 128 px x 64 ch wave tiles, N tile 128 (NA_ = 1)
-            elif (self.bn == 128 and TALL_TILE_128["value"] and
-                  ((th + 31) // 32) * ((tw + 15) // 16) * self.n_groups * ((self.cout + 127) // 128) >= TALL_TILE_128["min_blocks"]):
-                # Cout in 65..255 (and the 128-wide remainder classes): 8 waves = 4 (M) x 2 (N) of 128 px x 64 ch, block tile
-                # 32 x 16 px x 128 ch, one activation slot (conv_mfma2.hip, WMW = 4)
-                variant, rows = 7, 32
-        if (STREAM_1X1["value"] and self.precision in (0, 1, 3) and self.halo == 0 and self.n_groups == 1 and osy == 1
-                and (th, tw) == (oh, ow) == (H, W)):
-            variant, bn = 4, 64         # 1x1 convs: streaming kernel, no activation staging (conv1x1.hip)
-        elif (self.precision in (0, 1, 3) and self.halo == 1 and self.n_groups == 1 and osy == 1 and (th, tw) == (oh, ow)
-              and self.cout <= DIRECT_MAX["cout"] and self.nsteps <= DIRECT_MAX["nsteps"]):
-            # thin layers: direct form of the streaming kernel; plain 3x3 stride-1 tables (order (chunk, dy, dx)) on its
-            # register-reuse form
-            variant, bn = (6 if (self.kind in ("conv", "dgrad") and self.k == 3) else 5), 64
-        elif (self.precision == 0 and self.kind in ("conv", "dgrad") and self.k == 3 and 64 < self.cout <= DIRECT_MAX["cout3x3"]
-              and (th, tw) == (oh, ow)):
-            variant, bn = 6, 128        # 3x3 layers with 65..128 output channels: the register-reuse kernel, 32 px x 128 ch waves
-        if variant != 7:
-            rows = TILE_ROWS["value"]           # (a later choice -- stream / direct kernels -- replaced the tall-tile variant)
+        variant, bn, rows = self.choose_kernel(th, tw, oh, ow, H, W, osy)
         st = None
         if stats:
             tiles = lib.ppst_conv_tiles(th, tw, rows)

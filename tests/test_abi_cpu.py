@@ -258,3 +258,40 @@ def test_grid_sharding_work_per_rank():
             if world == 8:
                 assert len(ci) + len(si) == 2 and len(shard_pairs(8, 8, r, world)) == 8
         assert sorted(cs) == list(range(8)) and sorted(ss) == list(range(8)) and len(set(ps)) == 64
+
+
+def test_conv_kernel_choice_is_a_function_of_one_image():
+    """ConvPlan.choose_kernel: which kernel family runs a launch.  All families give bit-identical outputs, but their tile
+    statistics differ in the last bit, so the choice must depend on the plan and ONE image's geometry only (a shard of a batch
+    reproduces the whole batch bit for bit).  Structural: the batch size is not an argument.  Behavioural: the production
+    table of the swap path -- which layers go where -- and the contract that experiments stay off."""
+    import inspect
+    from ppst_amd import ops
+    assert "B" not in inspect.signature(ops.ConvPlan.choose_kernel).parameters
+
+    def plan(kind, cin, cout, k, nsteps, halo, n_groups=1, precision=0, early_a=1):
+        p = ops.ConvPlan.__new__(ops.ConvPlan)
+        p.kind, p.cin, p.cout, p.k, p.nsteps, p.halo, p.n_groups = kind, cin, cout, k, nsteps, halo, n_groups
+        p.precision, p.early_a, p.bn = precision, early_a, (128 if cout >= 128 else 64)
+        return p
+    ck = lambda p, s, osy=1, out=None: p.choose_kernel(s, s, *(out or (s, s)), s, s, osy)
+    # the generator's wide layers: N-256 tile where one image still gives >= 32 blocks
+    assert ck(plan("conv", 256, 256, 3, 72, 1), 256) == (2, 256, 16)
+    assert ck(plan("conv", 512, 512, 3, 144, 1), 128) == (2, 256, 16)
+    assert ck(plan("conv", 256, 256, 3, 72, 1), 64) == (0, 128, 16)              # 16 tiles per image: stays on the tile kernel
+    assert ck(plan("convT", 512, 256, 3, 64, 1, n_groups=4), 128, osy=2, out=(256, 256)) == (2, 256, 16)
+    # Cout = 128 layers: the tile kernel (the measured experiments are off)
+    assert ck(plan("conv", 128, 128, 3, 36, 1), 512) == (0, 128, 16)
+    # 1x1 -> streaming kernel; thin 3x3 -> register-reuse form; thin stride-2 -> direct form
+    assert ck(plan("conv", 128, 64, 1, 4, 0, early_a=0), 512) == (4, 64, 16)
+    assert ck(plan("conv", 256, 128, 1, 8, 0, early_a=0), 256) == (4, 64, 16)
+    assert ck(plan("conv", 32, 32, 3, 9, 1), 512) == (6, 64, 16)
+    assert ck(plan("s2d", 32, 64, 3, 10, 1), 256) == (5, 64, 16)
+    assert ck(plan("s2d", 64, 128, 3, 20, 1), 128) == (0, 128, 16)               # Cout 128: tile kernel
+    # single-pass modes: the N-256 and streaming kernels are built for them, the experiments are not
+    assert ck(plan("conv", 256, 256, 3, 72, 1, precision=3), 256) == (2, 256, 16)
+    assert ck(plan("conv", 32, 32, 3, 9, 1, precision=1), 512) == (6, 64, 16)
+    # fp16x2 experiment and the exact-fp32 verification mode: tile kernel only
+    assert ck(plan("conv", 256, 256, 3, 72, 1, precision=4), 256) == (0, 128, 16)
+    assert ck(plan("conv", 32, 32, 3, 9, 1, precision=2), 512) == (0, 64, 16)
+    assert not ops.TWO_BLOCK_128["value"] and not ops.TALL_TILE_128["value"] and ops.DIRECT_MAX["cout3x3"] == 64
