@@ -180,7 +180,13 @@ typedef struct ppst_conv_args {
                                        the device and is not re-read: the CALLER owns this promise (as with a_slots).
                                     7: conv_mfma2.hip with 8 waves as 4 (M) x 2 (N): block tile 32 x 16 px x 128 ch, one
                                        activation slot; bn = 128, tile_rows = 32, the early_a promise (experiment, measured slower).
-                                    Every variant gives bit-identical outputs; the per-tile statistics differ in the last
+                                    8: conv_ksplit.hip -- bn = 128, the block's 8 waves as 2 (K) x 2 (M) x 2 (N): wave group k
+                                       takes the steps of parity k (wave tile 128 px x 64 ch), the two partial sums meet in
+                                       LDS before the epilogue.  Needs the early_a promise, precision 0, unit output stride
+                                       and steps[i].w bit 2 = parity of the chunk step i belongs to (the activation slot).
+                                       NOT bit-identical to the others (the K sum is split in two: <= 1.1e-6 relative);
+                                       experiment, measured 3-7 % slower than variant 0.
+                                    Variants 0-7 give bit-identical outputs; the per-tile statistics differ in the last
                                     bit between variants (other summation tree).  The library returns PPST_EINVAL for a
                                     variant whose shape conditions do not hold. */
 } ppst_conv_args;

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libppst_hip.so")
-SOURCES = ["upfirdn2d.hip", "fused_bias_act.hip", "elementwise.hip", "linear.hip", "conv_mfma.hip", "conv_mfma2.hip", "conv1x1.hip", "conv_f32.hip",
+SOURCES = ["upfirdn2d.hip", "fused_bias_act.hip", "elementwise.hip", "linear.hip", "conv_mfma.hip", "conv_mfma2.hip", "conv1x1.hip", "conv_ksplit.hip", "conv_f32.hip",
            "corr.hip", "guided_filter.hip", "train.hip", "train_g.hip", "imageio.hip", "smooth_filter.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 

@@ -721,6 +721,7 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
 int ppst_conv1x1_stream_launch(const ppst_conv_args* a, int n_tiles, int tiles, hipStream_t st);                     // conv1x1.hip
 int ppst_conv_direct_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int tiles_x, hipStream_t st);         // conv1x1.hip
 int ppst_conv3x3_direct_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int tiles_x, hipStream_t st);      // conv1x1.hip
+int ppst_conv_ksplit_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int tiles_x, hipStream_t st);         // conv_ksplit.hip
 
 extern "C" int ppst_conv_tiles(int tile_h, int tile_w, int tile_rows) { return cdiv(tile_h, tile_rows) * cdiv(tile_w, 16); }
 
@@ -736,10 +737,13 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       a->out_ld < a->cout || a->cout <= 0 || a->cout % 4 || a->out_ld % 4 || (a->residual && a->res_ld % 4) || a->nsteps <= 0 || (a->n_groups != 1 && a->n_groups != 4) || a->pad_mode < 0 ||
       a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 ||
       (a->precision != 0 && a->precision != 1 && a->precision != 3 && a->precision != 4) || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128 && a->bn != 256) || (a->residual && a->res_ld < a->cout) ||
-      a->variant < 0 || a->variant > 7 || (a->variant == 0 && a->bn == 256) ||
+      a->variant < 0 || a->variant > 8 || (a->variant == 0 && a->bn == 256) ||
       ((a->variant >= 1 && a->variant <= 3 || a->variant == 7) &&
        ((a->precision != 0 && !(a->variant == 2 && (a->precision == 1 || a->precision == 3))) || a->bn == 64 || !a->early_a)) ||
       (a->variant == 7 && (a->bn != 128 || a->tile_rows != 32)) ||
+      // variant 8 = conv_ksplit.hip: two K-groups of four 128 px x 64 ch waves; bn = 128, bf16x3, chunks of >= 2 steps (and the
+      // caller's promise: 2-step chunks start at even steps, steps[i].w bit 2 = parity of step i's chunk index)
+      (a->variant == 8 && (a->precision != 0 || a->bn != 128 || !a->early_a)) ||
       (a->variant == 2 && a->bn != 256) || (a->variant == 3 && a->bn != 128) ||
       // variant 4 = the 1x1 streaming kernel (conv1x1.hip): all taps (0,0), one group, unit strides, bf16x3, 64-wide blobs
       (a->variant == 4 && ((a->precision != 0 && a->precision != 1 && a->precision != 3) || a->bn != 64 || a->halo != 0 || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
@@ -796,6 +800,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
     int e2 = a->variant == 4   ? ppst_conv1x1_stream_launch(a, k.n_tiles, k.tiles_y * k.tiles_x, st)
              : a->variant == 5 ? ppst_conv_direct_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st)
              : a->variant == 6 ? ppst_conv3x3_direct_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st)
+             : a->variant == 8 ? ppst_conv_ksplit_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st)
                                : ppst_conv2d_mfma2_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st);
     if (slot >= 0) (void)hipEventRecord(g_ev[slot][1], st);
     return e2;

@@ -33,6 +33,10 @@ DIRECT_MAX = {"cout": 64, "nsteps": 40, "cout3x3": 64}   # cout3x3 = 128 was mea
 WGRAD_SPLIT = {"blocks": 1024, "min_tiles": 4}   # conv_wgrad: target block count of a launch, fewest pixel tiles per block
 WGRAD_X3 = {"value": True}         # conv weight gradients on the bf16 matrix pipe (hi/lo split), exact fp32 with precision 2
 STREAM_1X1 = {"value": True}       # 1x1 convs (halo 0) on the streaming kernel of conv1x1.hip
+# variant 8 (conv_ksplit.hip: the block's waves split K in two, 128 px x 64 ch wave tiles, two activation slots) for the
+# Cout = 128-class layers when one image gives >= min_blocks: measured 3-7 % SLOWER than the tile kernel (128->128 @512^2
+# 342-348 vs 358-368 TFLOP/s; in-kernel trace: step pair 5 750 cycles against an issue floor of 3 072) and not bit-identical -- off
+KSPLIT_128 = {"value": False, "min_blocks": 32}
 # variant 7 (32 x 16 px x 128 ch blocks, conv_mfma2.hip WMW = 4) when one image gives >= min_blocks: measured 3-5 % SLOWER than
 # the tile kernel on the Cout = 128 layers (one activation slot: the chunk store sits between two barriers; 33-44 spills) -- off
 TALL_TILE_128 = {"value": False, "min_blocks": 32}
@@ -311,13 +315,20 @@ class ConvPlan:
         # offset (lets the kernel request a chunk's activations a step early when every chunk spans >= 2 steps)
         ns_ = self.nsteps
         enc = []
+        chunk_idx = -1
         for i, (c_, dy_, dx_, f_) in enumerate(steps):
+            if i % ns_ == 0:
+                chunk_idx = -1                   # the chunk count restarts with every group
+            chunk_idx += 1 if f_ else 0
             nxt = steps[i + 1] if (i + 1) % ns_ != 0 else None
-            w_ = f_ | ((2 | (nxt[0] << 8)) if (nxt is not None and nxt[3]) else 0)
+            # bit 2 = parity of this step's chunk index within its group (the activation-ring slot of conv_ksplit.hip)
+            w_ = f_ | ((2 | (nxt[0] << 8)) if (nxt is not None and nxt[3]) else 0) | ((chunk_idx & 1) << 2)
             enc.append((c_, dy_, dx_, w_))
         starts = [i for i, t in enumerate(steps) if t[3] == 1] + [len(steps)]
         lens = [b_ - a_ for a_, b_ in zip(starts[:-1], starts[1:])]
         self.early_a = 1 if (min(lens) >= 2 and ns_ >= 3) else 0
+        # conv_ksplit.hip stores a chunk one step PAIR before its first use: a 2-step chunk must not straddle two pairs
+        self.ksplit_ok = bool(self.early_a and all(l_ >= 3 or (a_ % ns_) % 2 == 0 for a_, l_ in zip(starts[:-1], lens)))
         # 4 padding rows: the kernel prefetches the descriptor of step s+3 without a bounds test
         self.steps = torch.tensor(enc + [(0, 0, 0, 0)] * 4, dtype=torch.int32, device=dev).contiguous()
         s = torch.tensor(src, dtype=torch.int32, device=dev)
@@ -378,6 +389,9 @@ class ConvPlan:
             elif self.bn == 128 and (force3 or (TWO_BLOCK_128["value"] and
                                                 tiles16 * ((self.cout + 127) // 128) >= 2 * FAT_MIN_BLOCKS)):
                 variant = 3                              # two 4-wave blocks per CU, N tile 128, one activation slot
+            elif (self.bn == 128 and KSPLIT_128["value"] and getattr(self, "ksplit_ok", False)
+                  and tiles16 * ((self.cout + 127) // 128) >= KSPLIT_128["min_blocks"]):
+                variant = 8                              # two K-groups of 128 px x 64 ch waves, N tile 128 (conv_ksplit.hip)
             elif (self.bn == 128 and TALL_TILE_128["value"] and
                   ((th + 31) // 32) * ((tw + 15) // 16) * self.n_groups * ((self.cout + 127) // 128) >= TALL_TILE_128["min_blocks"]):
                 variant, rows = 7, 32                    # block tile 32 x 16 px x 128 ch, one activation slot (WMW = 4)

@@ -23,6 +23,8 @@ if len(sys.argv) > 8:
     ops.DIRECT_MAX["cout3x3"] = int(sys.argv[8])
 if len(sys.argv) > 9:
     ops.TALL_TILE_128["value"] = bool(int(sys.argv[9]))
+if len(sys.argv) > 10:
+    ops.KSPLIT_128["value"] = bool(int(sys.argv[10]))
 dev = torch.device("cuda", 0)
 sd = W.make_state_dict(0, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
 m = create_model(state_dict=sd, device=dev)

@@ -8,6 +8,7 @@ sys.path.insert(0, ROOT)
 from ppst_amd import ops
 TRB, TRS, NW = 8, 160, 8
 shapes = [(8, 256, 256, 256, 3, "conv"), (8, 512, 512, 128, 3, "conv"), (8, 512, 256, 128, 3, "convT")]
+# (shapes with 128 output channels run the K-split kernel, variant 8, when ops.KSPLIT_128 is on: records are per step PAIR)
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in sys.argv[1:6]) + (sys.argv[6],)]
 for (B, ci, co, H, k, kind) in shapes:
@@ -26,7 +27,8 @@ for (B, ci, co, H, k, kind) in shapes:
     e0.record(); plan(x, prelu=dbg); e1.record()
     ops._chk = chk
     torch.cuda.synchronize()
-    ns = min(plan.nsteps, TRS)
+    ksplit = plan.bn == 128 and ops.KSPLIT_128["value"] and getattr(plan, "ksplit_ok", False)
+    ns = min((plan.nsteps + 1) // 2 if ksplit else plan.nsteps, TRS)
     d = dbg[:TRB * NW * TRS * 8].view(TRB, NW, TRS, 8).cpu().numpy()[:, :, :ns].astype(np.int64)
     se = dbg[TRB * NW * TRS * 8:].view(TRB, 2).cpu().numpy().astype(np.int64)
     print("\n%s %d->%d @%d k%d nsteps %d: kernel %.3f ms" % (kind, ci, co, H, k, plan.nsteps, e0.elapsed_time(e1)))

@@ -329,10 +329,12 @@ def t_conv_variants():
         outs = {}
         # 8-wave; fat N=128; fat N=256; 8-wave 128x64 tiles N=256; two 4-wave blocks per CU, 128x64 tiles, N=128
         tall = dict(ops.TALL_TILE_128)
-        for variant, minb in ((0, 384), (1, 1 << 30), (1, 0), (2, 0), (3, 0), (7, 0)):
+        ksp = dict(ops.KSPLIT_128)
+        for variant, minb in ((0, 384), (1, 1 << 30), (1, 0), (2, 0), (3, 0), (7, 0), (8, 0)):
             ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = variant, minb
             ops.TALL_TILE_128.update(value=variant == 7, min_blocks=0)
-            if variant == 7:      # the 32 x 16-pixel-tile kernel on every 128-wide plan (the N-256 tile switched off)
+            ops.KSPLIT_128.update(value=variant == 8, min_blocks=0)
+            if variant in (7, 8):  # the 32 x 16-pixel-tile / the K-split kernel on every 128-wide plan (the N-256 tile switched off)
                 ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = 2, 1 << 30
             plan = ops.ConvPlan(w, kind=kind)
             cin_eff = plan.max_chan + 32
@@ -351,6 +353,11 @@ def t_conv_variants():
             outs[(variant, minb)] = (y.cpu(), st.sum(1).cpu())
         ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = CONV_DEFAULTS
         ops.TALL_TILE_128.update(tall)
+        ops.KSPLIT_128.update(ksp)
+        # the K-split kernel adds an even-step and an odd-step partial sum: not bit-identical, 2e-6 of the largest output
+        y8, s8 = outs[(8, 0)]
+        report("K-split conv (variant 8) %s vs tile kernel" % name, y8, outs[(0, 384)][0], 2e-6)
+        report("K-split conv (variant 8) %s stats" % name, s8, outs[(0, 384)][1], 1e-5)
         y0, s0 = outs[(0, 384)]
         for key, tag in (((1, 1 << 30), "N=128"), ((1, 0), "N=256|128"), ((2, 0), "8w N=256"), ((3, 0), "2blk N=128"), ((7, 0), "32x16 N=128")):
             y1, s1 = outs[key]
@@ -440,6 +447,8 @@ def t_conv1x1_stream():
         ("s2d 32->64 -> 256x256", 2, 32, 64, 256, 256, "s2d", 3, 0, "plain"),
     ]
     dmax = dict(ops.DIRECT_MAX)
+    ksp = dict(ops.KSPLIT_128)
+    ops.KSPLIT_128["value"] = False      # the reference side of these bit-identity checks is the tile kernel (K-split is not bit-identical)
     for name, B, ci, co, H, Wd, kind, k, pm, feat in cases:
         w = g(nz_(co, ci, k, k) / math.sqrt(ci * k * k))
         outs = {}
@@ -469,6 +478,7 @@ def t_conv1x1_stream():
         RES.append(("stream/direct %s bit-identical" % name, bool(torch.equal(y0, y1))))
         print("stream/direct %-46s %s max diff %.3e" % (name, "ok  " if torch.equal(y0, y1) else "FAIL", (y0 - y1).abs().max().item()), flush=True)
         report("stream/direct %s stats" % name, s1, s0, 1e-5)
+    ops.KSPLIT_128.update(ksp)
 
 
 STREAM_DEFAULT = ops.STREAM_1X1["value"]
