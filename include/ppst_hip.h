@@ -126,7 +126,8 @@ typedef struct ppst_conv_args {
   const void* wpack;    /* from ppst_conv_pack */
   const void* steps;    /* device array ppst_conv_step[n_groups*nsteps + 4]: 4 padding entries at the end (the kernel
                            prefetches the descriptor of step s+3 without a bounds test; their content is ignored) */
-  void* y;              /* NHWC fp32 output, pixel stride out_ld floats */
+  void* y;              /* NHWC fp32 output, pixel stride out_ld floats; one image (out_h * out_w * out_ld, and the same with
+                           res_ld) must stay below 2^31 elements: the epilogues address inside an image with 32-bit offsets */
   const void* bias;     /* [cout] or NULL (sum of all per-channel biases) */
   const void* noise;    /* [B][out_h][out_w] or NULL (NoiseInjection, stylegan2_layers.py:376-399) */
   const void* prelu;    /* [1] PReLU slope (device) when act == PPST_ACT_PRELU */
@@ -153,7 +154,7 @@ typedef struct ppst_conv_args {
   const void* in_prelu;          /* [1] slope when in_act == PPST_ACT_PRELU */
   int32_t in_c, in_act;          /* channel count of the in_scale_shift table; PPST_ACT_* */
   int32_t flop_steps;            /* steps that carry real weights (profiling only; 0 = nsteps) */
-  int32_t tile_rows;             /* (32 only with variant 7) 16: 16x16-pixel tiles, 512- (bn 128) / 256-thread blocks, 1 block per CU;
+  int32_t tile_rows;             /* (32 only with variant 7, 24 only with variant 9) 16: 16x16-pixel tiles, 512- (bn 128) / 256-thread blocks, 1 block per CU;
                                     8:  8x16-pixel tiles, 256- / 128-thread blocks, 2 blocks per CU -- with halo=1
                                     every chunk of the step table must then span >= 2 steps */
   int32_t a_slots;               /* depth of the activation-tile ring in LDS: 0 = default (3).  1 or 2 may be given when
@@ -186,7 +187,11 @@ typedef struct ppst_conv_args {
                                        and steps[i].w bit 2 = parity of the chunk step i belongs to (the activation slot).
                                        NOT bit-identical to the others (the K sum is split in two: <= 1.1e-6 relative);
                                        experiment, measured 3-7 % slower than variant 0.
-                                    Variants 0-7 give bit-identical outputs; the per-tile statistics differ in the last
+                                    9: conv_mfma2.hip with 6 m-tiles per wave: block tile 24 x 16 px x 128 ch (wave tile 96 px x 64 ch),
+                                       TWO activation slots; bn = 128, tile_rows = 24, the early_a promise, precision 0
+                                       (experiment: bit-identical, +-1.5 % of variant 0 -- the 36-step tiles of the Cout = 128
+                                       layers are prologue / epilogue bound, not wave-tile bound).
+                                    Variants 0-7 and 9 give bit-identical outputs; the per-tile statistics differ in the last
                                     bit between variants (other summation tree).  The library returns PPST_EINVAL for a
                                     variant whose shape conditions do not hold. */
 } ppst_conv_args;

@@ -475,6 +475,33 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   float* tw = (float*)smem + wave * EPI_TILE;            // main-loop buffers are dead: last barrier passed
   float* red = (float*)smem + (NT / 64) * EPI_TILE;      // [WM][BN][2]
   const int f8 = lane & 7, prow = lane >> 3;
+  // Output addressing: 32-bit element offsets inside image b (the entry point rejects images of >= 2^31 elements); the tile row
+  // and the column half of a store are wave-uniform, so their strides are scalar.  (With `opix` as a 64-bit product per store
+  // the epilogue was bound by v_mul_lo_u32 / v_mad_u64_u32: ~45 vector instructions per store, a third of them quarter-rate.)
+  const int egy = a.n_groups > 1 ? gy : 0, egx = a.n_groups > 1 ? gx : 0;
+  const int tyb = ty0 + wm * 4, oyb = tyb * a.out_sy + egy;               // first tile / output row of this wave (uniform)
+  const int txl = tx0 + prow, oxl = txl * a.out_sx + egx;                 // this lane's column for even `it` (odd: 8 further)
+  const bool okx0 = txl < a.tile_w && oxl < a.out_w, okx1 = txl + 8 < a.tile_w && oxl + 8 * a.out_sx < a.out_w;
+  const int pix0 = oyb * a.out_w + oxl, rs_pix = a.out_sy * a.out_w;
+  const int64_t img = (int64_t)b * a.out_h * a.out_w;
+  float* const yb = a.y + img * a.out_ld;
+  const float* const nzb = a.noise ? a.noise + img : nullptr;
+  const float* const rb = a.residual ? a.residual + img * a.res_ld : nullptr;
+  // Bias and noise of the whole wave tile are fetched BEFORE the first store: vmcnt counts stores too and retires in order, so a
+  // load issued behind a pass's stores made its s_waitcnt sit out their acknowledgements (one HBM round trip per pass).
+  float nzv[8];
+  float4 bva[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = i >> 1, c8 = i & 1;
+    const bool ok = tyb + r < a.tile_h && oyb + r * a.out_sy < a.out_h && (c8 ? okx1 : okx0);
+    nzv[i] = (nzb && ok) ? a.noise_weight * nzb[pix0 + r * rs_pix + c8 * 8 * a.out_sx] : 0.f;
+  }
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int n0 = ntile * BN + wn * 64 + pass * 32 + f8 * 4;
+    bva[pass] = (n0 < a.cout && a.bias) ? *(const float4*)(a.bias + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   // The passes are instantiated per (activation, residual mode): as run-time values they cost ~30 VALU instructions per element
   // (both activation branches evaluated and selected), ~10 when specialised (conv_mfma2.hip).
   auto epi_passes = [&](auto act_c, auto res_c) {
@@ -493,21 +520,21 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     const int nl0 = wn * 64 + pass * 32 + f8 * 4;
     const int n0 = ntile * BN + nl0;
     const bool nok = n0 < a.cout;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (nok && a.bias) bv = *(const float4*)(a.bias + n0);
+    const float4 bv = bva[pass];
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int yo0 = pix0 * a.out_ld + n0, ro0 = pix0 * a.res_ld + n0;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int p = it * 8 + prow;
-      const int ty = ty0 + wm * 4 + (p >> 4), tx = tx0 + (p & 15);
+      const int r = it >> 1, c8 = it & 1;              // tile row p >> 4 and column half (p & 15) >> 3 of this store
       float4 v = *(const float4*)(tw + p * 36 + f8 * 4);
-      if (nok && ty < a.tile_h && tx < a.tile_w) {
-        const int oy = ty * a.out_sy + (a.n_groups > 1 ? gy : 0), ox = tx * a.out_sx + (a.n_groups > 1 ? gx : 0);
-        if (oy >= a.out_h || ox >= a.out_w) continue;  // odd scattered extents (input gradient of a stride-2 conv)
-        const int64_t opix = ((int64_t)b * a.out_h + oy) * a.out_w + ox;
-        float nz = a.noise ? a.noise_weight * a.noise[opix] : 0.f;
+      // (oy / ox bounds: odd scattered extents -- the input gradient of a stride-2 conv)
+      const bool rowok = tyb + r < a.tile_h && oyb + r * a.out_sy < a.out_h;
+      if (nok && rowok && (c8 ? okx1 : okx0)) {
+        const int d = r * rs_pix + c8 * 8 * a.out_sx;  // uniform pixel step from (row 0, even column half)
+        const float nz = nzv[it];
         float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (RES) rv = *(const float4*)(a.residual + opix * a.res_ld + n0);
+        if (RES) rv = *(const float4*)(rb + (ro0 + d * a.res_ld));
         float o[4] = {v.x + bv.x + nz, v.y + bv.y + nz, v.z + bv.z + nz, v.w + bv.w + nz};
         const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
@@ -519,7 +546,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
           if (RES == 2) t += r4[c];
           o[c] = t * a.out_scale;
         }
-        *(float4*)(a.y + opix * a.out_ld + n0) = make_float4(o[0], o[1], o[2], o[3]);
+        *(float4*)(yb + (yo0 + d * a.out_ld)) = make_float4(o[0], o[1], o[2], o[3]);
         s1.x += o[0]; s1.y += o[1]; s1.z += o[2]; s1.w += o[3];
         s2.x += o[0] * o[0]; s2.y += o[1] * o[1]; s2.z += o[2] * o[2]; s2.w += o[3] * o[3];
       }
@@ -737,10 +764,12 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       a->out_ld < a->cout || a->cout <= 0 || a->cout % 4 || a->out_ld % 4 || (a->residual && a->res_ld % 4) || a->nsteps <= 0 || (a->n_groups != 1 && a->n_groups != 4) || a->pad_mode < 0 ||
       a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 ||
       (a->precision != 0 && a->precision != 1 && a->precision != 3 && a->precision != 4) || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128 && a->bn != 256) || (a->residual && a->res_ld < a->cout) ||
-      a->variant < 0 || a->variant > 8 || (a->variant == 0 && a->bn == 256) ||
-      ((a->variant >= 1 && a->variant <= 3 || a->variant == 7) &&
+      a->variant < 0 || a->variant > 9 || (a->variant == 0 && a->bn == 256) ||
+      ((a->variant >= 1 && a->variant <= 3 || a->variant == 7 || a->variant == 9) &&
        ((a->precision != 0 && !(a->variant == 2 && (a->precision == 1 || a->precision == 3))) || a->bn == 64 || !a->early_a)) ||
       (a->variant == 7 && (a->bn != 128 || a->tile_rows != 32)) ||
+      // variant 9 = conv_mfma2.hip with 6 m-tiles per wave: block tile 24 x 16 px x 128 ch, two activation slots
+      (a->variant == 9 && (a->bn != 128 || a->tile_rows != 24)) ||
       // variant 8 = conv_ksplit.hip: two K-groups of four 128 px x 64 ch waves; bn = 128, bf16x3, chunks of >= 2 steps (and the
       // caller's promise: 2-step chunks start at even steps, steps[i].w bit 2 = parity of step i's chunk index)
       (a->variant == 8 && (a->precision != 0 || a->bn != 128 || !a->early_a)) ||
@@ -754,7 +783,10 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       ((a->variant == 5 || a->variant == 6) && ((a->precision != 0 && a->precision != 1 && a->precision != 3) ||
                                                 (a->bn != 64 && !(a->variant == 6 && a->bn == 128 && a->precision == 0)) || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
                            a->in_off_y != 0 || a->in_off_x != 0 || a->tile_h != a->out_h || a->tile_w != a->out_w)) ||
-      (a->tile_rows != 16 && !(a->variant == 7 && a->tile_rows == 32)) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
+      (a->tile_rows != 16 && !(a->variant == 7 && a->tile_rows == 32) && !(a->variant == 9 && a->tile_rows == 24)) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
+    return PPST_EINVAL;
+  // the epilogues address one image with 32-bit element offsets
+  if ((int64_t)a->out_h * a->out_w * a->out_ld > 0x7fffffff || (a->residual && (int64_t)a->out_h * a->out_w * a->res_ld > 0x7fffffff))
     return PPST_EINVAL;
   // the scattered output must reach into the output tensor (elements beyond it are dropped)
   if ((a->tile_h - 1) * a->out_sy >= a->out_h || (a->tile_w - 1) * a->out_sx >= a->out_w) return PPST_EINVAL;

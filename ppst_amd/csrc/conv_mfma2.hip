@@ -82,13 +82,16 @@ __device__ __forceinline__ int pad_index2(int i, int n, int mode) {
 // of ops.set_precision: one plane set in LDS, one MFMA) -- instantiated for the production geometry (variant 2) only.
 typedef _Float16 __attribute__((ext_vector_type(8))) half8_2;
 __device__ __forceinline__ unsigned short f2h_2(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
-template <int NT, int HALO, bool INSS, int WNW = 2, bool BDB = true, int NA_ = 2, int WMW = 2, int PREC = 0>
+// MT_: m-tiles (16-pixel rows) per wave.  6 (with WMW = 4, WNW = 2, NT = 4, BDB = false, NA_ = 2): block tile 24 x 16 px x 128 ch,
+// wave tile 96 px x 64 ch (variant 9) -- the largest wave tile for Cout = 128 layers whose activation ring still has TWO slots
+// (2 x 60 KB + 32 KB of weights = 152 KB): 20 ds_read_b128 per 72 MFMAs, and the chunk store overlaps the MFMAs as in variant 2.
+template <int NT, int HALO, bool INSS, int WNW = 2, bool BDB = true, int NA_ = 2, int WMW = 2, int PREC = 0, int MT_ = 8>
 __global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 1) void conv_mfma2_kernel(Conv2KArgs a) {
   constexpr bool X3 = PREC == 0;
   constexpr int NWV = WMW * WNW;                          // waves per block
   constexpr int NTH = 64 * NWV;
-  constexpr int MT = 8;                                   // m-tiles (16-pixel rows) per wave
-  constexpr int TH = 8 * WMW, TW = 16;
+  constexpr int MT = MT_;                                 // m-tiles (16-pixel rows) per wave
+  constexpr int TH = MT * WMW, TW = 16;
   constexpr int HH = TH + 2 * HALO, HW = TW + 2 * HALO, HP = HH * HW;
   constexpr int PLANE = ((HP * 16 + 255) / 256) * 256;    // bytes
   constexpr int ABUF = (X3 ? 8 : 4) * PLANE;              // hi g0..3 [, lo g0..3]
@@ -377,6 +380,30 @@ __global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 
   float* tw = (float*)smem + wave * EPI_TILE;
   float* red = (float*)smem + NWV * EPI_TILE;          // [2 (wm)][BN][2]
   const int f8 = lane & 7, prow = lane >> 3;
+  // output addressing as in conv_mfma.hip: 32-bit element offsets inside image b, row / column-half strides wave-uniform
+  const int egy = a.n_groups > 1 ? gy : 0, egx = a.n_groups > 1 ? gx : 0;
+  const int tyb = ty0 + wm * MT, oyb = tyb * a.out_sy + egy;
+  const int txl = tx0 + prow, oxl = txl * a.out_sx + egx;
+  const bool okx0 = txl < a.tile_w && oxl < a.out_w, okx1 = txl + 8 < a.tile_w && oxl + 8 * a.out_sx < a.out_w;
+  const int pix0 = oyb * a.out_w + oxl, rs_pix = a.out_sy * a.out_w;
+  const int64_t img = (int64_t)b * a.out_h * a.out_w;
+  float* const yb = a.y + img * a.out_ld;
+  const float* const nzb = a.noise ? a.noise + img : nullptr;
+  const float* const rb = a.residual ? a.residual + img * a.res_ld : nullptr;
+  // bias and noise of the whole wave tile fetched before the first store (vmcnt counts stores and retires in order: conv_mfma.hip)
+  float nzv[2 * MT];
+  float4 bva[NT / 2];
+#pragma unroll
+  for (int i = 0; i < 2 * MT; ++i) {
+    const int r = i >> 1, c8 = i & 1;
+    const bool ok = tyb + r < a.tile_h && oyb + r * a.out_sy < a.out_h && (c8 ? okx1 : okx0);
+    nzv[i] = (nzb && ok) ? a.noise_weight * nzb[pix0 + r * rs_pix + c8 * 8 * a.out_sx] : 0.f;
+  }
+#pragma unroll
+  for (int pass = 0; pass < NT / 2; ++pass) {
+    const int n0 = ntile * BN + wn * (16 * NT) + pass * 32 + f8 * 4;
+    bva[pass] = (n0 < a.cout && a.bias) ? *(const float4*)(a.bias + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   float4 s1a[NT / 2], s2a[NT / 2];
 #pragma unroll
   for (int i = 0; i < NT / 2; ++i) { s1a[i] = make_float4(0.f, 0.f, 0.f, 0.f); s2a[i] = s1a[i]; }
@@ -387,7 +414,8 @@ __global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 
 #pragma clang fp contract(off)   // no fused multiply-add here: every kernel family's epilogue must round like the others'
     const int ACT = act_c.value, RES = res_c.value;   // RES: 0 none, 1 joins before the activation, 2 after
 #pragma unroll
-  for (int mh = 0; mh < MT / 4; ++mh) {
+  for (int mh = 0; mh < (MT + 3) / 4; ++mh) {
+    const int MG = MT - mh * 4 < 4 ? MT - mh * 4 : 4;     // m-tiles of this group (MT = 6: 4 + 2)
 #pragma unroll
     for (int pass = 0; pass < NT / 2; ++pass) {
 #pragma unroll
@@ -395,26 +423,27 @@ __global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 
 #pragma unroll
         for (int ntl = 0; ntl < 2; ++ntl)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) tw[(mt * 16 + g * 4 + j) * 36 + ntl * 16 + r16] = acc[mh * 4 + mt][pass * 2 + ntl][j];
+          for (int j = 0; j < 4; ++j)
+            if (mt < MG) tw[(mt * 16 + g * 4 + j) * 36 + ntl * 16 + r16] = acc[mh * 4 + mt < MT ? mh * 4 + mt : 0][pass * 2 + ntl][j];
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_wave_barrier();
       const int nl0 = wn * (16 * NT) + pass * 32 + f8 * 4;
       const int n0 = ntile * BN + nl0;
       const bool nok = n0 < a.cout;
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (nok && a.bias) bv = *(const float4*)(a.bias + n0);
+      const float4 bv = bva[pass];
+      const int yo0 = pix0 * a.out_ld + n0, ro0 = pix0 * a.res_ld + n0;
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
+        if (it >= 2 * MG) continue;
         const int p = it * 8 + prow;
-        const int ty = ty0 + wm * MT + mh * 4 + (p >> 4), tx = tx0 + (p & 15);
+        const int r = mh * 4 + (it >> 1), c8 = it & 1;   // tile row of the wave and column half of this store
         float4 v = *(const float4*)(tw + p * 36 + f8 * 4);
-        if (nok && ty < a.tile_h && tx < a.tile_w) {
-          const int oy = ty * a.out_sy + (a.n_groups > 1 ? gy : 0), ox = tx * a.out_sx + (a.n_groups > 1 ? gx : 0);
-          if (oy >= a.out_h || ox >= a.out_w) continue;
-          const int64_t opix = ((int64_t)b * a.out_h + oy) * a.out_w + ox;
-          float nz = a.noise ? a.noise_weight * a.noise[opix] : 0.f;
+        const bool rowok = tyb + r < a.tile_h && oyb + r * a.out_sy < a.out_h;
+        if (nok && rowok && (c8 ? okx1 : okx0)) {
+          const int d = r * rs_pix + c8 * 8 * a.out_sx;
+          const float nz = nzv[mh * 8 + it];
           float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (RES) rv = *(const float4*)(a.residual + opix * a.res_ld + n0);
+          if (RES) rv = *(const float4*)(rb + (ro0 + d * a.res_ld));
           float o[4] = {v.x + bv.x + nz, v.y + bv.y + nz, v.z + bv.z + nz, v.w + bv.w + nz};
           const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
@@ -426,7 +455,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 
             if (RES == 2) t += r4[c];
             o[c] = t * a.out_scale;
           }
-          *(float4*)(a.y + opix * a.out_ld + n0) = make_float4(o[0], o[1], o[2], o[3]);
+          *(float4*)(yb + (yo0 + d * a.out_ld)) = make_float4(o[0], o[1], o[2], o[3]);
           s1a[pass].x += o[0]; s1a[pass].y += o[1]; s1a[pass].z += o[2]; s1a[pass].w += o[3];
           s2a[pass].x += o[0] * o[0]; s2a[pass].y += o[1] * o[1]; s2a[pass].z += o[2] * o[2]; s2a[pass].w += o[3] * o[3];
         }
@@ -520,6 +549,11 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
     if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 1, 4>), dim3(blocks), dim3(512), 0, st, k);   \
     else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 1, 4>), dim3(blocks), dim3(512), 0, st, k);          \
   } while (0)
+#define L9(HALO_)                                                                                               \
+  do {                                                                                                          \
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 2, 4, 0, 6>), dim3(blocks), dim3(512), 0, st, k);   \
+    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 2, 4, 0, 6>), dim3(blocks), dim3(512), 0, st, k);          \
+  } while (0)
 #define L2P(HALO_, PREC_)                                                                                       \
   do {                                                                                                          \
     if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 4, false, 2, 2, PREC_>), dim3(blocks), dim3(512), 0, st, k);   \
@@ -527,7 +561,9 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
   } while (0)
   if (a->variant == 2 && a->precision == 1) { if (a->halo) L2P(1, 1); else L2P(0, 1); }
   else if (a->variant == 2 && a->precision == 3) { if (a->halo) L2P(1, 3); else L2P(0, 3); }
-  else if (a->variant == 7) {                 // 8 waves = 4 (M) x 2 (N), wave tile 128 px x 64 ch, block 32 x 16 px x 128 ch, one slot
+  else if (a->variant == 9) {                 // 8 waves = 4 (M) x 2 (N), wave tile 96 px x 64 ch, block 24 x 16 px x 128 ch, two slots
+    if (a->halo) L9(1); else L9(0);
+  } else if (a->variant == 7) {                 // 8 waves = 4 (M) x 2 (N), wave tile 128 px x 64 ch, block 32 x 16 px x 128 ch, one slot
     if (a->halo) L7(1); else L7(0);
   } else if (a->variant == 2) {          // 8 waves, wave tile 128 px x 64 ch, N tile 256
     if (a->halo) L2(4, 1, 4, false, 2); else L2(4, 0, 4, false, 2);
