@@ -81,6 +81,25 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT
   float4 s1[NT], s2[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { s1[nt] = make_float4(0.f, 0.f, 0.f, 0.f); s2[nt] = s1[nt]; }
+  // Output addressing with 32-bit offsets inside image b; bias and noise of the whole wave tile are fetched before the first
+  // store (vmcnt counts stores and retires in order: a load behind a store waits for that store's acknowledgement) -- as in
+  // conv_mfma.hip.
+  const int64_t img = (int64_t)b * (TAPS ? a.out_h * a.out_w : a.hw);
+  float* const yb = a.y + img * a.out_ld;
+  const float* const nzb = a.noise ? a.noise + img : nullptr;
+  const float* const rb = a.residual ? a.residual + img * a.res_ld : nullptr;
+  const int nbase = ntile * (NT > 4 ? 128 : 64) + g * 4;
+  float nzv[MT];
+  float4 bva[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int p = pbase + mt * 16 + r16;
+    const bool ok = TAPS ? (oy0 + mt < a.out_h && ox < a.out_w) : p < a.hw;
+    nzv[mt] = (nzb && ok) ? a.noise_weight * nzb[TAPS ? (oy0 + mt) * a.out_w + ox : p] : 0.f;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+    bva[nt] = (a.bias && nbase + nt * 16 < a.cout) ? *(const float4*)(a.bias + nbase + nt * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
   // instantiated per (activation, residual mode), as in conv_mfma.hip / conv_mfma2.hip (same arithmetic, no FMA contraction)
   auto epi_passes = [&](auto act_c, auto res_c) {
 #pragma clang fp contract(off)
@@ -89,15 +108,16 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT
   for (int mt = 0; mt < MT; ++mt) {
     const int p = pbase + mt * 16 + r16;
     if (TAPS ? (oy0 + mt >= a.out_h || ox >= a.out_w) : p >= a.hw) continue;
-    const int64_t opix = TAPS ? ((int64_t)b * a.out_h + oy0 + mt) * a.out_w + ox : (int64_t)b * a.hw + p;
-    const float nz = a.noise ? a.noise_weight * a.noise[opix] : 0.f;
+    const int pin = TAPS ? (oy0 + mt) * a.out_w + ox : p;      // pixel index inside the image
+    const int yo = pin * a.out_ld, ro = pin * a.res_ld;
+    const float nz = nzv[mt];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int n0 = ntile * (NT > 4 ? 128 : 64) + nt * 16 + g * 4;
+      const int n0 = nbase + nt * 16;
       if (n0 >= a.cout) continue;
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), rv = bv;
-      if (a.bias) bv = *(const float4*)(a.bias + n0);
-      if (RES) rv = *(const float4*)(a.residual + opix * a.res_ld + n0);
+      float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 bv = bva[nt];
+      if (RES) rv = *(const float4*)(rb + (ro + n0));
       float o[4] = {acc[mt][nt][0] + bv.x + nz, acc[mt][nt][1] + bv.y + nz, acc[mt][nt][2] + bv.z + nz, acc[mt][nt][3] + bv.w + nz};
       const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
@@ -109,7 +129,7 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT
         if (RES == 2) t += r4[c];
         o[c] = t * a.out_scale;
       }
-      *(float4*)(a.y + opix * a.out_ld + n0) = make_float4(o[0], o[1], o[2], o[3]);
+      *(float4*)(yb + (yo + n0)) = make_float4(o[0], o[1], o[2], o[3]);
       s1[nt].x += o[0]; s1[nt].y += o[1]; s1[nt].z += o[2]; s1[nt].w += o[3];
       s2[nt].x += o[0] * o[0]; s2[nt].y += o[1] * o[1]; s2[nt].z += o[2] * o[2]; s2[nt].w += o[3] * o[3];
     }

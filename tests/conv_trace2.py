@@ -9,6 +9,8 @@ from ppst_amd import ops
 TRB, TRS, NW = 8, 160, 8
 shapes = [(8, 256, 256, 256, 3, "conv"), (8, 512, 512, 128, 3, "conv"), (8, 512, 256, 128, 3, "convT")]
 # (shapes with 128 output channels run the K-split kernel, variant 8, when ops.KSPLIT_128 is on: records are per step PAIR)
+if os.environ.get("TILE24"):      # trace variant 9 (24 x 16 px x 128 ch blocks) on the 128-wide plans
+    ops.TILE24_128.update(value=True, min_blocks=0, max_waste=10.0)
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in sys.argv[1:6]) + (sys.argv[6],)]
 for (B, ci, co, H, k, kind) in shapes:
