@@ -12,6 +12,15 @@
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// Output store of the conv epilogues.  -DPPST_EPI_NT (experiment, measured: no effect): non-temporal hint.
+#if defined(PPST_EPI_NOSTORE)   // timing ablation (results WRONG): what the output stores and their acknowledgements cost
+#define PPST_EPI_STORE(ptr, o) ((void)(ptr))
+#elif defined(PPST_EPI_NT)
+#define PPST_EPI_STORE(ptr, o) __builtin_nontemporal_store((f32x4){(o)[0], (o)[1], (o)[2], (o)[3]}, (f32x4*)(ptr))
+#else
+#define PPST_EPI_STORE(ptr, o) (*(float4*)(ptr) = make_float4((o)[0], (o)[1], (o)[2], (o)[3]))
+#endif
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // Tags for the conv epilogues' (activation, residual mode): EpiC = compile-time (the production kernels: the pass loops are

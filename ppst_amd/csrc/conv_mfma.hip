@@ -546,7 +546,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
           if (RES == 2) t += r4[c];
           o[c] = t * a.out_scale;
         }
-        *(float4*)(yb + (yo0 + d * a.out_ld)) = make_float4(o[0], o[1], o[2], o[3]);
+        PPST_EPI_STORE(yb + (yo0 + d * a.out_ld), o);
         s1.x += o[0]; s1.y += o[1]; s1.z += o[2]; s1.w += o[3];
         s2.x += o[0] * o[0]; s2.y += o[1] * o[1]; s2.z += o[2] * o[2]; s2.w += o[3] * o[3];
       }

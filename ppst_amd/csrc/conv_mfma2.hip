@@ -455,7 +455,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 
             if (RES == 2) t += r4[c];
             o[c] = t * a.out_scale;
           }
-          *(float4*)(yb + (yo0 + d * a.out_ld)) = make_float4(o[0], o[1], o[2], o[3]);
+          PPST_EPI_STORE(yb + (yo0 + d * a.out_ld), o);
           s1a[pass].x += o[0]; s1a[pass].y += o[1]; s1a[pass].z += o[2]; s1a[pass].w += o[3];
           s2a[pass].x += o[0] * o[0]; s2a[pass].y += o[1] * o[1]; s2a[pass].z += o[2] * o[2]; s2a[pass].w += o[3] * o[3];
         }
