@@ -394,6 +394,15 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
 #else
 #define MFMA_FIRST 1
 #endif
+// -DPPST_PRIO_SWAP (experiment, measured: no effect -- two same-box A/B pairs, -0.5 % / +1.8 % on the step's conv time): the two waves of a SIMD take the issue priority in turns within a step (waves 4-7 for M-tile
+// groups 0-1, waves 0-3 for groups 2-3) instead of waves 0-3 leading every step and waiting ~800 cycles at its barrier.
+#ifdef PPST_PRIO_SWAP
+#define PRIO_SWAP(mt)                                                                                 \
+  if ((mt) == 0) { if (wave >= 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); } \
+  if ((mt) == 2) { if (wave >= 4) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); }
+#else
+#define PRIO_SWAP(mt)
+#endif
 #define CONV_STEP(bch, bcl, bnh, bnl, s, D2, D3, H1, H2)                                              \
   {                                                                                                   \
     TR_DECL TR(0)                                                                                     \
@@ -413,6 +422,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
         nh = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0));                                         \
         if (ALO) nl = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0) + 4 * PLANE);                    \
       }                                                                                               \
+      PRIO_SWAP(mt)                                                                                   \
       ABL_MFMA_GROUP(bch, bcl, mt)                                                                    \
       if (MFMA_FIRST && mt == 0) {                                                                    \
         /* the matrix pipe is running the 12 MFMAs of group 0 (operands fetched during the previous */ \
