@@ -169,9 +169,44 @@ class ConvPlan:
     weight: (Cout, Cin, k, k) fp32 CUDA tensor; scale multiplies the weights.
     """
 
+    # Step tables are a function of (kind, weight shape, chan_base, device) only; building one is a Python loop over up to a few
+    # hundred steps plus three host-to-device copies from pageable memory.  A training step rebuilds every plan (the weights
+    # changed), ~150 per D + G iteration: the tables are shared between plans of one geometry, only the weights are new.
+    _GEOMETRY = {}
+    _GEOM_ATTRS = ("kind", "cout", "cin", "k", "bn", "n_groups", "halo", "src", "max_chan", "wstrides", "nsteps", "flop_steps",
+                   "early_a", "ksplit_ok", "steps", "src_dev", "chunk_start", "chunks_per_group", "w4_shape")
+
     def __init__(self, weight, kind="conv", scale=1.0, chan_base=0, precision=None):
         _chk(weight, "weight")
         w = weight.detach().contiguous()
+        gkey = (kind, tuple(w.shape), int(chan_base), str(w.device))
+        geom = ConvPlan._GEOMETRY.get(gkey)
+        if geom is None:
+            self._build(w, kind, scale, chan_base, precision)
+            ConvPlan._GEOMETRY[gkey] = {a: getattr(self, a) for a in ConvPlan._GEOM_ATTRS if hasattr(self, a)}
+            return
+        self.__dict__.update(geom)
+        self.precision = PRECISION["value"] if precision is None else precision
+        cout, cin, k, _ = w.shape
+        if kind in ("convT", "dgradT"):      # the fused upscale's 4x4 kernel (Cin, Cout, 4, 4), scale folded in
+            wsrc = torch.empty((cin, cout, 4, 4), device=w.device, dtype=torch.float32)
+            check(lib.ppst_upscale_weight(_p(w), _p(wsrc), cout, cin, float(scale), _stream()), "ppst_upscale_weight")
+            if kind == "dgradT":
+                self.fwd_scale = float(scale)
+            scale = 1.0
+        elif kind == "dgrad":
+            wsrc = w.view(-1)[k * k - 1:]
+        else:
+            wsrc = w
+        self.scale = float(scale)
+        self.wsrc = wsrc
+        if self.precision == 2:
+            self.wpack = None
+            return
+        self._packs = {}
+        self.wpack = self.pack_for(self.bn)
+
+    def _build(self, w, kind, scale, chan_base, precision):
         self.kind = kind
         self.precision = PRECISION["value"] if precision is None else precision
         cout, cin, k, _ = w.shape
