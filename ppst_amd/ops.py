@@ -55,7 +55,15 @@ def set_precision(p):
     PRECISION["value"] = p
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """torch's current stream on the current device as a raw hipStream_t.  (torch.cuda.current_stream() builds a Stream object
+    through several Python layers: ~9 us per call, 2000 calls per training step.)"""
+    if _raw_stream is not None and _cur_device is not None:
+        return ctypes.c_void_p(_raw_stream(_cur_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
