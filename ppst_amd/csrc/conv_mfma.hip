@@ -796,8 +796,11 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       (a->tile_rows != 16 && !(a->variant == 7 && a->tile_rows == 32) && !(a->variant == 9 && a->tile_rows == 24)) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
     return PPST_EINVAL;
   // the epilogues address one image with 32-bit element offsets
-  if ((int64_t)a->out_h * a->out_w * a->out_ld > 0x7fffffff || (a->residual && (int64_t)a->out_h * a->out_w * a->res_ld > 0x7fffffff))
-    return PPST_EINVAL;
+  // (+ one tile row of slack: lanes beyond the image edge form their offset too, and only then mask the access)
+  {
+    const int64_t px = (int64_t)a->out_h * a->out_w + 64 * (int64_t)a->out_sx;
+    if (px * a->out_ld > 0x7fffffff || (a->residual && px * a->res_ld > 0x7fffffff)) return PPST_EINVAL;
+  }
   // the scattered output must reach into the output tensor (elements beyond it are dropped)
   if ((a->tile_h - 1) * a->out_sy >= a->out_h || (a->tile_w - 1) * a->out_sx >= a->out_w) return PPST_EINVAL;
   if (a->B == 0) return PPST_OK;

@@ -56,6 +56,32 @@ def test_argument_errors_need_no_gpu():
     assert lib.ppst_rscl_loss(d, d, None, d, d, d, 6, 6, 2048, 128, 0.07, None) == -3                   # k0 missing
 
 
+def test_conv_entry_rejects_images_beyond_32bit_offsets():
+    """The conv epilogues address one image with 32-bit element offsets: the entry point must refuse an image of >= 2^31
+    elements (validation runs before anything is dereferenced or launched, so this needs no GPU)."""
+    from ppst_amd import _lib
+    a = _lib.ConvArgs()
+    tok = ctypes.c_void_p(16)
+    a.x = a.wpack = a.steps = a.y = tok
+    a.B, a.in_h, a.in_w, a.in_ld = 0, 64, 64, 32          # B = 0: a valid call returns PPST_OK without launching
+    a.out_h, a.out_w, a.out_ld, a.cout = 64, 64, 64, 64
+    a.nsteps, a.n_groups, a.pad_mode, a.out_sy, a.out_sx = 9, 1, 0, 1, 1
+    a.tile_h, a.tile_w, a.halo, a.bn, a.tile_rows, a.variant, a.precision = 64, 64, 1, 64, 16, 0, 0
+    a.out_scale = 1.0
+    assert _lib.lib.ppst_conv2d_mfma(ctypes.byref(a), None) == 0
+    a.in_h = a.in_w = a.out_h = a.out_w = a.tile_h = a.tile_w = 8192
+    a.out_ld = 64                                          # 8192 * 8192 * 64 = 2^32 elements in one image
+    assert _lib.lib.ppst_conv2d_mfma(ctypes.byref(a), None) == -1
+    a.out_ld, a.cout = 28, 28                              # 8192 * 8192 * 28 < 2^31: accepted again
+    assert _lib.lib.ppst_conv2d_mfma(ctypes.byref(a), None) == 0
+    a.variant, a.tile_rows, a.bn, a.early_a = 9, 16, 128, 1   # variant 9 needs tile_rows 24
+    a.out_ld, a.cout = 128, 128
+    a.in_h = a.in_w = a.out_h = a.out_w = a.tile_h = a.tile_w = 64
+    assert _lib.lib.ppst_conv2d_mfma(ctypes.byref(a), None) == -1
+    a.tile_rows = 24
+    assert _lib.lib.ppst_conv2d_mfma(ctypes.byref(a), None) == 0
+
+
 def test_ops_refuse_cpu_tensors():
     """No CPU fallback: a non-GPU tensor raises like the reference's CHECK_CUDA."""
     from ppst_amd.stylegan2_op import fused_leaky_relu, upfirdn2d
