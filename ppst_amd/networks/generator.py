@@ -80,12 +80,11 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
             if noise is None:
                 raise RuntimeError("noise weight of %s is non-zero: pass noise tensors (or noise='random')" % p)
             nz = noise[key]
-            if nz.shape[0] == 1 and B > 1:      # one fixed row applies to the whole batch, like NoiseInjection.fixed_noise
-                nz = nz.expand(B, *nz.shape[1:])
-            elif nz.shape[0] < B and B % nz.shape[0] == 0:
-                # several calls' batches run as one (content and style feature passes concatenated): the fixture's rows
-                # repeat, so image i of every sub-batch sees row i exactly as in separate calls
-                nz = nz.repeat(B // nz.shape[0], 1, 1, 1)
+            if nz.shape[0] < B and B % nz.shape[0] == 0:
+                # one fixed row applies to the whole batch, like NoiseInjection.fixed_noise; several calls' batches run as one
+                # (content and style feature passes concatenated): the fixture's rows repeat, so image i of every sub-batch
+                # sees row i exactly as in separate calls
+                nz = self._batch_noise(nz, B)
             nz = nz.contiguous()
         y, st = self.plan(p + "conv.weight", kind)(x, bias=bias, noise=nz, noise_weight=nw, act=ops.ACT_LRELU, stats=True,
                                                    in_ss=in_ss)
@@ -95,6 +94,20 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
         if out_stats is not None:  # 'rep' | 'plain': also emit the IN partials of the block output (feature heads)
             return ops.affine_act_stats(y, ss, res=res, out_scale=out_scale, rep_pad=(out_stats == "rep"), res_up2=res_up2)
         return ops.affine_act(y, ss, res=res, out_scale=out_scale, res_up2=res_up2)
+
+    def _batch_noise(self, nz, B):
+        """``nz`` (rows, 1, H, W) repeated to B rows, kept while the source tensor is unchanged (a pinned noise dict is
+        expanded once, not by 14 copy kernels per generator pass)."""
+        cache = self.__dict__.setdefault("_nz_cache", {})
+        k = (id(nz), B)
+        hit = cache.get(k)
+        if hit is not None and hit[0] is nz and hit[1] == nz._version:
+            return hit[2]
+        out = nz.repeat(B // nz.shape[0], 1, 1, 1).contiguous()
+        if len(cache) >= 64:
+            cache.clear()
+        cache[k] = (nz, nz._version, out)       # holding ``nz`` keeps its id from being reused
+        return out
 
     # -- correspondence feature heads (generator.py:174-238) ------------------
     def _feat_head(self, x, p, k, out, st=None, tail=None):
