@@ -265,7 +265,8 @@ __global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 
   // m-tile 0 of step s+1) is read one group ahead.  The non-MFMA head (descriptor, weight DMA, activation loads) follows
   // the first group's MFMAs; the staging store of a new chunk sits under the second-to-last group.
 // -DPPST_ABL_HALFBAR (timing ablation, results WRONG: races): only every second step ends in a barrier -- what a 4-slot weight ring
-// with one barrier per step pair could gain at most.
+// with one barrier per step pair could gain at most.  Measured: +-1 % on the N-256 layers; <= 3 % with 64 px x 64 ch waves (the tile
+// kernel's geometry instantiated on this loop, itself 3-5 % slower than conv_mfma.hip: commit bf39429).
 #ifdef PPST_ABL_HALFBAR
 #define HALFBAR_IF(s) if (((s) & 1) != 0)
 #else
@@ -561,11 +562,6 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
     if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 2, 4, 0, 6>), dim3(blocks), dim3(512), 0, st, k);   \
     else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 2, 4, 0, 6>), dim3(blocks), dim3(512), 0, st, k);          \
   } while (0)
-#define L10(HALO_)                                                                                              \
-  do {                                                                                                          \
-    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 2, 4, 0, 4>), dim3(blocks), dim3(512), 0, st, k);   \
-    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 2, 4, 0, 4>), dim3(blocks), dim3(512), 0, st, k);          \
-  } while (0)
 #define L2P(HALO_, PREC_)                                                                                       \
   do {                                                                                                          \
     if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 4, false, 2, 2, PREC_>), dim3(blocks), dim3(512), 0, st, k);   \
@@ -573,9 +569,7 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
   } while (0)
   if (a->variant == 2 && a->precision == 1) { if (a->halo) L2P(1, 1); else L2P(0, 1); }
   else if (a->variant == 2 && a->precision == 3) { if (a->halo) L2P(1, 3); else L2P(0, 3); }
-  else if (a->variant == 10) {                // the tile kernel's geometry (16 x 16 px x 128 ch, 64 px x 64 ch waves) on this file's step loop
-    if (a->halo) L10(1); else L10(0);
-  } else if (a->variant == 9) {                 // 8 waves = 4 (M) x 2 (N), wave tile 96 px x 64 ch, block 24 x 16 px x 128 ch, two slots
+  else if (a->variant == 9) {                 // 8 waves = 4 (M) x 2 (N), wave tile 96 px x 64 ch, block 24 x 16 px x 128 ch, two slots
     if (a->halo) L9(1); else L9(0);
   } else if (a->variant == 7) {                 // 8 waves = 4 (M) x 2 (N), wave tile 128 px x 64 ch, block 32 x 16 px x 128 ch, one slot
     if (a->halo) L7(1); else L7(0);
