@@ -86,7 +86,7 @@ __device__ __forceinline__ unsigned short f2h_2(float f) { return __builtin_bit_
 // wave tile 96 px x 64 ch (variant 9) -- the largest wave tile for Cout = 128 layers whose activation ring still has TWO slots
 // (2 x 60 KB + 32 KB of weights = 152 KB): 20 ds_read_b128 per 72 MFMAs, and the chunk store overlaps the MFMAs as in variant 2.
 template <int NT, int HALO, bool INSS, int WNW = 2, bool BDB = true, int NA_ = 2, int WMW = 2, int PREC = 0, int MT_ = 8>
-__global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 1) void conv_mfma2_kernel(Conv2KArgs a) {
+__global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW == 8 || NA_ == 1) ? 2 : 1)) void conv_mfma2_kernel(Conv2KArgs a) {
   constexpr bool X3 = PREC == 0;
   constexpr int NWV = WMW * WNW;                          // waves per block
   constexpr int NTH = 64 * NWV;
@@ -206,14 +206,14 @@ __global__ __launch_bounds__(64 * WNW * WMW, (WNW * WMW == 8 || NA_ == 1) ? 2 : 
   };
   // ---- B staging: LDS-DMA of the pre-packed step blob (global_load_lds_dwordx4, 1 KB per wave-instruction)
   constexpr int B_WI = BBUF / 1024;
-  constexpr int B_PER_WAVE = B_WI / NWV;
-  static_assert(B_WI % NWV == 0, "weight blob must split evenly over the waves");
+  constexpr int B_PER_WAVE = (B_WI + NWV - 1) / NWV;     // (12 waves: the last round is issued by the first B_WI % NWV waves only)
   auto b_dma = [&](int s, int slot) {
     const unsigned char* src = wblob + (int64_t)s * BBUF + lane * 16;
     unsigned char* dst = smB + slot * BBUF;
 #pragma unroll
     for (int it = 0; it < B_PER_WAVE; ++it) {
       const int wi = it * NWV + wave;
+      if (B_WI % NWV != 0 && wi >= B_WI) break;
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + wi * 1024),
                                        (void __attribute__((address_space(3)))*)(dst + wi * 1024), 16, 0, 0);
     }
@@ -562,6 +562,11 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
     if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 2, 4, 0, 6>), dim3(blocks), dim3(512), 0, st, k);   \
     else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 2, 4, 0, 6>), dim3(blocks), dim3(512), 0, st, k);          \
   } while (0)
+#define L11(HALO_)                                                                                              \
+  do {                                                                                                          \
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 2, 6, 0, 4>), dim3(blocks), dim3(768), 0, st, k);   \
+    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 2, 6, 0, 4>), dim3(blocks), dim3(768), 0, st, k);          \
+  } while (0)
 #define L2P(HALO_, PREC_)                                                                                       \
   do {                                                                                                          \
     if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 4, false, 2, 2, PREC_>), dim3(blocks), dim3(512), 0, st, k);   \
@@ -569,7 +574,9 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
   } while (0)
   if (a->variant == 2 && a->precision == 1) { if (a->halo) L2P(1, 1); else L2P(0, 1); }
   else if (a->variant == 2 && a->precision == 3) { if (a->halo) L2P(1, 3); else L2P(0, 3); }
-  else if (a->variant == 9) {                 // 8 waves = 4 (M) x 2 (N), wave tile 96 px x 64 ch, block 24 x 16 px x 128 ch, two slots
+  else if (a->variant == 11) {                // 12 waves = 6 (M) x 2 (N), THREE per SIMD, wave tile 64 px x 64 ch, block 24 x 16 px x 128 ch
+    if (a->halo) L11(1); else L11(0);
+  } else if (a->variant == 9) {                 // 8 waves = 4 (M) x 2 (N), wave tile 96 px x 64 ch, block 24 x 16 px x 128 ch, two slots
     if (a->halo) L9(1); else L9(0);
   } else if (a->variant == 7) {                 // 8 waves = 4 (M) x 2 (N), wave tile 128 px x 64 ch, block 32 x 16 px x 128 ch, one slot
     if (a->halo) L7(1); else L7(0);
