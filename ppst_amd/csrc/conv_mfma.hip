@@ -774,12 +774,12 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       a->out_ld < a->cout || a->cout <= 0 || a->cout % 4 || a->out_ld % 4 || (a->residual && a->res_ld % 4) || a->nsteps <= 0 || (a->n_groups != 1 && a->n_groups != 4) || a->pad_mode < 0 ||
       a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 ||
       (a->precision != 0 && a->precision != 1 && a->precision != 3 && a->precision != 4) || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128 && a->bn != 256) || (a->residual && a->res_ld < a->cout) ||
-      a->variant < 0 || a->variant > 11 || a->variant == 10 || (a->variant == 0 && a->bn == 256) ||
-      ((a->variant >= 1 && a->variant <= 3 || a->variant == 7 || a->variant == 9 || a->variant == 11) &&
+      a->variant < 0 || a->variant > 9 || (a->variant == 0 && a->bn == 256) ||
+      ((a->variant >= 1 && a->variant <= 3 || a->variant == 7 || a->variant == 9) &&
        ((a->precision != 0 && !(a->variant == 2 && (a->precision == 1 || a->precision == 3))) || a->bn == 64 || !a->early_a)) ||
       (a->variant == 7 && (a->bn != 128 || a->tile_rows != 32)) ||
       // variant 9 = conv_mfma2.hip with 6 m-tiles per wave: block tile 24 x 16 px x 128 ch, two activation slots
-      ((a->variant == 9 || a->variant == 11) && (a->bn != 128 || a->tile_rows != 24)) ||
+      (a->variant == 9 && (a->bn != 128 || a->tile_rows != 24)) ||
       // variant 8 = conv_ksplit.hip: two K-groups of four 128 px x 64 ch waves; bn = 128, bf16x3, chunks of >= 2 steps (and the
       // caller's promise: 2-step chunks start at even steps, steps[i].w bit 2 = parity of step i's chunk index)
       (a->variant == 8 && (a->precision != 0 || a->bn != 128 || !a->early_a)) ||
@@ -793,7 +793,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       ((a->variant == 5 || a->variant == 6) && ((a->precision != 0 && a->precision != 1 && a->precision != 3) ||
                                                 (a->bn != 64 && !(a->variant == 6 && a->bn == 128 && a->precision == 0)) || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
                            a->in_off_y != 0 || a->in_off_x != 0 || a->tile_h != a->out_h || a->tile_w != a->out_w)) ||
-      (a->tile_rows != 16 && !(a->variant == 7 && a->tile_rows == 32) && !((a->variant == 9 || a->variant == 11) && a->tile_rows == 24)) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
+      (a->tile_rows != 16 && !(a->variant == 7 && a->tile_rows == 32) && !(a->variant == 9 && a->tile_rows == 24)) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
     return PPST_EINVAL;
   // the epilogues address one image with 32-bit element offsets
   // (+ one tile row of slack: lanes beyond the image edge form their offset too, and only then mask the access)

@@ -562,11 +562,6 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
     if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 2, 4, 0, 6>), dim3(blocks), dim3(512), 0, st, k);   \
     else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 2, 4, 0, 6>), dim3(blocks), dim3(512), 0, st, k);          \
   } while (0)
-#define L11(HALO_)                                                                                              \
-  do {                                                                                                          \
-    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 2, 6, 0, 4>), dim3(blocks), dim3(768), 0, st, k);   \
-    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 2, 6, 0, 4>), dim3(blocks), dim3(768), 0, st, k);          \
-  } while (0)
 #define L2P(HALO_, PREC_)                                                                                       \
   do {                                                                                                          \
     if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 4, false, 2, 2, PREC_>), dim3(blocks), dim3(512), 0, st, k);   \
@@ -574,9 +569,7 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
   } while (0)
   if (a->variant == 2 && a->precision == 1) { if (a->halo) L2P(1, 1); else L2P(0, 1); }
   else if (a->variant == 2 && a->precision == 3) { if (a->halo) L2P(1, 3); else L2P(0, 3); }
-  else if (a->variant == 11) {                // 12 waves = 6 (M) x 2 (N), THREE per SIMD, wave tile 64 px x 64 ch, block 24 x 16 px x 128 ch
-    if (a->halo) L11(1); else L11(0);
-  } else if (a->variant == 9) {                 // 8 waves = 4 (M) x 2 (N), wave tile 96 px x 64 ch, block 24 x 16 px x 128 ch, two slots
+  else if (a->variant == 9) {                 // 8 waves = 4 (M) x 2 (N), wave tile 96 px x 64 ch, block 24 x 16 px x 128 ch, two slots
     if (a->halo) L9(1); else L9(0);
   } else if (a->variant == 7) {                 // 8 waves = 4 (M) x 2 (N), wave tile 128 px x 64 ch, block 32 x 16 px x 128 ch, one slot
     if (a->halo) L7(1); else L7(0);

@@ -42,7 +42,7 @@ KSPLIT_128 = {"value": False, "min_blocks": 32}
 TALL_TILE_128 = {"value": False, "min_blocks": 32}
 # variant 9 (24 x 16 px x 128 ch blocks, wave tile 96 px x 64 ch, TWO activation slots: conv_mfma2.hip MT_ = 6) for the Cout = 128-class
 # layers whose tile height wastes <= max_waste of the rows (512 -> 528, 256 -> 264: 3.1 %; 128 -> 144 would be 12.5 %)
-TILE24_128 = {"value": False, "min_blocks": 32, "max_waste": 0.04, "waves12": False}   # waves12: variant 11 (12 waves of 64 px x 64 ch)
+TILE24_128 = {"value": False, "min_blocks": 32, "max_waste": 0.04}
 TWO_BLOCK_128 = {"value": False}   # experiment: variant 3 (see __call__) for the Cout = 128-class layers
 FAT_MIN_BLOCKS = 32         # take the 256-channel tile only when ONE image still gives >= this many blocks (B = 8: one per CU)
 
@@ -440,7 +440,7 @@ class ConvPlan:
                 variant = 8                              # two K-groups of 128 px x 64 ch waves, N tile 128 (conv_ksplit.hip)
             elif (self.bn == 128 and TILE24_128["value"] and ((th + 23) // 24) * 24 <= th * (1.0 + TILE24_128["max_waste"]) and
                   ((th + 23) // 24) * ((tw + 15) // 16) * self.n_groups * ((self.cout + 127) // 128) >= TILE24_128["min_blocks"]):
-                variant, rows = (11 if TILE24_128["waves12"] else 9), 24   # block tile 24 x 16 px x 128 ch, two activation slots
+                variant, rows = 9, 24                    # block tile 24 x 16 px x 128 ch, two activation slots (WMW = 4, MT_ = 6)
             elif (self.bn == 128 and TALL_TILE_128["value"] and
                   ((th + 31) // 32) * ((tw + 15) // 16) * self.n_groups * ((self.cout + 127) // 128) >= TALL_TILE_128["min_blocks"]):
                 variant, rows = 7, 32                    # block tile 32 x 16 px x 128 ch, one activation slot (WMW = 4)

@@ -331,12 +331,12 @@ def t_conv_variants():
         tall = dict(ops.TALL_TILE_128)
         ksp = dict(ops.KSPLIT_128)
         t24 = dict(ops.TILE24_128)
-        for variant, minb in ((0, 384), (1, 1 << 30), (1, 0), (2, 0), (3, 0), (7, 0), (8, 0), (9, 0), (11, 0)):
+        for variant, minb in ((0, 384), (1, 1 << 30), (1, 0), (2, 0), (3, 0), (7, 0), (8, 0), (9, 0)):
             ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = variant, minb
             ops.TALL_TILE_128.update(value=variant == 7, min_blocks=0)
             ops.KSPLIT_128.update(value=variant == 8, min_blocks=0)
-            ops.TILE24_128.update(value=variant in (9, 11), min_blocks=0, max_waste=10.0, waves12=variant == 11)   # (on every 128-wide plan)
-            if variant in (7, 8, 9, 11):  # the 32 x 16-pixel-tile / the K-split kernel on every 128-wide plan (the N-256 tile switched off)
+            ops.TILE24_128.update(value=variant == 9, min_blocks=0, max_waste=10.0)   # (9: on every 128-wide plan, any tile height)
+            if variant in (7, 8, 9):  # the 32 x 16-pixel-tile / the K-split kernel on every 128-wide plan (the N-256 tile switched off)
                 ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS = 2, 1 << 30
             plan = ops.ConvPlan(w, kind=kind)
             cin_eff = plan.max_chan + 32
@@ -363,7 +363,7 @@ def t_conv_variants():
         report("K-split conv (variant 8) %s stats" % name, s8, outs[(0, 384)][1], 1e-5)
         y0, s0 = outs[(0, 384)]
         for key, tag in (((1, 1 << 30), "N=128"), ((1, 0), "N=256|128"), ((2, 0), "8w N=256"), ((3, 0), "2blk N=128"), ((7, 0), "32x16 N=128"),
-                         ((9, 0), "24x16 N=128"), ((11, 0), "24x16 12w")):
+                         ((9, 0), "24x16 N=128")):
             y1, s1 = outs[key]
             RES.append(("fat conv %s %s bit-identical" % (tag, name), bool(torch.equal(y0, y1))))
             print("fat conv %-9s %-52s %s max diff %.3e" % (tag, name, "ok  " if torch.equal(y0, y1) else "FAIL", (y0 - y1).abs().max().item()), flush=True)
