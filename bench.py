@@ -75,6 +75,21 @@ def conv_traffic():
         return None
 
 
+def conv_mfma_busy():
+    """Matrix-pipe busy fraction of the conv launches from the committed SQ_VALU_MFMA_BUSY_CYCLES pass (profiles/rNN_pmc_mfma.json,
+    tests/pmc_mfma_summary.py): a hardware-counter companion of roofline.frac, at the clock the kernels ran at."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return {"all_conv_launches": d["all_conv_launches"]["mfma_busy_frac"], "file": "profiles/" + os.path.basename(files[-1]),
+                "measured_at_commit": d.get("commit")}
+    except Exception:
+        return None
+
+
 def conv_traffic_source():
     d, name = _pmc_file()
     if d is None:
@@ -349,7 +364,7 @@ def main():
                 "frac_vs_dense_bf16": achieved / PEAK_BF16_DENSE_TF,
                 "launches": conv_launches, "kernel_ms_total": conv_ms,
                 "share_of_step_time": conv_ms * 1e-3 / dt, "traffic": conv_traffic(), "traffic_source": conv_traffic_source(),
-                "effective_clock_ghz_pmc": conv_pmc(),
+                "effective_clock_ghz_pmc": conv_pmc(), "mfma_busy_frac_pmc": conv_mfma_busy(),
             },
         }
         st_ach = st_flop / (st_ms * 1e-3) / 1e12 if st_ms > 0 else 0.0
