@@ -139,6 +139,13 @@ extern "C" int ppst_conv2d_f32(const ppst_conv_args* a, const void* w, int64_t s
       a->out_sy <= 0 || a->out_sx <= 0 || (a->residual && a->res_ld < a->cout) || (a->in_scale_shift && a->in_c <= 0))
     return PPST_EINVAL;
   if ((a->tile_h - 1) * a->out_sy >= a->out_h || (a->tile_w - 1) * a->out_sx >= a->out_w) return PPST_EINVAL;
+  // same limits as ppst_conv2d_mfma: 16-row tiles (the statistics layout assumes them) and 32-bit offsets inside one image
+  if (a->tile_rows != 16) return PPST_EINVAL;
+  {
+    const int64_t px = (int64_t)a->out_h * a->out_w + 64 * (int64_t)a->out_sx;
+    if (px * a->out_ld > 0x7fffffff || (a->residual && px * a->res_ld > 0x7fffffff)) return PPST_EINVAL;
+    if ((int64_t)a->in_h * a->in_w * a->in_ld * 4 > 0x7fffffff) return PPST_EINVAL;
+  }
   if (a->B == 0) return PPST_OK;
   if (!a->x || !w || !a->steps || !a->y || !src_c || !src_ky || !src_kx) return PPST_ENULL;
   ConvF32Args k;

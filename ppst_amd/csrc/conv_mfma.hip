@@ -86,7 +86,9 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   constexpr int NT = 64 * WM * WN;
   constexpr int TH = 4 * WM, TW = 16;
   constexpr int HH = TH + 2 * HALO, HW = TW + 2 * HALO, HP = HH * HW;
-  constexpr int PLANE = ((HP * 16 + 255) / 256) * 256;  // bytes
+  // bytes.  (The 256-B rounding is layout hygiene, not a bank requirement: a 16-lane ds_read_b128 / ds_write_b64 group stays inside
+  // one plane.  The 8-row two-block form drops it so that two 77-KB blocks fit the CU's 160 KB.)
+  constexpr int PLANE = (WM == 2) ? HP * 16 : ((HP * 16 + 255) / 256) * 256;
   constexpr int NPL = ALO ? 8 : 4;                       // planes per A buffer (hi g0..3, lo g0..3)
   constexpr int NPLB = X3 ? 8 : 4;                       // planes per weight blob
   constexpr int ABUF = NPL * PLANE;
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
       if (inb || a.pad_mode != PPST_PAD_ZERO) {
         iy = pad_index(iy, a.in_h, a.pad_mode);
         ix = pad_index(ix, a.in_w, a.pad_mode);
-        o = (iy * a.in_w + ix) * a.in_ld + q4 * 4;  // < 2^31: one image is at most 512*512*2048 elements
+        o = ((iy * a.in_w + ix) * a.in_ld + q4 * 4) * 4;  // bytes, < 2^31: the entry point rejects larger images
       }
     }
     aoff[it] = o;
@@ -180,13 +182,18 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   float4 ras0 = make_float4(1.f, 0.f, 1.f, 0.f), ras1 = ras0;
   const int q4lane = ((tid & 63) >> 4) * 2 + (tid & 1);
   const float in_slope = (INSS && a.in_act == PPST_ACT_PRELU && a.in_prelu) ? a.in_prelu[0] : 0.f;
+  // Buffer loads: address = image base (SGPR descriptor) + per-item byte offset (VGPR, fixed for the tile) + chunk offset (SGPR
+  // soffset).  No per-load 64-bit VALU address arithmetic -- with `xb + aoff + chan_off` as a flat pointer hipcc formed each address
+  // in the load's own destination registers, and that VALU write to registers of a possibly pending load cost a `s_waitcnt vmcnt(0)`
+  // right behind the weight DMA of the step (one L2 round trip per chunk).  Padding items carry the offset -1 (0xffffffff): out of
+  // the descriptor's range, the hardware returns zeros and the staging store needs no select.
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, a.in_h * a.in_w * a.in_ld * 4, 0x00020000);
   auto a_load = [&](int chan_off) {
 #pragma unroll
     for (int it = 0; it < A_IT2; ++it) {
-      // always issued (padding lanes read element 0 and are zeroed in a_store): the count of outstanding
-      // vector-memory operations must be a compile-time constant for the counted vmcnt wait that lets an
-      // early load stay in flight across the step barrier
-      ra[it] = *(const float4*)(xb + (aoff[it] >= 0 ? aoff[it] : 0) + chan_off);
+      // always issued: the count of outstanding vector-memory operations must be a compile-time constant for the counted
+      // vmcnt wait that lets an early load stay in flight across the step barrier
+      ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, aoff[it], chan_off * 4, 0));
     }
     if (INSS) {
       const float4* p = (const float4*)(a.in_ss + ((int64_t)b * a.in_c + chan_off + q4lane * 4) * 2);
@@ -207,8 +214,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
       int l = i & 63;
       int pix = (i >> 6) * 8 + ((l >> 1) & 7);
       if (pix < HP) {
-        float4 v = ra[it];
-        if (aoff[it] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = ra[it];                // (padding items: zeros from the out-of-range buffer load)
         if (INSS && aoff[it] >= 0) {  // padding zeros stay zeros (they pad the normalised tensor)
           v.x = in_act(ras0.x * v.x + ras0.y); v.y = in_act(ras0.z * v.y + ras0.w);
           v.z = in_act(ras1.x * v.z + ras1.y); v.w = in_act(ras1.z * v.w + ras1.w);
@@ -793,7 +799,9 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       ((a->variant == 5 || a->variant == 6) && ((a->precision != 0 && a->precision != 1 && a->precision != 3) ||
                                                 (a->bn != 64 && !(a->variant == 6 && a->bn == 128 && a->precision == 0)) || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
                            a->in_off_y != 0 || a->in_off_x != 0 || a->tile_h != a->out_h || a->tile_w != a->out_w)) ||
-      (a->tile_rows != 16 && !(a->variant == 7 && a->tile_rows == 32) && !(a->variant == 9 && a->tile_rows == 24)) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
+      // tile_rows 8 = two 4-wave blocks per CU (8 x 16 px x 128 ch, two activation slots): variant 0, bn 128, halo 1, early_a, bf16x3
+      (a->tile_rows != 16 && !(a->variant == 7 && a->tile_rows == 32) && !(a->variant == 9 && a->tile_rows == 24) &&
+       !(a->variant == 0 && a->tile_rows == 8 && a->bn == 128 && a->halo == 1 && a->early_a && a->precision == 0)) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
     return PPST_EINVAL;
   // the epilogues address one image with 32-bit element offsets
   // (+ one tile row of slack: lanes beyond the image edge form their offset too, and only then mask the access)
@@ -801,6 +809,8 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
     const int64_t px = (int64_t)a->out_h * a->out_w + 64 * (int64_t)a->out_sx;
     if (px * a->out_ld > 0x7fffffff || (a->residual && px * a->res_ld > 0x7fffffff)) return PPST_EINVAL;
   }
+  // the input side: every kernel family addresses one input image with 32-bit BYTE offsets (buffer loads / int offsets)
+  if ((int64_t)a->in_h * a->in_w * a->in_ld * 4 > 0x7fffffff) return PPST_EINVAL;
   // the scattered output must reach into the output tensor (elements beyond it are dropped)
   if ((a->tile_h - 1) * a->out_sy >= a->out_h || (a->tile_w - 1) * a->out_sx >= a->out_w) return PPST_EINVAL;
   if (a->B == 0) return PPST_OK;
@@ -857,11 +867,12 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
     if (a->halo) { if (x3) launch_conv<WM_, WN_, 1, true>(k, blocks, st); else if (x2) launch_conv<WM_, WN_, 1, false, 0, true, true>(k, blocks, st); else if (f16) launch_conv<WM_, WN_, 1, false, 0, true>(k, blocks, st); else launch_conv<WM_, WN_, 1, false>(k, blocks, st); } \
     else         { if (x3) launch_conv<WM_, WN_, 0, true>(k, blocks, st); else if (x2) launch_conv<WM_, WN_, 0, false, 0, true, true>(k, blocks, st); else if (f16) launch_conv<WM_, WN_, 0, false, 0, true>(k, blocks, st); else launch_conv<WM_, WN_, 0, false>(k, blocks, st); } \
   } while (0)
-  // (8-row tiles -- two 80-KB blocks per CU -- were measured 35 % slower than one 16-row block
-  //  per CU on MI355X and are not instantiated; tile_rows == 8 is rejected above.)
+  // (round 1 measured 8-row tiles -- two 80-KB blocks per CU -- 35 % slower: only one block was ever resident.  Round 3
+  //  re-instantiates them at 77 KB with the two-slot ring of the early_a tables: see ops.TWO_BLOCK_8ROW.)
   // small-K layers on the 64-channel tile: a shallower activation ring (59 / 48 / 80 KB of LDS instead of
   // 145 / 112) puts two blocks on a CU, so one block's loads and stores overlap the other's MFMAs
-  if (a->bn == 64 && x3 && a->halo == 1 && a->a_slots == 1) launch_conv<4, 1, 1, true, 1>(k, blocks, st);
+  if (a->tile_rows == 8) launch_conv<2, 2, 1, true, 2>(k, blocks, st);
+  else if (a->bn == 64 && x3 && a->halo == 1 && a->a_slots == 1) launch_conv<4, 1, 1, true, 1>(k, blocks, st);
   else if (a->bn == 64 && x3 && a->halo == 0 && a->a_slots == 1) launch_conv<4, 1, 0, true, 1>(k, blocks, st);
   else if (a->bn == 64 && x3 && a->halo == 0 && a->a_slots == 2) launch_conv<4, 1, 0, true, 2>(k, blocks, st);
   else if (a->bn == 128) DISPATCH(4, 2); else DISPATCH(4, 1);

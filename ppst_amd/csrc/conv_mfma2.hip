@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
       if (inb || a.pad_mode != PPST_PAD_ZERO) {
         iy = pad_index2(iy, a.in_h, a.pad_mode);
         ix = pad_index2(ix, a.in_w, a.pad_mode);
-        o = (iy * a.in_w + ix) * a.in_ld + q4 * 4;
+        o = ((iy * a.in_w + ix) * a.in_ld + q4 * 4) * 4;  // bytes, < 2^31: the entry point rejects larger images
       }
     }
     aoff[it] = o;
@@ -166,9 +166,11 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   float4 ras0 = make_float4(1.f, 0.f, 1.f, 0.f), ras1 = ras0;
   const int q4lane = ((tid & 63) >> 4) * 2 + (tid & 1);
   const float in_slope = (INSS && a.in_act == PPST_ACT_PRELU && a.in_prelu) ? a.in_prelu[0] : 0.f;
+  // buffer loads (SGPR descriptor + per-item byte offset + SGPR chunk offset; padding items out of range -> zeros): conv_mfma.hip
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, a.in_h * a.in_w * a.in_ld * 4, 0x00020000);
   auto a_load = [&](int chan_off) {
 #pragma unroll
-    for (int it = 0; it < A_IT2; ++it) ra[it] = *(const float4*)(xb + (aoff[it] >= 0 ? aoff[it] : 0) + chan_off);
+    for (int it = 0; it < A_IT2; ++it) ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, aoff[it], chan_off * 4, 0));
     if (INSS) {
       const float4* p = (const float4*)(a.in_ss + ((int64_t)b * a.in_c + chan_off + q4lane * 4) * 2);
       ras0 = p[0];
@@ -188,8 +190,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
       int l = i & 63;
       int pix = (i >> 6) * 8 + ((l >> 1) & 7);
       if (pix < HP) {
-        float4 v = ra[it];
-        if (aoff[it] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = ra[it];                // (padding items: zeros from the out-of-range buffer load)
         if (INSS && aoff[it] >= 0) {
           v.x = in_act(ras0.x * v.x + ras0.y); v.y = in_act(ras0.z * v.y + ras0.w);
           v.z = in_act(ras1.x * v.z + ras1.y); v.w = in_act(ras1.z * v.w + ras1.w);

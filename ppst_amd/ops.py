@@ -44,6 +44,9 @@ TALL_TILE_128 = {"value": False, "min_blocks": 32}
 # layers whose tile height wastes <= max_waste of the rows (512 -> 528, 256 -> 264: 3.1 %; 128 -> 144 would be 12.5 %)
 TILE24_128 = {"value": False, "min_blocks": 32, "max_waste": 0.04}
 TWO_BLOCK_128 = {"value": False}   # experiment: variant 3 (see __call__) for the Cout = 128-class layers
+# round 3: the tile kernel itself as two 4-wave blocks per CU (8 x 16 px x 128 ch tiles, 64 px x 64 ch waves, TWO activation slots,
+# 77 KB of LDS each) for the Cout = 128-class layers: one block's prologue / epilogue / barrier waits overlap the other's MFMAs
+TWO_BLOCK_8ROW = {"value": False, "min_blocks": 64}
 FAT_MIN_BLOCKS = 32         # take the 256-channel tile only when ONE image still gives >= this many blocks (B = 8: one per CU)
 
 
@@ -435,6 +438,9 @@ class ConvPlan:
             elif self.bn == 128 and (force3 or (TWO_BLOCK_128["value"] and
                                                 tiles16 * ((self.cout + 127) // 128) >= 2 * FAT_MIN_BLOCKS)):
                 variant = 3                              # two 4-wave blocks per CU, N tile 128, one activation slot
+            elif (self.bn == 128 and TWO_BLOCK_8ROW["value"] and self.halo == 1 and
+                  ((th + 7) // 8) * ((tw + 15) // 16) * self.n_groups * ((self.cout + 127) // 128) >= TWO_BLOCK_8ROW["min_blocks"]):
+                rows = 8                                 # tile kernel, two 4-wave blocks per CU
             elif (self.bn == 128 and KSPLIT_128["value"] and getattr(self, "ksplit_ok", False)
                   and tiles16 * ((self.cout + 127) // 128) >= KSPLIT_128["min_blocks"]):
                 variant = 8                              # two K-groups of 128 px x 64 ch waves, N tile 128 (conv_ksplit.hip)

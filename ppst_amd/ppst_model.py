@@ -244,83 +244,73 @@ class PPSTModel(nn.Module):
     def discriminate(self, x):
         return self.D(x)
 
-    # ---- train-step commands, forward values (models/ppst_model.py:68-235).  The parameter updates live in
-    # ppst_amd/train.py (discriminator + lazy R1); the generator/encoder backward is not built.
+    # ---- train-step commands (models/ppst_model.py:68-235).  Like the reference's, they return loss TENSORS that carry the
+    # graph: ``sum(v.mean() for v in losses.values()).backward()`` (optimizers/ppst_optimizer.py:86-88, :110-111, :121-123)
+    # leaves d/d(theta) in ``p.grad`` of the networks' parameters, so a restated PPSTOptimizer runs on top of this facade
+    # unchanged (ppst_amd/train_g.py:PPSTOptimizer).  ONE composition per command: the generator iteration is
+    # GeneratorTrainer.compute_generator_losses (autograd blocks over HIP kernels, ppst_amd/autograd.py), the discriminator
+    # iteration and the lazy R1 penalty are single autograd nodes over DiscriminatorTrainer's taped forward / backward.  Under
+    # torch.no_grad() the same code returns values only.
+    def trainer(self, **kw):
+        """The GeneratorTrainer that owns this model's E1 / E2 / G (and, through it, D's DiscriminatorTrainer): created on
+        first use, kept on the model.  Its constructor rebinds every parameter into a flat buffer per network."""
+        from .train_g import GeneratorTrainer
+        return GeneratorTrainer.for_model(self, **kw)
+
     def compute_image_discriminator_losses(self, real, rec, mix, cyc=None):
+        from .autograd import DLossesFn
         lam = self.opt.lambda_GAN
         if lam == 0.0:
             return {}
-        losses = {"D_real": ops.lsgan(self.D(real), 1.0, lam)[0], "D_rec": ops.lsgan(self.D(rec), 0.0, 0.5 * lam)[0]}
-        if mix is not None:
-            losses["D_mix"] = ops.lsgan(self.D(mix), 0.0, 0.5 * lam)[0]
-        if cyc is not None:
-            losses["D_cyc"] = ops.lsgan(self.D(cyc), 0.0, 0.5 * lam)[0]
-        return losses
+        assert cyc is None, "the reference never passes cyc (ppst_model.py:133-138)"
+        tr = self.trainer().d_trainer
+        names = ["D_real", "D_rec"] + (["D_mix"] if mix is not None else [])
+        vals = DLossesFn.apply(tr.anchor, tr, real, rec, mix, float(lam))
+        return dict(zip(names, vals))
 
     def compute_discriminator_losses(self, real, mask=None):
         from .train import d_step_images
         if hasattr(self, "num_discriminator_iters"):
             self.num_discriminator_iters.add_(1)
-        rec, mix, sp, gl = d_step_images(self, real, getattr(self.opt, "lambda_StyleCon", 1.0), want_codes=True)
+        with torch.no_grad():                       # ppst_model.py:106-131: rec / mix come from the frozen E1 / E2 / G
+            rec, mix, sp, gl = d_step_images(self, real, getattr(self.opt, "lambda_StyleCon", 1.0), want_codes=True)
         return self.compute_image_discriminator_losses(real, rec, mix), {}, sp, gl
 
     def compute_R1_loss(self, real):
-        from .train import DiscriminatorTrainer
-        if getattr(self.opt, "lambda_R1", 10.0) <= 0.0:
+        from .autograd import R1Fn
+        lam = float(getattr(self.opt, "lambda_R1", 10.0))
+        if lam <= 0.0:
             return {"D_R1": 0.0}
-        # ONE trainer per D: its constructor rebinds D's parameters into a flat buffer, so a second
-        # trainer would orphan the first one's flat / m / v (DiscriminatorTrainer.for_network)
-        tr = DiscriminatorTrainer.for_network(self.D)
-        return {"D_R1": tr.r1_penalty(real, getattr(self.opt, "lambda_R1", 10.0))}
+        tr = self.trainer().d_trainer
+        return {"D_R1": R1Fn.apply(tr.anchor, tr, real, lam)}
 
     def compute_generator_losses(self, real, sp_ma, gl_ma, mask):
-        """Loss / metric VALUES of the generator iteration (ppst_model.py:161-235, training_stage 2,
-        lambda_Cycwarp = 0: lpips is not available) and the NCE queue updates.  No gradients."""
-        opt = self.opt
-        lam = lambda k, d: float(getattr(opt, k, d))
-        B = real.shape[0]
-        losses, metrics = {}, {}
-        sp = self.E1(real)
-        gl, _ = self.E2(real)
-        _, feas, feas1 = self.G(sp, gl, extract_features=True, noise=self.noise, want_rgb=not self.skip_unused_rgb)
-        sps = torch.cat((feas, self.Rselfcorr(feas1)), dim=1)
-        corr = self.corrm(sps, self.swap(sps))
-        corr_self = self.corrm(sps, sps)
-        _, gl = self.E2(real, corrmatrix=corr_self)
-        _, pro_ms, gl_w, pro_mw = self.E2(real, mask=mask, corrmatrix=corr)
-        if lam("lambda_Maskwarp", 10.0) > 0.0:
-            losses["Mask_warp"] = ops.l1_mean(self.warp(mask, corr), self.swap(mask), lam("lambda_Maskwarp", 10.0))
-        rec = self.G(sp, gl, noise=self.noise)
-        if lam("lambda_L1", 3.0) > 0.0:
-            losses["G_L1"] = ops.l1_mean(rec, real, lam("lambda_L1", 3.0))
-        if lam("lambda_StyleCon", 1.0) > 0.0:
-            mix = self.G(self.swap(sp), gl_w, noise=self.noise)
-            _, pro_3m, _, _ = self.E2(mix, mask=self.swap(mask))
-            _, pro_2m, _, _ = self.E2(rec, mask=mask)
-            sp_3 = self.E1(mix)
-            nz = self.noise
-            if isinstance(nz, dict):
-                nz = {k: v[:B // 2] for k, v in nz.items()}
-            cyc = self.G(self.swap(sp_3)[:B // 2], [g[:B // 2] for g in gl], noise=nz)
-            metrics["L1_dist"] = ops.l1_mean(cyc, real[:B // 2].contiguous(), 1.0)
-            losses["G_L1_cyc"] = metrics["L1_dist"] * 3
-            s1 = s2 = 0.0
-            pending = []
-            for lid in range(0, 12, 3):
-                li = lid // 3
-                key0, keyw = torch.cat(pro_ms[lid:lid + 3], 0), torch.cat(pro_mw[lid:lid + 3], 0)
-                query, query_r = torch.cat(pro_3m[lid:lid + 3], 0), torch.cat(pro_2m[lid:lid + 3], 0)
-                s1 = s1 + self.criterionNCE(query, keyw, key0, li)
-                s2 = s2 + self.criterionNCE(query_r, key0, keyw, li)
-                pending.append((torch.cat((key0[0:3], keyw[0:3]), 0), li))
-            self.criterionNCE.enqueue_all(pending)     # each layer has its own queue: the enqueues can follow the losses
-            losses["G_styleContmix"] = s1 * lam("lambda_StyleCon", 1.0)
-            losses["G_styleContrec"] = s2 * lam("lambda_StyleCon", 1.0)
-        if lam("lambda_GAN", 1.0) > 0.0:
-            losses["G_GAN_rec"] = ops.lsgan(self.D(rec), 1.0, 0.5 * lam("lambda_GAN", 1.0))[0]
-            if lam("lambda_StyleCon", 1.0) > 0.0:
-                losses["G_GAN_mix"] = ops.lsgan(self.D(mix), 1.0, lam("lambda_GAN", 1.0))[0]
-        return losses, metrics
+        """ppst_model.py:161-235 (sp_ma / gl_ma are unused there too).  Differentiable: losses carry grad_fn when gradients are
+        enabled; also performs the NCE queue updates."""
+        return self.trainer().compute_generator_losses(real, mask)
+
+    # DistributedDataParallel's constructor broadcasts rank 0's parameters and buffers (models/__init__.py:88): without it the
+    # NCE queues -- torch.randn per process (networks/rscl.py:24-31) -- and any unseeded initialisation differ between ranks.
+    def sync_from_rank0(self):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return self
+        with torch.no_grad():
+            tr = getattr(self, "_trainer", None)
+            if tr is not None:                     # parameters live in flat buffers: one broadcast per network
+                for f in list(tr.fp.values()) + ([tr.d_trainer] if tr.d_trainer is not None else []):
+                    dist.broadcast(f.flat, 0)
+            else:
+                for p in self.parameters():
+                    dist.broadcast(p.data, 0)
+            for b in self.buffers():
+                dist.broadcast(b, 0)
+        for net in (self.E1, self.E2, self.G, getattr(self, "D", None)):
+            if net is not None and hasattr(net, "_cache"):
+                net._cache.clear()
+        if tr is not None:
+            tr.invalidate()
+        return self
 
     def get_parameters_for_mode(self, mode):
         m = {"generator": "G", "contentencoder": "E1", "colorencoder": "E2", "discriminator": "D"}[mode]

@@ -27,6 +27,8 @@ if len(sys.argv) > 10:
     ops.KSPLIT_128["value"] = bool(int(sys.argv[10]))
 if len(sys.argv) > 11:
     ops.TILE24_128["value"] = bool(int(sys.argv[11]))
+if len(sys.argv) > 12:
+    ops.TWO_BLOCK_8ROW["value"] = bool(int(sys.argv[12]))
 dev = torch.device("cuda", 0)
 sd = W.make_state_dict(0, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
 m = create_model(state_dict=sd, device=dev)

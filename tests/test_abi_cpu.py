@@ -70,10 +70,28 @@ def test_conv_entry_rejects_images_beyond_32bit_offsets():
     a.out_scale = 1.0
     assert _lib.lib.ppst_conv2d_mfma(ctypes.byref(a), None) == 0
     a.in_h = a.in_w = a.out_h = a.out_w = a.tile_h = a.tile_w = 8192
+    a.in_ld = 4                                            # (input side small: 8192 * 8192 * 4 floats = 2^30 bytes)
     a.out_ld = 64                                          # 8192 * 8192 * 64 = 2^32 elements in one image
     assert _lib.lib.ppst_conv2d_mfma(ctypes.byref(a), None) == -1
     a.out_ld, a.cout = 28, 28                              # 8192 * 8192 * 28 < 2^31: accepted again
     assert _lib.lib.ppst_conv2d_mfma(ctypes.byref(a), None) == 0
+    # the input side: the kernels address one input image with 32-bit BYTE offsets (buffer loads), also through the pixel stride
+    # of a channel slice of a wide tensor
+    a.in_ld = 8                                            # 8192 * 8192 * 8 floats = 2^31 bytes
+    assert _lib.lib.ppst_conv2d_mfma(ctypes.byref(a), None) == -1
+    a.in_ld = 4
+    assert _lib.lib.ppst_conv2d_mfma(ctypes.byref(a), None) == 0
+    # the exact-fp32 twin mirrors the checks (and wants 16-row tiles: its statistics layout assumes them)
+    w = ctypes.c_void_p(16)
+    f32 = lambda: _lib.lib.ppst_conv2d_f32(ctypes.byref(a), w, 9, 1, 3, 1, ctypes.c_float(1.0), w, w, w, None)
+    assert f32() == 0
+    a.in_ld = 8
+    assert f32() == -1
+    a.in_ld, a.out_ld, a.cout = 4, 64, 64
+    assert f32() == -1
+    a.out_ld, a.cout, a.tile_rows = 28, 28, 8
+    assert f32() == -1
+    a.tile_rows = 16
     a.variant, a.tile_rows, a.bn, a.early_a = 9, 16, 128, 1   # variant 9 needs tile_rows 24
     a.out_ld, a.cout = 128, 128
     a.in_h = a.in_w = a.out_h = a.out_w = a.tile_h = a.tile_w = 64
