@@ -489,6 +489,42 @@ class DiscriminatorLogitsFn(Function):
         return ops.nhwc_to_nchw(keep["d_img"]), None
 
 
+class DLossesFn(Function):
+    """compute_image_discriminator_losses (ppst_model.py:68-103) as ONE autograd node over the discriminator trainer's taped
+    forward / backward (ppst_amd/train.py): outputs D_real, D_rec[, D_mix]; backward writes d/d(theta_D) straight into the
+    trainer's flat gradient (= the ``p.grad`` views of D's parameters) -- the images are constants here (rec / mix were made
+    under no_grad), so no gradient leaves the node.  ``anchor`` is the trainer's requires-grad leaf that keeps the node alive."""
+
+    @staticmethod
+    def forward(ctx, anchor, trainer, real, rec, mix, lambda_GAN):
+        losses, state = trainer.d_forward(real, rec, mix, lambda_GAN)
+        ctx.trainer, ctx.state = trainer, state
+        return tuple(losses.values())
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        ctx.trainer.d_backward(ctx.state, [None if g is None else _c(g) for g in gouts])
+        ctx.state = None
+        return None, None, None, None, None, None
+
+
+class R1Fn(Function):
+    """compute_R1_loss (ppst_model.py:140-159): per-sample penalty; backward = the second-order sweep of
+    DiscriminatorTrainer.r1_backward with the upstream per-sample gradient."""
+
+    @staticmethod
+    def forward(ctx, anchor, trainer, real, lambda_R1):
+        pen, state = trainer.r1_forward(real, lambda_R1)
+        ctx.trainer, ctx.state = trainer, state
+        return pen
+
+    @staticmethod
+    def backward(ctx, gout):
+        ctx.trainer.r1_backward(ctx.state, _c(gout))
+        ctx.state = None
+        return None, None, None, None
+
+
 # ---------------------------------------------------------------- correspondence (ppst_model.py:330-387) ----
 class RSelfCorrFn(Function):
     """PPSTModel.Rselfcorr: (B,256,256,64) NHWC -> (B,64,64,256)."""

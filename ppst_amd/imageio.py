@@ -111,3 +111,15 @@ def preprocess(img, load_size=512):
     if (w2, h2) != (w1, h1):
         x = resize_bicubic_u8(x, h2, w2)
     return to_tensor_normalized(x)
+
+
+def preprocess_resize(img, load_size=512):
+    """The training transform of the reference's launcher (experiments/CelebA_launcher.py:17-18 ``preprocess="resize"``,
+    base_dataset.py:91-95): ``transforms.Resize([load_size, load_size], BICUBIC)`` (a square, whatever the aspect), then
+    ``__make_power_2``, ToTensor, Normalize: (B,H,W,3) uint8 -> (B,3,h,w) float32 in [-1,1]."""
+    B, H, W, C = img.shape
+    x = resize_bicubic_u8(img, load_size, load_size) if (W, H) != (load_size, load_size) else img
+    w2, h2 = make_power_2_size(load_size, load_size)
+    if (w2, h2) != (load_size, load_size):
+        x = resize_bicubic_u8(x, h2, w2)
+    return to_tensor_normalized(x)

@@ -124,7 +124,17 @@ class PPSTModel(nn.Module):
         if missing:
             raise KeyError("state dict lacks %d keys, e.g. %s" % (len(missing), missing[:3]))
         self.load_state_dict({k: sd[k] for k in own}, strict=True)
+        self._weights_changed()
         return self
+
+    def _weights_changed(self):
+        """Packed weights, style tables and the trainers' host-side scalar copies are stale after any external write."""
+        for net in (self.E1, self.E2, self.G, getattr(self, "D", None)):
+            if net is not None and hasattr(net, "_cache"):
+                net._cache.clear()
+        tr = self.__dict__.get("_trainer")
+        if tr is not None:
+            tr.invalidate()
 
     # BaseModel.save / BaseModel.load (models/base_model.py:33-112): same file layout
     # (<checkpoints_dir>/<name>/<iter>_checkpoint.pth + latest_checkpoint.pth symlink), same key
@@ -177,9 +187,7 @@ class PPSTModel(nn.Module):
                         own[hi].zero_()
                     continue
                 own.copy_(param)
-        for net in (self.E1, self.E2, self.G, getattr(self, "D", None)):
-            if net is not None and hasattr(net, "_cache"):
-                net._cache.clear()  # packed weights / style tables are stale
+        self._weights_changed()  # packed weights / style tables / host scalars are stale
         if verbose:
             print("checkpoint loaded from %s" % checkpoint_path)
         return True
@@ -296,7 +304,7 @@ class PPSTModel(nn.Module):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return self
         with torch.no_grad():
-            tr = getattr(self, "_trainer", None)
+            tr = self.__dict__.get("_trainer")
             if tr is not None:                     # parameters live in flat buffers: one broadcast per network
                 for f in list(tr.fp.values()) + ([tr.d_trainer] if tr.d_trainer is not None else []):
                     dist.broadcast(f.flat, 0)
@@ -305,11 +313,7 @@ class PPSTModel(nn.Module):
                     dist.broadcast(p.data, 0)
             for b in self.buffers():
                 dist.broadcast(b, 0)
-        for net in (self.E1, self.E2, self.G, getattr(self, "D", None)):
-            if net is not None and hasattr(net, "_cache"):
-                net._cache.clear()
-        if tr is not None:
-            tr.invalidate()
+        self._weights_changed()
         return self
 
     def get_parameters_for_mode(self, mode):

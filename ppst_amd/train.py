@@ -12,8 +12,7 @@ Everything numerical is a HIP kernel: the forward kernels of the inference path 
 where the backward needs the pre-merge activation), the conv input gradient = the same MFMA
 conv kernel on a transposed / flipped pack, the conv weight gradient = fp32-MFMA reduction over
 pixels (csrc/train.hip).  The lazy R1 penalty (double backward) is one more forward sweep with
-the same kernels (r1_losses_and_grads).  Not built yet: the generator/encoder update
-(compute_generator_losses) -- see DESIGN.md.
+the same kernels (r1_forward / r1_backward).  The generator / encoder update lives in ppst_amd/train_g.py.
 """
 import math
 
@@ -82,9 +81,14 @@ class DiscriminatorTrainer:
         self.v = torch.zeros_like(flat)
         self.offsets = {}
         off = 0
-        for n_, sz in zip(self.names, self.sizes):
+        for n_, p, sz in zip(self.names, params, self.sizes):
             self.offsets[n_] = (off, sz)
+            p.grad = self.grad[off:off + sz].view_as(p)      # what optimizer_D reads in the reference: views of the flat gradient
             off += sz
+        # the facade's loss tensors hang on this leaf (ppst_model.compute_discriminator_losses / compute_R1_loss): D's
+        # parameters themselves are not autograd inputs, their gradients are written by the taped backward below
+        self.anchor = torch.zeros(1, device=flat.device, requires_grad=True)
+        self._pending = None                                  # async gradient all-reduce whose Adam step is still owed
 
     def g(self, name):
         off, sz = self.offsets[name]
@@ -93,6 +97,7 @@ class DiscriminatorTrainer:
     # ---------------------------------------------------------------- forward
     def forward(self, img):
         """D forward keeping what the backward needs.  img NCHW.  Returns (pred (B,1), tape)."""
+        self.finish_pending()
         D, p = self.D, "stylegan2_D."
         tape = {}
         x0 = to_nhwc(img)
@@ -217,16 +222,22 @@ class DiscriminatorTrainer:
     # -------------------------------------------------------------- R1 penalty
     def r1_penalty(self, real, lambda_R1=10.0):
         """compute_R1_loss value only: per-sample 0.5*lambda*||d sum(D(x))/dx||^2 (forward + backward to the image)."""
+        return self.r1_forward(real, lambda_R1)[0]
+
+    def r1_forward(self, real, lambda_R1=10.0):
+        """compute_R1_loss (ppst_model.py:140-159): per-sample penalty 0.5*lambda*||d sum(D(x)) / dx||^2 -> (pen (B,), state)."""
         pred, tape = self.forward(real)
+        B = pred.shape[0]
         keep = {}
         self.backward(tape, torch.ones_like(pred), param_grads=False, keep=keep)
-        g_img = keep["d_img"]
-        part = ops.in_stats(g_img)
-        return torch.stack([ops.colsum(part[b].view(-1, 2), 0.5 * lambda_R1)[1] for b in range(pred.shape[0])])
+        g_img = keep["d_img"]                                    # (B,S,S,3)
+        part = ops.in_stats(g_img)                                # (B, n, 3, 2): per-channel (sum, sumsq) partials
+        pen = torch.stack([ops.colsum(part[b].view(-1, 2), 0.5 * lambda_R1)[1] for b in range(B)])
+        return pen, (tape, keep, lambda_R1)
 
-    def r1_losses_and_grads(self, real, lambda_R1=10.0, R1_once_every=16):
-        """Lazy R1 (ppst_model.py:140-159, ppst_optimizer.py:116-126): per-sample penalty
-        0.5*lambda*||d sum(D(x)) / dx||^2 and d(mean(penalty) * R1_once_every)/d(theta_D) into self.grad.
+    def r1_backward(self, state, gout):
+        """d(sum_b gout[b] * pen[b]) / d(theta_D) accumulated into self.grad (ppst_optimizer.py:116-126 feeds
+        gout = R1_once_every / B: ``r1_loss = mean(pen) * R1_once_every``).
 
         Leaky-ReLU gates are piecewise constant, so g(x) = J(theta)^T 1 is linear in each weight
         with the taped gates fixed and biases drop out.  Reverse mode over the *backward* pass
@@ -234,17 +245,12 @@ class DiscriminatorTrainer:
         convs / blurs / gates (no biases), and every layer adds wgrad(input = t_in, dy = the
         first backward's gradient at that layer's pre-activation)."""
         D, p = self.D, "stylegan2_D."
-        self.grad.zero_()
-        pred, tape = self.forward(real)
-        B = pred.shape[0]
-        ones = torch.ones_like(pred)
-        keep = {}
-        self.backward(tape, ones, param_grads=False, keep=keep)
-        g_img = keep["d_img"]                                    # (B,S,S,3)
-        part = ops.in_stats(g_img)                                # (B, n, 3, 2): per-channel (sum, sumsq) partials
-        pen = torch.stack([ops.colsum(part[b].view(-1, 2), 0.5 * lambda_R1)[1] for b in range(B)])
-        # L = R1_once_every * mean_b(pen_b)  ->  dL/dg = R1_once_every * lambda / B * g
-        t = ops.affine_act(g_img, None, out_scale=R1_once_every * lambda_R1 / B)
+        tape, keep, lambda_R1 = state
+        g_img = keep["d_img"]
+        B = g_img.shape[0]
+        # dL/dg_b = gout[b] * lambda * g_b: the per-image factor rides in as the (a, s) table of the apply kernel
+        ss = torch.stack((gout.reshape(B, 1).expand(B, 3), torch.zeros((B, 3), device=g_img.device)), dim=2).contiguous()
+        t = ops.affine_act(g_img, ss, out_scale=lambda_R1)
         w = D.p(p + "convs.0.Conv.weight")
         sc0 = 1.0 / math.sqrt(w.shape[1])
         self._acc("convs.0.Conv.weight", ops.wgrad_small_cin(t, keep["g0"], sc0))
@@ -277,17 +283,24 @@ class DiscriminatorTrainer:
         th = ops.linear(tf, w0, None, wscale=s0)
         th = _lrelu_bwd(th, tape["h"])
         self._acc("final_linear.1.weight", ops.linear_wgrad(keep["dpred"], th, s1))
+
+    def r1_losses_and_grads(self, real, lambda_R1=10.0, R1_once_every=16):
+        """Lazy R1 (ppst_model.py:140-159, ppst_optimizer.py:116-126): zero_grad, penalty, and
+        d(mean(penalty) * R1_once_every)/d(theta_D) into self.grad."""
+        self.grad.zero_()
+        pen, state = self.r1_forward(real, lambda_R1)
+        B = pen.shape[0]
+        self.r1_backward(state, torch.full((B,), R1_once_every / B, device=pen.device))
         return {"D_R1": pen}
 
     def _dgrad(self, wname, kind, scale):
         return self.D.plan(wname, kind, scale)
 
     # ------------------------------------------------------------------- step
-    def losses_and_grads(self, real, rec, mix, lambda_GAN=1.0):
-        """LSGAN losses on real / rec / mix and d(sum of losses)/d(theta_D) into self.grad.  The three image sets
-        go through D as ONE batch (the gradient is the sum over the sets either way): one forward, one backward,
-        a third of the launches, and the weight-gradient reduction runs over all images at once."""
-        self.grad.zero_()
+    def d_forward(self, real, rec, mix, lambda_GAN=1.0):
+        """LSGAN losses on real / rec / mix (ppst_model.py:68-103) -> (losses dict, state).  The three image sets go through D
+        as ONE batch (the gradient is the sum over the sets either way): one forward, one backward, a third of the launches,
+        and the weight-gradient reduction runs over all images at once."""
         sets = [(n, img, t, w) for n, img, t, w in (("D_real", real, 1.0, lambda_GAN), ("D_rec", rec, 0.0, 0.5 * lambda_GAN),
                                                     ("D_mix", mix, 0.0, 0.5 * lambda_GAN)) if img is not None]
         imgs = torch.cat([s_[1] for s_ in sets], dim=0) if len(sets) > 1 else sets[0][1]
@@ -299,8 +312,25 @@ class DiscriminatorTrainer:
             losses[name] = loss
             dparts.append(dp)
             o += nb
+        return losses, (tape, dparts)
+
+    def d_backward(self, state, gouts=None):
+        """d(sum_i gouts[i] * loss_i) / d(theta_D) accumulated into self.grad (gouts None: all ones)."""
+        tape, dparts = state
+        if gouts is not None:
+            dparts = [dp if g is None else ops.scale_by(dp, g.reshape(1)) for dp, g in zip(dparts, gouts)]
         self.backward(tape, torch.cat(dparts, dim=0) if len(dparts) > 1 else dparts[0])
+
+    def losses_and_grads(self, real, rec, mix, lambda_GAN=1.0):
+        """zero_grad + LSGAN losses + d(sum of losses)/d(theta_D) into self.grad."""
+        self.grad.zero_()
+        losses, state = self.d_forward(real, rec, mix, lambda_GAN)
+        self.d_backward(state)
         return losses
+
+    def zero_grad(self):
+        self.finish_pending()
+        self.grad.zero_()
 
     def all_reduce(self):
         """DDP gradient averaging: one flat all-reduce (RCCL when the tensors are on the GPU)."""
@@ -313,6 +343,26 @@ class DiscriminatorTrainer:
         self.step_count += 1
         ops.adam_step_(self.flat, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, self.step_count)
         self.D._cache.clear()  # packed weights are stale
+
+    # Data parallel, overlapped: the discriminator iteration ends with its 116-MB gradient all-reduce; nothing else in that
+    # iteration needs D any more, and the generator iteration that follows does not touch D before its GAN terms.  So the
+    # all-reduce is launched asynchronously and the Adam step that consumes it is OWED: finish_pending() settles it (wait,
+    # divide by the world size, Adam) in front of the next use of D -- forward(), zero_grad(), a checkpoint -- and the collective
+    # runs under the E1 / E2 / G forward passes of the generator iteration.
+    def step_deferred(self):
+        """all_reduce + adam of the reference's ``optimizer_D.step()`` under DDP; the collective is asynchronous for world > 1."""
+        if self.world <= 1:
+            return self.adam()
+        import torch.distributed as dist
+        self._pending = dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish_pending(self):
+        h = self._pending
+        if h is not None:
+            self._pending = None
+            h.wait()
+            self.grad.div_(self.world)
+            self.adam()
 
     def train_step(self, model, real, lambda_StyleCon=1.0, lambda_R1=10.0):
         """One discriminator iteration (ppst_optimizer.py:96-130): images from the frozen E1/E2/G,

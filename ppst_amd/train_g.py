@@ -65,6 +65,13 @@ class FlatParams:
             self._scalars, self._scalar_key = dict(zip(names, vals)), key
         return self._scalars[name]
 
+    def invalidate(self):
+        """Forget host-side copies of parameter values (the noise-weight scalars) and the network's packed weights: call after
+        ANY write to the parameters that did not go through adam() -- load_state_dict / PPSTModel.load copy into the parameter
+        views, which bumps their version counters, not the flat buffer's."""
+        self._scalar_key = None
+        self.net._cache.clear()
+
     def owns_parameters(self):
         off = 0
         for p, n in zip(self.params, self.sizes):
@@ -81,14 +88,30 @@ class FlatParams:
             raise RuntimeError("parameters / gradients no longer alias the flat buffers of this trainer")
         self.step_count += 1
         ops.adam_step_(self.flat, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, self.step_count)
-        self.net._cache.clear()      # packed weights are stale
+        self.invalidate()            # packed weights and host scalars are stale
 
 
 class GeneratorTrainer:
     """Differentiable E1 / E2 / G forward + the generator iteration of PPSTOptimizer."""
 
+    @classmethod
+    def for_model(cls, model, **kw):
+        """The trainer that owns ``model`` (created on first use and kept on it, like DiscriminatorTrainer.for_network): its
+        constructor rebinds the parameters of E1 / E2 / G into flat buffers, a second one would orphan the first one's state."""
+        tr = model.__dict__.get("_trainer")
+        if tr is None or not all(f.owns_parameters() for f in tr.fp.values()):
+            tr = cls(model, **kw)
+        return tr
+
+    def invalidate(self):
+        for f in self.fp.values():
+            f.invalidate()
+        if self.d_trainer is not None:
+            self.d_trainer.D._cache.clear()
+
     def __init__(self, model, lr=1e-3, beta1=0.0, beta2=0.99, world=1):
         self.model = model
+        model.__dict__["_trainer"] = self
         self.opt = model.opt
         self.world = world
         self.G, self.E1, self.E2 = model.G, model.E1, model.E2
@@ -297,8 +320,20 @@ class GeneratorTrainer:
     def gan_logits(self, img):
         return A.DiscriminatorLogitsFn.apply(img, self.d_trainer)
 
+    def begin_backward_overlap(self):
+        """Arm the per-network gradient all-reduces that fire from inside backward() (world > 1)."""
+        if self.world > 1:
+            self._install_overlap_hooks()
+            self._pending = {}
+            for k in self._done_count:
+                self._done_count[k] = 0
+
     def compute_generator_losses(self, real, mask=None):
+        """PPSTModel.compute_generator_losses (ppst_model.py:161-235; ``model(real, None, None, mask,
+        command="compute_generator_losses")`` lands here): the loss / metric tensors carry the autograd graph."""
         opt, m = self.opt, self.model
+        if torch.is_grad_enabled():
+            self.begin_backward_overlap()
         lam = lambda k, d: float(getattr(opt, k, d))
         stage = int(getattr(opt, "training_stage", 2))
         B = real.shape[0]
@@ -358,11 +393,6 @@ class GeneratorTrainer:
 
     def losses_and_grads(self, real, mask=None):
         self.zero_grad()
-        if self.world > 1:
-            self._install_overlap_hooks()
-            self._pending = {}
-            for k in self._done_count:
-                self._done_count[k] = 0
         with torch.enable_grad():
             losses, metrics = self.compute_generator_losses(real, mask)
             total = None
@@ -417,23 +447,52 @@ class GeneratorTrainer:
         return losses
 
 
+class FlatAdam:
+    """torch.optim.Adam of one network for the restated PPSTOptimizer: ``zero_grad()`` / ``step()`` on the network's flat
+    parameter / gradient / moment buffers (ONE launch).  ``step()`` first completes the data-parallel gradient average that
+    DistributedDataParallel performs inside ``backward()`` for the reference (models/__init__.py:88)."""
+
+    def __init__(self, flat, reduce=None):
+        self.flat, self.reduce = flat, reduce
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+    def step(self):
+        if self.reduce is not None:
+            self.reduce()
+        self.flat.adam()
+
+
 class PPSTOptimizer:
-    """optimizers/ppst_optimizer.py:PPSTOptimizer on the HIP path: the D / G alternation of ``train_one_step``
-    (:60-71 -- the first call is a discriminator iteration, the mode names are swapped in the reference), Adam for G, E1,
-    E2 (lr, betas) and for D (lazy-regularisation corrected lr / betas, :46-49), the lazy R1 penalty every
-    ``R1_once_every`` discriminator iterations (:116-126) and ``D_total`` (:127).  ``data_i`` = {"real_A": (B,3,H,W),
-    "mask_A": (B,3,H,W) one-hot}.  Gradients are averaged over ranks with one flat all-reduce per network (RCCL)."""
+    """optimizers/ppst_optimizer.py:PPSTOptimizer restated line by line on the model facade: the D / G alternation of
+    ``train_one_step`` (:60-71 -- the first call is a discriminator iteration, the mode names are swapped in the reference),
+    ``model(..., command=...)`` -> ``sum(v.mean())`` -> ``.backward()`` -> ``optimizer.step()`` for G, E2, E1 (:73-94) and for D
+    with the lazy R1 penalty every ``R1_once_every`` discriminator iterations (:96-130; lazy-regularisation corrected lr /
+    betas :46-49) and ``D_total`` (:127).  ``data_i`` = {"real_A": (B,3,H,W), "mask_A": (B,3,H,W) one-hot}.  Gradients are
+    averaged over ranks with one flat all-reduce per network (RCCL): G / E2 / E1 overlapped with backward, D overlapped with the
+    generator iteration that follows (DiscriminatorTrainer.step_deferred)."""
 
     def __init__(self, model, lr=1e-3, beta1=0.0, beta2=0.99, R1_once_every=16, world=1):
         self.model, self.opt = model, model.opt
         self.train_mode_counter = 0
+        self.discriminator_iter_counter = 0
         self.R1_once_every = R1_once_every
-        self.gen = GeneratorTrainer(model, lr, beta1, beta2, world)
+        self.gen = GeneratorTrainer.for_model(model, lr=lr, beta1=beta1, beta2=beta2, world=world)
+        self.gen.world = world
+        for f in self.gen.fp.values():
+            f.lr, f.b1, f.b2 = lr, beta1, beta2
         self.dis = self.gen.d_trainer
+        # the generator-side all-reduces are launched from inside backward(); the first step() of an iteration completes them
+        self.optimizer_G = FlatAdam(self.gen.fp["G"], reduce=self.gen.all_reduce)
+        self.optimizer_E2 = FlatAdam(self.gen.fp["E2"])
+        self.optimizer_E1 = FlatAdam(self.gen.fp["E1"])
+        self.optimizer_D = None
         if self.dis is not None:
             c = R1_once_every / (1 + R1_once_every)
             self.dis.lr, self.dis.b1, self.dis.b2 = lr * c, beta1 ** c, beta2 ** c
             self.dis.R1_once_every, self.dis.world = R1_once_every, world
+            self.optimizer_D = self.dis
 
     def prepare_images(self, data_i):
         return data_i["real_A"], data_i["mask_A"]
@@ -444,30 +503,59 @@ class PPSTOptimizer:
         return modes[self.train_mode_counter]
 
     def train_one_step(self, data_i, total_steps_so_far=0):
-        images, mask = self.prepare_images(data_i)
+        images_minibatch, mask_minibatch = self.prepare_images(data_i)
         if self.toggle_training_mode() == "generator":
-            losses = self.train_discriminator_one_step(images, mask)
+            losses = self.train_discriminator_one_step(images_minibatch, mask_minibatch)
         else:
-            losses = self.train_generator_one_step(images, mask)
+            losses = self.train_generator_one_step(images_minibatch, mask_minibatch)
         return {k: float(v.float().mean()) for k, v in losses.items()}      # util.to_numpy
 
     def train_generator_one_step(self, images, mask):
-        return self.gen.train_step(images, mask)
+        sp_ma, gl_ma = None, None
+        self.optimizer_G.zero_grad()
+        self.optimizer_E1.zero_grad()
+        self.optimizer_E2.zero_grad()
+        with torch.enable_grad():
+            g_losses, g_metrics = self.model(images, sp_ma, gl_ma, mask, command="compute_generator_losses")
+            g_loss = sum([v.mean() for v in g_losses.values()])
+            g_loss.backward()
+        self.optimizer_G.step()
+        self.optimizer_E2.step()
+        self.optimizer_E1.step()
+        g_losses = {k: v.detach() for k, v in g_losses.items()}
+        g_losses.update({k: v.detach() for k, v in g_metrics.items()})
+        return {**g_losses}
 
     def train_discriminator_one_step(self, images, mask):
         if float(getattr(self.opt, "lambda_GAN", 1.0)) == 0.0 or self.dis is None:
             return {}
-        with torch.no_grad():
-            losses = self.dis.train_step(self.model, images, float(getattr(self.opt, "lambda_StyleCon", 1.0)),
-                                         float(getattr(self.opt, "lambda_R1", 10.0)))
-        if hasattr(self.model, "num_discriminator_iters"):
-            self.model.num_discriminator_iters.add_(1)
-        total = None
-        for v in losses.values():
-            m_ = v.float().mean()
-            total = m_ if total is None else total + m_
-        losses["D_total"] = total
-        return losses
+        self.discriminator_iter_counter += 1
+        self.dis.iter_counter = self.discriminator_iter_counter
+        self.optimizer_D.zero_grad()
+        with torch.enable_grad():
+            d_losses, d_metrics, sp, gl = self.model(images, mask, command="compute_discriminator_losses")
+            self.previous_sp = sp.detach()
+            self.previous_gl = [g.detach() for g in gl]
+            d_loss = sum([v.mean() for v in d_losses.values()])
+            d_loss.backward()
+        lambda_R1 = float(getattr(self.opt, "lambda_R1", 10.0))
+        needs_R1_at_current_iter = lambda_R1 > 0.0 and self.discriminator_iter_counter % self.R1_once_every == 0
+        if needs_R1_at_current_iter:
+            self.optimizer_D.all_reduce(); self.optimizer_D.adam()          # optimizer_D.step(): R1 needs the updated D at once
+            self.optimizer_D.zero_grad()
+            with torch.enable_grad():
+                r1_losses = self.model(images, command="compute_R1_loss")
+                d_losses.update(r1_losses)
+                r1_loss = sum([v.mean() for v in r1_losses.values()])
+                r1_loss = r1_loss * self.R1_once_every
+                r1_loss.backward()
+        self.optimizer_D.step_deferred()                                     # optimizer_D.step(), all-reduce overlapped (world > 1)
+        d_losses = {k: v.detach() for k, v in d_losses.items()}
+        d_losses["D_total"] = sum([v.mean() for v in d_losses.values()])
+        d_losses.update(d_metrics)
+        return d_losses
 
     def save(self, total_steps_so_far):
+        if self.dis is not None:
+            self.dis.finish_pending()
         return self.model.save(total_steps_so_far)

@@ -38,10 +38,14 @@ class IterationCounter:
             steps = int(str(resume).replace("k", ""))
             self.steps_so_far = steps * 1000 if "k" in str(resume) else steps
 
-    def record_one_iteration(self):
-        if self.needs_saving():
+    def record_one_iteration(self, write=True):
+        """``write``: only rank 0 writes iter.txt (the reference calls this inside its ``local_rank == 0`` block, train.py:33-56;
+        here every rank advances its count, one writes) -- through a temporary file, so a reader never sees a truncated record."""
+        if write and self.needs_saving():
             os.makedirs(os.path.dirname(self.iter_record_path), exist_ok=True)
-            np.savetxt(self.iter_record_path, [self.steps_so_far], delimiter=",", fmt="%d")
+            tmp = self.iter_record_path + ".tmp%d" % os.getpid()
+            np.savetxt(tmp, [self.steps_so_far], delimiter=",", fmt="%d")
+            os.replace(tmp, self.iter_record_path)
         self.steps_so_far += self.batch_size
 
     def needs_saving(self):
@@ -92,13 +96,26 @@ class MetricTracker:
 class CelebAMaskDataset:
     """data/CelebAMask_dataset.py:20-60 + data/__init__.py's per-rank sharding: <dataroot>/images/*.jpg|png and
     <dataroot>/labels/<same stem>.png (integer label map {0, 1, 2}, g_mask.py's aggregation).  Images are decoded on the
-    host, resized and normalised ON THE DEVICE with the Pillow-exact kernels (ppst_amd/imageio.py); label maps are
-    resized nearest and turned into one-hot masks by the exact glue kernel (:54-60).  ``next()`` yields batches forever
-    (ConfigurableDataLoader, data/__init__.py:131-149), shuffled per epoch with a DistributedSampler-style split:
-    sample k of an epoch's permutation belongs to rank k mod world."""
+    host, resized and normalised ON THE DEVICE with the Pillow-exact kernels (ppst_amd/imageio.py); label maps are turned into
+    one-hot masks by the exact glue kernel (:54-60).  ``next()`` yields batches forever (ConfigurableDataLoader,
+    data/__init__.py:131-149), shuffled per epoch with a DistributedSampler-style split: sample k of an epoch's permutation
+    belongs to rank k mod world; ``batch_size`` is the PER-RANK batch (the reference's ``opt.batch_size / opt.num_gpus``,
+    data/__init__.py:116).
 
-    def __init__(self, dataroot, size=512, batch_size=2, rank=0, world=1, device="cuda", seed=0):
+    ``preprocess``: "resize" = the launcher's training transform (square ``load_size``, CelebA_launcher.py:17-18);
+    "scale_shortside" = the evaluators' transform.  ``flip``: RandomHorizontalFlip as in the reference's training transform
+    (``no_flip`` is not set there).  Two stated deviations: (1) the reference builds the image and the label transform
+    separately, so its two RandomHorizontalFlips draw independently and image / mask can end up mirrored against each other
+    (base_dataset.py:130-132, CelebAMask_dataset.py:17-18); here ONE draw flips both.  (2) the reference resizes the 'L' label
+    image with its BICUBIC transform and then compares ``mask_np == i``; at the dataset's native 512 that is the identity, off
+    size it invents label values -- here labels are resized NEAREST.  The next batch is decoded on a worker thread while the
+    current step runs (the reference: DataLoader workers)."""
+
+    def __init__(self, dataroot, size=512, batch_size=2, rank=0, world=1, device="cuda", seed=0, preprocess="scale_shortside",
+                 flip=False, prefetch=True):
+        assert preprocess in ("resize", "scale_shortside")
         self.size, self.batch_size, self.rank, self.world, self.device = size, batch_size, rank, world, device
+        self.preprocess, self.flip, self.prefetch = preprocess, flip, prefetch
         img_dir, lab_dir = os.path.join(dataroot, "images"), os.path.join(dataroot, "labels")
         exts = (".jpg", ".jpeg", ".png")
         names = sorted(f for f in os.listdir(img_dir) if f.lower().endswith(exts))
@@ -107,6 +124,7 @@ class CelebAMaskDataset:
             raise RuntimeError("no images under %s" % img_dir)
         self.epoch, self.pos, self.rng = 0, 0, random.Random(seed)
         self._order = self._epoch_order()
+        self._next = None
 
     def __len__(self):
         return len(self.pairs)
@@ -117,33 +135,70 @@ class CelebAMaskDataset:
         g.shuffle(order)
         return order[self.rank::self.world] or order[:1]
 
-    def _load(self, idx):
+    def _decode(self, idx):
+        """host side: file -> (uint8 HWC image, PIL 'L' label), optionally mirrored together."""
         from PIL import Image
-        from . import imageio
         ip, lp = self.pairs[idx]
         try:
             img = np.asarray(Image.open(ip).convert("RGB"))
             lab = Image.open(lp).convert("L")
         except OSError as err:                                   # CelebAMask_dataset.py:33-38: retry a random index
             print(err)
-            return self._load(self.rng.randrange(len(self.pairs)))
-        x = imageio.preprocess(torch.from_numpy(img[None]).to(self.device), self.size)[0]
+            return self._decode(self.rng.randrange(len(self.pairs)))
+        if self.flip and self.rng.random() < 0.5:
+            img = np.ascontiguousarray(img[:, ::-1])
+            lab = lab.transpose(Image.FLIP_LEFT_RIGHT)
+        return img, lab
+
+    def _to_device(self, img, lab):
+        from PIL import Image
+        from . import imageio
+        fn = imageio.preprocess_resize if self.preprocess == "resize" else imageio.preprocess
+        x = fn(torch.from_numpy(img[None]).to(self.device), self.size)[0]
         H, W = x.shape[1], x.shape[2]
         lab = torch.from_numpy(np.asarray(lab.resize((W, H), Image.NEAREST)).astype(np.int64))
         return x, lab
+
+    def _load(self, idx):
+        return self._to_device(*self._decode(idx))
+
+    def _decode_batch(self):
+        out = []
+        while len(out) < self.batch_size:
+            if self.pos >= len(self._order):
+                self.epoch, self.pos = self.epoch + 1, 0
+                self._order = self._epoch_order()
+            out.append(self._decode(self._order[self.pos]))
+            self.pos += 1
+        return out
 
     def __iter__(self):
         return self
 
     def __next__(self):
-        xs, labs = [], []
-        while len(xs) < self.batch_size:
-            if self.pos >= len(self._order):
-                self.epoch, self.pos = self.epoch + 1, 0
-                self._order = self._epoch_order()
-            x, lab = self._load(self._order[self.pos])
-            self.pos += 1
-            xs.append(x); labs.append(lab)
+        if self.prefetch:
+            import threading
+            if self._next is None:
+                cur = self._decode_batch()
+            else:
+                th, box = self._next
+                th.join()
+                if "err" in box:
+                    raise box["err"]
+                cur = box["batch"]
+            box = {}
+
+            def work():
+                try:
+                    box["batch"] = self._decode_batch()
+                except Exception as e:       # surfaced by the consumer's next call
+                    box["err"] = e
+            th = threading.Thread(target=work, daemon=True)
+            th.start()
+            self._next = (th, box)
+        else:
+            cur = self._decode_batch()
+        xs, labs = zip(*(self._to_device(img, lab) for img, lab in cur))
         labels = torch.stack(labs).to(self.device)
         return {"real_A": torch.stack(xs).contiguous(), "mask_A": glue.one_hot_mask(labels)}
 
@@ -218,7 +273,7 @@ def train_loop(opt, model, dataset, optimizer, iter_counter=None, log=print, max
         n += 1
         if iter_counter.completed_training() or (max_iterations is not None and n >= max_iterations):
             break
-        iter_counter.record_one_iteration()
+        iter_counter.record_one_iteration(write=rank0)
     if rank0:
         save_all(opt, optimizer, iter_counter.steps_so_far)
         log("Training finished.")

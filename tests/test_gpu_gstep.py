@@ -68,6 +68,69 @@ def test_train_step_reduced_precision():
     _run_blocks("t_train_precision")
 
 
+def test_facade_training_commands_are_differentiable_and_single_sourced():
+    """``model(real, None, None, mask, command="compute_generator_losses")`` returns tensors with grad_fn, and the reference's
+    ``sum(v.mean()).backward()`` (ppst_optimizer.py:86-88) on them leaves gradients BIT-IDENTICAL to
+    GeneratorTrainer.losses_and_grads in the networks' ``p.grad`` (one composition, two entry points); the same for
+    compute_discriminator_losses (:105-111) and compute_R1_loss (:119-123) against the discriminator trainer."""
+    import gstep_diag as D
+    from ppst_amd import weights as W
+    from ppst_amd.ppst_model import Options, create_model
+    from ppst_amd.train import d_step_images
+    real, mask, noise = D.gstep_inputs()
+    real, mask = real.cuda(), mask.cuda()
+    models = []
+    for _ in range(2):
+        sd = W.make_state_dict(17, bias_std=0.1, noise_weight=0.1)
+        m = create_model(Options(training_stage=2, lambda_Cycwarp=0.0), state_dict=sd, with_D=True, with_nce=True)
+        m.noise = {k: v.cuda() for k, v in noise.items()}
+        models.append(m)
+    m1, m2 = models
+    out1 = m1.trainer().losses_and_grads(real, mask)
+    tr2 = m2.trainer()
+    tr2.zero_grad()
+    with torch.enable_grad():
+        g_losses, g_metrics = m2(real, None, None, mask, command="compute_generator_losses")
+        assert all(v.grad_fn is not None for v in g_losses.values())
+        g_loss = sum([v.mean() for v in g_losses.values()])
+        g_loss.backward()
+    for k in ("G", "E2", "E1"):
+        assert float(tr2.fp[k].grad.abs().max()) > 0.0
+        assert torch.equal(m1.trainer().fp[k].grad, tr2.fp[k].grad), k
+        # and they sit in p.grad of the networks' own parameters
+        p = next(iter(getattr(m2, k).parameters()))
+        assert p.grad is not None and p.grad.data_ptr() == tr2.fp[k].grad.data_ptr()
+    for k, v in g_losses.items():
+        assert torch.equal(v.detach().reshape(-1), out1[k].reshape(-1)), k
+    with torch.no_grad():                                    # value path: no graph
+        lv, _ = m2(real, None, None, mask, command="compute_generator_losses")
+    assert all(v.grad_fn is None for v in lv.values())
+    # discriminator iteration
+    d1, d2 = m1.trainer().d_trainer, m2.trainer().d_trainer
+    with torch.no_grad():
+        rec, mix = d_step_images(m1, real, 1.0)
+    ref = d1.losses_and_grads(real, rec, mix)
+    d2.zero_grad()
+    m2.criterionNCE.load_state_dict(m1.criterionNCE.state_dict())
+    for net in ("E1", "E2", "G"):                            # the generator step above did not change weights; same images
+        assert torch.equal(m1.trainer().fp[net].flat, tr2.fp[net].flat)
+    with torch.enable_grad():
+        d_losses, d_metrics, sp, gl = m2(real, mask, command="compute_discriminator_losses")
+        assert all(v.grad_fn is not None for v in d_losses.values())
+        sum([v.mean() for v in d_losses.values()]).backward()
+    assert float(d2.grad.abs().max()) > 0.0 and torch.equal(d1.grad, d2.grad)
+    assert all(torch.equal(ref[k].reshape(-1), d_losses[k].detach().reshape(-1)) for k in ref)
+    pD = next(iter(m2.D.parameters()))
+    assert pD.grad.data_ptr() == d2.grad.data_ptr()
+    # lazy R1
+    r1_ref = d1.r1_losses_and_grads(real, 10.0, 16)
+    d2.zero_grad()
+    with torch.enable_grad():
+        r1 = m2(real, command="compute_R1_loss")
+        (sum([v.mean() for v in r1.values()]) * 16).backward()
+    assert torch.equal(r1_ref["D_R1"], r1["D_R1"].detach()) and torch.equal(d1.grad, d2.grad) and float(d2.grad.abs().max()) > 0.0
+
+
 def test_generator_adam_step_and_alternation():
     """PPSTOptimizer mirror: first call = discriminator iteration (+ D_total), second = generator iteration; the
     parameter update equals torch.optim.Adam(lr 1e-3, betas (0, 0.99)) applied to the gradients of that step."""
@@ -153,3 +216,30 @@ def test_celebamask_dataset_loader(tmp_path):
         assert np.array_equal(batch["real_A"][n].cpu().numpy(), R.preprocess(imgs[idx], 64))
         onehot = np.stack([(labs[idx] == c) for c in range(3)]).astype(np.float32)
         assert np.array_equal(batch["mask_A"][n].cpu().numpy(), onehot)
+    # second batch comes from the prefetch thread: same content rules
+    batch2 = next(ds)
+    assert tuple(batch2["real_A"].shape) == (3, 3, 64, 64) and torch.isfinite(batch2["real_A"]).all()
+    # the launcher's training transform: square resize whatever the aspect (preprocess="resize") + ONE flip draw for image and mask
+    a = rng.integers(0, 256, (48, 80, 3), dtype=np.uint8)
+    l = rng.integers(0, 3, (48, 80), dtype=np.uint8)
+    d2 = tmp_path / "ns"
+    os.makedirs(d2 / "images"); os.makedirs(d2 / "labels")
+    Image.fromarray(a).save(d2 / "images" / "0.png"); Image.fromarray(l).save(d2 / "labels" / "0.png")
+    ds2 = CelebAMaskDataset(str(d2), size=64, batch_size=1, preprocess="resize", flip=True, seed=5)
+    seen = set()
+    for _ in range(8):
+        b = next(ds2)
+        x, mk = b["real_A"][0].cpu().numpy(), b["mask_A"][0].cpu().numpy()
+        assert x.shape == (3, 64, 64)
+        for flipped in (False, True):
+            src, lab = (a[:, ::-1], l[:, ::-1]) if flipped else (a, l)
+            ref = np.asarray(Image.fromarray(np.ascontiguousarray(src)).resize((64, 64), Image.BICUBIC)).astype(np.float32) / np.float32(255)
+            ref = (ref - np.float32(0.5)) / np.float32(0.5)          # ToTensor, Normalize(0.5, 0.5)
+            labr = np.asarray(Image.fromarray(np.ascontiguousarray(lab)).resize((64, 64), Image.NEAREST))
+            if np.array_equal(x, ref.transpose(2, 0, 1)):
+                assert np.array_equal(mk, np.stack([(labr == c) for c in range(3)]).astype(np.float32))   # mask mirrored WITH the image
+                seen.add(flipped)
+                break
+        else:
+            raise AssertionError("batch matches neither the plain nor the mirrored Pillow resize")
+    assert seen == {False, True}

@@ -136,3 +136,110 @@ def test_two_rank_gloo_overlapped_gradient_all_reduce(tmp_path):
     outs = [p.communicate(timeout=300) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert b"OK" in outs[0][0]
+
+
+WORKER_RANKS = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
+from ppst_amd import ops
+from ppst_amd.ppst_model import Options, PPSTModel, RsclQueues
+
+# ---- (1) RsclQueues.enqueue_all == the reference's 24 sequential dequeue_and_enqueue calls (ppst_model.py:214-219 ->
+# networks/rscl.py:67-90: each call all_gathers its [1, 2048] key and writes ranks 0..world-1 at the queue pointer)
+torch.manual_seed(5)                                   # same initial queues on both ranks
+qa, qb = RsclQueues(Options()), RsclQueues(Options())
+qb.load_state_dict(qa.state_dict())
+for li in range(4):                                    # pointers off zero, and one queue about to wrap
+    getattr(qa, "queue_ptr_A%d" % li)[0] = getattr(qb, "queue_ptr_A%d" % li)[0] = (0, 6, 124, 64)[li]
+torch.manual_seed(100 + rank)                          # the keys differ per rank
+pending = [(torch.randn(6, 2048), li) for li in range(4)]
+for keys, li in pending:                               # the reference's order: six calls per layer, one key each
+    for i in range(6):
+        qa.dequeue_and_enqueue(keys[i:i + 1], li)
+qb.enqueue_all(pending)
+for li in range(4):
+    assert torch.equal(getattr(qa, "queue_data_A%d" % li), getattr(qb, "queue_data_A%d" % li)), li
+    assert int(getattr(qa, "queue_ptr_A%d" % li)) == int(getattr(qb, "queue_ptr_A%d" % li)) == ((0, 6, 124, 64)[li] + 12) % 128
+# every rank holds the same queue afterwards, and it contains the OTHER rank's keys too
+got = [torch.empty_like(qb.queue_data_A0) for _ in range(world)]
+dist.all_gather(got, qb.queue_data_A0)
+assert torch.equal(got[0], got[1])
+assert torch.equal(qb.queue_data_A0[:, rank:12:world].t(), pending[0][0])
+
+# ---- (2) PPSTModel.sync_from_rank0 = the parameter / buffer broadcast of DistributedDataParallel's constructor
+# (models/__init__.py:88): per-process torch.randn NCE queues and unseeded parameters must end up rank 0's
+torch.manual_seed(1000 + rank)
+m = PPSTModel(Options(), with_D=True, with_nce=True)
+for p in m.parameters():
+    p.data.normal_()
+sig = lambda: torch.stack([t.double().sum() for t in list(m.parameters()) + [b.double() for b in m.buffers()]])
+before = [torch.empty_like(sig()) for _ in range(world)]
+dist.all_gather(before, sig())
+assert not torch.equal(before[0], before[1])
+tr = m.trainer() if rank == 0 else None                # mixed: rank 0 already flattened, rank 1 not yet -- both layouts broadcast
+if rank == 1:
+    m.trainer()
+m.sync_from_rank0()
+after = [torch.empty_like(sig()) for _ in range(world)]
+dist.all_gather(after, sig())
+assert torch.equal(after[0], after[1]) and torch.equal(after[0], before[0])
+assert all(f.owns_parameters() for f in m.trainer().fp.values()) and m.trainer().d_trainer.owns_parameters()
+
+# ---- (3) the deferred discriminator step: async all-reduce now, average + Adam in front of the next use of D
+def adam_cpu(p, g, m_, v, lr, b1, b2, eps, step):       # torch.optim.Adam's update (the HIP kernel needs a GPU)
+    m_.mul_(b1).add_(g, alpha=1 - b1); v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.sub_(lr * (m_ / (1 - b1 ** step)) / ((v / (1 - b2 ** step)).sqrt() + eps))
+ops.adam_step_ = adam_cpu
+d = m.trainer().d_trainer
+d.world = world
+w0 = d.flat.clone()
+d.zero_grad()
+d.grad.fill_(float(rank + 1))                          # rank gradients 1 and 2 -> average 1.5
+d.step_deferred()
+assert d._pending is not None and torch.equal(d.flat, w0)          # nothing applied yet
+d.finish_pending()
+assert d._pending is None and d.step_count == 1
+assert torch.allclose(d.grad, torch.full_like(d.grad, 1.5))
+exp = w0.clone(); adam_cpu(exp, torch.full_like(w0, 1.5), torch.zeros_like(w0), torch.zeros_like(w0), d.lr, d.b1, d.b2, d.eps, 1)
+assert torch.allclose(d.flat, exp)
+d.grad.fill_(float(rank)); d.step_deferred()
+d.zero_grad()                                          # the next zero_grad settles an owed step first, then clears
+assert d._pending is None and d.step_count == 2 and float(d.grad.abs().max()) == 0.0
+if rank == 0:
+    print("OK")
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_nce_enqueue_order_broadcast_and_deferred_d_step(tmp_path):
+    """world_size 2 on gloo: (1) the fused NCE enqueue writes exactly what the reference's 24 per-key all_gather calls
+    write, incl. wrap-around; (2) sync_from_rank0 makes parameters / buffers rank 0's (DDP's constructor broadcast);
+    (3) DiscriminatorTrainer.step_deferred / finish_pending average the gradient and apply Adam once, before the next use."""
+    script = tmp_path / "wr.py"
+    script.write_text(WORKER_RANKS)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29623")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert b"OK" in outs[0][0]
+
+
+def test_scalar_cache_invalidated_by_weight_load():
+    """FlatParams.scalar() caches the NoiseInjection weights on the host; a load_state_dict after the first generator step
+    writes through the parameter views (their version counters, not the flat buffer's): load_weights() must invalidate."""
+    from ppst_amd.ppst_model import Options, PPSTModel
+    from ppst_amd import weights as W
+    m = PPSTModel(Options(), with_D=False, with_nce=False)
+    m.load_weights(W.make_state_dict(1, with_D=False, with_nce=False, noise_weight=0.25))
+    from ppst_amd.train_g import FlatParams
+    f = FlatParams(m.G, 1e-3, 0.0, 0.99)
+    m.__dict__["_trainer"] = type("T", (), {"fp": {"G": f}, "d_trainer": None,
+                                             "invalidate": lambda self: [x.invalidate() for x in self.fp.values()]})()
+    name = "HeadResnetBlock0.conv1.noise.weight"
+    assert abs(f.scalar(name) - 0.25) < 1e-7
+    m.load_weights(W.make_state_dict(2, with_D=False, with_nce=False, noise_weight=0.5))
+    assert abs(f.scalar(name) - 0.5) < 1e-7 and f.owns_parameters()
