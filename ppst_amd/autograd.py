@@ -618,6 +618,21 @@ class FoldFn(Function):
         return ops.unfold_patches(_c(g), ctx.s), None, None, None, None
 
 
+class UnfoldFn(Function):
+    """F.unfold(x, s, stride=s)^T: NCHW -> (B, P, C*s*s) non-overlapping patches (PPSTModel.warp, ppst_model.py:366-387);
+    its adjoint is the fold of the same patches."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.shape, ctx.s = tuple(x.shape), s
+        return ops.unfold_patches(_c(x), s)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.shape
+        return ops.fold_patches(_c(g), C, H, W, ctx.s), None
+
+
 class RsclLossFn(Function):
     """rsclLoss.forward (networks/rscl.py:42-64); gradient to the queries only (keys and queue are detached)."""
 

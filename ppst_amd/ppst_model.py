@@ -109,6 +109,10 @@ class PPSTModel(nn.Module):
         # True: the feature passes whose image nobody reads (extract_feat_from_image, the loss passes) skip ToRGB.  Off by
         # default: the benchmarked recipe does everything the reference's does, used or not.
         self.skip_unused_rgb = False
+        # the Cycwarp term's metric (ppst_model.py:61 ``lpips.LPIPS(net='alex')``): inject a differentiable callable
+        # (image_rec, real) -> tensor to train with lambda_Cycwarp > 0 (train_g.GeneratorTrainer.compute_generator_losses)
+        # (kept out of nn.Module's registry: an injected lpips module must not add keys to the checkpoint contract)
+        self.__dict__["perceptual_metric"] = None
 
     # BaseModel.forward (models/base_model.py:114-123)
     def forward(self, *args, command=None, **kwargs):
@@ -194,6 +198,10 @@ class PPSTModel(nn.Module):
 
     def per_gpu_initialize(self):
         pass
+
+    def set_perceptual_metric(self, fn):
+        self.__dict__["perceptual_metric"] = fn
+        return self
 
     def swap(self, x):
         return glue.swap(x)

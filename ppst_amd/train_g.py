@@ -316,6 +316,19 @@ class GeneratorTrainer:
         b, c, h, w = mask.shape
         return A.FoldFn.apply(A.GemmConstBFn.apply(corr, patches), c, h, w, s)
 
+    def warp_image(self, x, corr):
+        """PPSTModel.warp (ppst_model.py:366-387) of an image-sized tensor: unfold into the s x s patches of the correspondence
+        grid, corr @ patches, fold.  Differentiable in ``corr`` and -- when it carries a gradient (the second warp of the
+        Cycwarp branch) -- in ``x``."""
+        b, c, h, w = x.shape
+        s = int(((h * w) / corr.shape[1]) ** 0.5)
+        if x.requires_grad:
+            patches = A.UnfoldFn.apply(x, s)
+            out = A.WarpGemmFn.apply(corr, patches, patches.shape[2])
+        else:
+            out = A.GemmConstBFn.apply(corr, ops.unfold_patches(x, s))
+        return A.FoldFn.apply(out, c, h, w, s)
+
     # ------------------------------------------------------------ losses (ppst_model.py:161-235)
     def gan_logits(self, img):
         return A.DiscriminatorLogitsFn.apply(img, self.d_trainer)
@@ -349,6 +362,18 @@ class GeneratorTrainer:
             _, gl = self.encoder_col(real, corrmatrix=corr_self)
             if lam("lambda_StyleCon", 1.0) > 0.0:
                 _, pro_ms, gl_w, pro_mw = self.encoder_col(real, mask=mask, corrmatrix=corr)
+            if lam("lambda_Cycwarp", 0.0) > 0.0:
+                # ppst_model.py:175-179: warp the image to the partner and back, compare with a perceptual metric.  The
+                # reference's metric is lpips.LPIPS(net='alex') (:61); its weights ship with neither the reference nor this
+                # image, so the metric is INJECTED: model.perceptual_metric(image_rec, real) -> tensor, any differentiable
+                # callable (parity of the LPIPS term itself is unpinned; the double warp and its backward are tested)
+                metric = getattr(m, "perceptual_metric", None)
+                if metric is None:
+                    raise RuntimeError("lambda_Cycwarp > 0 needs model.perceptual_metric (the reference uses lpips.LPIPS(net='alex'), "
+                                       "whose weights are not available here): set it to a differentiable callable or lambda_Cycwarp = 0")
+                image_warp = self.warp_image(real, corr)
+                image_rec = self.warp_image(image_warp, glue.swap(corr))
+                losses["image_warp_reg"] = metric(image_rec, real) * lam("lambda_Cycwarp", 0.0)
             if lam("lambda_Maskwarp", 10.0) > 0.0:
                 losses["Mask_warp"] = A.L1LossFn.apply(self.warp_mask(mask, corr), glue.swap(mask), lam("lambda_Maskwarp", 10.0))
         rec = self.generator(sp, gl, noise)

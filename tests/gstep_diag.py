@@ -273,6 +273,26 @@ def t_blocks2():
         patches = ops.unfold_patches(mask.to(dev), 8)
         return nhwc(A.FoldFn.apply(A.GemmConstBFn.apply(i["c"], patches), 3, 32, 32, 8))   # NCHW -> the harness's NHWC
     check_block("mask warp (GemmConstB + Fold)", gpuw, lambda i: O.model_warp(mask.double(), i["c"]), dict(c=corr16), tol=5e-6)
+    # Cycwarp branch (ppst_model.py:175-179): image -> warp(corr) -> warp(swap(corr)); gradient to corr through both warps (the
+    # second one also through its image operand), with an L1 stand-in for the injected perceptual metric
+    from ppst_amd import glue
+    from ppst_amd.train_g import GeneratorTrainer
+    img = rn(2, 3, 32, 32)
+    trw = object.__new__(GeneratorTrainer)
+
+    def gpu_cyc(i):
+        rec = trw.warp_image(trw.warp_image(img.to(dev), i["c"]), glue.swap(i["c"]))
+        return nhwc(rec)
+
+    def ref_cyc(i):
+        return O.model_warp(O.model_warp(img.double(), i["c"]), glue.swap(i["c"]))
+    check_block("Cycwarp double image warp", gpu_cyc, ref_cyc, dict(c=corr16), tol=5e-6)
+    c_g = corr16.to(dev).requires_grad_(True)
+    c_r = corr16.double().requires_grad_(True)
+    lg = A.L1LossFn.apply(trw.warp_image(trw.warp_image(img.to(dev), c_g), glue.swap(c_g)), img.to(dev), 5.0)
+    lr_ = 5.0 * (O.model_warp(O.model_warp(img.double(), c_r), glue.swap(c_r)) - img.double()).abs().mean()
+    report("Cycwarp L1 stand-in loss", lg.reshape(()), lr_, 5e-6)
+    report("Cycwarp L1 stand-in d/dcorr", torch.autograd.grad(lg, c_g)[0], torch.autograd.grad(lr_, c_r)[0], 2e-5)
     q, k, k0 = (F.normalize(rn(6, 2048)) for _ in range(3))
     queue = F.normalize(rn(2048, 128), dim=0)
     check_block("RsclLossFn", lambda i: A.RsclLossFn.apply(i["q"], k.to(dev), k0.to(dev), queue.to(dev), 0.07),

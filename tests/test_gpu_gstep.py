@@ -131,6 +131,46 @@ def test_facade_training_commands_are_differentiable_and_single_sourced():
     assert torch.equal(r1_ref["D_R1"], r1["D_R1"].detach()) and torch.equal(d1.grad, d2.grad) and float(d2.grad.abs().max()) > 0.0
 
 
+def test_cycwarp_branch_with_injected_metric():
+    """ppst_model.py:175-179 (default lambda_Cycwarp = 5 in the reference): warp(real, corr) -> warp(., swap(corr)) -> metric.
+    LPIPS weights are unavailable (parity of that term unpinned); the branch runs with an injected differentiable metric, adds
+    ``image_warp_reg`` to the losses, back-propagates through both warps into the correspondence (and from there into G / E1 /
+    E2), and refuses to run without a metric.  The block-level gradient check against torch autograd is in t_blocks2."""
+    import gstep_diag as D
+    from ppst_amd import autograd as A, weights as W
+    from ppst_amd.ppst_model import Options, create_model
+    real, mask, noise = D.gstep_inputs()
+    real, mask = real.cuda(), mask.cuda()
+    grads = {}
+    for lam in (0.0, 5.0):
+        sd = W.make_state_dict(17, bias_std=0.1, noise_weight=0.1)
+        m = create_model(Options(training_stage=2, lambda_Cycwarp=lam), state_dict=sd, with_D=True, with_nce=True)
+        m.noise = {k: v.cuda() for k, v in noise.items()}
+        if lam > 0.0:
+            with pytest.raises(RuntimeError, match="perceptual_metric"):
+                m.trainer().losses_and_grads(real, mask)
+            m.set_perceptual_metric(lambda a, b: A.L1LossFn.apply(a, b, 1.0))
+            assert "perceptual_metric" not in dict(m.named_modules()) and len(m.state_dict()) == len(sd)
+        out = m.trainer().losses_and_grads(real, mask)
+        grads[lam] = {k: f.grad.clone() for k, f in m.trainer().fp.items()}
+        if lam > 0.0:
+            v = float(out["image_warp_reg"])
+            assert v == v and v > 0.0
+            # value = lambda * L1(double warp, real) with the inference-path kernels on the same correspondence
+            with torch.no_grad():
+                fea, fea1 = m.extract_feat_from_image(real)
+                sps = torch.cat((fea, m.Rselfcorr(fea1)), dim=1)
+                corr = m.corrm(sps, m.swap(sps))
+                rec = m.warp(m.warp(real, corr), m.swap(corr))
+                ref = 5.0 * float((rec - real).abs().mean())
+            assert abs(v - ref) <= 2e-3 * ref, (v, ref)
+        else:
+            assert "image_warp_reg" not in out
+    # the extra term reaches the feature-producing networks through the correspondence matrix
+    for k in ("G", "E1", "E2"):
+        assert not torch.equal(grads[0.0][k], grads[5.0][k]), k
+
+
 def test_generator_adam_step_and_alternation():
     """PPSTOptimizer mirror: first call = discriminator iteration (+ D_total), second = generator iteration; the
     parameter update equals torch.optim.Adam(lr 1e-3, betas (0, 0.99)) applied to the gradients of that step."""
@@ -209,9 +249,9 @@ def test_celebamask_dataset_loader(tmp_path):
         Image.fromarray(l).save(tmp_path / "labels" / ("%d.png" % i))
         imgs.append(a); labs.append(l)
     ds = CelebAMaskDataset(str(tmp_path), size=64, batch_size=3)
+    order = list(ds._order[:3])          # (read before next(): the prefetch thread already walks into the next epoch's order)
     batch = next(ds)
     assert tuple(batch["real_A"].shape) == (3, 3, 64, 64) and tuple(batch["mask_A"].shape) == (3, 3, 64, 64)
-    order = ds._order[:3]
     for n, idx in enumerate(order):
         assert np.array_equal(batch["real_A"][n].cpu().numpy(), R.preprocess(imgs[idx], 64))
         onehot = np.stack([(labs[idx] == c) for c in range(3)]).astype(np.float32)
