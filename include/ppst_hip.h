@@ -117,6 +117,32 @@ int ppst_conv_pack(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx
                    float scale, int cout, int bn,
                    const int32_t* src_c, const int32_t* src_ky, const int32_t* src_kx,
                    int nsteps, int n_groups, int precision, void* out, void* stream);
+/* Batched forms (training: every plan of a network is re-packed after each Adam step -- one launch instead of one per plan).
+ * ``jobs`` is a DEVICE array; the caller fills block0 / nblocks: consecutive block ranges, nblocks = ppst_pack_job_blocks(total),
+ * total_blocks = their sum.  Field meaning as the arguments of ppst_conv_pack / ppst_upscale_weight. */
+typedef struct ppst_pack_job {
+  const void* w;
+  int64_t sn, sc, sy, sx;
+  const int32_t* src_c;
+  const int32_t* src_ky;
+  const int32_t* src_kx;
+  void* out;
+  int64_t total;              /* n_groups * ceil(cout / bn) * nsteps * 4 * bn */
+  int64_t block0;
+  float scale;
+  int32_t cout, bn, nsteps, n_groups, x3, f16, nblocks;   /* x3: precision 0 (hi + lo planes); f16: precision 3 / 4 */
+} ppst_pack_job;
+typedef struct ppst_upscale_job {
+  const void* w;
+  void* out;
+  int64_t total, block0;      /* total = cin * cout * 16 */
+  float scale;
+  int32_t cout, cin, nblocks;
+} ppst_upscale_job;
+int ppst_pack_job_blocks(int64_t total);
+int ppst_conv_pack_batch(const void* jobs, int njobs, int total_blocks, void* stream);
+int ppst_upscale_weight_batch(const void* jobs, int njobs, int total_blocks, void* stream);
+
 /* EqualizedConv2d fused-upscale weight (stylegan2_layers.py:314-319):
  * w (Cout,Cin,3,3)*scale -> out (Cin,Cout,4,4), the F.conv_transpose2d operand */
 int ppst_upscale_weight(const void* w, void* out, int cout, int cin, float scale, void* stream);
@@ -449,9 +475,10 @@ int ppst_rselfcorr_bwd(const void* fea, const void* dout, void* dfea, int B, int
 int ppst_scale_by(const void* x, const void* s, void* y, int64_t n, void* stream);
 /* NoiseInjection weight gradient: out[0] = sum dpre[p][c] * noise[p] (stylegan2_layers.py:376-399) */
 int64_t ppst_noise_wgrad_ws(int64_t npix);
-int ppst_noise_wgrad(const void* dpre, const void* noise, void* out, void* ws, int64_t npix, int C, int ld, void* stream);
-/* adjoint of ppst_upscale_weight: dw4 (Cin,Cout,4,4) -> dw (Cout,Cin,3,3) */
-int ppst_upscale_weight_bwd(const void* dw4, void* dw, int cout, int cin, float scale, void* stream);
+int ppst_noise_wgrad(const void* dpre, const void* noise, void* out, void* ws, int64_t npix, int C, int ld, int accumulate, void* stream);
+/* adjoint of ppst_upscale_weight: dw4 (Cin,Cout,4,4) -> dw (Cout,Cin,3,3); accumulate != 0 adds into dw (like the other
+ * parameter-gradient entry points: the trainers point them at the flat gradient buffer, no separate accumulation pass) */
+int ppst_upscale_weight_bwd(const void* dw4, void* dw, int cout, int cin, float scale, int accumulate, void* stream);
 /* NHWC [B][H][W][C] -> space-to-depth [B][ceil(H/2)][ceil(W/2)][4C] (channel block (py*2+px)*C) */
 int ppst_space_to_depth(const void* x, void* y, int B, int H, int W, int C, int x_ld, void* stream);
 

@@ -28,6 +28,18 @@ lib = ctypes.CDLL(LIB_PATH)
 vp, i32, i64, f32, f64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
 
+class PackJob(ctypes.Structure):
+    """ppst_pack_job (include/ppst_hip.h)."""
+    _fields_ = [("w", vp), ("sn", i64), ("sc", i64), ("sy", i64), ("sx", i64), ("src_c", vp), ("src_ky", vp), ("src_kx", vp),
+                ("out", vp), ("total", i64), ("block0", i64), ("scale", f32), ("cout", i32), ("bn", i32), ("nsteps", i32),
+                ("n_groups", i32), ("x3", i32), ("f16", i32), ("nblocks", i32)]
+
+
+class UpscaleJob(ctypes.Structure):
+    """ppst_upscale_job (include/ppst_hip.h)."""
+    _fields_ = [("w", vp), ("out", vp), ("total", i64), ("block0", i64), ("scale", f32), ("cout", i32), ("cin", i32), ("nblocks", i32)]
+
+
 class ConvArgs(ctypes.Structure):
     """ppst_conv_args (include/ppst_hip.h)."""
     _fields_ = [
@@ -53,6 +65,9 @@ _SIGS = {
     "ppst_nhwc_to_nchw": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ppst_conv_pack": (i32, [vp, i64, i64, i64, i64, f32, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp]),
     "ppst_upscale_weight": (i32, [vp, vp, i32, i32, f32, vp]),
+    "ppst_pack_job_blocks": (i32, [i64]),
+    "ppst_conv_pack_batch": (i32, [vp, i32, i32, vp]),
+    "ppst_upscale_weight_batch": (i32, [vp, i32, i32, vp]),
     "ppst_conv2d_mfma": (i32, [ctypes.POINTER(ConvArgs), vp]),
     "ppst_conv2d_f32": (i32, [ctypes.POINTER(ConvArgs), vp, i64, i64, i64, i64, f32, vp, vp, vp, vp]),
     "ppst_conv_tiles": (i32, [i32, i32, i32]),
@@ -122,8 +137,8 @@ _SIGS = {
     "ppst_rscl_loss_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "ppst_rselfcorr_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ppst_noise_wgrad_ws": (i64, [i64]),
-    "ppst_noise_wgrad": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
-    "ppst_upscale_weight_bwd": (i32, [vp, vp, i32, i32, f32, vp]),
+    "ppst_noise_wgrad": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "ppst_upscale_weight_bwd": (i32, [vp, vp, i32, i32, f32, i32, vp]),
     "ppst_space_to_depth": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ppst_prof_enable": (i32, [i32]),
     "ppst_prof_dropped": (i32, []),

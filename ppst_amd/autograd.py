@@ -34,16 +34,42 @@ def relu_gate(g, x):
     return ops.fused_bias_act_raw(g, None, x, 3, 1, 0.0, 1.0)
 
 
-def _conv_grads(net, wname, kind, scale, pad_mode, x, gpre, need_x, need_w, out_hw=None):
-    """(dx, dw) of a stride-1 'conv' plan given the gradient at its raw output."""
+# ---- parameter gradients go straight into the trainer's flat gradient buffer -------------------------------------------
+# FlatParams / DiscriminatorTrainer bind ``p.grad`` of every parameter to a view of ONE flat buffer per network and mark the
+# parameter (``_ppst_direct``).  A block's backward then lets the producing kernel add into that view (the ``accumulate`` flag
+# of the C ABI) and returns None for the parameter: no temporary, no zero fill and no AccumulateGrad ``add`` launch per
+# (parameter, use) -- 866 + 320 launches per train step before.  ``_ppst_on_grad`` tells the trainer that one more
+# contribution has landed (it counts them to launch a network's gradient all-reduce from inside backward()).
+# Consequence: EVERY pass through a block's backward -- also torch.autograd.grad(..., inputs=[some activation]) -- adds that
+# block's parameter gradients to the flat buffer, exactly as a second .backward() would.  The reference's pattern (zero_grad ->
+# one backward -> step, ppst_optimizer.py:73-94) is what the trainers run; ``DIRECT["value"] = False`` restores returned
+# gradients (autograd accumulates them) for code that walks a graph more than once.
+DIRECT = {"value": True}
+
+
+def _direct(p):
+    if not DIRECT["value"] or p is None or not getattr(p, "_ppst_direct", False) or not p.requires_grad:
+        return None
+    return p.grad
+
+
+def _noted(p):
+    cb = getattr(p, "_ppst_on_grad", None)
+    if cb is not None:
+        cb()
+
+
+def _conv_grads(net, wname, kind, scale, pad_mode, x, gpre, need_x, need_w, out_hw=None, dw_out=None):
+    """(dx, dw) of a stride-1 'conv' plan given the gradient at its raw output (``dw_out``: add dw into this view)."""
     plan = net.plan(wname, kind, scale)
     k = plan.k
     dx = dw = None
+    acc = dw_out is not None
     if pad_mode == Z or k == 1:
         if need_x:
             dx = net.plan(wname, "dgrad", scale)(gpre)
         if need_w:
-            dw = ops.conv_wgrad(plan, x, gpre)
+            dw = ops.conv_wgrad(plan, x, gpre, out=dw_out, accumulate=acc)
         return dx, dw
     # reflection / replication padding: y = conv_valid(pad(x)).  On the padded canvas the same zero-padded kernels
     # are exact: the gradient canvas is zero on the border, so border outputs / out-of-canvas taps contribute nothing.
@@ -51,7 +77,7 @@ def _conv_grads(net, wname, kind, scale, pad_mode, x, gpre, need_x, need_w, out_
     if need_x:
         dx = ops.pad2d_bwd(net.plan(wname, "dgrad", scale)(gp), 1, 1, 1, 1, pad_mode)
     if need_w:
-        dw = ops.conv_wgrad(plan, ops.pad2d(x, 1, 1, 1, 1, pad_mode), gp)
+        dw = ops.conv_wgrad(plan, ops.pad2d(x, 1, 1, 1, 1, pad_mode), gp, out=dw_out, accumulate=acc)
     return dx, dw
 
 
@@ -61,7 +87,9 @@ class ConvFn(Function):
     of EqualizedConv2d (stylegan2_layers.py:312-321)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, noise_w, noise, net, wname, kind, scale, pad_mode, act, noise_w_host=None):
+    def forward(ctx, x, w, bias, noise_w, noise, net, wname, kind, scale, pad_mode, act, noise_w_host=None, bias_params=None):
+        """``bias_params``: leaf parameters whose sum is ``bias`` (StyledConv's three biases, summed by the caller outside the
+        graph): their gradients are written directly, ``bias`` itself is then a constant."""
         x = _c(x)
         plan = net.plan(wname, kind, scale)
         # the kernel takes the noise weight by value: the caller's cached host copy, or (a stream sync) the tensor itself
@@ -69,6 +97,7 @@ class ConvFn(Function):
         y, st = plan(x, bias=bias, noise=(noise if noise_w is not None else None), noise_weight=nw, act=act, pad_mode=pad_mode, stats=True)
         ctx.save_for_backward(x, y if act != NONE else None, noise if noise_w is not None else None)
         ctx.cfg = (net, wname, kind, scale, pad_mode, act, bias is not None, noise_w is not None)
+        ctx.refs = (w, bias, noise_w, bias_params)          # leaf parameters (for their flat-gradient views), not saved tensors
         ctx.mark_non_differentiable(st)
         return y, st
 
@@ -76,14 +105,30 @@ class ConvFn(Function):
     def backward(ctx, g, _gst):
         x, y, noise = ctx.saved_tensors
         net, wname, kind, scale, pad_mode, act, has_b, has_n = ctx.cfg
+        w, bias, noise_w, bias_params = ctx.refs
         g = _c(g)
         gpre = lrelu_bwd(g, y) if act == LRELU else g
         C = gpre.shape[3]
-        db = ops.colsum(gpre.view(-1, C)) if (has_b and ctx.needs_input_grad[2]) else None
-        dnw = ops.noise_wgrad(gpre, noise) if (has_n and ctx.needs_input_grad[3]) else None
+        db = dnw = None
+        if bias_params is not None:           # one column sum, added to each of the summed biases' gradients in ONE launch
+            v = ops.colsum(gpre.view(-1, C))
+            torch._foreach_add_([_direct(q).view(-1) for q in bias_params], [v] * len(bias_params))
+            for q in bias_params:
+                _noted(q)
+        elif has_b and ctx.needs_input_grad[2]:
+            dst = _direct(bias)
+            db = ops.colsum(gpre.view(-1, C), out=dst, accumulate=dst is not None)
+            if dst is not None:
+                _noted(bias); db = None
+        if has_n and ctx.needs_input_grad[3]:
+            dst = _direct(noise_w)
+            dnw = ops.noise_wgrad(gpre, noise, out=dst, accumulate=dst is not None)
+            if dst is not None:
+                _noted(noise_w); dnw = None
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dstw = _direct(w) if need_w else None
         if kind == "conv":
-            dx, dw = _conv_grads(net, wname, kind, scale, pad_mode, x, gpre, need_x, need_w)
+            dx, dw = _conv_grads(net, wname, kind, scale, pad_mode, x, gpre, need_x, need_w, dw_out=dstw)
         else:  # convT: dX = stride-2 4x4 conv of dY (run over its space-to-depth copy); dW through the blurred 4x4 kernel
             gs = ops.space_to_depth(gpre)
             pl = net.plan(wname, "dgradT", scale)
@@ -91,13 +136,15 @@ class ConvFn(Function):
             dw = None
             if need_w:
                 dw4 = ops.conv_wgrad(pl, gs, x)
-                dw = ops.upscale_weight_bwd(dw4, pl.cin, pl.cout, pl.fwd_scale)
-        return dx, dw, db, dnw, None, None, None, None, None, None, None, None
+                dw = ops.upscale_weight_bwd(dw4, pl.cin, pl.cout, pl.fwd_scale, out=dstw, accumulate=dstw is not None)
+        if dstw is not None:
+            _noted(w); dw = None
+        return dx, dw, db, dnw, None, None, None, None, None, None, None, None, None
 
 
 def conv(x, w, net, wname, bias=None, kind="conv", scale=1.0, pad_mode=Z, act=NONE, noise_w=None, noise=None, stats=False,
-         noise_w_host=None):
-    y, st = ConvFn.apply(x, w, bias, noise_w, noise, net, wname, kind, scale, pad_mode, act, noise_w_host)
+         noise_w_host=None, bias_params=None):
+    y, st = ConvFn.apply(x, w, bias, noise_w, noise, net, wname, kind, scale, pad_mode, act, noise_w_host, bias_params)
     return (y, st) if stats else y
 
 
@@ -114,6 +161,7 @@ class BlurConvFn(Function):
         y, st = net.plan(wname, "s2d", scale)(xb, bias=bias, act=act, out_hw=ohw, stats=True)
         ctx.save_for_backward(xb, y if act != NONE else None)
         ctx.cfg = (net, wname, kname, scale, p0, p1, pad_mode, act, bhw, bias is not None)
+        ctx.refs = (w, bias)
         ctx.mark_non_differentiable(st)
         return y, st
 
@@ -124,8 +172,18 @@ class BlurConvFn(Function):
         g = _c(g)
         gpre = lrelu_bwd(g, y) if act == LRELU else g
         C = gpre.shape[3]
-        db = ops.colsum(gpre.view(-1, C)) if (has_b and ctx.needs_input_grad[2]) else None
-        dw = ops.conv_wgrad(net.plan(wname, "s2d", scale), xb, gpre) if ctx.needs_input_grad[1] else None
+        w, bias = ctx.refs
+        db = dw = None
+        if has_b and ctx.needs_input_grad[2]:
+            dst = _direct(bias)
+            db = ops.colsum(gpre.view(-1, C), out=dst, accumulate=dst is not None)
+            if dst is not None:
+                _noted(bias); db = None
+        if ctx.needs_input_grad[1]:
+            dst = _direct(w)
+            dw = ops.conv_wgrad(net.plan(wname, "s2d", scale), xb, gpre, out=dst, accumulate=dst is not None)
+            if dst is not None:
+                _noted(w); dw = None
         dx = None
         if ctx.needs_input_grad[0]:
             d_xb = net.plan(wname, "dgrad_s2d", scale)(gpre, out_hw=bhw)
@@ -186,6 +244,7 @@ class InstanceNormFn(Function):
         out = ops.affine_act(y, ss, act=act, prelu=prelu)
         ctx.save_for_backward(y, out if act == LRELU else None, mr, style, ss if act == PRELU else None, prelu)
         ctx.act = act
+        ctx.refs = (post_bias,)
         return out
 
     @staticmethod
@@ -201,7 +260,13 @@ class InstanceNormFn(Function):
         want = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         coef, dstyle = ops.in_bwd_finalize(part, H * W, mr, style, want_dstyle=want)
         dy = ops.in_bwd_apply(g, y, coef, gate=gate) if ctx.needs_input_grad[0] else None
-        dpb = ops.colsum(dstyle[:, C:]) if ctx.needs_input_grad[3] else None
+        dpb = None
+        if ctx.needs_input_grad[3]:
+            (post_bias,) = ctx.refs
+            dst = _direct(post_bias)
+            dpb = ops.colsum(dstyle[:, C:], out=dst, accumulate=dst is not None)
+            if dst is not None:
+                _noted(post_bias); dpb = None
         return dy, None, (dstyle if ctx.needs_input_grad[2] else None), dpb, dprelu, None, None
 
 
@@ -303,6 +368,7 @@ class LinearFn(Function):
         y = ops.linear(x, w.reshape(w.shape[0], -1), b, wscale=wscale, bscale=bscale, relu_in=relu_in, act=act)
         ctx.save_for_backward(x, w, y if act == LRELU else None)
         ctx.cfg = (wscale, bscale, relu_in, act, b is not None)
+        ctx.refs = (w, b)
         return y
 
     @staticmethod
@@ -318,11 +384,20 @@ class LinearFn(Function):
             dx = ops.linear_dgrad(g, w2, wscale)
             if relu_in:
                 dx = relu_gate(dx, x)
+        wp, bp = ctx.refs
         if ctx.needs_input_grad[1]:
             xin = relu_gate(x, x) if relu_in else x      # relu(x) = x * [x > 0]
-            dw = ops.linear_wgrad(g, xin, wscale).view_as(w)
+            dst = _direct(wp)
+            dw = ops.linear_wgrad(g, xin, wscale, out=dst, accumulate=dst is not None)
+            if dst is not None:
+                _noted(wp); dw = None
+            else:
+                dw = dw.view_as(w)
         if has_b and ctx.needs_input_grad[2]:
-            db = ops.colsum(g, bscale)
+            dst = _direct(bp)
+            db = ops.colsum(g, bscale, out=dst, accumulate=dst is not None)
+            if dst is not None:
+                _noted(bp); db = None
         return dx, dw, db, None, None, None, None
 
 
@@ -377,6 +452,7 @@ class FromRGBFn(Function):
         y = ops.conv1x1_small_cin(x, w, b, scale, LRELU)
         ctx.save_for_backward(x, w, y)
         ctx.scale = scale
+        ctx.refs = (w, b)
         return y
 
     @staticmethod
@@ -384,8 +460,20 @@ class FromRGBFn(Function):
         x, w, y = ctx.saved_tensors
         g0 = lrelu_bwd(_c(g), y)
         C = g0.shape[3]
-        db = ops.colsum(g0.view(-1, C)) if ctx.needs_input_grad[2] else None
-        dw = ops.wgrad_small_cin(x, g0, ctx.scale).view_as(w) if ctx.needs_input_grad[1] else None
+        wp, bp = ctx.refs
+        db = dw = None
+        if ctx.needs_input_grad[2]:
+            dst = _direct(bp)
+            db = ops.colsum(g0.view(-1, C), out=dst, accumulate=dst is not None)
+            if dst is not None:
+                _noted(bp); db = None
+        if ctx.needs_input_grad[1]:
+            dst = _direct(wp)
+            dw = ops.wgrad_small_cin(x, g0, ctx.scale, out=dst, accumulate=dst is not None)
+            if dst is not None:
+                _noted(wp); dw = None
+            else:
+                dw = dw.view_as(w)
         dx = None
         if ctx.needs_input_grad[0]:
             wt = w.reshape(w.shape[0], w.shape[1]).t().contiguous()

@@ -638,43 +638,71 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
 
 // ------------------------------------------------------------ weight packing --
 // out[group][ntile][step][hilo][g][n_local][j] = split_bf16(scale * w[n][src_c+8g+j][ky][kx])
-__global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, int64_t sn, int64_t sc, int64_t sy,
-                                                        int64_t sx, float scale, int cout, int bn,
-                                                        const int* __restrict__ src_c, const int* __restrict__ src_ky,
-                                                        const int* __restrict__ src_kx, int nsteps, int n_groups, int x3,
-                                                        unsigned short* __restrict__ out, int64_t total, int f16) {
+struct PackJob {            // == ppst_pack_job of include/ppst_hip.h
+  const float* w;
+  int64_t sn, sc, sy, sx;
+  const int* src_c;
+  const int* src_ky;
+  const int* src_kx;
+  unsigned short* out;
+  int64_t total;            // n_groups * n_tiles * nsteps * 4 * bn items (one item = 8 k-values of one output channel)
+  int64_t block0;           // first block of this job inside a batched launch
+  float scale;
+  int cout, bn, nsteps, n_groups, x3, f16, nblocks;
+};
+__device__ __forceinline__ void pack_item(const PackJob& j, int64_t t) {
+  const float* __restrict__ w = j.w;
+  const int bn = j.bn, nsteps = j.nsteps, cout = j.cout;
   const int n_tiles = (cout + bn - 1) / bn;
-  const int npl = x3 ? 8 : 4;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    int nl = (int)(t % bn);
-    int64_t r = t / bn;
-    int g = (int)(r % 4); r /= 4;
-    int s = (int)(r % nsteps); r /= nsteps;
-    int ntile = (int)(r % n_tiles);
-    int group = (int)(r / n_tiles);
-    int n = ntile * bn + nl;
-    int gs = group * nsteps + s;
-    int c0 = src_c[gs] + 8 * g, ky = src_ky[gs], kx = src_kx[gs];
-    unsigned short hi[8], lo[8];
+  const int npl = j.x3 ? 8 : 4;
+  int nl = (int)(t % bn);
+  int64_t r = t / bn;
+  int g = (int)(r % 4); r /= 4;
+  int s = (int)(r % nsteps); r /= nsteps;
+  int ntile = (int)(r % n_tiles);
+  int group = (int)(r / n_tiles);
+  int n = ntile * bn + nl;
+  int gs = group * nsteps + s;
+  int c0 = j.src_c[gs] + 8 * g, ky = j.src_ky[gs], kx = j.src_kx[gs];
+  unsigned short hi[8], lo[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float v = 0.f;
-      if (n < cout && src_c[gs] >= 0) v = w[n * sn + (int64_t)(c0 + j) * sc + ky * sy + kx * sx] * scale;  // src_c < 0: zero-weight pad step
-      if (f16) { hi[j] = __builtin_bit_cast(unsigned short, (_Float16)v); lo[j] = 0; }
-      else split_bf16(v, hi[j], lo[j]);
-    }
-    int64_t blob = (((int64_t)group * n_tiles + ntile) * nsteps + s) * ((int64_t)npl * bn * 8);
-    unsigned short* oh = out + blob + ((int64_t)g * bn + nl) * 8;
+  for (int q = 0; q < 8; ++q) {
+    float v = 0.f;
+    if (n < cout && j.src_c[gs] >= 0) v = w[n * j.sn + (int64_t)(c0 + q) * j.sc + ky * j.sy + kx * j.sx] * j.scale;  // src_c < 0: zero-weight pad step
+    if (j.f16) { hi[q] = __builtin_bit_cast(unsigned short, (_Float16)v); lo[q] = 0; }
+    else split_bf16(v, hi[q], lo[q]);
+  }
+  int64_t blob = (((int64_t)group * n_tiles + ntile) * nsteps + s) * ((int64_t)npl * bn * 8);
+  unsigned short* oh = j.out + blob + ((int64_t)g * bn + nl) * 8;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) oh[j] = hi[j];
-    if (x3) {
-      unsigned short* ol = oh + (int64_t)4 * bn * 8;
+  for (int q = 0; q < 8; ++q) oh[q] = hi[q];
+  if (j.x3) {
+    unsigned short* ol = oh + (int64_t)4 * bn * 8;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) ol[j] = lo[j];
-    }
+    for (int q = 0; q < 8; ++q) ol[q] = lo[q];
   }
 }
+__global__ __launch_bounds__(256) void conv_pack_kernel(PackJob j) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < j.total; t += (int64_t)gridDim.x * 256) pack_item(j, t);
+}
+// All plans of a network in ONE launch (after every Adam step: 216 single launches per train step before): block b belongs to the
+// job whose [block0, block0 + nblocks) range holds it (binary search over the table, a handful of scalar loads).
+__global__ __launch_bounds__(256) void conv_pack_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;
+  const int64_t b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const PackJob j = jobs[lo];
+  for (int64_t t = (b - j.block0) * 256 + threadIdx.x; t < j.total; t += (int64_t)j.nblocks * 256) pack_item(j, t);
+}
 
+static int pack_blocks(int64_t total) {
+  int64_t blocks = cdiv64(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  return (int)blocks;
+}
 extern "C" int ppst_conv_pack(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx, float scale, int cout, int bn,
                               const int32_t* src_c, const int32_t* src_ky, const int32_t* src_kx, int nsteps, int n_groups,
                               int precision, void* out, void* stream) {
@@ -683,37 +711,73 @@ extern "C" int ppst_conv_pack(const void* w, int64_t sn, int64_t sc, int64_t sy,
     return PPST_EINVAL;
   if (!w || !src_c || !src_ky || !src_kx || !out) return PPST_ENULL;
   int n_tiles = (cout + bn - 1) / bn;
-  int64_t total = (int64_t)n_groups * n_tiles * nsteps * 4 * bn;
-  int64_t blocks = cdiv64(total, 256);
-  if (blocks > 4096) blocks = 4096;
-  PPST_LAUNCH(conv_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)w, sn, sc, sy, sx,
-                     scale, cout, bn, src_c, src_ky, src_kx, nsteps, n_groups, precision == 0 ? 1 : 0, (unsigned short*)out, total,
-                     (precision == 3 || precision == 4) ? 1 : 0);
+  PackJob j;
+  j.w = (const float*)w; j.sn = sn; j.sc = sc; j.sy = sy; j.sx = sx; j.src_c = src_c; j.src_ky = src_ky; j.src_kx = src_kx;
+  j.out = (unsigned short*)out; j.total = (int64_t)n_groups * n_tiles * nsteps * 4 * bn; j.block0 = 0; j.scale = scale;
+  j.cout = cout; j.bn = bn; j.nsteps = nsteps; j.n_groups = n_groups; j.x3 = precision == 0 ? 1 : 0;
+  j.f16 = (precision == 3 || precision == 4) ? 1 : 0;
+  j.nblocks = pack_blocks(j.total);
+  PPST_LAUNCH(conv_pack_kernel, dim3((unsigned)j.nblocks), dim3(256), 0, as_stream(stream), j);
+  return PPST_LAUNCH_CHECK();
+}
+// jobs: DEVICE array of ppst_pack_job (block0 / nblocks filled by the caller: consecutive ranges, nblocks = ppst_pack_job_blocks(total))
+extern "C" int ppst_pack_job_blocks(int64_t total) { return total > 0 ? pack_blocks(total) : 0; }
+extern "C" int ppst_conv_pack_batch(const void* jobs, int njobs, int total_blocks, void* stream) {
+  static_assert(sizeof(PackJob) == sizeof(ppst_pack_job), "ppst_pack_job layout");
+  if (njobs < 0 || total_blocks < 0) return PPST_EINVAL;
+  if (njobs == 0 || total_blocks == 0) return PPST_OK;
+  if (!jobs) return PPST_ENULL;
+  PPST_LAUNCH(conv_pack_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), (const PackJob*)jobs, njobs);
   return PPST_LAUNCH_CHECK();
 }
 
 // EqualizedConv2d fused-upscale weight (stylegan2_layers.py:314-319):
 // w (Cout,Cin,3,3) -> out (Cin,Cout,4,4) = sum of the 4 unit shifts of the zero-padded kernel
-__global__ __launch_bounds__(256) void upscale_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin,
-                                                             float scale, int64_t total) {
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    int kx = (int)(t & 3), ky = (int)((t >> 2) & 3);
-    int64_t r = t >> 4;
-    int n = (int)(r % cout), c = (int)(r / cout);
-    const float* wp = w + ((int64_t)n * cin + c) * 9;
-    auto at = [&](int y, int x) -> float { return (y >= 0 && y < 3 && x >= 0 && x < 3) ? wp[y * 3 + x] * scale : 0.f; };
-    // padded p[y][x] = w[y-1][x-1]; out[ky][kx] = p[ky+1][kx+1] + p[ky][kx+1] + p[ky+1][kx] + p[ky][kx]
-    out[t] = at(ky, kx) + at(ky - 1, kx) + at(ky, kx - 1) + at(ky - 1, kx - 1);
+struct UpscaleJob {         // == ppst_upscale_job
+  const float* w;
+  float* out;
+  int64_t total, block0;
+  float scale;
+  int cout, cin, nblocks;
+};
+__device__ __forceinline__ void upscale_item(const UpscaleJob& j, int64_t t) {
+  int kx = (int)(t & 3), ky = (int)((t >> 2) & 3);
+  int64_t r = t >> 4;
+  int n = (int)(r % j.cout), c = (int)(r / j.cout);
+  const float* wp = j.w + ((int64_t)n * j.cin + c) * 9;
+  const float scale = j.scale;
+  auto at = [&](int y, int x) -> float { return (y >= 0 && y < 3 && x >= 0 && x < 3) ? wp[y * 3 + x] * scale : 0.f; };
+  // padded p[y][x] = w[y-1][x-1]; out[ky][kx] = p[ky+1][kx+1] + p[ky][kx+1] + p[ky+1][kx] + p[ky][kx]
+  j.out[t] = at(ky, kx) + at(ky - 1, kx) + at(ky, kx - 1) + at(ky - 1, kx - 1);
+}
+__global__ __launch_bounds__(256) void upscale_weight_kernel(UpscaleJob j) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < j.total; t += (int64_t)gridDim.x * 256) upscale_item(j, t);
+}
+__global__ __launch_bounds__(256) void upscale_weight_batch_kernel(const UpscaleJob* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;
+  const int64_t b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block0 <= b) lo = mid; else hi = mid - 1;
   }
+  const UpscaleJob j = jobs[lo];
+  for (int64_t t = (b - j.block0) * 256 + threadIdx.x; t < j.total; t += (int64_t)j.nblocks * 256) upscale_item(j, t);
 }
 extern "C" int ppst_upscale_weight(const void* w, void* out, int cout, int cin, float scale, void* stream) {
   if (cout <= 0 || cin <= 0) return PPST_EINVAL;
   if (!w || !out) return PPST_ENULL;
-  int64_t total = (int64_t)cin * cout * 16;
-  int64_t blocks = cdiv64(total, 256);
-  if (blocks > 4096) blocks = 4096;
-  PPST_LAUNCH(upscale_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)w, (float*)out,
-                     cout, cin, scale, total);
+  UpscaleJob j;
+  j.w = (const float*)w; j.out = (float*)out; j.total = (int64_t)cin * cout * 16; j.block0 = 0; j.scale = scale; j.cout = cout; j.cin = cin;
+  j.nblocks = pack_blocks(j.total);
+  PPST_LAUNCH(upscale_weight_kernel, dim3((unsigned)j.nblocks), dim3(256), 0, as_stream(stream), j);
+  return PPST_LAUNCH_CHECK();
+}
+extern "C" int ppst_upscale_weight_batch(const void* jobs, int njobs, int total_blocks, void* stream) {
+  static_assert(sizeof(UpscaleJob) == sizeof(ppst_upscale_job), "ppst_upscale_job layout");
+  if (njobs < 0 || total_blocks < 0) return PPST_EINVAL;
+  if (njobs == 0 || total_blocks == 0) return PPST_OK;
+  if (!jobs) return PPST_ENULL;
+  PPST_LAUNCH(upscale_weight_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), (const UpscaleJob*)jobs, njobs);
   return PPST_LAUNCH_CHECK();
 }
 

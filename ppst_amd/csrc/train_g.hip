@@ -644,36 +644,41 @@ __global__ __launch_bounds__(256) void noise_wgrad_kernel(const float* __restric
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int n, float scale) {
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int n, float scale,
+                                                           int accumulate) {
   __shared__ float red[4];
   float acc = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) * scale;
+  if (threadIdx.x == 0) {
+    const float v = (red[0] + red[1] + red[2] + red[3]) * scale;
+    out[0] = accumulate ? out[0] + v : v;
+  }
 }
 extern "C" int64_t ppst_noise_wgrad_ws(int64_t npix) {
   int64_t b = cdiv64(npix, 4);
   if (b > 2048) b = 2048;
   return (b < 1 ? 1 : b) * (int64_t)sizeof(float);
 }
-extern "C" int ppst_noise_wgrad(const void* dpre, const void* noise, void* out, void* ws, int64_t npix, int C, int ld, void* stream) {
+extern "C" int ppst_noise_wgrad(const void* dpre, const void* noise, void* out, void* ws, int64_t npix, int C, int ld, int accumulate,
+                                void* stream) {
   if (npix < 0 || C <= 0 || ld < C) return PPST_EINVAL;
   if (!out) return PPST_ENULL;
-  if (npix == 0) return (int)hipMemsetAsync(out, 0, sizeof(float), as_stream(stream));
+  if (npix == 0) return accumulate ? PPST_OK : (int)hipMemsetAsync(out, 0, sizeof(float), as_stream(stream));
   if (!dpre || !noise || !ws) return PPST_ENULL;
   const int blocks = (int)(ppst_noise_wgrad_ws(npix) / (int64_t)sizeof(float));
   PPST_LAUNCH(noise_wgrad_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)dpre, (const float*)noise, (float*)ws,
               npix, C, ld);
-  PPST_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const float*)ws, (float*)out, blocks, 1.f);
+  PPST_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const float*)ws, (float*)out, blocks, 1.f, accumulate);
   return PPST_LAUNCH_CHECK();
 }
 // sum of a small float vector times scale -> out[0] (PReLU slope gradient from ppst_prelu_bwd's partials)
 extern "C" int ppst_sum_partials(const void* partial, void* out, int n, float scale, void* stream) {
   if (n <= 0) return PPST_EINVAL;
   if (!partial || !out) return PPST_ENULL;
-  PPST_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const float*)partial, (float*)out, n, scale);
+  PPST_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const float*)partial, (float*)out, n, scale, 0);
   return PPST_LAUNCH_CHECK();
 }
 
@@ -681,21 +686,22 @@ extern "C" int ppst_sum_partials(const void* partial, void* out, int n, float sc
 // adjoint of ppst_upscale_weight: w4[c][n][ky][kx] = scale * (w[n][c][ky][kx] + w[ky-1][kx] + w[ky][kx-1] + w[ky-1][kx-1])
 // -> dw[n][c][y][x] = scale * (dw4[c][n][y][x] + dw4[y+1][x] + dw4[y][x+1] + dw4[y+1][x+1])
 __global__ __launch_bounds__(256) void upscale_weight_bwd_kernel(const float* __restrict__ dw4, float* __restrict__ dw, int cout, int cin,
-                                                                 float scale, int64_t total) {
+                                                                 float scale, int64_t total, int accumulate) {
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
     const int xk = (int)(t % 3), yk = (int)((t / 3) % 3);
     const int64_t r = t / 9;
     const int c = (int)(r % cin), n = (int)(r / cin);
     const float* p = dw4 + ((int64_t)c * cout + n) * 16;
-    dw[t] = scale * (p[yk * 4 + xk] + p[(yk + 1) * 4 + xk] + p[yk * 4 + xk + 1] + p[(yk + 1) * 4 + xk + 1]);
+    const float v = scale * (p[yk * 4 + xk] + p[(yk + 1) * 4 + xk] + p[yk * 4 + xk + 1] + p[(yk + 1) * 4 + xk + 1]);
+    dw[t] = accumulate ? dw[t] + v : v;
   }
 }
-extern "C" int ppst_upscale_weight_bwd(const void* dw4, void* dw, int cout, int cin, float scale, void* stream) {
+extern "C" int ppst_upscale_weight_bwd(const void* dw4, void* dw, int cout, int cin, float scale, int accumulate, void* stream) {
   if (cout <= 0 || cin <= 0) return PPST_EINVAL;
   if (!dw4 || !dw) return PPST_ENULL;
   const int64_t total = (int64_t)cout * cin * 9;
   PPST_LAUNCH(upscale_weight_bwd_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)dw4, (float*)dw, cout, cin,
-              scale, total);
+              scale, total, accumulate);
   return PPST_LAUNCH_CHECK();
 }
 

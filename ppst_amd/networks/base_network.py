@@ -104,6 +104,28 @@ class BaseNetwork(nn.Module):
         w = self.p(wname)
         return self.cached(("plan", wname, kind), [w], lambda: ops.ConvPlan(w, kind=kind, scale=scale))
 
+    def refresh_plans(self):
+        """After an in-place parameter update (the Adam kernel writes the flat buffer through a raw pointer: no version counter
+        moves): re-pack every cached ConvPlan from its parameter storage with two batched launches (ops.repack_plans) instead of
+        dropping the plans and rebuilding each with its own pack launch on next use (216 launches per train step); every other
+        derived value (folded biases, style tables) is dropped as before."""
+        plans, keep = [], {}
+        for key, (ver, val) in self._cache.items():
+            if isinstance(key, tuple) and key and key[0] == "plan" and isinstance(val, ops.ConvPlan) and val.precision != 2 \
+                    and val.wparam.data_ptr() == self.p(key[1]).data_ptr():
+                plans.append(val)
+                keep[key] = (ver, val)
+        self._cache.clear()
+        if not plans:
+            return
+        sig = tuple((id(pl), tuple(sorted(pl._packs))) for pl in plans)
+        hit = self.__dict__.get("_repack")
+        if hit is not None and hit[0] == sig:
+            ops.run_repack(hit[1])
+        else:
+            self.__dict__["_repack"] = (sig, ops.repack_plans(plans), plans)     # (plans held: ids stay unique)
+        self._cache.update(keep)
+
     def print_architecture(self, verbose=False):
         n = sum(p.numel() for p in self.parameters())
         print("[Network %s] Total number of parameters : %.3f M" % (type(self).__name__, n / 1e6))

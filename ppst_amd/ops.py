@@ -198,6 +198,7 @@ class ConvPlan:
             return
         self.__dict__.update(geom)
         self.precision = PRECISION["value"] if precision is None else precision
+        self.wparam, self.up_scale = w, float(scale)       # (repack_plans: the fp32 parameter storage this plan was packed from)
         cout, cin, k, _ = w.shape
         if kind in ("convT", "dgradT"):      # the fused upscale's 4x4 kernel (Cin, Cout, 4, 4), scale folded in
             wsrc = torch.empty((cin, cout, 4, 4), device=w.device, dtype=torch.float32)
@@ -219,6 +220,7 @@ class ConvPlan:
 
     def _build(self, w, kind, scale, chan_base, precision):
         self.kind = kind
+        self.wparam, self.up_scale = w, float(scale)
         self.precision = PRECISION["value"] if precision is None else precision
         cout, cin, k, _ = w.shape
         assert cin % 32 == 0, "fused conv needs Cin % 32 == 0 (got %d)" % cin
@@ -533,11 +535,83 @@ class ConvPlan:
         return out
 
 
-def conv_wgrad(plan, x, dy, splits=None):
+def repack_plans(plans):
+    """Refresh the packed weights of ``plans`` (ConvPlan objects whose fp32 weights changed in place -- an Adam step) with TWO
+    launches: the fused-upscale 4x4 kernels of the 'convT' / 'dgradT' plans (ppst_upscale_weight_batch), then every pack of every
+    plan (ppst_conv_pack_batch).  Returns the job tables; pass them back as ``tables`` while the set of plans / packs is unchanged
+    (they hold device pointers only: nothing is rebuilt on the host)."""
+    import numpy as np
+    up, pk = [], []
+    for pl in plans:
+        if pl.precision == 2:
+            continue
+        if pl.kind in ("convT", "dgradT"):
+            cin4, cout4 = pl.wsrc.shape[0], pl.wsrc.shape[1]         # wsrc is the (Cin, Cout, 4, 4) kernel of the FORWARD conv
+            up.append((pl.wparam.data_ptr(), pl.wsrc.data_ptr(), cin4 * cout4 * 16, float(pl.up_scale), cout4, cin4))
+        sn, sc, sy, sx = pl.wstrides
+        c_, ky_, kx_ = pl.src_dev
+        for bn, wpack in pl._packs.items():
+            n_tiles = (pl.cout + bn - 1) // bn
+            pk.append((pl.wsrc.data_ptr(), sn, sc, sy, sx, c_.data_ptr(), ky_.data_ptr(), kx_.data_ptr(), wpack.data_ptr(),
+                       pl.n_groups * n_tiles * pl.nsteps * 4 * bn, float(pl.scale), pl.cout, bn, pl.nsteps, pl.n_groups,
+                       1 if pl.precision == 0 else 0, 1 if pl.precision in (3, 4) else 0))
+    dev = plans[0].steps.device if plans else None
+
+    def table(cls, rows, fill):
+        if not rows:
+            return None, 0
+        arr = (cls * len(rows))()
+        b0 = 0
+        for j, r in zip(arr, rows):
+            nb = lib.ppst_pack_job_blocks(fill(j, r))
+            j.block0, j.nblocks = b0, nb
+            b0 += nb
+        buf = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        return buf, b0
+
+    def fill_up(j, r):
+        j.w, j.out, j.total, j.scale, j.cout, j.cin = r
+        return j.total
+
+    def fill_pk(j, r):
+        (j.w, j.sn, j.sc, j.sy, j.sx, j.src_c, j.src_ky, j.src_kx, j.out, j.total, j.scale, j.cout, j.bn, j.nsteps, j.n_groups,
+         j.x3, j.f16) = r
+        return j.total
+    tu, nbu = table(_lib.UpscaleJob, up, fill_up)
+    tp, nbp = table(_lib.PackJob, pk, fill_pk)
+    tables = (tu, len(up), nbu, tp, len(pk), nbp)
+    run_repack(tables)
+    return tables
+
+
+def run_repack(tables):
+    tu, nu, nbu, tp, npk, nbp = tables
+    if nu:
+        check(lib.ppst_upscale_weight_batch(_p(tu), nu, nbu, _stream()), "ppst_upscale_weight_batch")
+    if npk:
+        check(lib.ppst_conv_pack_batch(_p(tp), npk, nbp, _stream()), "ppst_conv_pack_batch")
+
+
+def _grad_out(out, shape, like):
+    """destination of a parameter gradient: ``out`` (a contiguous view of the trainer's flat gradient, written or added into
+    by the kernel itself) or a fresh tensor."""
+    if out is None:
+        return torch.empty(shape, device=like.device, dtype=torch.float32)
+    n = 1
+    for d in shape:
+        n *= d
+    if out.numel() != n or not out.is_contiguous() or out.dtype != torch.float32 or not out.is_cuda:
+        raise RuntimeError("gradient destination must be a contiguous float32 CUDA tensor of %d elements, got %s" % (n, tuple(out.shape)))
+    return out
+
+
+def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False):
     """Weight gradient of the conv described by forward ``plan`` ('conv' or 's2d'):
     x = the tensor the forward conv read (NHWC, or the space-to-depth tensor for 's2d'),
     dy = gradient w.r.t. the conv output (before bias/activation).  Returns dW shaped
-    (Cout, Cin, k, k), already multiplied by the plan's weight scale (EqualConv2d)."""
+    (Cout, Cin, k, k), already multiplied by the plan's weight scale (EqualConv2d).
+    ``out`` / ``accumulate``: write (or add) into a given destination -- the reduction over the pixel splits adds straight
+    into the flat gradient buffer, so no separate accumulation pass (and no zero fill) runs."""
     assert plan.kind in ("conv", "s2d", "dgradT")
     in_ld = _nhwc_ld(x, "x")
     dy_ld = _nhwc_ld(dy, "dy")
@@ -561,46 +635,53 @@ def conv_wgrad(plan, x, dy, splits=None):
              cout, plan.nsteps, nchunks, splits, _stream()), name)
     # 'dgradT': the plan's "weights" are the blurred 4x4 kernel (Cin,Cout,4,4) of the transposed conv
     shape = plan.w4_shape if plan.kind == "dgradT" else (plan.cout, plan.cin, plan.k, plan.k)
-    dw = torch.zeros(shape, device=x.device, dtype=torch.float32)
+    if out is None:
+        dw = torch.zeros(shape, device=x.device, dtype=torch.float32)
+    else:
+        dw = _grad_out(out, shape, x)
+        if not accumulate:
+            dw.zero_()
     sn, sc, sy, sx = plan.wstrides
     c_, ky_, kx_ = plan.src_dev
     check(lib.ppst_wgrad_scatter(_p(partial), _p(c_), _p(ky_), _p(kx_), _p(dw), sn, sc, sy, sx, cout, plan.nsteps, splits,
-                                 plan.scale, 0, _stream()), "ppst_wgrad_scatter")
+                                 plan.scale, 1 if (accumulate and out is not None) else 0, _stream()), "ppst_wgrad_scatter")
     return dw
 
 
-def wgrad_small_cin(x, dy, scale):
+def wgrad_small_cin(x, dy, scale, out=None, accumulate=False):
     """FromRGB: x (B,H,W,cin<=4), dy (B,H,W,cout) -> dW (cout, cin, 1, 1)."""
     in_ld = _nhwc_ld(x)
     B, H, W, cin = x.shape
     cout = dy.shape[3]
     assert _nhwc_ld(dy) == cout
     ws = torch.empty(lib.ppst_wgrad_small_cin_ws(B * H * W, cin, cout) // 4, device=x.device, dtype=torch.float32)
-    dw = torch.empty((cout, cin, 1, 1), device=x.device, dtype=torch.float32)
-    check(lib.ppst_wgrad_small_cin(_p(x), _p(dy), _p(dw), _p(ws), B * H * W, cin, in_ld, cout, float(scale), 0, _stream()),
-          "ppst_wgrad_small_cin")
+    dw = _grad_out(out, (cout, cin, 1, 1), x)
+    check(lib.ppst_wgrad_small_cin(_p(x), _p(dy), _p(dw), _p(ws), B * H * W, cin, in_ld, cout, float(scale),
+                                   1 if (accumulate and out is not None) else 0, _stream()), "ppst_wgrad_small_cin")
     return dw
 
 
-def colsum(x2d, scale=1.0):
+def colsum(x2d, scale=1.0, out=None, accumulate=False):
     """x2d (rows, C) [row stride ld] -> (C,) column sums (bias gradients)."""
     _chk(x2d)
     rows, C = x2d.shape
     ld = x2d.stride(0)
     assert x2d.stride(1) == 1
     ws = torch.empty(lib.ppst_colsum_ws(rows, C) // 4, device=x2d.device, dtype=torch.float32)
-    out = torch.empty((C,), device=x2d.device, dtype=torch.float32)
-    check(lib.ppst_colsum(_p(x2d), _p(out), _p(ws), rows, C, ld, float(scale), 0, _stream()), "ppst_colsum")
-    return out
+    dst = _grad_out(out, (C,), x2d)
+    check(lib.ppst_colsum(_p(x2d), _p(dst), _p(ws), rows, C, ld, float(scale), 1 if (accumulate and out is not None) else 0, _stream()),
+          "ppst_colsum")
+    return dst
 
 
-def linear_wgrad(dy, x, scale=1.0):
+def linear_wgrad(dy, x, scale=1.0, out=None, accumulate=False):
     _chk(dy); _chk(x)
     dy, x = dy.contiguous(), x.contiguous()
     B, N = dy.shape
     K = x.shape[1]
-    dw = torch.empty((N, K), device=x.device, dtype=torch.float32)
-    check(lib.ppst_linear_wgrad(_p(dy), _p(x), _p(dw), B, N, K, float(scale), 0, _stream()), "ppst_linear_wgrad")
+    dw = _grad_out(out, (N, K), x)
+    check(lib.ppst_linear_wgrad(_p(dy), _p(x), _p(dw), B, N, K, float(scale), 1 if (accumulate and out is not None) else 0, _stream()),
+          "ppst_linear_wgrad")
     return dw
 
 
@@ -681,11 +762,12 @@ def conv1x1_small_cout(x, w, bias, wscale):
     return y
 
 
-def upscale_weight_bwd(dw4, cout, cin, scale=1.0):
+def upscale_weight_bwd(dw4, cout, cin, scale=1.0, out=None, accumulate=False):
     """adjoint of the fused-upscale weight blur (stylegan2_layers.py:314-319): dw4 (Cin,Cout,4,4) -> (Cout,Cin,3,3)."""
     _chk(dw4)
-    dw = torch.empty((cout, cin, 3, 3), device=dw4.device, dtype=torch.float32)
-    check(lib.ppst_upscale_weight_bwd(_p(dw4.contiguous()), _p(dw), cout, cin, float(scale), _stream()), "ppst_upscale_weight_bwd")
+    dw = _grad_out(out, (cout, cin, 3, 3), dw4)
+    check(lib.ppst_upscale_weight_bwd(_p(dw4.contiguous()), _p(dw), cout, cin, float(scale), 1 if (accumulate and out is not None) else 0,
+                                      _stream()), "ppst_upscale_weight_bwd")
     return dw
 
 
@@ -918,16 +1000,17 @@ def scale_by(x, s):
     return y
 
 
-def noise_wgrad(dpre, noise):
+def noise_wgrad(dpre, noise, out=None, accumulate=False):
     ld = _nhwc_ld(dpre)
     B, H, W, C = dpre.shape
     _chk(noise)
     noise = noise.contiguous()
     assert noise.numel() == B * H * W
     ws = torch.empty(lib.ppst_noise_wgrad_ws(B * H * W) // 4, device=dpre.device, dtype=torch.float32)
-    out = torch.empty((1,), device=dpre.device, dtype=torch.float32)
-    check(lib.ppst_noise_wgrad(_p(dpre), _p(noise), _p(out), _p(ws), B * H * W, C, ld, _stream()), "ppst_noise_wgrad")
-    return out
+    dst = _grad_out(out, (1,), dpre)
+    check(lib.ppst_noise_wgrad(_p(dpre), _p(noise), _p(dst), _p(ws), B * H * W, C, ld, 1 if (accumulate and out is not None) else 0,
+                               _stream()), "ppst_noise_wgrad")
+    return dst
 
 
 def affine_act(x, scale_shift=None, res=None, act=ACT_NONE, prelu=None, out_scale=1.0, res_before_act=False, out=None,

@@ -132,30 +132,31 @@ class DiscriminatorTrainer:
         return pred, tape
 
     # --------------------------------------------------------------- backward
-    def _acc(self, name, val):
-        g = self.g("stylegan2_D." + name)
-        g.add_(val.reshape(-1))  # gradient accumulation over the real / rec / mix passes (memory op)
+    def _gdst(self, name):
+        """flat-gradient view of ``stylegan2_D.<name>``: the destination the gradient kernels add into (accumulate flag of the
+        C ABI) -- no temporary and no separate accumulation launch per parameter."""
+        return self.g("stylegan2_D." + name)
 
     def backward(self, tape, dpred, param_grads=True, keep=None):
         """Back-propagate ``dpred`` (B,1) through the taped forward.  ``param_grads`` accumulates
         d/d(theta_D) into self.grad; ``keep`` (a dict) receives the gradient wrt every conv / linear
         pre-activation and wrt the image (what the R1 second-order pass contracts against)."""
         D, p = self.D, "stylegan2_D."
-        acc = self._acc if param_grads else (lambda *a: None)
+        G = self._gdst                     # parameter gradients are ADDED into the flat buffer by the kernels themselves
         pg = param_grads
         w0, w1 = D.p(p + "final_linear.0.weight"), D.p(p + "final_linear.1.weight")
         s0, s1 = 1.0 / math.sqrt(w0.shape[1]), 1.0 / math.sqrt(w1.shape[1])
         f, h = tape["f"], tape["h"]
         # final_linear.1 (EqualLinear 512 -> 1)
         if pg:
-            acc("final_linear.1.weight", ops.linear_wgrad(dpred, h, s1))
-            acc("final_linear.1.bias", ops.colsum(dpred))
+            ops.linear_wgrad(dpred, h, s1, out=G("final_linear.1.weight"), accumulate=True)
+            ops.colsum(dpred, out=G("final_linear.1.bias"), accumulate=True)
         dh = ops.linear_dgrad(dpred, w1, s1)
         # final_linear.0 (EqualLinear 8192 -> 512, fused lrelu)
         gpre_h = _lrelu_bwd(dh, h)
         if pg:
-            acc("final_linear.0.weight", ops.linear_wgrad(gpre_h, f, s0))
-            acc("final_linear.0.bias", ops.colsum(gpre_h))
+            ops.linear_wgrad(gpre_h, f, s0, out=G("final_linear.0.weight"), accumulate=True)
+            ops.colsum(gpre_h, out=G("final_linear.0.bias"), accumulate=True)
         df = ops.linear_dgrad(gpre_h, w0, s0)
         fc = tape["fc"]
         B, hh, ww, C = fc.shape
@@ -164,8 +165,8 @@ class DiscriminatorTrainer:
         gpre = _lrelu_bwd(dfc, fc)
         scf = 1.0 / math.sqrt(tape["x_last"].shape[3] * 9)
         if pg:
-            acc("final_conv.Conv.weight", ops.conv_wgrad(D.plan(p + "final_conv.Conv.weight", scale=scf), tape["x_last"], gpre))
-            acc("final_conv.Act.bias", ops.colsum(gpre.view(-1, C)))
+            ops.conv_wgrad(D.plan(p + "final_conv.Conv.weight", scale=scf), tape["x_last"], gpre, out=G("final_conv.Conv.weight"), accumulate=True)
+            ops.colsum(gpre.view(-1, C), out=G("final_conv.Act.bias"), accumulate=True)
         dx = self._dgrad(p + "final_conv.Conv.weight", "dgrad", scf)(gpre)
         if keep is not None:
             keep["dpred"], keep["gpre_h"], keep["gpre_fc"], keep["blocks"] = dpred, gpre_h, gpre, []
@@ -177,21 +178,21 @@ class DiscriminatorTrainer:
             # out = (a2 + skip)/sqrt2 ;  a2 = lrelu(conv2 + b)*sqrt2
             g2 = _lrelu_bwd(dx, blk["a2"], INV_SQRT2)
             if pg:
-                acc(name + "conv2.Act.bias", ops.colsum(g2.view(-1, cout)))
-                acc(name + "conv2.Conv.weight", ops.conv_wgrad(D.plan(q + "conv2.Conv.weight", "s2d", sc1), blk["xb"], g2))
+                ops.colsum(g2.view(-1, cout), out=G(name + "conv2.Act.bias"), accumulate=True)
+                ops.conv_wgrad(D.plan(q + "conv2.Conv.weight", "s2d", sc1), blk["xb"], g2, out=G(name + "conv2.Conv.weight"), accumulate=True)
             d_xb = self._dgrad(q + "conv2.Conv.weight", "dgrad_s2d", sc1)(g2, out_hw=blk["bhw"])
             # blur backward: upfirdn2d with the flipped (symmetric) taps and g_pad = (1, 1)
             kf = torch.flip(D.p(q + "conv2.Blur.kernel"), [0, 1]).contiguous()
             d_y1, _ = ops.blur_nhwc(d_xb, kf, 1, 1, ops.PAD_ZERO)
             g1 = _lrelu_bwd(d_y1, blk["y1"])
             if pg:
-                acc(name + "conv1.Act.bias", ops.colsum(g1.view(-1, cin)))
-                acc(name + "conv1.Conv.weight", ops.conv_wgrad(D.plan(q + "conv1.Conv.weight", scale=sc1), blk["x"], g1))
+                ops.colsum(g1.view(-1, cin), out=G(name + "conv1.Act.bias"), accumulate=True)
+                ops.conv_wgrad(D.plan(q + "conv1.Conv.weight", scale=sc1), blk["x"], g1, out=G(name + "conv1.Conv.weight"), accumulate=True)
             d_xa = self._dgrad(q + "conv1.Conv.weight", "dgrad", sc1)(g1)
             # skip branch: 1x1 conv on the blurred + decimated input, no bias / activation
             gs = ops.affine_act(dx, None, out_scale=INV_SQRT2)
             if pg:
-                acc(name + "skip.Conv.weight", ops.conv_wgrad(D.plan(q + "skip.Conv.weight", scale=scs), blk["xs"], gs))
+                ops.conv_wgrad(D.plan(q + "skip.Conv.weight", scale=scs), blk["xs"], gs, out=G(name + "skip.Conv.weight"), accumulate=True)
             d_xs = self._dgrad(q + "skip.Conv.weight", "dgrad", scs)(gs)
             # blur(down=2, pad (1,1)) backward = zero-insert x2 then FIR with g_pad (upfirdn2d.py:116-121)
             S = blk["S"]
@@ -210,8 +211,8 @@ class DiscriminatorTrainer:
         w = D.p(p + "convs.0.Conv.weight")
         sc0 = 1.0 / math.sqrt(w.shape[1])
         if pg:
-            acc("convs.0.Act.bias", ops.colsum(g0.view(-1, g0.shape[3])))
-            acc("convs.0.Conv.weight", ops.wgrad_small_cin(tape["img"], g0, sc0))
+            ops.colsum(g0.view(-1, g0.shape[3]), out=G("convs.0.Act.bias"), accumulate=True)
+            ops.wgrad_small_cin(tape["img"], g0, sc0, out=G("convs.0.Conv.weight"), accumulate=True)
         if keep is not None:
             keep["blocks"].reverse()
             keep["g0"] = g0
@@ -245,6 +246,7 @@ class DiscriminatorTrainer:
         convs / blurs / gates (no biases), and every layer adds wgrad(input = t_in, dy = the
         first backward's gradient at that layer's pre-activation)."""
         D, p = self.D, "stylegan2_D."
+        G = self._gdst
         tape, keep, lambda_R1 = state
         g_img = keep["d_img"]
         B = g_img.shape[0]
@@ -253,36 +255,36 @@ class DiscriminatorTrainer:
         t = ops.affine_act(g_img, ss, out_scale=lambda_R1)
         w = D.p(p + "convs.0.Conv.weight")
         sc0 = 1.0 / math.sqrt(w.shape[1])
-        self._acc("convs.0.Conv.weight", ops.wgrad_small_cin(t, keep["g0"], sc0))
+        ops.wgrad_small_cin(t, keep["g0"], sc0, out=G("convs.0.Conv.weight"), accumulate=True)
         t = ops.conv1x1_small_cin(t, w, None, sc0, ops.ACT_NONE)
         t = _lrelu_bwd(t, tape["x0"])
         for blk, kb in zip(tape["blocks"], keep["blocks"]):
             q, cin = blk["q"], blk["cin"]
             name = q[len(p):]
             sc1, scs = 1.0 / math.sqrt(cin * 9), 1.0 / math.sqrt(cin)
-            self._acc(name + "conv1.Conv.weight", ops.conv_wgrad(D.plan(q + "conv1.Conv.weight", scale=sc1), t, kb["g1"]))
+            ops.conv_wgrad(D.plan(q + "conv1.Conv.weight", scale=sc1), t, kb["g1"], out=G(name + "conv1.Conv.weight"), accumulate=True)
             t1 = D.plan(q + "conv1.Conv.weight", scale=sc1)(t)
             t1 = _lrelu_bwd(t1, blk["y1"])
             ts, _ = ops.blur_nhwc(t, D.p(q + "skip.Blur.kernel"), 1, 1, ops.PAD_ZERO, down=2)
-            self._acc(name + "skip.Conv.weight", ops.conv_wgrad(D.plan(q + "skip.Conv.weight", scale=scs), ts, kb["gs"]))
+            ops.conv_wgrad(D.plan(q + "skip.Conv.weight", scale=scs), ts, kb["gs"], out=G(name + "skip.Conv.weight"), accumulate=True)
             tskip = D.plan(q + "skip.Conv.weight", scale=scs)(ts)
             tb, bhw = ops.blur_nhwc(t1, D.p(q + "conv2.Blur.kernel"), 2, 2, ops.PAD_ZERO, s2d=True)
-            self._acc(name + "conv2.Conv.weight", ops.conv_wgrad(D.plan(q + "conv2.Conv.weight", "s2d", sc1), tb, kb["g2"]))
+            ops.conv_wgrad(D.plan(q + "conv2.Conv.weight", "s2d", sc1), tb, kb["g2"], out=G(name + "conv2.Conv.weight"), accumulate=True)
             ohw = ((bhw[0] - 3) // 2 + 1, (bhw[1] - 3) // 2 + 1)
             t2 = D.plan(q + "conv2.Conv.weight", "s2d", sc1)(tb, out_hw=ohw)
             t2 = _lrelu_bwd(t2, blk["a2"])
             t = ops.affine_act(t2, None, res=tskip, out_scale=INV_SQRT2)
         scf = 1.0 / math.sqrt(t.shape[3] * 9)
-        self._acc("final_conv.Conv.weight", ops.conv_wgrad(D.plan(p + "final_conv.Conv.weight", scale=scf), t, keep["gpre_fc"]))
+        ops.conv_wgrad(D.plan(p + "final_conv.Conv.weight", scale=scf), t, keep["gpre_fc"], out=G("final_conv.Conv.weight"), accumulate=True)
         t = D.plan(p + "final_conv.Conv.weight", scale=scf)(t)
         t = _lrelu_bwd(t, tape["fc"])
         tf = ops.nhwc_to_nchw(t).reshape(B, -1)
         w0, w1 = D.p(p + "final_linear.0.weight"), D.p(p + "final_linear.1.weight")
         s0, s1 = 1.0 / math.sqrt(w0.shape[1]), 1.0 / math.sqrt(w1.shape[1])
-        self._acc("final_linear.0.weight", ops.linear_wgrad(keep["gpre_h"], tf, s0))
+        ops.linear_wgrad(keep["gpre_h"], tf, s0, out=G("final_linear.0.weight"), accumulate=True)
         th = ops.linear(tf, w0, None, wscale=s0)
         th = _lrelu_bwd(th, tape["h"])
-        self._acc("final_linear.1.weight", ops.linear_wgrad(keep["dpred"], th, s1))
+        ops.linear_wgrad(keep["dpred"], th, s1, out=G("final_linear.1.weight"), accumulate=True)
 
     def r1_losses_and_grads(self, real, lambda_R1=10.0, R1_once_every=16):
         """Lazy R1 (ppst_model.py:140-159, ppst_optimizer.py:116-126): zero_grad, penalty, and
@@ -342,7 +344,7 @@ class DiscriminatorTrainer:
                                "on the same network, or .to()/.cuda() moved it): the update would be lost")
         self.step_count += 1
         ops.adam_step_(self.flat, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, self.step_count)
-        self.D._cache.clear()  # packed weights are stale
+        self.D.refresh_plans()  # packed weights are stale: re-packed in place, two launches
 
     # Data parallel, overlapped: the discriminator iteration ends with its 116-MB gradient all-reduce; nothing else in that
     # iteration needs D any more, and the generator iteration that follows does not touch D before its GAN terms.  So the

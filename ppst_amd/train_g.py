@@ -43,10 +43,17 @@ class FlatParams:
             p.data = flat[off:off + sz].view_as(p)
             p.requires_grad_(True)
             p.grad = self.grad[off:off + sz].view_as(p)     # autograd accumulates in place into the flat gradient
+            p._ppst_direct = True                           # ... and the backward kernels add straight into it (autograd._direct)
+            p._ppst_on_grad = self._on_grad
             self.offsets[n_] = (off, sz)
             off += sz
+        self.on_event = None                                # set by the trainer: called once per gradient contribution
         net._flat.clear(); net._cache.clear()
         self.lr, self.b1, self.b2, self.eps, self.step_count = lr, beta1, beta2, 1e-8, 0
+
+    def _on_grad(self):
+        if self.on_event is not None:
+            self.on_event()
 
     def g(self, name):
         off, sz = self.offsets[name]
@@ -88,7 +95,8 @@ class FlatParams:
             raise RuntimeError("parameters / gradients no longer alias the flat buffers of this trainer")
         self.step_count += 1
         ops.adam_step_(self.flat, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, self.step_count)
-        self.invalidate()            # packed weights and host scalars are stale
+        self._scalar_key = None      # host scalars are stale; the conv plans are re-packed in place (two launches)
+        self.net.refresh_plans()
 
 
 class GeneratorTrainer:
@@ -210,7 +218,13 @@ class GeneratorTrainer:
     # ------------------------------------------------------------ G (generator.py:244-281)
     def _styled_conv(self, x, p, code, key, noise, upsample=False):
         net, P = self.G, self.G.p
-        bias = P(p + "conv.bias") + P(p + "bias").reshape(-1) + P(p + "activate.bias")   # three biases of StyledConv collapse
+        parts = (P(p + "conv.bias"), P(p + "bias"), P(p + "activate.bias"))                # three biases of StyledConv collapse
+        bias_params = parts if all(A._direct(q) is not None for q in parts) else None
+        if bias_params is not None:       # the sum is a constant of the graph; the block adds d/d(bias) to all three gradients itself
+            with torch.no_grad():
+                bias = parts[0] + parts[1].reshape(-1) + parts[2]
+        else:
+            bias = parts[0] + parts[1].reshape(-1) + parts[2]
         kind = "conv"
         if upsample:
             if min(x.shape[1], x.shape[2]) * 2 < 128:
@@ -222,7 +236,7 @@ class GeneratorTrainer:
             nz = torch.randn(B, 1, H, W, device=x.device)          # NoiseInjection draws N(0,1) (stylegan2_layers.py:388-390)
         wn = p + "conv.weight"
         a, st = A.conv(x, P(wn), net, wn, bias=bias, kind=kind, act=A.LRELU, noise_w=P(p + "noise.weight"), noise=nz.contiguous(), stats=True,
-                       noise_w_host=self.fp["G"].scalar(p + "noise.weight"))
+                       noise_w_host=self.fp["G"].scalar(p + "noise.weight"), bias_params=bias_params)
         wl = P(p + "epi1.style_mod.lin.weight")
         style = A.linear(code, wl, P(p + "epi1.style_mod.lin.bias"), wscale=wl.shape[1] ** -0.5)
         return A.instance_norm(a, st, style=style)
@@ -429,24 +443,34 @@ class GeneratorTrainer:
         return out
 
     # ---- data parallel: flat gradient all-reduce per network, overlapped with the rest of the backward pass.
-    # Autograd runs a leaf's AccumulateGrad once per backward, after ALL uses of the parameter have contributed, so a
-    # post-accumulate hook that counts a network's parameters knows when that network's flat gradient is final: its
-    # all-reduce is launched (async, RCCL) right there, while autograd is still working on the networks behind it
-    # (backward order: D -> G -> E2 / E1).  Whatever did not complete (parameters without a gradient in this step) is
-    # reduced after backward() returns.
+    # A network's flat gradient is final once every contribution of this backward has landed.  Contributions are counted per
+    # network: a post-accumulate hook fires once for each parameter whose gradient still travels through autograd's
+    # AccumulateGrad, and every backward kernel that adds straight into the flat buffer reports itself (autograd._noted).  The
+    # count of one full backward is LEARNED in the first armed step (whose all-reduces start after backward() returns); from
+    # then on the all-reduce of a network is launched (async, RCCL) by the contribution that completes its count, while
+    # autograd is still working on the networks behind it (backward order: D -> G -> E2 / E1).  The graph of the generator
+    # iteration is static for fixed options; a step whose count differs from the learned one raises (call relearn_overlap()
+    # after changing loss weights / training stage).
     def _install_overlap_hooks(self):
         if getattr(self, "_hooks", None) is not None:
             return
         self._hooks, self._pending, self._done_count = [], {}, {}
+        self._expected = {}
         for key, f in self.fp.items():
             self._done_count[key] = 0
+
+            def event(key=key, f=f):
+                self._done_count[key] += 1
+                if self.world > 1 and self._expected.get(key) == self._done_count[key] and key not in self._pending:
+                    import torch.distributed as dist
+                    self._pending[key] = dist.all_reduce(f.grad, op=dist.ReduceOp.SUM, async_op=True)
+            f.on_event = event
             for p in f.params:
-                def hook(_p, key=key, f=f):
-                    self._done_count[key] += 1
-                    if self._done_count[key] == len(f.params) and self.world > 1:
-                        import torch.distributed as dist
-                        self._pending[key] = dist.all_reduce(f.grad, op=dist.ReduceOp.SUM, async_op=True)
-                self._hooks.append(p.register_post_accumulate_grad_hook(hook))
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, ev=event: ev()))
+
+    def relearn_overlap(self):
+        if getattr(self, "_expected", None) is not None:
+            self._expected = {}
 
     def all_reduce(self):
         """Finish the gradient average: wait for the all-reduces launched during backward, launch + wait the rest."""
@@ -454,7 +478,15 @@ class GeneratorTrainer:
             return
         import torch.distributed as dist
         pending = getattr(self, "_pending", {})
+        counts = getattr(self, "_done_count", None)
         for key, f in self.fp.items():
+            if counts is not None:
+                exp = self._expected.get(key)
+                if exp is None:
+                    self._expected[key] = counts[key]           # learned: the next step overlaps
+                elif exp != counts[key]:
+                    raise RuntimeError("gradient contributions of %s changed (%d, learned %d): the graph of the generator iteration "
+                                       "is not the one the overlap was learned on -- call relearn_overlap()" % (key, counts[key], exp))
             h = pending.pop(key, None)
             if h is None:
                 h = dist.all_reduce(f.grad, op=dist.ReduceOp.SUM, async_op=True)

@@ -453,8 +453,13 @@ def _net_grad_check(tag, trainer, fp, sd64, outs_gpu, outs_ref, extra_gpu=(), ex
     for o, c in zip(outs_gpu, cots):
         t = (o * c.float().to(dev)).sum()
         loss = t if loss is None else loss + t
-    gin = torch.autograd.grad(loss, list(extra_gpu), retain_graph=True, allow_unused=True) if extra_gpu else ()
+    # ONE backward: the blocks add parameter gradients straight into the trainer's flat buffers (autograd._direct), so a second
+    # pass through the graph (torch.autograd.grad for the inputs, then backward()) would count them twice -- like two backward()
+    # calls would.  The extra inputs are leaves: their gradients are read from .grad.
+    for t in extra_gpu:
+        t.grad = None
     loss.backward()
+    gin = tuple(t.grad for t in extra_gpu)
     lr = sum((o * c).sum() for o, c in zip(outs_ref, cots))
     names = [n for n in fp.names if sd64[prefix + n].requires_grad]
     gr = torch.autograd.grad(lr, [sd64[prefix + n] for n in names] + list(extra_ref), allow_unused=True)

@@ -95,12 +95,12 @@ def loss_fn(seed):
         x = torch.randn(f.net.a.shape[0])
         tot = tot + ((f.net.a @ x + f.net.b) ** 2).sum() + (f.net.a * f.net.a).sum()      # a is used twice
     return tot
-for step in range(2):                       # twice: the hook counters must re-arm
+for step in range(3):                       # the counters must re-arm; step 0 LEARNS the contribution count per network
     tr.zero_grad()
-    tr._install_overlap_hooks(); tr._pending = {}
-    for k in tr._done_count: tr._done_count[k] = 0
+    tr.begin_backward_overlap()
     loss_fn(100 * step + rank).backward()
-    launched = sorted(tr._pending)          # 'unused' never gets a gradient -> nothing completes during backward
+    launched = sorted(tr._pending)          # from step 1 on every network's all-reduce starts inside backward() -- although
+    assert launched == ([] if step == 0 else ["E1", "E2", "G"]), (step, launched)   # 'unused' never gets a gradient
     tr.all_reduce()
     got = {k: f.grad.clone() for k, f in tr.fp.items()}
     # expected: average over ranks of the single-rank gradients (autograd.grad: no AccumulateGrad, the hooks stay quiet)
@@ -118,6 +118,15 @@ for step in range(2):                       # twice: the hook counters must re-a
                 assert float(mine.abs().max()) == 0.0
             else:
                 assert torch.allclose(mine, exp[id(p)], atol=1e-5), (step, k, n_)
+# a changed graph (one contribution fewer) must be refused, not silently reduced early
+tr.zero_grad(); tr.begin_backward_overlap()
+f = tr.fp["G"]
+(f.net.a.sum() * 1.0).backward()
+try:
+    tr.all_reduce()
+    raise SystemExit("a changed contribution count went unnoticed")
+except RuntimeError as e:
+    assert "relearn_overlap" in str(e)
 if rank == 0:
     print("OK")
 dist.destroy_process_group()
