@@ -219,17 +219,35 @@ def bench_train(args, rank, world, dev, barrier, max_over_ranks):
     mask = torch.nn.functional.one_hot(lab, 3).permute(0, 3, 1, 2).float().contiguous().to(dev)
     opt = PPSTOptimizer(model, world=world)
     data = {"real_A": real, "mask_A": mask}
+    from ppst_amd import ops
     for _ in range(args.warmup):
         opt.train_one_step(data, 0); opt.train_one_step(data, 0)
     barrier()
+    ops.prof_enable(True)        # HIP events around every conv (forward / input-gradient) and weight-gradient launch, on their stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         dl = opt.train_one_step(data, 0)
         gl = opt.train_one_step(data, 0)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
+    detail = ops.prof_detail()
+    ops.prof_collect()
+    ops.prof_enable(False)
     assert all(v == v for v in list(dl.values()) + list(gl.values())), "NaN loss"
     imgs = world * B * args.steps
+    passes = {"bf16x3": 3, "fp16x2": 2}.get(args.precision, 1)
+
+    def roof(rows, kernel, npass):
+        ms, fl = sum(r[0] for r in rows), sum(r[1] for r in rows)
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        peak = PEAK_BF16_DENSE_TF / npass
+        return {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "peak_note": "bf16 dense MFMA 2500 TF / %d MFMA passes per algorithmic MAC" % npass,
+                "frac_vs_dense_bf16": ach / PEAK_BF16_DENSE_TF, "launches_per_step": len(rows) / args.steps,
+                "kernel_ms_per_step": ms / args.steps, "algorithmic_tflop_per_step": fl / args.steps / 1e12,
+                "share_of_step_time": ms * 1e-3 / dt, "traffic": None}
+    wg = [r for r in detail if r[2][7] == 0]
+    cv = [r for r in detail if r[2][7] != 0]
     return {"metric": "512x512 train images/sec (one D + one G iteration per step)", "value": imgs / dt, "unit": "images/s (all GPUs)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NOTE[args.precision], "data": "synthetic",
@@ -237,6 +255,10 @@ def bench_train(args, rank, world, dev, barrier, max_over_ranks):
                                    "(lpips unavailable), random init (BASELINE configs[3])",
                        "collectives": "flat gradient all-reduce per network (D 29.0 M, G 42.5 M, E2 27.0 M, E1 0.83 M fp32) + one "
                                       "[24, 2048] all_gather of the NCE keys"},
+            # the dominant kernel of the step by time: the weight gradient (always bf16x3: three passes of the hi / lo split)
+            "roofline": roof(wg, "conv_wgrad_x3_kernel (conv weight gradients, bf16 hi+lo split on the matrix pipe; all launches of the step)", 3),
+            "roofline_conv": roof(cv, "ppst_conv2d_mfma launches of the step: forward and input-gradient convs (same kernels as the swap line)", passes),
+            "algorithmic_tflops_conv_and_wgrad": (sum(r[1] for r in detail)) / dt / 1e12,
             "losses": {**dl, **gl}}
 
 

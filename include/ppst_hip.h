@@ -491,8 +491,11 @@ int ppst_prof_dropped(void);
 /* after a stream sync: total ms, launches, algorithmic flop of bracketed calls */
 int ppst_prof_collect(double* ms, int64_t* launches, double* flop);
 /* per-launch detail of bracketed call idx (before ppst_prof_collect resets the pool):
- * info = {B, tile_h, tile_w, nsteps, cout, n_groups, halo, bn} */
+ * info = {B, tile_h, tile_w, nsteps, cout, n_groups, halo, bn}; a ppst_conv_wgrad_bf16x3 launch is bracketed too, with
+ * info = {B, oh, ow, nsteps, cout, nchunks, splits, 0} (bn = 0 marks it) */
 int ppst_prof_detail(int idx, double* ms, double* flop, int32_t* info);
+/* profiling only: number of steps of the NEXT weight-gradient launch that carry real weights (default: all of them) */
+int ppst_wgrad_flop_steps(int flop_steps);
 
 #ifdef __cplusplus
 }

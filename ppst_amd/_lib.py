@@ -142,6 +142,7 @@ _SIGS = {
     "ppst_space_to_depth": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ppst_prof_enable": (i32, [i32]),
     "ppst_prof_dropped": (i32, []),
+    "ppst_wgrad_flop_steps": (i32, [i32]),
     "ppst_prof_collect": (i32, [ctypes.POINTER(f64), ctypes.POINTER(i64), ctypes.POINTER(f64)]),
     "ppst_prof_detail": (i32, [i32, ctypes.POINTER(f64), ctypes.POINTER(f64), ctypes.POINTER(i32)]),
 }

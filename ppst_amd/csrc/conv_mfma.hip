@@ -791,6 +791,25 @@ static int g_ev_made = 0, g_ev_used = 0;
 static int g_prof_dropped = 0;   // launches not bracketed because PROF_MAX events were in use
 extern "C" int ppst_prof_dropped(void) { return g_prof_dropped; }
 
+// bracket one launch on ``st`` (used by ppst_conv2d_mfma here and by the weight-gradient entry points of train.hip): returns the event
+// slot or -1 when profiling is off / the pool is full
+int ppst_prof_begin_(double flop, const int* info8, hipStream_t st) {
+  if (!g_prof_on) return -1;
+  if (g_ev_used >= PROF_MAX) { ++g_prof_dropped; return -1; }
+  while (g_ev_made <= g_ev_used) {
+    if (hipEventCreate(&g_ev[g_ev_made][0]) != hipSuccess || hipEventCreate(&g_ev[g_ev_made][1]) != hipSuccess) return -1;
+    ++g_ev_made;
+  }
+  const int slot = g_ev_used++;
+  g_flop[slot] = flop;
+  for (int i = 0; i < 8; ++i) g_info[slot][i] = info8[i];
+  (void)hipEventRecord(g_ev[slot][0], st);
+  return slot;
+}
+void ppst_prof_end_(int slot, hipStream_t st) {
+  if (slot >= 0) (void)hipEventRecord(g_ev[slot][1], st);
+}
+
 extern "C" int ppst_prof_enable(int on) {
   g_prof_on = on;
   g_ev_used = 0;
@@ -903,17 +922,10 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   int blocks = (int)blocks64;
   hipStream_t st = as_stream(stream);
   int slot = -1;
-  if (g_prof_on && g_ev_used >= PROF_MAX) ++g_prof_dropped;
-  if (g_prof_on && g_ev_used < PROF_MAX) {
-    while (g_ev_made <= g_ev_used) {
-      if (hipEventCreate(&g_ev[g_ev_made][0]) != hipSuccess || hipEventCreate(&g_ev[g_ev_made][1]) != hipSuccess) return PPST_EINVAL;
-      ++g_ev_made;
-    }
-    slot = g_ev_used++;
-    g_flop[slot] = 2.0 * 32.0 * (a->flop_steps > 0 ? a->flop_steps : a->nsteps) * (double)a->n_groups * a->cout * (double)a->B * a->tile_h * a->tile_w;
-    int inf[8] = {a->B, a->tile_h, a->tile_w, a->nsteps, a->cout, a->n_groups, a->halo, a->bn};
-    for (int i = 0; i < 8; ++i) g_info[slot][i] = inf[i];
-    (void)hipEventRecord(g_ev[slot][0], st);
+  if (g_prof_on) {
+    const int inf[8] = {a->B, a->tile_h, a->tile_w, a->nsteps, a->cout, a->n_groups, a->halo, a->bn};
+    slot = ppst_prof_begin_(2.0 * 32.0 * (a->flop_steps > 0 ? a->flop_steps : a->nsteps) * (double)a->n_groups * a->cout * (double)a->B * a->tile_h * a->tile_w,
+                            inf, st);
   }
   if (a->variant >= 1) {
     int e2 = a->variant == 4   ? ppst_conv1x1_stream_launch(a, k.n_tiles, k.tiles_y * k.tiles_x, st)

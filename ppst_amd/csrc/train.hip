@@ -310,6 +310,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __re
   }
 }
 
+// profiling brackets of conv_mfma.hip: a weight-gradient launch is recorded with info = {B, oh, ow, nsteps, cout, nchunks, splits, 0}
+// (bn = 0 marks it) and the algorithmic 2 * 32 * flop_steps * cout * B * oh * ow (flop_steps < nsteps where the table carries
+// zero-weight pad steps)
+int ppst_prof_begin_(double flop, const int* info8, hipStream_t st);
+void ppst_prof_end_(int slot, hipStream_t st);
+static int wgrad_prof_begin(int B, int oh, int ow, int cout, int nsteps, int flop_steps, int nchunks, int splits, hipStream_t st) {
+  const int inf[8] = {B, oh, ow, nsteps, cout, nchunks, splits, 0};
+  return ppst_prof_begin_(2.0 * 32.0 * (flop_steps > 0 ? flop_steps : nsteps) * (double)cout * (double)B * oh * ow, inf, st);
+}
+static int g_wgrad_flop_steps = 0;   // set by ppst_wgrad_flop_steps for the NEXT weight-gradient launch (profiling only)
+extern "C" int ppst_wgrad_flop_steps(int flop_steps) { g_wgrad_flop_steps = flop_steps; return PPST_OK; }
+
 // same contract as ppst_conv_wgrad_f32 (which stays the exact-fp32 path of precision 2); needs the 16-B aligned rows every
 // caller on the train path has, taps in [-1, 1]^2 (every step table of the path)
 extern "C" int ppst_conv_wgrad_bf16x3(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial,
@@ -325,9 +337,12 @@ extern "C" int ppst_conv_wgrad_bf16x3(const void* x, const void* dy, const void*
   const int tiles_total = B * tiles_per_image;
   const int tps = cdiv(tiles_total, splits);
   dim3 grid(cdiv(cout, 128), nchunks, splits);
+  const int slot = wgrad_prof_begin(B, oh, ow, cout, nsteps, g_wgrad_flop_steps, nchunks, splits, as_stream(stream));
+  g_wgrad_flop_steps = 0;
   PPST_LAUNCH(conv_wgrad_x3_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (const int4*)steps,
               (const int*)chunk_start, (float*)partial, B, in_h, in_w, in_ld, oh, ow, dy_ld, cout, nsteps, tiles_x, tiles_per_image,
               tiles_total, tps);
+  ppst_prof_end_(slot, as_stream(stream));
   return PPST_LAUNCH_CHECK();
 }
 

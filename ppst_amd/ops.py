@@ -631,6 +631,8 @@ def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False):
     aligned = cout % 4 == 0 and dy_ld % 4 == 0 and in_ld % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
     fn, name = ((lib.ppst_conv_wgrad_bf16x3, "ppst_conv_wgrad_bf16x3") if (WGRAD_X3["value"] and plan.precision != 2 and aligned)
                 else (lib.ppst_conv_wgrad_f32, "ppst_conv_wgrad_f32"))
+    if PROF_ON["value"]:
+        lib.ppst_wgrad_flop_steps(int(plan.flop_steps))
     check(fn(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), B, H, W, in_ld, oh, ow, dy_ld,
              cout, plan.nsteps, nchunks, splits, _stream()), name)
     # 'dgradT': the plan's "weights" are the blurred 4x4 kernel (Cin,Cout,4,4) of the transposed conv
@@ -1251,7 +1253,11 @@ def guided_filter(guide_u8, src_u8, r=30, eps=(0.02 * 255) ** 2, want_u8=False):
 
 
 # --------------------------------------------------------------- profiling ----
+PROF_ON = {"value": False}
+
+
 def prof_enable(on):
+    PROF_ON["value"] = bool(on)
     check(lib.ppst_prof_enable(1 if on else 0), "ppst_prof_enable")
 
 
