@@ -262,6 +262,80 @@ def bench_train(args, rank, world, dev, barrier, max_over_ranks):
             "losses": {**dl, **gl}}
 
 
+def bench_hires(args, rank, world, dev, barrier, max_over_ranks):
+    """BASELINE configs[4]: 1024x1024 swap + guided-filter post-process, fp16 generator with fp32 style modulation (precision
+    mode 3: fp16 MFMA operands, fp32 accumulate / instance-norm statistics / StyleMod), one GPU per batch.  The correspondence
+    recipe does not exist at 1024^2 in the reference (its matching assumes 64 x 64 feature maps), so a
+    swap here is the reference's plain command sequence: encode(content) -> sp, encode(style) -> gl, decode(sp, gl,
+    target=content) = G + GIFSmoothing(r = 30, eps = (0.02 * 255)^2) (models/ppst_model.py:288-306, photo_gif.py:25-46).
+    One step = one batch of pairs; nothing is cached (both encode commands run E1 and E2 like the reference's)."""
+    from ppst_amd import glue, ops, weights as W
+    from ppst_amd.ppst_model import create_model
+    B, S = args.batch, 1024
+    sd = W.make_state_dict(0, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
+    model = create_model(state_dict=sd, device=dev)
+    model.noise = {k: v.to(dev) for k, v in W.make_noise(2 + rank, 1, S=S // 8).items()}     # one fixed row for every batch row
+    imgs = W.synthetic_images(4 + rank, 2, size=S)
+    content = imgs[0:1].expand(B, -1, -1, -1).contiguous().to(dev)
+    style = imgs[1:2].expand(B, -1, -1, -1).contiguous().to(dev)
+
+    def step():
+        sp, _ = model(content, command="encode")
+        _, gl = model(style, command="encode")
+        return model(sp, gl, target=content, command="decode")
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+        barrier()
+        ops.prof_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        detail = ops.prof_detail()
+        conv_ms, conv_launches, conv_flop = ops.prof_collect()
+        ops.prof_enable(False)
+        assert torch.isfinite(out).all()
+        # the guided filter alone, HIP events on the launch stream (= torch's current stream): uint8 guide + uint8 source in,
+        # float image out of the command; algorithmic minimum 9 bytes per pixel with uint8 I/O (SURVEY.md section 8d)
+        sp, _ = model(content, command="encode")
+        _, gl = model(style, command="encode")
+        raw = model(sp, gl, target=None, command="decode")
+        gu, su = glue.tensor2im(content), glue.tensor2im(raw)
+        for _ in range(2):
+            ops.guided_filter(gu, su, 30, (0.02 * 255) ** 2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 5
+        e0.record()
+        for _ in range(n):
+            ops.guided_filter(gu, su, 30, (0.02 * 255) ** 2)
+        e1.record()
+        torch.cuda.synchronize()
+        gf_ms = e0.elapsed_time(e1) / n
+    passes = {"bf16x3": 3, "fp16x2": 2}.get(args.precision, 1)
+    achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    peak = PEAK_BF16_DENSE_TF / passes
+    gf_bytes = 9.0 * S * S * B
+    swaps = world * B * args.steps
+    return {"metric": "1024x1024 swaps/sec (encode + decode + guided filter)", "value": swaps / dt, "unit": "swaps/s (all GPUs)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NOTE[args.precision], "data": "synthetic",
+            "config": {"workload": "1024x1024 swap + guided-filter post-process, batch %d per GPU (BASELINE configs[4]): encode(content), "
+                                   "encode(style), decode(sp, gl, target=content)" % B,
+                       "precision": "conv operands %s; accumulation, instance-norm statistics and StyleMod fp32" % args.precision},
+            "roofline": {"kernel": "ppst_conv2d_mfma launches of the step (E1, E2, G at 1024^2)", "bound": "mfma", "achieved": achieved,
+                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "peak_note": "bf16 / fp16 dense MFMA 2500 TF / %d MFMA passes per algorithmic MAC" % passes,
+                         "launches": conv_launches, "kernel_ms_total": conv_ms, "share_of_step_time": conv_ms * 1e-3 / dt, "traffic": None},
+            "roofline_guided_filter": {"kernel": "gf_* (guided_filter.hip): 33 box-filtered planes, r = 30, colour guide", "bound": "hbm",
+                                       "achieved": gf_bytes / (gf_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": gf_bytes / (gf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_batch": gf_ms,
+                                       "bytes_note": "algorithmic minimum 9 B / pixel (uint8 guide + source in, uint8 out); the kernels keep "
+                                                     "33 fp32 planes of intermediates between their passes",
+                                       "share_of_step_time": gf_ms * args.steps * 1e-3 / dt, "traffic": None}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,9 +344,10 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp16", "fp16x2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="swap", choices=["swap", "grid", "train"],
+    ap.add_argument("--workload", default="swap", choices=["swap", "grid", "train", "hires"],
                     help="swap: BASELINE configs[1] (the headline line); grid: configs[2], 8x8 folder at 512 with the guided filter, "
-                         "images and pairs sharded over the ranks; train: configs[3], one D (+ lazy R1) and one G iteration per step")
+                         "images and pairs sharded over the ranks; train: configs[3], one D (+ lazy R1) and one G iteration per step; "
+                         "hires: configs[4], 1024x1024 encode / decode + guided filter (use --precision fp16)")
     ap.add_argument("--conv-variant", type=int, default=None, help="2 (default): N-256 / 128x64-wave-tile kernel where eligible; 0: the 64x64-wave-tile kernel everywhere; 1: one-wave-per-SIMD experiment")
     args = ap.parse_args()
 
@@ -307,7 +382,7 @@ def main():
         return float(t.item())
 
     if args.workload != "swap":
-        res = (bench_grid if args.workload == "grid" else bench_train)(args, rank, world, dev, barrier, max_over_ranks)
+        res = {"grid": bench_grid, "train": bench_train, "hires": bench_hires}[args.workload](args, rank, world, dev, barrier, max_over_ranks)
         if rank == 0:
             print(json.dumps(res))
         if dist is not None:
