@@ -158,9 +158,37 @@ def cpu_baseline(seed):
             times.append(time.time() - t0)
             print("[bench] cpu_baseline run %d: %.1f s on %d threads" % (len(times), times[-1], torch.get_num_threads()), file=sys.stderr, flush=True)
     dt = sorted(times)[1]
+    model, phys = host_cpu()
     return {"value": 1.0 / dt, "unit": "swaps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": model, "physical_cores_host": phys, "cores_available_to_process": nproc, "torch_threads": torch.get_num_threads(),
+            "gflops": FLOP_PER_SWAP / dt / 1e9,
             "sample": "1 warm-up (256x256 encode/decode) + 3 timed runs of 1 pair (batch 1) of the same 512x512 recipe, fp32, "
-                      "median %.1f s (runs: %s)" % (dt, ", ".join("%.1f" % t for t in times))}
+                      "median %.1f s (runs: %s); a batch-8 run costs the same per pair on the host (the oracle's convs are already "
+                      "threaded over pixels), so the batch-1 rate is the bounded sample of BASELINE.md section 4's B = 8 leg"
+                      % (dt, ", ".join("%.1f" % t for t in times))}
+
+
+def host_cpu():
+    """(model name, physical core count of the host) from /proc/cpuinfo -- BASELINE.md section 4 asks for both."""
+    try:
+        model, cores = None, set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None and core is not None:
+                cores.add((phys, core)); phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+        return model, (len(cores) or None)
+    except OSError:
+        return None, None
 
 
 DTYPE_NOTE = {"bf16x3": "bf16x3 (fp32 split into hi+lo bf16, 3 MFMA passes, fp32 accumulate)",

@@ -223,6 +223,9 @@ typedef struct ppst_conv_args {
 } ppst_conv_args;
 
 int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream);
+/* 1 when the library was built with PPST_EXPERIMENTS=1: the measured-and-off forms (variants 1 / 3 / 7 / 8 / 9, precision 4,
+ * tile_rows 8) are then compiled in; the production build returns PPST_EINVAL for them. */
+int ppst_has_experiments(void);
 /* Exact-fp32 twin of ppst_conv2d_mfma (v_mfma_f32_32x32x2_f32; a->wpack, bn, precision, a_slots, early_a are ignored):
  * same step table / padding / epilogue semantics, weights read from the fp32 tensor itself -- element (n, c, ky, kx) at
  * w[n*sn + c*sc + ky*sy + kx*sx], step s of group g uses w[n][src_c .. src_c+31][src_ky][src_kx] * wscale (src_c < 0:

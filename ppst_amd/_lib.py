@@ -69,6 +69,7 @@ _SIGS = {
     "ppst_conv_pack_batch": (i32, [vp, i32, i32, vp]),
     "ppst_upscale_weight_batch": (i32, [vp, i32, i32, vp]),
     "ppst_conv2d_mfma": (i32, [ctypes.POINTER(ConvArgs), vp]),
+    "ppst_has_experiments": (i32, []),
     "ppst_conv2d_f32": (i32, [ctypes.POINTER(ConvArgs), vp, i64, i64, i64, i64, f32, vp, vp, vp, vp]),
     "ppst_conv_tiles": (i32, [i32, i32, i32]),
     "ppst_conv1x1_small_cin": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp]),

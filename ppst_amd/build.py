@@ -13,9 +13,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libppst_hip.so")
-SOURCES = ["upfirdn2d.hip", "fused_bias_act.hip", "elementwise.hip", "linear.hip", "conv_mfma.hip", "conv_mfma2.hip", "conv1x1.hip", "conv_ksplit.hip", "conv_f32.hip",
-           "corr.hip", "guided_filter.hip", "train.hip", "train_g.hip", "imageio.hip", "smooth_filter.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+# PPST_EXPERIMENTS=1: also compile the measured-and-off conv forms (conv_ksplit.hip, conv_mfma2.hip variants 1 / 3 / 7 / 9, the
+# two-pass fp16 mode, the 8-row two-block tile): tuning builds only -- the production library carries what runs.
+EXPERIMENTS = os.environ.get("PPST_EXPERIMENTS") == "1"
+SOURCES = ["upfirdn2d.hip", "fused_bias_act.hip", "elementwise.hip", "linear.hip", "conv_mfma.hip", "conv_mfma2.hip", "conv1x1.hip", "conv_f32.hip",
+           "corr.hip", "guided_filter.hip", "train.hip", "train_g.hip", "imageio.hip", "smooth_filter.hip"] + (["conv_ksplit.hip"] if EXPERIMENTS else [])
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"] + (["-DPPST_EXPERIMENTS"] if EXPERIMENTS else [])
+MODE_STAMP = os.path.join(HERE, ".libmode")       # flavour of the built library (git-ignored, travels with the .so)
 
 
 def _hipcc():
@@ -32,14 +36,26 @@ def _stale(target, deps):
     return not os.path.exists(target) or any(os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
 
 
+def _mode():
+    return "experiments" if EXPERIMENTS else "production"
+
+
+def _mode_changed():
+    try:
+        return open(MODE_STAMP).read().strip() != _mode()
+    except OSError:
+        return os.path.exists(LIB)            # a library of unknown flavour
+
+
 def needs_build():
-    return _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
+    return _mode_changed() or _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     os.makedirs(OBJ, exist_ok=True)
+    force = force or _mode_changed()              # objects of the other flavour are not reused
     hipcc = _hipcc()
 
     def cc(src):
@@ -60,8 +76,10 @@ def build(force=False, verbose=True):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stderr)
+    with open(MODE_STAMP, "w") as f:
+        f.write(_mode() + "\n")
     if verbose:
-        print("built", LIB)
+        print("built", LIB, "(%s)" % _mode())
     return LIB
 
 

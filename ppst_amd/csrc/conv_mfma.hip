@@ -847,7 +847,18 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
 int ppst_conv1x1_stream_launch(const ppst_conv_args* a, int n_tiles, int tiles, hipStream_t st);                     // conv1x1.hip
 int ppst_conv_direct_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int tiles_x, hipStream_t st);         // conv1x1.hip
 int ppst_conv3x3_direct_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int tiles_x, hipStream_t st);      // conv1x1.hip
+#ifdef PPST_EXPERIMENTS
 int ppst_conv_ksplit_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int tiles_x, hipStream_t st);         // conv_ksplit.hip
+#endif
+// The measured-and-off kernel forms (variants 1 / 3 / 7 / 8 / 9, the two-pass fp16 mode, the 8-row two-block tile) are compiled
+// only into a PPST_EXPERIMENTS=1 build (python -m ppst_amd.build with that variable set); the production library rejects them.
+extern "C" int ppst_has_experiments(void) {
+#ifdef PPST_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 extern "C" int ppst_conv_tiles(int tile_h, int tile_w, int tile_rows) { return cdiv(tile_h, tile_rows) * cdiv(tile_w, 16); }
 
@@ -886,6 +897,10 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       (a->tile_rows != 16 && !(a->variant == 7 && a->tile_rows == 32) && !(a->variant == 9 && a->tile_rows == 24) &&
        !(a->variant == 0 && a->tile_rows == 8 && a->bn == 128 && a->halo == 1 && a->early_a && a->precision == 0)) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
     return PPST_EINVAL;
+#ifndef PPST_EXPERIMENTS
+  if (a->variant == 1 || a->variant == 3 || a->variant == 7 || a->variant == 8 || a->variant == 9 || a->precision == 4 || a->tile_rows == 8)
+    return PPST_EINVAL;          // experiment forms: not in this build
+#endif
   // the epilogues address one image with 32-bit element offsets
   // (+ one tile row of slack: lanes beyond the image edge form their offset too, and only then mask the access)
   {
@@ -931,28 +946,39 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
     int e2 = a->variant == 4   ? ppst_conv1x1_stream_launch(a, k.n_tiles, k.tiles_y * k.tiles_x, st)
              : a->variant == 5 ? ppst_conv_direct_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st)
              : a->variant == 6 ? ppst_conv3x3_direct_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st)
+#ifdef PPST_EXPERIMENTS
              : a->variant == 8 ? ppst_conv_ksplit_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st)
+#endif
                                : ppst_conv2d_mfma2_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st);
     if (slot >= 0) (void)hipEventRecord(g_ev[slot][1], st);
     return e2;
   }
   const bool x3 = a->precision == 0;
   const bool f16 = a->precision == 3, x2 = a->precision == 4;
+#ifdef PPST_EXPERIMENTS
+#define X2_LAUNCH(WM_, WN_, H_) launch_conv<WM_, WN_, H_, false, 0, true, true>(k, blocks, st)
+#else
+#define X2_LAUNCH(WM_, WN_, H_) (void)0      /* precision 4 was rejected above */
+#endif
 #define DISPATCH(WM_, WN_)                                                                                         \
   do {                                                                                                             \
-    if (a->halo) { if (x3) launch_conv<WM_, WN_, 1, true>(k, blocks, st); else if (x2) launch_conv<WM_, WN_, 1, false, 0, true, true>(k, blocks, st); else if (f16) launch_conv<WM_, WN_, 1, false, 0, true>(k, blocks, st); else launch_conv<WM_, WN_, 1, false>(k, blocks, st); } \
-    else         { if (x3) launch_conv<WM_, WN_, 0, true>(k, blocks, st); else if (x2) launch_conv<WM_, WN_, 0, false, 0, true, true>(k, blocks, st); else if (f16) launch_conv<WM_, WN_, 0, false, 0, true>(k, blocks, st); else launch_conv<WM_, WN_, 0, false>(k, blocks, st); } \
+    if (a->halo) { if (x3) launch_conv<WM_, WN_, 1, true>(k, blocks, st); else if (x2) X2_LAUNCH(WM_, WN_, 1); else if (f16) launch_conv<WM_, WN_, 1, false, 0, true>(k, blocks, st); else launch_conv<WM_, WN_, 1, false>(k, blocks, st); } \
+    else         { if (x3) launch_conv<WM_, WN_, 0, true>(k, blocks, st); else if (x2) X2_LAUNCH(WM_, WN_, 0); else if (f16) launch_conv<WM_, WN_, 0, false, 0, true>(k, blocks, st); else launch_conv<WM_, WN_, 0, false>(k, blocks, st); } \
   } while (0)
   // (round 1 measured 8-row tiles -- two 80-KB blocks per CU -- 35 % slower: only one block was ever resident.  Round 3
   //  re-instantiates them at 77 KB with the two-slot ring of the early_a tables: see ops.TWO_BLOCK_8ROW.)
   // small-K layers on the 64-channel tile: a shallower activation ring (59 / 48 / 80 KB of LDS instead of
   // 145 / 112) puts two blocks on a CU, so one block's loads and stores overlap the other's MFMAs
+#ifdef PPST_EXPERIMENTS
   if (a->tile_rows == 8) launch_conv<2, 2, 1, true, 2>(k, blocks, st);
-  else if (a->bn == 64 && x3 && a->halo == 1 && a->a_slots == 1) launch_conv<4, 1, 1, true, 1>(k, blocks, st);
+  else
+#endif
+  if (a->bn == 64 && x3 && a->halo == 1 && a->a_slots == 1) launch_conv<4, 1, 1, true, 1>(k, blocks, st);
   else if (a->bn == 64 && x3 && a->halo == 0 && a->a_slots == 1) launch_conv<4, 1, 0, true, 1>(k, blocks, st);
   else if (a->bn == 64 && x3 && a->halo == 0 && a->a_slots == 2) launch_conv<4, 1, 0, true, 2>(k, blocks, st);
   else if (a->bn == 128) DISPATCH(4, 2); else DISPATCH(4, 1);
 #undef DISPATCH
+#undef X2_LAUNCH
   int e = PPST_LAUNCH_CHECK();
   if (slot >= 0) (void)hipEventRecord(g_ev[slot][1], st);
   return e;

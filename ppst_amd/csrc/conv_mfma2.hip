@@ -570,16 +570,21 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
   } while (0)
   if (a->variant == 2 && a->precision == 1) { if (a->halo) L2P(1, 1); else L2P(0, 1); }
   else if (a->variant == 2 && a->precision == 3) { if (a->halo) L2P(1, 3); else L2P(0, 3); }
+  else if (a->variant == 2) {            // 8 waves, wave tile 128 px x 64 ch, N tile 256: the production form
+    if (a->halo) L2(4, 1, 4, false, 2); else L2(4, 0, 4, false, 2);
+  }
+#ifdef PPST_EXPERIMENTS                  // measured and off: only in a PPST_EXPERIMENTS=1 build
   else if (a->variant == 9) {                 // 8 waves = 4 (M) x 2 (N), wave tile 96 px x 64 ch, block 24 x 16 px x 128 ch, two slots
     if (a->halo) L9(1); else L9(0);
   } else if (a->variant == 7) {                 // 8 waves = 4 (M) x 2 (N), wave tile 128 px x 64 ch, block 32 x 16 px x 128 ch, one slot
     if (a->halo) L7(1); else L7(0);
-  } else if (a->variant == 2) {          // 8 waves, wave tile 128 px x 64 ch, N tile 256
-    if (a->halo) L2(4, 1, 4, false, 2); else L2(4, 0, 4, false, 2);
   } else if (a->variant == 3) {          // two 4-wave blocks per CU, wave tile 128 px x 64 ch, N tile 128, one activation slot
     if (a->halo) L2(4, 1, 2, false, 1); else L2(4, 0, 2, false, 1);
   } else if (a->bn == 256) { if (a->halo) L2(8, 1, 2, true, 2); else L2(8, 0, 2, true, 2); }
   else { if (a->halo) L2(4, 1, 2, true, 2); else L2(4, 0, 2, true, 2); }
+#else
+  else return PPST_EINVAL;
+#endif
 #undef L2
   return PPST_LAUNCH_CHECK();
 }

@@ -50,11 +50,22 @@ TWO_BLOCK_8ROW = {"value": False, "min_blocks": 64}
 FAT_MIN_BLOCKS = 32         # take the 256-channel tile only when ONE image still gives >= this many blocks (B = 8: one per CU)
 
 
+# the measured-and-off conv forms exist only in a PPST_EXPERIMENTS=1 build of the library (ppst_amd/build.py)
+EXPERIMENTS = bool(lib.ppst_has_experiments())
+
+
+def _need_experiments(what):
+    if not EXPERIMENTS:
+        raise RuntimeError("%s is an experiment kernel: rebuild the library with PPST_EXPERIMENTS=1 (python -m ppst_amd.build)" % what)
+
+
 def set_precision(p):
     """0: bf16x3 (fp32-class, the measured path); 1: single-pass bf16; 2: exact fp32 MFMA (verification only, slow);
     3: single-pass fp16 (the "fp16 generator" of BASELINE configs[4]; fp32 accumulate / statistics / StyleMod);
     4: two-pass fp16 (activation hi + lo, weight rounded once to fp16): a measured experiment, 2/3 of the MFMAs of mode 0."""
     assert p in (0, 1, 2, 3, 4)
+    if p == 4:
+        _need_experiments("precision 4 (two-pass fp16)")
     PRECISION["value"] = p
 
 
@@ -428,6 +439,8 @@ class ConvPlan:
             return variant, bn, rows                     # fp16x2 experiment / exact-fp32 verification: the tile kernel only
         tiles16 = ((th + 15) // 16) * ((tw + 15) // 16) * self.n_groups          # blocks PER IMAGE per N tile
         cv = CONV_VARIANT["value"]
+        if cv in (1, 3) or TWO_BLOCK_128["value"] or TWO_BLOCK_8ROW["value"] or KSPLIT_128["value"] or TILE24_128["value"] or TALL_TILE_128["value"]:
+            _need_experiments("the requested conv variant")
         n256_ok = self.cout % 256 == 0 and tiles16 * (self.cout // 256) >= FAT_MIN_BLOCKS
         if cv == 1 and not single and self.early_a and self.cout >= 128:
             variant, bn = 1, (256 if n256_ok else 128)
