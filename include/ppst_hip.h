@@ -391,6 +391,14 @@ int ppst_conv_wgrad_f32(const void* x, const void* dy, const void* steps, const 
 int ppst_conv_wgrad_bf16x3(const void* x, const void* dy, const void* steps, const void* chunk_start,
                            void* partial, int B, int in_h, int in_w, int in_ld, int oh, int ow,
                            int dy_ld, int cout, int nsteps, int nchunks, int splits, void* stream);
+/* the production form of round 3 (same arithmetic: bf16 hi / lo split, three MFMA passes, fp32 accumulation): raw fp32 tiles by
+ * LDS-DMA one tile ahead, one conversion pass per tile, transposed LDS reads (ds_read_b64_tr_b16) for the MFMA operands.
+ * ``splits`` must be even: the grid covers splits / 2 pixel ranges and every block writes two partial slots.  ``csum`` (NULL or
+ * [splits / 2][cout]): partial fp32 column sums of dy, fused into the conversion pass -- summed over the rows (ppst_colsum) they
+ * are the bias gradient. */
+int ppst_conv_wgrad_tr(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial, void* csum,
+                       int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps, int nchunks,
+                       int splits, void* stream);
 /* dw[n*sn + (src_c+k)*sc + ky*sy + kx*sx] (+)= scale * sum_splits partial[.][step][n][k] */
 int ppst_wgrad_scatter(const void* partial, const void* src_c, const void* src_ky, const void* src_kx,
                        void* dw, int64_t sn, int64_t sc, int64_t sy, int64_t sx, int cout, int nsteps,
@@ -494,7 +502,7 @@ int ppst_prof_dropped(void);
 /* after a stream sync: total ms, launches, algorithmic flop of bracketed calls */
 int ppst_prof_collect(double* ms, int64_t* launches, double* flop);
 /* per-launch detail of bracketed call idx (before ppst_prof_collect resets the pool):
- * info = {B, tile_h, tile_w, nsteps, cout, n_groups, halo, bn}; a ppst_conv_wgrad_bf16x3 launch is bracketed too, with
+ * info = {B, tile_h, tile_w, nsteps, cout, n_groups, halo, bn}; a ppst_conv_wgrad_bf16x3 / ppst_conv_wgrad_tr launch is bracketed too, with
  * info = {B, oh, ow, nsteps, cout, nchunks, splits, 0} (bn = 0 marks it) */
 int ppst_prof_detail(int idx, double* ms, double* flop, int32_t* info);
 /* profiling only: number of steps of the NEXT weight-gradient launch that carry real weights (default: all of them) */

@@ -59,26 +59,32 @@ def _noted(p):
         cb()
 
 
-def _conv_grads(net, wname, kind, scale, pad_mode, x, gpre, need_x, need_w, out_hw=None, dw_out=None):
-    """(dx, dw) of a stride-1 'conv' plan given the gradient at its raw output (``dw_out``: add dw into this view)."""
+def _conv_grads(net, wname, kind, scale, pad_mode, x, gpre, need_x, need_w, out_hw=None, dw_out=None, want_bias=False, bias_out=None):
+    """(dx, dw, db) of a stride-1 'conv' plan given the gradient at its raw output (``dw_out``: add dw into this view;
+    ``want_bias``: the column sums of gpre come out of the weight-gradient kernel's own staging pass, into ``bias_out`` if given)."""
     plan = net.plan(wname, kind, scale)
     k = plan.k
-    dx = dw = None
+    dx = dw = db = None
     acc = dw_out is not None
+    bkw = dict(want_bias=True, bias_out=bias_out, bias_accumulate=bias_out is not None) if (want_bias and need_w) else {}
+
+    def wg(xx, gg):
+        r = ops.conv_wgrad(plan, xx, gg, out=dw_out, accumulate=acc, **bkw)
+        return r if bkw else (r, None)
     if pad_mode == Z or k == 1:
         if need_x:
             dx = net.plan(wname, "dgrad", scale)(gpre)
         if need_w:
-            dw = ops.conv_wgrad(plan, x, gpre, out=dw_out, accumulate=acc)
-        return dx, dw
+            dw, db = wg(x, gpre)
+        return dx, dw, db
     # reflection / replication padding: y = conv_valid(pad(x)).  On the padded canvas the same zero-padded kernels
     # are exact: the gradient canvas is zero on the border, so border outputs / out-of-canvas taps contribute nothing.
     gp = ops.pad2d(gpre, 1, 1, 1, 1, Z)
     if need_x:
         dx = ops.pad2d_bwd(net.plan(wname, "dgrad", scale)(gp), 1, 1, 1, 1, pad_mode)
     if need_w:
-        dw = ops.conv_wgrad(plan, ops.pad2d(x, 1, 1, 1, 1, pad_mode), gp, out=dw_out, accumulate=acc)
-    return dx, dw
+        dw, db = wg(ops.pad2d(x, 1, 1, 1, 1, pad_mode), gp)      # (the zero border of gp adds nothing to the column sums)
+    return dx, dw, db
 
 
 class ConvFn(Function):
@@ -110,25 +116,24 @@ class ConvFn(Function):
         gpre = lrelu_bwd(g, y) if act == LRELU else g
         C = gpre.shape[3]
         db = dnw = None
-        if bias_params is not None:           # one column sum, added to each of the summed biases' gradients in ONE launch
-            v = ops.colsum(gpre.view(-1, C))
-            torch._foreach_add_([_direct(q).view(-1) for q in bias_params], [v] * len(bias_params))
-            for q in bias_params:
-                _noted(q)
-        elif has_b and ctx.needs_input_grad[2]:
-            dst = _direct(bias)
-            db = ops.colsum(gpre.view(-1, C), out=dst, accumulate=dst is not None)
-            if dst is not None:
-                _noted(bias); db = None
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = bias_params is not None or (has_b and ctx.needs_input_grad[2])
+        # the bias gradient = column sums of gpre: from the weight-gradient kernel's staging pass when that kernel runs on gpre
+        # anyway (kind 'conv'; the transposed conv's weight gradient has gpre as its OTHER operand), else its own pass
+        fuse_b = need_b and need_w and kind == "conv"
+        bdst = _direct(bias) if (need_b and bias_params is None) else None
+        if need_b and not fuse_b:
+            v = ops.colsum(gpre.view(-1, C), out=bdst, accumulate=bdst is not None)
         if has_n and ctx.needs_input_grad[3]:
             dst = _direct(noise_w)
             dnw = ops.noise_wgrad(gpre, noise, out=dst, accumulate=dst is not None)
             if dst is not None:
                 _noted(noise_w); dnw = None
-        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dstw = _direct(w) if need_w else None
         if kind == "conv":
-            dx, dw = _conv_grads(net, wname, kind, scale, pad_mode, x, gpre, need_x, need_w, dw_out=dstw)
+            dx, dw, vb = _conv_grads(net, wname, kind, scale, pad_mode, x, gpre, need_x, need_w, dw_out=dstw, want_bias=fuse_b, bias_out=bdst)
+            if fuse_b:
+                v = vb
         else:  # convT: dX = stride-2 4x4 conv of dY (run over its space-to-depth copy); dW through the blurred 4x4 kernel
             gs = ops.space_to_depth(gpre)
             pl = net.plan(wname, "dgradT", scale)
@@ -139,6 +144,15 @@ class ConvFn(Function):
                 dw = ops.upscale_weight_bwd(dw4, pl.cin, pl.cout, pl.fwd_scale, out=dstw, accumulate=dstw is not None)
         if dstw is not None:
             _noted(w); dw = None
+        if need_b:
+            if bias_params is not None:       # one column sum, added to each of the summed biases' gradients in ONE launch
+                torch._foreach_add_([_direct(q).view(-1) for q in bias_params], [v] * len(bias_params))
+                for q in bias_params:
+                    _noted(q)
+            elif bdst is not None:
+                _noted(bias)
+            else:
+                db = v
         return dx, dw, db, dnw, None, None, None, None, None, None, None, None, None
 
 
@@ -174,16 +188,19 @@ class BlurConvFn(Function):
         C = gpre.shape[3]
         w, bias = ctx.refs
         db = dw = None
-        if has_b and ctx.needs_input_grad[2]:
-            dst = _direct(bias)
-            db = ops.colsum(gpre.view(-1, C), out=dst, accumulate=dst is not None)
-            if dst is not None:
-                _noted(bias); db = None
-        if ctx.needs_input_grad[1]:
+        need_b, need_w = has_b and ctx.needs_input_grad[2], ctx.needs_input_grad[1]
+        bdst = _direct(bias) if need_b else None
+        if need_w:
             dst = _direct(w)
-            dw = ops.conv_wgrad(net.plan(wname, "s2d", scale), xb, gpre, out=dst, accumulate=dst is not None)
+            r = ops.conv_wgrad(net.plan(wname, "s2d", scale), xb, gpre, out=dst, accumulate=dst is not None,
+                               want_bias=need_b, bias_out=bdst, bias_accumulate=bdst is not None)
+            dw, db = r if need_b else (r, None)        # the bias gradient rides on the weight-gradient kernel's staging pass
             if dst is not None:
                 _noted(w); dw = None
+        elif need_b:
+            db = ops.colsum(gpre.view(-1, C), out=bdst, accumulate=bdst is not None)
+        if need_b and bdst is not None:
+            _noted(bias); db = None
         dx = None
         if ctx.needs_input_grad[0]:
             d_xb = net.plan(wname, "dgrad_s2d", scale)(gpre, out_hw=bhw)

@@ -310,6 +310,227 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 3: the bf16x3 weight gradient without exposed memory latency.  rocprofv3 + ISA of conv_wgrad_x3_kernel: its staging
+// loops were not unrolled (256 registers, 144 of them accumulators), so a tile cost ~9 SERIALISED global round trips
+// (load 2 x 16 B -> s_waitcnt vmcnt(0) -> convert -> ds_write), 10-12 k cycles per tile against 3.5 k of MFMA work: 0.16 of the
+// bf16x3 ceiling over the step.  This kernel:
+//   * raw fp32 tiles (dY 64 px x 128 n, input halo 4 x 34 px x 32 ch) arrive by LDS-DMA (global_load_lds_dwordx4: no registers,
+//     out-of-image / out-of-range lanes read a 16-byte zero word), requested one tile AHEAD, under the MFMA phase;
+//   * ONE conversion pass per tile (all 512 threads): fp32 -> bf16 hi / lo into plain [pixel][channel] images -- and, in the
+//     blocks of chunk 0, the fp32 column sums of dY (the bias gradient: the 304 colsum launches per train step re-read every dY
+//     the weight gradient had just read);
+//   * MFMA operands by ds_read_b64_tr_b16 (the K index of this GEMM is the PIXEL; the transposed read turns 4 pixel rows x 16
+//     channels into 4 k-values per lane): no pixel-pair packing, ONE input image for all nine taps, half the LDS cycles;
+//   * 8 waves = 4 (n slabs of 32) x 2 (tile rows): the two row groups accumulate separate partial sums, written as two split
+//     slots -- the existing scatter kernel adds them like any other split.
+// LDS: two raw buffers (the DMA runs TWO tiles ahead: a 49-KB fill takes longer than one tile's MFMA phase when every CU asks
+// at once) + the converted images = 147 KB (one block per CU, two waves per SIMD).
+#define WT_PX (WG_TR * WG_TC)                 // 64 pixels of dY per tile
+#define WT_XW (WG_TC + 2)
+#define WT_XPX ((WG_TR + 2) * WT_XW)          // 136 halo pixels of the input chunk
+__device__ __attribute__((aligned(16))) float g_wg_zero[4] = {0.f, 0.f, 0.f, 0.f};
+typedef short __attribute__((ext_vector_type(4))) wt_v4s;
+__device__ __forceinline__ bf16x8 wt_tr2(const unsigned char* p0) {
+  // two transposed reads, 4 pixel rows (64-B rows) apart: k = 0..3 and 4..7 of this lane's channel
+  const wt_v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wt_v4s __attribute__((address_space(3)))*)(p0));
+  const wt_v4s b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wt_v4s __attribute__((address_space(3)))*)(p0 + 4 * 64));
+  return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+__global__ __launch_bounds__(512, 1) void conv_wgrad_tr_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const int4* __restrict__ steps, const int* __restrict__ chunk_start,
+                                                             float* __restrict__ partial, float* __restrict__ csum, int B, int in_h,
+                                                             int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
+                                                             int tiles_x, int tiles_per_image, int tiles_total, int tiles_per_split, int abl) {
+  // abl (timing ablations, results WRONG, tests/wgrad_tr_check.py only): 1 no MFMA phase, 2 no conversion pass, 4 no DMA after the prologue
+  constexpr int RAW_DY = WT_PX * 128 * 4, RAW_X = WT_XPX * 32 * 4;          // 32768 + 17408 bytes
+  constexpr int CV_DY = WT_PX * 128 * 2, CV_X = WT_XPX * 32 * 2;            // per plane: 16384, 8704 bytes
+  constexpr int RAW = RAW_DY + RAW_X;                                         // 49 pieces of 1 KB
+  static_assert(RAW_X == 17 * 1024, "input halo = 17 DMA pieces");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * RAW + 2 * CV_DY + 2 * CV_X];
+  unsigned char* const cvdy = smem + 2 * RAW;                 // [hi | lo][slab 0..3][64 px][32 ch] bf16
+  unsigned char* const cvx = cvdy + 2 * CV_DY;                // [hi | lo][136 px][32 ch] bf16
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = wave & 3, kh = wave >> 2;                     // n slab (32 channels), tile row this wave reduces over
+  const int li = lane & 31, kb = lane >> 5;
+  // XCD-aware block map.  Blocks go to the 8 XCDs round-robin by linear id, and the blocks that share a tile of dY (all chunks
+  // y of one pixel range z) or of the input (all n tiles x) had consecutive ids: every XCD's L2 fetched those tiles from HBM
+  // itself (the three 3x3 layers of the generator each moved 1.34 GB per launch instead of 0.54).  The bijective 8-way remap
+  // gives each XCD a contiguous range of the (z, y, x) order -- x fastest -- so co-resident blocks of one XCD walk the same tiles.
+  int bx, by, bz;
+  {
+    const int nb = gridDim.x * gridDim.y * gridDim.z;
+    const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int q8 = nb >> 3, r8 = nb & 7, xcd = id & 7;
+    int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+    bx = v % (int)gridDim.x; v /= (int)gridDim.x;
+    by = v % (int)gridDim.y; bz = v / (int)gridDim.y;
+  }
+  const int n0 = bx * 128;
+  const int s0 = chunk_start[by], s1 = chunk_start[by + 1];
+  const int T = s1 - s0;
+  const int chan = steps[s0].x;
+  int tdy[WG_MAXT], tdx[WG_MAXT];
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t) {
+    int4 d = steps[s0 + (t < T ? t : 0)];
+    tdy[t] = d.y; tdx[t] = d.z;
+  }
+  f32x16 acc[WG_MAXT];
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  const int t_begin = bz * tiles_per_split;
+  const int t_end = min(t_begin + tiles_per_split, tiles_total);
+  const bool wave_live = n0 + nw * 32 < cout;
+  const bool want_csum = csum != nullptr && by == 0;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);               // this thread's 4 channels (tid & 31), its pixels of every tile
+
+  // ---- LDS-DMA of one tile's raw fp32 data: 32 pieces of dY (2 pixels x 512 B each) + 17 of the input (8 pixels x 128 B)
+  // one piece (wave-uniform index wi) of a tile's raw data
+  auto dma_piece = [&](int tile, int slot, int wi) {
+    unsigned char* const rawdy = smem + slot * RAW;
+    unsigned char* const rawx = rawdy + RAW_DY;
+    const int b = tile / tiles_per_image;
+    const int r = tile - b * tiles_per_image;
+    const int ty0 = (r / tiles_x) * WG_TR, tx0 = (r - (r / tiles_x) * tiles_x) * WG_TC;
+    {
+      const float* src = g_wg_zero;
+      unsigned char* dst;
+      if (wi < 32) {
+        const int p = 2 * wi + (lane >> 5), q = lane & 31;
+        const int y = ty0 + (p >> 5), xx = tx0 + (p & 31), n = n0 + q * 4;
+        if (y < oh && xx < ow && n < cout) src = dy + (((int64_t)b * oh + y) * ow + xx) * dy_ld + n;
+        dst = rawdy + wi * 1024;
+      } else {
+        const int P = 8 * (wi - 32) + (lane >> 3), q = lane & 7;
+        const int row = P / WT_XW, col = P - row * WT_XW;
+        const int iy = ty0 - 1 + row, ix = tx0 - 1 + col;
+        if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) src = x + (((int64_t)b * in_h + iy) * in_w + ix) * in_ld + chan + q * 4;
+        dst = rawx + (wi - 32) * 1024;
+      }
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+    }
+  };
+  auto dma_tile = [&](int tile, int slot) {
+    for (int wi = wave; wi < 32 + 17; wi += 8) dma_piece(tile, slot, wi);
+  };
+  auto split4 = [](float4 v, uint2& hi, uint2& lo) {
+    unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
+    split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
+    hi = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
+    lo = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+  };
+  // transposed-read lane geometry: group g = lane / 16 reads 4 pixel rows x 16 channels; lane 4q + p of the group supplies the
+  // address of row q, channels 4p .. 4p+3; lane i receives channel i of the 4 rows.  Groups 0 / 1: channels 0-15 / 16-31 of
+  // k-half 0, groups 2 / 3 the same of k-half 1 -- i.e. channel li, k-half kb, as the 32x32x16 operand wants.
+  const int g = lane >> 4, qd = (lane & 15) >> 2, pp = lane & 3;
+  const int tr_off = (8 * (g >> 1) + qd) * 64 + (16 * (g & 1) + 4 * pp) * 2;      // bytes, relative to the operand's first pixel
+
+  if (t_begin < t_end) dma_tile(t_begin, 0);
+  if (t_begin + 1 < t_end) dma_tile(t_begin + 1, 1);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int slot = (tile - t_begin) & 1;
+    const unsigned char* const rawdy = smem + slot * RAW;
+    const unsigned char* const rawx = rawdy + RAW_DY;
+    // this tile's raw data have landed (hipcc adds no wait for LDS-DMA); the NEXT tile's pieces -- younger, 7 from wave 0 and
+    // 6 from the others -- may stay in flight: vmcnt retires in issue order
+    if (tile + 1 < t_end && !(abl & 4)) {
+      if (wave == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                                        // ... for every wave; and the previous tile's MFMA reads are done
+    // ---- conversion pass: raw fp32 -> bf16 hi / lo images
+    if (!(abl & 2)) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i = tid + it * 512;
+      const int q = i & 31, p = i >> 5;
+      const float4 v = *(const float4*)(rawdy + (p * 128 + q * 4) * 4);
+      if (want_csum) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
+      uint2 hi, lo;
+      split4(v, hi, lo);
+      unsigned char* o = cvdy + (q >> 3) * 4096 + p * 64 + (q & 7) * 8;
+      *(uint2*)o = hi;
+      *(uint2*)(o + CV_DY) = lo;
+    }
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int i = tid + it * 512;
+      if (i < WT_XPX * 8) {
+        const float4 v = *(const float4*)(rawx + i * 16);
+        uint2 hi, lo;
+        split4(v, hi, lo);
+        *(uint2*)(cvx + i * 8) = hi;
+        *(uint2*)(cvx + CV_X + i * 8) = lo;
+      }
+    }
+    }
+    __syncthreads();                                        // images complete; this raw slot is free again
+    // The raw data of tile + 2 go into the slot just converted, requested in one burst in front of the MFMA phase.  (Measured:
+    // handing the 6-7 pieces of a wave out between the taps of the MFMA loop instead is 30 % SLOWER, 0.68 -> 0.89 ms on
+    // 128->128 @512^2 -- an in-order wave that waits at the issue of a request does not issue its MFMAs either.  Timing
+    // ablations of that layer, ms: barriers only 0.08, + DMA 0.29, + conversion 0.19, + MFMA 0.39, everything 0.68-0.75: the
+    // three phases of a tile add up; 49 KB per tile and CU move at 7.5 TB/s chip-wide, as long as the tile's MFMA work.)
+    if (tile + 2 < t_end && !(abl & 4)) dma_tile(tile + 2, slot);
+    if (wave_live && !(abl & 1)) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {                       // the two 16-pixel halves of this wave's tile row
+        const int xh = kk * 16;
+        const unsigned char* pa = cvdy + nw * 4096 + (kh * 32 + xh) * 64 + tr_off;
+        const bf16x8 a_h = wt_tr2(pa), a_l = wt_tr2(pa + CV_DY);
+        // software pipeline over the taps: the fragments of tap t + 1 are requested before the MFMAs of tap t
+        const unsigned char* pb0 = cvx + ((kh + 1 + tdy[0]) * WT_XW + xh + 1 + tdx[0]) * 64 + tr_off;
+        bf16x8 b_h = wt_tr2(pb0), b_l = wt_tr2(pb0 + CV_X);
+#pragma unroll
+        for (int t = 0; t < WG_MAXT; ++t) {
+          if (t < T) {
+            bf16x8 n_h = b_h, n_l = b_l;
+            if (t + 1 < WG_MAXT && t + 1 < T) {
+              const unsigned char* pb = cvx + ((kh + 1 + tdy[t + 1]) * WT_XW + xh + 1 + tdx[t + 1]) * 64 + tr_off;
+              n_h = wt_tr2(pb); n_l = wt_tr2(pb + CV_X);
+            }
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b_h, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_l, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_h, acc[t], 0, 0, 0);
+            b_h = n_h; b_l = n_l;
+          }
+        }
+      }
+    }
+  }
+  // ---- column sums of dY (chunk-0 blocks): 16 threads share a channel quad -> one partial row per block
+  if (want_csum) {
+    __syncthreads();                                        // the images are dead: reuse the front of the raw buffer
+    float4* red = (float4*)smem;                            // [16][32] float4
+    red[(tid >> 5) * 32 + (tid & 31)] = cs;
+    __syncthreads();
+    if (tid < 32) {
+      float4 a = red[tid];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) { const float4 v = red[r * 32 + tid]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+      const int n = n0 + tid * 4;
+      float* o = csum + (int64_t)bz * cout + n;
+      if (n < cout) { o[0] = a.x; if (n + 1 < cout) o[1] = a.y; if (n + 2 < cout) o[2] = a.z; if (n + 3 < cout) o[3] = a.w; }
+    }
+  }
+  if (!wave_live) return;
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t) {
+    if (t < T) {
+      float* o = partial + ((((int64_t)bz * 2 + kh) * nsteps + s0 + t) * cout) * 32;
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        int nn = n0 + nw * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kb;
+        if (nn < cout) o[(int64_t)nn * 32 + li] = acc[t][rg];
+      }
+    }
+  }
+}
+
 // profiling brackets of conv_mfma.hip: a weight-gradient launch is recorded with info = {B, oh, ow, nsteps, cout, nchunks, splits, 0}
 // (bn = 0 marks it) and the algorithmic 2 * 32 * flop_steps * cout * B * oh * ow (flop_steps < nsteps where the table carries
 // zero-weight pad steps)
@@ -319,6 +540,8 @@ static int wgrad_prof_begin(int B, int oh, int ow, int cout, int nsteps, int flo
   const int inf[8] = {B, oh, ow, nsteps, cout, nchunks, splits, 0};
   return ppst_prof_begin_(2.0 * 32.0 * (flop_steps > 0 ? flop_steps : nsteps) * (double)cout * (double)B * oh * ow, inf, st);
 }
+static int g_wgrad_abl = 0;          // timing ablations of conv_wgrad_tr_kernel (diagnostic: results wrong while non-zero)
+extern "C" int ppst_wgrad_ablate(int mask) { g_wgrad_abl = mask; return PPST_OK; }
 static int g_wgrad_flop_steps = 0;   // set by ppst_wgrad_flop_steps for the NEXT weight-gradient launch (profiling only)
 extern "C" int ppst_wgrad_flop_steps(int flop_steps) { g_wgrad_flop_steps = flop_steps; return PPST_OK; }
 
@@ -342,6 +565,31 @@ extern "C" int ppst_conv_wgrad_bf16x3(const void* x, const void* dy, const void*
   PPST_LAUNCH(conv_wgrad_x3_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (const int4*)steps,
               (const int*)chunk_start, (float*)partial, B, in_h, in_w, in_ld, oh, ow, dy_ld, cout, nsteps, tiles_x, tiles_per_image,
               tiles_total, tps);
+  ppst_prof_end_(slot, as_stream(stream));
+  return PPST_LAUNCH_CHECK();
+}
+
+// LDS-DMA + transposed-read form (conv_wgrad_tr_kernel).  ``splits`` (even) = partial slots: the grid has splits / 2 pixel ranges,
+// each block writes two slots (one per tile row).  ``csum`` (optional): [splits / 2][cout] partial column sums of dY, written by the
+// blocks of chunk 0 -- their column-wise sum is the bias gradient (ppst_colsum over those rows finishes it).
+extern "C" int ppst_conv_wgrad_tr(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial, void* csum,
+                                  int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
+                                  int nchunks, int splits, void* stream) {
+  if (B < 0 || in_h <= 0 || in_w <= 0 || in_ld <= 0 || oh <= 0 || ow <= 0 || dy_ld < cout || cout <= 0 || nsteps <= 0 ||
+      nchunks <= 0 || splits <= 0 || (splits & 1))
+    return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !dy || !steps || !chunk_start || !partial) return PPST_ENULL;
+  if (cout % 4 || dy_ld % 4 || in_ld % 4 || ((uintptr_t)x | (uintptr_t)dy) % 16) return PPST_EINVAL;
+  const int tiles_x = cdiv(ow, WG_TC), tiles_per_image = cdiv(oh, WG_TR) * tiles_x;
+  const int tiles_total = B * tiles_per_image;
+  const int tps = cdiv(tiles_total, splits / 2);
+  dim3 grid(cdiv(cout, 128), nchunks, splits / 2);
+  const int slot = wgrad_prof_begin(B, oh, ow, cout, nsteps, g_wgrad_flop_steps, nchunks, splits, as_stream(stream));
+  g_wgrad_flop_steps = 0;
+  PPST_LAUNCH(conv_wgrad_tr_kernel, grid, dim3(512), 0, as_stream(stream), (const float*)x, (const float*)dy, (const int4*)steps,
+              (const int*)chunk_start, (float*)partial, (float*)csum, B, in_h, in_w, in_ld, oh, ow, dy_ld, cout, nsteps, tiles_x,
+              tiles_per_image, tiles_total, tps, g_wgrad_abl);
   ppst_prof_end_(slot, as_stream(stream));
   return PPST_LAUNCH_CHECK();
 }

@@ -618,13 +618,20 @@ def _grad_out(out, shape, like):
     return out
 
 
-def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False):
+# the LDS-DMA / transposed-read weight-gradient kernel (round 3): one 8-wave block per CU -> ONE round of <= 256 blocks (every
+# further split is 2 x 147 KB of partial sums written and re-read by the scatter), >= min_tiles pixel tiles per block
+WGRAD_TR = {"value": True, "blocks": 256, "min_tiles": 8}
+
+
+def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=None, bias_accumulate=False, want_bias=False):
     """Weight gradient of the conv described by forward ``plan`` ('conv' or 's2d'):
     x = the tensor the forward conv read (NHWC, or the space-to-depth tensor for 's2d'),
     dy = gradient w.r.t. the conv output (before bias/activation).  Returns dW shaped
     (Cout, Cin, k, k), already multiplied by the plan's weight scale (EqualConv2d).
     ``out`` / ``accumulate``: write (or add) into a given destination -- the reduction over the pixel splits adds straight
-    into the flat gradient buffer, so no separate accumulation pass (and no zero fill) runs."""
+    into the flat gradient buffer, so no separate accumulation pass (and no zero fill) runs.
+    ``want_bias`` / ``bias_out``: also the column sums of dy (the bias gradient), from the fp32 values the weight-gradient kernel
+    stages anyway (no second pass over dy): returns (dW, db)."""
     assert plan.kind in ("conv", "s2d", "dgradT")
     in_ld = _nhwc_ld(x, "x")
     dy_ld = _nhwc_ld(dy, "dy")
@@ -632,22 +639,36 @@ def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False):
     _, oh, ow, cout = dy.shape
     assert cout == plan.cout
     nchunks = plan.chunk_start.numel() - 1
-    if splits is None:
+    want_bias = want_bias or bias_out is not None
+    aligned = cout % 4 == 0 and dy_ld % 4 == 0 and in_ld % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
+    x3 = WGRAD_X3["value"] and plan.precision != 2 and aligned
+    use_tr = x3 and WGRAD_TR["value"]
+    per = nchunks * ((cout + 127) // 128)
+    tiles_total = B * ((oh + 1) // 2) * ((ow + 31) // 32)
+    csum = None
+    if use_tr:
+        # one 8-wave block per CU (256 slots): ~2 rounds of blocks, >= min_tiles pixel tiles (2 x 32 px) each; a block writes two
+        # partial slots (one per tile row)
+        gz = splits // 2 if splits is not None else max(1, min(WGRAD_TR["blocks"] // per, max(1, tiles_total // WGRAD_TR["min_tiles"]), 1024))
+        splits = 2 * gz
+        if want_bias:
+            csum = torch.empty((gz, cout), device=x.device, dtype=torch.float32)
+    elif splits is None:
         # blocks = n-tiles x chunks x splits; the LDS-staged kernel runs 3 blocks per CU (768 slots): aim for ~2 rounds, keep
         # >= 2 pixel tiles (2 x 32 px) per block.  (Round 1 capped splits at 64: the 512x512 layers with few channels ran on
         # 64-256 blocks, a third of the chip or less.)
-        per = nchunks * ((cout + 127) // 128)
-        tiles_total = B * ((oh + 1) // 2) * ((ow + 31) // 32)
         splits = max(1, min((WGRAD_SPLIT["blocks"] + per - 1) // per, max(1, tiles_total // WGRAD_SPLIT["min_tiles"]), 2048))
     partial = torch.empty((splits, plan.nsteps, cout, 32), device=x.device, dtype=torch.float32)
-    # production: bf16x3 on the bf16 matrix pipe; precision 2 (verification): the exact fp32 MFMA
-    aligned = cout % 4 == 0 and dy_ld % 4 == 0 and in_ld % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
-    fn, name = ((lib.ppst_conv_wgrad_bf16x3, "ppst_conv_wgrad_bf16x3") if (WGRAD_X3["value"] and plan.precision != 2 and aligned)
-                else (lib.ppst_conv_wgrad_f32, "ppst_conv_wgrad_f32"))
     if PROF_ON["value"]:
         lib.ppst_wgrad_flop_steps(int(plan.flop_steps))
-    check(fn(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), B, H, W, in_ld, oh, ow, dy_ld,
-             cout, plan.nsteps, nchunks, splits, _stream()), name)
+    if use_tr:
+        check(lib.ppst_conv_wgrad_tr(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), _p(csum), B, H, W, in_ld, oh, ow,
+                                     dy_ld, cout, plan.nsteps, nchunks, splits, _stream()), "ppst_conv_wgrad_tr")
+    else:
+        # bf16x3 with register staging (round 2), or precision 2 (verification): the exact fp32 MFMA
+        fn, name = ((lib.ppst_conv_wgrad_bf16x3, "ppst_conv_wgrad_bf16x3") if x3 else (lib.ppst_conv_wgrad_f32, "ppst_conv_wgrad_f32"))
+        check(fn(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), B, H, W, in_ld, oh, ow, dy_ld,
+                 cout, plan.nsteps, nchunks, splits, _stream()), name)
     # 'dgradT': the plan's "weights" are the blurred 4x4 kernel (Cin,Cout,4,4) of the transposed conv
     shape = plan.w4_shape if plan.kind == "dgradT" else (plan.cout, plan.cin, plan.k, plan.k)
     if out is None:
@@ -660,7 +681,13 @@ def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False):
     c_, ky_, kx_ = plan.src_dev
     check(lib.ppst_wgrad_scatter(_p(partial), _p(c_), _p(ky_), _p(kx_), _p(dw), sn, sc, sy, sx, cout, plan.nsteps, splits,
                                  plan.scale, 1 if (accumulate and out is not None) else 0, _stream()), "ppst_wgrad_scatter")
-    return dw
+    if not want_bias:
+        return dw
+    if csum is not None:
+        db = colsum(csum, out=bias_out, accumulate=bias_accumulate)
+    else:
+        db = colsum(dy.as_strided((dy.shape[0] * oh * ow, cout), (dy_ld, 1)), out=bias_out, accumulate=bias_accumulate)
+    return dw, db
 
 
 def wgrad_small_cin(x, dy, scale, out=None, accumulate=False):

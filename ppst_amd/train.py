@@ -165,8 +165,9 @@ class DiscriminatorTrainer:
         gpre = _lrelu_bwd(dfc, fc)
         scf = 1.0 / math.sqrt(tape["x_last"].shape[3] * 9)
         if pg:
-            ops.conv_wgrad(D.plan(p + "final_conv.Conv.weight", scale=scf), tape["x_last"], gpre, out=G("final_conv.Conv.weight"), accumulate=True)
-            ops.colsum(gpre.view(-1, C), out=G("final_conv.Act.bias"), accumulate=True)
+            # (bias gradients = column sums of the same gradient tensor: out of the weight-gradient kernel's staging pass)
+            ops.conv_wgrad(D.plan(p + "final_conv.Conv.weight", scale=scf), tape["x_last"], gpre, out=G("final_conv.Conv.weight"), accumulate=True,
+                           bias_out=G("final_conv.Act.bias"), bias_accumulate=True)
         dx = self._dgrad(p + "final_conv.Conv.weight", "dgrad", scf)(gpre)
         if keep is not None:
             keep["dpred"], keep["gpre_h"], keep["gpre_fc"], keep["blocks"] = dpred, gpre_h, gpre, []
@@ -178,16 +179,16 @@ class DiscriminatorTrainer:
             # out = (a2 + skip)/sqrt2 ;  a2 = lrelu(conv2 + b)*sqrt2
             g2 = _lrelu_bwd(dx, blk["a2"], INV_SQRT2)
             if pg:
-                ops.colsum(g2.view(-1, cout), out=G(name + "conv2.Act.bias"), accumulate=True)
-                ops.conv_wgrad(D.plan(q + "conv2.Conv.weight", "s2d", sc1), blk["xb"], g2, out=G(name + "conv2.Conv.weight"), accumulate=True)
+                ops.conv_wgrad(D.plan(q + "conv2.Conv.weight", "s2d", sc1), blk["xb"], g2, out=G(name + "conv2.Conv.weight"), accumulate=True,
+                               bias_out=G(name + "conv2.Act.bias"), bias_accumulate=True)
             d_xb = self._dgrad(q + "conv2.Conv.weight", "dgrad_s2d", sc1)(g2, out_hw=blk["bhw"])
             # blur backward: upfirdn2d with the flipped (symmetric) taps and g_pad = (1, 1)
             kf = torch.flip(D.p(q + "conv2.Blur.kernel"), [0, 1]).contiguous()
             d_y1, _ = ops.blur_nhwc(d_xb, kf, 1, 1, ops.PAD_ZERO)
             g1 = _lrelu_bwd(d_y1, blk["y1"])
             if pg:
-                ops.colsum(g1.view(-1, cin), out=G(name + "conv1.Act.bias"), accumulate=True)
-                ops.conv_wgrad(D.plan(q + "conv1.Conv.weight", scale=sc1), blk["x"], g1, out=G(name + "conv1.Conv.weight"), accumulate=True)
+                ops.conv_wgrad(D.plan(q + "conv1.Conv.weight", scale=sc1), blk["x"], g1, out=G(name + "conv1.Conv.weight"), accumulate=True,
+                               bias_out=G(name + "conv1.Act.bias"), bias_accumulate=True)
             d_xa = self._dgrad(q + "conv1.Conv.weight", "dgrad", sc1)(g1)
             # skip branch: 1x1 conv on the blurred + decimated input, no bias / activation
             gs = ops.affine_act(dx, None, out_scale=INV_SQRT2)
