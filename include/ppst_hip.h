@@ -399,6 +399,12 @@ int ppst_conv_wgrad_bf16x3(const void* x, const void* dy, const void* steps, con
 int ppst_conv_wgrad_tr(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial, void* csum,
                        int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps, int nchunks,
                        int splits, void* stream);
+/* the two-blocks-per-CU form of it (256-thread blocks, fp32 -> bf16 hi | lo converted in place in LDS, 49 KB per block): the
+ * phases of one block (request, wait, convert, MFMA) overlap the other block's.  ``splits`` = partial slots = pixel ranges (any
+ * positive count); csum NULL or [splits][cout]. */
+int ppst_conv_wgrad_tr2(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial, void* csum,
+                        int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps, int nchunks,
+                        int splits, void* stream);
 /* dw[n*sn + (src_c+k)*sc + ky*sy + kx*sx] (+)= scale * sum_splits partial[.][step][n][k] */
 int ppst_wgrad_scatter(const void* partial, const void* src_c, const void* src_ky, const void* src_kx,
                        void* dw, int64_t sn, int64_t sc, int64_t sy, int64_t sx, int cout, int nsteps,

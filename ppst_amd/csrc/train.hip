@@ -531,6 +531,185 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr_kernel(const float* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The two-blocks-per-CU form of the same idea (the production weight gradient).  conv_wgrad_tr_kernel's phases ADD UP inside
+// its one block per CU (timing ablations at its DMA call site): the fix is not a deeper pipeline inside the block but a second
+// block on the CU that is in another phase.  For that the tile has to fit 80 KB:
+//   * the fp32 data are converted IN PLACE: a 16-byte unit (one pixel, four channels) becomes [hi x 4 | lo x 4] bf16 in the same
+//     16 bytes -- no second image.  ds_read_b64_tr_b16 takes a per-lane address, so any unit layout works; units of pixels p and
+//     p + 2 alias the same banks, so every other pixel PAIR stores [lo | hi] instead: the 32 eight-byte reads of a half-wave
+//     (4 pixels x 8 channel quads) then hit 64 distinct banks;
+//   * dY image: 4 slabs (32 channels) x 64 pixels x 128 B = 32 KB, input halo image 136 pixels x 128 B = 17 KB: 49 KB per block,
+//     256 threads, 4 waves = 4 n slabs, each wave reduces over the tile's four 16-pixel groups.
+// Per tile: request (LDS-DMA, 49 pieces) -> wait -> convert (+ the bias column sums) -> MFMA; nothing inside the block overlaps,
+// the co-resident block does.
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              const int4* __restrict__ steps, const int* __restrict__ chunk_start,
+                                                              float* __restrict__ partial, float* __restrict__ csum, int B, int in_h,
+                                                              int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
+                                                              int tiles_x, int tiles_per_image, int tiles_total, int tiles_per_split) {
+  constexpr int IMG_DY = WT_PX * 128 * 4, IMG_X = WT_XPX * 32 * 4;           // 32768 + 17408 bytes
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[IMG_DY + IMG_X];
+  unsigned char* const imdy = smem;                           // [slab 0..3][64 px][8 quads][16 B]
+  unsigned char* const imx = smem + IMG_DY;                   // [136 px][8 quads][16 B]
+  const int tid = threadIdx.x, lane = tid & 63, nw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kb = lane >> 5;
+  int bx, by, bz;                                             // XCD-aware block map (conv_wgrad_tr_kernel)
+  {
+    const int nb = gridDim.x * gridDim.y * gridDim.z;
+    const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int q8 = nb >> 3, r8 = nb & 7, xcd = id & 7;
+    int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+    bx = v % (int)gridDim.x; v /= (int)gridDim.x;
+    by = v % (int)gridDim.y; bz = v / (int)gridDim.y;
+  }
+  const int n0 = bx * 128;
+  const int s0 = chunk_start[by], s1 = chunk_start[by + 1];
+  const int T = s1 - s0;
+  const int chan = steps[s0].x;
+  int tdy[WG_MAXT], tdx[WG_MAXT];
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t) {
+    int4 d = steps[s0 + (t < T ? t : 0)];
+    tdy[t] = d.y; tdx[t] = d.z;
+  }
+  f32x16 acc[WG_MAXT];
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  const int t_begin = bz * tiles_per_split;
+  const int t_end = min(t_begin + tiles_per_split, tiles_total);
+  const bool wave_live = n0 + nw * 32 < cout;
+  const bool want_csum = csum != nullptr && by == 0;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);               // this thread's 4 channels (tid & 31) over its pixels of every tile
+  // transposed-read lane geometry (conv_wgrad_tr_kernel): channel quad 4 (g & 1) + pp, pixel 8 kb + qd (+ 4 for the second read)
+  const int g = lane >> 4, qd = (lane & 15) >> 2, pp = lane & 3;
+  const int tr_unit = (8 * (g >> 1) + qd) * 128 + (4 * (g & 1) + pp) * 16;
+  auto split4 = [](float4 v, uint2& hi, uint2& lo) {
+    unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
+    split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
+    hi = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
+    lo = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+  };
+  // operand of 8 k-values (pixels) from the unit image: ``u`` = address of this lane's unit of the first pixel group, ``sw`` = 1
+  // when that pixel pair stores [lo | hi]
+  auto frag = [&](const unsigned char* u, int sw, bf16x8& h, bf16x8& l) {
+    const unsigned char* ph = u + sw * 8;
+    const unsigned char* pl = u + (sw ^ 1) * 8;
+    const wt_v4s h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wt_v4s __attribute__((address_space(3)))*)ph);
+    const wt_v4s h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wt_v4s __attribute__((address_space(3)))*)(ph + 4 * 128));
+    const wt_v4s l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wt_v4s __attribute__((address_space(3)))*)pl);
+    const wt_v4s l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wt_v4s __attribute__((address_space(3)))*)(pl + 4 * 128));
+    h = (bf16x8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    l = (bf16x8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+  };
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int b = tile / tiles_per_image;
+    const int r = tile - b * tiles_per_image;
+    const int ty0 = (r / tiles_x) * WG_TR, tx0 = (r - (r / tiles_x) * tiles_x) * WG_TC;
+    __syncthreads();                                        // the previous tile's MFMA reads are done
+    // ---- LDS-DMA: 32 pieces of dY (slab s, pixels 8 j .. 8 j + 7: 8 x 128 B) + 17 of the input halo (8 pixels x 128 B)
+    for (int wi = nw; wi < 32 + 17; wi += 4) {
+      const float* src = g_wg_zero;
+      unsigned char* dst;
+      const int q = lane & 7;
+      if (wi < 32) {
+        const int p = 8 * (wi & 7) + (lane >> 3), n = n0 + (wi >> 3) * 32 + q * 4;
+        const int y = ty0 + (p >> 5), xx = tx0 + (p & 31);
+        if (y < oh && xx < ow && n < cout) src = dy + (((int64_t)b * oh + y) * ow + xx) * dy_ld + n;
+        dst = imdy + wi * 1024;
+      } else {
+        const int P = 8 * (wi - 32) + (lane >> 3);
+        const int row = P / WT_XW, col = P - row * WT_XW;
+        const int iy = ty0 - 1 + row, ix = tx0 - 1 + col;
+        if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) src = x + (((int64_t)b * in_h + iy) * in_w + ix) * in_ld + chan + q * 4;
+        dst = imx + (wi - 32) * 1024;
+      }
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (hipcc adds no wait for LDS-DMA)
+    __syncthreads();
+    // ---- in-place conversion: unit (pixel p, quad) fp32 x 4 -> [hi | lo] bf16 x 4 (swapped for odd pixel pairs)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int i = tid + it * 256;                           // pixel-major: channel quad (slab * 8 + quad) = tid & 31 for every it
+      const int cq = i & 31, p = i >> 5;
+      unsigned char* u = imdy + (cq >> 3) * 8192 + p * 128 + (cq & 7) * 16;
+      const float4 v = *(const float4*)u;
+      if (want_csum) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
+      uint2 hi, lo;
+      split4(v, hi, lo);
+      const int sw = (p >> 1) & 1;
+      *(uint4*)u = sw ? make_uint4(lo.x, lo.y, hi.x, hi.y) : make_uint4(hi.x, hi.y, lo.x, lo.y);
+    }
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+      const int i = tid + it * 256;
+      if (i < WT_XPX * 8) {
+        unsigned char* u = imx + i * 16;
+        const float4 v = *(const float4*)u;
+        uint2 hi, lo;
+        split4(v, hi, lo);
+        const int sw = (i >> 4) & 1;                          // pixel = i >> 3
+        *(uint4*)u = sw ? make_uint4(lo.x, lo.y, hi.x, hi.y) : make_uint4(hi.x, hi.y, lo.x, lo.y);
+      }
+    }
+    __syncthreads();
+    if (wave_live) {
+#pragma unroll 1                                             // (unrolled, hipcc hoists 4 x 9 x 2 fragment addresses: 44 registers spilled)
+      for (int ks = 0; ks < 4; ++ks) {                       // four groups of 16 pixels: tile row ks / 2, half ks % 2
+        const int row = ks >> 1, xh = (ks & 1) * 16;
+        bf16x8 a_h, a_l;
+        frag(imdy + nw * 8192 + (row * 32 + xh) * 128 + tr_unit, (qd >> 1) & 1, a_h, a_l);
+        const int pb0 = (row + 1 + tdy[0]) * WT_XW + xh + 1 + tdx[0];
+        bf16x8 b_h, b_l;
+        frag(imx + pb0 * 128 + tr_unit, (((pb0 & 3) + qd) >> 1) & 1, b_h, b_l);
+#pragma unroll
+        for (int t = 0; t < WG_MAXT; ++t) {
+          if (t < T) {
+            bf16x8 n_h = b_h, n_l = b_l;
+            if (t + 1 < WG_MAXT && t + 1 < T) {               // the next tap's fragments are requested before this tap's MFMAs
+              const int pb = (row + 1 + tdy[t + 1]) * WT_XW + xh + 1 + tdx[t + 1];
+              frag(imx + pb * 128 + tr_unit, (((pb & 3) + qd) >> 1) & 1, n_h, n_l);
+            }
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b_h, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_l, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_h, acc[t], 0, 0, 0);
+            b_h = n_h; b_l = n_l;
+          }
+        }
+      }
+    }
+  }
+  if (want_csum) {                                            // column sums of dY: 8 threads share a channel quad
+    __syncthreads();
+    float4* red = (float4*)smem;                              // [8][32] float4
+    red[(tid >> 5) * 32 + (tid & 31)] = cs;
+    __syncthreads();
+    if (tid < 32) {
+      float4 a = red[tid];
+#pragma unroll
+      for (int r = 1; r < 8; ++r) { const float4 v = red[r * 32 + tid]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+      const int n = n0 + tid * 4;
+      float* o = csum + (int64_t)bz * cout + n;
+      if (n < cout) { o[0] = a.x; if (n + 1 < cout) o[1] = a.y; if (n + 2 < cout) o[2] = a.z; if (n + 3 < cout) o[3] = a.w; }
+    }
+  }
+  if (!wave_live) return;
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t) {
+    if (t < T) {
+      float* o = partial + (((int64_t)bz * nsteps + s0 + t) * cout) * 32;
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        int nn = n0 + nw * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kb;
+        if (nn < cout) o[(int64_t)nn * 32 + li] = acc[t][rg];
+      }
+    }
+  }
+}
+
 // profiling brackets of conv_mfma.hip: a weight-gradient launch is recorded with info = {B, oh, ow, nsteps, cout, nchunks, splits, 0}
 // (bn = 0 marks it) and the algorithmic 2 * 32 * flop_steps * cout * B * oh * ow (flop_steps < nsteps where the table carries
 // zero-weight pad steps)
@@ -590,6 +769,30 @@ extern "C" int ppst_conv_wgrad_tr(const void* x, const void* dy, const void* ste
   PPST_LAUNCH(conv_wgrad_tr_kernel, grid, dim3(512), 0, as_stream(stream), (const float*)x, (const float*)dy, (const int4*)steps,
               (const int*)chunk_start, (float*)partial, (float*)csum, B, in_h, in_w, in_ld, oh, ow, dy_ld, cout, nsteps, tiles_x,
               tiles_per_image, tiles_total, tps, g_wgrad_abl);
+  ppst_prof_end_(slot, as_stream(stream));
+  return PPST_LAUNCH_CHECK();
+}
+
+// two-blocks-per-CU form (conv_wgrad_tr2_kernel, in-place conversion): ``splits`` partial slots = pixel ranges; csum (optional):
+// [splits][cout] partial column sums of dy
+extern "C" int ppst_conv_wgrad_tr2(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial, void* csum,
+                                   int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
+                                   int nchunks, int splits, void* stream) {
+  if (B < 0 || in_h <= 0 || in_w <= 0 || in_ld <= 0 || oh <= 0 || ow <= 0 || dy_ld < cout || cout <= 0 || nsteps <= 0 ||
+      nchunks <= 0 || splits <= 0)
+    return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !dy || !steps || !chunk_start || !partial) return PPST_ENULL;
+  if (cout % 4 || dy_ld % 4 || in_ld % 4 || ((uintptr_t)x | (uintptr_t)dy) % 16) return PPST_EINVAL;
+  const int tiles_x = cdiv(ow, WG_TC), tiles_per_image = cdiv(oh, WG_TR) * tiles_x;
+  const int tiles_total = B * tiles_per_image;
+  const int tps = cdiv(tiles_total, splits);
+  dim3 grid(cdiv(cout, 128), nchunks, splits);
+  const int slot = wgrad_prof_begin(B, oh, ow, cout, nsteps, g_wgrad_flop_steps, nchunks, splits, as_stream(stream));
+  g_wgrad_flop_steps = 0;
+  PPST_LAUNCH(conv_wgrad_tr2_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (const int4*)steps,
+              (const int*)chunk_start, (float*)partial, (float*)csum, B, in_h, in_w, in_ld, oh, ow, dy_ld, cout, nsteps, tiles_x,
+              tiles_per_image, tiles_total, tps);
   ppst_prof_end_(slot, as_stream(stream));
   return PPST_LAUNCH_CHECK();
 }

@@ -620,7 +620,7 @@ def _grad_out(out, shape, like):
 
 # the LDS-DMA / transposed-read weight-gradient kernel (round 3): one 8-wave block per CU -> ONE round of <= 256 blocks (every
 # further split is 2 x 147 KB of partial sums written and re-read by the scatter), >= min_tiles pixel tiles per block
-WGRAD_TR = {"value": True, "blocks": 256, "min_tiles": 8}
+WGRAD_TR = {"value": True, "blocks": 256, "min_tiles": 8, "form": 2, "blocks2": 512}    # form 2: two 256-thread blocks per CU
 
 
 def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=None, bias_accumulate=False, want_bias=False):
@@ -649,8 +649,13 @@ def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=No
     if use_tr:
         # one 8-wave block per CU (256 slots): ~2 rounds of blocks, >= min_tiles pixel tiles (2 x 32 px) each; a block writes two
         # partial slots (one per tile row)
-        gz = splits // 2 if splits is not None else max(1, min(WGRAD_TR["blocks"] // per, max(1, tiles_total // WGRAD_TR["min_tiles"]), 1024))
-        splits = 2 * gz
+        form2 = WGRAD_TR["form"] == 2
+        if form2:       # one partial slot per block, two blocks per CU: one round of <= 512 blocks
+            gz = splits if splits is not None else max(1, min(max(1, WGRAD_TR["blocks2"] // per), max(1, tiles_total // WGRAD_TR["min_tiles"]), 2048))
+            splits = gz
+        else:
+            gz = splits // 2 if splits is not None else max(1, min(max(1, WGRAD_TR["blocks"] // per), max(1, tiles_total // WGRAD_TR["min_tiles"]), 1024))
+            splits = 2 * gz
         if want_bias:
             csum = torch.empty((gz, cout), device=x.device, dtype=torch.float32)
     elif splits is None:
@@ -662,8 +667,9 @@ def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=No
     if PROF_ON["value"]:
         lib.ppst_wgrad_flop_steps(int(plan.flop_steps))
     if use_tr:
-        check(lib.ppst_conv_wgrad_tr(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), _p(csum), B, H, W, in_ld, oh, ow,
-                                     dy_ld, cout, plan.nsteps, nchunks, splits, _stream()), "ppst_conv_wgrad_tr")
+        fn, name = (lib.ppst_conv_wgrad_tr2, "ppst_conv_wgrad_tr2") if WGRAD_TR["form"] == 2 else (lib.ppst_conv_wgrad_tr, "ppst_conv_wgrad_tr")
+        check(fn(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), _p(csum), B, H, W, in_ld, oh, ow,
+                 dy_ld, cout, plan.nsteps, nchunks, splits, _stream()), name)
     else:
         # bf16x3 with register staging (round 2), or precision 2 (verification): the exact fp32 MFMA
         fn, name = ((lib.ppst_conv_wgrad_bf16x3, "ppst_conv_wgrad_bf16x3") if x3 else (lib.ppst_conv_wgrad_f32, "ppst_conv_wgrad_f32"))
