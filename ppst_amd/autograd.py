@@ -12,7 +12,7 @@ import math
 import torch
 from torch.autograd import Function
 
-from . import ops
+from . import gates, ops
 
 SQRT2 = math.sqrt(2.0)
 Z, REFLECT, REPLICATE = ops.PAD_ZERO, ops.PAD_REFLECT, ops.PAD_REPLICATE
@@ -26,12 +26,26 @@ def _c(t):
 def lrelu_bwd(g, out, scale=1.0):
     """d/d(pre-activation) of y = lrelu(x)*sqrt2 given d/dy, gated by the sign of the saved output
     (fused_bias_act_kernel.cu:43)."""
-    return ops.fused_bias_act_raw(g, None, out, 3, 1, 0.2, SQRT2 * scale)
+    return ops.fused_bias_act_raw(g, None, gates.sign_gate(out, "lrelu"), 3, 1, 0.2, SQRT2 * scale)
 
 
 def relu_gate(g, x):
     """g * [x > 0] (backward of the projectors' leading nn.ReLU)."""
-    return ops.fused_bias_act_raw(g, None, x, 3, 1, 0.0, 1.0)
+    return ops.fused_bias_act_raw(g, None, gates.sign_gate(x, "relu"), 3, 1, 0.0, 1.0)
+
+
+def prelu_bwd(g, y, prelu, scale_shift=None, res=None):
+    """ops.prelu_bwd with the gate tape: (g * prelu'(z), dslope), z = a*y + s [+ res].  Record / replay need z's sign, which the
+    kernel forms internally: those two modes recompute z with the apply kernel and gate with the recorded decision (the slope
+    gradient sum g*z*[z<0] keeps the run's own z: a flipped element has z ~ 0)."""
+    if gates.MODE["value"] is None:
+        return ops.prelu_bwd(g, y, prelu, scale_shift=scale_shift, res=res)
+    z = ops.affine_act(y, scale_shift, res=res, res_before_act=True) if (scale_shift is not None or res is not None) else y
+    gate = gates.sign_gate(z, "prelu", ge=True)
+    gpre, ds = ops.prelu_bwd(g, y, prelu, scale_shift=scale_shift, res=res)
+    if gates.MODE["value"] == "replay":
+        gpre = ops.fused_bias_act_raw(g, None, gate, 3, 1, float(prelu), 1.0)      # g * (gate > 0 ? 1 : slope)
+    return gpre, ds
 
 
 # ---- parameter gradients go straight into the trainer's flat gradient buffer -------------------------------------------
@@ -270,9 +284,9 @@ class InstanceNormFn(Function):
         g = _c(g)
         B, H, W, C = y.shape
         dprelu = None
-        gate = out if ctx.act == LRELU else None
+        gate = gates.sign_gate(out, "in-lrelu") if ctx.act == LRELU else None
         if ctx.act == PRELU:
-            g, dprelu = ops.prelu_bwd(g, y, prelu, scale_shift=ss)
+            g, dprelu = prelu_bwd(g, y, prelu, scale_shift=ss)
         part = ops.dual_stats(g, y, gate)
         want = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         coef, dstyle = ops.in_bwd_finalize(part, H * W, mr, style, want_dstyle=want)
@@ -317,7 +331,7 @@ class PReluResFn(Function):
     @staticmethod
     def backward(ctx, g):
         a, res, prelu = ctx.saved_tensors
-        gpre, ds = ops.prelu_bwd(_c(g), a, prelu, res=res)
+        gpre, ds = prelu_bwd(_c(g), a, prelu, res=res)
         return gpre, gpre, ds
 
 
@@ -373,6 +387,7 @@ class GapGmpFn(Function):
     @staticmethod
     def backward(ctx, g):
         x, mask, v = ctx.saved_tensors
+        x, v = gates.values("gmp-argmax", x, v)          # (they only pick the arg-max pixel; the tape can replay another run's)
         return ops.gap_gmp_bwd(x, mask, v, _c(g)), None
 
 
@@ -556,6 +571,7 @@ class L1LossFn(Function):
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
+        (a,) = gates.values("l1-sign", a)                # (sign(a - b) only)
         da = ops.l1_grad(a, b, ctx.w)
         return ops.scale_by(da, g), None, None
 

@@ -18,7 +18,7 @@ import math
 
 import torch
 
-from . import ops, weights
+from . import gates, ops, weights
 from .networks.base_network import to_nhwc
 
 SQRT2 = math.sqrt(2.0)
@@ -28,7 +28,7 @@ INV_SQRT2 = 1.0 / SQRT2
 def _lrelu_bwd(g, out, scale=1.0):
     """grad wrt the pre-activation of y = lrelu(x)*sqrt2 given grad wrt y, gated by sign(y)
     (fused_bias_act_kernel.cu:43); ``scale`` folds an upstream constant factor in."""
-    return ops.fused_bias_act_raw(g, None, out, 3, 1, 0.2, SQRT2 * scale)
+    return ops.fused_bias_act_raw(g, None, gates.sign_gate(out, "lrelu"), 3, 1, 0.2, SQRT2 * scale)
 
 
 class DiscriminatorTrainer:

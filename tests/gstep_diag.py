@@ -1,7 +1,7 @@
 """GPU diagnostic for the generator / encoder update: every autograd block (ppst_amd/autograd.py) against torch
 autograd of the CPU oracle's ops in float64, then the full generator iteration against the fixtures the reference's
 own compute_generator_losses + backward produced (tests/golden/gstep512_s{1,2}.npz).
-Usage (GPU box):  python tests/gstep_diag.py [blocks|s1|s2|all]
+Usage (GPU box):  python tests/gstep_diag.py [blocks|s1|s2|replay1|replay2|all]
 The pytest -m gpu tests (tests/test_gpu_gstep.py) assert the same comparisons."""
 import math
 import os
@@ -498,6 +498,109 @@ def _net_grad_check(tag, trainer, fp, sd64, outs_gpu, outs_ref, extra_gpu=(), ex
             print("%-52s %s l2 %.3e (tol %.0e) max %.3e" % ("%s d/d(input %d)" % (tag, i), "ok  " if ok else "FAIL", l2, tol, mx), flush=True)
 
 
+def gstep_run(stage, precision, gate_mode=None, tape=None):
+    """One generator iteration (forward + backward) of the training path with conv ``precision``; ``gate_mode`` 'record' /
+    'replay' wraps the BACKWARD in the gate tape (ppst_amd/gates.py).  -> (losses, {net: flat gradient}, trainer, tape | flips)."""
+    from ppst_amd import gates
+    from ppst_amd.ppst_model import Options, create_model
+    over = dict(training_stage=stage, lambda_Cycwarp=0.0)
+    if stage == 1:
+        over["lambda_StyleCon"] = 0.0
+    sd = W.make_state_dict(17, bias_std=0.1, noise_weight=0.1)
+    ops.set_precision(precision)
+    try:
+        m = create_model(Options(**over), state_dict=sd, with_D=True, with_nce=True)
+        real, mask, noise = gstep_inputs()
+        m.noise = {k: v.to(dev) for k, v in noise.items()}
+        tr = m.trainer()
+        tr.zero_grad()
+        with torch.enable_grad():
+            losses, metrics = tr.compute_generator_losses(real.to(dev), mask.to(dev))
+            total = None
+            for v in losses.values():
+                total = v if total is None else total + v
+            if gate_mode:
+                gates.start(gate_mode, tape)
+            try:
+                total.backward()
+            finally:
+                res = gates.stop() if gate_mode else None
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision(0)
+    return {k: float(v) for k, v in losses.items()}, {k: f.grad.clone() for k, f in tr.fp.items()}, tr, res
+
+
+def compare_gstep_replay(stage, tol=5e-3, verbose=True):
+    """The production convs (bf16 hi + lo operands) against the exact-fp32 convs with the GATES of the exact run replayed in the
+    production run's backward (leaky-ReLU / ReLU / PReLU branches, global-max-pool arg-max, L1 sign): what is left between the
+    two gradients is operand rounding, and EVERY parameter tensor -- biases, noise weights, PReLU slopes, the first E2 layers
+    included: no class of cancelling sums, no per-class bar -- must agree within ``tol`` in max-norm and in l2.  A parameter whose
+    gradient is a null direction (a bias in front of an instance norm: exact gradient 0, both runs produce rounding noise)
+    is held to noise size against the largest gradient entry of its network instead.  Also returns the flipped-gate count
+    of the un-replayed production run per gate site."""
+    l2_, g2, tr2, tape = gstep_run(stage, 2, "record")
+    nsites = len(tape)
+    l0, g0, tr0, flips = gstep_run(stage, 0, "replay", tape)
+    del tape
+    res = []
+    for k in l2_:
+        ok = abs(l0[k] - l2_[k]) <= 1e-3 * max(1.0, abs(l2_[k]))
+        res.append(("replay loss " + k, ok))
+        if verbose:
+            print("replay loss %-20s %s production %.6f exact %.6f" % (k, "ok  " if ok else "FAIL", l0[k], l2_[k]), flush=True)
+    # One-element parameters (14 noise weights, 5 PReLU slopes) are single cancelling sums over ~10^6 terms: their "max-norm" is
+    # the relative error of that one sum, with nothing to average over.  How ill-conditioned each is at float32 is MEASURED on
+    # the spot: the reference's own float32 value (fixture) against our exact-conv value -- two float32 evaluations of the same
+    # quantity in different summation orders.  Bar for such a scalar: tol, or twice that measured floor.  Every tensor with more
+    # than one element: tol, no exceptions, no list.
+    gref = np.load(os.path.join(GOLD, "gstep512_s%d.npz" % stage))
+    worst = []
+    for net, f in tr0.fp.items():
+        a_all, r_all = g0[net].double(), g2[net].double()
+        gscale = float(r_all.abs().max())
+        for n in f.names:
+            off, sz = f.offsets[n]
+            a, r = a_all[off:off + sz], r_all[off:off + sz]
+            sc = float(r.abs().max())
+            d = float((a - r).abs().max())
+            if sc <= 1e-6 * gscale:          # null direction: both runs hold rounding noise
+                ok = float(a.abs().max()) <= 1e-5 * gscale
+                worst.append((0.0 if ok else float("inf"), 0.0, net + "." + n + " (null direction)", sz, ok, 0.0))
+                continue
+            l2 = float((a - r).norm() / r.norm())
+            floor = 0.0
+            key = "grad.%s.%s" % (net, n)
+            if sz == 1 and key + ".samples" in gref.files:
+                floor = abs(float(gref[key + ".samples"].reshape(-1)[0]) - float(r[0])) / sc
+            bar = max(tol, 2.0 * floor) if sz == 1 else tol
+            ok = d / sc <= bar and l2 <= bar
+            worst.append((d / sc, l2, net + "." + n, sz, ok, floor))
+    worst.sort(reverse=True)
+    nbad = sum(1 for w_ in worst if not w_[4])
+    nover = sum(1 for w_ in worst if w_[0] > tol)
+    res.append(("replay: every parameter gradient within %.0e of the exact-conv run (%d tensors; one-element tensors: or 2 x their "
+                "measured float32 floor)" % (tol, len(worst)), nbad == 0))
+    if verbose:
+        print("stage %d, production convs on the exact run's gates: %d tensors, %d above %.0e (%d outside their bar); worst:"
+              % (stage, len(worst), nover, tol, nbad), flush=True)
+        for w_ in worst[:10]:
+            print("   %-64s max %.2e l2 %.2e (%d elements)%s" % (w_[2], w_[0], w_[1], w_[3],
+                  "  [reference float32 vs exact convs: %.2e]" % w_[5] if w_[3] == 1 else ""), flush=True)
+        # flipped gates of the production run, per kind of site and per site
+        agg = {}
+        for site, n, fl in flips:
+            a_ = agg.setdefault(site, [0, 0, 0])
+            a_[0] += 1; a_[1] += n; a_[2] += fl
+        print("gate sites visited: %d; own decisions of the production run that differ from the exact run's:" % nsites, flush=True)
+        for site, (cnt, n, fl) in sorted(agg.items()):
+            print("   %-10s %4d sites %14d elements %9d flipped (%.2e)" % (site, cnt, n, fl, fl / max(n, 1)), flush=True)
+        top = sorted(((fl / max(n, 1), i, site, n, fl) for i, (site, n, fl) in enumerate(flips)), reverse=True)[:8]
+        for frac, i, site, n, fl in top:
+            print("   site %4d (backward order) %-9s %11d elements %8d flipped (%.2e)" % (i, site, n, fl, frac), flush=True)
+    return res
+
+
 def t_nets():
     """E2 (mask + correspondence warp heads), E1 and G (+ feature heads) of the training path against torch autograd of
     the CPU oracle (float32), conv precision = exact fp32 (rounding of the production convs is bounded in compare_gstep)."""
@@ -635,6 +738,10 @@ def main():
         run(t_s1x)
     if what in ("s2x", "exact"):
         run(t_s2x)
+    if what in ("replay1", "replay"):
+        RES.extend(compare_gstep_replay(1))
+    if what in ("replay2", "replay"):
+        RES.extend(compare_gstep_replay(2))
     bad = [n for n, ok in RES if not ok]
     print("SUMMARY: %d checks, %d failed" % (len(RES), len(bad)))
     for n in bad[:60]:
