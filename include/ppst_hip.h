@@ -220,9 +220,15 @@ typedef struct ppst_conv_args {
                                     Variants 0-7 and 9 give bit-identical outputs; the per-tile statistics differ in the last
                                     bit between variants (other summation tree).  The library returns PPST_EINVAL for a
                                     variant whose shape conditions do not hold. */
+  int32_t in_presplit;           /* experiment (PPST_EXPERIMENTS builds): x is pre-split -- per pixel and 8-channel group 32 bytes
+                                    [hi x 8 | lo x 8] bf16 (ppst_presplit), same pixel stride in_ld -- and the activation tile is
+                                    staged by LDS-DMA.  variant 0, bn 128, halo 1, precision 0, no in_scale_shift, every chunk of
+                                    the step table >= 4 steps (the caller's promise, like early_a). */
 } ppst_conv_args;
 
 int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream);
+/* fp32 NHWC [npix][x_ld] -> the pre-split layout of ppst_conv_args.in_presplit in y [npix][y_ld] (C % 8 == 0) */
+int ppst_presplit(const void* x, void* y, int64_t npix, int C, int x_ld, int y_ld, void* stream);
 /* 1 when the library was built with PPST_EXPERIMENTS=1: the measured-and-off forms (variants 1 / 3 / 7 / 8 / 9, precision 4,
  * tile_rows 8) are then compiled in; the production build returns PPST_EINVAL for them. */
 int ppst_has_experiments(void);

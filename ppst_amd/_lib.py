@@ -52,7 +52,7 @@ class ConvArgs(ctypes.Structure):
         ("in_off_y", i32), ("in_off_x", i32), ("out_sy", i32), ("out_sx", i32),
         ("act", i32), ("precision", i32), ("res_ld", i32), ("tile_h", i32), ("tile_w", i32),
         ("halo", i32), ("bn", i32), ("in_scale_shift", vp), ("in_prelu", vp), ("in_c", i32), ("in_act", i32),
-        ("flop_steps", i32), ("tile_rows", i32), ("a_slots", i32), ("early_a", i32), ("variant", i32),
+        ("flop_steps", i32), ("tile_rows", i32), ("a_slots", i32), ("early_a", i32), ("variant", i32), ("in_presplit", i32),
     ]
 
 
@@ -70,6 +70,7 @@ _SIGS = {
     "ppst_upscale_weight_batch": (i32, [vp, i32, i32, vp]),
     "ppst_conv2d_mfma": (i32, [ctypes.POINTER(ConvArgs), vp]),
     "ppst_has_experiments": (i32, []),
+    "ppst_presplit": (i32, [vp, vp, i64, i32, i32, i32, vp]),
     "ppst_conv2d_f32": (i32, [ctypes.POINTER(ConvArgs), vp, i64, i64, i64, i64, f32, vp, vp, vp, vp]),
     "ppst_conv_tiles": (i32, [i32, i32, i32]),
     "ppst_conv1x1_small_cin": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp]),

@@ -25,6 +25,8 @@
 //    ordering so that co-resident blocks of one XCD stream the same weight blobs from its L2.
 #include "common.h"
 
+__device__ __attribute__((aligned(16))) float g_conv_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
 struct ConvKArgs {
   const float* x;
   const unsigned short* wpack;
@@ -80,7 +82,11 @@ __device__ __forceinline__ void split_f16(float x, unsigned short& hi, unsigned 
 }
 // X2 (with F16, !X3): two passes -- the activation as fp16 hi + lo (22 significant bits), the weight rounded once to
 // fp16 (11 bits): al*b + ah*b.  A measured experiment: 2/3 of the MFMAs of the fp32-class mode.
-template <int WM, int WN, int HALO, bool X3, bool INSS, int NAS = 0, bool F16 = false, bool X2 = false>
+// PRES (experiment, PPST_EXPERIMENTS builds; VERDICT r2 "lever (i)"): the input is PRE-SPLIT -- per pixel and 8-channel group 32
+// bytes [hi x 8 | lo x 8] bf16, same bytes and pixel stride as the fp32 tensor (ppst_presplit) -- and the activation tile is
+// staged by LDS-DMA like the weights: no registers, no conversion, no staging store.  Two activation slots (needs chunks of
+// >= 4 steps), no normalise-on-load.
+template <int WM, int WN, int HALO, bool X3, bool INSS, int NAS = 0, bool F16 = false, bool X2 = false, bool PRES = false>
 __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(ConvKArgs a) {
   constexpr bool ALO = X3 || X2;                         // the activation tile has lo planes
   constexpr int NT = 64 * WM * WN;
@@ -103,7 +109,8 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
 
   // A ring slots (hazard note at the main loop): 3 in general; NAS = 1 / 2 when the step table has no more chunks
   // than that (smaller LDS footprint, two blocks per CU).
-  constexpr int NA = NAS ? NAS : 3;
+  constexpr int NA = PRES ? 2 : (NAS ? NAS : 3);
+  static_assert(!PRES || (NT == 512 && HP <= 384 && !INSS && X3), "pre-split staging: the 8-wave tile kernel, 6 pieces per plane");
   constexpr int EPI_TILE = 64 * 36;                              // floats per wave: 64 px x (32 ch + 4 pad)
   constexpr int EPI_BYTES = (NT / 64) * EPI_TILE * 4 + WM * BN * 2 * 4;  // transposition tiles + stats scratch
   constexpr int MAIN_BYTES = NA * ABUF + 2 * BBUF;
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   constexpr int A_WCH = (HP + 7) / 8;                      // wave-chunks of 8 pixels x 8 float4
   constexpr int A_IT2 = (A_WCH * 64 + NT - 1) / NT;
   float4 ra[A_IT2];
-  constexpr int A_NLOADS = A_IT2 + (INSS ? 2 : 0);   // vector-memory operations of one a_load
+  constexpr int A_NLOADS = PRES ? 6 : A_IT2 + (INSS ? 2 : 0);   // vector-memory operations of one a_load / a_dma
 
   // A staging.  One wave-instruction covers 8 pixels x 128 B (fully coalesced global read);
   // inside it lane l -> plane g = l>>4, pixel (l>>1)&7, half h = l&1, so the 16 lanes of a
@@ -188,6 +195,38 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   // right behind the weight DMA of the step (one L2 round trip per chunk).  Padding items carry the offset -1 (0xffffffff): out of
   // the descriptor's range, the hardware returns zeros and the staging store needs no select.
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, a.in_h * a.in_w * a.in_ld * 4, 0x00020000);
+  // PRES: piece k (0..5) of this wave is plane (wave + 8k) / 6, pixels 64 j .. 64 j + 63 with j = (wave + 8k) % 6; a piece is one
+  // global_load_lds_dwordx4 (1 KB of one plane); out-of-image pixels of a zero-padded conv read a 16-byte zero word
+  int poff[6];
+  if (PRES) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int pix = 64 * ((wave + 8 * k) % 6) + lane;
+      int o = -1;
+      if (pix < HP) {
+        int hy = pix / HW, hx = pix - hy * HW;
+        int iy = ty0 + hy - HALO + a.in_off_y, ix = tx0 + hx - HALO + a.in_off_x;
+        bool inb = iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w;
+        if (inb || a.pad_mode != PPST_PAD_ZERO) {
+          iy = pad_index(iy, a.in_h, a.pad_mode);
+          ix = pad_index(ix, a.in_w, a.pad_mode);
+          o = (iy * a.in_w + ix) * a.in_ld * 4;
+        }
+      }
+      poff[k] = o;
+    }
+  }
+  auto a_dma = [&](int chan_off, int slot) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int i = wave + 8 * k, pl = i / 6, j = i - pl * 6;       // wave-uniform
+      const unsigned char* src = (const unsigned char*)g_conv_zero;
+      if (poff[k] >= 0) src = (const unsigned char*)xb + poff[k] + chan_off * 4 + (pl & 3) * 32 + (pl >> 2) * 16;
+      if (64 * j + lane < HP)
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                         (void __attribute__((address_space(3)))*)(smA + slot * ABUF + pl * PLANE + j * 1024), 16, 0, 0);
+    }
+  };
   auto a_load = [&](int chan_off) {
 #pragma unroll
     for (int it = 0; it < A_IT2; ++it) {
@@ -283,18 +322,20 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   int4 d = steps[0];
   int dy0 = d.y, dx0 = d.z, sl0 = 0;
   int dy1 = d.y, dx1 = d.z, sl1 = 0;
-  a_load(d.x);
+  if (PRES) a_dma(d.x, 0); else a_load(d.x);
   b_dma(0, 0);
-  a_store(0);
+  if (!PRES) a_store(0);
   if (a.nsteps > 1) {
     d = steps[1];
     dy1 = d.y; dx1 = d.z;
     sl1 = (d.w & 1) ? 1 : 0;
     b_dma(1, 1);
-    if (d.w & 1) a_load(d.x);
-    if (d.w & 1) a_store(sl1);
-    // early mode: the chunk opened by step 2 is staged during step 0 and must already be in registers
-    if (a.early_a && (d.w & 2)) a_load(d.w >> 8);
+    if (!PRES) {                    // (pre-split: chunks span >= 4 steps, steps 1 and 2 open none)
+      if (d.w & 1) a_load(d.x);
+      if (d.w & 1) a_store(sl1);
+      // early mode: the chunk opened by step 2 is staged during step 0 and must already be in registers
+      if (a.early_a && (d.w & 2)) a_load(d.w >> 8);
+    }
   }
   int4 dE = d, dO = d;                       // descriptor of step s+2, alternating register sets
   if (a.nsteps > 2) dE = steps[2];
@@ -379,7 +420,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
       /* in this step).  ONE a_load call site: two would make hipcc merge their results with copies + vmcnt(0).    */ \
     const bool ld_ = a.early_a ? ABL_A(has2 && (D2.w & 2)) : newA2;                                    \
     const int ch_ = a.early_a ? (D2.w >> 8) : D2.x;                                                   \
-    if (ld_) { a_load(ch_); a_early = a.early_a != 0; }                                               \
+    if (ld_) { if (PRES) a_dma(ch_, (sl2 == NA - 1) ? 0 : sl2 + 1); else a_load(ch_); a_early = a.early_a != 0; } \
   }                                                                                                   \
   if (ABL_LB(has1)) ld_b(bnh, bnl, ((s) + 1) & 1);
 #define STEP_HEAD_IF(cond, bnh, bnl, s, D2, D3)                                                       \
@@ -443,7 +484,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
       if (ALO) al = nl;                                                                               \
       /* convert + write the next chunk's tile while the last MFMA group executes: the VALU   */     \
       /* work of the staging store overlaps the matrix pipe instead of following it            */     \
-      if (mt == 2 && newA2) a_store(sl2);                                                             \
+      if (!PRES && mt == 2 && newA2) a_store(sl2);                                                    \
     }                                                                                                 \
     TR(4)                                                                                             \
     /* hipcc (ROCm 7.2) does NOT add vmcnt(0) for an in-flight LDS-DMA at this barrier (it only  */  \
@@ -634,6 +675,38 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     o[1] = r1 - tr_r0;
   }
 #endif
+}
+
+// fp32 NHWC -> pre-split layout (experiment): per pixel and 8-channel group [hi x 8 | lo x 8] bf16 in the group's own 32 bytes
+__global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__ x, unsigned* __restrict__ y, int64_t npix, int C, int x_ld,
+                                                       int y_ld) {
+  const int groups = C >> 3;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < npix * groups; t += (int64_t)gridDim.x * 256) {
+    const int64_t p = t / groups;
+    const int g8 = (int)(t - p * groups);
+    const float* src = x + p * x_ld + g8 * 8;
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned short h0, l0, h1, l1;
+      split_bf16(src[2 * q], h0, l0);
+      split_bf16(src[2 * q + 1], h1, l1);
+      hi[q] = (unsigned)h0 | ((unsigned)h1 << 16);
+      lo[q] = (unsigned)l0 | ((unsigned)l1 << 16);
+    }
+    unsigned* o = y + p * y_ld + g8 * 8;
+    *(uint4*)o = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    *(uint4*)(o + 4) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+extern "C" int ppst_presplit(const void* x, void* y, int64_t npix, int C, int x_ld, int y_ld, void* stream) {
+  if (npix < 0 || C <= 0 || C % 8 || x_ld < C || y_ld < C || x_ld % 4 || y_ld % 4) return PPST_EINVAL;
+  if (npix == 0) return PPST_OK;
+  if (!x || !y) return PPST_ENULL;
+  int64_t blocks = cdiv64(npix * (C >> 3), 256);
+  if (blocks > 65536) blocks = 65536;
+  PPST_LAUNCH(presplit_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)x, (unsigned*)y, npix, C, x_ld, y_ld);
+  return PPST_LAUNCH_CHECK();
 }
 
 // ------------------------------------------------------------ weight packing --
@@ -898,9 +971,15 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
        !(a->variant == 0 && a->tile_rows == 8 && a->bn == 128 && a->halo == 1 && a->early_a && a->precision == 0)) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
     return PPST_EINVAL;
 #ifndef PPST_EXPERIMENTS
-  if (a->variant == 1 || a->variant == 3 || a->variant == 7 || a->variant == 8 || a->variant == 9 || a->precision == 4 || a->tile_rows == 8)
+  if (a->variant == 1 || a->variant == 3 || a->variant == 7 || a->variant == 8 || a->variant == 9 || a->precision == 4 || a->tile_rows == 8 ||
+      a->in_presplit)
     return PPST_EINVAL;          // experiment forms: not in this build
 #endif
+  // pre-split input (experiment): the 8-wave tile kernel only, chunks of >= 4 steps (the caller's promise with early_a), no
+  // normalise-on-load
+  if (a->in_presplit && (a->variant != 0 || a->bn != 128 || a->halo != 1 || a->precision != 0 || !a->early_a || a->tile_rows != 16 ||
+                         a->in_scale_shift))
+    return PPST_EINVAL;
   // the epilogues address one image with 32-bit element offsets
   // (+ one tile row of slack: lanes beyond the image edge form their offset too, and only then mask the access)
   {
@@ -970,7 +1049,8 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   // small-K layers on the 64-channel tile: a shallower activation ring (59 / 48 / 80 KB of LDS instead of
   // 145 / 112) puts two blocks on a CU, so one block's loads and stores overlap the other's MFMAs
 #ifdef PPST_EXPERIMENTS
-  if (a->tile_rows == 8) launch_conv<2, 2, 1, true, 2>(k, blocks, st);
+  if (a->in_presplit) PPST_LAUNCH((conv_mfma_kernel<4, 2, 1, true, false, 0, false, false, true>), dim3(blocks), dim3(512), 0, st, k);
+  else if (a->tile_rows == 8) launch_conv<2, 2, 1, true, 2>(k, blocks, st);
   else
 #endif
   if (a->bn == 64 && x3 && a->halo == 1 && a->a_slots == 1) launch_conv<4, 1, 1, true, 1>(k, blocks, st);

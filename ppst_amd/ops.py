@@ -479,7 +479,7 @@ class ConvPlan:
 
     def __call__(self, x, bias=None, noise=None, noise_weight=0.0, act=ACT_NONE, prelu=None, stats=False,
                  residual=None, out=None, out_scale=1.0, pad_mode=PAD_ZERO, out_hw=None, res_after_act=False,
-                 in_ss=None, in_act=ACT_NONE, in_prelu=None):
+                 in_ss=None, in_act=ACT_NONE, in_prelu=None, presplit=False):
         in_ld = _nhwc_ld(x, "conv input")
         B, H, W, xc = x.shape
         # the step table lives on the device: the C ABI cannot check these, and the kernel indexes
@@ -536,6 +536,11 @@ class ConvPlan:
         a.flop_steps = self.flop_steps
         a.a_slots = min(3, self.chunks_per_group)
         a.early_a = self.early_a
+        if presplit:         # experiment: x holds the pre-split layout (ops.presplit); the tile kernel stages it by LDS-DMA
+            _need_experiments("pre-split conv input")
+            if variant != 0 or bn != 128 or in_ss is not None or self.nsteps // max(1, self.chunks_per_group) < 4:
+                raise RuntimeError("pre-split input: tile kernel (bn 128) plans with chunks of >= 4 steps and no in_ss only")
+            a.in_presplit = 1
         if self.precision == 2:
             sn, sc, sy, sx = self.wstrides
             c_, ky_, kx_ = self.src_dev
@@ -621,6 +626,16 @@ def _grad_out(out, shape, like):
 # the LDS-DMA / transposed-read weight-gradient kernel (round 3): one 8-wave block per CU -> ONE round of <= 256 blocks (every
 # further split is 2 x 147 KB of partial sums written and re-read by the scatter), >= min_tiles pixel tiles per block
 WGRAD_TR = {"value": True, "blocks": 256, "min_tiles": 8, "form": 2, "blocks2": 512}    # form 2: two 256-thread blocks per CU
+
+
+def presplit(x):
+    """fp32 NHWC -> the pre-split layout (experiment, ppst_conv_args.in_presplit): same shape / dtype container, per pixel and
+    8-channel group 32 bytes [hi x 8 | lo x 8] bf16."""
+    ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    y = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+    check(lib.ppst_presplit(_p(x), _p(y), B * H * W, C, ld, C, _stream()), "ppst_presplit")
+    return y
 
 
 def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=None, bias_accumulate=False, want_bias=False):
