@@ -414,7 +414,8 @@ int ppst_conv_wgrad_tr2(const void* x, const void* dy, const void* steps, const 
 /* dw[n*sn + (src_c+k)*sc + ky*sy + kx*sx] (+)= scale * sum_splits partial[.][step][n][k] */
 int ppst_wgrad_scatter(const void* partial, const void* src_c, const void* src_ky, const void* src_kx,
                        void* dw, int64_t sn, int64_t sc, int64_t sy, int64_t sx, int cout, int nsteps,
-                       int splits, float scale, int accumulate, void* stream);
+                       int splits, float scale, int accumulate, const void* csum, void* db, int csum_rows, int db_accumulate,
+                       void* stream);   /* csum (NULL or [csum_rows][cout] from ppst_conv_wgrad_tr*): db[n] (+)= sum of its rows */
 /* FromRGB (Cin <= 4) weight gradient: dw[n][c] (+)= scale * sum_p dy[p][n]*x[p][c] */
 int64_t ppst_wgrad_small_cin_ws(int64_t npix, int cin, int cout);
 int ppst_wgrad_small_cin(const void* x, const void* dy, void* dw, void* ws, int64_t npix, int cin,

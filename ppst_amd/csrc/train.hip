@@ -831,7 +831,15 @@ __global__ __launch_bounds__(256) void wgrad_scatter_kernel(const float* __restr
                                                             const int* __restrict__ src_ky, const int* __restrict__ src_kx,
                                                             float* __restrict__ dw, int64_t sn, int64_t sc, int64_t sy, int64_t sx,
                                                             int cout, int nsteps, int splits, float scale, int accumulate,
-                                                            int64_t total) {
+                                                            int64_t total, const float* __restrict__ csum, float* __restrict__ db,
+                                                            int csum_rows, int db_accumulate) {
+  // the bias gradient rides along: column sums of the weight-gradient kernel's per-block partial sums of dy (fixed order)
+  if (csum)
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < cout; n += (int64_t)gridDim.x * 256) {
+      float v = 0.f;
+      for (int r = 0; r < csum_rows; ++r) v += csum[(int64_t)r * cout + n];
+      db[n] = db_accumulate ? db[n] + v : v;
+    }
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
     int k = (int)(t & 31);
     int64_t r = t >> 5;
@@ -846,14 +854,15 @@ __global__ __launch_bounds__(256) void wgrad_scatter_kernel(const float* __restr
 }
 extern "C" int ppst_wgrad_scatter(const void* partial, const void* src_c, const void* src_ky, const void* src_kx, void* dw,
                                   int64_t sn, int64_t sc, int64_t sy, int64_t sx, int cout, int nsteps, int splits, float scale,
-                                  int accumulate, void* stream) {
-  if (cout <= 0 || nsteps <= 0 || splits <= 0) return PPST_EINVAL;
-  if (!partial || !src_c || !src_ky || !src_kx || !dw) return PPST_ENULL;
+                                  int accumulate, const void* csum, void* db, int csum_rows, int db_accumulate, void* stream) {
+  if (cout <= 0 || nsteps <= 0 || splits <= 0 || (csum && csum_rows <= 0)) return PPST_EINVAL;
+  if (!partial || !src_c || !src_ky || !src_kx || !dw || (csum && !db)) return PPST_ENULL;
   int64_t total = (int64_t)nsteps * cout * 32;
   int64_t blocks = cdiv64(total, 256);
   if (blocks > 4096) blocks = 4096;
   PPST_LAUNCH(wgrad_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)partial, (const int*)src_c,
-              (const int*)src_ky, (const int*)src_kx, (float*)dw, sn, sc, sy, sx, cout, nsteps, splits, scale, accumulate, total);
+              (const int*)src_ky, (const int*)src_kx, (float*)dw, sn, sc, sy, sx, cout, nsteps, splits, scale, accumulate, total,
+              (const float*)csum, (float*)db, csum_rows, db_accumulate);
   return PPST_LAUNCH_CHECK();
 }
 

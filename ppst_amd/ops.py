@@ -700,13 +700,16 @@ def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=No
             dw.zero_()
     sn, sc, sy, sx = plan.wstrides
     c_, ky_, kx_ = plan.src_dev
+    db = None
+    if csum is not None:         # the split reduction also sums the bias partials: no launch of its own
+        db = _grad_out(bias_out, (cout,), x)
     check(lib.ppst_wgrad_scatter(_p(partial), _p(c_), _p(ky_), _p(kx_), _p(dw), sn, sc, sy, sx, cout, plan.nsteps, splits,
-                                 plan.scale, 1 if (accumulate and out is not None) else 0, _stream()), "ppst_wgrad_scatter")
+                                 plan.scale, 1 if (accumulate and out is not None) else 0, _p(csum), _p(db),
+                                 csum.shape[0] if csum is not None else 0, 1 if (bias_accumulate and bias_out is not None) else 0,
+                                 _stream()), "ppst_wgrad_scatter")
     if not want_bias:
         return dw
-    if csum is not None:
-        db = colsum(csum, out=bias_out, accumulate=bias_accumulate)
-    else:
+    if csum is None:
         db = colsum(dy.as_strided((dy.shape[0] * oh * ow, cout), (dy_ld, 1)), out=bias_out, accumulate=bias_accumulate)
     return dw, db
 

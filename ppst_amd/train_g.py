@@ -171,33 +171,54 @@ class GeneratorTrainer:
         return A.instance_norm(y, st)
 
     # ------------------------------------------------------------ E2 (encoder_col.py:150-251)
-    def _e2_head(self, tag, x, mask=None):
+    def _e2_heads(self, tag, items):
+        """The projection head of level ``tag`` (encoder_col.py:162-168, 217-245: GAP || GMP of x * mask -> conv1x1 as a linear ->
+        three ReLU + linear projectors -> F.normalize) for several (feature map, mask) pairs at once: the pooled vectors are
+        stacked and go through the shared linears as ONE batch -- the same arithmetic per row (the weight gradients sum over rows
+        either way), a chain of launches per level instead of one per head (76 heads per generator iteration)."""
         P = self.E2.p
-        v = A.GapGmpFn.apply(x, mask)
+        vs = [A.GapGmpFn.apply(x, mask) for x, mask in items]
+        v = vs[0] if len(vs) == 1 else torch.cat(vs, 0)
         v = A.linear(v, P("conv1x1_%s.weight" % tag), P("conv1x1_%s.bias" % tag))
         q = "projector%s." % tag
         for i in (1, 3, 5):
             v = A.linear(v, P(q + "%d.weight" % i), P(q + "%d.bias" % i), relu_in=True)
-        return A.L2NormFn.apply(v, 1e-12, 1)
+        v = A.L2NormFn.apply(v, 1e-12, 1)
+        if len(vs) == 1:
+            return [v]
+        B = vs[0].shape[0]
+        return [v[i * B:(i + 1) * B] for i in range(len(vs))]
 
     def encoder_col(self, img, mask=None, corrmatrix=None):
         net = self.E2
         feats = [self._from_rgb(net, img, "FromRGB.")]
         for i in range(3):
             feats.append(self._res_block(net, feats[-1], "DownToGlobalCode1.ResBlockDownBy%d." % (2 ** i), norm=False))
-        vectors = [self._e2_head(t, f) for t, f in zip(TAGS, feats)]
-        vectors_w, pm, pmw, warped = [], [], [], None
-        if corrmatrix is not None:
-            warped = self._warp_levels(feats, corrmatrix)
-            vectors_w = [self._e2_head(t, f) for t, f in zip(TAGS, warped)]
-        if mask is not None:
-            levels = net._mask_planes(mask)
-            sw = net._mask_planes(glue.swap(mask)) if warped is not None else None
-            for lvl, (t, f) in enumerate(zip(TAGS, feats)):
+        warped = self._warp_levels(feats, corrmatrix) if corrmatrix is not None else None
+        levels = net._mask_planes(mask) if mask is not None else None
+        sw = net._mask_planes(glue.swap(mask)) if (mask is not None and warped is not None) else None
+        vectors, vectors_w, pm, pmw = [], [], [], []
+        for lvl, (t, f) in enumerate(zip(TAGS, feats)):
+            # every head of this level in one batch, in the reference's order of use
+            items = [(f, None)]
+            if warped is not None:
+                items.append((warped[lvl], None))
+            if mask is not None:
                 for i in range(3):
-                    pm.append(self._e2_head(t, f, levels[lvl][..., i].contiguous()))
+                    items.append((f, levels[lvl][..., i].contiguous()))
                     if warped is not None:
-                        pmw.append(self._e2_head(t, warped[lvl], sw[lvl][..., i].contiguous()))
+                        items.append((warped[lvl], sw[lvl][..., i].contiguous()))
+            out = self._e2_heads(t, items)
+            vectors.append(out[0])
+            k = 1
+            if warped is not None:
+                vectors_w.append(out[k]); k += 1
+            if mask is not None:
+                for i in range(3):
+                    pm.append(out[k]); k += 1
+                    if warped is not None:
+                        pmw.append(out[k]); k += 1
+        if mask is not None:
             return vectors, pm, vectors_w, pmw
         return vectors, vectors_w
 
@@ -390,13 +411,22 @@ class GeneratorTrainer:
                 losses["image_warp_reg"] = metric(image_rec, real) * lam("lambda_Cycwarp", 0.0)
             if lam("lambda_Maskwarp", 10.0) > 0.0:
                 losses["Mask_warp"] = A.L1LossFn.apply(self.warp_mask(mask, corr), glue.swap(mask), lam("lambda_Maskwarp", 10.0))
-        rec = self.generator(sp, gl, noise)
+        style_con = lam("lambda_StyleCon", 1.0) > 0.0
+        both = None
+        if style_con:
+            # rec = G(sp, gl) and mix = G(swap(sp), gl_w) (ppst_model.py:182, :191) are independent: ONE generator pass over the
+            # batch of 2B (the same arithmetic per image; fuller grids and half the launches at the reference's B = 2), and the two
+            # masked E2 passes on them (:192-193) and the two D passes (:224-233) likewise
+            nz2 = {k: torch.cat((v, v), 0) for k, v in noise.items()} if noise is not None else None
+            both = self.generator(torch.cat((sp, glue.swap(sp)), 0), [torch.cat((a, b), 0) for a, b in zip(gl, gl_w)], nz2)
+            rec, mix = both[:B], both[B:]
+        else:
+            rec = self.generator(sp, gl, noise)
         if lam("lambda_L1", 3.0) > 0.0:
             losses["G_L1"] = A.L1LossFn.apply(rec, real, lam("lambda_L1", 3.0))
-        if lam("lambda_StyleCon", 1.0) > 0.0:
-            mix = self.generator(glue.swap(sp), gl_w, noise)
-            _, pro_3m, _, _ = self.encoder_col(mix, mask=glue.swap(mask))
-            _, pro_2m, _, _ = self.encoder_col(rec, mask=mask)
+        if style_con:
+            _, pro_32m, _, _ = self.encoder_col(both, mask=torch.cat((mask, glue.swap(mask)), 0))
+            pro_2m, pro_3m = [p_[:B] for p_ in pro_32m], [p_[B:] for p_ in pro_32m]
             sp_3 = self.encoder_con(mix)
             nz = {k: v[:B // 2] for k, v in noise.items()} if noise is not None else None
             cyc = self.generator(glue.swap(sp_3)[:B // 2], [g[:B // 2] for g in gl], nz)
@@ -420,9 +450,12 @@ class GeneratorTrainer:
             losses["G_styleContmix"] = s1 if lsc == 1.0 else s1 * lsc
             losses["G_styleContrec"] = s2 if lsc == 1.0 else s2 * lsc
         if lam("lambda_GAN", 1.0) > 0.0:
-            losses["G_GAN_rec"] = A.LsganFn.apply(self.gan_logits(rec), 1.0, 0.5 * lam("lambda_GAN", 1.0))
-            if lam("lambda_StyleCon", 1.0) > 0.0:
-                losses["G_GAN_mix"] = A.LsganFn.apply(self.gan_logits(mix), 1.0, lam("lambda_GAN", 1.0))
+            if style_con:
+                pred = self.gan_logits(both)
+                losses["G_GAN_rec"] = A.LsganFn.apply(pred[:B], 1.0, 0.5 * lam("lambda_GAN", 1.0))
+                losses["G_GAN_mix"] = A.LsganFn.apply(pred[B:], 1.0, lam("lambda_GAN", 1.0))
+            else:
+                losses["G_GAN_rec"] = A.LsganFn.apply(self.gan_logits(rec), 1.0, 0.5 * lam("lambda_GAN", 1.0))
         return losses, metrics
 
     # ------------------------------------------------------------ one generator iteration
