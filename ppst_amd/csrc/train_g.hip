@@ -448,10 +448,44 @@ __global__ __launch_bounds__(256) void gap_gmp_bwd_kernel(const float* __restric
   }
 }
 // 16-B forms of the two passes (C % 4 == 0, 16-B aligned rows): one thread = 4 channels of one pixel
+// One thread = 4 channels of GMP_NP consecutive pixels: the first matching pixel of its strip is found in registers, then ONE
+// guarded atomicMin per channel (round 2 did the guard read + atomic per ELEMENT: four volatile loads per pixel, 140 us for a
+// (4, 512, 512, 32) tensor that a plain read moves in 30).  Needs hw % GMP_NP == 0 (a strip stays inside one image).
+#define GMP_NP 16
 __global__ __launch_bounds__(256) void gmp_argmax4_kernel(const float4* __restrict__ x, const float* __restrict__ mask,
                                                           const float* __restrict__ v, int* __restrict__ arg, unsigned hw, int C, int ld4,
-                                                          unsigned total, FastDiv d_c4, FastDiv d_hw) {
-  const int c4n = C >> 2;
+                                                          unsigned total_strips, FastDiv d_c4, FastDiv d_hwn) {
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total_strips; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned c4;
+    const unsigned strip = fd_divmod((unsigned)t64, d_c4, c4);     // strip index over all images (hw / GMP_NP strips per image)
+    const unsigned b = fd_div(strip, d_hwn);
+    const unsigned bp0 = strip * GMP_NP;                            // first (image-major) pixel of the strip
+    const int pix0 = (int)(bp0 - b * hw);
+    const float4 mv = *(const float4*)(v + (int64_t)b * 2 * C + C + c4 * 4);
+    int f0 = -1, f1 = -1, f2 = -1, f3 = -1;
+#pragma unroll
+    for (int j = GMP_NP - 1; j >= 0; --j) {                         // descending: the last assignment is the first match
+      const float m = mask ? mask[bp0 + j] : 1.f;
+      const float4 xv = x[(int64_t)(bp0 + j) * ld4 + c4];
+      if (xv.x * m == mv.x) f0 = j;
+      if (xv.y * m == mv.y) f1 = j;
+      if (xv.z * m == mv.z) f2 = j;
+      if (xv.w * m == mv.w) f3 = j;
+    }
+    int* ap = arg + (int64_t)b * C + c4 * 4;
+    // masked pooling makes ties massive (every masked-out pixel is 0 = the maximum of an all-negative channel): read the current
+    // winner first -- a stale value is only larger, so at worst an unnecessary atomic -- instead of 10^5 atomics on one address
+    const volatile int* cur = ap;
+    if (f0 >= 0 && pix0 + f0 < cur[0]) atomicMin(ap, pix0 + f0);
+    if (f1 >= 0 && pix0 + f1 < cur[1]) atomicMin(ap + 1, pix0 + f1);
+    if (f2 >= 0 && pix0 + f2 < cur[2]) atomicMin(ap + 2, pix0 + f2);
+    if (f3 >= 0 && pix0 + f3 < cur[3]) atomicMin(ap + 3, pix0 + f3);
+  }
+}
+// (the per-element form: any hw)
+__global__ __launch_bounds__(256) void gmp_argmax4e_kernel(const float4* __restrict__ x, const float* __restrict__ mask,
+                                                           const float* __restrict__ v, int* __restrict__ arg, unsigned hw, int C, int ld4,
+                                                           unsigned total, FastDiv d_c4, FastDiv d_hw) {
   for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
     unsigned c4;
     const unsigned bpu = fd_divmod((unsigned)t64, d_c4, c4);
@@ -461,15 +495,11 @@ __global__ __launch_bounds__(256) void gmp_argmax4_kernel(const float4* __restri
     const float4 mv = *(const float4*)(v + (int64_t)b * 2 * C + C + c4 * 4);
     int* ap = arg + (int64_t)b * C + c4 * 4;
     const int pix = (int)(bpu - b * hw);
-    // masked pooling makes ties massive (every masked-out pixel is 0 = the maximum of an all-negative channel): read the
-    // current winner first -- a stale value is only larger, so at worst an unnecessary atomic -- instead of 10^5 atomics on
-    // one address
     const volatile int* cur = ap;
     if (xv.x * m == mv.x && pix < cur[0]) atomicMin(ap, pix);
     if (xv.y * m == mv.y && pix < cur[1]) atomicMin(ap + 1, pix);
     if (xv.z * m == mv.z && pix < cur[2]) atomicMin(ap + 2, pix);
     if (xv.w * m == mv.w && pix < cur[3]) atomicMin(ap + 3, pix);
-    (void)c4n;
   }
 }
 __global__ __launch_bounds__(256) void gap_gmp_bwd4_kernel(const float* __restrict__ mask, const int* __restrict__ arg,
@@ -502,8 +532,15 @@ extern "C" int ppst_gap_gmp_bwd(const void* x, const void* mask, const void* v, 
   if (e != hipSuccess) return (int)e;
   if (C % 4 == 0 && ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)v | (uintptr_t)g | (uintptr_t)dx | (uintptr_t)arg_ws) % 16) == 0) {
     const int64_t t4 = total / 4;
-    PPST_LAUNCH(gmp_argmax4_kernel, dim3(tg_grid(t4)), dim3(256), 0, as_stream(stream), (const float4*)x, (const float*)mask,
-                (const float*)v, (int*)arg_ws, (unsigned)hw, C, ld / 4, (unsigned)t4, make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)hw));
+    if (hw % GMP_NP == 0) {
+      const int64_t strips = t4 / GMP_NP;
+      PPST_LAUNCH(gmp_argmax4_kernel, dim3(tg_grid(strips)), dim3(256), 0, as_stream(stream), (const float4*)x, (const float*)mask,
+                  (const float*)v, (int*)arg_ws, (unsigned)hw, C, ld / 4, (unsigned)strips, make_fastdiv((unsigned)(C / 4)),
+                  make_fastdiv((unsigned)(hw / GMP_NP)));
+    } else {
+      PPST_LAUNCH(gmp_argmax4e_kernel, dim3(tg_grid(t4)), dim3(256), 0, as_stream(stream), (const float4*)x, (const float*)mask,
+                  (const float*)v, (int*)arg_ws, (unsigned)hw, C, ld / 4, (unsigned)t4, make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)hw));
+    }
     PPST_LAUNCH(gap_gmp_bwd4_kernel, dim3(tg_grid(t4)), dim3(256), 0, as_stream(stream), (const float*)mask, (const int*)arg_ws,
                 (const float*)g, (float4*)dx, (unsigned)hw, C, accumulate, (unsigned)t4, make_fastdiv((unsigned)(C / 4)),
                 make_fastdiv((unsigned)hw));
