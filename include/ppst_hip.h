@@ -181,8 +181,9 @@ typedef struct ppst_conv_args {
   int32_t in_c, in_act;          /* channel count of the in_scale_shift table; PPST_ACT_* */
   int32_t flop_steps;            /* steps that carry real weights (profiling only; 0 = nsteps) */
   int32_t tile_rows;             /* (32 only with variant 7, 24 only with variant 9) 16: 16x16-pixel tiles, 512- (bn 128) / 256-thread blocks, 1 block per CU;
-                                    8:  8x16-pixel tiles, 256- / 128-thread blocks, 2 blocks per CU -- with halo=1
-                                    every chunk of the step table must then span >= 2 steps */
+                                    8:  8x16-pixel tiles, 256-thread blocks, 2 blocks per CU, a two-slot activation ring: variant 0,
+                                    bn 128, halo 1, precision 0 and the early_a promise (chunks of >= 2 steps).  Bit-identical
+                                    outputs; for launches whose 16-row grid would under-fill the chip */
   int32_t a_slots;               /* depth of the activation-tile ring in LDS: 0 = default (3).  1 or 2 may be given when
                                     NO group of the step table has more chunks (steps with new_chunk = 1) than that:
                                     with bn = 64 the smaller footprint lets two blocks share a CU (small-K layers are
@@ -230,7 +231,7 @@ int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream);
 /* fp32 NHWC [npix][x_ld] -> the pre-split layout of ppst_conv_args.in_presplit in y [npix][y_ld] (C % 8 == 0) */
 int ppst_presplit(const void* x, void* y, int64_t npix, int C, int x_ld, int y_ld, void* stream);
 /* 1 when the library was built with PPST_EXPERIMENTS=1: the measured-and-off forms (variants 1 / 3 / 7 / 8 / 9, precision 4,
- * tile_rows 8) are then compiled in; the production build returns PPST_EINVAL for them. */
+ * in_presplit) are then compiled in; the production build returns PPST_EINVAL for them. */
 int ppst_has_experiments(void);
 /* Exact-fp32 twin of ppst_conv2d_mfma (v_mfma_f32_32x32x2_f32; a->wpack, bn, precision, a_slots, early_a are ignored):
  * same step table / padding / epilogue semantics, weights read from the fp32 tensor itself -- element (n, c, ky, kx) at

@@ -971,8 +971,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
        !(a->variant == 0 && a->tile_rows == 8 && a->bn == 128 && a->halo == 1 && a->early_a && a->precision == 0)) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
     return PPST_EINVAL;
 #ifndef PPST_EXPERIMENTS
-  if (a->variant == 1 || a->variant == 3 || a->variant == 7 || a->variant == 8 || a->variant == 9 || a->precision == 4 || a->tile_rows == 8 ||
-      a->in_presplit)
+  if (a->variant == 1 || a->variant == 3 || a->variant == 7 || a->variant == 8 || a->variant == 9 || a->precision == 4 || a->in_presplit)
     return PPST_EINVAL;          // experiment forms: not in this build
 #endif
   // pre-split input (experiment): the 8-wave tile kernel only, chunks of >= 4 steps (the caller's promise with early_a), no
@@ -1050,9 +1049,13 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   // 145 / 112) puts two blocks on a CU, so one block's loads and stores overlap the other's MFMAs
 #ifdef PPST_EXPERIMENTS
   if (a->in_presplit) PPST_LAUNCH((conv_mfma_kernel<4, 2, 1, true, false, 0, false, false, true>), dim3(blocks), dim3(512), 0, st, k);
-  else if (a->tile_rows == 8) launch_conv<2, 2, 1, true, 2>(k, blocks, st);
   else
 #endif
+  // 8 x 16-px tiles, two 4-wave blocks per CU: the same per-pixel MFMA sequence as the 16-row tile (bit-identical outputs); a
+  // wash on full grids, but twice the blocks where ONE small image per launch leaves the chip under-filled
+  // (64 x 64 layers of the train step at batch 2: 64 blocks for 256 CUs)
+  if (a->tile_rows == 8) launch_conv<2, 2, 1, true, 2>(k, blocks, st);
+  else
   if (a->bn == 64 && x3 && a->halo == 1 && a->a_slots == 1) launch_conv<4, 1, 1, true, 1>(k, blocks, st);
   else if (a->bn == 64 && x3 && a->halo == 0 && a->a_slots == 1) launch_conv<4, 1, 0, true, 1>(k, blocks, st);
   else if (a->bn == 64 && x3 && a->halo == 0 && a->a_slots == 2) launch_conv<4, 1, 0, true, 2>(k, blocks, st);

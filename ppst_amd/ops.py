@@ -47,6 +47,23 @@ TWO_BLOCK_128 = {"value": False}   # experiment: variant 3 (see __call__) for th
 # round 3: the tile kernel itself as two 4-wave blocks per CU (8 x 16 px x 128 ch tiles, 64 px x 64 ch waves, TWO activation slots,
 # 77 KB of LDS each) for the Cout = 128-class layers: one block's prologue / epilogue / barrier waits overlap the other's MFMAs
 TWO_BLOCK_8ROW = {"value": False, "min_blocks": 64}
+# Batch-aware kernel choice (the TRAINING path only: the trainers switch it on around their passes).  The inference recipes keep
+# the batch out of the choice on purpose (a shard of a batch reproduces the whole batch bit for bit); the train step runs 64 x 64
+# layers at batch 1-4, where one launch has 32-128 blocks for 256 CUs: with fewer than ``fill`` blocks a Cout % 256 layer leaves
+# the N-256 kernel for the tile kernel (twice the N tiles) and the tile kernel takes its 8-row form (twice the M tiles, two blocks
+# per CU).  Outputs are bit-identical across these forms; tile statistics differ in the last bit.
+BATCH_AWARE = {"value": False, "fill": 192}
+
+
+class batch_aware:
+    """``with ops.batch_aware():`` -- conv kernel choice may look at the batch size inside the block (the train step)."""
+
+    def __enter__(self):
+        self.prev = BATCH_AWARE["value"]
+        BATCH_AWARE["value"] = True
+
+    def __exit__(self, *exc):
+        BATCH_AWARE["value"] = self.prev
 FAT_MIN_BLOCKS = 32         # take the 256-channel tile only when ONE image still gives >= this many blocks (B = 8: one per CU)
 
 
@@ -424,7 +441,7 @@ class ConvPlan:
         self._packs[bn] = wpack
         return wpack
 
-    def choose_kernel(self, th, tw, oh, ow, H, W, osy):
+    def choose_kernel(self, th, tw, oh, ow, H, W, osy, B=None):
         """(variant, N tile, tile rows) of ppst_conv_args for one launch of this plan -- a function of the plan and of ONE
         image's geometry only.  The batch size is deliberately not an argument: every variant gives bit-identical outputs,
         but their tile statistics differ in the last bit (other summation tree), and a shard of a batch has to reproduce the
@@ -439,9 +456,13 @@ class ConvPlan:
             return variant, bn, rows                     # fp16x2 experiment / exact-fp32 verification: the tile kernel only
         tiles16 = ((th + 15) // 16) * ((tw + 15) // 16) * self.n_groups          # blocks PER IMAGE per N tile
         cv = CONV_VARIANT["value"]
-        if cv in (1, 3) or TWO_BLOCK_128["value"] or TWO_BLOCK_8ROW["value"] or KSPLIT_128["value"] or TILE24_128["value"] or TALL_TILE_128["value"]:
+        if cv in (1, 3) or TWO_BLOCK_128["value"] or KSPLIT_128["value"] or TILE24_128["value"] or TALL_TILE_128["value"]:
             _need_experiments("the requested conv variant")
         n256_ok = self.cout % 256 == 0 and tiles16 * (self.cout // 256) >= FAT_MIN_BLOCKS
+        aware = BATCH_AWARE["value"] and B is not None and not single and self.bn == 128 and self.early_a and self.halo == 1
+        if aware and n256_ok and tiles16 * (self.cout // 256) * B < BATCH_AWARE["fill"]:
+            n256_ok = False                              # under-filled: the tile kernel has twice the N tiles
+        small = aware and tiles16 * ((self.cout + 127) // 128) * B < BATCH_AWARE["fill"]
         if cv == 1 and not single and self.early_a and self.cout >= 128:
             variant, bn = 1, (256 if n256_ok else 128)
         elif cv in (2, 3) and self.early_a:
@@ -453,8 +474,8 @@ class ConvPlan:
             elif self.bn == 128 and (force3 or (TWO_BLOCK_128["value"] and
                                                 tiles16 * ((self.cout + 127) // 128) >= 2 * FAT_MIN_BLOCKS)):
                 variant = 3                              # two 4-wave blocks per CU, N tile 128, one activation slot
-            elif (self.bn == 128 and TWO_BLOCK_8ROW["value"] and self.halo == 1 and
-                  ((th + 7) // 8) * ((tw + 15) // 16) * self.n_groups * ((self.cout + 127) // 128) >= TWO_BLOCK_8ROW["min_blocks"]):
+            elif (self.bn == 128 and self.halo == 1 and (small or (TWO_BLOCK_8ROW["value"] and
+                  ((th + 7) // 8) * ((tw + 15) // 16) * self.n_groups * ((self.cout + 127) // 128) >= TWO_BLOCK_8ROW["min_blocks"]))):
                 rows = 8                                 # tile kernel, two 4-wave blocks per CU
             elif (self.bn == 128 and KSPLIT_128["value"] and getattr(self, "ksplit_ok", False)
                   and tiles16 * ((self.cout + 127) // 128) >= KSPLIT_128["min_blocks"]):
@@ -511,7 +532,7 @@ class ConvPlan:
             raise RuntimeError("residual must match the output shape %s, got %s" % ((B, oh, ow, self.cout), tuple(residual.shape)))
         for t, n in ((bias, "bias"), (noise, "noise"), (prelu, "prelu"), (residual, "residual")):
             _chk(t, n)
-        variant, bn, rows = self.choose_kernel(th, tw, oh, ow, H, W, osy)
+        variant, bn, rows = self.choose_kernel(th, tw, oh, ow, H, W, osy, B)
         st = None
         if stats:
             tiles = lib.ppst_conv_tiles(th, tw, rows)

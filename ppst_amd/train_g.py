@@ -594,10 +594,11 @@ class PPSTOptimizer:
 
     def train_one_step(self, data_i, total_steps_so_far=0):
         images_minibatch, mask_minibatch = self.prepare_images(data_i)
-        if self.toggle_training_mode() == "generator":
-            losses = self.train_discriminator_one_step(images_minibatch, mask_minibatch)
-        else:
-            losses = self.train_generator_one_step(images_minibatch, mask_minibatch)
+        with ops.batch_aware():         # batch 2: the 64 x 64 layers would leave three quarters of the chip idle (ops.BATCH_AWARE)
+            if self.toggle_training_mode() == "generator":
+                losses = self.train_discriminator_one_step(images_minibatch, mask_minibatch)
+            else:
+                losses = self.train_generator_one_step(images_minibatch, mask_minibatch)
         return {k: float(v.float().mean()) for k, v in losses.items()}      # util.to_numpy
 
     def train_generator_one_step(self, images, mask):

@@ -332,9 +332,9 @@ def t_conv_variants():
         tall = dict(ops.TALL_TILE_128)
         ksp = dict(ops.KSPLIT_128)
         t24 = dict(ops.TILE24_128)
-        # the production library carries the tile kernel (0) and its N-256 form (2); variants 1 / 3 / 7 / 8 / 9 and the 8-row
-        # two-block tile ("8row") are measured-and-off experiments, compiled only with PPST_EXPERIMENTS=1
-        todo = ((0, 384), (1, 1 << 30), (1, 0), (2, 0), (3, 0), (7, 0), (8, 0), (9, 0), ("8row", 0)) if ops.EXPERIMENTS else ((0, 384), (2, 0))
+        # the production library carries the tile kernel (0), its N-256 form (2) and its 8-row two-block form ("8row": under-filled
+        # grids of the train step); variants 1 / 3 / 7 / 8 / 9 are measured-and-off experiments, compiled only with PPST_EXPERIMENTS=1
+        todo = ((0, 384), (1, 1 << 30), (1, 0), (2, 0), (3, 0), (7, 0), (8, 0), (9, 0), ("8row", 0)) if ops.EXPERIMENTS else ((0, 384), (2, 0), ("8row", 0))
         row8 = dict(ops.TWO_BLOCK_8ROW)
         for variant, minb in todo:
             if variant == "8row":

@@ -99,7 +99,9 @@ def test_conv_entry_rejects_images_beyond_32bit_offsets():
     a.tile_rows = 24
     # ... and is an experiment kernel: accepted only by a PPST_EXPERIMENTS=1 build, refused by the production library
     assert _lib.lib.ppst_conv2d_mfma(ctypes.byref(a), None) == (0 if _lib.lib.ppst_has_experiments() else -1)
-    for variant, rows, prec in ((1, 16, 0), (3, 16, 0), (7, 32, 0), (8, 16, 0), (0, 8, 0), (0, 16, 4)):
+    a.variant, a.tile_rows, a.precision, a.halo = 0, 8, 0, 1          # the 8-row two-block form is a production kernel
+    assert _lib.lib.ppst_conv2d_mfma(ctypes.byref(a), None) == 0
+    for variant, rows, prec in ((1, 16, 0), (3, 16, 0), (7, 32, 0), (8, 16, 0), (0, 16, 4)):
         a.variant, a.tile_rows, a.precision, a.halo = variant, rows, prec, 1
         rc = _lib.lib.ppst_conv2d_mfma(ctypes.byref(a), None)
         assert rc == (0 if _lib.lib.ppst_has_experiments() else -1), (variant, rows, prec, rc)
