@@ -316,11 +316,11 @@ def test_grid_sharding_work_per_rank():
 def test_conv_kernel_choice_is_a_function_of_one_image():
     """ConvPlan.choose_kernel: which kernel family runs a launch.  All families give bit-identical outputs, but their tile
     statistics differ in the last bit, so the choice must depend on the plan and ONE image's geometry only (a shard of a batch
-    reproduces the whole batch bit for bit).  Structural: the batch size is not an argument.  Behavioural: the production
-    table of the swap path -- which layers go where -- and the contract that experiments stay off."""
-    import inspect
+    reproduces the whole batch bit for bit).  Structural: the batch size enters only inside ``ops.batch_aware()`` (the train
+    step: under-filled grids at batch 2), and is ignored outside it.  Behavioural: the production table of the swap path --
+    which layers go where -- and the contract that experiments stay off."""
     from ppst_amd import ops
-    assert "B" not in inspect.signature(ops.ConvPlan.choose_kernel).parameters
+    assert not ops.BATCH_AWARE["value"]
 
     def plan(kind, cin, cout, k, nsteps, halo, n_groups=1, precision=0, early_a=1):
         p = ops.ConvPlan.__new__(ops.ConvPlan)
@@ -341,6 +341,17 @@ def test_conv_kernel_choice_is_a_function_of_one_image():
     assert ck(plan("conv", 32, 32, 3, 9, 1), 512) == (6, 64, 16)
     assert ck(plan("s2d", 32, 64, 3, 10, 1), 256) == (5, 64, 16)
     assert ck(plan("s2d", 64, 128, 3, 20, 1), 128) == (0, 128, 16)               # Cout 128: tile kernel
+    # the batch changes nothing outside the train step ...
+    for B in (1, 2, 16):
+        assert plan("conv", 256, 256, 3, 72, 1).choose_kernel(64, 64, 64, 64, 64, 64, 1, B) == (0, 128, 16)
+        assert plan("conv", 512, 512, 3, 144, 1).choose_kernel(64, 64, 64, 64, 64, 64, 1, B) == (2, 256, 16)
+    # ... inside it an under-filled launch takes twice the N tiles (tile kernel instead of N-256) and twice the M tiles (8 rows)
+    with ops.batch_aware():
+        assert plan("conv", 256, 256, 3, 72, 1).choose_kernel(64, 64, 64, 64, 64, 64, 1, 2) == (0, 128, 8)
+        assert plan("conv", 512, 512, 3, 144, 1).choose_kernel(64, 64, 64, 64, 64, 64, 1, 2) == (0, 128, 8)
+        assert plan("conv", 512, 512, 3, 144, 1).choose_kernel(64, 64, 64, 64, 64, 64, 1, 16) == (2, 256, 16)
+        assert plan("conv", 128, 128, 3, 36, 1).choose_kernel(512, 512, 512, 512, 512, 512, 1, 2) == (0, 128, 16)
+    assert not ops.BATCH_AWARE["value"]
     # single-pass modes: the N-256 and streaming kernels are built for them, the experiments are not
     assert ck(plan("conv", 256, 256, 3, 72, 1, precision=3), 256) == (2, 256, 16)
     assert ck(plan("conv", 32, 32, 3, 9, 1, precision=1), 512) == (6, 64, 16)
