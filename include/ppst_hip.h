@@ -411,7 +411,8 @@ int ppst_conv_wgrad_tr(const void* x, const void* dy, const void* steps, const v
  * positive count); csum NULL or [splits][cout]. */
 int ppst_conv_wgrad_tr2(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial, void* csum,
                         int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps, int nchunks,
-                        int splits, void* stream);
+                        int splits, int max_taps, void* stream);   /* max_taps: 0 = unknown (<= 9); 1..4 = the caller's promise that
+                        no chunk of the table has more steps: with an even chunk count two chunks then share one block / dY image */
 /* dw[n*sn + (src_c+k)*sc + ky*sy + kx*sx] (+)= scale * sum_splits partial[.][step][n][k] */
 int ppst_wgrad_scatter(const void* partial, const void* src_c, const void* src_ky, const void* src_kx,
                        void* dw, int64_t sn, int64_t sc, int64_t sy, int64_t sx, int cout, int nsteps,

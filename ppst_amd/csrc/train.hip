@@ -543,15 +543,19 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr_kernel(const float* __re
 //     256 threads, 4 waves = 4 n slabs, each wave reduces over the tile's four 16-pixel groups.
 // Per tile: request (LDS-DMA, 49 pieces) -> wait -> convert (+ the bias column sums) -> MFMA; nothing inside the block overlaps,
 // the co-resident block does.
+// NCH chunks (32 input channels each) per block, at most TM taps per chunk: <1, 9> for 3x3 tables; <2, 4> for tables whose chunks
+// have <= 4 steps (transposed conv, stride-2 tables, 1x1): two input images share ONE dY image, i.e. a third fewer bytes per MFMA
+// where a 4-tap chunk would otherwise do 4/9 of the MFMA work of a 3x3 chunk per staged tile (blockIdx.y = pair of chunks).
+template <int NCH, int TM>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               const int4* __restrict__ steps, const int* __restrict__ chunk_start,
                                                               float* __restrict__ partial, float* __restrict__ csum, int B, int in_h,
                                                               int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
                                                               int tiles_x, int tiles_per_image, int tiles_total, int tiles_per_split) {
   constexpr int IMG_DY = WT_PX * 128 * 4, IMG_X = WT_XPX * 32 * 4;           // 32768 + 17408 bytes
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[IMG_DY + IMG_X];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[IMG_DY + NCH * IMG_X];
   unsigned char* const imdy = smem;                           // [slab 0..3][64 px][8 quads][16 B]
-  unsigned char* const imx = smem + IMG_DY;                   // [136 px][8 quads][16 B]
+  unsigned char* const imx = smem + IMG_DY;                   // NCH x [136 px][8 quads][16 B]
   const int tid = threadIdx.x, lane = tid & 63, nw = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, kb = lane >> 5;
   int bx, by, bz;                                             // XCD-aware block map (conv_wgrad_tr_kernel)
@@ -564,20 +568,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
     by = v % (int)gridDim.y; bz = v / (int)gridDim.y;
   }
   const int n0 = bx * 128;
-  const int s0 = chunk_start[by], s1 = chunk_start[by + 1];
-  const int T = s1 - s0;
-  const int chan = steps[s0].x;
-  int tdy[WG_MAXT], tdx[WG_MAXT];
+  int s0[NCH], T[NCH], chan[NCH];
+  int tdy[NCH][TM], tdx[NCH][TM];
 #pragma unroll
-  for (int t = 0; t < WG_MAXT; ++t) {
-    int4 d = steps[s0 + (t < T ? t : 0)];
-    tdy[t] = d.y; tdx[t] = d.z;
+  for (int ci = 0; ci < NCH; ++ci) {
+    s0[ci] = chunk_start[by * NCH + ci];
+    T[ci] = chunk_start[by * NCH + ci + 1] - s0[ci];
+    chan[ci] = steps[s0[ci]].x;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      int4 d = steps[s0[ci] + (t < T[ci] ? t : 0)];
+      tdy[ci][t] = d.y; tdx[ci][t] = d.z;
+    }
   }
-  f32x16 acc[WG_MAXT];
+  f32x16 acc[NCH][TM];
 #pragma unroll
-  for (int t = 0; t < WG_MAXT; ++t)
+  for (int ci = 0; ci < NCH; ++ci)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[ci][t][i] = 0.f;
   const int t_begin = bz * tiles_per_split;
   const int t_end = min(t_begin + tiles_per_split, tiles_total);
   const bool wave_live = n0 + nw * 32 < cout;
@@ -609,8 +619,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
     const int r = tile - b * tiles_per_image;
     const int ty0 = (r / tiles_x) * WG_TR, tx0 = (r - (r / tiles_x) * tiles_x) * WG_TC;
     __syncthreads();                                        // the previous tile's MFMA reads are done
-    // ---- LDS-DMA: 32 pieces of dY (slab s, pixels 8 j .. 8 j + 7: 8 x 128 B) + 17 of the input halo (8 pixels x 128 B)
-    for (int wi = nw; wi < 32 + 17; wi += 4) {
+    // ---- LDS-DMA: 32 pieces of dY (slab s, pixels 8 j .. 8 j + 7: 8 x 128 B) + 17 per chunk of the input halo (8 pixels x 128 B)
+    for (int wi = nw; wi < 32 + NCH * 17; wi += 4) {
       const float* src = g_wg_zero;
       unsigned char* dst;
       const int q = lane & 7;
@@ -620,10 +630,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
         if (y < oh && xx < ow && n < cout) src = dy + (((int64_t)b * oh + y) * ow + xx) * dy_ld + n;
         dst = imdy + wi * 1024;
       } else {
-        const int P = 8 * (wi - 32) + (lane >> 3);
+        const int ci = (wi - 32) / 17, pj = (wi - 32) - ci * 17;          // wave-uniform
+        const int P = 8 * pj + (lane >> 3);
         const int row = P / WT_XW, col = P - row * WT_XW;
         const int iy = ty0 - 1 + row, ix = tx0 - 1 + col;
-        if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) src = x + (((int64_t)b * in_h + iy) * in_w + ix) * in_ld + chan + q * 4;
+        if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w)
+          src = x + (((int64_t)b * in_h + iy) * in_w + ix) * in_ld + (NCH == 1 ? chan[0] : (ci == 0 ? chan[0] : chan[NCH - 1])) + q * 4;
         dst = imx + (wi - 32) * 1024;
       }
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
@@ -644,17 +656,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
       *(uint4*)u = sw ? make_uint4(lo.x, lo.y, hi.x, hi.y) : make_uint4(hi.x, hi.y, lo.x, lo.y);
     }
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {
-      const int i = tid + it * 256;
-      if (i < WT_XPX * 8) {
-        unsigned char* u = imx + i * 16;
-        const float4 v = *(const float4*)u;
-        uint2 hi, lo;
-        split4(v, hi, lo);
-        const int sw = (i >> 4) & 1;                          // pixel = i >> 3
-        *(uint4*)u = sw ? make_uint4(lo.x, lo.y, hi.x, hi.y) : make_uint4(hi.x, hi.y, lo.x, lo.y);
+    for (int ci = 0; ci < NCH; ++ci)
+#pragma unroll
+      for (int it = 0; it < 5; ++it) {
+        const int i = tid + it * 256;
+        if (i < WT_XPX * 8) {
+          unsigned char* u = imx + ci * IMG_X + i * 16;
+          const float4 v = *(const float4*)u;
+          uint2 hi, lo;
+          split4(v, hi, lo);
+          const int sw = (i >> 4) & 1;                        // pixel = i >> 3
+          *(uint4*)u = sw ? make_uint4(lo.x, lo.y, hi.x, hi.y) : make_uint4(hi.x, hi.y, lo.x, lo.y);
+        }
       }
-    }
     __syncthreads();
     if (wave_live) {
 #pragma unroll 1                                             // (unrolled, hipcc hoists 4 x 9 x 2 fragment addresses: 44 registers spilled)
@@ -662,21 +676,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
         const int row = ks >> 1, xh = (ks & 1) * 16;
         bf16x8 a_h, a_l;
         frag(imdy + nw * 8192 + (row * 32 + xh) * 128 + tr_unit, (qd >> 1) & 1, a_h, a_l);
-        const int pb0 = (row + 1 + tdy[0]) * WT_XW + xh + 1 + tdx[0];
-        bf16x8 b_h, b_l;
-        frag(imx + pb0 * 128 + tr_unit, (((pb0 & 3) + qd) >> 1) & 1, b_h, b_l);
 #pragma unroll
-        for (int t = 0; t < WG_MAXT; ++t) {
-          if (t < T) {
-            bf16x8 n_h = b_h, n_l = b_l;
-            if (t + 1 < WG_MAXT && t + 1 < T) {               // the next tap's fragments are requested before this tap's MFMAs
-              const int pb = (row + 1 + tdy[t + 1]) * WT_XW + xh + 1 + tdx[t + 1];
-              frag(imx + pb * 128 + tr_unit, (((pb & 3) + qd) >> 1) & 1, n_h, n_l);
+        for (int ci = 0; ci < NCH; ++ci) {
+          const unsigned char* const im = imx + ci * IMG_X;
+          const int pb0 = (row + 1 + tdy[ci][0]) * WT_XW + xh + 1 + tdx[ci][0];
+          bf16x8 b_h, b_l;
+          frag(im + pb0 * 128 + tr_unit, (((pb0 & 3) + qd) >> 1) & 1, b_h, b_l);
+#pragma unroll
+          for (int t = 0; t < TM; ++t) {
+            if (t < T[ci]) {
+              bf16x8 n_h = b_h, n_l = b_l;
+              if (t + 1 < TM && t + 1 < T[ci]) {              // the next tap's fragments are requested before this tap's MFMAs
+                const int pb = (row + 1 + tdy[ci][t + 1]) * WT_XW + xh + 1 + tdx[ci][t + 1];
+                frag(im + pb * 128 + tr_unit, (((pb & 3) + qd) >> 1) & 1, n_h, n_l);
+              }
+              acc[ci][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b_h, acc[ci][t], 0, 0, 0);
+              acc[ci][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_l, acc[ci][t], 0, 0, 0);
+              acc[ci][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_h, acc[ci][t], 0, 0, 0);
+              b_h = n_h; b_l = n_l;
             }
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b_h, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_l, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_h, acc[t], 0, 0, 0);
-            b_h = n_h; b_l = n_l;
           }
         }
       }
@@ -698,16 +716,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
   }
   if (!wave_live) return;
 #pragma unroll
-  for (int t = 0; t < WG_MAXT; ++t) {
-    if (t < T) {
-      float* o = partial + (((int64_t)bz * nsteps + s0 + t) * cout) * 32;
+  for (int ci = 0; ci < NCH; ++ci)
 #pragma unroll
-      for (int rg = 0; rg < 16; ++rg) {
-        int nn = n0 + nw * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kb;
-        if (nn < cout) o[(int64_t)nn * 32 + li] = acc[t][rg];
+    for (int t = 0; t < TM; ++t) {
+      if (t < T[ci]) {
+        float* o = partial + (((int64_t)bz * nsteps + s0[ci] + t) * cout) * 32;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+          int nn = n0 + nw * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kb;
+          if (nn < cout) o[(int64_t)nn * 32 + li] = acc[ci][t][rg];
+        }
       }
     }
-  }
 }
 
 // profiling brackets of conv_mfma.hip: a weight-gradient launch is recorded with info = {B, oh, ow, nsteps, cout, nchunks, splits, 0}
@@ -777,7 +797,7 @@ extern "C" int ppst_conv_wgrad_tr(const void* x, const void* dy, const void* ste
 // [splits][cout] partial column sums of dy
 extern "C" int ppst_conv_wgrad_tr2(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial, void* csum,
                                    int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
-                                   int nchunks, int splits, void* stream) {
+                                   int nchunks, int splits, int max_taps, void* stream) {
   if (B < 0 || in_h <= 0 || in_w <= 0 || in_ld <= 0 || oh <= 0 || ow <= 0 || dy_ld < cout || cout <= 0 || nsteps <= 0 ||
       nchunks <= 0 || splits <= 0)
     return PPST_EINVAL;
@@ -787,12 +807,20 @@ extern "C" int ppst_conv_wgrad_tr2(const void* x, const void* dy, const void* st
   const int tiles_x = cdiv(ow, WG_TC), tiles_per_image = cdiv(oh, WG_TR) * tiles_x;
   const int tiles_total = B * tiles_per_image;
   const int tps = cdiv(tiles_total, splits);
-  dim3 grid(cdiv(cout, 128), nchunks, splits);
+  // max_taps: the caller's promise about the table (it lives on the device): <= 4 steps in every chunk and an even chunk count
+  // select the two-chunks-per-block form
+  const bool pair = max_taps > 0 && max_taps <= 4 && (nchunks & 1) == 0;
+  dim3 grid(cdiv(cout, 128), pair ? nchunks / 2 : nchunks, splits);
   const int slot = wgrad_prof_begin(B, oh, ow, cout, nsteps, g_wgrad_flop_steps, nchunks, splits, as_stream(stream));
   g_wgrad_flop_steps = 0;
-  PPST_LAUNCH(conv_wgrad_tr2_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (const int4*)steps,
-              (const int*)chunk_start, (float*)partial, (float*)csum, B, in_h, in_w, in_ld, oh, ow, dy_ld, cout, nsteps, tiles_x,
-              tiles_per_image, tiles_total, tps);
+  if (pair)
+    PPST_LAUNCH((conv_wgrad_tr2_kernel<2, 4>), grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (const int4*)steps,
+                (const int*)chunk_start, (float*)partial, (float*)csum, B, in_h, in_w, in_ld, oh, ow, dy_ld, cout, nsteps, tiles_x,
+                tiles_per_image, tiles_total, tps);
+  else
+    PPST_LAUNCH((conv_wgrad_tr2_kernel<1, WG_MAXT>), grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (const int4*)steps,
+                (const int*)chunk_start, (float*)partial, (float*)csum, B, in_h, in_w, in_ld, oh, ow, dy_ld, cout, nsteps, tiles_x,
+                tiles_per_image, tiles_total, tps);
   ppst_prof_end_(slot, as_stream(stream));
   return PPST_LAUNCH_CHECK();
 }

@@ -213,7 +213,7 @@ class ConvPlan:
     # changed), ~150 per D + G iteration: the tables are shared between plans of one geometry, only the weights are new.
     _GEOMETRY = {}
     _GEOM_ATTRS = ("kind", "cout", "cin", "k", "bn", "n_groups", "halo", "src", "max_chan", "wstrides", "nsteps", "flop_steps",
-                   "early_a", "ksplit_ok", "steps", "src_dev", "chunk_start", "chunks_per_group", "w4_shape")
+                   "early_a", "ksplit_ok", "steps", "src_dev", "chunk_start", "chunks_per_group", "w4_shape", "max_chunk_steps")
 
     def __init__(self, weight, kind="conv", scale=1.0, chan_base=0, precision=None):
         _chk(weight, "weight")
@@ -406,6 +406,7 @@ class ConvPlan:
         starts = [i for i, t in enumerate(steps) if t[3] == 1] + [len(steps)]
         lens = [b_ - a_ for a_, b_ in zip(starts[:-1], starts[1:])]
         self.early_a = 1 if (min(lens) >= 2 and ns_ >= 3) else 0
+        self.max_chunk_steps = max(lens)
         # conv_ksplit.hip stores a chunk one step PAIR before its first use: a 2-step chunk must not straddle two pairs
         self.ksplit_ok = bool(self.early_a and all(l_ >= 3 or (a_ % ns_) % 2 == 0 for a_, l_ in zip(starts[:-1], lens)))
         # 4 padding rows: the kernel prefetches the descriptor of step s+3 without a bounds test
@@ -646,7 +647,7 @@ def _grad_out(out, shape, like):
 
 # the LDS-DMA / transposed-read weight-gradient kernel (round 3): one 8-wave block per CU -> ONE round of <= 256 blocks (every
 # further split is 2 x 147 KB of partial sums written and re-read by the scatter), >= min_tiles pixel tiles per block
-WGRAD_TR = {"value": True, "blocks": 256, "min_tiles": 8, "form": 2, "blocks2": 512}    # form 2: two 256-thread blocks per CU
+WGRAD_TR = {"value": True, "blocks": 256, "min_tiles": 8, "form": 2, "blocks2": 512, "pair": True}    # form 2: two 256-thread blocks per CU
 
 
 def presplit(x):
@@ -686,6 +687,8 @@ def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=No
         # one 8-wave block per CU (256 slots): ~2 rounds of blocks, >= min_tiles pixel tiles (2 x 32 px) each; a block writes two
         # partial slots (one per tile row)
         form2 = WGRAD_TR["form"] == 2
+        if form2 and WGRAD_TR["pair"] and plan.max_chunk_steps <= 4 and nchunks % 2 == 0:
+            per = (nchunks // 2) * ((cout + 127) // 128)       # two chunks per block
         if form2:       # one partial slot per block, two blocks per CU: one round of <= 512 blocks
             gz = splits if splits is not None else max(1, min(max(1, WGRAD_TR["blocks2"] // per), max(1, tiles_total // WGRAD_TR["min_tiles"]), 2048))
             splits = gz
@@ -703,9 +706,13 @@ def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=No
     if PROF_ON["value"]:
         lib.ppst_wgrad_flop_steps(int(plan.flop_steps))
     if use_tr:
-        fn, name = (lib.ppst_conv_wgrad_tr2, "ppst_conv_wgrad_tr2") if WGRAD_TR["form"] == 2 else (lib.ppst_conv_wgrad_tr, "ppst_conv_wgrad_tr")
-        check(fn(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), _p(csum), B, H, W, in_ld, oh, ow,
-                 dy_ld, cout, plan.nsteps, nchunks, splits, _stream()), name)
+        if WGRAD_TR["form"] == 2:
+            check(lib.ppst_conv_wgrad_tr2(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), _p(csum), B, H, W, in_ld, oh, ow,
+                                          dy_ld, cout, plan.nsteps, nchunks, splits, plan.max_chunk_steps if WGRAD_TR["pair"] else 0,
+                                          _stream()), "ppst_conv_wgrad_tr2")
+        else:
+            check(lib.ppst_conv_wgrad_tr(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), _p(csum), B, H, W, in_ld, oh, ow,
+                                         dy_ld, cout, plan.nsteps, nchunks, splits, _stream()), "ppst_conv_wgrad_tr")
     else:
         # bf16x3 with register staging (round 2), or precision 2 (verification): the exact fp32 MFMA
         fn, name = ((lib.ppst_conv_wgrad_bf16x3, "ppst_conv_wgrad_bf16x3") if x3 else (lib.ppst_conv_wgrad_f32, "ppst_conv_wgrad_f32"))
