@@ -99,7 +99,7 @@ def _gather_rows(local, idx, total, world, like):
     return out.view((world, per) + shape[1:])
 
 
-def grid_exchange(local_c, local_s, n_content, n_style, world, gathered=None):
+def grid_exchange(local_c, local_s, n_content, n_style, world, gathered=None, like=None):
     """Phase 2: assemble the full tables {content i: (sp, fc)}, {style j: fs} from every rank's phase-1 output.
     ``gathered``: list over ranks of phase-1 outputs (single-process simulation of N ranks); otherwise the live
     process group is used.  Tensors keep the commands' NCHW shape; the storage layout is plain contiguous."""
@@ -115,7 +115,12 @@ def grid_exchange(local_c, local_s, n_content, n_style, world, gathered=None):
     if world == 1:
         return grid_exchange(None, None, n_content, n_style, 1, gathered=[(local_c, local_s)])
     ref = sp_c if sp_c is not None else (f_c if f_c is not None else f_s)
-    dev, h, w = ref.device, ref.shape[2], ref.shape[3]
+    if ref is not None:
+        dev, h, w = ref.device, ref.shape[2], ref.shape[3]
+    elif like is not None:          # a rank that owns no image (world > N + M) still takes part in both gathers, with zero rows
+        dev, h, w = like
+    else:
+        raise RuntimeError("this rank owns no image: pass like=(device, h, w) of the code grid")
     # rows of one rank: its contents' (sp | fc) = 768 channels, its styles' fs = 512 channels
     nc_max = (n_content + world - 1) // world + 1
     ns_max = (n_style + world - 1) // world + 1
@@ -155,7 +160,8 @@ def swapping_grid(model, contents, styles, rank=0, world=1, smooth=True, pair_ba
     """contents (N,3,H,W), styles (M,3,H,W) on this rank's GPU (every rank holds all images: they are small; the image
     passes and the pair passes are sharded).  Returns {(i, j): image (3,H,W)} for the pairs this rank owns."""
     local_c, local_s = grid_image_pass(model, contents, styles, rank, world, image_batch)
-    table_c, table_s = grid_exchange(local_c, local_s, contents.shape[0], styles.shape[0], world)
+    table_c, table_s = grid_exchange(local_c, local_s, contents.shape[0], styles.shape[0], world,
+                                     like=(contents.device, contents.shape[2] // 8, contents.shape[3] // 8))
     return grid_pair_pass(model, contents, styles, table_c, table_s, rank, world, smooth, pair_batch)
 
 

@@ -193,6 +193,11 @@ for j in range(M):
 mine = shard_pairs(N, M, rank, world)
 cnt = torch.tensor([float(len(mine))]); dist.all_reduce(cnt)
 assert cnt.item() == N * M
+# a rank that owns NO image (world > N + M; here one image for two ranks) still joins both gathers, with zero rows
+ci1, si1 = shard_images(1, 0, rank, world)
+assert (ci1, si1) == (([0], []) if rank == 0 else ([], []))
+tc1, ts1 = grid_exchange((ci1, fab(1, ci1, 256), fab(2, ci1, 512)), (si1, None), 1, 0, world, like=(torch.device("cpu"), h, h))
+assert sorted(tc1) == [0] and not ts1 and torch.equal(tc1[0][0], fab(1, [0], 256))
 if rank == 0:
     print("OK")
 dist.destroy_process_group()
