@@ -284,7 +284,7 @@ def bench_train(args, rank, world, dev, barrier, max_over_ranks):
                        "collectives": "flat gradient all-reduce per network (D 29.0 M, G 42.5 M, E2 27.0 M, E1 0.83 M fp32) + one "
                                       "[24, 2048] all_gather of the NCE keys"},
             # the dominant kernel of the step by time: the weight gradient (always bf16x3: three passes of the hi / lo split)
-            "roofline": roof(wg, "conv_wgrad_x3_kernel (conv weight gradients, bf16 hi+lo split on the matrix pipe; all launches of the step)", 3),
+            "roofline": roof(wg, "conv_wgrad_tr2_kernel / conv_wgrad_x3_kernel (conv weight gradients, bf16 hi+lo split on the matrix pipe; all launches of the step)", 3),
             "roofline_conv": roof(cv, "ppst_conv2d_mfma launches of the step: forward and input-gradient convs (same kernels as the swap line)", passes),
             "algorithmic_tflops_conv_and_wgrad": (sum(r[1] for r in detail)) / dt / 1e12,
             "losses": {**dl, **gl}}
