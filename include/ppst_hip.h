@@ -342,6 +342,16 @@ int ppst_gemm_nt_f32(const void* A, const void* Bm, void* C, int batch, int M, i
 /* fp32 MFMA GEMM, C[b] = A[b] (MxK row-major) * B[b] (KxN row-major, ldb) -> ldc */
 int ppst_gemm_nn_f32(const void* A, const void* Bm, void* C, int batch, int M, int N, int K,
                      int ldb, int ldc, void* stream);
+/* The same two products on the bf16 matrix pipe (torch.matmul of ppst_model.py:363 / :377 / :385, fp32 in and out).
+ * passes = 6: three bf16 planes per operand (all 24 mantissa bits), fp32-class results -- the cosine logits the softmax
+ *             multiplies by 1 / T = 100; K % 16 == 0.
+ * passes = 3: two planes (the convs' bf16x3, ~2^-16 relative per product) -- softmax rows times feature / gradient
+ *             matrices; K % 32 == 0.
+ * A, Bm 16-byte aligned; other values of passes: PPST_EINVAL. */
+int ppst_gemm_nt_split(const void* A, const void* Bm, void* C, int batch, int M, int N, int K,
+                       float alpha, int passes, void* stream);
+int ppst_gemm_nn_split(const void* A, const void* Bm, void* C, int batch, int M, int N, int K,
+                       int ldb, int ldc, int passes, void* stream);
 /* in-place row softmax of x/div (F.softmax(matmul/0.01, dim=-1), ppst_model.py:363) */
 int ppst_softmax_rows(void* x, int64_t rows, int cols, float div, void* stream);
 /* PPSTModel.warp unfold/fold plumbing (ppst_model.py:366-387): NCHW image

@@ -682,9 +682,9 @@ class CorrMFn(Function):
         ds = ops.softmax_rows_bwd_(corr, _c(g).clone(), 0.01)          # d/d(cosine matrix)
         dk = dq = None
         if ctx.needs_input_grad[1]:
-            dq = ops.corr_prep_bwd(ops.gemm_nn(ds, kn), q, 256).view(ctx.shape)
+            dq = ops.corr_prep_bwd(ops.gemm_nn(ds, kn, mode="x3"), q, 256).view(ctx.shape)
         if ctx.needs_input_grad[0]:
-            dk = ops.corr_prep_bwd(ops.gemm_nn(ops.transpose_last2(ds), qn), k, 256).view(ctx.shape)
+            dk = ops.corr_prep_bwd(ops.gemm_nn(ops.transpose_last2(ds), qn, mode="x3"), k, 256).view(ctx.shape)
         return dk, dq
 
 
@@ -697,7 +697,7 @@ class WarpGemmFn(Function):
         corr, V = _c(corr), _c(V)
         ctx.save_for_backward(corr, V)
         ctx.nlive = nlive
-        return ops.gemm_nn(corr, V)
+        return ops.gemm_nn(corr, V, mode="x3")
 
     @staticmethod
     def backward(ctx, g):
@@ -706,9 +706,9 @@ class WarpGemmFn(Function):
         dcorr = dV = None
         if ctx.needs_input_grad[0]:
             n = ctx.nlive
-            dcorr = ops.gemm_nt(g[..., :n].contiguous(), V[..., :n].contiguous())
+            dcorr = ops.gemm_nt(g[..., :n].contiguous(), V[..., :n].contiguous(), mode="x3")
         if ctx.needs_input_grad[1]:
-            dV = ops.gemm_nn(ops.transpose_last2(corr), g)
+            dV = ops.gemm_nn(ops.transpose_last2(corr), g, mode="x3")
         return dcorr, dV, None
 
 
@@ -718,12 +718,12 @@ class GemmConstBFn(Function):
     @staticmethod
     def forward(ctx, corr, M):
         ctx.save_for_backward(M)
-        return ops.gemm_nn(_c(corr), M)
+        return ops.gemm_nn(_c(corr), M, mode="x3")
 
     @staticmethod
     def backward(ctx, g):
         (M,) = ctx.saved_tensors
-        return ops.gemm_nt(_c(g), M), None
+        return ops.gemm_nt(_c(g), M, mode="x3"), None
 
 
 class FoldFn(Function):

@@ -1,10 +1,10 @@
 // Semantic-correspondence kernels (models/ppst_model.py:330-387):
 //   Rselfcorr  -> ppst_rselfcorr      (no 268 MB (B,64,4096,16,16) intermediate)
-//   corrm      -> ppst_corr_prep (centre + L2 normalise) + ppst_gemm_nt_f32 + ppst_softmax_rows
-//   warp / E2.warp -> ppst_gemm_nn_f32 (+ unfold/fold plumbing)
-// The two GEMMs use the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the logits are cosine
-// similarities divided by T = 0.01, so a bf16-class error would move softmax outputs by
-// ~1e-2 relative.  fp32 MFMA peak is 157 TFLOP/s; these GEMMs are ~33 GFLOP per swap.
+//   corrm      -> ppst_corr_prep (centre + L2 normalise) + ppst_gemm_nt_split (6 passes) + ppst_softmax_rows
+//   warp / E2.warp -> ppst_gemm_nn_split (3 passes) (+ unfold/fold plumbing)
+// The logits are cosine similarities divided by T = 0.01, so a bf16-class error would move softmax outputs by ~1e-2
+// relative: they are computed from three bf16 planes per operand (all of fp32's mantissa, six MFMA passes); rounds 1-2 used the
+// exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak), which stays for precision 2 and K % 16 != 0 (ppst_gemm_*_f32).
 #include "common.h"
 
 // ---------------------------------------------------------------- Rselfcorr --
@@ -241,6 +241,254 @@ extern "C" int ppst_gemm_nn_f32(const void* A, const void* Bm, void* C, int batc
   if (!A || !Bm || !C) return PPST_ENULL;
   return gemm_dispatch<false>((const float*)A, (const float*)Bm, (float*)C, batch, M, N, K, K, ldb, ldc, (int64_t)M * K,
                               (int64_t)K * ldb, (int64_t)M * ldc, 1.f, as_stream(stream));
+}
+
+// ------------------------------------------------ split-bf16 MFMA GEMM (fp32 in / out) --
+// The same products on the bf16 matrix pipe (2.5 PFLOP/s dense against the fp32 MFMA's 157 TFLOP/s):
+//   NP = 3 planes, 6 passes: x = h + m + l (8 + 8 + 8 mantissa bits = all of fp32); h.h + h.m + m.h + m.m + h.l + l.h, the
+//     dropped terms (m.l, l.m, l.l) are <= 2^-24 relative each: fp32-class results (the cosine logits, which the softmax
+//     multiplies by 1 / T = 100), ceiling 2500 / 6 = 417 TFLOP/s;
+//   NP = 2 planes, 3 passes: x = h + l, h.h + h.l + l.h (the convs' bf16x3: ~2^-16 relative per product), ceiling 833 TFLOP/s:
+//     the products of softmax rows with feature / gradient matrices.
+// WM x WN waves, each TM x TN tiles of v_mfma_f32_32x32x16_bf16; register prefetch TWO K tiles ahead, double-buffered LDS, one
+// barrier per K tile.  fp32 -> planes while staging.  A (and B when it is N x K) sit in LDS as [row][BK] bf16 with a 16-byte row
+// pad (ds_read_b128 operands, conflict-free: row stride = 4 x odd dwords); a K x N matrix B sits as [32-column slab][k][32]
+// bf16 and is read through ds_read_b64_tr_b16 (the k index of the operand is the ROW).
+// Two shapes: 2 x 2 waves of 64 x 64 (block 128 x 128, two blocks per CU) and 2 x 4 waves of 128 x 64 (block 256 x 256, one
+// block per CU).  Timing ablations of the 128 x 128 form on q.k^T (8 x 4096 x 4096 x 512, 3 passes): everything 0.50 ms, without
+// the global loads 0.30, staging alone (no MFMA) 0.36 -- its fp32 operand tiles ask the L2 for 4.3 GB per launch (12 TB/s);
+// the 256 x 256 block asks for half.
+template <bool B_NT, int NP, int BK, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_split_kernel(
+    const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
+    int64_t sA, int64_t sB, int64_t sC, float alpha) {
+  constexpr int NTHR = WM * WN * 64;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int ROW = BK * 2 + 16;                      // bytes per padded row of one plane
+  constexpr int PL_A = BM * ROW;
+  constexpr int PL_B = B_NT ? BN * ROW : (BN / 32) * BK * 64;
+  constexpr int STAGE = NP * (PL_A + PL_B);
+  constexpr int FA = BM * BK / 4 / NTHR, FB = BN * BK / 4 / NTHR;      // float4 per thread and operand tile
+  static_assert(FA * NTHR * 4 == BM * BK && FB * NTHR * 4 == BN * BK, "tile / thread count");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv / WN, wn = wv % WN;
+  const int li = lane & 31, kb = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  A += (int64_t)blockIdx.z * sA;
+  Bm += (int64_t)blockIdx.z * sB;
+  C += (int64_t)blockIdx.z * sC;
+  // operand tiles through buffer loads: descriptor = this batch element's matrix, per-item byte offset fixed for the block
+  // (-1 = row / column outside the matrix: the hardware returns zeros), the K-tile offset as SGPR soffset -- no per-load VALU
+  const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((int64_t)M * lda * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t brs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)Bm, 0, (int)((int64_t)(B_NT ? N : K) * ldb * 4), 0x00020000);
+  int aoff[FA], boff[FB];
+#pragma unroll
+  for (int it = 0; it < FA; ++it) {
+    const int idx = tid + it * NTHR, row = idx / (BK / 4), c4 = idx % (BK / 4);
+    aoff[it] = (m0 + row < M) ? ((m0 + row) * lda + c4 * 4) * 4 : -1;
+  }
+#pragma unroll
+  for (int it = 0; it < FB; ++it) {
+    const int idx = tid + it * NTHR;
+    if (B_NT) {
+      const int row = idx / (BK / 4), c4 = idx % (BK / 4);
+      boff[it] = (n0 + row < N) ? ((n0 + row) * ldb + c4 * 4) * 4 : -1;
+    } else {
+      const int k = idx / (BN / 4), n4 = idx % (BN / 4);
+      boff[it] = (n0 + n4 * 4 < N) ? (k * ldb + n0 + n4 * 4) * 4 : -1;
+    }
+  }
+  // two register sets: the loads of K tile t + 2 are issued while tile t is multiplied and tile t + 1 (requested one
+  // iteration earlier) waits in the other set -- a full iteration of MFMAs between a request and its first use
+  float4 ra0[FA], rb0[FB], ra1[FA], rb1[FB];
+  auto g_load = [&](float4 (&ra)[FA], float4 (&rb)[FB], int k0) {
+#if defined(GEMM_ABL) && (GEMM_ABL & 4)
+    if (kb >= 0) return;
+#endif
+    const int sa_off = k0 * 4, sb_off = B_NT ? k0 * 4 : k0 * ldb * 4;
+#pragma unroll
+    for (int it = 0; it < FA; ++it)
+      ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ars, aoff[it], sa_off, 0));
+#pragma unroll
+    for (int it = 0; it < FB; ++it)
+      rb[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(brs, boff[it], sb_off, 0));
+  };
+  // fp32 x 4 -> NP planes of bf16 x 4 (p[0] = h, then the successive remainders), two elements per v_cvt_pk_bf16_f32
+  auto planes = [](float4 v, uint2* p) {
+    typedef __bf16 __attribute__((ext_vector_type(2))) bf2;
+    typedef float __attribute__((ext_vector_type(2))) f2;
+    f2 r0 = {v.x, v.y}, r1 = {v.z, v.w};
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+      const unsigned q0 = __builtin_bit_cast(unsigned, __builtin_convertvector(r0, bf2));
+      const unsigned q1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf2));
+      p[pl] = make_uint2(q0, q1);
+      if (pl + 1 < NP) {
+        r0 -= (f2){__uint_as_float(q0 << 16), __uint_as_float(q0 & 0xffff0000u)};
+        r1 -= (f2){__uint_as_float(q1 << 16), __uint_as_float(q1 & 0xffff0000u)};
+      }
+    }
+  };
+  auto s_store = [&](const float4 (&ra)[FA], const float4 (&rb)[FB], int buf) {
+#if defined(GEMM_ABL) && (GEMM_ABL & 2)
+    if (kb >= 0) return;
+#endif
+    unsigned char* const sa = smem + buf * STAGE;
+    unsigned char* const sb = sa + NP * PL_A;
+#pragma unroll
+    for (int it = 0; it < FA; ++it) {
+      const int idx = tid + it * NTHR, row = idx / (BK / 4), c4 = idx % (BK / 4);
+      uint2 p[NP];
+      planes(ra[it], p);
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) *(uint2*)(sa + pl * PL_A + row * ROW + c4 * 8) = p[pl];
+    }
+#pragma unroll
+    for (int it = 0; it < FB; ++it) {
+      const int idx = tid + it * NTHR;
+      uint2 p[NP];
+      planes(rb[it], p);
+      if (B_NT) {
+        const int row = idx / (BK / 4), c4 = idx % (BK / 4);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) *(uint2*)(sb + pl * PL_B + row * ROW + c4 * 8) = p[pl];
+      } else {
+        const int k = idx / (BN / 4), n4 = idx % (BN / 4);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) *(uint2*)(sb + pl * PL_B + (n4 >> 3) * (BK * 64) + k * 64 + (n4 & 7) * 8) = p[pl];
+      }
+    }
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // transposed-read lane geometry (train.hip, conv_wgrad_tr_kernel): lane -> row 8 kb + qd (+ 4), column group 16 (g & 1) + 4 pp
+  const int g = lane >> 4, qd = (lane & 15) >> 2, pp = lane & 3;
+  const int tr_off = (8 * (g >> 1) + qd) * 64 + (16 * (g & 1) + 4 * pp) * 2;
+  auto compute = [&](int buf) {
+#if defined(GEMM_ABL) && (GEMM_ABL & 1)
+    if (kb >= 0) return;
+#endif
+    const unsigned char* const sa = smem + buf * STAGE;
+    const unsigned char* const sb = sa + NP * PL_A;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 fa[TM][NP], fb[TN][NP];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+          fa[i][pl] = *(const bf16x8*)(sa + pl * PL_A + ((wm * TM + i) * 32 + li) * ROW + (ks * 16 + kb * 8) * 2);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+          if (B_NT) {
+            fb[j][pl] = *(const bf16x8*)(sb + pl * PL_B + ((wn * TN + j) * 32 + li) * ROW + (ks * 16 + kb * 8) * 2);
+          } else {
+            typedef short __attribute__((ext_vector_type(4))) v4s;
+            const unsigned char* p0 = sb + pl * PL_B + (wn * TN + j) * (BK * 64) + ks * 16 * 64 + tr_off;
+            const v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p0));
+            const v4s b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p0 + 4 * 64));
+            fb[j][pl] = (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+          }
+        }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          // smallest terms first
+          if (NP == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][NP - 1], fb[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][NP - 1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+  // Every request and every staging store below is unconditional (tiles past the end re-read the last tile; their stores go
+  // to a buffer nobody reads again), and no branch sits between a request and its use: with a request under a branch hipcc's
+  // wait-count pass has to assume it was NOT issued and turns the counted wait in front of the older set's conversion into
+  // vmcnt(7..0) -- it waits for the youngest loads -- and LLVM sinks loads below a branch their users sit behind.
+  const int nk = K / BK;
+  auto tile_k0 = [&](int t) { return (t < nk ? t : nk - 1) * BK; };
+  g_load(ra0, rb0, 0);
+  s_store(ra0, rb0, 0);
+  __syncthreads();
+  g_load(ra0, rb0, tile_k0(1));
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    g_load(ra1, rb1, tile_k0(kt + 2));
+    __builtin_amdgcn_sched_barrier(0);                      // (the scheduler would move the requests down to their use)
+    compute(0);
+    s_store(ra0, rb0, 1);
+    __syncthreads();
+    g_load(ra0, rb0, tile_k0(kt + 3));
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    s_store(ra1, rb1, 0);
+    __syncthreads();
+  }
+  if (kt < nk) compute(0);                                  // odd tile count: the last tile sits in buffer 0
+  // C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + li;
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        const int m = m0 + (wm * TM + i) * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kb;
+        if (m < M && n < N) C[(int64_t)m * ldc + n] = acc[i][j][rg] * alpha;
+      }
+    }
+}
+
+// passes: 6 (fp32-class) | 3 (bf16x3).  K % 32 == 0 (3 passes) / K % 16 == 0 (6 passes).  The 256 x 256 block runs when its
+// grid still gives every CU a block.
+template <bool B_NT>
+static int gemm_split_dispatch(const float* A, const float* Bm, float* C, int batch, int M, int N, int K, int lda, int ldb, int ldc,
+                               int64_t sA, int64_t sB, int64_t sC, float alpha, int passes, hipStream_t st) {
+  const bool big = (int64_t)cdiv(M, 256) * cdiv(N, 256) * batch >= 224 && N > 128 && M > 128;
+#define GS(NP, BK, WM, WN, TM, TN)                                                                                                 \
+  PPST_LAUNCH((gemm_split_kernel<B_NT, NP, BK, WM, WN, TM, TN>), dim3(cdiv(M, WM * TM * 32), cdiv(N, WN * TN * 32), batch),        \
+              dim3(WM * WN * 64), 0, st, A, Bm, C, M, N, K, lda, ldb, ldc, sA, sB, sC, alpha)
+  if (passes == 6) {
+    if (big) GS(3, 16, 2, 4, 4, 2); else GS(3, 16, 2, 2, 2, 2);
+  } else {
+    if (big) GS(2, 16, 2, 4, 4, 2); else GS(2, 32, 2, 2, 2, 2);
+  }
+#undef GS
+  return PPST_LAUNCH_CHECK();
+}
+extern "C" int ppst_gemm_nt_split(const void* A, const void* Bm, void* C, int batch, int M, int N, int K, float alpha, int passes,
+                                  void* stream) {
+  if (batch < 0 || M <= 0 || N <= 0 || K <= 0 || (passes != 3 && passes != 6) || K % (passes == 6 ? 16 : 32)) return PPST_EINVAL;
+  if (batch == 0) return PPST_OK;
+  if (!A || !Bm || !C) return PPST_ENULL;
+  if (((uintptr_t)A | (uintptr_t)Bm) % 16 || (int64_t)M * K * 4 > 0x7fffffffll || (int64_t)N * K * 4 > 0x7fffffffll) return PPST_EINVAL;
+  return gemm_split_dispatch<true>((const float*)A, (const float*)Bm, (float*)C, batch, M, N, K, K, K, N, (int64_t)M * K,
+                                   (int64_t)N * K, (int64_t)M * N, alpha, passes, as_stream(stream));
+}
+extern "C" int ppst_gemm_nn_split(const void* A, const void* Bm, void* C, int batch, int M, int N, int K, int ldb, int ldc, int passes,
+                                  void* stream) {
+  if (batch < 0 || M <= 0 || N <= 0 || K <= 0 || (passes != 3 && passes != 6) || K % (passes == 6 ? 16 : 32) || N % 4 || ldb % 4 ||
+      ldb < N || ldc < N)
+    return PPST_EINVAL;
+  if (batch == 0) return PPST_OK;
+  if (!A || !Bm || !C) return PPST_ENULL;
+  if (((uintptr_t)A | (uintptr_t)Bm) % 16 || (int64_t)M * K * 4 > 0x7fffffffll || (int64_t)K * ldb * 4 > 0x7fffffffll) return PPST_EINVAL;
+  return gemm_split_dispatch<false>((const float*)A, (const float*)Bm, (float*)C, batch, M, N, K, K, ldb, ldc, (int64_t)M * K,
+                                    (int64_t)K * ldb, (int64_t)M * ldc, 1.f, passes, as_stream(stream));
 }
 
 // ------------------------------------------------------------------ softmax --

@@ -43,7 +43,7 @@ class StyleGAN2ResnetEncodercol(BaseNetwork):
             assert f.shape[1] == f.shape[2] and f.shape[1] % 64 == 0, "correspondence needs square inputs (64x64 code grid)"
             ops.avgpool(f, f.shape[1] // 64, out=V[..., off:off + c])
             off += c
-        Wv = ops.gemm_nn(corr, V.view(B, 4096, sum(CH))).view(B, 64, 64, sum(CH))
+        Wv = ops.gemm_nn(corr, V.view(B, 4096, sum(CH)), mode="x3").view(B, 64, 64, sum(CH))
         out, off = [], 0
         for f, c in zip(feats, CH):
             sl = Wv[..., off:off + c]

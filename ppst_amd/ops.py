@@ -1270,25 +1270,50 @@ def corr_prep(fea, ncenter=256):
     return y
 
 
-def gemm_nt(A, Bm, alpha=1.0):
-    """A (b,M,K), Bm (b,N,K) -> (b,M,N) = alpha * A @ Bm^T (exact-fp32 MFMA)."""
+GEMM_MODE = {"value": None}    # None: per call site ("x6" fp32-class / "x3" bf16x3); "f32": the exact-fp32 MFMA kernels everywhere
+
+
+def _gemm_passes(mode, K):
+    """0 = exact-fp32 MFMA kernel, 6 / 3 = bf16 planes (ppst_gemm_*_split).  Exact-conv mode (precision 2) and shapes the
+    split kernels do not take (K % 16 / K % 32) use the fp32 kernel."""
+    mode = GEMM_MODE["value"] or mode or "x6"
+    if mode not in ("f32", "x6", "x3"):
+        raise ValueError("gemm mode %r" % (mode,))
+    if mode == "f32" or PRECISION["value"] == 2:
+        return 0
+    if mode == "x3" and K % 32 == 0:
+        return 3
+    return 6 if K % 16 == 0 else 0
+
+
+def gemm_nt(A, Bm, alpha=1.0, mode=None):
+    """A (b,M,K), Bm (b,N,K) -> (b,M,N) = alpha * A @ Bm^T.  mode: "x6" (default: three bf16 planes per operand, fp32-class),
+    "x3" (bf16x3, the convs' accuracy class), "f32" (fp32 MFMA)."""
     _chk(A); _chk(Bm)
     A, Bm = A.contiguous(), Bm.contiguous()
     b, M, K = A.shape
     N = Bm.shape[1]
     C = torch.empty((b, M, N), device=A.device, dtype=torch.float32)
-    check(lib.ppst_gemm_nt_f32(_p(A), _p(Bm), _p(C), b, M, N, K, float(alpha), _stream()), "ppst_gemm_nt_f32")
+    passes = _gemm_passes(mode, K)
+    if passes:
+        check(lib.ppst_gemm_nt_split(_p(A), _p(Bm), _p(C), b, M, N, K, float(alpha), passes, _stream()), "ppst_gemm_nt_split")
+    else:
+        check(lib.ppst_gemm_nt_f32(_p(A), _p(Bm), _p(C), b, M, N, K, float(alpha), _stream()), "ppst_gemm_nt_f32")
     return C
 
 
-def gemm_nn(A, Bm):
-    """A (b,M,K), Bm (b,K,N) -> (b,M,N) (exact-fp32 MFMA)."""
+def gemm_nn(A, Bm, mode=None):
+    """A (b,M,K), Bm (b,K,N) -> (b,M,N); mode as gemm_nt."""
     _chk(A); _chk(Bm)
     A, Bm = A.contiguous(), Bm.contiguous()
     b, M, K = A.shape
     N = Bm.shape[2]
     C = torch.empty((b, M, N), device=A.device, dtype=torch.float32)
-    check(lib.ppst_gemm_nn_f32(_p(A), _p(Bm), _p(C), b, M, N, K, N, N, _stream()), "ppst_gemm_nn_f32")
+    passes = _gemm_passes(mode, K) if N % 4 == 0 else 0
+    if passes:
+        check(lib.ppst_gemm_nn_split(_p(A), _p(Bm), _p(C), b, M, N, K, N, N, passes, _stream()), "ppst_gemm_nn_split")
+    else:
+        check(lib.ppst_gemm_nn_f32(_p(A), _p(Bm), _p(C), b, M, N, K, N, N, _stream()), "ppst_gemm_nn_f32")
     return C
 
 

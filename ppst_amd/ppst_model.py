@@ -246,9 +246,9 @@ class PPSTModel(nn.Module):
         if H != h * w:
             s = int(((h * w) / H) ** 0.5)
             patches = ops.unfold_patches(fea, s)
-            return ops.fold_patches(ops.gemm_nn(corr, patches), c, h, w, s)
+            return ops.fold_patches(ops.gemm_nn(corr, patches, mode="x3"), c, h, w, s)
         f = to_nhwc(fea).reshape(b, h * w, c)
-        return as_nchw(ops.gemm_nn(corr, f.contiguous()).view(b, h, w, c))
+        return as_nchw(ops.gemm_nn(corr, f.contiguous(), mode="x3").view(b, h, w, c))
 
     def decode(self, spatial_code, global_code, target=None):
         out = self.G(spatial_code, global_code, noise=self.noise)

@@ -580,10 +580,14 @@ def t_corr():
     report("corr_prep", ops.corr_prep(g(nhwc(f)).reshape(2, 256, 512), 256), ref, 2e-6)
     for (b, M, N, K) in [(2, 256, 256, 512), (1, 4096, 4096, 512), (1, 130, 70, 64)]:
         A = torch.randn(b, M, K); Bm = torch.randn(b, N, K)
-        report("gemm_nt f32 %dx%dx%d" % (M, N, K), ops.gemm_nt(g(A), g(Bm), 0.5), 0.5 * torch.matmul(A.double(), Bm.double().transpose(1, 2)), 2e-6)
+        ref = 0.5 * torch.matmul(A.double(), Bm.double().transpose(1, 2))
+        for mode, tol in (("f32", 2e-6), ("x6", 2e-6), ("x3", 3e-5)):
+            report("gemm_nt %s %dx%dx%d" % (mode, M, N, K), ops.gemm_nt(g(A), g(Bm), 0.5, mode=mode), ref, tol)
     for (b, M, N, K) in [(2, 256, 480, 256), (1, 4096, 480, 4096), (1, 200, 192, 64), (1, 128, 32, 128)]:
         A = torch.randn(b, M, K); Bm = torch.randn(b, K, N)
-        report("gemm_nn f32 %dx%dx%d" % (M, N, K), ops.gemm_nn(g(A), g(Bm)), torch.matmul(A.double(), Bm.double()), 2e-6 if K <= 256 else 1e-5)
+        ref = torch.matmul(A.double(), Bm.double())
+        for mode, tol in (("f32", 2e-6 if K <= 256 else 1e-5), ("x6", 2e-6 if K <= 256 else 1e-5), ("x3", 3e-5)):
+            report("gemm_nn %s %dx%dx%d" % (mode, M, N, K), ops.gemm_nn(g(A), g(Bm), mode=mode), ref, tol)
     x = torch.randn(300, 4096) * 0.3
     report("softmax rows /0.01", ops.softmax_rows_(g(x).clone(), 0.01), F.softmax(x.double() / 0.01, -1), 2e-5)
     fa = torch.randn(1, 512, 64, 64); fb = torch.randn(1, 512, 64, 64)
@@ -962,6 +966,8 @@ def main():
         run(t_networks)
     if which == "prec":
         run(t_precision)
+    if which == "corr":
+        run(t_corr)
     if which == "convv":
         run(t_conv_variants)
         run(t_conv_variants_single_pass)

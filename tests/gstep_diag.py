@@ -265,14 +265,16 @@ def t_blocks2():
         full = torch.matmul(i["c"], i["v"])
         det = torch.matmul(i["c"].detach(), i["v"])
         return torch.cat((full[..., :32], det[..., 32:]), -1)
-    check_block("WarpGemmFn (corr live on 32 ch)", lambda i: A.WarpGemmFn.apply(i["c"], i["v"], 32), refwarp, dict(c=corr, v=V), tol=5e-6)
+    # (the warp products run as bf16x3 -- two bf16 planes per operand, ops.gemm_nn(mode="x3") -- like the convs: ~5e-6 relative
+    # against float64; the exact-fp32 kernel they replaced sat at 5e-7)
+    check_block("WarpGemmFn (corr live on 32 ch)", lambda i: A.WarpGemmFn.apply(i["c"], i["v"], 32), refwarp, dict(c=corr, v=V), tol=3e-5)
     mask = (torch.rand(2, 3, 32, 32) > 0.5).float()
     corr16 = torch.softmax(rn(2, 16, 16) * 2, -1)
 
     def gpuw(i):
         patches = ops.unfold_patches(mask.to(dev), 8)
         return nhwc(A.FoldFn.apply(A.GemmConstBFn.apply(i["c"], patches), 3, 32, 32, 8))   # NCHW -> the harness's NHWC
-    check_block("mask warp (GemmConstB + Fold)", gpuw, lambda i: O.model_warp(mask.double(), i["c"]), dict(c=corr16), tol=5e-6)
+    check_block("mask warp (GemmConstB + Fold)", gpuw, lambda i: O.model_warp(mask.double(), i["c"]), dict(c=corr16), tol=3e-5)
     # Cycwarp branch (ppst_model.py:175-179): image -> warp(corr) -> warp(swap(corr)); gradient to corr through both warps (the
     # second one also through its image operand), with an L1 stand-in for the injected perceptual metric
     from ppst_amd import glue
@@ -286,7 +288,7 @@ def t_blocks2():
 
     def ref_cyc(i):
         return O.model_warp(O.model_warp(img.double(), i["c"]), glue.swap(i["c"]))
-    check_block("Cycwarp double image warp", gpu_cyc, ref_cyc, dict(c=corr16), tol=5e-6)
+    check_block("Cycwarp double image warp", gpu_cyc, ref_cyc, dict(c=corr16), tol=3e-5)
     c_g = corr16.to(dev).requires_grad_(True)
     c_r = corr16.double().requires_grad_(True)
     lg = A.L1LossFn.apply(trw.warp_image(trw.warp_image(img.to(dev), c_g), glue.swap(c_g)), img.to(dev), 5.0)

@@ -40,6 +40,13 @@ def test_argument_errors_need_no_gpu():
     assert lib.ppst_fused_bias_act(None, None, None, None, -1, 1, 1, 3, 0, 0.2, 1.0, 0, None) == -1
     assert lib.ppst_fused_bias_act(None, None, None, None, 0, 1, 1, 3, 0, 0.2, 1.0, 0, None) == 0  # empty input
     assert lib.ppst_gemm_nt_f32(None, None, None, 1, 4, 4, 7, 1.0, None) == -1                      # K % 16
+    # split-bf16 GEMMs: passes in {3, 6}, K % 32 (3 passes) / K % 16 (6 passes), empty batch is a no-op, null data after that
+    assert lib.ppst_gemm_nt_split(None, None, None, 1, 4, 4, 32, 1.0, 4, None) == -1
+    assert lib.ppst_gemm_nt_split(None, None, None, 1, 4, 4, 16, 1.0, 3, None) == -1
+    assert lib.ppst_gemm_nt_split(None, None, None, 0, 4, 4, 16, 1.0, 6, None) == 0
+    assert lib.ppst_gemm_nt_split(None, None, None, 1, 4, 4, 16, 1.0, 6, None) == -3
+    assert lib.ppst_gemm_nn_split(None, None, None, 1, 4, 6, 32, 6, 6, 3, None) == -1                 # N % 4
+    assert lib.ppst_gemm_nn_split(None, None, None, 1, 4, 8, 32, 8, 8, 3, None) == -3
     assert lib.ppst_softmax_rows(None, 0, 4096, 0.01, None) == 0
     assert lib.ppst_conv_tiles(512, 512, 16) == 1024 and lib.ppst_conv_tiles(17, 16, 8) == 3
     # entry points added later in the round: same contract
