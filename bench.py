@@ -245,7 +245,11 @@ def bench_train(args, rank, world, dev, barrier, max_over_ranks):
     g = torch.Generator().manual_seed(7 + rank)
     lab = torch.randint(0, 3, (B, 32, 32), generator=g).repeat_interleave(16, 1).repeat_interleave(16, 2)
     mask = torch.nn.functional.one_hot(lab, 3).permute(0, 3, 1, 2).float().contiguous().to(dev)
-    opt = PPSTOptimizer(model, world=world)
+    # PPST_BENCH_FORCE_DIST on one GPU: a 1-rank RCCL group is up (main()); run the data-parallel code path against it -- the
+    # asynchronous flat all-reduces fired from inside backward, the deferred D step, the NCE all_gather -- by telling the
+    # optimizer the world is 2 (gradients are halved: a rehearsal of the collectives on the device, not a measurement)
+    rehearsal = bool(os.environ.get("PPST_BENCH_FORCE_DIST")) and world == 1
+    opt = PPSTOptimizer(model, world=2 if rehearsal else world)
     data = {"real_A": real, "mask_A": mask}
     from ppst_amd import ops
     for _ in range(args.warmup):
@@ -282,7 +286,8 @@ def bench_train(args, rank, world, dev, barrier, max_over_ranks):
             "config": {"workload": "CelebAMaskHQ_default train step 512x512, batch 2 per GPU, training stage 2, lambda_Cycwarp 0 "
                                    "(lpips unavailable), random init (BASELINE configs[3])",
                        "collectives": "flat gradient all-reduce per network (D 29.0 M, G 42.5 M, E2 27.0 M, E1 0.83 M fp32) + one "
-                                      "[24, 2048] all_gather of the NCE keys"},
+                                      "[24, 2048] all_gather of the NCE keys",
+                       **({"collectives_rehearsal": "1-rank RCCL group, optimizer told world = 2 (not a measurement)"} if rehearsal else {})},
             # the dominant kernel of the step by time: the weight gradient (always bf16x3: three passes of the hi / lo split)
             "roofline": roof(wg, "conv_wgrad_tr2_kernel / conv_wgrad_x3_kernel (conv weight gradients, bf16 hi+lo split on the matrix pipe; all launches of the step)", 3),
             "roofline_conv": roof(cv, "ppst_conv2d_mfma launches of the step: forward and input-gradient convs (same kernels as the swap line)", passes),
@@ -389,7 +394,19 @@ def main():
     dist = None
     if world > 1 or os.environ.get("PPST_BENCH_FORCE_DIST"):   # the override exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world)
+        # RCCL prints a version banner on stdout when the first communicator comes up; this program's stdout is ONE JSON line.
+        # Create the communicator here (first barrier) with fd 1 pointed at stderr.
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     from ppst_amd import glue, ops, weights as W
     from ppst_amd.ppst_model import create_model
