@@ -336,6 +336,11 @@ int ppst_rselfcorr(const void* fea, void* out, int B, int H, int W, int C, int o
 /* corrm feature prep (ppst_model.py:349-361): per pixel, mean-centre the first
  * `ncenter` channels, then L2-normalise all C channels (+eps). [B][P][C] rows. */
 int ppst_corr_prep(const void* fea, void* out, int B, int P, int C, int ncenter, void* stream);
+/* corrm with opt.match_kernel = k != 1 (ppst_model.py:345-347): F.unfold(fea, k, padding = k / 2) of an NHWC map
+ * [B][H][W][C] written as rows [B][H*W][C*k*k], column c*k*k + ky*k + kx (F.unfold's order), zeros outside; k odd.
+ * _bwd: dx [B][H][W][C] from the gradient of those rows.  (ppst_corr_prep takes rows of any length.) */
+int ppst_unfold_rows(const void* x, void* out, int B, int H, int W, int C, int k, void* stream);
+int ppst_unfold_rows_bwd(const void* g, void* dx, int B, int H, int W, int C, int k, void* stream);
 /* fp32 MFMA GEMM, C[b] = alpha * A[b] (MxK, row-major) * B[b]^T (NxK row-major) */
 int ppst_gemm_nt_f32(const void* A, const void* Bm, void* C, int batch, int M, int N, int K,
                      float alpha, void* stream);

@@ -382,6 +382,29 @@ def gen_gstep(ns, stage, f64=False):
     print(tag, len(out), {k: float(v) for k, v in out.items() if k.startswith(("loss.", "metric."))})
 
 
+def corrm_mk_inputs(h=16, seed=31):
+    """Seeded (key, query) feature maps of the match_kernel fixture (shared with the tests): a common direction plus noise, so
+    the T = 0.01 softmax stays soft (random 512-vectors would give one-hot rows and pin nothing but the arg-max)."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randn(1, 512, 1, 1, generator=g)
+    fea = base + 0.5 * torch.randn(1, 512, h, h, generator=g)
+    fea0 = base + 0.5 * torch.randn(1, 512, h, h, generator=g)
+    return fea, fea0
+
+
+def gen_corrm_mk(ns):
+    """PPSTModel.corrm with match_kernel = 3 / 5 (ppst_model.py:341-364, the F.unfold branch :345-347) on a 16 x 16 map: the
+    reference method itself, called on a stub that carries only ``opt.match_kernel`` (it touches nothing else of the model)."""
+    from types import SimpleNamespace
+    fea, fea0 = corrm_mk_inputs()
+    out = {}
+    for k in (1, 3, 5):
+        corr = ns.ppst_model.PPSTModel.corrm(SimpleNamespace(opt=SimpleNamespace(match_kernel=k)), fea, fea0)
+        out["corr.k%d" % k] = corr.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "corrm_mk.npz"), **out)
+    print("corrm_mk.npz", {k: v.shape for k, v in out.items()}, "max prob", {k: float(v.max()) for k, v in out.items()})
+
+
 def gen_iter_counter():
     """Schedule of the reference's own IterationCounter (util/iter_counter.py, loaded from its file: util/__init__ needs
     packages that are absent): for two option sets, the image count and the save / evaluate / print decisions of the first
@@ -418,7 +441,7 @@ def main():
         for a in sys.argv[1:]:
             {"gstep1": lambda: gen_gstep(ns, 1), "gstep2": lambda: gen_gstep(ns, 2),
              "gstep1_f64": lambda: gen_gstep(ns, 1, True), "gstep2_f64": lambda: gen_gstep(ns, 2, True),
-             "iter_counter": gen_iter_counter,
+             "iter_counter": gen_iter_counter, "corrm_mk": lambda: gen_corrm_mk(ns),
              "train512": lambda: gen_train(ns, 512), "train128": lambda: gen_train(ns), "gloss": lambda: gen_gloss(ns)}[a]()
         return
     m = ref_loader.build_reference_model()
@@ -435,6 +458,7 @@ def main():
     gen_gstep(ns, 1, True)
     # gen_gstep(ns, 2, True) needs more than the build container's 62 GB (killed by the kernel twice): not a fixture
     gen_iter_counter()
+    gen_corrm_mk(ns)
 
 
 if __name__ == "__main__":

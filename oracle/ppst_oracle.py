@@ -471,12 +471,17 @@ def rselfcorr(fea):
     return g.reshape(B, gy * gx, 256).permute(0, 2, 1).reshape(B, 256, gy, gx)
 
 
-def corrm(fea, fea0):
-    """PPSTModel.corrm (match_kernel=1), ppst_model.py:341-364.
+def corrm(fea, fea0, match_kernel=1):
+    """PPSTModel.corrm, ppst_model.py:341-364.
     fea = style/key (B,512,h,w), fea0 = content/query; returns (B, hw_query, hw_key)
-    = softmax over keys of cosine similarity / 0.01."""
+    = softmax over keys of cosine similarity / 0.01.  match_kernel k != 1 (:345-347): both maps are unfolded into
+    k x k neighbourhoods first (F.unfold, zero padding k // 2: rows c * k^2 + ky * k + kx) -- the mean is then taken over
+    the first 256 ROWS of the unfolded matrix, whatever channels / taps those are, exactly as the reference slices it."""
     def prep(f):
-        f = f.reshape(f.shape[0], f.shape[1], -1)
+        if match_kernel == 1:
+            f = f.reshape(f.shape[0], f.shape[1], -1)
+        else:
+            f = F.unfold(f, kernel_size=match_kernel, padding=int(match_kernel // 2))
         h1 = f[:, :256]
         h1 = h1 - h1.mean(dim=1, keepdim=True)
         f = torch.cat((h1, f[:, 256:]), dim=1)

@@ -94,6 +94,8 @@ _SIGS = {
     "ppst_corr_prep": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ppst_gemm_nt_f32": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "ppst_gemm_nn_f32": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ppst_unfold_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ppst_unfold_rows_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ppst_gemm_nt_split": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "ppst_gemm_nn_split": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ppst_softmax_rows": (i32, [vp, i64, i32, f32, vp]),

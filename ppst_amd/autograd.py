@@ -663,29 +663,36 @@ class RSelfCorrFn(Function):
 
 
 class CorrMFn(Function):
-    """PPSTModel.corrm: softmax(cos(q_i, k_j) / 0.01) over j; fea (keys) / fea0 (queries) NHWC (B,h,w,512)."""
+    """PPSTModel.corrm: softmax(cos(q_i, k_j) / 0.01) over j; fea (keys) / fea0 (queries) NHWC (B,h,w,512).
+    match_kernel k != 1: both maps as k x k neighbourhood rows first (ppst_model.py:345-347)."""
 
     @staticmethod
-    def forward(ctx, fea, fea0):
+    def forward(ctx, fea, fea0, match_kernel=1):
         k, q = _c(fea), _c(fea0)
         B, h, w, C = k.shape
-        k, q = k.reshape(B, h * w, C), q.reshape(B, h * w, C)
+        if match_kernel == 1:
+            k, q = k.reshape(B, h * w, C), q.reshape(B, h * w, C)
+        else:
+            k, q = ops.unfold_rows(k, match_kernel), ops.unfold_rows(q, match_kernel)
         kn, qn = ops.corr_prep(k, 256), ops.corr_prep(q, 256)
         corr = ops.softmax_rows_(ops.gemm_nt(qn, kn), 0.01)
         ctx.save_for_backward(k, q, kn, qn, corr)
-        ctx.shape = (B, h, w, C)
+        ctx.shape, ctx.mk = (B, h, w, C), match_kernel
         return corr
 
     @staticmethod
     def backward(ctx, g):
         k, q, kn, qn, corr = ctx.saved_tensors
         ds = ops.softmax_rows_bwd_(corr, _c(g).clone(), 0.01)          # d/d(cosine matrix)
+
+        def rows_to_map(d):
+            return d.view(ctx.shape) if ctx.mk == 1 else ops.unfold_rows_bwd(d, ctx.shape, ctx.mk)
         dk = dq = None
         if ctx.needs_input_grad[1]:
-            dq = ops.corr_prep_bwd(ops.gemm_nn(ds, kn, mode="x3"), q, 256).view(ctx.shape)
+            dq = rows_to_map(ops.corr_prep_bwd(ops.gemm_nn(ds, kn, mode="x3"), q, 256))
         if ctx.needs_input_grad[0]:
-            dk = ops.corr_prep_bwd(ops.gemm_nn(ops.transpose_last2(ds), qn, mode="x3"), k, 256).view(ctx.shape)
-        return dk, dq
+            dk = rows_to_map(ops.corr_prep_bwd(ops.gemm_nn(ops.transpose_last2(ds), qn, mode="x3"), k, 256))
+        return dk, dq, None
 
 
 class WarpGemmFn(Function):

@@ -99,15 +99,100 @@ __global__ __launch_bounds__(256) void corr_prep_kernel(const float* __restrict_
       if (i < per) y[r * C + i * 64 + lane] = v[i] / nrm;
   }
 }
+// the same for any C (match_kernel != 1: rows of 512 k^2 unfolded values): one wave per row, the row is re-read per pass
+__global__ __launch_bounds__(256) void corr_prep_loop_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int C,
+                                                             int ncenter, float eps) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+    const float* xr = x + r * C;
+    float s = 0.f;
+    for (int c = lane; c < ncenter; c += 64) s += xr[c];
+    const float mean = ncenter > 0 ? wave_sum(s) / (float)ncenter : 0.f;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float z = xr[c] - (c < ncenter ? mean : 0.f);
+      q += z * z;
+    }
+    const float nrm = sqrtf(wave_sum(q)) + eps;
+    for (int c = lane; c < C; c += 64) y[r * C + c] = (xr[c] - (c < ncenter ? mean : 0.f)) / nrm;
+  }
+}
 extern "C" int ppst_corr_prep(const void* fea, void* out, int B, int P, int C, int ncenter, void* stream) {
-  if (B < 0 || P <= 0 || C <= 0 || C % 64 || C > 1024 || ncenter < 0 || ncenter > C) return PPST_EINVAL;
+  if (B < 0 || P <= 0 || C <= 0 || ncenter < 0 || ncenter > C) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!fea || !out) return PPST_ENULL;
   int64_t rows = (int64_t)B * P;
   int64_t blocks = cdiv64(rows, 4);
   if (blocks > 256 * 8) blocks = 256 * 8;
+  if (C % 64 || C > 1024) {
+    PPST_LAUNCH(corr_prep_loop_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)fea, (float*)out, rows, C,
+                ncenter, 2.220446049250313e-16f);
+    return PPST_LAUNCH_CHECK();
+  }
   PPST_LAUNCH(corr_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)fea, (float*)out, rows, C,
                      ncenter, 2.220446049250313e-16f);
+  return PPST_LAUNCH_CHECK();
+}
+
+// ------------------------------------------- F.unfold rows (match_kernel != 1) --
+// corrm with opt.match_kernel = k (ppst_model.py:345-347): F.unfold(fea, k, padding = k / 2) of an NHWC map, written as the
+// GEMM's rows: out[b][p][c k^2 + ky k + kx] = x[b][y + ky - r][x + kx - r][c] (zero outside), p = y W + x, r = k / 2 (k odd).
+// One block per output row; the k^2 x C neighbourhood it gathers stays in L1.  Backward = the gather in the other direction.
+__global__ __launch_bounds__(256) void unfold_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int C, int k,
+                                                          int64_t rows) {
+  const int kk = k * k, r = k >> 1, K = C * kk;
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int p = (int)(row % ((int64_t)H * W));
+    const int64_t b = row / ((int64_t)H * W);
+    const int y = p / W, xx = p - y * W;
+    for (int j = threadIdx.x; j < K; j += 256) {
+      const int c = j / kk, t = j - c * kk, ky = t / k, kx = t - ky * k;
+      const int iy = y + ky - r, ix = xx + kx - r;
+      out[row * K + j] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[((b * H + iy) * W + ix) * C + c] : 0.f;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void unfold_rows_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, int H, int W, int C,
+                                                              int k, int64_t total) {
+  const int kk = k * k, r = k >> 1;
+  const int64_t K = (int64_t)C * kk;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t q = i / C;
+    const int xx = (int)(q % W); q /= W;
+    const int y = (int)(q % H);
+    const int64_t b = q / H;
+    float acc = 0.f;
+    for (int ky = 0; ky < k; ++ky) {
+      const int py = y - ky + r;
+      if (py < 0 || py >= H) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int px = xx - kx + r;
+        if (px < 0 || px >= W) continue;
+        acc += g[((b * H + py) * W + px) * K + (int64_t)c * kk + ky * k + kx];
+      }
+    }
+    dx[i] = acc;
+  }
+}
+extern "C" int ppst_unfold_rows(const void* x, void* out, int B, int H, int W, int C, int k, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || k % 2 == 0 || (int64_t)C * k * k > 0x7fffffffll) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !out) return PPST_ENULL;
+  const int64_t rows = (int64_t)B * H * W;
+  PPST_LAUNCH(unfold_rows_kernel, dim3((unsigned)(rows > 65536 ? 65536 : rows)), dim3(256), 0, as_stream(stream), (const float*)x,
+              (float*)out, H, W, C, k, rows);
+  return PPST_LAUNCH_CHECK();
+}
+extern "C" int ppst_unfold_rows_bwd(const void* g, void* dx, int B, int H, int W, int C, int k, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || k % 2 == 0 || (int64_t)C * k * k > 0x7fffffffll) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!g || !dx) return PPST_ENULL;
+  const int64_t total = (int64_t)B * H * W * C;
+  int64_t blocks = cdiv64(total, 256);
+  if (blocks > 65536) blocks = 65536;
+  PPST_LAUNCH(unfold_rows_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)g, (float*)dx, H, W, C, k,
+              total);
   return PPST_LAUNCH_CHECK();
 }
 

@@ -1270,6 +1270,26 @@ def corr_prep(fea, ncenter=256):
     return y
 
 
+def unfold_rows(x, k):
+    """F.unfold(x, k, padding=k // 2) of an NHWC map (B,H,W,C) as rows (B, H*W, C*k*k) (ppst_model.py:345-347; k odd)."""
+    _chk(x)
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    out = torch.empty((B, H * W, C * k * k), device=x.device, dtype=torch.float32)
+    check(lib.ppst_unfold_rows(_p(x), _p(out), B, H, W, C, int(k), _stream()), "ppst_unfold_rows")
+    return out
+
+
+def unfold_rows_bwd(g, shape, k):
+    """gradient of unfold_rows: g (B, H*W, C*k*k) -> (B,H,W,C)."""
+    _chk(g)
+    g = g.contiguous()
+    B, H, W, C = shape
+    dx = torch.empty((B, H, W, C), device=g.device, dtype=torch.float32)
+    check(lib.ppst_unfold_rows_bwd(_p(g), _p(dx), B, H, W, C, int(k), _stream()), "ppst_unfold_rows_bwd")
+    return dx
+
+
 GEMM_MODE = {"value": None}    # None: per call site ("x6" fp32-class / "x3" bf16x3); "f32": the exact-fp32 MFMA kernels everywhere
 
 

@@ -229,13 +229,21 @@ class PPSTModel(nn.Module):
     def corrm(self, fea, fea0):
         """softmax(cos(fea0_i, fea_j)/0.01) over j -> (B, hw, hw) (ppst_model.py:341-364);
         fea = style/key features, fea0 = content/query features, both (B,512,h,w)."""
-        if getattr(self.opt, "match_kernel", 1) != 1:
-            raise NotImplementedError("match_kernel != 1 (F.unfold matching) is not on the PPST path")
+        mk = int(getattr(self.opt, "match_kernel", 1))
         k = to_nhwc(fea)
         q = to_nhwc(fea0)
         B, h, w, C = k.shape
-        kn = ops.corr_prep(k.reshape(B, h * w, C), 256)
-        qn = ops.corr_prep(q.reshape(B, h * w, C), 256)
+        if mk == 1:
+            kr, qr = k.reshape(B, h * w, C), q.reshape(B, h * w, C)
+        else:
+            # F.unfold matching (:345-347): k x k neighbourhoods as rows; the mean is taken over the first 256 unfolded ROWS
+            # as the reference slices them.  An even k makes F.unfold return (h + 1)(w + 1) positions: the reference's warp
+            # would not accept that matrix either.
+            if mk < 1 or mk % 2 == 0:
+                raise ValueError("match_kernel must be odd (got %d)" % mk)
+            kr, qr = ops.unfold_rows(k, mk), ops.unfold_rows(q, mk)
+        kn = ops.corr_prep(kr, 256)
+        qn = ops.corr_prep(qr, 256)
         corr = ops.gemm_nt(qn, kn)
         return ops.softmax_rows_(corr, 0.01)
 

@@ -342,7 +342,10 @@ class GeneratorTrainer:
 
     def corrm(self, fea, fea0):
         """fea (keys) / fea0 (queries): NHWC (B,64,64,512) -> (B,4096,4096)."""
-        return A.CorrMFn.apply(fea, fea0)
+        mk = int(getattr(self.model.opt, "match_kernel", 1))
+        if mk < 1 or mk % 2 == 0:
+            raise ValueError("match_kernel must be odd (got %d)" % mk)
+        return A.CorrMFn.apply(fea, fea0, mk)
 
     def warp_mask(self, mask, corr):
         """PPSTModel.warp of the one-hot mask (no gradient to the mask)."""

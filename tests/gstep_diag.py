@@ -258,6 +258,9 @@ def t_blocks2():
     fq = base + 0.03 * rn(1, 512, 8, 8)
     check_block("CorrMFn", lambda i: A.CorrMFn.apply(i["k"], i["q"]), lambda i: O.corrm(i["k"], i["q"]), dict(k=fk, q=fq),
                 layouts={"k": "act", "q": "act"}, tol=5e-4)
+    # match_kernel = 3 (ppst_model.py:345-347): 3 x 3 neighbourhood rows (F.unfold) in front of the same centring / cosine / softmax
+    check_block("CorrMFn match_kernel 3", lambda i: A.CorrMFn.apply(i["k"], i["q"], 3), lambda i: O.corrm(i["k"], i["q"], match_kernel=3),
+                dict(k=fk, q=fq), layouts={"k": "act", "q": "act"}, tol=5e-4)
     corr = torch.softmax(rn(2, 64, 64) * 2, -1)
     V = rn(2, 64, 96)
 

@@ -350,6 +350,38 @@ def test_edge_cases():
         upfirdn2d(torch.zeros(1, 1, 8, 8, device=dev, dtype=torch.float16), k)
 
 
+def test_corrm_match_kernel_vs_reference_golden():
+    """``model(fea, fea0, command="corrm")`` with opt.match_kernel in {1, 3, 5} against the reference method's own output
+    (tests/golden/corrm_mk.npz, ppst_model.py:341-364 with the F.unfold branch :345-347) on the fixture's seeded 16 x 16 maps:
+    1e-4 of the largest probability (logits are cosines / 0.01; the kernel path measured 2e-6 at k = 1), rows sum to one;
+    the F.unfold rows themselves bit-equal to F.unfold; an even kernel is refused."""
+    import numpy as np
+    import torch.nn.functional as F
+    from test_oracle_golden import corrm_mk_inputs
+    from ppst_amd import ops
+    from ppst_amd.ppst_model import Options, create_model
+    from ppst_amd import weights as W
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "corrm_mk.npz"))
+    fea, fea0 = corrm_mk_inputs()
+    x = torch.randn(2, 5, 7, 12)
+    for k in (3, 5):
+        rows = ops.unfold_rows(x.permute(0, 2, 3, 1).contiguous().cuda(), k)
+        assert torch.equal(rows.cpu(), F.unfold(x, k, padding=k // 2).permute(0, 2, 1))
+    sd = W.make_state_dict(0, with_D=False, with_nce=False)
+    for k in (1, 3, 5):
+        m = create_model(Options(match_kernel=k), state_dict=sd, device="cuda")
+        with torch.no_grad():
+            corr = m(fea.cuda(), fea0.cuda(), command="corrm")
+        ref = torch.from_numpy(g["corr.k%d" % k])
+        assert corr.shape == ref.shape
+        err = (corr.cpu() - ref).abs().max().item()
+        assert err <= 1e-4 * ref.max().item(), (k, err)
+        assert (corr.sum(-1) - 1).abs().max().item() < 1e-5
+    m = create_model(Options(match_kernel=2), state_dict=sd, device="cuda")
+    with pytest.raises(ValueError):
+        m(fea.cuda(), fea0.cuda(), command="corrm")
+
+
 def test_smooth_filter_local_affine_vs_oracle():
     """SURVEY section 8 f4 (smooth_filter.py:149-378): the two HIP launches against the numpy restatement of the three
     reference kernels -- per-pixel affine model, smoothed model and reconstructed image; r = 15 (LDS-tiled path), a small

@@ -76,6 +76,28 @@ def test_exact_glue_golden(golden_dir):
     assert np.array_equal(O.gan_loss(a, False).numpy(), g["gan.fake"])
 
 
+def corrm_mk_inputs(h=16, seed=31):
+    """the seeded (key, query) maps of tests/golden/corrm_mk.npz (oracle/gen_golden.py:corrm_mk_inputs)."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randn(1, 512, 1, 1, generator=g)
+    fea = base + 0.5 * torch.randn(1, 512, h, h, generator=g)
+    fea0 = base + 0.5 * torch.randn(1, 512, h, h, generator=g)
+    return fea, fea0
+
+
+def test_corrm_match_kernel_golden(golden_dir):
+    """corrm with opt.match_kernel in {1, 3, 5} (ppst_model.py:341-364, the F.unfold branch :345-347): the reference method's own
+    output on a 16 x 16 map.  Rows are genuinely soft (median row maximum 0.01-0.05 against 1/256 for a uniform row)."""
+    g = np.load(os.path.join(golden_dir, "corrm_mk.npz"))
+    fea, fea0 = corrm_mk_inputs()
+    for k in (1, 3, 5):
+        ref = g["corr.k%d" % k].astype(np.float64)
+        got = O.corrm(fea, fea0, match_kernel=k).double().numpy()
+        assert got.shape == ref.shape == (1, 256, 256)
+        assert np.abs(got - ref).max() <= 2e-5 * ref.max(), (k, np.abs(got - ref).max())
+        assert np.median(ref[0].max(-1)) < 0.1          # the fixture pins a distribution, not an arg-max
+
+
 def test_cfg1_256_encode_decode(golden_dir):
     g = np.load(os.path.join(golden_dir, "cfg1_256.npz"))
     sd = W.make_state_dict(0)
