@@ -79,6 +79,9 @@ __global__ __launch_bounds__(256) void upfirdn2d_planes(const float* __restrict_
   }
 }
 
+#ifndef UF_PY
+#define UF_PY 4                      // output rows per thread of the DOWN == 1 forms (2: -5..8 % at batch 24, equal at batch 8; 8: -15 % at batch 8)
+#endif
 // ---- chan: minor % 4 == 0, up == down == 1 --------------------------------
 // DOWN = 2 keeps every second sample (the blur in front of a stride-2 1x1 conv only needs
 // those).  S2D writes the output space-to-depth: out[m][oy>>1][ox>>1][((oy&1)*2+(ox&1))*C + c]
@@ -87,8 +90,8 @@ template <int KH, int KW, int DOWN, bool S2D>
 __global__ __launch_bounds__(256) void upfirdn2d_chan(const float4* __restrict__ x, float4* __restrict__ y, UfParams p, unsigned nwork,
                                                       FastDiv d_c, FastDiv d_xs, FastDiv d_oh) {
   // One thread = PX x PY output pixels x 4 channels: the (PY-1+KH) x ((PX-1)*DOWN+KW) input patch is read once into
-  // registers (DOWN = 1: 4 x 6 loads for 8 outputs instead of 3 x 6 for 4).
-  constexpr int PX = 4, PY = (DOWN == 1) ? 2 : 1;
+  // registers (DOWN = 1, PY = 4: 6 x 6 loads for 16 outputs; the rows shared with the thread above / below come through L2).
+  constexpr int PX = 4, PY = (DOWN == 1) ? UF_PY : 1;
   const int c4n = p.minor >> 2;
   float kf[KH * KW];
 #pragma unroll
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_up2_chan(const float4* __restri
 template <int KH, int KW>
 static int launch_chan(const float* x, float* y, const UfParams& p, int down, bool s2d, hipStream_t st) {
   const int eh = s2d ? ((p.out_h + 1) & ~1) : p.out_h, ew = s2d ? ((p.out_w + 1) & ~1) : p.out_w;
-  const int rows = down == 1 ? cdiv(eh, 2) : eh;   // row groups: two output rows per thread when down == 1
+  const int rows = down == 1 ? cdiv(eh, UF_PY) : eh;   // row groups: UF_PY output rows per thread when down == 1
   int64_t nwork = (int64_t)p.major * rows * cdiv(ew, 4) * (p.minor / 4);
   if (nwork > PPST_IDX32_MAX) return PPST_EINVAL;
   int64_t blocks = cdiv64(cdiv64(nwork, 256), 8) * 8;      // a multiple of 8: v % 8 is the XCD slot in every stride iteration
