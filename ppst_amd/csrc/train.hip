@@ -546,7 +546,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr_kernel(const float* __re
 // NCH chunks (32 input channels each) per block, at most TM taps per chunk: <1, 9> for 3x3 tables; <2, 4> for tables whose chunks
 // have <= 4 steps (transposed conv, stride-2 tables, 1x1): two input images share ONE dY image, i.e. a third fewer bytes per MFMA
 // where a 4-tap chunk would otherwise do 4/9 of the MFMA work of a 3x3 chunk per staged tile (blockIdx.y = pair of chunks).
-template <int NCH, int TM>
+// X1: single-pass bf16 (precision mode 1, BASELINE configs[3]'s "bf16 compute, fp32 master weights"): only the hi halves are
+// written and multiplied -- a third of the MFMA phase; the bias column sums still come from the fp32 values.
+template <int NCH, int TM, bool X1>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               const int4* __restrict__ steps, const int* __restrict__ chunk_start,
                                                               float* __restrict__ partial, float* __restrict__ csum, int B, int in_h,
@@ -609,10 +611,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
     const unsigned char* pl = u + (sw ^ 1) * 8;
     const wt_v4s h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wt_v4s __attribute__((address_space(3)))*)ph);
     const wt_v4s h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wt_v4s __attribute__((address_space(3)))*)(ph + 4 * 128));
-    const wt_v4s l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wt_v4s __attribute__((address_space(3)))*)pl);
-    const wt_v4s l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wt_v4s __attribute__((address_space(3)))*)(pl + 4 * 128));
     h = (bf16x8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-    l = (bf16x8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    if (!X1) {
+      const wt_v4s l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wt_v4s __attribute__((address_space(3)))*)pl);
+      const wt_v4s l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wt_v4s __attribute__((address_space(3)))*)(pl + 4 * 128));
+      l = (bf16x8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    } else {
+      l = h;
+    }
   };
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int b = tile / tiles_per_image;
@@ -653,7 +659,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
       uint2 hi, lo;
       split4(v, hi, lo);
       const int sw = (p >> 1) & 1;
-      *(uint4*)u = sw ? make_uint4(lo.x, lo.y, hi.x, hi.y) : make_uint4(hi.x, hi.y, lo.x, lo.y);
+      if (X1) *(uint2*)(u + sw * 8) = hi;
+      else *(uint4*)u = sw ? make_uint4(lo.x, lo.y, hi.x, hi.y) : make_uint4(hi.x, hi.y, lo.x, lo.y);
     }
 #pragma unroll
     for (int ci = 0; ci < NCH; ++ci)
@@ -666,7 +673,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
           uint2 hi, lo;
           split4(v, hi, lo);
           const int sw = (i >> 4) & 1;                        // pixel = i >> 3
-          *(uint4*)u = sw ? make_uint4(lo.x, lo.y, hi.x, hi.y) : make_uint4(hi.x, hi.y, lo.x, lo.y);
+          if (X1) *(uint2*)(u + sw * 8) = hi;
+          else *(uint4*)u = sw ? make_uint4(lo.x, lo.y, hi.x, hi.y) : make_uint4(hi.x, hi.y, lo.x, lo.y);
         }
       }
     __syncthreads();
@@ -690,8 +698,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
                 const int pb = (row + 1 + tdy[ci][t + 1]) * WT_XW + xh + 1 + tdx[ci][t + 1];
                 frag(im + pb * 128 + tr_unit, (((pb & 3) + qd) >> 1) & 1, n_h, n_l);
               }
-              acc[ci][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b_h, acc[ci][t], 0, 0, 0);
-              acc[ci][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_l, acc[ci][t], 0, 0, 0);
+              if (!X1) {
+                acc[ci][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b_h, acc[ci][t], 0, 0, 0);
+                acc[ci][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_l, acc[ci][t], 0, 0, 0);
+              }
               acc[ci][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_h, acc[ci][t], 0, 0, 0);
               b_h = n_h; b_l = n_l;
             }
@@ -797,9 +807,9 @@ extern "C" int ppst_conv_wgrad_tr(const void* x, const void* dy, const void* ste
 // [splits][cout] partial column sums of dy
 extern "C" int ppst_conv_wgrad_tr2(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial, void* csum,
                                    int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
-                                   int nchunks, int splits, int max_taps, void* stream) {
+                                   int nchunks, int splits, int max_taps, int passes, void* stream) {
   if (B < 0 || in_h <= 0 || in_w <= 0 || in_ld <= 0 || oh <= 0 || ow <= 0 || dy_ld < cout || cout <= 0 || nsteps <= 0 ||
-      nchunks <= 0 || splits <= 0)
+      nchunks <= 0 || splits <= 0 || (passes != 1 && passes != 3))
     return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!x || !dy || !steps || !chunk_start || !partial) return PPST_ENULL;
@@ -813,14 +823,13 @@ extern "C" int ppst_conv_wgrad_tr2(const void* x, const void* dy, const void* st
   dim3 grid(cdiv(cout, 128), pair ? nchunks / 2 : nchunks, splits);
   const int slot = wgrad_prof_begin(B, oh, ow, cout, nsteps, g_wgrad_flop_steps, nchunks, splits, as_stream(stream));
   g_wgrad_flop_steps = 0;
-  if (pair)
-    PPST_LAUNCH((conv_wgrad_tr2_kernel<2, 4>), grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (const int4*)steps,
-                (const int*)chunk_start, (float*)partial, (float*)csum, B, in_h, in_w, in_ld, oh, ow, dy_ld, cout, nsteps, tiles_x,
-                tiles_per_image, tiles_total, tps);
-  else
-    PPST_LAUNCH((conv_wgrad_tr2_kernel<1, WG_MAXT>), grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (const int4*)steps,
-                (const int*)chunk_start, (float*)partial, (float*)csum, B, in_h, in_w, in_ld, oh, ow, dy_ld, cout, nsteps, tiles_x,
-                tiles_per_image, tiles_total, tps);
+#define WG2(NCH, TM, X1)                                                                                                              \
+  PPST_LAUNCH((conv_wgrad_tr2_kernel<NCH, TM, X1>), grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy,             \
+              (const int4*)steps, (const int*)chunk_start, (float*)partial, (float*)csum, B, in_h, in_w, in_ld, oh, ow, dy_ld, cout,     \
+              nsteps, tiles_x, tiles_per_image, tiles_total, tps)
+  if (pair) { if (passes == 1) WG2(2, 4, true); else WG2(2, 4, false); }
+  else { if (passes == 1) WG2(1, WG_MAXT, true); else WG2(1, WG_MAXT, false); }
+#undef WG2
   ppst_prof_end_(slot, as_stream(stream));
   return PPST_LAUNCH_CHECK();
 }
@@ -855,28 +864,42 @@ extern "C" int ppst_conv_wgrad_f32(const void* x, const void* dy, const void* st
 }
 
 // dW[n][src_c+k][ky][kx] (strides sn, sc, sy, sx) (+)= scale * sum_splits partial[split][step][n][k]
+// One block per (step s, output channel n): 32 k-values x 8 split lanes -- thread (k, j) adds the partial slots j, j + 8, ...,
+// the eight sums meet in LDS in a fixed order.  (One thread per output walking ALL slots, the first form, was a chain of up to
+// 2048 dependent-latency loads on 36 blocks for the thin layers -- 32 -> 32 @512^2: 0.13 of its 0.39 ms -- and the bias column
+// sums rode on block 0 in front of its own outputs.)  The bias gradient (column sums of the weight-gradient kernel's per-block
+// partial sums of dy) takes cdiv(cout, 32) extra blocks of the same shape.
 __global__ __launch_bounds__(256) void wgrad_scatter_kernel(const float* __restrict__ partial, const int* __restrict__ src_c,
                                                             const int* __restrict__ src_ky, const int* __restrict__ src_kx,
                                                             float* __restrict__ dw, int64_t sn, int64_t sc, int64_t sy, int64_t sx,
                                                             int cout, int nsteps, int splits, float scale, int accumulate,
-                                                            int64_t total, const float* __restrict__ csum, float* __restrict__ db,
+                                                            int nrows, const float* __restrict__ csum, float* __restrict__ db,
                                                             int csum_rows, int db_accumulate) {
-  // the bias gradient rides along: column sums of the weight-gradient kernel's per-block partial sums of dy (fixed order)
-  if (csum)
-    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < cout; n += (int64_t)gridDim.x * 256) {
-      float v = 0.f;
-      for (int r = 0; r < csum_rows; ++r) v += csum[(int64_t)r * cout + n];
+  __shared__ float red[8][32];
+  const int k = threadIdx.x & 31, j = threadIdx.x >> 5;
+  if ((int)blockIdx.x >= nrows) {                           // bias blocks
+    const int n = ((int)blockIdx.x - nrows) * 32 + k;
+    float v = 0.f;
+    if (n < cout)
+      for (int r = j; r < csum_rows; r += 8) v += csum[(int64_t)r * cout + n];
+    red[j][k] = v;
+    __syncthreads();
+    if (j == 0 && n < cout) {
+      v = ((red[0][k] + red[1][k]) + (red[2][k] + red[3][k])) + ((red[4][k] + red[5][k]) + (red[6][k] + red[7][k]));
       db[n] = db_accumulate ? db[n] + v : v;
     }
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    int k = (int)(t & 31);
-    int64_t r = t >> 5;
-    int n = (int)(r % cout);
-    int s = (int)(r / cout);
-    if (src_c[s] < 0) continue;  // zero-weight pad step
-    float v = 0.f;
-    for (int sp = 0; sp < splits; ++sp) v += partial[(((int64_t)sp * nsteps + s) * cout + n) * 32 + k];
-    float* o = dw + n * sn + (int64_t)(src_c[s] + k) * sc + src_ky[s] * sy + src_kx[s] * sx;
+    return;
+  }
+  const int s = (int)blockIdx.x / cout, n = (int)blockIdx.x - s * cout;
+  const int c0 = src_c[s];
+  if (c0 < 0) return;                                       // zero-weight pad step (block-uniform)
+  float v = 0.f;
+  for (int sp = j; sp < splits; sp += 8) v += partial[(((int64_t)sp * nsteps + s) * cout + n) * 32 + k];
+  red[j][k] = v;
+  __syncthreads();
+  if (j == 0) {
+    v = ((red[0][k] + red[1][k]) + (red[2][k] + red[3][k])) + ((red[4][k] + red[5][k]) + (red[6][k] + red[7][k]));
+    float* o = dw + n * sn + (int64_t)(c0 + k) * sc + src_ky[s] * sy + src_kx[s] * sx;
     *o = accumulate ? *o + v * scale : v * scale;
   }
 }
@@ -885,11 +908,11 @@ extern "C" int ppst_wgrad_scatter(const void* partial, const void* src_c, const 
                                   int accumulate, const void* csum, void* db, int csum_rows, int db_accumulate, void* stream) {
   if (cout <= 0 || nsteps <= 0 || splits <= 0 || (csum && csum_rows <= 0)) return PPST_EINVAL;
   if (!partial || !src_c || !src_ky || !src_kx || !dw || (csum && !db)) return PPST_ENULL;
-  int64_t total = (int64_t)nsteps * cout * 32;
-  int64_t blocks = cdiv64(total, 256);
-  if (blocks > 4096) blocks = 4096;
+  const int64_t nrows = (int64_t)nsteps * cout;
+  const int64_t blocks = nrows + (csum ? cdiv(cout, 32) : 0);
+  if (blocks > 0x7fffffffll) return PPST_EINVAL;
   PPST_LAUNCH(wgrad_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)partial, (const int*)src_c,
-              (const int*)src_ky, (const int*)src_kx, (float*)dw, sn, sc, sy, sx, cout, nsteps, splits, scale, accumulate, total,
+              (const int*)src_ky, (const int*)src_kx, (float*)dw, sn, sc, sy, sx, cout, nsteps, splits, scale, accumulate, (int)nrows,
               (const float*)csum, (float*)db, csum_rows, db_accumulate);
   return PPST_LAUNCH_CHECK();
 }

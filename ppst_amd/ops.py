@@ -647,7 +647,9 @@ def _grad_out(out, shape, like):
 
 # the LDS-DMA / transposed-read weight-gradient kernel (round 3): one 8-wave block per CU -> ONE round of <= 256 blocks (every
 # further split is 2 x 147 KB of partial sums written and re-read by the scatter), >= min_tiles pixel tiles per block
-WGRAD_TR = {"value": True, "blocks": 256, "min_tiles": 8, "form": 2, "blocks2": 512, "pair": True}    # form 2: two 256-thread blocks per CU
+# form 2: two 256-thread blocks per CU; bf16_single_pass: in precision mode 1 (bf16 compute, fp32 master weights -- BASELINE
+# configs[3]) the weight gradient multiplies the hi halves only (one MFMA pass instead of three)
+WGRAD_TR = {"value": True, "blocks": 256, "min_tiles": 8, "form": 2, "blocks2": 512, "pair": True, "bf16_single_pass": True}
 
 
 def presplit(x):
@@ -709,6 +711,7 @@ def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=No
         if WGRAD_TR["form"] == 2:
             check(lib.ppst_conv_wgrad_tr2(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), _p(csum), B, H, W, in_ld, oh, ow,
                                           dy_ld, cout, plan.nsteps, nchunks, splits, plan.max_chunk_steps if WGRAD_TR["pair"] else 0,
+                                          1 if (PRECISION["value"] == 1 and WGRAD_TR["bf16_single_pass"]) else 3,
                                           _stream()), "ppst_conv_wgrad_tr2")
         else:
             check(lib.ppst_conv_wgrad_tr(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), _p(csum), B, H, W, in_ld, oh, ow,
