@@ -1084,6 +1084,22 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     dw[t] = accumulate ? dw[t] + s * scale : s * scale;
   }
 }
+// K % 4 == 0, 16-byte aligned x / dw: four columns per thread
+__global__ __launch_bounds__(256) void linear_wgrad4_kernel(const float* __restrict__ dy, const float4* __restrict__ x, float4* __restrict__ dw,
+                                                            int B, int N, int K4, float scale, int accumulate, int64_t total4) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total4; t += (int64_t)gridDim.x * 256) {
+    const int k4 = (int)(t % K4), n = (int)(t / K4);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < B; ++b) {
+      const float d = dy[(int64_t)b * N + n];
+      const float4 v = x[(int64_t)b * K4 + k4];
+      s.x += d * v.x; s.y += d * v.y; s.z += d * v.z; s.w += d * v.w;
+    }
+    float4 o = make_float4(s.x * scale, s.y * scale, s.z * scale, s.w * scale);
+    if (accumulate) { const float4 p = dw[t]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+    dw[t] = o;
+  }
+}
 // dX = dY W streams the weight matrix once (4*N*K bytes): block (kx, ns) owns 256 columns k and the LDG_ROWS rows
 // n of its slice, accumulates every batch row in registers (dY[b][n] is a wave-uniform broadcast) and writes a partial;
 // a second launch sums the slices in a fixed order (deterministic).  (Round 1's version ran one thread per output with a
@@ -1098,11 +1114,24 @@ __global__ __launch_bounds__(256) void linear_dgrad_partial_kernel(const float* 
 #pragma unroll
   for (int b = 0; b < LDG_BMAX; ++b) acc[b] = 0.f;
   if (k < K) {
-    for (int n = n0; n < n1; ++n) {
-      const float wv = w[(int64_t)n * K + k];
+    if (n1 - n0 == LDG_ROWS) {
+      // full slice: all LDG_ROWS weight loads are issued before the first use (a runtime trip count left hipcc a chain of
+      // partially unrolled dependent-latency loads: 27 us per launch for 8 MB of weights)
+      float wv[LDG_ROWS];
 #pragma unroll
-      for (int b = 0; b < LDG_BMAX; ++b)
-        if (b0 + b < B) acc[b] += dy[(int64_t)(b0 + b) * N + n] * wv;
+      for (int i = 0; i < LDG_ROWS; ++i) wv[i] = w[(int64_t)(n0 + i) * K + k];
+#pragma unroll
+      for (int i = 0; i < LDG_ROWS; ++i)
+#pragma unroll
+        for (int b = 0; b < LDG_BMAX; ++b)
+          if (b0 + b < B) acc[b] += dy[(int64_t)(b0 + b) * N + n0 + i] * wv[i];
+    } else {
+      for (int n = n0; n < n1; ++n) {
+        const float wv = w[(int64_t)n * K + k];
+#pragma unroll
+        for (int b = 0; b < LDG_BMAX; ++b)
+          if (b0 + b < B) acc[b] += dy[(int64_t)(b0 + b) * N + n] * wv;
+      }
     }
 #pragma unroll
     for (int b = 0; b < LDG_BMAX; ++b)
@@ -1113,7 +1142,14 @@ __global__ __launch_bounds__(256) void linear_dgrad_reduce_kernel(const float* _
                                                                   int64_t bk, float scale) {
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < bk; t += (int64_t)gridDim.x * 256) {
     float s = 0.f;
-    for (int i = 0; i < nsplit; ++i) s += partial[(int64_t)i * bk + t];
+    int i = 0;
+    for (; i + 8 <= nsplit; i += 8) {                       // eight slices in flight, fixed order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(i + u) * bk + t];
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; i < nsplit; ++i) s += partial[(int64_t)i * bk + t];
     dx[t] = s * scale;
   }
 }
@@ -1121,6 +1157,13 @@ extern "C" int ppst_linear_wgrad(const void* dy, const void* x, void* dw, int B,
   if (B <= 0 || N <= 0 || K <= 0) return PPST_EINVAL;
   if (!dy || !x || !dw) return PPST_ENULL;
   int64_t total = (int64_t)N * K, blocks = cdiv64(total, 256);
+  if (K % 4 == 0 && ((uintptr_t)x | (uintptr_t)dw) % 16 == 0) {
+    blocks = cdiv64(total / 4, 256);
+    if (blocks > 8192) blocks = 8192;
+    PPST_LAUNCH(linear_wgrad4_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)dy, (const float4*)x, (float4*)dw,
+                B, N, K / 4, scale, accumulate, total / 4);
+    return PPST_LAUNCH_CHECK();
+  }
   if (blocks > 4096) blocks = 4096;
   PPST_LAUNCH(linear_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)dy, (const float*)x, (float*)dw, B, N,
               K, scale, accumulate, total);

@@ -95,7 +95,13 @@ __global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const float* __res
   double s = 0.0, q = 0.0;
   if (c < C) {
     const float2* p = (const float2*)partial + ((int64_t)b * n_partials * C + c);
-    for (int k = kk; k < n_partials; k += 8) {
+    int k = kk;
+    for (; k + 24 < n_partials; k += 32) {                  // four rows in flight per thread (as in_finalize_kernel), fixed order
+      const float2 v0 = p[(int64_t)k * C], v1 = p[(int64_t)(k + 8) * C], v2 = p[(int64_t)(k + 16) * C], v3 = p[(int64_t)(k + 24) * C];
+      s += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+      q += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    for (; k < n_partials; k += 8) {
       float2 v = p[(int64_t)k * C];
       s += (double)v.x;
       q += (double)v.y;
