@@ -213,7 +213,8 @@ class ConvPlan:
     # changed), ~150 per D + G iteration: the tables are shared between plans of one geometry, only the weights are new.
     _GEOMETRY = {}
     _GEOM_ATTRS = ("kind", "cout", "cin", "k", "bn", "n_groups", "halo", "src", "max_chan", "wstrides", "nsteps", "flop_steps",
-                   "early_a", "ksplit_ok", "steps", "src_dev", "chunk_start", "chunks_per_group", "w4_shape", "max_chunk_steps")
+                   "early_a", "ksplit_ok", "steps", "src_dev", "chunk_start", "chunks_per_group", "w4_shape", "max_chunk_steps",
+                   "full_cover")
 
     def __init__(self, weight, kind="conv", scale=1.0, chan_base=0, precision=None):
         _chk(weight, "weight")
@@ -389,6 +390,11 @@ class ConvPlan:
         self.wstrides = (sn, sc, sy, sx)
         self.nsteps = len(steps) // self.n_groups
         self.flop_steps = sum(1 for t in src if t[0] >= 0) // self.n_groups
+        # every element of the weight tensor is the target of exactly one (step, output channel, k) of the table: the weight
+        # gradient's split reduction then WRITES all of dW and no zero fill has to run in front of it
+        live = [tuple(t[:3]) for t in src if t[0] >= 0]
+        target = math.prod(self.w4_shape) if kind == "dgradT" else w.numel()     # what conv_wgrad(plan, ...) returns
+        self.full_cover = bool(self.n_groups == 1 and len(set(live)) == len(live) and len(live) * 32 * cout == target)
         dev = w.device
         # flags: bit 0 = this step opens a chunk; bit 1 = the NEXT step of the group opens one, bits 8.. = its channel
         # offset (lets the kernel request a chunk's activations a step early when every chunk spans >= 2 steps)
@@ -723,11 +729,12 @@ def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=No
                  cout, plan.nsteps, nchunks, splits, _stream()), name)
     # 'dgradT': the plan's "weights" are the blurred 4x4 kernel (Cin,Cout,4,4) of the transposed conv
     shape = plan.w4_shape if plan.kind == "dgradT" else (plan.cout, plan.cin, plan.k, plan.k)
+    cover = getattr(plan, "full_cover", False)
     if out is None:
-        dw = torch.zeros(shape, device=x.device, dtype=torch.float32)
+        dw = (torch.empty if cover else torch.zeros)(shape, device=x.device, dtype=torch.float32)
     else:
         dw = _grad_out(out, shape, x)
-        if not accumulate:
+        if not accumulate and not cover:
             dw.zero_()
     sn, sc, sy, sx = plan.wstrides
     c_, ky_, kx_ = plan.src_dev
