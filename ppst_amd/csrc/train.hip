@@ -548,7 +548,10 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr_kernel(const float* __re
 // where a 4-tap chunk would otherwise do 4/9 of the MFMA work of a 3x3 chunk per staged tile (blockIdx.y = pair of chunks).
 // X1: single-pass bf16 (precision mode 1, BASELINE configs[3]'s "bf16 compute, fp32 master weights"): only the hi halves are
 // written and multiplied -- a third of the MFMA phase; the bias column sums still come from the fp32 values.
-template <int NCH, int TM, bool X1>
+// EXACT: every chunk of the table has exactly TM steps (3x3 convs: 9; the transposed conv's phases: 4) -- the tap loop then has
+// no `t < T` tests.  With the runtime count each tap was its own basic block behind a branch (hipcc's wait-count pass drains the
+// LDS queue at every block entry, and the next tap's fragments could not be requested across it).
+template <int NCH, int TM, bool X1, bool EXACT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               const int4* __restrict__ steps, const int* __restrict__ chunk_start,
                                                               float* __restrict__ partial, float* __restrict__ csum, int B, int in_h,
@@ -692,9 +695,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
           frag(im + pb0 * 128 + tr_unit, (((pb0 & 3) + qd) >> 1) & 1, b_h, b_l);
 #pragma unroll
           for (int t = 0; t < TM; ++t) {
-            if (t < T[ci]) {
+            if (EXACT || t < T[ci]) {
               bf16x8 n_h = b_h, n_l = b_l;
-              if (t + 1 < TM && t + 1 < T[ci]) {              // the next tap's fragments are requested before this tap's MFMAs
+              if (t + 1 < TM && (EXACT || t + 1 < T[ci])) {   // the next tap's fragments are requested before this tap's MFMAs
                 const int pb = (row + 1 + tdy[ci][t + 1]) * WT_XW + xh + 1 + tdx[ci][t + 1];
                 frag(im + pb * 128 + tr_unit, (((pb & 3) + qd) >> 1) & 1, n_h, n_l);
               }
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
   for (int ci = 0; ci < NCH; ++ci)
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
-      if (t < T[ci]) {
+      if (EXACT || t < T[ci]) {
         float* o = partial + (((int64_t)bz * nsteps + s0[ci] + t) * cout) * 32;
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) {
@@ -807,7 +810,7 @@ extern "C" int ppst_conv_wgrad_tr(const void* x, const void* dy, const void* ste
 // [splits][cout] partial column sums of dy
 extern "C" int ppst_conv_wgrad_tr2(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial, void* csum,
                                    int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
-                                   int nchunks, int splits, int max_taps, int passes, void* stream) {
+                                   int nchunks, int splits, int max_taps, int min_taps, int passes, void* stream) {
   if (B < 0 || in_h <= 0 || in_w <= 0 || in_ld <= 0 || oh <= 0 || ow <= 0 || dy_ld < cout || cout <= 0 || nsteps <= 0 ||
       nchunks <= 0 || splits <= 0 || (passes != 1 && passes != 3))
     return PPST_EINVAL;
@@ -823,12 +826,15 @@ extern "C" int ppst_conv_wgrad_tr2(const void* x, const void* dy, const void* st
   dim3 grid(cdiv(cout, 128), pair ? nchunks / 2 : nchunks, splits);
   const int slot = wgrad_prof_begin(B, oh, ow, cout, nsteps, g_wgrad_flop_steps, nchunks, splits, as_stream(stream));
   g_wgrad_flop_steps = 0;
-#define WG2(NCH, TM, X1)                                                                                                              \
-  PPST_LAUNCH((conv_wgrad_tr2_kernel<NCH, TM, X1>), grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy,             \
+#define WG2(NCH, TM, X1, EX)                                                                                                          \
+  PPST_LAUNCH((conv_wgrad_tr2_kernel<NCH, TM, X1, EX>), grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy,         \
               (const int4*)steps, (const int*)chunk_start, (float*)partial, (float*)csum, B, in_h, in_w, in_ld, oh, ow, dy_ld, cout,     \
               nsteps, tiles_x, tiles_per_image, tiles_total, tps)
-  if (pair) { if (passes == 1) WG2(2, 4, true); else WG2(2, 4, false); }
-  else { if (passes == 1) WG2(1, WG_MAXT, true); else WG2(1, WG_MAXT, false); }
+#define WG2X(NCH, TM, EX) do { if (passes == 1) WG2(NCH, TM, true, EX); else WG2(NCH, TM, false, EX); } while (0)
+  // max_taps / min_taps: the caller's promise about the table's chunk lengths (the table lives on the device)
+  if (pair) { if (min_taps == 4 && max_taps == 4) WG2X(2, 4, true); else WG2X(2, 4, false); }
+  else { if (min_taps == WG_MAXT && max_taps == WG_MAXT) WG2X(1, WG_MAXT, true); else WG2X(1, WG_MAXT, false); }
+#undef WG2X
 #undef WG2
   ppst_prof_end_(slot, as_stream(stream));
   return PPST_LAUNCH_CHECK();

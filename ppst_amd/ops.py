@@ -214,7 +214,7 @@ class ConvPlan:
     _GEOMETRY = {}
     _GEOM_ATTRS = ("kind", "cout", "cin", "k", "bn", "n_groups", "halo", "src", "max_chan", "wstrides", "nsteps", "flop_steps",
                    "early_a", "ksplit_ok", "steps", "src_dev", "chunk_start", "chunks_per_group", "w4_shape", "max_chunk_steps",
-                   "full_cover")
+                   "min_chunk_steps", "full_cover")
 
     def __init__(self, weight, kind="conv", scale=1.0, chan_base=0, precision=None):
         _chk(weight, "weight")
@@ -413,6 +413,7 @@ class ConvPlan:
         lens = [b_ - a_ for a_, b_ in zip(starts[:-1], starts[1:])]
         self.early_a = 1 if (min(lens) >= 2 and ns_ >= 3) else 0
         self.max_chunk_steps = max(lens)
+        self.min_chunk_steps = min(lens)
         # conv_ksplit.hip stores a chunk one step PAIR before its first use: a 2-step chunk must not straddle two pairs
         self.ksplit_ok = bool(self.early_a and all(l_ >= 3 or (a_ % ns_) % 2 == 0 for a_, l_ in zip(starts[:-1], lens)))
         # 4 padding rows: the kernel prefetches the descriptor of step s+3 without a bounds test
@@ -655,7 +656,7 @@ def _grad_out(out, shape, like):
 # further split is 2 x 147 KB of partial sums written and re-read by the scatter), >= min_tiles pixel tiles per block
 # form 2: two 256-thread blocks per CU; bf16_single_pass: in precision mode 1 (bf16 compute, fp32 master weights -- BASELINE
 # configs[3]) the weight gradient multiplies the hi halves only (one MFMA pass instead of three)
-WGRAD_TR = {"value": True, "blocks": 256, "min_tiles": 8, "form": 2, "blocks2": 512, "pair": True, "bf16_single_pass": True}
+WGRAD_TR = {"value": True, "blocks": 256, "min_tiles": 8, "form": 2, "blocks2": 512, "pair": True, "bf16_single_pass": True, "exact": True}
 
 
 def presplit(x):
@@ -717,6 +718,7 @@ def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=No
         if WGRAD_TR["form"] == 2:
             check(lib.ppst_conv_wgrad_tr2(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), _p(csum), B, H, W, in_ld, oh, ow,
                                           dy_ld, cout, plan.nsteps, nchunks, splits, plan.max_chunk_steps if WGRAD_TR["pair"] else 0,
+                                          plan.min_chunk_steps if WGRAD_TR["exact"] else 0,
                                           1 if (PRECISION["value"] == 1 and WGRAD_TR["bf16_single_pass"]) else 3,
                                           _stream()), "ppst_conv_wgrad_tr2")
         else:
