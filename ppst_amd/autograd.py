@@ -266,16 +266,25 @@ class InstanceNormFn(Function):
     ``st``: tile statistics of y from the producing kernel (None: computed here)."""
 
     @staticmethod
-    def forward(ctx, y, st, style, post_bias, prelu, act, eps):
+    def forward(ctx, y, st, style, post_bias, prelu, act, eps, res=None, out_scale=1.0):
+        """``res`` / ``out_scale`` (act NONE only): (IN(y) + res) * out_scale in the same pass -- the resnet merge
+        (skip + res) / sqrt2 of generator.py:47-78 without materialising the normalised branch (bit-identical to
+        instance_norm followed by AddScaleFn: the same fp32 operations in the same order)."""
         y = _c(y)
         B, H, W, C = y.shape
         if st is None:
             st = ops.in_stats(y)
         ss, mr = ops.in_finalize_train(st, H * W, style=style, post_bias=post_bias, eps=eps)
-        out = ops.affine_act(y, ss, act=act, prelu=prelu)
+        if res is not None:
+            assert act == NONE
+            out = ops.affine_act(y, ss, res=_c(res), out_scale=out_scale)
+        else:
+            assert out_scale == 1.0
+            out = ops.affine_act(y, ss, act=act, prelu=prelu)
         ctx.save_for_backward(y, out if act == LRELU else None, mr, style, ss if act == PRELU else None, prelu)
         ctx.act = act
         ctx.refs = (post_bias,)
+        ctx.out_scale = float(out_scale) if res is not None else None
         return out
 
     @staticmethod
@@ -287,6 +296,10 @@ class InstanceNormFn(Function):
         gate = gates.sign_gate(out, "in-lrelu") if ctx.act == LRELU else None
         if ctx.act == PRELU:
             g, dprelu = prelu_bwd(g, y, prelu, scale_shift=ss)
+        dres = None
+        if ctx.out_scale is not None:
+            # the merge's backward: g * out_scale is the gradient of the residual input AND the upstream of the norm
+            g = dres = ops.affine_act(g, None, out_scale=ctx.out_scale)
         part = ops.dual_stats(g, y, gate)
         want = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         coef, dstyle = ops.in_bwd_finalize(part, H * W, mr, style, want_dstyle=want)
@@ -298,11 +311,11 @@ class InstanceNormFn(Function):
             dpb = ops.colsum(dstyle[:, C:], out=dst, accumulate=dst is not None)
             if dst is not None:
                 _noted(post_bias); dpb = None
-        return dy, None, (dstyle if ctx.needs_input_grad[2] else None), dpb, dprelu, None, None
+        return dy, None, (dstyle if ctx.needs_input_grad[2] else None), dpb, dprelu, None, None, dres, None
 
 
-def instance_norm(y, st=None, style=None, post_bias=None, prelu=None, act=NONE, eps=1e-5):
-    return InstanceNormFn.apply(y, st, style, post_bias, prelu, act, eps)
+def instance_norm(y, st=None, style=None, post_bias=None, prelu=None, act=NONE, eps=1e-5, res=None, out_scale=1.0):
+    return InstanceNormFn.apply(y, st, style, post_bias, prelu, act, eps, res, out_scale)
 
 
 class AddScaleFn(Function):
