@@ -266,10 +266,12 @@ class InstanceNormFn(Function):
     ``st``: tile statistics of y from the producing kernel (None: computed here)."""
 
     @staticmethod
-    def forward(ctx, y, st, style, post_bias, prelu, act, eps, res=None, out_scale=1.0):
+    def forward(ctx, y, st, style, post_bias, prelu, act, eps, res=None, out_scale=1.0, res_up2=False):
         """``res`` / ``out_scale`` (act NONE only): (IN(y) + res) * out_scale in the same pass -- the resnet merge
         (skip + res) / sqrt2 of generator.py:47-78 without materialising the normalised branch (bit-identical to
-        instance_norm followed by AddScaleFn: the same fp32 operations in the same order)."""
+        instance_norm followed by AddScaleFn: the same fp32 operations in the same order).  ``res_up2``: ``res`` is the
+        half-resolution skip tensor, sampled bilinearly (x2, align_corners=False) by the pass itself -- the upsampled skip of
+        UpsamplingResnetBlock (generator.py:63-78) is never written."""
         y = _c(y)
         B, H, W, C = y.shape
         if st is None:
@@ -277,7 +279,7 @@ class InstanceNormFn(Function):
         ss, mr = ops.in_finalize_train(st, H * W, style=style, post_bias=post_bias, eps=eps)
         if res is not None:
             assert act == NONE
-            out = ops.affine_act(y, ss, res=_c(res), out_scale=out_scale)
+            out = ops.affine_act(y, ss, res=_c(res), out_scale=out_scale, res_up2=res_up2)
         else:
             assert out_scale == 1.0
             out = ops.affine_act(y, ss, act=act, prelu=prelu)
@@ -285,6 +287,7 @@ class InstanceNormFn(Function):
         ctx.act = act
         ctx.refs = (post_bias,)
         ctx.out_scale = float(out_scale) if res is not None else None
+        ctx.res_low = (res.shape[1], res.shape[2]) if (res is not None and res_up2) else None
         return out
 
     @staticmethod
@@ -300,6 +303,8 @@ class InstanceNormFn(Function):
         if ctx.out_scale is not None:
             # the merge's backward: g * out_scale is the gradient of the residual input AND the upstream of the norm
             g = dres = ops.affine_act(g, None, out_scale=ctx.out_scale)
+            if ctx.res_low is not None:
+                dres = ops.bilinear_bwd(g, *ctx.res_low) if ctx.needs_input_grad[7] else None
         part = ops.dual_stats(g, y, gate)
         want = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         coef, dstyle = ops.in_bwd_finalize(part, H * W, mr, style, want_dstyle=want)
@@ -311,11 +316,11 @@ class InstanceNormFn(Function):
             dpb = ops.colsum(dstyle[:, C:], out=dst, accumulate=dst is not None)
             if dst is not None:
                 _noted(post_bias); dpb = None
-        return dy, None, (dstyle if ctx.needs_input_grad[2] else None), dpb, dprelu, None, None, dres, None
+        return dy, None, (dstyle if ctx.needs_input_grad[2] else None), dpb, dprelu, None, None, dres, None, None
 
 
-def instance_norm(y, st=None, style=None, post_bias=None, prelu=None, act=NONE, eps=1e-5, res=None, out_scale=1.0):
-    return InstanceNormFn.apply(y, st, style, post_bias, prelu, act, eps, res, out_scale)
+def instance_norm(y, st=None, style=None, post_bias=None, prelu=None, act=NONE, eps=1e-5, res=None, out_scale=1.0, res_up2=False):
+    return InstanceNormFn.apply(y, st, style, post_bias, prelu, act, eps, res, out_scale, res_up2)
 
 
 class AddScaleFn(Function):

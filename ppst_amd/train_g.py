@@ -20,6 +20,8 @@ from .train import DiscriminatorTrainer, ddp_average_
 
 SQRT2 = math.sqrt(2.0)
 INV_SQRT2 = 1.0 / SQRT2
+# tuning switches of the differentiable generator (tests/train_ab.py flips them for same-process A/B timing)
+TRAIN_FUSE = {"merge": True, "res_up2": True}
 HEAD_CH = [(256, 256), (256, 256), (256, 384), (384, 512)]
 UP = [(16, 512, 512), (32, 512, 256), (64, 256, 128)]
 TAGS = ["9", "0", "1", "2"]
@@ -237,7 +239,7 @@ class GeneratorTrainer:
         return out
 
     # ------------------------------------------------------------ G (generator.py:244-281)
-    def _styled_conv(self, x, p, code, key, noise, upsample=False, res=None, out_scale=1.0):
+    def _styled_conv(self, x, p, code, key, noise, upsample=False, res=None, out_scale=1.0, res_up2=False):
         net, P = self.G, self.G.p
         parts = (P(p + "conv.bias"), P(p + "bias"), P(p + "activate.bias"))                # three biases of StyledConv collapse
         bias_params = parts if all(A._direct(q) is not None for q in parts) else None
@@ -260,7 +262,7 @@ class GeneratorTrainer:
                        noise_w_host=self.fp["G"].scalar(p + "noise.weight"), bias_params=bias_params)
         wl = P(p + "epi1.style_mod.lin.weight")
         style = A.linear(code, wl, P(p + "epi1.style_mod.lin.bias"), wscale=wl.shape[1] ** -0.5)
-        return A.instance_norm(a, st, style=style, res=res, out_scale=out_scale)     # res: the block's (skip + res) / sqrt2 merge
+        return A.instance_norm(a, st, style=style, res=res, out_scale=out_scale, res_up2=res_up2)     # res: the block's (skip + res) / sqrt2 merge
 
     def generator(self, sp, global_codes, noise=None, extract_features=False):
         """sp NHWC (B,h,w,256), codes 4 x (B,2048) -> rgb NCHW (B,3,8h,8w) [, feat NHWC, feat1 NHWC]."""
@@ -277,7 +279,10 @@ class GeneratorTrainer:
             sw = q + "skip.Conv.weight"
             skip = x if ci == co else A.conv(x, P(sw), net, sw, scale=1.0 / math.sqrt(ci))
             r = self._styled_conv(x, q + "conv1.", g, "HeadResnetBlock%d.conv1" % i, noise)
-            x = self._styled_conv(r, q + "conv2.", g, "HeadResnetBlock%d.conv2" % i, noise, res=skip, out_scale=INV_SQRT2)
+            if TRAIN_FUSE["merge"]:
+                x = self._styled_conv(r, q + "conv2.", g, "HeadResnetBlock%d.conv2" % i, noise, res=skip, out_scale=INV_SQRT2)
+            else:
+                x = A.AddScaleFn.apply(skip, self._styled_conv(r, q + "conv2.", g, "HeadResnetBlock%d.conv2" % i, noise), INV_SQRT2)
         feas = []
         if extract_features:
             feas.append(self._feat_head(x.detach(), "layer32.", 3))
@@ -289,9 +294,16 @@ class GeneratorTrainer:
             else:
                 sw = q + "skip.Conv.weight"
                 skip = A.conv(x, P(sw), net, sw, bias=P(q + "skip.Act.bias"), scale=1.0 / math.sqrt(ci), act=A.LRELU)
-            skip = A.BilinearFn.apply(skip, 2 * skip.shape[1], 2 * skip.shape[2])
+            # (the x2 bilinear upsample of the skip is sampled on the fly by the merge pass, as in the inference path)
+            up2 = TRAIN_FUSE["res_up2"] and TRAIN_FUSE["merge"]
+            if not up2:
+                skip = A.BilinearFn.apply(skip, 2 * skip.shape[1], 2 * skip.shape[2])
             r = self._styled_conv(x, q + "conv1.", g, "UpsamplingResBlock%d.conv1" % key, noise, upsample=True)
-            x = self._styled_conv(r, q + "conv2.", g, "UpsamplingResBlock%d.conv2" % key, noise, res=skip, out_scale=INV_SQRT2)
+            if TRAIN_FUSE["merge"]:
+                x = self._styled_conv(r, q + "conv2.", g, "UpsamplingResBlock%d.conv2" % key, noise, res=skip, out_scale=INV_SQRT2,
+                                      res_up2=up2)
+            else:
+                x = A.AddScaleFn.apply(skip, self._styled_conv(r, q + "conv2.", g, "UpsamplingResBlock%d.conv2" % key, noise), INV_SQRT2)
             if extract_features:
                 feas.append(self._feat_head(x.detach(), "layer%d." % (2 ** (j + 6)), 3 if j < 2 else 1))
         wr = P("ToRGB.conv.weight")
