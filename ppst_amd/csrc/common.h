@@ -73,6 +73,25 @@ __device__ __forceinline__ void split_bf16(float x, unsigned short& hi, unsigned
   lo = f2bf(x - bf2f(hi));
 }
 
+// the same split for four values at once, two elements per instruction: v_cvt_pk_bf16_f32 converts a PAIR, v_pk_add_f32
+// subtracts a pair -- 10 vector instructions per float4 (2 cvt + 4 shift / mask + 2 sub + 2 cvt).  The element-wise form above
+// compiled to 12 cvt_pk + 12 SDWA merges + 8 more per float4 in the conv kernels' staging (hipcc does not pair scalar casts).
+// Bit-identical: the same round-to-nearest-even conversions and the same fp32 subtraction.
+typedef __bf16 __attribute__((ext_vector_type(2))) ppst_bf2;
+typedef float __attribute__((ext_vector_type(2))) ppst_f2;
+__device__ __forceinline__ unsigned f2bf_pk(ppst_f2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ppst_bf2)); }
+__device__ __forceinline__ void split_bf16x4(float4 v, uint2& hi, uint2& lo) {
+  const ppst_f2 a = {v.x, v.y}, b = {v.z, v.w};
+  const unsigned h0 = f2bf_pk(a), h1 = f2bf_pk(b);
+  const ppst_f2 ra = a - (ppst_f2){__uint_as_float(h0 << 16), __uint_as_float(h0 & 0xffff0000u)};
+  const ppst_f2 rb = b - (ppst_f2){__uint_as_float(h1 << 16), __uint_as_float(h1 & 0xffff0000u)};
+  hi = make_uint2(h0, h1);
+  lo = make_uint2(f2bf_pk(ra), f2bf_pk(rb));
+}
+__device__ __forceinline__ uint2 f2bf_x4(float4 v) {        // single-pass bf16: the hi halves only
+  return make_uint2(f2bf_pk((ppst_f2){v.x, v.y}), f2bf_pk((ppst_f2){v.z, v.w}));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

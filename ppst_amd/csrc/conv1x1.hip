@@ -51,6 +51,31 @@ __device__ __forceinline__ void c1_cvt(float v, unsigned short& h, unsigned shor
   else if (PREC == 3) { h = __builtin_bit_cast(unsigned short, (_Float16)v); l = 0; }
   else { h = f2bf(v); l = 0; }
 }
+// eight values -> the hi / lo operands; PREC 0 / 1 convert pairs (split_bf16x4 / f2bf_x4 of common.h: a third of the vector
+// instructions of the element-wise form, same bits)
+template <int PREC>
+__device__ __forceinline__ void c1_cvt8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+  if (PREC == 3) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      unsigned short h, l;
+      c1_cvt<PREC>(v[j], h, l);
+      hi[j] = (short)h;
+      lo[j] = (short)l;
+    }
+    return;
+  }
+  uint2 h0, l0 = make_uint2(0u, 0u), h1, l1 = make_uint2(0u, 0u);
+  if (PREC == 0) {
+    split_bf16x4(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
+    split_bf16x4(make_float4(v[4], v[5], v[6], v[7]), h1, l1);
+  } else {
+    h0 = f2bf_x4(make_float4(v[0], v[1], v[2], v[3]));
+    h1 = f2bf_x4(make_float4(v[4], v[5], v[6], v[7]));
+  }
+  hi = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+  lo = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+}
 template <int PREC>
 __device__ __forceinline__ f32x4 c1_mfma(bf16x8 bh, bf16x8 bl, bf16x8 xh, bf16x8 xl, f32x4 acc) {
   if (PREC == 0) {
@@ -299,13 +324,9 @@ __global__ __launch_bounds__(512, 4) void conv1x1_stream_kernel(C1Args a) {
           for (int j = 0; j < 8; ++j) v[j] = in_act(sc[j] * v[j] + sh[j]);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 8; ++j)
           if (!vok[mt]) v[j] = 0.f;
-          unsigned short h, l;
-          c1_cvt<PREC>(v[j], h, l);
-          ah[mt][j] = (short)h;
-          al[mt][j] = (short)l;
-        }
+        c1_cvt8<PREC>(v, ah[mt], al[mt]);
       }
       if (s + 1 < a.nsteps) a_load(steps[s + 1]);            // in flight while the matrix pipe works on this step
       const unsigned char* bs = (const unsigned char*)sB + sl * BLOB1 + g * 1024 + r16 * 16;
@@ -424,13 +445,9 @@ __global__ __launch_bounds__(512, NT_ > 4 ? 2 : 4) void conv3x3_direct_kernel(C1
       for (int j = 0; j < 8; ++j) v[j] = in_act(sc[j] * v[j] + sh[j]);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 8; ++j)
       if (!ok) v[j] = 0.f;
-      unsigned short h, l;
-      c1_cvt<PREC>(v[j], h, l);
-      hi[j] = (short)h;
-      lo[j] = (short)l;
-    }
+    c1_cvt8<PREC>(v, hi, lo);
   };
 
   int chan = steps[0].x;

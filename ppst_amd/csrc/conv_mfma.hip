@@ -258,17 +258,19 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
           v.x = in_act(ras0.x * v.x + ras0.y); v.y = in_act(ras0.z * v.y + ras0.w);
           v.z = in_act(ras1.x * v.z + ras1.y); v.w = in_act(ras1.z * v.w + ras1.w);
         }
-        unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
-        if (F16 && X2) { split_f16(v.x, h0, l0); split_f16(v.y, h1, l1); split_f16(v.z, h2, l2); split_f16(v.w, h3, l3); }
-        else if (F16) { h0 = f2h(v.x); h1 = f2h(v.y); h2 = f2h(v.z); h3 = f2h(v.w); l0 = l1 = l2 = l3 = 0; }
-        else { split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3); }
-        int off = (l >> 4) * PLANE + pix * 16 + (l & 1) * 8;
-        uint2 hv = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
-        *(uint2*)(base + off) = hv;
-        if (ALO) {
-          uint2 lv = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
-          *(uint2*)(base + 4 * PLANE + off) = lv;
+        uint2 hv, lv;
+        if (F16) {
+          unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
+          if (X2) { split_f16(v.x, h0, l0); split_f16(v.y, h1, l1); split_f16(v.z, h2, l2); split_f16(v.w, h3, l3); }
+          else { h0 = f2h(v.x); h1 = f2h(v.y); h2 = f2h(v.z); h3 = f2h(v.w); l0 = l1 = l2 = l3 = 0; }
+          hv = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
+          lv = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+        } else {
+          split_bf16x4(v, hv, lv);          // two elements per conversion / subtraction instruction (common.h)
         }
+        int off = (l >> 4) * PLANE + pix * 16 + (l & 1) * 8;
+        *(uint2*)(base + off) = hv;
+        if (ALO) *(uint2*)(base + 4 * PLANE + off) = lv;
       }
     }
   };

@@ -195,13 +195,15 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
           v.x = in_act(ras0.x * v.x + ras0.y); v.y = in_act(ras0.z * v.y + ras0.w);
           v.z = in_act(ras1.x * v.z + ras1.y); v.w = in_act(ras1.z * v.w + ras1.w);
         }
-        unsigned short h0, h1, h2, h3, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
-        if (X3) { split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3); }
-        else if (PREC == 3) { h0 = f2h_2(v.x); h1 = f2h_2(v.y); h2 = f2h_2(v.z); h3 = f2h_2(v.w); }
-        else { h0 = f2bf(v.x); h1 = f2bf(v.y); h2 = f2bf(v.z); h3 = f2bf(v.w); }
+        uint2 hv, lv = make_uint2(0u, 0u);
+        if (X3) split_bf16x4(v, hv, lv);     // two elements per conversion / subtraction instruction (common.h)
+        else if (PREC == 3) {
+          const unsigned short h0 = f2h_2(v.x), h1 = f2h_2(v.y), h2 = f2h_2(v.z), h3 = f2h_2(v.w);
+          hv = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
+        } else hv = f2bf_x4(v);
         int off = (l >> 4) * PLANE + pix * 16 + (l & 1) * 8;
-        *(uint2*)(base + off) = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
-        if (X3) *(uint2*)(base + 4 * PLANE + off) = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+        *(uint2*)(base + off) = hv;
+        if (X3) *(uint2*)(base + 4 * PLANE + off) = lv;
       }
     }
   };

@@ -416,12 +416,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr_kernel(const float* __re
   auto dma_tile = [&](int tile, int slot) {
     for (int wi = wave; wi < 32 + 17; wi += 8) dma_piece(tile, slot, wi);
   };
-  auto split4 = [](float4 v, uint2& hi, uint2& lo) {
-    unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
-    split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
-    hi = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
-    lo = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
-  };
+  auto split4 = [](float4 v, uint2& hi, uint2& lo) { split_bf16x4(v, hi, lo); };
   // transposed-read lane geometry: group g = lane / 16 reads 4 pixel rows x 16 channels; lane 4q + p of the group supplies the
   // address of row q, channels 4p .. 4p+3; lane i receives channel i of the 4 rows.  Groups 0 / 1: channels 0-15 / 16-31 of
   // k-half 0, groups 2 / 3 the same of k-half 1 -- i.e. channel li, k-half kb, as the 32x32x16 operand wants.
@@ -601,12 +596,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
   // transposed-read lane geometry (conv_wgrad_tr_kernel): channel quad 4 (g & 1) + pp, pixel 8 kb + qd (+ 4 for the second read)
   const int g = lane >> 4, qd = (lane & 15) >> 2, pp = lane & 3;
   const int tr_unit = (8 * (g >> 1) + qd) * 128 + (4 * (g & 1) + pp) * 16;
-  auto split4 = [](float4 v, uint2& hi, uint2& lo) {
-    unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
-    split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
-    hi = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
-    lo = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
-  };
+  auto split4 = [](float4 v, uint2& hi, uint2& lo) { split_bf16x4(v, hi, lo); };
   // operand of 8 k-values (pixels) from the unit image: ``u`` = address of this lane's unit of the first pixel group, ``sw`` = 1
   // when that pixel pair stores [lo | hi]
   auto frag = [&](const unsigned char* u, int sw, bf16x8& h, bf16x8& l) {
