@@ -371,3 +371,28 @@ def test_conv_kernel_choice_is_a_function_of_one_image():
     assert ck(plan("conv", 256, 256, 3, 72, 1, precision=4), 256) == (0, 128, 16)
     assert ck(plan("conv", 32, 32, 3, 9, 1, precision=2), 512) == (0, 64, 16)
     assert not ops.TWO_BLOCK_128["value"] and not ops.TALL_TILE_128["value"] and ops.DIRECT_MAX["cout3x3"] == 64
+
+
+def test_gemm_mode_selection():
+    """ops.gemm_nt / gemm_nn pick the kernel from the call site's mode, the conv precision and K (no launch here):
+    cosine logits -> six passes over three bf16 planes (fp32-class), products with the softmax matrix -> three passes,
+    exact-conv mode (precision 2) and K the split kernels do not take -> the fp32 MFMA kernel."""
+    from ppst_amd import ops
+    assert ops._gemm_passes(None, 512) == 6 and ops._gemm_passes("x6", 4608) == 6
+    assert ops._gemm_passes("x3", 4096) == 3
+    assert ops._gemm_passes("x3", 48) == 6            # K % 32 != 0: the six-pass form takes K % 16
+    assert ops._gemm_passes("x3", 24) == 0 and ops._gemm_passes(None, 8) == 0
+    assert ops._gemm_passes("f32", 512) == 0
+    prev = ops.PRECISION["value"]
+    try:
+        ops.PRECISION["value"] = 2
+        assert ops._gemm_passes("x3", 4096) == 0 and ops._gemm_passes(None, 512) == 0
+    finally:
+        ops.PRECISION["value"] = prev
+    ops.GEMM_MODE["value"] = "f32"
+    try:
+        assert ops._gemm_passes("x3", 4096) == 0
+    finally:
+        ops.GEMM_MODE["value"] = None
+    with pytest.raises(ValueError):
+        ops._gemm_passes("bf16", 64)
