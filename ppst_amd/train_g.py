@@ -267,6 +267,18 @@ class GeneratorTrainer:
     def generator(self, sp, global_codes, noise=None, extract_features=False):
         """sp NHWC (B,h,w,256), codes 4 x (B,2048) -> rgb NCHW (B,3,8h,8w) [, feat NHWC, feat1 NHWC]."""
         net, P = self.G, self.G.p
+        if not isinstance(noise, dict):
+            # NoiseInjection draws N(0,1) per layer (stylegan2_layers.py:388-390): all fourteen planes of this pass from ONE
+            # torch.randn (one generator launch instead of fourteen), handed out as views
+            B, H0, W0 = sp.shape[0], sp.shape[1], sp.shape[2]
+            sizes = [("HeadResnetBlock%d.%s" % (i, c), 0) for i in range(len(HEAD_CH)) for c in ("conv1", "conv2")]
+            sizes += [("UpsamplingResBlock%d.%s" % (key, c), j + 1) for j, (key, _, _) in enumerate(UP) for c in ("conv1", "conv2")]
+            flat = torch.randn(B * sum((H0 << e) * (W0 << e) for _, e in sizes), device=sp.device)
+            noise, off = {}, 0
+            for name, e in sizes:
+                n_ = B * (H0 << e) * (W0 << e)
+                noise[name] = flat[off:off + n_].view(B, 1, H0 << e, W0 << e)
+                off += n_
         codes = [A.L2NormFn.apply(c, 1e-8, 0) for c in global_codes]
         g = codes[-1]
         ws = P("SpatialCodeModulation.scale.weight")
