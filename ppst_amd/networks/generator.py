@@ -136,15 +136,14 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
         return ops.affine_act(y, ops.in_finalize(st, H * W), res=x, res_before_act=True, act=ops.ACT_PRELU, prelu=a)
 
     def make_noise(self, B, S, device):
-        out = {}
-        for i in range(4):
-            for c in ("conv1", "conv2"):
-                out["HeadResnetBlock%d.%s" % (i, c)] = torch.randn(B, 1, S, S, device=device)
-        s = S
-        for key, _, _ in UP:
-            s *= 2
-            for c in ("conv1", "conv2"):
-                out["UpsamplingResBlock%d.%s" % (key, c)] = torch.randn(B, 1, s, s, device=device)
+        """the fourteen N(0,1) planes NoiseInjection draws in one pass (stylegan2_layers.py:388-390), from ONE torch.randn."""
+        sizes = [("HeadResnetBlock%d.%s" % (i, c), S) for i in range(4) for c in ("conv1", "conv2")]
+        sizes += [("UpsamplingResBlock%d.%s" % (key, c), S << (j + 1)) for j, (key, _, _) in enumerate(UP) for c in ("conv1", "conv2")]
+        flat = torch.randn(B * sum(s * s for _, s in sizes), device=device)
+        out, off = {}, 0
+        for name, s in sizes:
+            out[name] = flat[off:off + B * s * s].view(B, 1, s, s)
+            off += B * s * s
         return out
 
     def forward(self, spatial_code, global_codes, extract_features=False, noise=None, want_rgb=True):
