@@ -119,6 +119,7 @@ class ConvFn(Function):
         ctx.cfg = (net, wname, kind, scale, pad_mode, act, bias is not None, noise_w is not None)
         ctx.refs = (w, bias, noise_w, bias_params)          # leaf parameters (for their flat-gradient views), not saved tensors
         ctx.mark_non_differentiable(st)
+        ctx.set_materialize_grads(False)        # no zero tensor is built for the statistics output's (absent) gradient
         return y, st
 
     @staticmethod
@@ -191,6 +192,7 @@ class BlurConvFn(Function):
         ctx.cfg = (net, wname, kname, scale, p0, p1, pad_mode, act, bhw, bias is not None)
         ctx.refs = (w, bias)
         ctx.mark_non_differentiable(st)
+        ctx.set_materialize_grads(False)        # no zero tensor is built for the statistics output's (absent) gradient
         return y, st
 
     @staticmethod
