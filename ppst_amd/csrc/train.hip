@@ -591,8 +591,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
   const int t_begin = bz * tiles_per_split;
   const int t_end = min(t_begin + tiles_per_split, tiles_total);
   const bool wave_live = n0 + nw * 32 < cout;
+  const int nslab = min(4, (cout - n0 + 31) >> 5);            // 32-channel slabs of dY this block has any use for
   const bool want_csum = csum != nullptr && by == 0;
-  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);               // this thread's 4 channels (tid & 31) over its pixels of every tile
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);               // this thread's 4 channels (quad tid % (8 nslab)) over its pixels of every tile
   // transposed-read lane geometry (conv_wgrad_tr_kernel): channel quad 4 (g & 1) + pp, pixel 8 kb + qd (+ 4 for the second read)
   const int g = lane >> 4, qd = (lane & 15) >> 2, pp = lane & 3;
   const int tr_unit = (8 * (g >> 1) + qd) * 128 + (4 * (g & 1) + pp) * 16;
@@ -623,6 +624,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
       const float* src = g_wg_zero;
       unsigned char* dst;
       const int q = lane & 7;
+      if (wi < 32 && (wi >> 3) >= nslab) continue;          // slab beyond cout: no wave reads it (thin layers: 8 of 32 pieces)
       if (wi < 32) {
         const int p = 8 * (wi & 7) + (lane >> 3), n = n0 + (wi >> 3) * 32 + q * 4;
         const int y = ty0 + (p >> 5), xx = tx0 + (p & 31);
@@ -642,18 +644,36 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (hipcc adds no wait for LDS-DMA)
     __syncthreads();
     // ---- in-place conversion: unit (pixel p, quad) fp32 x 4 -> [hi | lo] bf16 x 4 (swapped for odd pixel pairs)
+    if (nslab == 4) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int i = tid + it * 256;                           // pixel-major: channel quad (slab * 8 + quad) = tid & 31 for every it
-      const int cq = i & 31, p = i >> 5;
-      unsigned char* u = imdy + (cq >> 3) * 8192 + p * 128 + (cq & 7) * 16;
-      const float4 v = *(const float4*)u;
-      if (want_csum) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
-      uint2 hi, lo;
-      split4(v, hi, lo);
-      const int sw = (p >> 1) & 1;
-      if (X1) *(uint2*)(u + sw * 8) = hi;
-      else *(uint4*)u = sw ? make_uint4(lo.x, lo.y, hi.x, hi.y) : make_uint4(hi.x, hi.y, lo.x, lo.y);
+      for (int it = 0; it < 8; ++it) {
+        const int i = tid + it * 256;                         // pixel-major: channel quad (slab * 8 + quad) = tid & 31 for every it
+        const int cq = i & 31, p = i >> 5;
+        unsigned char* u = imdy + (cq >> 3) * 8192 + p * 128 + (cq & 7) * 16;
+        const float4 v = *(const float4*)u;
+        if (want_csum) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
+        uint2 hi, lo;
+        split4(v, hi, lo);
+        const int sw = (p >> 1) & 1;
+        if (X1) *(uint2*)(u + sw * 8) = hi;
+        else *(uint4*)u = sw ? make_uint4(lo.x, lo.y, hi.x, hi.y) : make_uint4(hi.x, hi.y, lo.x, lo.y);
+      }
+    } else {
+      // fewer live slabs (cout - n0 <= 96): NQ = 8 nslab channel quads; unit i -> quad i % NQ (= tid % NQ in every pass: 256 is a
+      // multiple of 8, 16 and -- with the pass stride rounded down to a multiple of 24 -- of 24), pixel i / NQ
+      const int NQ = 8 * nslab, stride = (256 / NQ) * NQ;
+      if (tid < stride)
+        for (int i = tid; i < 64 * NQ; i += stride) {
+          const int p = i / NQ, cq = i - p * NQ;
+          unsigned char* u = imdy + (cq >> 3) * 8192 + p * 128 + (cq & 7) * 16;
+          const float4 v = *(const float4*)u;
+          if (want_csum) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
+          uint2 hi, lo;
+          split4(v, hi, lo);
+          const int sw = (p >> 1) & 1;
+          if (X1) *(uint2*)(u + sw * 8) = hi;
+          else *(uint4*)u = sw ? make_uint4(lo.x, lo.y, hi.x, hi.y) : make_uint4(hi.x, hi.y, lo.x, lo.y);
+        }
     }
 #pragma unroll
     for (int ci = 0; ci < NCH; ++ci)
@@ -703,15 +723,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
       }
     }
   }
-  if (want_csum) {                                            // column sums of dY: 8 threads share a channel quad
+  if (want_csum) {                                            // column sums of dY: the threads with equal tid % NQ share a channel quad
     __syncthreads();
-    float4* red = (float4*)smem;                              // [8][32] float4
-    red[(tid >> 5) * 32 + (tid & 31)] = cs;
+    float4* red = (float4*)smem;                              // [256] float4, thread order
+    const int NQ = 8 * nslab, stride = (256 / NQ) * NQ;
+    red[tid] = tid < stride ? cs : make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    if (tid < 32) {
+    if (tid < NQ) {
       float4 a = red[tid];
-#pragma unroll
-      for (int r = 1; r < 8; ++r) { const float4 v = red[r * 32 + tid]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+      for (int r = tid + NQ; r < stride; r += NQ) { const float4 v = red[r]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
       const int n = n0 + tid * 4;
       float* o = csum + (int64_t)bz * cout + n;
       if (n < cout) { o[0] = a.x; if (n + 1 < cout) o[1] = a.y; if (n + 2 < cout) o[2] = a.z; if (n + 3 < cout) o[3] = a.w; }
