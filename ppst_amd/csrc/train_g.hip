@@ -233,8 +233,10 @@ __device__ __forceinline__ int pad_src(int t, int n, int mode) {   // padded coo
   }
   return t < 0 ? 0 : n - 1;
 }
-// y[b][ty][tx][c] = x[b][src(ty - py0)][src(tx - px0)][c]  (F.pad zero / reflect / replicate)
-__global__ __launch_bounds__(256) void pad2d_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int x_ld,
+// y[b][ty][tx][c] = x[b][src(ty - py0)][src(tx - px0)][c]  (F.pad zero / reflect / replicate).  VT = float4 when C, x_ld are
+// multiples of 4 and the pointers 16-byte aligned (every tensor of the train step): C and x_ld are then counted in float4s.
+template <typename VT>
+__global__ __launch_bounds__(256) void pad2d_kernel(const VT* __restrict__ x, VT* __restrict__ y, int H, int W, int C, int x_ld,
                                                     int OH, int OW, int py0, int px0, int mode, unsigned total, FastDiv d_c,
                                                     FastDiv d_ow, FastDiv d_oh) {
   for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256) void pad2d_kernel(const float* __restrict__ x,
     r = fd_divmod(r, d_ow, tx);
     const unsigned b = fd_divmod(r, d_oh, ty);
     const int sy = pad_src((int)ty - py0, H, mode), sx = pad_src((int)tx - px0, W, mode);
-    float v = 0.f;
+    VT v = {};
     if (sy >= 0 && sx >= 0) v = x[(((int64_t)b * H + sy) * W + sx) * x_ld + c];
     y[t64] = v;
   }
@@ -257,23 +259,32 @@ extern "C" int ppst_pad2d(const void* x, void* y, int B, int H, int W, int C, in
   if (!x || !y) return PPST_ENULL;
   const int64_t total = (int64_t)B * OH * OW * C;
   if (total > PPST_IDX32_MAX) return PPST_EINVAL;
-  PPST_LAUNCH(pad2d_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, H, W, C, x_ld, OH, OW,
+  if (C % 4 == 0 && x_ld % 4 == 0 && ((uintptr_t)x | (uintptr_t)y) % 16 == 0) {
+    PPST_LAUNCH(pad2d_kernel<float4>, dim3(tg_grid(total / 4)), dim3(256), 0, as_stream(stream), (const float4*)x, (float4*)y, H, W, C / 4,
+                x_ld / 4, OH, OW, py0, px0, mode, (unsigned)(total / 4), make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)OW),
+                make_fastdiv((unsigned)OH));
+    return PPST_LAUNCH_CHECK();
+  }
+  PPST_LAUNCH(pad2d_kernel<float>, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, H, W, C, x_ld, OH, OW,
               py0, px0, mode, (unsigned)total, make_fastdiv((unsigned)C), make_fastdiv((unsigned)OW), make_fastdiv((unsigned)OH));
   return PPST_LAUNCH_CHECK();
 }
 // adjoint of ppst_pad2d: dx[b][y][x][c] = sum of dy over every padded position whose source is (y, x).
 // Candidates per axis: the interior copy plus the (py0 + py1) border positions -- tested, not enumerated in closed form.
-__global__ __launch_bounds__(256) void pad2d_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int C,
+__device__ __forceinline__ void pad_acc(float& a, float v) { a += v; }
+__device__ __forceinline__ void pad_acc(float4& a, float4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+template <typename VT>
+__global__ __launch_bounds__(256) void pad2d_bwd_kernel(const VT* __restrict__ dy, VT* __restrict__ dx, int H, int W, int C,
                                                         int OH, int OW, int py0, int py1, int px0, int px1, int mode, unsigned total,
                                                         FastDiv d_c, FastDiv d_w, FastDiv d_h) {
+  const int ny = 1 + (py0 > 0 ? py0 : 0) + (py1 > 0 ? py1 : 0), nx = 1 + (px0 > 0 ? px0 : 0) + (px1 > 0 ? px1 : 0);
   for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
     unsigned c, xx, yy;
     unsigned r = fd_divmod((unsigned)t64, d_c, c);
     r = fd_divmod(r, d_w, xx);
     const unsigned b = fd_divmod(r, d_h, yy);
-    const float* base = dy + (int64_t)b * OH * OW * C + c;
-    float acc = 0.f;
-    const int ny = 1 + (py0 > 0 ? py0 : 0) + (py1 > 0 ? py1 : 0), nx = 1 + (px0 > 0 ? px0 : 0) + (px1 > 0 ? px1 : 0);
+    const VT* base = dy + (int64_t)b * OH * OW * C + c;
+    VT acc = {};
     for (int iy = 0; iy < ny; ++iy) {
       // candidate padded row (coordinates relative to the unpadded origin): itself, the top border rows, the bottom ones
       int ty = iy == 0 ? (int)yy : (iy <= (py0 > 0 ? py0 : 0) ? -iy : H - 1 + (iy - (py0 > 0 ? py0 : 0)));
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(256) void pad2d_bwd_kernel(const float* __restrict_
         int tx = ix == 0 ? (int)xx : (ix <= (px0 > 0 ? px0 : 0) ? -ix : W - 1 + (ix - (px0 > 0 ? px0 : 0)));
         if (tx + px0 < 0 || tx + px0 >= OW) continue;
         if (pad_src(tx, W, mode) != (int)xx) continue;
-        acc += base[((int64_t)(ty + py0) * OW + (tx + px0)) * C];
+        pad_acc(acc, base[((int64_t)(ty + py0) * OW + (tx + px0)) * C]);
       }
     }
     dx[t64] = acc;
@@ -298,7 +309,13 @@ extern "C" int ppst_pad2d_bwd(const void* dy, void* dx, int B, int H, int W, int
   if (!dy || !dx) return PPST_ENULL;
   const int64_t total = (int64_t)B * H * W * C;
   if (total > PPST_IDX32_MAX || (int64_t)B * OH * OW * C > PPST_IDX32_MAX) return PPST_EINVAL;
-  PPST_LAUNCH(pad2d_bwd_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)dy, (float*)dx, H, W, C, OH, OW,
+  if (C % 4 == 0 && ((uintptr_t)dy | (uintptr_t)dx) % 16 == 0) {     // four channels per thread (same sums, same order)
+    PPST_LAUNCH(pad2d_bwd_kernel<float4>, dim3(tg_grid(total / 4)), dim3(256), 0, as_stream(stream), (const float4*)dy, (float4*)dx, H, W,
+                C / 4, OH, OW, py0, py1, px0, px1, mode, (unsigned)(total / 4), make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)W),
+                make_fastdiv((unsigned)H));
+    return PPST_LAUNCH_CHECK();
+  }
+  PPST_LAUNCH(pad2d_bwd_kernel<float>, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)dy, (float*)dx, H, W, C, OH, OW,
               py0, py1, px0, px1, mode, (unsigned)total, make_fastdiv((unsigned)C), make_fastdiv((unsigned)W),
               make_fastdiv((unsigned)H));
   return PPST_LAUNCH_CHECK();
