@@ -64,6 +64,50 @@ __global__ __launch_bounds__(256) void dual_stats_kernel(const float* __restrict
     __syncthreads();
   }
 }
+// four channels per thread (C and the pixel strides multiples of 4, 16-byte aligned tensors: every tensor of the train step)
+__global__ __launch_bounds__(256) void dual_stats4_kernel(const float4* __restrict__ g, const float4* __restrict__ y,
+                                                          const float4* __restrict__ gate, float* __restrict__ partial, int P, int C4,
+                                                          int g_ld4, int y_ld4, int gate_ld4, int nchunks, int PIX_CHUNK) {
+  __shared__ float4 s0[256], s1[256];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int pbeg = chunk * PIX_CHUNK;
+  const int pend = (pbeg + PIX_CHUNK < P) ? pbeg + PIX_CHUNK : P;
+  int lanesC = 1;
+  while (lanesC < C4 && lanesC < 256) lanesC <<= 1;
+  const int rows = 256 / lanesC;
+  const int cl = threadIdx.x % lanesC, pr = threadIdx.x / lanesC;
+  for (int cbase = 0; cbase < C4; cbase += lanesC) {
+    const int c = cbase + cl;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    if (c < C4) {
+      for (int p = pbeg + pr; p < pend; p += rows) {
+        const int64_t bp = (int64_t)b * P + p;
+        float4 gv = g[bp * g_ld4 + c];
+        const float4 yv = y[bp * y_ld4 + c];
+        if (gate) {
+          const float4 t = gate[bp * gate_ld4 + c];
+          gv.x *= lrelu_gate(t.x); gv.y *= lrelu_gate(t.y); gv.z *= lrelu_gate(t.z); gv.w *= lrelu_gate(t.w);
+        }
+        a0.x += gv.x; a0.y += gv.y; a0.z += gv.z; a0.w += gv.w;
+        a1.x += gv.x * yv.x; a1.y += gv.y * yv.y; a1.z += gv.z * yv.z; a1.w += gv.w * yv.w;
+      }
+    }
+    s0[threadIdx.x] = a0;
+    s1[threadIdx.x] = a1;
+    __syncthreads();
+    if (pr == 0 && c < C4) {
+      for (int r = 1; r < rows; ++r) {
+        const float4 u = s0[r * lanesC + cl], w = s1[r * lanesC + cl];
+        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+        a1.x += w.x; a1.y += w.y; a1.z += w.z; a1.w += w.w;
+      }
+      float4* o = (float4*)(partial + (((int64_t)b * nchunks + chunk) * C4 * 4 + c * 4) * 2);
+      o[0] = make_float4(a0.x, a1.x, a0.y, a1.y);
+      o[1] = make_float4(a0.z, a1.z, a0.w, a1.w);
+    }
+    __syncthreads();
+  }
+}
 extern "C" int ppst_dual_stats(const void* g, const void* y, const void* gate, void* partial, int B, int64_t hw, int C, int g_ld,
                                int y_ld, int gate_ld, int* n_partials, void* stream) {
   if (B < 0 || hw <= 0 || hw > 0x7fffffffll || C <= 0 || g_ld < C || y_ld < C || (gate && gate_ld < C)) return PPST_EINVAL;
@@ -73,6 +117,12 @@ extern "C" int ppst_dual_stats(const void* g, const void* y, const void* gate, v
   if (!g && !partial) return PPST_OK;  // size query
   if (B == 0) return PPST_OK;
   if (!g || !y || !partial) return PPST_ENULL;
+  if (C % 4 == 0 && g_ld % 4 == 0 && y_ld % 4 == 0 && (!gate || gate_ld % 4 == 0) &&
+      ((uintptr_t)g | (uintptr_t)y | (uintptr_t)gate | (uintptr_t)partial) % 16 == 0) {
+    PPST_LAUNCH(dual_stats4_kernel, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float4*)g, (const float4*)y,
+                (const float4*)gate, (float*)partial, (int)hw, C / 4, g_ld / 4, y_ld / 4, gate_ld / 4, nchunks, chunk);
+    return PPST_LAUNCH_CHECK();
+  }
   PPST_LAUNCH(dual_stats_kernel, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)g, (const float*)y,
               (const float*)gate, (float*)partial, (int)hw, C, g_ld, y_ld, gate_ld, nchunks, chunk);
   return PPST_LAUNCH_CHECK();
@@ -166,6 +216,31 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restri
     dx[bp * dx_ld + c] = o;
   }
 }
+__global__ __launch_bounds__(256) void in_bwd_apply4_kernel(const float4* __restrict__ g, const float4* __restrict__ y,
+                                                            const float4* __restrict__ gate, const float4* __restrict__ coef,
+                                                            float4* __restrict__ dx, unsigned hw, int C4, int g_ld4, int y_ld4,
+                                                            int gate_ld4, int dx_ld4, int post_gate, unsigned total, FastDiv d_c,
+                                                            FastDiv d_hw) {
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned cq;
+    const unsigned bpu = fd_divmod((unsigned)t64, d_c, cq);
+    const int c = (int)cq;
+    const int b = (int)fd_div(bpu, d_hw);
+    const int64_t bp = bpu;
+    const float4* k = coef + ((int64_t)b * C4 + c) * 4;      // (k0, k1, k2, -) of the thread's four channels
+    const float4 k0 = k[0], k1 = k[1], k2 = k[2], k3 = k[3];
+    float4 gv = g[bp * g_ld4 + c];
+    const float4 yv = y[bp * y_ld4 + c];
+    if (gate) {
+      const float4 t = gate[bp * gate_ld4 + c];
+      gv.x *= lrelu_gate(t.x); gv.y *= lrelu_gate(t.y); gv.z *= lrelu_gate(t.z); gv.w *= lrelu_gate(t.w);
+    }
+    float4 o = make_float4(k0.x * gv.x + k0.y * yv.x + k0.z, k1.x * gv.y + k1.y * yv.y + k1.z, k2.x * gv.z + k2.y * yv.z + k2.z,
+                           k3.x * gv.w + k3.y * yv.w + k3.z);
+    if (post_gate) { o.x *= lrelu_gate(yv.x); o.y *= lrelu_gate(yv.y); o.z *= lrelu_gate(yv.z); o.w *= lrelu_gate(yv.w); }
+    dx[bp * dx_ld4 + c] = o;
+  }
+}
 extern "C" int ppst_in_bwd_apply(const void* g, const void* y, const void* gate, const void* coef, void* dx, int B, int64_t hw, int C,
                                  int g_ld, int y_ld, int gate_ld, int dx_ld, int post_gate, void* stream) {
   if (B < 0 || hw <= 0 || C <= 0 || g_ld < C || y_ld < C || dx_ld < C || (gate && gate_ld < C)) return PPST_EINVAL;
@@ -173,6 +248,13 @@ extern "C" int ppst_in_bwd_apply(const void* g, const void* y, const void* gate,
   if (!g || !y || !coef || !dx) return PPST_ENULL;
   const int64_t total = (int64_t)B * hw * C;
   if (total > PPST_IDX32_MAX) return PPST_EINVAL;
+  if (C % 4 == 0 && g_ld % 4 == 0 && y_ld % 4 == 0 && dx_ld % 4 == 0 && (!gate || gate_ld % 4 == 0) &&
+      ((uintptr_t)g | (uintptr_t)y | (uintptr_t)gate | (uintptr_t)coef | (uintptr_t)dx) % 16 == 0) {
+    PPST_LAUNCH(in_bwd_apply4_kernel, dim3(tg_grid(total / 4)), dim3(256), 0, as_stream(stream), (const float4*)g, (const float4*)y,
+                (const float4*)gate, (const float4*)coef, (float4*)dx, (unsigned)hw, C / 4, g_ld / 4, y_ld / 4, gate_ld / 4, dx_ld / 4,
+                post_gate, (unsigned)(total / 4), make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)hw));
+    return PPST_LAUNCH_CHECK();
+  }
   PPST_LAUNCH(in_bwd_apply_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)g, (const float*)y,
               (const float*)gate, (const float*)coef, (float*)dx, (unsigned)hw, C, g_ld, y_ld, gate_ld, dx_ld, post_gate,
               (unsigned)total, make_fastdiv((unsigned)C), make_fastdiv((unsigned)hw));
