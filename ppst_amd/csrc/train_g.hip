@@ -786,6 +786,25 @@ __global__ __launch_bounds__(256) void noise_wgrad_kernel(const float* __restric
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
+// float4 form (C, ld multiples of 4, aligned): a wave covers 256 / C4 ... whole pixels per pass -- lane -> (pixel, channel quad)
+__global__ __launch_bounds__(256) void noise_wgrad4_kernel(const float4* __restrict__ dpre, const float* __restrict__ noise,
+                                                           float* __restrict__ partial, int64_t npix, int C4, int ld4) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const int lanes = C4 < 256 ? C4 : 256;                     // threads per pixel
+  const int ppb = 256 / lanes;                                // pixels per block pass
+  const int cl = threadIdx.x % lanes, pr = threadIdx.x / lanes;
+  if (pr < ppb)
+    for (int64_t p = (int64_t)blockIdx.x * ppb + pr; p < npix; p += (int64_t)gridDim.x * ppb) {
+      float s = 0.f;
+      for (int c = cl; c < C4; c += lanes) { const float4 v = dpre[p * ld4 + c]; s += (v.x + v.y) + (v.z + v.w); }
+      acc += s * noise[p];
+    }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int n, float scale,
                                                            int accumulate) {
   __shared__ float red[4];
@@ -811,8 +830,12 @@ extern "C" int ppst_noise_wgrad(const void* dpre, const void* noise, void* out, 
   if (npix == 0) return accumulate ? PPST_OK : (int)hipMemsetAsync(out, 0, sizeof(float), as_stream(stream));
   if (!dpre || !noise || !ws) return PPST_ENULL;
   const int blocks = (int)(ppst_noise_wgrad_ws(npix) / (int64_t)sizeof(float));
-  PPST_LAUNCH(noise_wgrad_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)dpre, (const float*)noise, (float*)ws,
-              npix, C, ld);
+  if (C % 4 == 0 && ld % 4 == 0 && (uintptr_t)dpre % 16 == 0 && (C / 4 >= 256 || 256 % (C / 4) == 0))
+    PPST_LAUNCH(noise_wgrad4_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float4*)dpre, (const float*)noise, (float*)ws,
+                npix, C / 4, ld / 4);
+  else
+    PPST_LAUNCH(noise_wgrad_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)dpre, (const float*)noise, (float*)ws,
+                npix, C, ld);
   PPST_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const float*)ws, (float*)out, blocks, 1.f, accumulate);
   return PPST_LAUNCH_CHECK();
 }
@@ -849,7 +872,8 @@ extern "C" int ppst_upscale_weight_bwd(const void* dw4, void* dw, int cout, int 
 
 // space-to-depth copy: x [B][H][W][C] -> y [B][ceil(H/2)][ceil(W/2)][4C], channel block (py*2+px)*C (zeros beyond the edge):
 // the layout the stride-2 step tables read (input gradient of the fused transposed conv = a stride-2 4x4 conv of dY)
-__global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int x_ld,
+template <typename VT>
+__global__ __launch_bounds__(256) void s2d_kernel(const VT* __restrict__ x, VT* __restrict__ y, int H, int W, int C, int x_ld,
                                                   int H2, int W2, unsigned total, FastDiv d_c, FastDiv d_4, FastDiv d_w2, FastDiv d_h2) {
   for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
     unsigned c, ph, qx, qy;
@@ -858,7 +882,9 @@ __global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ x, f
     r = fd_divmod(r, d_w2, qx);
     const unsigned b = fd_divmod(r, d_h2, qy);
     const int iy = (int)qy * 2 + (int)(ph >> 1), ix = (int)qx * 2 + (int)(ph & 1);
-    y[t64] = (iy < H && ix < W) ? x[(((int64_t)b * H + iy) * W + ix) * x_ld + c] : 0.f;
+    VT v = {};
+    if (iy < H && ix < W) v = x[(((int64_t)b * H + iy) * W + ix) * x_ld + c];
+    y[t64] = v;
   }
 }
 extern "C" int ppst_space_to_depth(const void* x, void* y, int B, int H, int W, int C, int x_ld, void* stream) {
@@ -868,8 +894,13 @@ extern "C" int ppst_space_to_depth(const void* x, void* y, int B, int H, int W, 
   const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
   const int64_t total = (int64_t)B * H2 * W2 * 4 * C;
   if (total > PPST_IDX32_MAX) return PPST_EINVAL;
-  PPST_LAUNCH(s2d_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, H, W, C, x_ld, H2, W2,
-              (unsigned)total, make_fastdiv((unsigned)C), make_fastdiv(4u), make_fastdiv((unsigned)W2), make_fastdiv((unsigned)H2));
+  if (C % 4 == 0 && x_ld % 4 == 0 && ((uintptr_t)x | (uintptr_t)y) % 16 == 0)
+    PPST_LAUNCH(s2d_kernel<float4>, dim3(tg_grid(total / 4)), dim3(256), 0, as_stream(stream), (const float4*)x, (float4*)y, H, W, C / 4,
+                x_ld / 4, H2, W2, (unsigned)(total / 4), make_fastdiv((unsigned)(C / 4)), make_fastdiv(4u), make_fastdiv((unsigned)W2),
+                make_fastdiv((unsigned)H2));
+  else
+    PPST_LAUNCH(s2d_kernel<float>, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, H, W, C, x_ld, H2, W2,
+                (unsigned)total, make_fastdiv((unsigned)C), make_fastdiv(4u), make_fastdiv((unsigned)W2), make_fastdiv((unsigned)H2));
   return PPST_LAUNCH_CHECK();
 }
 
