@@ -1120,7 +1120,7 @@ __global__ __launch_bounds__(256) void linear_wgrad4_kernel(const float* __restr
 // n of its slice, accumulates every batch row in registers (dY[b][n] is a wave-uniform broadcast) and writes a partial;
 // a second launch sums the slices in a fixed order (deterministic).  (Round 1's version ran one thread per output with a
 // sequential loop over n: 16 blocks, latency bound -- 17 % of the train step.)
-#define LDG_ROWS 32
+#define LDG_ROWS 16                 // (32: 19 us per launch at N = 1024, 16: 12, 8: 11 with twice the partial traffic)
 #define LDG_BMAX 16
 __global__ __launch_bounds__(256) void linear_dgrad_partial_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                                    float* __restrict__ partial, int B, int N, int K, int b0) {
