@@ -970,6 +970,53 @@ __global__ __launch_bounds__(256) void wgrad_small_cin_kernel(const float* __res
     __syncthreads();
   }
 }
+// float4 form for cout = 4 Q with Q a divisor of 256 (FromRGB: cout = 32 -> the scalar form above ran half its lanes, 128 B per
+// wave load): thread = (pixel slot tid / Q, channel quad tid % Q); 256 / Q pixels per block pass, four passes in flight.
+__global__ __launch_bounds__(256) void wgrad_small_cin4_kernel(const float* __restrict__ x, const float4* __restrict__ dy,
+                                                               float* __restrict__ partial, int64_t npix, int cin, int in_ld, int Q,
+                                                               int64_t pix_per_block) {
+  __shared__ float4 sm[4][256];                              // [input channel][thread]
+  const int q = threadIdx.x % Q, slot = threadIdx.x / Q, P = 256 / Q;
+  const int64_t p0 = (int64_t)blockIdx.x * pix_per_block, p1 = min(p0 + pix_per_block, npix);
+  float4 a[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int64_t p = p0 + slot;
+  for (; p + 3 * P < p1; p += 4 * P) {
+    const float4 g0 = dy[p * Q + q], g1 = dy[(p + P) * Q + q], g2 = dy[(p + 2 * P) * Q + q], g3 = dy[(p + 3 * P) * Q + q];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < cin) {
+        const float x0 = x[p * in_ld + c], x1 = x[(p + P) * in_ld + c], x2 = x[(p + 2 * P) * in_ld + c], x3 = x[(p + 3 * P) * in_ld + c];
+        a[c].x += (g0.x * x0 + g1.x * x1) + (g2.x * x2 + g3.x * x3);
+        a[c].y += (g0.y * x0 + g1.y * x1) + (g2.y * x2 + g3.y * x3);
+        a[c].z += (g0.z * x0 + g1.z * x1) + (g2.z * x2 + g3.z * x3);
+        a[c].w += (g0.w * x0 + g1.w * x1) + (g2.w * x2 + g3.w * x3);
+      }
+  }
+  for (; p < p1; p += P) {
+    const float4 g = dy[p * Q + q];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < cin) {
+        const float xv = x[p * in_ld + c];
+        a[c].x += g.x * xv; a[c].y += g.y * xv; a[c].z += g.z * xv; a[c].w += g.w * xv;
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) sm[c][threadIdx.x] = a[c];
+  __syncthreads();
+  if (threadIdx.x < Q) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < cin) {
+        float4 t = sm[c][q];
+        for (int r = 1; r < P; ++r) { const float4 v = sm[c][r * Q + q]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        float* o = partial + ((int64_t)blockIdx.x * 4 * Q + 4 * q) * cin + c;      // partial[block][n][cin]
+        o[0] = t.x; o[cin] = t.y; o[2 * cin] = t.z; o[3 * cin] = t.w;
+      }
+  }
+}
 // out[i] (+)= scale * sum_b partial[b][i]: a block owns 32 consecutive outputs, its 8 thread groups walk the partial rows
 // 8 apart with 4 loads in flight each (double accumulation, fixed order).  (The one-thread-per-output form walked
 // `nblocks` dependent loads per thread: 0.1-0.3 ms for the 128-1280 partial rows of the FromRGB / bias gradients.)
@@ -1004,8 +1051,12 @@ extern "C" int ppst_wgrad_small_cin(const void* x, const void* dy, void* dw, voi
   if (npix <= 0 || cin <= 0 || cin > 4 || in_ld < cin || cout <= 0) return PPST_EINVAL;
   if (!x || !dy || !dw || !ws) return PPST_ENULL;
   int nblocks = (int)cdiv64(npix, WSC_PIX);
-  PPST_LAUNCH(wgrad_small_cin_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (float*)ws,
-              npix, cin, in_ld, cout, (int64_t)WSC_PIX);
+  if (cout % 4 == 0 && cout / 4 <= 256 && 256 % (cout / 4) == 0 && (uintptr_t)dy % 16 == 0)
+    PPST_LAUNCH(wgrad_small_cin4_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), (const float*)x, (const float4*)dy, (float*)ws,
+                npix, cin, in_ld, cout / 4, (int64_t)WSC_PIX);
+  else
+    PPST_LAUNCH(wgrad_small_cin_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (float*)ws,
+                npix, cin, in_ld, cout, (int64_t)WSC_PIX);
   int e = PPST_LAUNCH_CHECK();
   if (e) return e;
   int64_t n = (int64_t)cout * cin;
