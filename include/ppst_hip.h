@@ -425,11 +425,13 @@ int ppst_conv_wgrad_tr(const void* x, const void* dy, const void* steps, const v
  * phases of one block (request, wait, convert, MFMA) overlap the other block's.  ``splits`` = partial slots = pixel ranges (any
  * positive count); csum NULL or [splits][cout].  max_taps / min_taps: longest / shortest chunk of the step table (0 = unknown):
  * <= 4 and an even chunk count select the two-chunks-per-block form, min == max == 9 (or 4) the form without per-tap tests.
+ * halo: 1 in general; 0 = every step has offset (0, 0) and the input has the output's extent (1x1 convs): with one step per
+ * chunk the block then stages no halo and takes four (two) chunks per dY image.
  * passes: 3 = bf16x3 (fp32-class), 1 = single-pass bf16 (precision mode 1: the
  * "bf16 compute, fp32 master weights" of BASELINE configs[3]); anything else PPST_EINVAL. */
 int ppst_conv_wgrad_tr2(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial, void* csum,
                         int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps, int nchunks,
-                        int splits, int max_taps, int min_taps, int passes, void* stream);   /* max_taps: 0 = unknown (<= 9); 1..4 = the caller's promise that
+                        int splits, int max_taps, int min_taps, int halo, int passes, void* stream);   /* max_taps: 0 = unknown (<= 9); 1..4 = the caller's promise that
                         no chunk of the table has more steps: with an even chunk count two chunks then share one block / dY image */
 /* dw[n*sn + (src_c+k)*sc + ky*sy + kx*sx] (+)= scale * sum_splits partial[.][step][n][k] */
 int ppst_wgrad_scatter(const void* partial, const void* src_c, const void* src_ky, const void* src_kx,

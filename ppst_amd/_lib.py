@@ -111,7 +111,7 @@ _SIGS = {
     "ppst_conv_wgrad_f32": (i32, [vp, vp, vp, vp, vp] + [i32] * 11 + [vp]),
     "ppst_conv_wgrad_bf16x3": (i32, [vp, vp, vp, vp, vp] + [i32] * 11 + [vp]),
     "ppst_conv_wgrad_tr": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "ppst_conv_wgrad_tr2": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ppst_conv_wgrad_tr2": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ppst_wgrad_scatter": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, f32, i32, vp, vp, i32, i32, vp]),
     "ppst_wgrad_small_cin_ws": (i64, [i64, i32, i32]),
     "ppst_wgrad_small_cin": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp]),

@@ -546,13 +546,18 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_tr_kernel(const float* __re
 // EXACT: every chunk of the table has exactly TM steps (3x3 convs: 9; the transposed conv's phases: 4) -- the tap loop then has
 // no `t < T` tests.  With the runtime count each tap was its own basic block behind a branch (hipcc's wait-count pass drains the
 // LDS queue at every block entry, and the next tap's fragments could not be requested across it).
-template <int NCH, int TM, bool X1, bool EXACT>
+// HALO = false (1x1 tables: one step per chunk, no offsets): the input image is the tile's own 2 x 32 pixels (8 KB per chunk
+// instead of the 17-KB halo image), so FOUR chunks share a block and one dY image at 64 KB of LDS.
+template <int NCH, int TM, bool X1, bool EXACT, bool HALO = true>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               const int4* __restrict__ steps, const int* __restrict__ chunk_start,
                                                               float* __restrict__ partial, float* __restrict__ csum, int B, int in_h,
                                                               int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
                                                               int tiles_x, int tiles_per_image, int tiles_total, int tiles_per_split) {
-  constexpr int IMG_DY = WT_PX * 128 * 4, IMG_X = WT_XPX * 32 * 4;           // 32768 + 17408 bytes
+  constexpr int XW = HALO ? WT_XW : WG_TC, XPX = HALO ? WT_XPX : WT_PX, XO = HALO ? 1 : 0;      // input image: width, pixels, origin offset
+  constexpr int XPC = XPX / 8;                                // DMA pieces (8 pixels x 128 B) per chunk: 17 / 8
+  constexpr int IMG_DY = WT_PX * 128 * 4, IMG_X = XPX * 32 * 4;              // 32768 + 17408 (8192) bytes
+  static_assert(!HALO ? TM == 1 : true, "the no-halo image serves 1x1 tables");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[IMG_DY + NCH * IMG_X];
   unsigned char* const imdy = smem;                           // [slab 0..3][64 px][8 quads][16 B]
   unsigned char* const imx = smem + IMG_DY;                   // NCH x [136 px][8 quads][16 B]
@@ -581,6 +586,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
       tdy[ci][t] = d.y; tdx[ci][t] = d.z;
     }
   }
+  auto chan_of = [&](int ci) {                               // (wave-uniform runtime index: no dynamically indexed register array)
+    int c = chan[0];
+#pragma unroll
+    for (int j = 1; j < NCH; ++j) c = ci == j ? chan[j] : c;
+    return c;
+  };
   f32x16 acc[NCH][TM];
 #pragma unroll
   for (int ci = 0; ci < NCH; ++ci)
@@ -620,7 +631,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
     const int ty0 = (r / tiles_x) * WG_TR, tx0 = (r - (r / tiles_x) * tiles_x) * WG_TC;
     __syncthreads();                                        // the previous tile's MFMA reads are done
     // ---- LDS-DMA: 32 pieces of dY (slab s, pixels 8 j .. 8 j + 7: 8 x 128 B) + 17 per chunk of the input halo (8 pixels x 128 B)
-    for (int wi = nw; wi < 32 + NCH * 17; wi += 4) {
+    for (int wi = nw; wi < 32 + NCH * XPC; wi += 4) {
       const float* src = g_wg_zero;
       unsigned char* dst;
       const int q = lane & 7;
@@ -631,12 +642,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
         if (y < oh && xx < ow && n < cout) src = dy + (((int64_t)b * oh + y) * ow + xx) * dy_ld + n;
         dst = imdy + wi * 1024;
       } else {
-        const int ci = (wi - 32) / 17, pj = (wi - 32) - ci * 17;          // wave-uniform
+        const int ci = (wi - 32) / XPC, pj = (wi - 32) - ci * XPC;        // wave-uniform
         const int P = 8 * pj + (lane >> 3);
-        const int row = P / WT_XW, col = P - row * WT_XW;
-        const int iy = ty0 - 1 + row, ix = tx0 - 1 + col;
+        const int row = P / XW, col = P - row * XW;
+        const int iy = ty0 - XO + row, ix = tx0 - XO + col;
         if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w)
-          src = x + (((int64_t)b * in_h + iy) * in_w + ix) * in_ld + (NCH == 1 ? chan[0] : (ci == 0 ? chan[0] : chan[NCH - 1])) + q * 4;
+          src = x + (((int64_t)b * in_h + iy) * in_w + ix) * in_ld + chan_of(ci) + q * 4;
         dst = imx + (wi - 32) * 1024;
       }
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
@@ -678,9 +689,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
 #pragma unroll
     for (int ci = 0; ci < NCH; ++ci)
 #pragma unroll
-      for (int it = 0; it < 5; ++it) {
+      for (int it = 0; it < (XPX * 8 + 255) / 256; ++it) {
         const int i = tid + it * 256;
-        if (i < WT_XPX * 8) {
+        if (i < XPX * 8) {
           unsigned char* u = imx + ci * IMG_X + i * 16;
           const float4 v = *(const float4*)u;
           uint2 hi, lo;
@@ -700,7 +711,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
 #pragma unroll
         for (int ci = 0; ci < NCH; ++ci) {
           const unsigned char* const im = imx + ci * IMG_X;
-          const int pb0 = (row + 1 + tdy[ci][0]) * WT_XW + xh + 1 + tdx[ci][0];
+          const int pb0 = (row + XO + tdy[ci][0]) * XW + xh + XO + tdx[ci][0];
           bf16x8 b_h, b_l;
           frag(im + pb0 * 128 + tr_unit, (((pb0 & 3) + qd) >> 1) & 1, b_h, b_l);
 #pragma unroll
@@ -708,7 +719,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
             if (EXACT || t < T[ci]) {
               bf16x8 n_h = b_h, n_l = b_l;
               if (t + 1 < TM && (EXACT || t + 1 < T[ci])) {   // the next tap's fragments are requested before this tap's MFMAs
-                const int pb = (row + 1 + tdy[ci][t + 1]) * WT_XW + xh + 1 + tdx[ci][t + 1];
+                const int pb = (row + XO + tdy[ci][t + 1]) * XW + xh + XO + tdx[ci][t + 1];
                 frag(im + pb * 128 + tr_unit, (((pb & 3) + qd) >> 1) & 1, n_h, n_l);
               }
               if (!X1) {
@@ -820,7 +831,7 @@ extern "C" int ppst_conv_wgrad_tr(const void* x, const void* dy, const void* ste
 // [splits][cout] partial column sums of dy
 extern "C" int ppst_conv_wgrad_tr2(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial, void* csum,
                                    int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
-                                   int nchunks, int splits, int max_taps, int min_taps, int passes, void* stream) {
+                                   int nchunks, int splits, int max_taps, int min_taps, int halo, int passes, void* stream) {
   if (B < 0 || in_h <= 0 || in_w <= 0 || in_ld <= 0 || oh <= 0 || ow <= 0 || dy_ld < cout || cout <= 0 || nsteps <= 0 ||
       nchunks <= 0 || splits <= 0 || (passes != 1 && passes != 3))
     return PPST_EINVAL;
@@ -833,7 +844,9 @@ extern "C" int ppst_conv_wgrad_tr2(const void* x, const void* dy, const void* st
   // max_taps: the caller's promise about the table (it lives on the device): <= 4 steps in every chunk and an even chunk count
   // select the two-chunks-per-block form
   const bool pair = max_taps > 0 && max_taps <= 4 && (nchunks & 1) == 0;
-  dim3 grid(cdiv(cout, 128), pair ? nchunks / 2 : nchunks, splits);
+  // halo == 0: the caller's promise that every step has offset (0, 0) on an input of the output's extent (1x1 conv tables)
+  const int one = (halo == 0 && max_taps == 1 && min_taps == 1 && in_h == oh && in_w == ow) ? ((nchunks & 3) == 0 ? 4 : ((nchunks & 1) == 0 ? 2 : 0)) : 0;
+  dim3 grid(cdiv(cout, 128), one ? nchunks / one : (pair ? nchunks / 2 : nchunks), splits);
   const int slot = wgrad_prof_begin(B, oh, ow, cout, nsteps, g_wgrad_flop_steps, nchunks, splits, as_stream(stream));
   g_wgrad_flop_steps = 0;
 #define WG2(NCH, TM, X1, EX)                                                                                                          \
@@ -841,9 +854,23 @@ extern "C" int ppst_conv_wgrad_tr2(const void* x, const void* dy, const void* st
               (const int4*)steps, (const int*)chunk_start, (float*)partial, (float*)csum, B, in_h, in_w, in_ld, oh, ow, dy_ld, cout,     \
               nsteps, tiles_x, tiles_per_image, tiles_total, tps)
 #define WG2X(NCH, TM, EX) do { if (passes == 1) WG2(NCH, TM, true, EX); else WG2(NCH, TM, false, EX); } while (0)
+#define WG2N(NCH)                                                                                                                     \
+  do {                                                                                                                                \
+    if (passes == 1)                                                                                                                  \
+      PPST_LAUNCH((conv_wgrad_tr2_kernel<NCH, 1, true, true, false>), grid, dim3(256), 0, as_stream(stream), (const float*)x,           \
+                  (const float*)dy, (const int4*)steps, (const int*)chunk_start, (float*)partial, (float*)csum, B, in_h, in_w, in_ld,  \
+                  oh, ow, dy_ld, cout, nsteps, tiles_x, tiles_per_image, tiles_total, tps);                                            \
+    else                                                                                                                              \
+      PPST_LAUNCH((conv_wgrad_tr2_kernel<NCH, 1, false, true, false>), grid, dim3(256), 0, as_stream(stream), (const float*)x,          \
+                  (const float*)dy, (const int4*)steps, (const int*)chunk_start, (float*)partial, (float*)csum, B, in_h, in_w, in_ld,  \
+                  oh, ow, dy_ld, cout, nsteps, tiles_x, tiles_per_image, tiles_total, tps);                                            \
+  } while (0)
   // max_taps / min_taps: the caller's promise about the table's chunk lengths (the table lives on the device)
-  if (pair) { if (min_taps == 4 && max_taps == 4) WG2X(2, 4, true); else WG2X(2, 4, false); }
+  if (one == 4) WG2N(4);
+  else if (one == 2) WG2N(2);
+  else if (pair) { if (min_taps == 4 && max_taps == 4) WG2X(2, 4, true); else WG2X(2, 4, false); }
   else { if (min_taps == WG_MAXT && max_taps == WG_MAXT) WG2X(1, WG_MAXT, true); else WG2X(1, WG_MAXT, false); }
+#undef WG2N
 #undef WG2X
 #undef WG2
   ppst_prof_end_(slot, as_stream(stream));

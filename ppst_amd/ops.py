@@ -656,7 +656,7 @@ def _grad_out(out, shape, like):
 # further split is 2 x 147 KB of partial sums written and re-read by the scatter), >= min_tiles pixel tiles per block
 # form 2: two 256-thread blocks per CU; bf16_single_pass: in precision mode 1 (bf16 compute, fp32 master weights -- BASELINE
 # configs[3]) the weight gradient multiplies the hi halves only (one MFMA pass instead of three)
-WGRAD_TR = {"value": True, "blocks": 256, "min_tiles": 8, "form": 2, "blocks2": 512, "pair": True, "bf16_single_pass": True, "exact": True}
+WGRAD_TR = {"value": True, "blocks": 256, "min_tiles": 8, "form": 2, "blocks2": 512, "pair": True, "bf16_single_pass": True, "exact": True, "nohalo": True}
 
 
 def presplit(x):
@@ -698,6 +698,9 @@ def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=No
         form2 = WGRAD_TR["form"] == 2
         if form2 and WGRAD_TR["pair"] and plan.max_chunk_steps <= 4 and nchunks % 2 == 0:
             per = (nchunks // 2) * ((cout + 127) // 128)       # two chunks per block
+            if (WGRAD_TR["nohalo"] and WGRAD_TR["exact"] and plan.kind == "conv" and plan.k == 1 and plan.halo == 0 and nchunks % 4 == 0
+                    and (H, W) == (oh, ow)):
+                per = (nchunks // 4) * ((cout + 127) // 128)   # 1x1 tables: four chunks per block (no halo image)
         if form2:       # one partial slot per block, two blocks per CU: one round of <= 512 blocks
             gz = splits if splits is not None else max(1, min(max(1, WGRAD_TR["blocks2"] // per), max(1, tiles_total // WGRAD_TR["min_tiles"]), 2048))
             splits = gz
@@ -719,6 +722,7 @@ def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=No
             check(lib.ppst_conv_wgrad_tr2(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), _p(csum), B, H, W, in_ld, oh, ow,
                                           dy_ld, cout, plan.nsteps, nchunks, splits, plan.max_chunk_steps if WGRAD_TR["pair"] else 0,
                                           plan.min_chunk_steps if WGRAD_TR["exact"] else 0,
+                                          0 if (WGRAD_TR["nohalo"] and plan.kind == "conv" and plan.k == 1 and plan.halo == 0) else 1,
                                           1 if (PRECISION["value"] == 1 and WGRAD_TR["bf16_single_pass"]) else 3,
                                           _stream()), "ppst_conv_wgrad_tr2")
         else:
