@@ -13,6 +13,9 @@ exercised; data is synthetic.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 8] [--precision bf16x3|bf16]
     N>1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+          (or just `python bench.py --gpus N`: with WORLD_SIZE unset the program starts its N ranks itself -- child processes
+          through torch.distributed.run, like the reference's launcher, experiments/tmux_launcher.py:84-90 -- before it touches
+          a GPU, relays rank 0's line and exits with the children's code)
 
 Multi-GPU: pairs are independent -> each rank swaps its own batch (weak scaling),
 no data-path collective; only the timing barrier / max-reduction use RCCL.
@@ -150,22 +153,26 @@ def cpu_baseline(seed):
     orc = O.PPSTOracle(sd, noise=noise)
     times = []
     with torch.no_grad():
-        small = W.synthetic_images(seed, 2, size=256)
-        O.generator(sd, O.encoder_con(sd, small[0:1]), O.encoder_col(sd, small[1:2])[0], noise=W.make_noise(seed, 1, S=32))
-        for _ in range(3):
+        # warm-up = the SAME 512x512 recipe once, untimed (round 3 warmed up at 256^2 and the first timed 512^2 run still took
+        # 1.4x the others: thread pool, allocator arenas and oneDNN primitive caches are per shape)
+        t0 = time.time()
+        orc.simple_swap(imgs[0:1], imgs[1:2], alpha=1.0)
+        warm = time.time() - t0
+        print("[bench] cpu_baseline warm-up: %.1f s on %d threads" % (warm, torch.get_num_threads()), file=sys.stderr, flush=True)
+        for _ in range(2):
             t0 = time.time()
             orc.simple_swap(imgs[0:1], imgs[1:2], alpha=1.0)
             times.append(time.time() - t0)
             print("[bench] cpu_baseline run %d: %.1f s on %d threads" % (len(times), times[-1], torch.get_num_threads()), file=sys.stderr, flush=True)
-    dt = sorted(times)[1]
+    dt = sum(times) / len(times)
     model, phys = host_cpu()
     return {"value": 1.0 / dt, "unit": "swaps/s", "cores": torch.get_num_threads(), "kind": "port",
             "cpu_model": model, "physical_cores_host": phys, "cores_available_to_process": nproc, "torch_threads": torch.get_num_threads(),
             "gflops": FLOP_PER_SWAP / dt / 1e9,
-            "sample": "1 warm-up (256x256 encode/decode) + 3 timed runs of 1 pair (batch 1) of the same 512x512 recipe, fp32, "
-                      "median %.1f s (runs: %s); a batch-8 run costs the same per pair on the host (the oracle's convs are already "
-                      "threaded over pixels), so the batch-1 rate is the bounded sample of BASELINE.md section 4's B = 8 leg"
-                      % (dt, ", ".join("%.1f" % t for t in times))}
+            "sample": "1 untimed warm-up run (%.1f s) + 2 timed runs of 1 pair (batch 1) of the same 512x512 recipe, fp32, mean %.1f s "
+                      "(runs: %s); a batch-8 run costs the same per pair on the host (the oracle's convs are already threaded over "
+                      "pixels), so the batch-1 rate is the bounded sample of BASELINE.md section 4's B = 8 leg"
+                      % (warm, dt, ", ".join("%.1f" % t for t in times))}
 
 
 def host_cpu():
@@ -237,7 +244,7 @@ def bench_train(args, rank, world, dev, barrier, max_over_ranks):
     from ppst_amd import weights as W
     from ppst_amd.ppst_model import Options, create_model
     from ppst_amd.train_g import PPSTOptimizer
-    B = 2
+    B = args.train_batch
     sd = W.make_state_dict(0, bias_std=0.1, noise_weight=0.1)
     model = create_model(Options(training_stage=2, lambda_Cycwarp=0.0), state_dict=sd, with_D=True, with_nce=True, device=dev)
     model.noise = "random"
@@ -280,16 +287,21 @@ def bench_train(args, rank, world, dev, barrier, max_over_ranks):
                 "share_of_step_time": ms * 1e-3 / dt, "traffic": None}
     wg = [r for r in detail if r[2][7] == 0]
     cv = [r for r in detail if r[2][7] != 0]
+    # MFMA passes per algorithmic MAC of the weight gradient AS IT RAN: three (bf16 hi / lo split) -- or one in precision mode 1,
+    # where ops.conv_wgrad multiplies the hi halves only (ops.WGRAD_TR["bf16_single_pass"], the transposed-read kernel, form 2)
+    wtr = ops.WGRAD_TR
+    npass_wg = 1 if (args.precision == "bf16" and wtr["bf16_single_pass"] and wtr["value"] and wtr["form"] == 2) else 3
     return {"metric": "512x512 train images/sec (one D + one G iteration per step)", "value": imgs / dt, "unit": "images/s (all GPUs)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NOTE[args.precision], "data": "synthetic",
-            "config": {"workload": "CelebAMaskHQ_default train step 512x512, batch 2 per GPU, training stage 2, lambda_Cycwarp 0 "
-                                   "(lpips unavailable), random init (BASELINE configs[3])",
+            "config": {"workload": "CelebAMaskHQ_default train step 512x512, batch %d per GPU, training stage 2, lambda_Cycwarp 0 "
+                                   "(lpips unavailable), random init (BASELINE configs[3])" % B,
                        "collectives": "flat gradient all-reduce per network (D 29.0 M, G 42.5 M, E2 27.0 M, E1 0.83 M fp32) + one "
                                       "[24, 2048] all_gather of the NCE keys",
                        **({"collectives_rehearsal": "1-rank RCCL group, optimizer told world = 2 (not a measurement)"} if rehearsal else {})},
-            # the dominant kernel of the step by time: the weight gradient (always bf16x3: three passes of the hi / lo split)
-            "roofline": roof(wg, "conv_wgrad_tr2_kernel / conv_wgrad_x3_kernel (conv weight gradients, bf16 hi+lo split on the matrix pipe; all launches of the step)", 3),
+            # the dominant kernel of the step by time: the weight gradient
+            "roofline": roof(wg, "conv_wgrad_tr2_kernel / conv_wgrad_x3_kernel (conv weight gradients on the bf16 matrix pipe, %s; all launches of the step)"
+                             % ("hi halves only: ONE MFMA pass" if npass_wg == 1 else "hi + lo split: three MFMA passes"), npass_wg),
             "roofline_conv": roof(cv, "ppst_conv2d_mfma launches of the step: forward and input-gradient convs (same kernels as the swap line)", passes),
             "algorithmic_tflops_conv_and_wgrad": (sum(r[1] for r in detail)) / dt / 1e12,
             "losses": {**dl, **gl}}
@@ -369,6 +381,106 @@ def bench_hires(args, rank, world, dev, barrier, max_over_ranks):
                                        "share_of_step_time": gf_ms * args.steps * 1e-3 / dt, "traffic": None}}
 
 
+def extras(args, dev):
+    """The other BASELINE configs, measured in this same process behind the headline line so that the driver's default run
+    carries them (round-3 verdict: only the swap line was driver-timed): configs[3] train step in the fp32-class mode and in
+    --precision bf16, configs[4] 1024^2 swap + guided filter in fp16.  Each is the same code path as `--workload train|hires`
+    with few steps; every sub-object carries its own roofline objects."""
+    import copy
+    from ppst_amd import ops
+    out = {}
+
+    def run(name, fn, precision, steps, warmup, **kw):
+        a = copy.copy(args)
+        a.precision, a.steps, a.warmup = precision, steps, warmup
+        for k, v in kw.items():
+            setattr(a, k, v)
+        ops.set_precision({"bf16x3": 0, "bf16": 1, "fp16": 3}[precision])
+        t0 = time.time()
+        try:
+            r = fn(a, 0, 1, dev, torch.cuda.synchronize, lambda dt: dt)
+            r["wall_s_incl_setup"] = time.time() - t0
+            out[name] = r
+        except Exception as e:      # an extra must not take the headline line down
+            out[name] = {"error": repr(e)}
+        finally:
+            ops.set_precision(0)
+            torch.cuda.empty_cache()
+    run("train_bf16x3", bench_train, "bf16x3", 3, 1)
+    run("train_bf16", bench_train, "bf16", 3, 1)
+    run("hires_fp16", bench_hires, "fp16", 3, 1, batch=4)
+    return out
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (python -m torch.distributed.run, one
+    rank per GPU, rendezvous on 127.0.0.1 at a free port) with this program's own arguments, let rank 0's single JSON line
+    through on the inherited stdout, and return the launcher's exit code (non-zero if any rank failed).  The reference starts
+    its ranks the same way (experiments/tmux_launcher.py:84-90: python -m torch.distributed.launch --nproc_per_node ...
+    train.py).  Never exec: the parent has not touched a GPU and only waits."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+class stdout_to_stderr:
+    """RCCL / gloo print connection banners on stdout when a communicator comes up; this program's stdout is ONE JSON line:
+    bring the communicator up with fd 1 pointed at stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def bench_stub(args, rank, world):
+    """--workload stub: the harness of the line without a GPU -- process group (gloo), barrier on both sides of the timed
+    region, max over ranks, ONE JSON line from rank 0.  For the launcher test (tests/test_bench_launcher_cpu.py)."""
+    import torch.distributed as dist
+    if world > 1:
+        with stdout_to_stderr():
+            dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
+            dist.barrier()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if os.environ.get("PPST_BENCH_STUB_FAIL_RANK") == str(rank):      # (launcher test: a rank that dies must fail the whole run)
+        raise SystemExit(3)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (rank + 1))                    # ranks differ: the line must carry the slowest
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "stub steps/sec", "value": world * args.steps / dt, "unit": "steps/s (all ranks)", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
+                          "config": {"workload": "launcher / barrier / max-reduce harness only (gloo, no GPU)"}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -377,7 +489,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp16", "fp16x2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="swap", choices=["swap", "grid", "train", "hires"],
+    ap.add_argument("--train-batch", type=int, default=2, help="--workload train: images per GPU (the reference's default is 2; SURVEY 8d also asks for 8)")
+    ap.add_argument("--no-extras", action="store_true", help="swap workload on one GPU: skip the train / hires sub-measurements of the default line")
+    ap.add_argument("--workload", default="swap", choices=["swap", "grid", "train", "hires", "stub"],
                     help="swap: BASELINE configs[1] (the headline line); grid: configs[2], 8x8 folder at 512 with the guided filter, "
                          "images and pairs sharded over the ranks; train: configs[3], one D (+ lazy R1) and one G iteration per step; "
                          "hires: configs[4], 1024x1024 encode / decode + guided filter (use --precision fp16)")
@@ -387,26 +501,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))          # (before anything touches a GPU; the parent only waits)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if args.workload == "stub":
+        return bench_stub(args, rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or os.environ.get("PPST_BENCH_FORCE_DIST"):   # the override exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
-        # RCCL prints a version banner on stdout when the first communicator comes up; this program's stdout is ONE JSON line.
-        # Create the communicator here (first barrier) with fd 1 pointed at stderr.
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with stdout_to_stderr():      # (the communicator comes up at the first barrier)
             dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world, device_id=dev)
             dist.barrier()
             torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
 
     from ppst_amd import glue, ops, weights as W
     from ppst_amd.ppst_model import create_model
@@ -517,6 +626,8 @@ def main():
             "frac_vs_dense_bf16": st_ach / PEAK_BF16_DENSE_TF, "launches": len(tag["styled"]), "kernel_ms_total": st_ms,
             "share_of_step_time": st_ms * 1e-3 / dt}
         res["roofline_upfirdn2d"] = upfirdn2d_rate(B, dev)
+        if world == 1 and not args.no_extras and args.precision == "bf16x3":
+            res["extra"] = extras(args, dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(0)
         print(json.dumps(res))

@@ -214,6 +214,10 @@ typedef struct ppst_conv_args {
                                        and steps[i].w bit 2 = parity of the chunk step i belongs to (the activation slot).
                                        NOT bit-identical to the others (the K sum is split in two: <= 1.1e-6 relative);
                                        experiment, measured 3-7 % slower than variant 0.
+                                    10: conv_wino.hip -- plain 3x3 stride-1 tables only (the variant-6 promise: nsteps = 9 * chunks,
+                                       steps[9c].x = first channel of chunk c), wpack from ppst_conv_pack_wino, bn = 128,
+                                       tile_rows = 16, one group, unit strides, precision 0.  Winograd F(2,3) along x: fp32-class
+                                       like the others (<= 3e-5 against float64) but NOT bit-identical to them.
                                     9: conv_mfma2.hip with 6 m-tiles per wave: block tile 24 x 16 px x 128 ch (wave tile 96 px x 64 ch),
                                        TWO activation slots; bn = 128, tile_rows = 24, the early_a promise, precision 0
                                        (experiment: bit-identical, +-1.5 % of variant 0 -- the 36-step tiles of the Cout = 128
@@ -228,6 +232,16 @@ typedef struct ppst_conv_args {
 } ppst_conv_args;
 
 int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream);
+/* Weights of a plain 3x3 stride-1 conv for ppst_conv_args.variant 10 (conv_wino.hip: Winograd F(2,3) along x, direct along y --
+ * 12 K-steps per 32-channel chunk and pixel PAIR instead of 9 per pixel, 1.5x fewer MFMAs; EqualConv2d / StyledConv conv,
+ * stylegan2_layers.py:184-193, 275-348, 439-475).  Element (n, c, ky, kx) of the kernel at w[n*sn + c*sc + ky*sy + kx*sx] (any
+ * strides: the input-gradient plan passes the transposed, flipped view of the same tensor), scaled by ``scale``; the row
+ * transform U = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) is formed in double and stored as bf16 hi + lo in the register-fragment
+ * order of the kernel's waves: [Cout/128][4 positions][2 channel halves][Cin/32][3 ky][4 n-tiles][hi|lo][64 lanes][8 k].
+ * cin % 32 == 0; ``out`` holds ppst_conv_pack_wino_bytes(cout, cin) bytes. */
+int64_t ppst_conv_pack_wino_bytes(int cout, int cin);
+int ppst_conv_pack_wino(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx, float scale, int cout, int cin,
+                        void* out, void* stream);
 /* fp32 NHWC [npix][x_ld] -> the pre-split layout of ppst_conv_args.in_presplit in y [npix][y_ld] (C % 8 == 0) */
 int ppst_presplit(const void* x, void* y, int64_t npix, int C, int x_ld, int y_ld, void* stream);
 /* 1 when the library was built with PPST_EXPERIMENTS=1: the measured-and-off forms (variants 1 / 3 / 7 / 8 / 9, precision 4,

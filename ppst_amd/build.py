@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libppst_hip.so")
 # PPST_EXPERIMENTS=1: also compile the measured-and-off conv forms (conv_ksplit.hip, conv_mfma2.hip variants 1 / 3 / 7 / 9, the
 # two-pass fp16 mode, the 8-row two-block tile): tuning builds only -- the production library carries what runs.
 EXPERIMENTS = os.environ.get("PPST_EXPERIMENTS") == "1"
-SOURCES = ["upfirdn2d.hip", "fused_bias_act.hip", "elementwise.hip", "linear.hip", "conv_mfma.hip", "conv_mfma2.hip", "conv1x1.hip", "conv_f32.hip",
+SOURCES = ["upfirdn2d.hip", "fused_bias_act.hip", "elementwise.hip", "linear.hip", "conv_mfma.hip", "conv_mfma2.hip", "conv1x1.hip", "conv_wino.hip", "conv_f32.hip",
            "corr.hip", "guided_filter.hip", "train.hip", "train_g.hip", "imageio.hip", "smooth_filter.hip"] + (["conv_ksplit.hip"] if EXPERIMENTS else [])
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"] + (["-DPPST_EXPERIMENTS"] if EXPERIMENTS else [])
 MODE_STAMP = os.path.join(HERE, ".libmode")       # flavour of the built library (git-ignored, travels with the .so)
@@ -40,11 +40,28 @@ def _mode():
     return "experiments" if EXPERIMENTS else "production"
 
 
-def _mode_changed():
+def _lib_flavour():
+    """'experiments' / 'production' of the built library: the stamp file, or -- a library without one (built before the stamp
+    existed, or copied alone) -- whether it carries the experiment kernels (conv_ksplit.hip is compiled only with PPST_EXPERIMENTS=1); None if unreadable."""
     try:
-        return open(MODE_STAMP).read().strip() != _mode()
+        return open(MODE_STAMP).read().strip()
     except OSError:
-        return os.path.exists(LIB)            # a library of unknown flavour
+        pass
+    if not os.path.exists(LIB):
+        return None
+    try:    # (no dlopen here: loading the library ahead of torch would bring the system's HIP runtime in first, ppst_amd/_lib.py)
+        return "experiments" if b"conv_ksplit_kernel" in open(LIB, "rb").read() else "production"
+    except OSError:
+        return None
+
+
+def _mode_changed():
+    """True only when the library exists in the OTHER flavour (an up-to-date production library without a stamp is not
+    rebuilt -- and is usable on a host without hipcc)."""
+    have = _lib_flavour()
+    if have is None:
+        return os.path.exists(LIB)            # a library that cannot say what it is
+    return have != _mode()
 
 
 def needs_build():

@@ -922,6 +922,7 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
 int ppst_conv1x1_stream_launch(const ppst_conv_args* a, int n_tiles, int tiles, hipStream_t st);                     // conv1x1.hip
 int ppst_conv_direct_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int tiles_x, hipStream_t st);         // conv1x1.hip
 int ppst_conv3x3_direct_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int tiles_x, hipStream_t st);      // conv1x1.hip
+int ppst_conv_wino_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int tiles_x, hipStream_t st);            // conv_wino.hip
 #ifdef PPST_EXPERIMENTS
 int ppst_conv_ksplit_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int tiles_x, hipStream_t st);         // conv_ksplit.hip
 #endif
@@ -949,7 +950,12 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       a->out_ld < a->cout || a->cout <= 0 || a->cout % 4 || a->out_ld % 4 || (a->residual && a->res_ld % 4) || a->nsteps <= 0 || (a->n_groups != 1 && a->n_groups != 4) || a->pad_mode < 0 ||
       a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 ||
       (a->precision != 0 && a->precision != 1 && a->precision != 3 && a->precision != 4) || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128 && a->bn != 256) || (a->residual && a->res_ld < a->cout) ||
-      a->variant < 0 || a->variant > 9 || (a->variant == 0 && a->bn == 256) ||
+      a->variant < 0 || a->variant > 10 || (a->variant == 0 && a->bn == 256) ||
+      // variant 10 = conv_wino.hip: Winograd F(2,3) along x for plain 3x3 stride-1 tables (the CALLER promises the (chunk, dy, dx)
+      // step order, as with variant 6, and a wpack from ppst_conv_pack_wino); bf16x3, bn 128, 16-row tiles, one group, unit strides
+      (a->variant == 10 && (a->precision != 0 || a->bn != 128 || a->halo != 1 || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
+                            a->in_off_y != 0 || a->in_off_x != 0 || a->tile_h != a->out_h || a->tile_w != a->out_w ||
+                            a->in_h != a->out_h || a->in_w != a->out_w || a->nsteps % 9 != 0 || a->tile_rows != 16)) ||
       ((a->variant >= 1 && a->variant <= 3 || a->variant == 7 || a->variant == 9) &&
        ((a->precision != 0 && !(a->variant == 2 && (a->precision == 1 || a->precision == 3))) || a->bn == 64 || !a->early_a)) ||
       (a->variant == 7 && (a->bn != 128 || a->tile_rows != 32)) ||
@@ -1026,6 +1032,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
     int e2 = a->variant == 4   ? ppst_conv1x1_stream_launch(a, k.n_tiles, k.tiles_y * k.tiles_x, st)
              : a->variant == 5 ? ppst_conv_direct_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st)
              : a->variant == 6 ? ppst_conv3x3_direct_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st)
+             : a->variant == 10 ? ppst_conv_wino_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st)
 #ifdef PPST_EXPERIMENTS
              : a->variant == 8 ? ppst_conv_ksplit_launch(a, k.n_tiles, k.tiles_y, k.tiles_x, st)
 #endif

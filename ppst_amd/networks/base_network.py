@@ -118,7 +118,7 @@ class BaseNetwork(nn.Module):
         self._cache.clear()
         if not plans:
             return
-        sig = tuple((id(pl), tuple(sorted(pl._packs))) for pl in plans)
+        sig = tuple((id(pl), tuple(sorted(map(str, pl._packs)))) for pl in plans)
         hit = self.__dict__.get("_repack")
         if hit is not None and hit[0] == sig:
             ops.run_repack(hit[1])

@@ -64,6 +64,10 @@ class batch_aware:
 
     def __exit__(self, *exc):
         BATCH_AWARE["value"] = self.prev
+# variant 10 (conv_wino.hip): Winograd F(2,3) along x for the plain 3x3 stride-1 layers with Cout >= 128 -- 1.5x fewer MFMAs per
+# output; fp32-class (<= 3e-5 against float64) but not bit-identical to the direct kernels.  ``min_blocks``: blocks ONE image gives
+# (the choice stays a function of the plan and one image's geometry).
+WINO = {"value": True, "min_blocks": 16}
 FAT_MIN_BLOCKS = 32         # take the 256-channel tile only when ONE image still gives >= this many blocks (B = 8: one per CU)
 
 
@@ -449,6 +453,24 @@ class ConvPlan:
         self._packs[bn] = wpack
         return wpack
 
+    def pack_wino(self):
+        """transformed weights for variant 10 (ppst_conv_pack_wino), built on first use."""
+        hit = self._packs.get("wino")
+        if hit is not None:
+            return hit
+        sn, sc, sy, sx = self.wstrides
+        nbytes = lib.ppst_conv_pack_wino_bytes(self.cout, self.cin)
+        wpack = torch.empty(nbytes // 2, dtype=torch.int16, device=self.steps.device)
+        check(lib.ppst_conv_pack_wino(_p(self.wsrc), sn, sc, sy, sx, float(self.scale), self.cout, self.cin, _p(wpack), _stream()),
+              "ppst_conv_pack_wino")
+        self._packs["wino"] = wpack
+        return wpack
+
+    def wino_ok(self, th, tw, oh, ow, H, W, osy):
+        return (self.precision == 0 and self.kind in ("conv", "dgrad") and self.k == 3 and self.cout >= 128 and osy == 1
+                and (th, tw) == (oh, ow) == (H, W)
+                and ((th + 15) // 16) * ((tw + 15) // 16) * ((self.cout + 127) // 128) >= WINO["min_blocks"])
+
     def choose_kernel(self, th, tw, oh, ow, H, W, osy, B=None):
         """(variant, N tile, tile rows) of ppst_conv_args for one launch of this plan -- a function of the plan and of ONE
         image's geometry only.  The batch size is deliberately not an argument: every variant gives bit-identical outputs,
@@ -462,6 +484,8 @@ class ConvPlan:
         single = self.precision in (1, 3)
         if self.precision not in (0, 1, 3):
             return variant, bn, rows                     # fp16x2 experiment / exact-fp32 verification: the tile kernel only
+        if WINO["value"] and self.wino_ok(th, tw, oh, ow, H, W, osy):
+            return 10, 128, 16
         tiles16 = ((th + 15) // 16) * ((tw + 15) // 16) * self.n_groups          # blocks PER IMAGE per N tile
         cv = CONV_VARIANT["value"]
         if cv in (1, 3) or TWO_BLOCK_128["value"] or KSPLIT_128["value"] or TILE24_128["value"] or TALL_TILE_128["value"]:
@@ -546,7 +570,8 @@ class ConvPlan:
             tiles = lib.ppst_conv_tiles(th, tw, rows)
             st = torch.empty((B, self.n_groups * tiles, self.cout, 2), device=x.device, dtype=torch.float32)
         a = _lib.ConvArgs()
-        a.x, a.wpack, a.steps, a.y = _p(x), _p(self.pack_for(bn) if self.precision != 2 else None), _p(self.steps), _p(out)
+        wp = None if self.precision == 2 else (self.pack_wino() if variant == 10 else self.pack_for(bn))
+        a.x, a.wpack, a.steps, a.y = _p(x), _p(wp), _p(self.steps), _p(out)
         a.variant = variant
         a.bias, a.noise, a.prelu, a.stats = _p(bias), _p(noise), _p(prelu), _p(st)
         a.residual = _p(residual)
@@ -588,7 +613,7 @@ def repack_plans(plans):
     plan (ppst_conv_pack_batch).  Returns the job tables; pass them back as ``tables`` while the set of plans / packs is unchanged
     (they hold device pointers only: nothing is rebuilt on the host)."""
     import numpy as np
-    up, pk = [], []
+    up, pk, wino = [], [], []
     for pl in plans:
         if pl.precision == 2:
             continue
@@ -598,6 +623,9 @@ def repack_plans(plans):
         sn, sc, sy, sx = pl.wstrides
         c_, ky_, kx_ = pl.src_dev
         for bn, wpack in pl._packs.items():
+            if bn == "wino":                     # variant-10 pack: its own transform kernel, one launch per plan
+                wino.append((pl.wsrc, pl.wstrides, float(pl.scale), pl.cout, pl.cin, wpack))
+                continue
             n_tiles = (pl.cout + bn - 1) // bn
             pk.append((pl.wsrc.data_ptr(), sn, sc, sy, sx, c_.data_ptr(), ky_.data_ptr(), kx_.data_ptr(), wpack.data_ptr(),
                        pl.n_groups * n_tiles * pl.nsteps * 4 * bn, float(pl.scale), pl.cout, bn, pl.nsteps, pl.n_groups,
@@ -626,17 +654,19 @@ def repack_plans(plans):
         return j.total
     tu, nbu = table(_lib.UpscaleJob, up, fill_up)
     tp, nbp = table(_lib.PackJob, pk, fill_pk)
-    tables = (tu, len(up), nbu, tp, len(pk), nbp)
+    tables = (tu, len(up), nbu, tp, len(pk), nbp, wino)
     run_repack(tables)
     return tables
 
 
 def run_repack(tables):
-    tu, nu, nbu, tp, npk, nbp = tables
+    tu, nu, nbu, tp, npk, nbp, wino = tables
     if nu:
         check(lib.ppst_upscale_weight_batch(_p(tu), nu, nbu, _stream()), "ppst_upscale_weight_batch")
     if npk:
         check(lib.ppst_conv_pack_batch(_p(tp), npk, nbp, _stream()), "ppst_conv_pack_batch")
+    for wsrc, (sn, sc, sy, sx), scale, cout, cin, wpack in wino:
+        check(lib.ppst_conv_pack_wino(_p(wsrc), sn, sc, sy, sx, scale, cout, cin, _p(wpack), _stream()), "ppst_conv_pack_wino")
 
 
 def _grad_out(out, shape, like):

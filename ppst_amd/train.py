@@ -290,7 +290,7 @@ class DiscriminatorTrainer:
     def r1_losses_and_grads(self, real, lambda_R1=10.0, R1_once_every=16):
         """Lazy R1 (ppst_model.py:140-159, ppst_optimizer.py:116-126): zero_grad, penalty, and
         d(mean(penalty) * R1_once_every)/d(theta_D) into self.grad."""
-        self.grad.zero_()
+        self.zero_grad()          # (settles an owed deferred step first: its all-reduce may still be reading self.grad)
         pen, state = self.r1_forward(real, lambda_R1)
         B = pen.shape[0]
         self.r1_backward(state, torch.full((B,), R1_once_every / B, device=pen.device))
@@ -326,7 +326,7 @@ class DiscriminatorTrainer:
 
     def losses_and_grads(self, real, rec, mix, lambda_GAN=1.0):
         """zero_grad + LSGAN losses + d(sum of losses)/d(theta_D) into self.grad."""
-        self.grad.zero_()
+        self.zero_grad()          # (settles an owed deferred step first: its all-reduce may still be reading self.grad)
         losses, state = self.d_forward(real, rec, mix, lambda_GAN)
         self.d_backward(state)
         return losses
@@ -337,9 +337,11 @@ class DiscriminatorTrainer:
 
     def all_reduce(self):
         """DDP gradient averaging: one flat all-reduce (RCCL when the tensors are on the GPU)."""
+        self.finish_pending()
         ddp_average_(self.grad, self.world)
 
     def adam(self):
+        self.finish_pending()     # (an owed step is applied first, in order; no-op when called from finish_pending itself)
         if not self.owns_parameters():
             raise RuntimeError("D's parameters no longer alias this trainer's flat buffer (a second trainer was built "
                                "on the same network, or .to()/.cuda() moved it): the update would be lost")

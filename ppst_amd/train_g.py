@@ -551,6 +551,17 @@ class GeneratorTrainer:
         import torch.distributed as dist
         pending = getattr(self, "_pending", {})
         counts = getattr(self, "_done_count", None)
+        if counts is not None and any(self._expected.get(k) is None for k in self.fp):
+            # the learning step: every rank must have seen the same number of contributions per network -- a rank that learned
+            # another count would launch its all-reduces at another point of backward, and the collectives of one communicator
+            # have to be issued in the same order everywhere.  One small all_gather, once (and after relearn_overlap()).
+            keys = list(self.fp)
+            mine = torch.tensor([counts[k] for k in keys], dtype=torch.int64, device=self.fp[keys[0]].grad.device)
+            got = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(got, mine)
+            if any(not torch.equal(g_, got[0]) for g_ in got):
+                raise RuntimeError("gradient contribution counts differ between ranks (%s per rank for %s): the overlapped "
+                                   "all-reduces would be issued in different orders" % ([g_.tolist() for g_ in got], keys))
         for key, f in self.fp.items():
             if counts is not None:
                 exp = self._expected.get(key)
@@ -622,6 +633,11 @@ class PPSTOptimizer:
             self.dis.lr, self.dis.b1, self.dis.b2 = lr * c, beta1 ** c, beta2 ** c
             self.dis.R1_once_every, self.dis.world = R1_once_every, world
             self.optimizer_D = self.dis
+        # DistributedDataParallel's constructor broadcasts rank 0's parameters and buffers (models/__init__.py:88): without it the
+        # per-process torch.randn NCE queues (and any unseeded parameter) differ between the ranks
+        import torch.distributed as dist
+        if world > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size() == world:
+            model.sync_from_rank0()
 
     def prepare_images(self, data_i):
         return data_i["real_A"], data_i["mask_A"]

@@ -102,6 +102,8 @@ class CelebAMaskDataset:
     belongs to rank k mod world; ``batch_size`` is the PER-RANK batch (the reference's ``opt.batch_size / opt.num_gpus``,
     data/__init__.py:116).
 
+    The defaults are the launcher's TRAINING transform (preprocess="resize" + RandomHorizontalFlip, CelebA_launcher.py:17-18,
+    base_dataset.py:130-132); the evaluators' transform (short side scaled, no flip) is passed explicitly at its call sites.
     ``preprocess``: "resize" = the launcher's training transform (square ``load_size``, CelebA_launcher.py:17-18);
     "scale_shortside" = the evaluators' transform.  ``flip``: RandomHorizontalFlip as in the reference's training transform
     (``no_flip`` is not set there).  Two stated deviations: (1) the reference builds the image and the label transform
@@ -111,8 +113,8 @@ class CelebAMaskDataset:
     size it invents label values -- here labels are resized NEAREST.  The next batch is decoded on a worker thread while the
     current step runs (the reference: DataLoader workers)."""
 
-    def __init__(self, dataroot, size=512, batch_size=2, rank=0, world=1, device="cuda", seed=0, preprocess="scale_shortside",
-                 flip=False, prefetch=True):
+    def __init__(self, dataroot, size=512, batch_size=2, rank=0, world=1, device="cuda", seed=0, preprocess="resize",
+                 flip=True, prefetch=True):
         assert preprocess in ("resize", "scale_shortside")
         self.size, self.batch_size, self.rank, self.world, self.device = size, batch_size, rank, world, device
         self.preprocess, self.flip, self.prefetch = preprocess, flip, prefetch

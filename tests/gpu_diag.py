@@ -309,6 +309,23 @@ def t_conv():
 CONV_DEFAULTS = (ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS)
 
 
+def direct_kernels_only(fn):
+    """Run ``fn`` with the Winograd kernel (variant 10) switched off: the bit-identity checks below compare the DIRECT kernel
+    families with each other (same MFMA sequence per output element); variant 10 is fp32-class but a different sum."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        prev = ops.WINO["value"]
+        ops.WINO["value"] = False
+        try:
+            return fn(*a, **k)
+        finally:
+            ops.WINO["value"] = prev
+    return wrapped
+
+
+@direct_kernels_only
 def t_conv_variants():
     """The fat-wave kernel (conv_mfma2.hip, N tile 128 and 256) against the 8-wave kernel on the same plans: same MFMA
     sequence per output element, so outputs must be bit-identical; tile statistics to rounding (other summation tree)."""
@@ -399,6 +416,81 @@ def t_conv_variants():
             report("fat conv %s %s stats" % (tag, name), s1, s0, 1e-5)
 
 
+def t_conv_wino():
+    """conv_wino.hip (variant 10: Winograd F(2,3) along x, 1.5x fewer MFMAs) against float64 torch for every padding mode, ragged
+    and sliced tensors, every epilogue option, normalise-on-load and the input-gradient plan -- the bar of the direct kernels
+    (3e-5 of the largest output); NOT bit-identical to them (another sum), so the direct result is printed beside it."""
+    torch.manual_seed(5)
+    prev = dict(ops.WINO)
+    ops.WINO.update(value=True, min_blocks=1)          # the small shapes here on the Winograd kernel too
+    try:
+        pad_ref = lambda x, pm: F.pad(x, (1, 1, 1, 1), mode={0: "constant", 1: "reflect", 2: "replicate"}[pm])
+        lrelu = lambda t: F.leaky_relu(t, 0.2) * math.sqrt(2.0)
+        for name, B, ci, co, H, Wd, pm in [("64->128 32x32 zero", 2, 64, 128, 32, 32, 0), ("32->128 40x24 ragged zero", 1, 32, 128, 40, 24, 0),
+                                          ("64->256 33x47 reflect", 2, 64, 256, 33, 47, 1), ("128->128 16x16 replicate", 1, 128, 128, 16, 16, 2),
+                                          ("256->384 16x16 zero", 1, 256, 384, 16, 16, 0), ("512->512 8x8 zero", 1, 512, 512, 8, 8, 0),
+                                          ("128->128 64x64 zero", 3, 128, 128, 64, 64, 0), ("96->160 18x50 zero (cout % 128 != 0)", 1, 96, 160, 18, 50, 0),
+                                          ("32->128 3x5 zero (smaller than a tile)", 1, 32, 128, 3, 5, 0)]:
+            x = torch.randn(B, ci, H, Wd)
+            w = torch.randn(co, ci, 3, 3) / math.sqrt(ci * 9)
+            ref = F.conv2d(pad_ref(x.double(), pm), w.double())
+            plan = ops.ConvPlan(g(w))
+            assert plan.choose_kernel(H, Wd, H, Wd, H, Wd, 1)[0] == 10
+            report("wino " + name, nchw(plan(g(nhwc(x)), pad_mode=pm).cpu()), ref, 3e-5)
+        B, ci, co, H, Wd = 2, 64, 128, 24, 40
+        x = torch.randn(B, ci, H, Wd); w = torch.randn(co, ci, 3, 3) / 24.0
+        bias = torch.randn(co); noise = torch.randn(B, 1, H, Wd); res = torch.randn(B, co, H, Wd)
+        conv = F.conv2d(x.double(), w.double(), padding=1)
+        plan = ops.ConvPlan(g(w))
+        y, st = plan(g(nhwc(x)), bias=g(bias), noise=g(noise), noise_weight=0.3, act=ops.ACT_LRELU, stats=True)
+        ref = lrelu(conv + 0.3 * noise.double() + bias.double().view(1, -1, 1, 1))
+        report("wino epilogue bias+noise+lrelu", nchw(y.cpu()), ref, 3e-5)
+        s_ = st.cpu().double().sum(1)
+        report("wino tile stats sum", s_[..., 0], ref.sum((2, 3)), 1e-5)
+        report("wino tile stats sumsq", s_[..., 1], (ref ** 2).sum((2, 3)), 1e-5)
+        report("wino in_finalize+affine == instance_norm", nchw(ops.affine_act(y, ops.in_finalize(st, H * Wd)).cpu()), O.instance_norm(ref), 3e-5)
+        y = plan(g(nhwc(x)), bias=g(bias), act=ops.ACT_LRELU, residual=g(nhwc(res)), res_after_act=True, out_scale=0.5)
+        report("wino residual after act * scale", nchw(y.cpu()), (lrelu(conv + bias.double().view(1, -1, 1, 1)) + res.double()) * 0.5, 3e-5)
+        a_ = torch.tensor([0.25])
+        y = plan(g(nhwc(x)), bias=g(bias), act=ops.ACT_PRELU, prelu=g(a_), residual=g(nhwc(res)))
+        t = conv + bias.double().view(1, -1, 1, 1) + res.double()
+        report("wino residual before prelu", nchw(y.cpu()), torch.where(t >= 0, t, 0.25 * t), 3e-5)
+        big = torch.zeros(B, H, Wd, 200, device=dev)
+        plan(g(nhwc(x)), out=big[..., 40:168])
+        report("wino out slice", nchw(big[..., 40:168].contiguous().cpu()), conv, 3e-5)
+        report("wino out slice untouched", big[..., :40].cpu(), torch.zeros(B, H, Wd, 40), 0)
+        ss = torch.stack([torch.rand(B, ci) + 0.5, torch.randn(B, ci)], -1).contiguous()
+        xn = x.double() * ss[..., 0].double().view(B, ci, 1, 1) + ss[..., 1].double().view(B, ci, 1, 1)
+        for pm in (0, 1, 2):
+            for in_act, fn in ((ops.ACT_NONE, lambda t: t), (ops.ACT_PRELU, lambda t: torch.where(t >= 0, t, 0.25 * t)), (ops.ACT_LRELU, lrelu)):
+                y = plan(g(nhwc(x)), pad_mode=pm, in_ss=g(ss), in_act=in_act, in_prelu=g(a_))
+                report("wino normalise-on-load pad %d act %d" % (pm, in_act), nchw(y.cpu()), F.conv2d(pad_ref(fn(xn), pm), w.double()), 3e-5)
+        xb = torch.randn(B, H, Wd, 160)
+        report("wino input slice", nchw(plan(g(xb)[..., 32:96]).cpu()), F.conv2d(xb[..., 32:96].permute(0, 3, 1, 2).double(), w.double(), padding=1), 3e-5)
+        wd = torch.randn(128, 256, 3, 3) / 30.0      # forward (Cout 128, Cin 256): its input gradient maps 128 -> 256 channels
+        dy = torch.randn(B, 128, H, Wd)
+        pd = ops.ConvPlan(g(wd), kind="dgrad")
+        assert pd.choose_kernel(H, Wd, H, Wd, H, Wd, 1)[0] == 10
+        report("wino dgrad 128->256", nchw(pd(g(nhwc(dy))).cpu()), F.conv_transpose2d(dy.double(), wd.double(), padding=1), 3e-5)
+        y = ops.ConvPlan(g(w), scale=0.05)(g(nhwc(x)))
+        report("wino weight scale", nchw(y.cpu()), F.conv2d(x.double(), w.double() * 0.05, padding=1), 3e-5)
+        # cold caches == warm (the weight fragments come straight from memory), and two launches agree bit for bit
+        xg = g(nhwc(torch.randn(4, 128, 64, 64))); wg = g(torch.randn(256, 128, 3, 3) / 34.0)
+        pw = ops.ConvPlan(wg)
+        y1 = pw(xg).clone()
+        _ = torch.empty(256 << 20, device=dev).fill_(1.0)     # 1 GB through the caches
+        y2 = pw(xg)
+        RES.append(("wino cold == warm", bool(torch.equal(y1, y2))))
+        print("wino cold == warm                                           %s" % ("ok" if torch.equal(y1, y2) else "FAIL"), flush=True)
+        # a shard of a batch reproduces the batch bit for bit (the kernel choice and the sums do not depend on B)
+        ya = pw(xg[1:3])
+        RES.append(("wino batch shard bit-identical", bool(torch.equal(ya, y2[1:3]))))
+        print("wino batch shard bit-identical                              %s" % ("ok" if torch.equal(ya, y2[1:3]) else "FAIL"), flush=True)
+    finally:
+        ops.WINO.update(prev)
+
+
+@direct_kernels_only
 def t_conv_variants_single_pass():
     """The N-256 kernel in the single-pass modes (bf16, fp16) against the tile kernel in the same mode: bit-identical."""
     torch.manual_seed(8)
@@ -446,6 +538,7 @@ def t_conv_variants_single_pass():
             report("single-pass prec %d %s stats" % (prec, name), outs[1][1], outs[0][1], 1e-5)
 
 
+@direct_kernels_only
 def t_conv1x1_stream():
     """conv1x1.hip (streaming 1x1 kernel and its direct form for thin 3x3 / stride-2 layers; operands swapped) against
     conv_mfma.hip on the same plans: bit-identical outputs, statistics to rounding; every epilogue / normalise-on-load

@@ -592,6 +592,10 @@ def compare_gstep_replay(stage, tol=5e-3, verbose=True):
         for w_ in worst[:10]:
             print("   %-64s max %.2e l2 %.2e (%d elements)%s" % (w_[2], w_[0], w_[1], w_[3],
                   "  [reference float32 vs exact convs: %.2e]" % w_[5] if w_[3] == 1 else ""), flush=True)
+        print("one-element tensors (each ONE cancelling sum; bar = max(%.0e, 2 x the float32 floor measured here = reference float32 "
+              "fixture vs our exact-conv value):" % tol, flush=True)
+        for w_ in sorted((w_ for w_ in worst if w_[3] == 1 and "null direction" not in w_[2]), key=lambda t: t[2]):
+            print("   %-56s error %.2e  floor %.2e  bar %.2e  %s" % (w_[2], w_[0], w_[5], max(tol, 2.0 * w_[5]), "ok" if w_[4] else "FAIL"), flush=True)
         # flipped gates of the production run, per kind of site and per site
         agg = {}
         for site, n, fl in flips:

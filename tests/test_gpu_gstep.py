@@ -265,7 +265,7 @@ def test_celebamask_dataset_loader(tmp_path):
         Image.fromarray(a).save(tmp_path / "images" / ("%d.png" % i))
         Image.fromarray(l).save(tmp_path / "labels" / ("%d.png" % i))
         imgs.append(a); labs.append(l)
-    ds = CelebAMaskDataset(str(tmp_path), size=64, batch_size=3)
+    ds = CelebAMaskDataset(str(tmp_path), size=64, batch_size=3, preprocess="scale_shortside", flip=False)   # (the evaluators' transform)
     order = list(ds._order[:3])          # (read before next(): the prefetch thread already walks into the next epoch's order)
     batch = next(ds)
     assert tuple(batch["real_A"].shape) == (3, 3, 64, 64) and tuple(batch["mask_A"].shape) == (3, 3, 64, 64)

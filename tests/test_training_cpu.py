@@ -216,6 +216,27 @@ assert torch.allclose(d.flat, exp)
 d.grad.fill_(float(rank)); d.step_deferred()
 d.zero_grad()                                          # the next zero_grad settles an owed step first, then clears
 assert d._pending is None and d.step_count == 2 and float(d.grad.abs().max()) == 0.0
+# the entry points that zero / reduce / step on their own settle an owed step first too (ADVICE r3: losses_and_grads used to zero
+# the buffer the all-reduce was still reading; all_reduce / adam used to run past a pending handle)
+d.d_forward = lambda *a, **k: ({}, None)               # (the real forward / backward need the GPU: only the bookkeeping is under test)
+d.d_backward = lambda st, gouts=None: None
+w2 = d.flat.clone(); m2, v2 = d.m.clone(), d.v.clone()
+d.grad.fill_(float(rank + 3)); d.step_deferred()       # gradients 3 and 4 -> the owed step must use 3.5
+d.losses_and_grads(None, None, None)
+assert d._pending is None and d.step_count == 3 and float(d.grad.abs().max()) == 0.0
+exp = w2.clone(); adam_cpu(exp, torch.full_like(w2, 3.5), m2, v2, d.lr, d.b1, d.b2, d.eps, 3)
+assert torch.allclose(d.flat, exp), float((d.flat - exp).abs().max())
+d.r1_forward = lambda real, lam: (torch.zeros(2), None)
+d.r1_backward = lambda st, g: None
+d.grad.fill_(1.0); d.step_deferred()
+d.r1_losses_and_grads(None)
+assert d._pending is None and d.step_count == 4 and float(d.grad.abs().max()) == 0.0
+d.grad.fill_(float(rank)); d.step_deferred()
+d.all_reduce()                                         # settles (step 5), then averages what is in the buffer now
+assert d._pending is None and d.step_count == 5
+d.grad.fill_(2.0); d.step_deferred()
+d.adam()                                               # the owed step (6) first, then this one (7)
+assert d._pending is None and d.step_count == 7
 if rank == 0:
     print("OK")
 dist.destroy_process_group()
