@@ -80,17 +80,30 @@ __device__ __forceinline__ float wino_swap1(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true));
 }
 
-template <bool INSS>
+// The lane id, computed afresh (2 VALU) and opaque to hipcc: what is derived from it at a point of use -- LDS store address, table
+// address, weight-fragment offset, sign of the pair exchange -- is then not a loop-invariant register.  The kernel sits AT the 256
+// registers of two waves per SIMD; every invariant hipcc hoisted was one more spill, and a scratch reload is a vector-memory
+// operation: the in-order vmcnt makes its wait drain the weight fragments requested for the next step.
+__device__ __forceinline__ int wino_lane() {
+  int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(l));
+  return l;
+}
+
+// INMODE: normalise on load -- 0 off, 1 affine only (in_act none: the StyledConv conv2 case), 2 affine + activation
+template <int INMODE>
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
+  constexpr bool INSS = INMODE != 0;
   constexpr int NP = 8, HH = 18;
   constexpr int PLANE = HH * NP * 16;      // one k-group plane of one transform position: 2304 B (a multiple of 256)
   constexpr int XIB = 8 * PLANE;           // hi g0..3 | lo g0..3
-  constexpr int SKEW = 0;
   constexpr int ABUF = 4 * XIB + 128;      // 73856 B per chunk slot
   constexpr int TROW = 36;                 // padded row of the output-transform tile (floats)
   constexpr int TXI = 128 * TROW;          // floats per transform position
   constexpr int TBUF = 4 * TXI;            // floats per pass buffer (73728 B: the two buffers overlay the two chunk slots)
-  __shared__ __attribute__((aligned(256))) unsigned char smem[2 * ABUF + 8 * 128 * 2 * 4];
+  // [2 chunk slots | (a, s) table of normalise-on-load, up to 1024 channels]; the epilogue's pass buffers overlay the chunk slots
+  __shared__ __attribute__((aligned(256))) unsigned char smem[2 * ABUF + 1024 * 2 * 4];
+  float* const ss_lds = (float*)(smem + 2 * ABUF);
 
   // XCD-aware block -> (n tile, image tile) map: as conv_mfma.hip (bijective remap, N-major order)
   const int nwg = gridDim.x;
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
     colA = col(se ? 3 : 0, okA);
     colB = col(se ? 1 : 2, okB);
   }
-  const float sgn = se ? -1.f : 1.f;
+  const bool interior = a.pad_mode != PPST_PAD_ZERO || (ty0 >= 1 && ty0 + 16 < a.in_h && tx0 >= 1 && tx0 + 16 < a.in_w);
   // the three halo rows this wave stages per chunk: wave, wave + 8, wave + 16; waves 2..7 have no third row: they request zeros
   // (no branch around a load: see the loop) and skip the arithmetic and the stores
   int rowoff[3];
@@ -166,41 +179,71 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
   const float in_pos = (INSS && a.in_act == PPST_ACT_LRELU) ? 1.41421356237309515f : 1.f;
   auto in_act = [&](float t) -> float { return (t > 0.f ? t : t * in_neg) * in_pos; };
   float4 rd[4];                                       // A ch 0-3, A ch 4-7, B ch 0-3, B ch 4-7
-  auto stage_load = [&](int r, int chan) {            // r compile-time after unrolling; chan wave-uniform
-    const bool rowok = rowoff[r] >= 0;
-    const int so = (rowok ? rowoff[r] : 0) + chan * 4;
-    const int va = rowok ? colA : WINO_OOB, vb = rowok ? colB : WINO_OOB;
-    rd[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, va, so, 0));
-    rd[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, va + 16, so, 0));
-    rd[2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vb, so, 0));
-    rd[3] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vb + 16, so, 0));
+  auto stage_load = [&](float4 (&q)[4], int r, int chan) {      // r compile-time after unrolling; chan wave-uniform
+    // a halo row outside the image under zero padding (rowoff < 0; wave-uniform) is requested at row 0 -- in bounds, ONE address
+    // register pair for all rows -- and zeroed in stage_prep
+    const int so = (rowoff[r] >= 0 ? rowoff[r] : 0) + chan * 4;
+    const int va = colA, vb = colB;
+    // (channels 4-7: +16 bytes on the SCALAR offset -- two address registers per lane instead of four; the four spilled in
+    //  the normalise-on-load build, and every scratch reload is a vector-memory operation the in-order vmcnt has to drain)
+    q[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, va, so, 0));
+    q[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, va, so + 16, 0));
+    q[2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vb, so, 0));
+    q[3] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vb, so + 16, 0));
   };
   auto stage_skip = [&](int r) { return r == 2 && wave >= 2; };     // (wave-uniform; LDS stores only behind it)
-  // normalise on load: (a, s) of the lane's 8 channels, fetched where they are used (16 registers otherwise live across the step;
-  // the table of one image is 2-4 KB: L1 hits)
-  auto stage_prep = [&](int r, int chan, int part) {   // part 0: channels 0-3 of A and B, part 1: channels 4-7
+  // normalise on load: (a, s) of the lane's 8 channels from the block's LDS copy of the image's table (a global load here sat in
+  // front of its own use: one L2 round trip per row in the middle of the MFMA stream, 3.14 instead of 2.4 ms on 128 -> 128 @512^2)
+  const int chan_first = steps[0].x;
+  auto stage_prep = [&](float4 (&q)[4], int r, int chan, int part) {   // part 0: channels 0-3 of A and B, part 1: channels 4-7
+    const bool rowok = rowoff[r] >= 0;
     if (INSS) {
-      const float4* p = (const float4*)(a.in_ss + ((int64_t)b * a.in_c + chan + sg * 8) * 2) + part * 2;
-      const bool rowok = rowoff[r] >= 0;
+      const float4* p = (const float4*)((const unsigned char*)ss_lds + (chan - chan_first) * 8 + (wino_lane() >> 4) * 64) + part * 2;
       const float4 s0 = p[0], s1 = p[1];
+      auto nact = [&](float t) -> float { return INMODE == 2 ? in_act(t) : t; };
+      if (interior) {      // (wave-uniform: no padding item in this block's halo -- or a padding mode that has none: no masks)
 #pragma unroll
-      for (int h = part; h < 4; h += 2) {              // (padding items: zeros from the out-of-range buffer load, and they stay zero)
-        float4 v = rd[h];
-        if (rowok && (h < 2 ? okA : okB)) {
-          v.x = in_act(s0.x * v.x + s0.y); v.y = in_act(s0.z * v.y + s0.w);
-          v.z = in_act(s1.x * v.z + s1.y); v.w = in_act(s1.z * v.w + s1.w);
-        } else v = make_float4(0.f, 0.f, 0.f, 0.f);
-        rd[h] = v;
+        for (int h = part; h < 4; h += 2) {
+          float4 v = q[h];
+          v.x = nact(s0.x * v.x + s0.y); v.y = nact(s0.z * v.y + s0.w);
+          v.z = nact(s1.x * v.z + s1.y); v.w = nact(s1.z * v.w + s1.w);
+          q[h] = v;
+        }
+      } else {
+#pragma unroll
+        for (int h = part; h < 4; h += 2) {            // (padding items: zeros from the out-of-range buffer load, and they stay zero)
+          float4 v = q[h];
+          if (rowok && (h < 2 ? okA : okB)) {
+            v.x = nact(s0.x * v.x + s0.y); v.y = nact(s0.z * v.y + s0.w);
+            v.z = nact(s1.x * v.z + s1.y); v.w = nact(s1.z * v.w + s1.w);
+          } else v = make_float4(0.f, 0.f, 0.f, 0.f);
+          q[h] = v;
+        }
+      }
+    } else {               // (a row outside the image was requested at row 0: AND it away -- no branch in the MFMA stream)
+      const unsigned keep = rowok ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int h = part; h < 4; h += 2) {
+        float4 v = q[h];
+        v.x = __uint_as_float(__float_as_uint(v.x) & keep); v.y = __uint_as_float(__float_as_uint(v.y) & keep);
+        v.z = __uint_as_float(__float_as_uint(v.z) & keep); v.w = __uint_as_float(__float_as_uint(v.w) & keep);
+        q[h] = v;
       }
     }
   };
   // piece 0: A - B -> position 0 (se = 0) / 3 (se = 1); piece 1: B(partner) + sgn B -> position 1 / 2.  The 8 lanes of a
   // ds_write_b128 group are the 8 pairs of one (se, sg): 128 contiguous bytes of one plane.
-  auto stage_put = [&](int r, int slot, int piece) {
+  auto stage_put = [&](float4 (&q)[4], int r, int slot, int piece) {
     const int hrow = wave + 8 * r;
-    const float4 A0 = rd[0], A1 = rd[1], B0_ = rd[2], B1_ = rd[3];
+    const float4 A0 = q[0], A1 = q[1], B0_ = q[2], B1_ = q[3];
     float4 V0, V1;
     int i;
+#ifdef WINO_KEEP_STB
+    const int ln = lane, se = (ln >> 3) & 1, stb = (ln >> 4) * PLANE + (ln & 7) * 16;
+#else
+    const int ln = wino_lane(), se = (ln >> 3) & 1, stb = (ln >> 4) * PLANE + (ln & 7) * 16;
+#endif
+    const float sgn = se ? -1.f : 1.f;
     if (piece == 0) {
       i = se ? 3 : 0;
       V0 = make_float4(A0.x - B0_.x, A0.y - B0_.y, A0.z - B0_.z, A0.w - B0_.w);
@@ -217,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
     uint2 h0, l0, h1, l1;
     split_bf16x4(V0, h0, l0);
     split_bf16x4(V1, h1, l1);
-    unsigned char* dst = smem + slot * ABUF + i * XIB + (i >= 2 ? SKEW : 0) + sg * PLANE + (hrow * NP + sp) * 16;
+    unsigned char* dst = smem + (slot * ABUF + hrow * NP * 16) + i * XIB + stb;
 #ifdef WINO_ABL_NOLDSW       /* the arithmetic without the LDS stores */
     asm volatile("" ::"v"(h0.x), "v"(h0.y), "v"(l0.x), "v"(l0.y), "v"(h1.x), "v"(h1.y), "v"(l1.x), "v"(l1.y));
 #else
@@ -235,36 +278,48 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
     if (s > 0) return;
 #endif
     const int so = s * WINO_STEP_BYTES + half * 4096;
+#ifdef WINO_KEEP_LO16
+    const int lo16 = lane * 16;
+#else
+    const int lo16 = wino_lane() * 16;
+#endif
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
-        dst[n][h] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16 + (n * 2 + h) * 1024, so, 0));
+        dst[n][h] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lo16 + (n * 2 + h) * 1024, so, 0));
   };
+
+  // ---- prologue: every request of the block's first chunk goes out at once (weight fragments of step 0, the three halo rows,
+  // the (a, s) table) -- the accumulators are not live yet, so three row register sets fit -- then chunk 0 is staged into slot 0
+  load_b(B0, 0, 0);
+  load_b(B1, 0, 1);
+  {
+    float4 q1[4], q2[4];
+    stage_load(rd, 0, chan_first);
+    stage_load(q1, 1, chan_first);
+    stage_load(q2, 2, chan_first);
+    if (INSS) {
+      const float* src = a.in_ss + ((int64_t)b * a.in_c + chan_first) * 2;
+      for (int i = tid * 4; i < nchunk * 64; i += 512 * 4) *(float4*)(ss_lds + i) = *(const float4*)(src + i);
+      __syncthreads();
+    }
+    stage_prep(rd, 0, chan_first, 0); stage_prep(rd, 0, chan_first, 1);
+    stage_put(rd, 0, 0, 0); stage_put(rd, 0, 0, 1);
+    stage_prep(q1, 1, chan_first, 0); stage_prep(q1, 1, chan_first, 1);
+    stage_put(q1, 1, 0, 0); stage_put(q1, 1, 0, 1);
+    if (!stage_skip(2)) {
+      stage_prep(q2, 2, chan_first, 0); stage_prep(q2, 2, chan_first, 1);
+      stage_put(q2, 2, 0, 0); stage_put(q2, 2, 0, 1);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   f32x4 acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // ---- prologue: chunk 0 staged into slot 0, weight fragments of step 0 requested
-  {
-    const int chan0 = steps[0].x;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      stage_load(r, chan0);
-      if (!stage_skip(r)) {
-        stage_prep(r, chan0, 0);
-        stage_prep(r, chan0, 1);
-        stage_put(r, 0, 0);
-        stage_put(r, 0, 1);
-      }
-    }
-  }
-  load_b(B0, 0, 0);
-  load_b(B1, 0, 1);
-  __syncthreads();
 
   // A fragment of m-tile mt (tile rows 2 mt, 2 mt + 1; 8 pairs each) for tap row dy: halo rows 2 mt + dy, 2 mt + dy + 1.
   //
@@ -275,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
   // request to just before its first use and waits at once -- zero prefetch distance (~1.6 k cycles of s_waitcnt per step and
   // wave by counter).  The staged row's two transform pieces sit between m-tiles of the second half, free to interleave with
   // that m-tile's six MFMAs.
-#define WA_OFF(slot, dy, mt) ((slot) * ABUF + xi * XIB + (xi >= 2 ? SKEW : 0) + g * PLANE + ((2 * (mt) + (dy)) * NP + r16) * 16)
+#define WA_OFF(slot, dy, mt) ((slot) * ABUF + xi * XIB + g * PLANE + ((2 * (mt) + (dy)) * NP + r16) * 16)
   int s = 0;
   for (int c = 0; c < nchunk; ++c) {
     const int slot = c & 1;
@@ -290,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
     for (int dy = 0; dy < 3; ++dy) {
       const int sn = s + 1 < nsteps ? s + 1 : s;
 #ifndef WINO_ABL_NOSTAGE
-      stage_load(dy, chan_next);
+      stage_load(rd, dy, chan_next);
 #endif
       __builtin_amdgcn_sched_barrier(0);
       // half 0: n-tiles 0, 1
@@ -334,10 +389,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
         __builtin_amdgcn_sched_barrier(0);
 #ifndef WINO_ABL_NOSTAGE
         if (!skip) {           // (the last chunk writes the dead slot once more: harmless, and no branch around the loads)
-          if (mt == 2) stage_prep(dy, chan_next, 0);
-          if (mt == 3) stage_prep(dy, chan_next, 1);
-          if (mt == 4) stage_put(dy, slot ^ 1, 0);
-          if (mt == 6) stage_put(dy, slot ^ 1, 1);
+          if (mt == 2) stage_prep(rd, dy, chan_next, 0);
+          if (mt == 3) stage_prep(rd, dy, chan_next, 1);
+          if (mt == 4) stage_put(rd, dy, slot ^ 1, 0);
+          if (mt == 6) stage_put(rd, dy, slot ^ 1, 1);
         }
 #endif
 #pragma unroll
@@ -369,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
   // conflict-free), then all eight waves form y[2p] = m0 + m1 + m2, y[2p+1] = m1 - m2 + m3: a thread takes 4 consecutive
   // channels of one pair, a wave-instruction stores two full 512-byte pixel rows.  Two buffers: one barrier per pass.
   float* const T = (float*)smem;
-  float* const red = (float*)(smem + 2 * ABUF);      // [8 waves][128][2]
+  float* const red = (float*)smem;                   // [8 waves][128][2]: in pass buffer 0, free once every wave is in / past pass 3
   const int act = a.act & 0xff;
   const bool res_after = (a.act >> 8) & 1;
   const float slope = (act == PPST_ACT_PRELU && a.prelu) ? a.prelu[0] : 0.f;
@@ -463,7 +518,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
     float4 s1 = s1a, s2 = s2a;
     s1.x += __shfl_xor(s1.x, 32, 64); s1.y += __shfl_xor(s1.y, 32, 64); s1.z += __shfl_xor(s1.z, 32, 64); s1.w += __shfl_xor(s1.w, 32, 64);
     s2.x += __shfl_xor(s2.x, 32, 64); s2.y += __shfl_xor(s2.y, 32, 64); s2.z += __shfl_xor(s2.z, 32, 64); s2.w += __shfl_xor(s2.w, 32, 64);
-    __syncthreads();     // (`red` lies behind the pass buffers, but be explicit: every wave has left its last pass)
+    __syncthreads();     // every wave has left its last pass (which read buffer 1; `red` lies in buffer 0)
     if (lane < 32) {
       float* r = red + (wave * 128 + f32_ * 4) * 2;
       r[0] = s1.x; r[1] = s2.x; r[2] = s1.y; r[3] = s2.y; r[4] = s1.z; r[5] = s2.z; r[6] = s1.w; r[7] = s2.w;
@@ -497,8 +552,9 @@ int ppst_conv_wino_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int
   k.in_ss = (const float*)a->in_scale_shift; k.in_prelu = (const float*)a->in_prelu;
   k.in_c = a->in_c; k.in_act = a->in_act;
   const int blocks = n_tiles * a->B * tiles_y * tiles_x;
-  if (k.in_ss) PPST_LAUNCH((conv_wino_kernel<true>), dim3(blocks), dim3(512), 0, st, k);
-  else PPST_LAUNCH((conv_wino_kernel<false>), dim3(blocks), dim3(512), 0, st, k);
+  if (k.in_ss && k.in_act != PPST_ACT_NONE) PPST_LAUNCH((conv_wino_kernel<2>), dim3(blocks), dim3(512), 0, st, k);
+  else if (k.in_ss) PPST_LAUNCH((conv_wino_kernel<1>), dim3(blocks), dim3(512), 0, st, k);
+  else PPST_LAUNCH((conv_wino_kernel<0>), dim3(blocks), dim3(512), 0, st, k);
   return PPST_LAUNCH_CHECK();
 }
 

@@ -153,7 +153,12 @@ def time_wino_only(B):
         plan = ops.ConvPlan(w)
         y = torch.empty(B, S, S, co, device=dev)
         t = timeit(lambda: plan(x, stats=True, out=y))
-        out.append("%d->%d@%d %.3f ms %4.0f TF" % (ci, co, S, t, 2.0 * B * S * S * ci * co * 9 / t / 1e9))
+        # the StyledConv conv2 call: normalise-on-load + bias + noise + leaky ReLU + statistics
+        ss = torch.stack([torch.rand(B, ci, device=dev) + 0.5, torch.randn(B, ci, device=dev)], -1).contiguous()
+        bias = torch.randn(co, device=dev); nz = torch.randn(B, 1, S, S, device=dev)
+        t1 = timeit(lambda: plan(x, stats=True, out=y, bias=bias, noise=nz, noise_weight=0.1, act=ops.ACT_LRELU))
+        t2 = timeit(lambda: plan(x, stats=True, out=y, in_ss=ss, bias=bias, noise=nz, noise_weight=0.1, act=ops.ACT_LRELU))
+        out.append("%d->%d@%d %.3f / %.3f / %.3f ms" % (ci, co, S, t, t1, t2))
     print("%-10s %s" % (os.path.basename(os.environ.get("PPST_HIP_LIB", "base")).replace("libppst_hip_", "").replace(".so", ""),
                         " | ".join(out)), flush=True)
 
