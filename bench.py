@@ -408,6 +408,7 @@ def extras(args, dev):
             torch.cuda.empty_cache()
     run("train_bf16x3", bench_train, "bf16x3", 3, 1)
     run("train_bf16", bench_train, "bf16", 3, 1)
+    run("train_bf16x3_batch8", bench_train, "bf16x3", 2, 1, train_batch=8)       # B = 8 per GPU beside the reference's 2
     run("hires_fp16", bench_hires, "fp16", 3, 1, batch=4)
     return out
 

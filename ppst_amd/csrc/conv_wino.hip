@@ -238,11 +238,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
     const float4 A0 = q[0], A1 = q[1], B0_ = q[2], B1_ = q[3];
     float4 V0, V1;
     int i;
-#ifdef WINO_KEEP_STB
-    const int ln = lane, se = (ln >> 3) & 1, stb = (ln >> 4) * PLANE + (ln & 7) * 16;
-#else
     const int ln = wino_lane(), se = (ln >> 3) & 1, stb = (ln >> 4) * PLANE + (ln & 7) * 16;
-#endif
     const float sgn = se ? -1.f : 1.f;
     if (piece == 0) {
       i = se ? 3 : 0;
@@ -278,11 +274,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
     if (s > 0) return;
 #endif
     const int so = s * WINO_STEP_BYTES + half * 4096;
-#ifdef WINO_KEEP_LO16
-    const int lo16 = lane * 16;
-#else
     const int lo16 = wino_lane() * 16;
-#endif
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll

@@ -67,7 +67,9 @@ class batch_aware:
 # variant 10 (conv_wino.hip): Winograd F(2,3) along x for the plain 3x3 stride-1 layers with Cout >= 128 -- 1.5x fewer MFMAs per
 # output; fp32-class (<= 3e-5 against float64) but not bit-identical to the direct kernels.  ``min_blocks``: blocks ONE image gives
 # (the choice stays a function of the plan and one image's geometry).
-WINO = {"value": True, "min_blocks": 16}
+# ``fill`` (batch-aware passes only, i.e. the train step): with fewer than this many blocks in the LAUNCH the choice falls through to
+# the direct kernels' under-filled forms (8-row two-block tiles: twice the blocks)
+WINO = {"value": True, "min_blocks": 16, "fill": 0}
 FAT_MIN_BLOCKS = 32         # take the 256-channel tile only when ONE image still gives >= this many blocks (B = 8: one per CU)
 
 
@@ -484,7 +486,9 @@ class ConvPlan:
         single = self.precision in (1, 3)
         if self.precision not in (0, 1, 3):
             return variant, bn, rows                     # fp16x2 experiment / exact-fp32 verification: the tile kernel only
-        if WINO["value"] and self.wino_ok(th, tw, oh, ow, H, W, osy):
+        if WINO["value"] and self.wino_ok(th, tw, oh, ow, H, W, osy) and not (
+                BATCH_AWARE["value"] and B is not None and
+                ((th + 15) // 16) * ((tw + 15) // 16) * ((self.cout + 127) // 128) * B < WINO["fill"]):
             return 10, 128, 16
         tiles16 = ((th + 15) // 16) * ((tw + 15) // 16) * self.n_groups          # blocks PER IMAGE per N tile
         cv = CONV_VARIANT["value"]

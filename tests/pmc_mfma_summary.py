@@ -15,7 +15,7 @@ def per_kernel(counter):
 
 
 busy, act = per_kernel("SQ_VALU_MFMA_BUSY_CYCLES"), per_kernel("GRBM_GUI_ACTIVE")
-CONV = ("conv_mfma_kernel", "conv_mfma2_kernel", "conv1x1_stream_kernel", "conv3x3_direct_kernel")
+CONV = ("conv_mfma_kernel", "conv_mfma2_kernel", "conv1x1_stream_kernel", "conv3x3_direct_kernel", "conv_wino_kernel")
 out = {"commit": commit, "command": "rocprofv3 --kernel-trace --pmc <SQ_VALU_MFMA_BUSY_CYCLES|GRBM_GUI_ACTIVE> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
        "note": "utilisation = MFMA busy cycles / (1024 SIMDs x duration x clock of the same kernel from the GRBM_GUI_ACTIVE pass / 8 XCDs); "
                "bf16x3 issues three MFMAs per algorithmic MAC, so this is the fraction of the dense-bf16 matrix peak AT THE CLOCK THE KERNEL RAN AT",

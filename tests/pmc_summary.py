@@ -28,7 +28,7 @@ for k in fetch:
         e["kernel_ms_in_clock_pass"] = act[k][2] / 1e6
     kernels[k] = e
 kernels = dict(sorted(kernels.items(), key=lambda kv: -(kv[1]["fetch_bytes_corrected"] + kv[1]["write_bytes"])))
-CONV = ("conv_mfma_kernel", "conv_mfma2_kernel", "conv1x1_stream_kernel", "conv3x3_direct_kernel")   # every ppst_conv2d_mfma variant
+CONV = ("conv_mfma_kernel", "conv_mfma2_kernel", "conv1x1_stream_kernel", "conv3x3_direct_kernel", "conv_wino_kernel")   # every ppst_conv2d_mfma variant
 is_conv = lambda k: any(c in k for c in CONV)
 conv = [v for k, v in kernels.items() if is_conv(k)]
 n = sum(v["launches"] for v in conv)
