@@ -180,6 +180,212 @@ __global__ __launch_bounds__(256) void gf_v_final_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same pipeline with SLIDING windows (the path's radius only, RR = 30).  Round 3's passes summed 2 RR + 1 = 61
+// values per output and plane -- 61 LDS reads per output in the H passes, 61 L2 reads per output in the final V pass: 1.38 ms per
+// batch of four 1024^2 images, 27 GB/s against the algorithmic 9 B / pixel.  Here a thread owns GF_SEG consecutive outputs of one
+// plane: its first window is a direct sum, the next ones add the entering and subtract the leaving value (5.7 / 3.9 reads per
+// output instead of 61).
+//   * the 15 moment planes of stage 1 are INTEGERS: a 61-term row sum is < 2^22, exact in fp32 whatever the order; the column
+//     sums (< 2^28) run in uint32 -- exact too, and the mean is formed from the exact sum (the direct fp32 sums of round 3, and
+//     of the oracle, carry ~1e-7 relative rounding there);
+//   * the (a, b) planes of stage 2 are floats: a window slides over at most GF_SEG - 1 = 15 (rows: GF_VSEG - 1 = 63) steps before
+//     the next thread starts from a direct sum again, so the drift is bounded by that many roundings of a sum of 61 terms.
+// Bar: <= 1 uint8 LSB against the oracle (tests/gpu_diag.py:t_guided), as before.
+#define GF_SEG 16
+#ifndef GF_VSEG
+#define GF_VSEG 32
+#endif
+// LDS row index with one pad slot per 16 entries: lanes are 16 entries apart (one segment each) -- unpadded, all of a wave's
+// reads fall on two banks
+#define GF_ROW(i) ((i) + ((i) >> 4))
+
+// H pass of stage 1: grid (H, column chunks of GF_HCW outputs, B), 256 threads.  Phase 1: the 21 moments of every pixel of the
+// chunk (+ RR on both sides, reflected) are formed ONCE and laid out as 21 padded LDS rows; phase 2: thread = (plane group, 16-output
+// segment) slides the window over its segment plane by plane -- one LDS read and one add per entering / leaving value.
+#define GF_HCW 512
+#define GF_HROWLEN (GF_ROW(GF_HCW + 2 * GF_MAXR) + 1)
+template <int RR>
+__global__ __launch_bounds__(256) void gf_h1_slide_kernel(const unsigned char* __restrict__ guide, const unsigned char* __restrict__ src,
+                                                          float* __restrict__ out, int H, int W) {
+  __shared__ unsigned mom[21][GF_HROWLEN];
+  const int y = blockIdx.x, xc0 = blockIdx.y * GF_HCW, b = blockIdx.z;
+  const int cw = min(GF_HCW, W - xc0);
+  const int64_t P = (int64_t)H * W;
+  for (int i = threadIdx.x; i < cw + 2 * RR; i += 256) {
+    const int x = reflect_idx(xc0 + i - RR, W);
+    const int64_t o = (((int64_t)b * H + y) * W + x) * 3;
+    const unsigned I0 = guide[o], I1 = guide[o + 1], I2 = guide[o + 2], P0 = src[o], P1 = src[o + 1], P2 = src[o + 2];
+    const int k = GF_ROW(i);
+    mom[0][k] = I0; mom[1][k] = I1; mom[2][k] = I2; mom[3][k] = P0; mom[4][k] = P1; mom[5][k] = P2;
+    mom[6][k] = __umul24(I0, I0); mom[7][k] = __umul24(I0, I1); mom[8][k] = __umul24(I0, I2);
+    mom[9][k] = __umul24(I1, I1); mom[10][k] = __umul24(I1, I2); mom[11][k] = __umul24(I2, I2);
+    mom[12][k] = __umul24(I0, P0); mom[13][k] = __umul24(I1, P0); mom[14][k] = __umul24(I2, P0);
+    mom[15][k] = __umul24(I0, P1); mom[16][k] = __umul24(I1, P1); mom[17][k] = __umul24(I2, P1);
+    mom[18][k] = __umul24(I0, P2); mom[19][k] = __umul24(I1, P2); mom[20][k] = __umul24(I2, P2);
+  }
+  __syncthreads();
+  const int seg = threadIdx.x & 31, pg = threadIdx.x >> 5;        // 8 plane groups x 32 segments
+  const int x0 = seg * GF_SEG;
+  if (x0 >= cw) return;
+  for (int pl = pg; pl < 21; pl += 8) {
+    const unsigned* row = mom[pl];
+    unsigned s = 0;
+    for (int k = 0; k <= 2 * RR; ++k) s += row[GF_ROW(x0 + k)];
+    float o[GF_SEG];
+    o[0] = (float)s;
+#pragma unroll
+    for (int j = 1; j < GF_SEG; ++j) {
+      // (past the chunk's end the LDS row holds no pixel: clamp the index, the value is dropped below)
+      s += row[GF_ROW(min(x0 + j + 2 * RR, cw + 2 * RR - 1))] - row[GF_ROW(x0 + j - 1)];
+      o[j] = (float)s;
+    }
+    float* op = out + ((int64_t)b * 21 + pl) * P + (int64_t)y * W + xc0 + x0;
+    if (x0 + GF_SEG <= cw && (W & 3) == 0) {
+#pragma unroll
+      for (int j = 0; j < GF_SEG; j += 4) *(float4*)(op + j) = make_float4(o[j], o[j + 1], o[j + 2], o[j + 3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < GF_SEG; ++j)
+        if (x0 + j < cw) op[j] = o[j];
+    }
+  }
+}
+
+// V pass of stage 1 + the per-pixel 3x3 solve: a thread owns one column x and GF_VSEG output rows; the 21 column sums slide in
+// uint32 (exact), every output row is solved at once: hs [B][21][P] (exact integer row sums) -> ab [B][12][P].
+template <int RR>
+__global__ __launch_bounds__(256) void gf_v1_solve_slide_kernel(const float* __restrict__ hs, float* __restrict__ ab, int H, int W,
+                                                                float eps) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= W) return;
+  const int y0 = blockIdx.y * GF_VSEG, b = blockIdx.z;
+  const int64_t P = (int64_t)H * W;
+  const float* in = hs + (int64_t)b * 21 * P + x;
+  float* o = ab + (int64_t)b * 12 * P + x;
+  const float inv = 1.f / (float)((2 * RR + 1) * (2 * RR + 1));
+  unsigned s[21];
+#pragma unroll
+  for (int pl = 0; pl < 21; ++pl) s[pl] = 0;
+  for (int k = -RR; k <= RR; ++k) {
+    const int64_t ro = (int64_t)reflect_idx(y0 + k, H) * W;
+#pragma unroll
+    for (int pl = 0; pl < 21; ++pl) s[pl] += (unsigned)in[pl * P + ro];
+  }
+  const int y1 = min(y0 + GF_VSEG, H);
+  for (int y = y0; y < y1; ++y) {
+    float m[21];
+#pragma unroll
+    for (int pl = 0; pl < 21; ++pl) m[pl] = (float)s[pl] * inv;
+    const float mI0 = m[0], mI1 = m[1], mI2 = m[2];
+    const float a00 = m[6] - mI0 * mI0 + eps, a01 = m[7] - mI0 * mI1, a02 = m[8] - mI0 * mI2;
+    const float a11 = m[9] - mI1 * mI1 + eps, a12 = m[10] - mI1 * mI2, a22 = m[11] - mI2 * mI2 + eps;
+    const float c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+    const float c11 = a00 * a22 - a02 * a02, c12 = a02 * a01 - a00 * a12, c22 = a00 * a11 - a01 * a01;
+    const float det = a00 * c00 + a01 * c01 + a02 * c02;
+    const float i00 = c00 / det, i01 = c01 / det, i02 = c02 / det, i11 = c11 / det, i12 = c12 / det, i22 = c22 / det;
+    const int64_t po = (int64_t)y * W;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float mp_c = m[3 + c];
+      const float cp0 = m[12 + c * 3 + 0] - mI0 * mp_c, cp1 = m[12 + c * 3 + 1] - mI1 * mp_c, cp2 = m[12 + c * 3 + 2] - mI2 * mp_c;
+      const float A0 = i00 * cp0 + i01 * cp1 + i02 * cp2;
+      const float A1 = i01 * cp0 + i11 * cp1 + i12 * cp2;
+      const float A2 = i02 * cp0 + i12 * cp1 + i22 * cp2;
+      const float bb = mp_c - A0 * mI0 - A1 * mI1 - A2 * mI2;
+      o[(c * 4 + 0) * P + po] = A0; o[(c * 4 + 1) * P + po] = A1; o[(c * 4 + 2) * P + po] = A2; o[(c * 4 + 3) * P + po] = bb;
+    }
+    if (y + 1 < y1) {
+      const int64_t rin = (int64_t)reflect_idx(y + 1 + RR, H) * W, rout = (int64_t)reflect_idx(y - RR, H) * W;
+#pragma unroll
+      for (int pl = 0; pl < 21; ++pl) s[pl] += (unsigned)in[pl * P + rin] - (unsigned)in[pl * P + rout];
+    }
+  }
+}
+
+// H pass of stage 2 (12 float planes): grid (H, column chunks, B), 128 threads = 4 plane groups x 32 segments; the chunk's 12 rows
+// are staged at once.
+template <int RR>
+__global__ __launch_bounds__(128) void gf_h2_slide_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W) {
+  __shared__ float rows[12][GF_HROWLEN];
+  const int y = blockIdx.x, xc0 = blockIdx.y * GF_HCW, b = blockIdx.z;
+  const int cw = min(GF_HCW, W - xc0);
+  const int64_t P = (int64_t)H * W;
+  {
+    const float* ip = in + (int64_t)b * 12 * P + (int64_t)y * W;
+    for (int i = threadIdx.x; i < cw + 2 * RR; i += 128) {       // the 12 planes' loads of a pixel go out together
+      const int x = reflect_idx(xc0 + i - RR, W);
+      float v[12];
+#pragma unroll
+      for (int pl = 0; pl < 12; ++pl) v[pl] = ip[pl * P + x];
+#pragma unroll
+      for (int pl = 0; pl < 12; ++pl) rows[pl][GF_ROW(i)] = v[pl];
+    }
+  }
+  __syncthreads();
+  const int seg = threadIdx.x & 31, pg = threadIdx.x >> 5;
+  const int x0 = seg * GF_SEG;
+  if (x0 >= cw) return;
+  for (int pl = pg; pl < 12; pl += 4) {
+    const float* row = rows[pl];
+    float s = 0.f;
+    for (int k = 0; k <= 2 * RR; ++k) s += row[GF_ROW(x0 + k)];
+    float o[GF_SEG];
+    o[0] = s;
+#pragma unroll
+    for (int j = 1; j < GF_SEG; ++j) {
+      s += row[GF_ROW(min(x0 + j + 2 * RR, cw + 2 * RR - 1))] - row[GF_ROW(x0 + j - 1)];
+      o[j] = s;
+    }
+    float* op = out + ((int64_t)b * 12 + pl) * P + (int64_t)y * W + xc0 + x0;
+    if (x0 + GF_SEG <= cw && (W & 3) == 0) {
+#pragma unroll
+      for (int j = 0; j < GF_SEG; j += 4) *(float4*)(op + j) = make_float4(o[j], o[j + 1], o[j + 2], o[j + 3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < GF_SEG; ++j)
+        if (x0 + j < cw) op[j] = o[j];
+    }
+  }
+}
+
+// final V pass: a thread owns one column and GF_VSEG rows; 12 sliding float column sums, combination with the guide, rounding.
+template <int RR>
+__global__ __launch_bounds__(256) void gf_v2_final_slide_kernel(const float* __restrict__ hs, const unsigned char* __restrict__ guide,
+                                                                float* __restrict__ out, unsigned char* __restrict__ out_u8, int H, int W) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= W) return;
+  const int y0 = blockIdx.y * GF_VSEG, b = blockIdx.z;
+  const int64_t P = (int64_t)H * W;
+  const float* in = hs + (int64_t)b * 12 * P + x;
+  const float inv = 1.f / (float)((2 * RR + 1) * (2 * RR + 1));
+  float s[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = 0.f;
+  for (int k = -RR; k <= RR; ++k) {
+    const int64_t ro = (int64_t)reflect_idx(y0 + k, H) * W;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] += in[i * P + ro];
+  }
+  const int y1 = min(y0 + GF_VSEG, H);
+  for (int y = y0; y < y1; ++y) {
+    const unsigned char* g = guide + (((int64_t)b * H + y) * W + x) * 3;
+    const float I0 = g[0], I1 = g[1], I2 = g[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float qv = (s[c * 4] * inv) * I0 + (s[c * 4 + 1] * inv) * I1 + (s[c * 4 + 2] * inv) * I2 + s[c * 4 + 3] * inv;
+      const float rq = fminf(fmaxf(rintf(qv), 0.f), 255.f);
+      if (out_u8) out_u8[(((int64_t)b * H + y) * W + x) * 3 + c] = (unsigned char)rq;
+      if (out) out[((int64_t)b * 3 + c) * P + (int64_t)y * W + x] = (rq / 255.0f - 0.5f) * 2.f;  // ToTensor, (x-0.5)*2 (ppst_model.py:301-303)
+    }
+    if (y + 1 < y1) {
+      const int64_t rin = (int64_t)reflect_idx(y + 1 + RR, H) * W, rout = (int64_t)reflect_idx(y - RR, H) * W;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) s[i] += in[i * P + rin] - in[i * P + rout];
+    }
+  }
+}
+
 extern "C" int64_t ppst_guided_filter_ws(int B, int H, int W) { return (int64_t)B * 42 * H * W * (int64_t)sizeof(float); }
 
 extern "C" int ppst_guided_filter(const void* guide_u8, const void* src_u8, void* out, void* out_u8, int B, int H, int W, int r,
@@ -195,6 +401,17 @@ extern "C" int ppst_guided_filter(const void* guide_u8, const void* src_u8, void
   const unsigned char* s = (const unsigned char*)src_u8;
   auto blocks_for = [](int64_t total) { int64_t b = cdiv64(total, 256); return (unsigned)(b > 256 * 32 ? 256 * 32 : b); };
   int e;
+  if (r == 30) {       // the path's radius (photo_gif.py:43): sliding-window passes (round 4)
+    PPST_LAUNCH(gf_h1_slide_kernel<30>, dim3(H, cdiv(W, GF_HCW), B), dim3(256), 0, st, g, s, bufA, H, W);
+    if ((e = PPST_LAUNCH_CHECK())) return e;
+    PPST_LAUNCH(gf_v1_solve_slide_kernel<30>, dim3(cdiv(W, 256), cdiv(H, GF_VSEG), B), dim3(256), 0, st, (const float*)bufA, bufB, H, W, eps);
+    if ((e = PPST_LAUNCH_CHECK())) return e;
+    PPST_LAUNCH(gf_h2_slide_kernel<30>, dim3(H, cdiv(W, GF_HCW), B), dim3(128), 0, st, (const float*)bufB, bufA, H, W);
+    if ((e = PPST_LAUNCH_CHECK())) return e;
+    PPST_LAUNCH(gf_v2_final_slide_kernel<30>, dim3(cdiv(W, 256), cdiv(H, GF_VSEG), B), dim3(256), 0, st, (const float*)bufA, g, (float*)out,
+                (unsigned char*)out_u8, H, W);
+    return PPST_LAUNCH_CHECK();
+  }
   PPST_LAUNCH(gf_h_kernel<true>, dim3(H, 21, B), dim3(256), 0, st, g, s, (const float*)nullptr, bufA, H, W, r, 21);
   if ((e = PPST_LAUNCH_CHECK())) return e;
   int64_t t21 = (int64_t)B * 21 * P;
