@@ -91,9 +91,15 @@ __device__ __forceinline__ int wino_lane() {
 }
 
 // INMODE: normalise on load -- 0 off, 1 affine only (in_act none: the StyledConv conv2 case), 2 affine + activation
-template <int INMODE>
-__global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
+// FAT: four waves (ONE per SIMD, up to 512 registers) instead of eight: a wave takes a transform position with all 128 channels
+// (wave tile 128 pairs x 128 ch, 256 accumulator registers), reads every A fragment ONCE per K-step (16 ds_read_b128 per 192 MFMAs
+// instead of 32 per 96 ... reloaded half a step ahead) and has no SIMD
+// partner running the same program phase.
+template <int INMODE, bool FAT>
+__global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 1 : 2) void conv_wino_kernel(WinoKArgs a) {
   constexpr bool INSS = INMODE != 0;
+  constexpr int NWV = FAT ? 4 : 8, NTH = 64 * NWV, NTW = FAT ? 8 : 4;      // waves, threads, n-tiles per wave
+  constexpr int NRND = FAT ? 5 : 3;                                        // halo rows a wave stages per chunk: wave + NWV * round
   constexpr int NP = 8, HH = 18;
   constexpr int PLANE = HH * NP * 16;      // one k-group plane of one transform position: 2304 B (a multiple of 256)
   constexpr int XIB = 8 * PLANE;           // hi g0..3 | lo g0..3
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
   const int ty0 = tyi * 16, tx0 = txi * 16;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int xi = wave >> 1, nh = wave & 1;
+  const int xi = FAT ? wave : wave >> 1, nh = FAT ? 0 : wave & 1;
   const int r16 = lane & 15, g = lane >> 4;
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -131,7 +137,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
 #endif
   StepPtr steps = (StepPtr)a.steps;
   const int nchunk = a.nchunk, nsteps = nchunk * 3;
-  const float* xb = a.x + (int64_t)b * a.in_h * a.in_w * a.in_ld;
+  const int64_t xoff_ = (int64_t)b * a.in_h * a.in_w * a.in_ld;
+  const float* xb = a.x + (((int64_t)__builtin_amdgcn_readfirstlane((int)(xoff_ >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)xoff_));
 
   // ---- activation staging.  A wave-instruction covers ONE halo row: lane = (k-group sg: 8 channels) x (se) x (pixel pair sp, lowest bits).
   // The two lanes of a pair split the four PIXELS, not the channels: the even lane loads d0 and d2, the odd lane d3 and d1 (8
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
   int colA, colB;
   bool okA, okB;
   {
-    auto col = [&](int k, bool& ok) {
+    auto col = [&](int k, bool& ok) __attribute__((always_inline)) {
       int ix = tx0 + 2 * sp - 1 + k;
       ok = (ix >= 0 && ix < a.in_w) || a.pad_mode != PPST_PAD_ZERO;
       ix = wino_pad_index(ix, a.in_w, a.pad_mode);
@@ -156,12 +163,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
     colB = col(se ? 1 : 2, okB);
   }
   const bool interior = a.pad_mode != PPST_PAD_ZERO || (ty0 >= 1 && ty0 + 16 < a.in_h && tx0 >= 1 && tx0 + 16 < a.in_w);
-  // the three halo rows this wave stages per chunk: wave, wave + 8, wave + 16; waves 2..7 have no third row: they request zeros
-  // (no branch around a load: see the loop) and skip the arithmetic and the stores
-  int rowoff[3];
+  // the halo rows this wave stages per chunk: wave + NWV * round (eight waves: three rounds, four waves: five); waves >= 2 have no
+  // last row: they request row 0 (no branch around a load: see the loop) and skip the arithmetic and the stores
+  int rowoff[NRND];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int hrow = wave + 8 * r;
+  for (int r = 0; r < NRND; ++r) {
+    const int hrow = wave + NWV * r;
     int iy = ty0 + hrow - 1;
     const bool inb = iy >= 0 && iy < a.in_h;
     int o = -1;
@@ -177,9 +184,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
   // (0.2, sqrt 2) leaky ReLU, (slope, 1) PReLU -- the same operations as conv_mfma.hip's three-way form, element for element
   const float in_neg = !INSS ? 1.f : a.in_act == PPST_ACT_LRELU ? 0.2f : a.in_act == PPST_ACT_PRELU ? in_slope : 1.f;
   const float in_pos = (INSS && a.in_act == PPST_ACT_LRELU) ? 1.41421356237309515f : 1.f;
-  auto in_act = [&](float t) -> float { return (t > 0.f ? t : t * in_neg) * in_pos; };
+  auto in_act = [&](float t) __attribute__((always_inline)) -> float { return (t > 0.f ? t : t * in_neg) * in_pos; };
   float4 rd[4];                                       // A ch 0-3, A ch 4-7, B ch 0-3, B ch 4-7
-  auto stage_load = [&](float4 (&q)[4], int r, int chan) {      // r compile-time after unrolling; chan wave-uniform
+  auto stage_load = [&](float4 (&q)[4], int r, int chan) __attribute__((always_inline)) {      // r compile-time after unrolling; chan wave-uniform
     // a halo row outside the image under zero padding (rowoff < 0; wave-uniform) is requested at row 0 -- in bounds, ONE address
     // register pair for all rows -- and zeroed in stage_prep
     const int so = (rowoff[r] >= 0 ? rowoff[r] : 0) + chan * 4;
@@ -191,16 +198,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
     q[2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vb, so, 0));
     q[3] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vb, so + 16, 0));
   };
-  auto stage_skip = [&](int r) { return r == 2 && wave >= 2; };     // (wave-uniform; LDS stores only behind it)
+  auto stage_skip = [&](int r) __attribute__((always_inline)) { return r == NRND - 1 && wave >= 2; };     // (wave-uniform; LDS stores only behind it)
   // normalise on load: (a, s) of the lane's 8 channels from the block's LDS copy of the image's table (a global load here sat in
   // front of its own use: one L2 round trip per row in the middle of the MFMA stream, 3.14 instead of 2.4 ms on 128 -> 128 @512^2)
   const int chan_first = steps[0].x;
-  auto stage_prep = [&](float4 (&q)[4], int r, int chan, int part) {   // part 0: channels 0-3 of A and B, part 1: channels 4-7
+  auto stage_prep = [&](float4 (&q)[4], int r, int chan, int part) __attribute__((always_inline)) {   // part 0: channels 0-3 of A and B, part 1: channels 4-7
     const bool rowok = rowoff[r] >= 0;
     if (INSS) {
       const float4* p = (const float4*)((const unsigned char*)ss_lds + (chan - chan_first) * 8 + (wino_lane() >> 4) * 64) + part * 2;
       const float4 s0 = p[0], s1 = p[1];
-      auto nact = [&](float t) -> float { return INMODE == 2 ? in_act(t) : t; };
+      auto nact = [&](float t) __attribute__((always_inline)) -> float { return INMODE == 2 ? in_act(t) : t; };
       if (interior) {      // (wave-uniform: no padding item in this block's halo -- or a padding mode that has none: no masks)
 #pragma unroll
         for (int h = part; h < 4; h += 2) {
@@ -233,8 +240,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
   };
   // piece 0: A - B -> position 0 (se = 0) / 3 (se = 1); piece 1: B(partner) + sgn B -> position 1 / 2.  The 8 lanes of a
   // ds_write_b128 group are the 8 pairs of one (se, sg): 128 contiguous bytes of one plane.
-  auto stage_put = [&](float4 (&q)[4], int r, int slot, int piece) {
-    const int hrow = wave + 8 * r;
+  auto stage_put = [&](float4 (&q)[4], int r, int slot, int piece) __attribute__((always_inline)) {
+    const int hrow = wave + NWV * r;
     const float4 A0 = q[0], A1 = q[1], B0_ = q[2], B1_ = q[3];
     float4 V0, V1;
     int i;
@@ -266,10 +273,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
   };
 
   // ---- weight fragments: this wave's stream [step][n-tile 0..3][hi | lo][lane][16 B], straight into registers
-  const unsigned char* wbase = a.wpack + ((((int64_t)ntile * 4 + xi) * 2 + nh) * nsteps) * WINO_STEP_BYTES;
-  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, nsteps * WINO_STEP_BYTES, 0x00020000);
+  // (block- and wave-uniform, but computed with vector divisions: say so, or every load through it becomes a waterfall loop)
+  const int64_t woff_ = ((((int64_t)ntile * 4 + xi) * 2 + nh) * nsteps) * WINO_STEP_BYTES;
+  const unsigned char* wbase = a.wpack + (((int64_t)__builtin_amdgcn_readfirstlane((int)(woff_ >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)woff_));
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, (FAT ? 2 : 1) * nsteps * WINO_STEP_BYTES, 0x00020000);
   bf16x8 B0[2][2], B1[2][2];      // [n-tile of the half][hi, lo]
-  auto load_b = [&](bf16x8 (&dst)[2][2], int s, int half) {
+  auto load_b = [&](bf16x8 (&dst)[2][2], int s, int half) __attribute__((always_inline)) {
 #ifdef WINO_ABL_NOB
     if (s > 0) return;
 #endif
@@ -282,37 +292,134 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
         dst[n][h] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lo16 + (n * 2 + h) * 1024, so, 0));
   };
 
-  // ---- prologue: every request of the block's first chunk goes out at once (weight fragments of step 0, the three halo rows,
-  // the (a, s) table) -- the accumulators are not live yet, so three row register sets fit -- then chunk 0 is staged into slot 0
-  load_b(B0, 0, 0);
-  load_b(B1, 0, 1);
+  // (FAT) both halves of a step as one set of eight n-tiles; two sets: the next step's is requested at the top of this one
+  bf16x8 BxA[FAT ? 4 : 1][2], BxB[FAT ? 4 : 1][2];       // (FAT) n-tiles 0-3 / 4-7: each reloaded for the next step behind its half
+  auto load_b4 = [&](bf16x8 (&dst)[FAT ? 4 : 1][2], int st_, int half) __attribute__((always_inline)) {
+    if (!FAT) return;
+#ifdef WINO_ABL_NOB
+    if (st_ > 0) return;
+#endif
+    // (the pack keeps the two channel halves of a position as two streams of steps: n-tiles 4..7 come from the second)
+    const int so = st_ * WINO_STEP_BYTES + half * nsteps * WINO_STEP_BYTES;
+    const int lo16 = wino_lane() * 16;
+#pragma unroll
+    for (int n = 0; n < (FAT ? 4 : 1); ++n)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        dst[n][h] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lo16 + (n * 2 + h) * 1024, so, 0));
+  };
+
+  // ---- prologue: every request of the block's first chunk goes out at once (weight fragments of step 0, the halo rows, the
+  // (a, s) table) -- the accumulators are not live yet, so several row register sets fit -- then chunk 0 is staged into slot 0
+  if (FAT) { load_b4(BxA, 0, 0); load_b4(BxB, 0, 1); }
+  else { load_b(B0, 0, 0); load_b(B1, 0, 1); }
   {
-    float4 q1[4], q2[4];
-    stage_load(rd, 0, chan_first);
-    stage_load(q1, 1, chan_first);
-    stage_load(q2, 2, chan_first);
+    float4 q[NRND][4];
+#pragma unroll
+    for (int r = 0; r < NRND; ++r) stage_load(q[r], r, chan_first);
     if (INSS) {
       const float* src = a.in_ss + ((int64_t)b * a.in_c + chan_first) * 2;
-      for (int i = tid * 4; i < nchunk * 64; i += 512 * 4) *(float4*)(ss_lds + i) = *(const float4*)(src + i);
+      for (int i = tid * 4; i < nchunk * 64; i += NTH * 4) *(float4*)(ss_lds + i) = *(const float4*)(src + i);
       __syncthreads();
     }
-    stage_prep(rd, 0, chan_first, 0); stage_prep(rd, 0, chan_first, 1);
-    stage_put(rd, 0, 0, 0); stage_put(rd, 0, 0, 1);
-    stage_prep(q1, 1, chan_first, 0); stage_prep(q1, 1, chan_first, 1);
-    stage_put(q1, 1, 0, 0); stage_put(q1, 1, 0, 1);
-    if (!stage_skip(2)) {
-      stage_prep(q2, 2, chan_first, 0); stage_prep(q2, 2, chan_first, 1);
-      stage_put(q2, 2, 0, 0); stage_put(q2, 2, 0, 1);
+#pragma unroll
+    for (int r = 0; r < NRND; ++r) {
+      if (!stage_skip(r)) {
+        stage_prep(q[r], r, chan_first, 0); stage_prep(q[r], r, chan_first, 1);
+        stage_put(q[r], r, 0, 0); stage_put(q[r], r, 0, 1);
+      }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-  f32x4 acc[8][4];
+  f32x4 acc[8][NTW];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+#define WA_OFF(slot, dy, mt) ((slot) * ABUF + xi * XIB + g * PLANE + ((2 * (mt) + (dy)) * NP + r16) * 16)
+  int s = 0;
+  if constexpr (FAT) {
+    // One wave per SIMD: the step is ONE stream of 192 MFMAs (8 m-tiles x 8 n-tiles x 3) with everything else in its gaps -- per
+    // m-tile one A fragment request (pinned one m-tile ahead), and the two halo rows of the step transformed piecewise between
+    // the m-tiles.  The next step's weight fragments (16 KB) go out at the top of the step into the other register set.
+    float4 rd2[4];
+    bf16x8 ah, al;
+    int slot = 0, chan_next = 0, aoff0 = 0;
+    // one K-step = two halves (n-tiles 0-3 with set A, 4-7 with set B): 96 MFMAs each; a set is reloaded for the next step right
+    // behind its half, i.e. half a step (~1.5 k cycles) ahead of its use.  The step's two halo rows are transformed piecewise
+    // between the m-tiles: round r0 in the first half, r1 in the second.
+    auto step_fat = [&](auto dy_c) __attribute__((always_inline)) {
+      constexpr int dy = decltype(dy_c)::value;
+      const int sn = s + 1 < nsteps ? s + 1 : s;
+      constexpr int r0 = 2 * dy, r1 = dy < 2 ? 2 * dy + 1 : 0;
+      stage_load(rd, r0, chan_next);
+      if (dy < 2) stage_load(rd2, r1, chan_next);
+      __builtin_amdgcn_sched_barrier(0);
+      const bool skip0 = stage_skip(r0);
+      int aoff1 = aoff0;
+      asm volatile("" : "+v"(aoff1));
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+          bf16x8 nh_ = ah, nl_ = al;
+          if (mt < 7) {
+            WINO_LDA(nh_, (half ? aoff1 : aoff0) + (2 * (mt + 1) + dy) * NP * 16, ah);
+            WINO_LDA(nl_, (half ? aoff1 : aoff0) + (2 * (mt + 1) + dy) * NP * 16 + 4 * PLANE, al);
+          } else if (half == 0) {
+            WINO_LDA(nh_, aoff1 + dy * NP * 16, ah);
+            WINO_LDA(nl_, aoff1 + dy * NP * 16 + 4 * PLANE, al);
+          } else if (dy < 2) {
+            WINO_LDA(nh_, aoff0 + (dy + 1) * NP * 16, ah);
+            WINO_LDA(nl_, aoff0 + (dy + 1) * NP * 16 + 4 * PLANE, al);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (half == 0 && !skip0) {
+            if (mt == 3) stage_prep(rd, r0, chan_next, 0);
+            if (mt == 4) stage_prep(rd, r0, chan_next, 1);
+            if (mt == 5) stage_put(rd, r0, slot ^ 1, 0);
+            if (mt == 6) stage_put(rd, r0, slot ^ 1, 1);
+          }
+          if (half == 1 && dy < 2) {                        // (rounds 1 and 3 exist for every wave)
+            if (mt == 1) stage_prep(rd2, r1, chan_next, 0);
+            if (mt == 2) stage_prep(rd2, r1, chan_next, 1);
+            if (mt == 3) stage_put(rd2, r1, slot ^ 1, 0);
+            if (mt == 4) stage_put(rd2, r1, slot ^ 1, 1);
+          }
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            if (half == 0) {
+              WINO_MFMA(al, BxA[n][0], acc[mt][n]);
+              WINO_MFMA(ah, BxA[n][1], acc[mt][n]);
+              WINO_MFMA(ah, BxA[n][0], acc[mt][n]);
+            } else {
+              WINO_MFMA(al, BxB[n][0], acc[mt][4 + n]);
+              WINO_MFMA(ah, BxB[n][1], acc[mt][4 + n]);
+              WINO_MFMA(ah, BxB[n][0], acc[mt][4 + n]);
+            }
+          }
+          ah = nh_;
+          al = nl_;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (half == 0) load_b4(BxA, sn, 0); else load_b4(BxB, sn, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ++s;
+    };
+    auto chunk_fat = [&](int c) __attribute__((always_inline)) {
+      slot = c & 1;
+      chan_next = steps[(c + 1 < nchunk ? c + 1 : c) * 9].x;
+      aoff0 = WA_OFF(slot, 0, 0);
+      ah = *(const bf16x8*)(smem + aoff0);
+      al = *(const bf16x8*)(smem + aoff0 + 4 * PLANE);
+      step_fat(EpiC<0>{}); step_fat(EpiC<1>{}); step_fat(EpiC<2>{});
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    for (int c = 0; c < nchunk; ++c) chunk_fat(c);
+  } else {
   // A fragment of m-tile mt (tile rows 2 mt, 2 mt + 1; 8 pairs each) for tap row dy: halo rows 2 mt + dy, 2 mt + dy + 1.
   //
   // Every vector-memory instruction of the loop is UNCONDITIONAL (the last step re-requests its own weight fragments, the last
@@ -322,8 +429,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
   // request to just before its first use and waits at once -- zero prefetch distance (~1.6 k cycles of s_waitcnt per step and
   // wave by counter).  The staged row's two transform pieces sit between m-tiles of the second half, free to interleave with
   // that m-tile's six MFMAs.
-#define WA_OFF(slot, dy, mt) ((slot) * ABUF + xi * XIB + g * PLANE + ((2 * (mt) + (dy)) * NP + r16) * 16)
-  int s = 0;
   for (int c = 0; c < nchunk; ++c) {
     const int slot = c & 1;
     const bool more = c + 1 < nchunk;
@@ -409,6 +514,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
   }
+  }
 #undef WA_OFF
 
   // ---- output transform + epilogue: four passes of 4 tile rows (two m-tiles) x all 128 channels.  In a pass EVERY wave puts
@@ -420,7 +526,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
   const int act = a.act & 0xff;
   const bool res_after = (a.act >> 8) & 1;
   const float slope = (act == PPST_ACT_PRELU && a.prelu) ? a.prelu[0] : 0.f;
-  const int f32_ = tid & 31, mloc = tid >> 5;        // mloc 0..15 (+16 it): pass-local pair row; channels 4 f32_ .. +3
+  constexpr int NML = NTH / 32, NIT = 32 / NML;      // pass-local pair rows covered per item round; item rounds per pass
+  const int f32_ = tid & 31, mloc = tid >> 5;        // mloc 0..NML-1 (+NML it): pass-local pair row; channels 4 f32_ .. +3
   const int n0 = ntile * 128 + f32_ * 4;
   const bool nok = n0 < a.cout;
   const int64_t img = (int64_t)b * a.in_h * a.in_w;
@@ -430,22 +537,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
   // pass ph, item it: pair row m = 32 ph + 16 it + mloc -> tile row m >> 3, pair m & 7
   // bias and noise fetched before the first store (vmcnt counts stores and retires in order: conv_mfma.hip)
   const float4 bv = (nok && a.bias) ? *(const float4*)(a.bias + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
-  float nzv[16];
+  float nzv[8 * NIT];
   if (nzb) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int m = 32 * (i >> 2) + 16 * ((i >> 1) & 1) + mloc;
+    for (int i = 0; i < 8 * NIT; ++i) {
+      const int m = 32 * (i / (2 * NIT)) + NML * ((i >> 1) % NIT) + mloc;
       const int oy = ty0 + (m >> 3), ox = tx0 + 2 * (m & 7) + (i & 1);
       nzv[i] = (oy < a.in_h && ox < a.in_w) ? a.noise_weight * nzb[oy * a.in_w + ox] : 0.f;
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) nzv[i] = 0.f;
+    for (int i = 0; i < 8 * NIT; ++i) nzv[i] = 0.f;
   }
   float4 s1a = make_float4(0.f, 0.f, 0.f, 0.f), s2a = s1a;
   const int resm = a.residual ? (res_after ? 2 : 1) : 0;
   constexpr int TROW2 = 132, TXI2 = 32 * TROW2, TBUF2 = 4 * TXI2;     // floats: 67584 B per buffer
-  auto epi_passes = [&](auto act_c) {
+  auto epi_passes = [&](auto act_c) __attribute__((always_inline)) {
 #pragma clang fp contract(off)   // no fused multiply-add here: every kernel family's epilogue rounds alike
     const int ACT = act_c.value;
 #pragma unroll
@@ -454,14 +561,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
 #pragma unroll
       for (int ml = 0; ml < 2; ++ml)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
           for (int j = 0; j < 4; ++j) tw[(ml * 16 + g * 4 + j) * TROW2 + nt * 16] = acc[ph * 2 + ml][nt][j];
       __syncthreads();
       const float* tr = T + (ph & 1) * TBUF2 + f32_ * 4;
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int ml_ = it * 16 + mloc, m = ph * 32 + ml_;
+      for (int it = 0; it < NIT; ++it) {
+        const int ml_ = it * NML + mloc, m = ph * 32 + ml_;
         const float4 v0 = *(const float4*)(tr + 0 * TXI2 + ml_ * TROW2), v1 = *(const float4*)(tr + 1 * TXI2 + ml_ * TROW2);
         const float4 v2 = *(const float4*)(tr + 2 * TXI2 + ml_ * TROW2), v3 = *(const float4*)(tr + 3 * TXI2 + ml_ * TROW2);
         const int oy = ty0 + (m >> 3), ox0 = tx0 + 2 * (m & 7);
@@ -472,7 +579,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
             if (px == 0) { o[0] = (v0.x + v1.x) + v2.x; o[1] = (v0.y + v1.y) + v2.y; o[2] = (v0.z + v1.z) + v2.z; o[3] = (v0.w + v1.w) + v2.w; }
             else         { o[0] = (v1.x - v2.x) + v3.x; o[1] = (v1.y - v2.y) + v3.y; o[2] = (v1.z - v2.z) + v3.z; o[3] = (v1.w - v2.w) + v3.w; }
             const int pix = oy * a.in_w + ox0 + px;
-            const float nz = nzv[ph * 4 + it * 2 + px];
+            const float nz = nzv[ph * 2 * NIT + it * 2 + px];
             float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (resm) rv = *(const float4*)(rb + (pix * a.res_ld + n0));
             const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
@@ -498,7 +605,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    for (int j = 0; j < NTW; ++j) asm volatile("" ::"v"(acc[i][j]));
   if (a.B < 0)
 #endif
   if (act == PPST_ACT_LRELU) epi_passes(EpiC<PPST_ACT_LRELU>{});
@@ -521,7 +628,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoKArgs a) {
       if (n < a.cout) {
         float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) { t0 += red[(w * 128 + tid) * 2]; t1 += red[(w * 128 + tid) * 2 + 1]; }
+        for (int w = 0; w < NWV; ++w) { t0 += red[(w * 128 + tid) * 2]; t1 += red[(w * 128 + tid) * 2 + 1]; }
         float* o = a.stats + ((((int64_t)b * a.tiles_y + tyi) * a.tiles_x + txi) * a.cout + n) * 2;
         o[0] = t0;
         o[1] = t1;
@@ -544,9 +651,15 @@ int ppst_conv_wino_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int
   k.in_ss = (const float*)a->in_scale_shift; k.in_prelu = (const float*)a->in_prelu;
   k.in_c = a->in_c; k.in_act = a->in_act;
   const int blocks = n_tiles * a->B * tiles_y * tiles_x;
-  if (k.in_ss && k.in_act != PPST_ACT_NONE) PPST_LAUNCH((conv_wino_kernel<2>), dim3(blocks), dim3(512), 0, st, k);
-  else if (k.in_ss) PPST_LAUNCH((conv_wino_kernel<1>), dim3(blocks), dim3(512), 0, st, k);
-  else PPST_LAUNCH((conv_wino_kernel<0>), dim3(blocks), dim3(512), 0, st, k);
+#ifdef WINO_FAT
+  if (k.in_ss && k.in_act != PPST_ACT_NONE) PPST_LAUNCH((conv_wino_kernel<2, true>), dim3(blocks), dim3(256), 0, st, k);
+  else if (k.in_ss) PPST_LAUNCH((conv_wino_kernel<1, true>), dim3(blocks), dim3(256), 0, st, k);
+  else PPST_LAUNCH((conv_wino_kernel<0, true>), dim3(blocks), dim3(256), 0, st, k);
+#else
+  if (k.in_ss && k.in_act != PPST_ACT_NONE) PPST_LAUNCH((conv_wino_kernel<2, false>), dim3(blocks), dim3(512), 0, st, k);
+  else if (k.in_ss) PPST_LAUNCH((conv_wino_kernel<1, false>), dim3(blocks), dim3(512), 0, st, k);
+  else PPST_LAUNCH((conv_wino_kernel<0, false>), dim3(blocks), dim3(512), 0, st, k);
+#endif
   return PPST_LAUNCH_CHECK();
 }
 
