@@ -113,6 +113,11 @@ typedef struct ppst_conv_step {
  *           w[n][src_c .. src_c+31][src_ky][src_kx]
  *  bn       64, 128 or 256 = N tile of the kernel variant that will consume the blob
  *  out      n_groups * ceil(cout/bn) * nsteps * (precision==0 ? 8 : 4) * bn * 8 bf16 */
+/* The same for ppst_conv_args.dual_b: bn = 256 = two column phases x 128 channels of N tile t (channels 128 t ..); src_kx[i] holds
+ * (kx of phase 0) | (kx of phase 1) << 8.  out: n_groups * ceil(cout/128) * nsteps * (precision==0 ? 8 : 4) * 256 * 8 bf16. */
+int ppst_conv_pack_dual(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx, float scale, int cout,
+                        const int32_t* src_c, const int32_t* src_ky, const int32_t* src_kx, int nsteps, int n_groups,
+                        int precision, void* out, void* stream);
 int ppst_conv_pack(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx,
                    float scale, int cout, int bn,
                    const int32_t* src_c, const int32_t* src_ky, const int32_t* src_kx,
@@ -131,6 +136,7 @@ typedef struct ppst_pack_job {
   int64_t block0;
   float scale;
   int32_t cout, bn, nsteps, n_groups, x3, f16, nblocks;   /* x3: precision 0 (hi + lo planes); f16: precision 3 / 4 */
+  int32_t dual;               /* 1: ppst_conv_pack_dual semantics (the N tile holds two output column phases) */
 } ppst_pack_job;
 typedef struct ppst_upscale_job {
   const void* w;
@@ -229,6 +235,12 @@ typedef struct ppst_conv_args {
                                     [hi x 8 | lo x 8] bf16 (ppst_presplit), same pixel stride in_ld -- and the activation tile is
                                     staged by LDS-DMA.  variant 0, bn 128, halo 1, precision 0, no in_scale_shift, every chunk of
                                     the step table >= 4 steps (the caller's promise, like early_a). */
+  int32_t dual_b;                /* 1 (variant 2, bn 256, n_groups 2, halo 1, precision 0, out_sy = out_sx = 2): the fused 4x4 stride-2
+                                    upscale (stylegan2_layers.py:312-321) with Cout % 128 == 0 as TWO row phases whose N tile of 256
+                                    is [column phase 0: 128 channels | column phase 1: 128 channels] -- wpack from
+                                    ppst_conv_pack_dual, steps[i].dx = (dx of phase 0 + 1) | (dx of phase 1 + 1) << 8.  The
+                                    activation tile is staged once for two phases and the layer runs on the 128 x 64 wave
+                                    tiles; outputs bit-identical to the four-group form, stats [B][4 * tiles][cout][2] as there. */
 } ppst_conv_args;
 
 int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream);

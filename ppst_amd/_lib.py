@@ -32,7 +32,7 @@ class PackJob(ctypes.Structure):
     """ppst_pack_job (include/ppst_hip.h)."""
     _fields_ = [("w", vp), ("sn", i64), ("sc", i64), ("sy", i64), ("sx", i64), ("src_c", vp), ("src_ky", vp), ("src_kx", vp),
                 ("out", vp), ("total", i64), ("block0", i64), ("scale", f32), ("cout", i32), ("bn", i32), ("nsteps", i32),
-                ("n_groups", i32), ("x3", i32), ("f16", i32), ("nblocks", i32)]
+                ("n_groups", i32), ("x3", i32), ("f16", i32), ("nblocks", i32), ("dual", i32)]
 
 
 class UpscaleJob(ctypes.Structure):
@@ -52,7 +52,7 @@ class ConvArgs(ctypes.Structure):
         ("in_off_y", i32), ("in_off_x", i32), ("out_sy", i32), ("out_sx", i32),
         ("act", i32), ("precision", i32), ("res_ld", i32), ("tile_h", i32), ("tile_w", i32),
         ("halo", i32), ("bn", i32), ("in_scale_shift", vp), ("in_prelu", vp), ("in_c", i32), ("in_act", i32),
-        ("flop_steps", i32), ("tile_rows", i32), ("a_slots", i32), ("early_a", i32), ("variant", i32), ("in_presplit", i32),
+        ("flop_steps", i32), ("tile_rows", i32), ("a_slots", i32), ("early_a", i32), ("variant", i32), ("in_presplit", i32), ("dual_b", i32),
     ]
 
 
@@ -66,6 +66,7 @@ _SIGS = {
     "ppst_conv_pack": (i32, [vp, i64, i64, i64, i64, f32, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp]),
     "ppst_conv_pack_wino_bytes": (i64, [i32, i32]),
     "ppst_conv_pack_wino": (i32, [vp, i64, i64, i64, i64, f32, i32, i32, vp, vp]),
+    "ppst_conv_pack_dual": (i32, [vp, i64, i64, i64, i64, f32, i32, vp, vp, vp, i32, i32, i32, vp, vp]),
     "ppst_upscale_weight": (i32, [vp, vp, i32, i32, f32, vp]),
     "ppst_pack_job_blocks": (i32, [i64]),
     "ppst_conv_pack_batch": (i32, [vp, i32, i32, vp]),

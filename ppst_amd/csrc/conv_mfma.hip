@@ -724,11 +724,13 @@ struct PackJob {            // == ppst_pack_job of include/ppst_hip.h
   int64_t block0;           // first block of this job inside a batched launch
   float scale;
   int cout, bn, nsteps, n_groups, x3, f16, nblocks;
+  int dual;                 // the N tile is [column phase 0 | column phase 1] x bn / 2 channels: src_kx = kx0 | kx1 << 8
 };
 __device__ __forceinline__ void pack_item(const PackJob& j, int64_t t) {
   const float* __restrict__ w = j.w;
   const int bn = j.bn, nsteps = j.nsteps, cout = j.cout;
-  const int n_tiles = (cout + bn - 1) / bn;
+  const int bnc = j.dual ? bn / 2 : bn;            // channels per N tile
+  const int n_tiles = (cout + bnc - 1) / bnc;
   const int npl = j.x3 ? 8 : 4;
   int nl = (int)(t % bn);
   int64_t r = t / bn;
@@ -736,9 +738,10 @@ __device__ __forceinline__ void pack_item(const PackJob& j, int64_t t) {
   int s = (int)(r % nsteps); r /= nsteps;
   int ntile = (int)(r % n_tiles);
   int group = (int)(r / n_tiles);
-  int n = ntile * bn + nl;
+  int n = ntile * bnc + (nl % bnc);
   int gs = group * nsteps + s;
   int c0 = j.src_c[gs] + 8 * g, ky = j.src_ky[gs], kx = j.src_kx[gs];
+  if (j.dual) kx = nl < bnc ? (kx & 0xff) : (kx >> 8);
   unsigned short hi[8], lo[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -791,6 +794,20 @@ extern "C" int ppst_conv_pack(const void* w, int64_t sn, int64_t sc, int64_t sy,
   j.out = (unsigned short*)out; j.total = (int64_t)n_groups * n_tiles * nsteps * 4 * bn; j.block0 = 0; j.scale = scale;
   j.cout = cout; j.bn = bn; j.nsteps = nsteps; j.n_groups = n_groups; j.x3 = precision == 0 ? 1 : 0;
   j.f16 = (precision == 3 || precision == 4) ? 1 : 0;
+  j.dual = 0;
+  j.nblocks = pack_blocks(j.total);
+  PPST_LAUNCH(conv_pack_kernel, dim3((unsigned)j.nblocks), dim3(256), 0, as_stream(stream), j);
+  return PPST_LAUNCH_CHECK();
+}
+extern "C" int ppst_conv_pack_dual(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx, float scale, int cout,
+                                   const int32_t* src_c, const int32_t* src_ky, const int32_t* src_kx, int nsteps, int n_groups,
+                                   int precision, void* out, void* stream) {
+  if (cout <= 0 || nsteps <= 0 || n_groups != 2 || precision != 0) return PPST_EINVAL;
+  if (!w || !src_c || !src_ky || !src_kx || !out) return PPST_ENULL;
+  PackJob j;
+  j.w = (const float*)w; j.sn = sn; j.sc = sc; j.sy = sy; j.sx = sx; j.src_c = src_c; j.src_ky = src_ky; j.src_kx = src_kx;
+  j.out = (unsigned short*)out; j.total = (int64_t)n_groups * cdiv(cout, 128) * nsteps * 4 * 256; j.block0 = 0; j.scale = scale;
+  j.cout = cout; j.bn = 256; j.nsteps = nsteps; j.n_groups = n_groups; j.x3 = 1; j.f16 = 0; j.dual = 1;
   j.nblocks = pack_blocks(j.total);
   PPST_LAUNCH(conv_pack_kernel, dim3((unsigned)j.nblocks), dim3(256), 0, as_stream(stream), j);
   return PPST_LAUNCH_CHECK();
@@ -947,7 +964,9 @@ static void launch_conv(const ConvKArgs& k, int blocks, hipStream_t st) {
 extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   if (!a) return PPST_ENULL;
   if (a->B < 0 || a->in_h <= 0 || a->in_w <= 0 || a->in_ld <= 0 || a->in_ld % 4 || a->out_h <= 0 || a->out_w <= 0 ||
-      a->out_ld < a->cout || a->cout <= 0 || a->cout % 4 || a->out_ld % 4 || (a->residual && a->res_ld % 4) || a->nsteps <= 0 || (a->n_groups != 1 && a->n_groups != 4) || a->pad_mode < 0 ||
+      a->out_ld < a->cout || a->cout <= 0 || a->cout % 4 || a->out_ld % 4 || (a->residual && a->res_ld % 4) || a->nsteps <= 0 ||
+      (a->n_groups != 1 && a->n_groups != 4 && !(a->n_groups == 2 && a->dual_b)) || a->pad_mode < 0 ||
+      (a->dual_b && (a->variant != 2 || a->bn != 256 || a->n_groups != 2 || a->halo != 1 || a->precision != 0 || a->out_sy != 2 || a->out_sx != 2 || !a->early_a)) ||
       a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 ||
       (a->precision != 0 && a->precision != 1 && a->precision != 3 && a->precision != 4) || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128 && a->bn != 256) || (a->residual && a->res_ld < a->cout) ||
       a->variant < 0 || a->variant > 10 || (a->variant == 0 && a->bn == 256) ||
@@ -1009,7 +1028,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   k.in_off_y = a->in_off_y; k.in_off_x = a->in_off_x; k.out_sy = a->out_sy; k.out_sx = a->out_sx; k.act = a->act;
   k.res_ld = a->res_ld; k.tile_h = a->tile_h; k.tile_w = a->tile_w;
   k.tiles_y = cdiv(a->tile_h, a->tile_rows); k.tiles_x = cdiv(a->tile_w, 16);
-  k.n_tiles = cdiv(a->cout, a->bn);
+  k.n_tiles = cdiv(a->cout, a->dual_b ? a->bn / 2 : a->bn);
   k.in_ss = (const float*)a->in_scale_shift; k.in_prelu = (const float*)a->in_prelu;
   k.in_c = a->in_c; k.in_act = a->in_act;
   k.early_a = a->early_a ? 1 : 0;
@@ -1025,7 +1044,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   int slot = -1;
   if (g_prof_on) {
     const int inf[8] = {a->B, a->tile_h, a->tile_w, a->nsteps, a->cout, a->n_groups, a->halo, a->bn};
-    slot = ppst_prof_begin_(2.0 * 32.0 * (a->flop_steps > 0 ? a->flop_steps : a->nsteps) * (double)a->n_groups * a->cout * (double)a->B * a->tile_h * a->tile_w,
+    slot = ppst_prof_begin_(2.0 * 32.0 * (a->flop_steps > 0 ? a->flop_steps : a->nsteps) * (double)(a->dual_b ? 4 : a->n_groups) * a->cout * (double)a->B * a->tile_h * a->tile_w,
                             inf, st);
   }
   if (a->variant >= 1) {

@@ -85,7 +85,12 @@ __device__ __forceinline__ unsigned short f2h_2(float f) { return __builtin_bit_
 // MT_: m-tiles (16-pixel rows) per wave.  6 (with WMW = 4, WNW = 2, NT = 4, BDB = false, NA_ = 2): block tile 24 x 16 px x 128 ch,
 // wave tile 96 px x 64 ch (variant 9) -- the largest wave tile for Cout = 128 layers whose activation ring still has TWO slots
 // (2 x 60 KB + 32 KB of weights = 152 KB): 20 ds_read_b128 per 72 MFMAs, and the chunk store overlaps the MFMAs as in variant 2.
-template <int NT, int HALO, bool INSS, int WNW = 2, bool BDB = true, int NA_ = 2, int WMW = 2, int PREC = 0, int MT_ = 8>
+// DUAL (round 4, with WNW = 4, bn = 256): the fused upscale with Cout = 128 as TWO output-phase pairs instead of four phases -- the
+// N tile of 256 is [phase b = 0: 128 channels | phase b = 1: 128 channels] of one row phase a (= the group), N-waves 0-1 / 2-3.  A
+// step is a tap ROW dy with one tap COLUMN per b (steps[i].z = (dx_b0 + 1) | (dx_b1 + 1) << 8): every wave multiplies in every
+// step, the activation tile is staged once for two phases, and the layer runs on this kernel's 128 x 64 wave tiles instead of
+// the tile kernel's 64 x 64.  Per output element the MFMA sequence is the tile kernel's (dy-major taps): bit-identical outputs.
+template <int NT, int HALO, bool INSS, int WNW = 2, bool BDB = true, int NA_ = 2, int WMW = 2, int PREC = 0, int MT_ = 8, bool DUAL = false>
 __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW == 8 || NA_ == 1) ? 2 : 1)) void conv_mfma2_kernel(Conv2KArgs a) {
   constexpr bool X3 = PREC == 0;
   constexpr int NWV = WMW * WNW;                          // waves per block
@@ -224,6 +229,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   // fragment addresses
 #define B_ADDR(slot, nt) (smB + (slot) * BBUF + g * BPLANE + ((wn * NT + (nt)) * 16 + r16) * 16)
 #define A_OFF(slot, dy, dx, mt) ((slot) * ABUF + g * PLANE + (((wm * MT + (mt) + HALO + (dy)) * HW + HALO + (dx) + r16) * 16))
+#define DXW(z) (DUAL ? ((((z) >> (wn >= WNW / 2 ? 8 : 0)) & 0xff) - 1) : (z))   /* this wave's tap column of the step */
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -233,14 +239,14 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
 
   // ---- prologue: steps 0 and 1 staged, descriptors of step 2 fetched
   int4 d = steps[0];
-  int dy0 = d.y, dx0 = d.z, sl0 = 0;
-  int dy1 = d.y, dx1 = d.z, sl1 = 0;
+  int dy0 = d.y, dx0 = DXW(d.z), sl0 = 0;
+  int dy1 = d.y, dx1 = DXW(d.z), sl1 = 0;
   a_load(d.x);
   b_dma(0, 0);
   a_store(0);
   if (a.nsteps > 1) {
     d = steps[1];
-    dy1 = d.y; dx1 = d.z;
+    dy1 = d.y; dx1 = DXW(d.z);
     sl1 = (d.w & 1) ? 1 : 0;
     b_dma(1, 1);
     if (d.w & 1) a_load(d.x);
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
     TR2_FLUSH(s, newA2)                                                                                       \
     freshA = storeA; pendA = newA2;                                                                           \
     dy0 = dy1; dx0 = dx1; sl0 = sl1;                                                                          \
-    if (has2) { dy1 = D2.y; dx1 = D2.z; }                                                                     \
+    if (has2) { dy1 = D2.y; dx1 = DXW(D2.z); }                                                                \
     sl1 = sl2;                                                                                                \
   }
   int s = 0;
@@ -381,10 +387,13 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   }
 #undef STEP2
 #undef A_OFF
+#undef DXW
 #undef B_ADDR
 
   // ---- epilogue (as conv_mfma.hip): per wave, passes of 64 pixels x 32 channels through an LDS transposition tile
-  const int gy = group >> 1, gx = group & 1;
+  const int gy = DUAL ? group : group >> 1, gx = DUAL ? wn / (WNW / 2) : group & 1;   // output row / column phase
+  constexpr int BNC = DUAL ? BN / 2 : BN;                                              // channels per N tile
+  const int nw0 = DUAL ? (wn % (WNW / 2)) * (16 * NT) : wn * (16 * NT);               // this wave's first channel in the N tile
   const int act = a.act & 0xff;
   const bool res_after = (a.act >> 8) & 1;
   const float slope = (act == PPST_ACT_PRELU && a.prelu) ? a.prelu[0] : 0.f;
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   float* red = (float*)smem + NWV * EPI_TILE;          // [2 (wm)][BN][2]
   const int f8 = lane & 7, prow = lane >> 3;
   // output addressing as in conv_mfma.hip: 32-bit element offsets inside image b, row / column-half strides wave-uniform
-  const int egy = a.n_groups > 1 ? gy : 0, egx = a.n_groups > 1 ? gx : 0;
+  const int egy = a.n_groups > 1 ? gy : 0, egx = a.n_groups > 1 ? gx : 0;   // (DUAL: n_groups = 2)
   const int tyb = ty0 + wm * MT, oyb = tyb * a.out_sy + egy;
   const int txl = tx0 + prow, oxl = txl * a.out_sx + egx;
   const bool okx0 = txl < a.tile_w && oxl < a.out_w, okx1 = txl + 8 < a.tile_w && oxl + 8 * a.out_sx < a.out_w;
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   }
 #pragma unroll
   for (int pass = 0; pass < NT / 2; ++pass) {
-    const int n0 = ntile * BN + wn * (16 * NT) + pass * 32 + f8 * 4;
+    const int n0 = ntile * BNC + nw0 + pass * 32 + f8 * 4;
     bva[pass] = (n0 < a.cout && a.bias) ? *(const float4*)(a.bias + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float4 s1a[NT / 2], s2a[NT / 2];
@@ -438,8 +447,8 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
             if (mt < MG) tw[(mt * 16 + g * 4 + j) * 36 + ntl * 16 + r16] = acc[mh * 4 + mt < MT ? mh * 4 + mt : 0][pass * 2 + ntl][j];
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_wave_barrier();
-      const int nl0 = wn * (16 * NT) + pass * 32 + f8 * 4;
-      const int n0 = ntile * BN + nl0;
+      const int nl0 = nw0 + pass * 32 + f8 * 4;
+      const int n0 = ntile * BNC + nl0;
       const bool nok = n0 < a.cout;
       const float4 bv = bva[pass];
       const int yo0 = pix0 * a.out_ld + n0, ro0 = pix0 * a.res_ld + n0;
@@ -508,9 +517,11 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
     __syncthreads();
     const int tiles = a.tiles_y * a.tiles_x;
     for (int nl = tid; nl < BN; nl += NTH) {
-      int n = ntile * BN + nl;
+      // (DUAL: the N tile is two column phases of BNC channels; the partial slots are the four phases' of the 4-group form)
+      const int n = DUAL ? ntile * BNC + (nl % BNC) : ntile * BN + nl;
+      const int og = DUAL ? group * 2 + nl / BNC : group, ogn = DUAL ? 4 : a.n_groups;
       if (n < a.cout) {
-        float* o = a.stats + ((((int64_t)b * a.n_groups + group) * tiles + tyi * a.tiles_x + txi) * a.cout + n) * 2;
+        float* o = a.stats + ((((int64_t)b * ogn + og) * tiles + tyi * a.tiles_x + txi) * a.cout + n) * 2;
         float t0 = red[nl * 2], t1 = red[nl * 2 + 1];
 #pragma unroll
         for (int w = 1; w < WMW; ++w) { t0 += red[(w * BN + nl) * 2]; t1 += red[(w * BN + nl) * 2 + 1]; }
@@ -570,6 +581,10 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
     if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 4, false, 2, 2, PREC_>), dim3(blocks), dim3(512), 0, st, k);   \
     else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 4, false, 2, 2, PREC_>), dim3(blocks), dim3(512), 0, st, k);          \
   } while (0)
+  if (a->variant == 2 && a->dual_b) {     // Cout = 128 fused upscale as two phase pairs (halo 1, precision 0, no normalise-on-load needed twice: both built)
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, 1, true, 4, false, 2, 2, 0, 8, true>), dim3(blocks), dim3(512), 0, st, k);
+    else PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 4, false, 2, 2, 0, 8, true>), dim3(blocks), dim3(512), 0, st, k);
+  } else
   if (a->variant == 2 && a->precision == 1) { if (a->halo) L2P(1, 1); else L2P(0, 1); }
   else if (a->variant == 2 && a->precision == 3) { if (a->halo) L2P(1, 3); else L2P(0, 3); }
   else if (a->variant == 2) {            // 8 waves, wave tile 128 px x 64 ch, N tile 256: the production form

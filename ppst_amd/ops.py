@@ -28,6 +28,9 @@ TILE_ROWS = {"value": 16}  # conv tile rows: 8 (2 blocks per CU) or 16 (1 block 
 # 128 px x 64 ch wave tiles and a 256-channel N tile (conv_mfma2.hip, WNW = 4): bit-identical to the 64x64-wave-tile kernel
 # and 10-16 % faster on those layers (256->256 @256^2 459 vs 417 TFLOP/s, 512->512 @128^2 494 vs 440).
 CONV_VARIANT = {"value": 2}
+# the fused upscale with Cout % 128 == 0 (and not % 256: those run the N-256 kernel as four phases) as two phase pairs on the N-256
+# kernel (ppst_conv_args.dual_b): 256 -> 128 up 2 was the slowest StyledConv layer on the tile kernel (0.42 of the ceiling)
+DUAL_CONVT = {"value": True, "min_blocks": 32}
 DIRECT_MAX = {"cout": 64, "nsteps": 40, "cout3x3": 64}   # cout3x3 = 128 was measured: 128->128 @512^2 230 vs 357 TFLOP/s
 # thin layers (few channels in and out) on the direct form of that kernel
 WGRAD_SPLIT = {"blocks": 1024, "min_tiles": 4}   # conv_wgrad: target block count of a launch, fewest pixel tiles per block
@@ -220,7 +223,7 @@ class ConvPlan:
     _GEOMETRY = {}
     _GEOM_ATTRS = ("kind", "cout", "cin", "k", "bn", "n_groups", "halo", "src", "max_chan", "wstrides", "nsteps", "flop_steps",
                    "early_a", "ksplit_ok", "steps", "src_dev", "chunk_start", "chunks_per_group", "w4_shape", "max_chunk_steps",
-                   "min_chunk_steps", "full_cover")
+                   "min_chunk_steps", "full_cover", "steps_dual", "src_dual")
 
     def __init__(self, weight, kind="conv", scale=1.0, chan_base=0, precision=None):
         _chk(weight, "weight")
@@ -318,6 +321,20 @@ class ConvPlan:
                                 src.append((32 * c, ky, kx))
                                 first = False
             sn, sc, sy, sx = 16, cout * 16, 4, 1
+            if cout % 128 == 0 and chan_base % 1 == 0:
+                # the same conv as TWO row phases whose N tile holds both column phases (ppst_conv_args.dual_b): a step is a tap row
+                # dy with one tap column per column phase -- the per-element tap order stays (dy major), outputs bit-identical
+                dsteps, dsrc = [], []
+                for a in range(2):
+                    for c in range(nchunk):
+                        first = True
+                        for dy, ky in taps[a]:
+                            for j in range(2):
+                                (dx0, kx0), (dx1, kx1) = taps[0][j], taps[1][j]
+                                dsteps.append((chan_base + 32 * c, dy, (dx0 + 1) | ((dx1 + 1) << 8), 1 if first else 0))
+                                dsrc.append((32 * c, ky, kx0 | (kx1 << 8)))
+                                first = False
+                self._dual_tmp = (dsteps, dsrc)
         elif kind == "dgrad":
             # input gradient of a stride-1 conv (zero padding): a conv of dY with the transposed,
             # flipped weights  Wd[c][n][ky][kx] = W[n][c][k-1-ky][k-1-kx]  -- same memory, other strides
@@ -405,16 +422,19 @@ class ConvPlan:
         # flags: bit 0 = this step opens a chunk; bit 1 = the NEXT step of the group opens one, bits 8.. = its channel
         # offset (lets the kernel request a chunk's activations a step early when every chunk spans >= 2 steps)
         ns_ = self.nsteps
-        enc = []
-        chunk_idx = -1
-        for i, (c_, dy_, dx_, f_) in enumerate(steps):
-            if i % ns_ == 0:
-                chunk_idx = -1                   # the chunk count restarts with every group
-            chunk_idx += 1 if f_ else 0
-            nxt = steps[i + 1] if (i + 1) % ns_ != 0 else None
-            # bit 2 = parity of this step's chunk index within its group (the activation-ring slot of conv_ksplit.hip)
-            w_ = f_ | ((2 | (nxt[0] << 8)) if (nxt is not None and nxt[3]) else 0) | ((chunk_idx & 1) << 2)
-            enc.append((c_, dy_, dx_, w_))
+
+        def encode(steps_):
+            enc, chunk_idx = [], -1
+            for i, (c_, dy_, dx_, f_) in enumerate(steps_):
+                if i % ns_ == 0:
+                    chunk_idx = -1                   # the chunk count restarts with every group
+                chunk_idx += 1 if f_ else 0
+                nxt = steps_[i + 1] if (i + 1) % ns_ != 0 else None
+                # bit 2 = parity of this step's chunk index within its group (the activation-ring slot of conv_ksplit.hip)
+                w_ = f_ | ((2 | (nxt[0] << 8)) if (nxt is not None and nxt[3]) else 0) | ((chunk_idx & 1) << 2)
+                enc.append((c_, dy_, dx_, w_))
+            return enc
+        enc = encode(steps)
         starts = [i for i, t in enumerate(steps) if t[3] == 1] + [len(steps)]
         lens = [b_ - a_ for a_, b_ in zip(starts[:-1], starts[1:])]
         self.early_a = 1 if (min(lens) >= 2 and ns_ >= 3) else 0
@@ -424,6 +444,12 @@ class ConvPlan:
         self.ksplit_ok = bool(self.early_a and all(l_ >= 3 or (a_ % ns_) % 2 == 0 for a_, l_ in zip(starts[:-1], lens)))
         # 4 padding rows: the kernel prefetches the descriptor of step s+3 without a bounds test
         self.steps = torch.tensor(enc + [(0, 0, 0, 0)] * 4, dtype=torch.int32, device=dev).contiguous()
+        self.steps_dual = self.src_dual = None
+        dual = self.__dict__.pop("_dual_tmp", None)
+        if dual is not None:
+            self.steps_dual = torch.tensor(encode(dual[0]) + [(0, 0, 0, 0)] * 4, dtype=torch.int32, device=dev).contiguous()
+            sd_ = torch.tensor(dual[1], dtype=torch.int32, device=dev)
+            self.src_dual = (sd_[:, 0].contiguous(), sd_[:, 1].contiguous(), sd_[:, 2].contiguous())
         s = torch.tensor(src, dtype=torch.int32, device=dev)
         src_c, src_ky, src_kx = s[:, 0].contiguous(), s[:, 1].contiguous(), s[:, 2].contiguous()
         self.src_dev = (src_c, src_ky, src_kx)
@@ -453,6 +479,20 @@ class ConvPlan:
         check(lib.ppst_conv_pack(_p(self.wsrc), sn, sc, sy, sx, float(self.scale), cout, bn, _p(src_c), _p(src_ky), _p(src_kx),
                                  self.nsteps, self.n_groups, self.precision, _p(wpack), _stream()), "ppst_conv_pack")
         self._packs[bn] = wpack
+        return wpack
+
+    def pack_dual(self):
+        """weights for ppst_conv_args.dual_b (ppst_conv_pack_dual), built on first use."""
+        hit = self._packs.get("dual")
+        if hit is not None:
+            return hit
+        sn, sc, sy, sx = self.wstrides
+        c_, ky_, kx_ = self.src_dual
+        n_tiles = (self.cout + 127) // 128
+        wpack = torch.empty(2 * n_tiles * self.nsteps * 8 * 256 * 8, dtype=torch.int16, device=self.steps.device)
+        check(lib.ppst_conv_pack_dual(_p(self.wsrc), sn, sc, sy, sx, float(self.scale), self.cout, _p(c_), _p(ky_), _p(kx_),
+                                      self.nsteps, 2, 0, _p(wpack), _stream()), "ppst_conv_pack_dual")
+        self._packs["dual"] = wpack
         return wpack
 
     def pack_wino(self):
@@ -494,6 +534,10 @@ class ConvPlan:
         cv = CONV_VARIANT["value"]
         if cv in (1, 3) or TWO_BLOCK_128["value"] or KSPLIT_128["value"] or TILE24_128["value"] or TALL_TILE_128["value"]:
             _need_experiments("the requested conv variant")
+        if (DUAL_CONVT["value"] and self.kind == "convT" and self.precision == 0 and getattr(self, "steps_dual", None) is not None
+                and self.cout % 256 != 0 and CONV_VARIANT["value"] == 2 and self.early_a
+                and ((th + 15) // 16) * ((tw + 15) // 16) * 2 * (self.cout // 128) >= DUAL_CONVT["min_blocks"]):
+            return "dual", 256, 16
         n256_ok = self.cout % 256 == 0 and tiles16 * (self.cout // 256) >= FAT_MIN_BLOCKS
         aware = BATCH_AWARE["value"] and B is not None and not single and self.bn == 128 and self.early_a and self.halo == 1
         if aware and n256_ok and tiles16 * (self.cout // 256) * B < BATCH_AWARE["fill"]:
@@ -574,16 +618,20 @@ class ConvPlan:
             tiles = lib.ppst_conv_tiles(th, tw, rows)
             st = torch.empty((B, self.n_groups * tiles, self.cout, 2), device=x.device, dtype=torch.float32)
         a = _lib.ConvArgs()
-        wp = None if self.precision == 2 else (self.pack_wino() if variant == 10 else self.pack_for(bn))
-        a.x, a.wpack, a.steps, a.y = _p(x), _p(wp), _p(self.steps), _p(out)
+        dual = variant == "dual"
+        if dual:
+            variant = 2
+        wp = None if self.precision == 2 else (self.pack_wino() if variant == 10 else self.pack_dual() if dual else self.pack_for(bn))
+        a.x, a.wpack, a.steps, a.y = _p(x), _p(wp), _p(self.steps_dual if dual else self.steps), _p(out)
         a.variant = variant
+        a.dual_b = 1 if dual else 0
         a.bias, a.noise, a.prelu, a.stats = _p(bias), _p(noise), _p(prelu), _p(st)
         a.residual = _p(residual)
         a.res_ld = _nhwc_ld(residual, "residual") if residual is not None else 0
         a.noise_weight, a.out_scale = float(noise_weight), float(out_scale)
         a.B, a.in_h, a.in_w, a.in_ld = B, H, W, in_ld
         a.out_h, a.out_w, a.out_ld, a.cout = oh, ow, out_ld, self.cout
-        a.nsteps, a.n_groups, a.pad_mode = self.nsteps, self.n_groups, pad_mode
+        a.nsteps, a.n_groups, a.pad_mode = self.nsteps, (2 if dual else self.n_groups), pad_mode
         a.in_off_y = a.in_off_x = 0
         a.out_sy = a.out_sx = osy
         a.act, a.precision = act | (0x100 if res_after_act else 0), self.precision
@@ -630,10 +678,15 @@ def repack_plans(plans):
             if bn == "wino":                     # variant-10 pack: its own transform kernel, one launch per plan
                 wino.append((pl.wsrc, pl.wstrides, float(pl.scale), pl.cout, pl.cin, wpack))
                 continue
+            if bn == "dual":                     # two-phase-pair pack of the fused upscale: a job of the batched pack kernel
+                dc, dky, dkx = pl.src_dual
+                pk.append((pl.wsrc.data_ptr(), sn, sc, sy, sx, dc.data_ptr(), dky.data_ptr(), dkx.data_ptr(), wpack.data_ptr(),
+                           2 * ((pl.cout + 127) // 128) * pl.nsteps * 4 * 256, float(pl.scale), pl.cout, 256, pl.nsteps, 2, 1, 0, 1))
+                continue
             n_tiles = (pl.cout + bn - 1) // bn
             pk.append((pl.wsrc.data_ptr(), sn, sc, sy, sx, c_.data_ptr(), ky_.data_ptr(), kx_.data_ptr(), wpack.data_ptr(),
                        pl.n_groups * n_tiles * pl.nsteps * 4 * bn, float(pl.scale), pl.cout, bn, pl.nsteps, pl.n_groups,
-                       1 if pl.precision == 0 else 0, 1 if pl.precision in (3, 4) else 0))
+                       1 if pl.precision == 0 else 0, 1 if pl.precision in (3, 4) else 0, 0))
     dev = plans[0].steps.device if plans else None
 
     def table(cls, rows, fill):
@@ -654,7 +707,7 @@ def repack_plans(plans):
 
     def fill_pk(j, r):
         (j.w, j.sn, j.sc, j.sy, j.sx, j.src_c, j.src_ky, j.src_kx, j.out, j.total, j.scale, j.cout, j.bn, j.nsteps, j.n_groups,
-         j.x3, j.f16) = r
+         j.x3, j.f16, j.dual) = r
         return j.total
     tu, nbu = table(_lib.UpscaleJob, up, fill_up)
     tp, nbp = table(_lib.PackJob, pk, fill_pk)

@@ -316,12 +316,12 @@ def direct_kernels_only(fn):
 
     @functools.wraps(fn)
     def wrapped(*a, **k):
-        prev = ops.WINO["value"]
-        ops.WINO["value"] = False
+        prev = ops.WINO["value"], ops.DUAL_CONVT["value"]
+        ops.WINO["value"] = ops.DUAL_CONVT["value"] = False
         try:
             return fn(*a, **k)
         finally:
-            ops.WINO["value"] = prev
+            ops.WINO["value"], ops.DUAL_CONVT["value"] = prev
     return wrapped
 
 
@@ -488,6 +488,42 @@ def t_conv_wino():
         print("wino batch shard bit-identical                              %s" % ("ok" if torch.equal(ya, y2[1:3]) else "FAIL"), flush=True)
     finally:
         ops.WINO.update(prev)
+
+
+def t_conv_dual():
+    """The fused 4x4 stride-2 upscale with Cout % 128 == 0 as two phase pairs on the N-256 kernel (ppst_conv_args.dual_b) against
+    the four-group tile-kernel form of the same plan: the per-element MFMA sequence is the same, so outputs are bit-identical;
+    tile statistics to rounding; and against float64 torch."""
+    torch.manual_seed(9)
+    prev = dict(ops.DUAL_CONVT)
+    try:
+        for name, B, ci, co, H, Wd, feat in [("convT 64->128 40x24 full", 2, 64, 128, 40, 24, "full"), ("convT 256->128 64x64 plain", 1, 256, 128, 64, 64, "plain"),
+                                             ("convT 128->384 17x33 inss (ragged)", 2, 128, 384, 17, 33, "inss"), ("convT 32->128 16x16 res", 1, 32, 128, 16, 16, "res")]:
+            w = g(torch.randn(co, ci, 3, 3) / math.sqrt(ci * 9))
+            x = g(torch.randn(B, H, Wd, ci))
+            kw = {}
+            if feat == "full":
+                kw = dict(bias=g(torch.randn(co)), noise=g(torch.randn(B, 1, 2 * H, 2 * Wd)), noise_weight=0.3, act=ops.ACT_LRELU)
+            elif feat == "inss":
+                kw = dict(in_ss=g(torch.rand(B, ci, 2) + 0.5), in_act=ops.ACT_PRELU, in_prelu=g(torch.tensor([0.25])))
+            elif feat == "res":
+                kw = dict(residual=g(torch.randn(B, 2 * H, 2 * Wd, co)), res_after_act=True, act=ops.ACT_LRELU, out_scale=0.7)
+            outs = []
+            for on in (False, True):
+                ops.DUAL_CONVT.update(value=on, min_blocks=0)
+                plan = ops.ConvPlan(w, kind="convT")
+                assert (plan.choose_kernel(H, Wd, 2 * H, 2 * Wd, H, Wd, 2)[0] == "dual") == on
+                y, st = plan(x, stats=True, **kw)
+                outs.append((y.cpu(), st.sum(1).cpu(), st.shape))
+            ok = bool(torch.equal(outs[0][0], outs[1][0])) and outs[0][2] == outs[1][2]
+            RES.append(("dual-phase upscale %s bit-identical to the four-group form" % name, ok))
+            print("dual convT %-44s %s max diff %.3e" % (name, "ok  " if ok else "FAIL", (outs[0][0] - outs[1][0]).abs().max().item()), flush=True)
+            report("dual convT %s stats" % name, outs[1][1], outs[0][1], 1e-5)
+            if feat == "plain":
+                ref = conv_ref(nchw(x.cpu()).double(), w.cpu().double(), "convT", 0)
+                report("dual convT %s vs float64" % name, nchw(outs[1][0]), ref, 3e-5)
+    finally:
+        ops.DUAL_CONVT.update(prev)
 
 
 @direct_kernels_only

@@ -340,6 +340,31 @@ def test_conv_kernel_choice_is_a_function_of_one_image():
         p.precision, p.early_a, p.bn = precision, early_a, (128 if cout >= 128 else 64)
         return p
     ck = lambda p, s, osy=1, out=None: p.choose_kernel(s, s, *(out or (s, s)), s, s, osy)
+    # round 4: plain 3x3 stride-1 layers with Cout >= 128 run the Winograd kernel (variant 10) when one image gives >= 16 blocks,
+    # whatever the batch; the fused upscale with Cout = 128 runs the N-256 kernel as two phase pairs ("dual")
+    assert ops.WINO["value"] and ops.DUAL_CONVT["value"]
+    assert ck(plan("conv", 256, 256, 3, 72, 1), 256) == (10, 128, 16) and ck(plan("conv", 128, 128, 3, 36, 1), 512) == (10, 128, 16)
+    assert ck(plan("conv", 256, 256, 3, 72, 1), 64) == (10, 128, 16)             # 16 tiles x 2 N tiles per image
+    assert ck(plan("conv", 128, 128, 3, 36, 1), 32) == (0, 128, 16)              # 4 blocks per image: stays direct
+    assert ck(plan("dgrad", 256, 128, 3, 72, 1), 128) == (10, 128, 16)           # the input gradient of a 3x3 conv is one too
+    assert ck(plan("conv", 128, 64, 3, 36, 1), 512)[0] != 10 and ck(plan("conv", 256, 256, 3, 72, 1, precision=3), 256)[0] != 10
+    assert ck(plan("s2d", 64, 128, 3, 20, 1), 128)[0] != 10 and ck(plan("convT", 512, 256, 3, 64, 1, n_groups=4), 128, osy=2, out=(256, 256))[0] != 10
+    for B in (1, 2, 16):
+        assert plan("conv", 256, 256, 3, 72, 1).choose_kernel(64, 64, 64, 64, 64, 64, 1, B) == (10, 128, 16)
+    pd = plan("convT", 256, 128, 3, 32, 1, n_groups=4)
+    pd.steps_dual = object()
+    assert ck(pd, 256, osy=2, out=(512, 512)) == ("dual", 256, 16)
+    assert ck(pd, 32, osy=2, out=(64, 64)) == (0, 128, 16)                        # 8 blocks per image: the four-group tile kernel
+    # the DIRECT kernels' table (what runs with the two switches off, and what the bit-identity tests compare)
+    wino_prev, dual_prev = ops.WINO["value"], ops.DUAL_CONVT["value"]
+    ops.WINO["value"] = ops.DUAL_CONVT["value"] = False
+    try:
+        _direct_kernel_table(ops, plan, ck)
+    finally:
+        ops.WINO["value"], ops.DUAL_CONVT["value"] = wino_prev, dual_prev
+
+
+def _direct_kernel_table(ops, plan, ck):
     # the generator's wide layers: N-256 tile where one image still gives >= 32 blocks
     assert ck(plan("conv", 256, 256, 3, 72, 1), 256) == (2, 256, 16)
     assert ck(plan("conv", 512, 512, 3, 144, 1), 128) == (2, 256, 16)
