@@ -19,6 +19,10 @@ EXPERIMENTS = os.environ.get("PPST_EXPERIMENTS") == "1"
 SOURCES = ["upfirdn2d.hip", "fused_bias_act.hip", "elementwise.hip", "linear.hip", "conv_mfma.hip", "conv_mfma2.hip", "conv1x1.hip", "conv_wino.hip", "conv_f32.hip",
            "corr.hip", "guided_filter.hip", "train.hip", "train_g.hip", "imageio.hip", "smooth_filter.hip"] + (["conv_ksplit.hip"] if EXPERIMENTS else [])
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"] + (["-DPPST_EXPERIMENTS"] if EXPERIMENTS else [])
+# per-file flags.  conv_wino.hip: its staging arithmetic runs inside the MFMA stream and the kernel sits at 256 registers -- with SLP
+# vectorisation hipcc packs it into v_pk_* (operand pairs assembled with moves, 1 100 packed instructions, spills in the
+# normalise-on-load + activation build); without it: no spills, same speed
+FILE_FLAGS = {"conv_wino.hip": ["-fno-slp-vectorize"]}
 MODE_STAMP = os.path.join(HERE, ".libmode")       # flavour of the built library (git-ignored, travels with the .so)
 
 
@@ -79,7 +83,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
         if not force and not _stale(obj, [os.path.join(CSRC, src)] + HEADERS):
             return obj                                   # this object is current: only what changed is recompiled
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))

@@ -74,6 +74,21 @@ __device__ __forceinline__ int wino_pad_index(int i, int n, int mode) {
 #define WINO_STEP_BYTES 8192   // one wave's weight fragments of one K-step: 4 n-tiles x (hi | lo) x 64 lanes x 16 B
 #define WINO_OOB ((int)0x80000000)   // buffer-load offset of a padding item: out of range of every image (< 2^31 bytes) -> zeros
 
+// split_bf16x4 (common.h) with the residual formed by scalar subtractions: packed fp32 arithmetic beside MFMAs costs more than two
+// plain instructions (microarch guide), and this kernel's staging runs in the MFMA stream.  Same conversions, same subtraction:
+// bit-identical to split_bf16x4.
+__device__ __forceinline__ void wino_split4(float4 v, uint2& hi, uint2& lo) {
+#ifdef WINO_PK_SPLIT
+  split_bf16x4(v, hi, lo);
+#else
+  const unsigned h0 = f2bf_pk((ppst_f2){v.x, v.y}), h1 = f2bf_pk((ppst_f2){v.z, v.w});
+  const float rx = v.x - __uint_as_float(h0 << 16), ry = v.y - __uint_as_float(h0 & 0xffff0000u);
+  const float rz = v.z - __uint_as_float(h1 << 16), rw = v.w - __uint_as_float(h1 & 0xffff0000u);
+  hi = make_uint2(h0, h1);
+  lo = make_uint2(f2bf_pk((ppst_f2){rx, ry}), f2bf_pk((ppst_f2){rz, rw}));
+#endif
+}
+
 // the value of lane ^ 8 (row_ror:8 -- a rotation by 8 inside each row of 16 lanes); hipcc folds the move into the consuming VALU
 // instruction's DPP operand
 __device__ __forceinline__ float wino_swap1(float v) {
@@ -190,7 +205,9 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 1 : 2) void conv_wino_kernel
     // a halo row outside the image under zero padding (rowoff < 0; wave-uniform) is requested at row 0 -- in bounds, ONE address
     // register pair for all rows -- and zeroed in stage_prep
     const int so = (rowoff[r] >= 0 ? rowoff[r] : 0) + chan * 4;
-    const int va = colA, vb = colB;
+    // (without normalise-on-load the kernel has the two registers per row to spare: the row's requests go out of range and come back
+    //  as zeros; with it they are requested at row 0 and zeroed by the prep's mask)
+    const int va = (INMODE == 0 && rowoff[r] < 0) ? WINO_OOB : colA, vb = (INMODE == 0 && rowoff[r] < 0) ? WINO_OOB : colB;
     // (channels 4-7: +16 bytes on the SCALAR offset -- two address registers per lane instead of four; the four spilled in
     //  the normalise-on-load build, and every scratch reload is a vector-memory operation the in-order vmcnt has to drain)
     q[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, va, so, 0));
@@ -227,15 +244,6 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 1 : 2) void conv_wino_kernel
           q[h] = v;
         }
       }
-    } else {               // (a row outside the image was requested at row 0: AND it away -- no branch in the MFMA stream)
-      const unsigned keep = rowok ? 0xffffffffu : 0u;
-#pragma unroll
-      for (int h = part; h < 4; h += 2) {
-        float4 v = q[h];
-        v.x = __uint_as_float(__float_as_uint(v.x) & keep); v.y = __uint_as_float(__float_as_uint(v.y) & keep);
-        v.z = __uint_as_float(__float_as_uint(v.z) & keep); v.w = __uint_as_float(__float_as_uint(v.w) & keep);
-        q[h] = v;
-      }
     }
   };
   // piece 0: A - B -> position 0 (se = 0) / 3 (se = 1); piece 1: B(partner) + sgn B -> position 1 / 2.  The 8 lanes of a
@@ -261,8 +269,8 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 1 : 2) void conv_wino_kernel
     return;
 #endif
     uint2 h0, l0, h1, l1;
-    split_bf16x4(V0, h0, l0);
-    split_bf16x4(V1, h1, l1);
+    wino_split4(V0, h0, l0);
+    wino_split4(V1, h1, l1);
     unsigned char* dst = smem + (slot * ABUF + hrow * NP * 16) + i * XIB + stb;
 #ifdef WINO_ABL_NOLDSW       /* the arithmetic without the LDS stores */
     asm volatile("" ::"v"(h0.x), "v"(h0.y), "v"(l0.x), "v"(l0.y), "v"(h1.x), "v"(h1.y), "v"(l1.x), "v"(l1.y));
@@ -310,7 +318,8 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 1 : 2) void conv_wino_kernel
   };
 
   // ---- prologue: every request of the block's first chunk goes out at once (weight fragments of step 0, the halo rows, the
-  // (a, s) table) -- the accumulators are not live yet, so several row register sets fit -- then chunk 0 is staged into slot 0
+  // (a, s) table) -- the accumulators are not live yet, so every row has its register set -- then chunk 0 is staged into slot 0.
+  // (Row by row with the weight request last: +-1.5 %, and the plain build then spills in its loop.)
   if (FAT) { load_b4(BxA, 0, 0); load_b4(BxB, 0, 1); }
   else { load_b(B0, 0, 0); load_b(B1, 0, 1); }
   {
