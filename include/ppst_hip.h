@@ -12,8 +12,11 @@
  *
  * Tensor layouts: "NCHW" = the reference's contiguous torch layout;
  * "NHWC" = channels-last [B][H][W][C], the internal layout of the fused path.
- * All tensors are fp32 unless stated; `dtype` arguments are reserved for
- * f16/bf16 I/O (only PPST_F32 is accepted today).
+ * All tensors are fp32 unless stated.  Activation tensors of the single-pass precision
+ * modes may be stored as IEEE half / bfloat16: the `*_st` entry points and
+ * ppst_conv_args.io_st take a storage type (PPST_ST_* below, the values of the PPST_F32 /
+ * PPST_F16 / PPST_BF16 dtype enum); the older `dtype` argument of ppst_upfirdn2d still
+ * accepts PPST_F32 only.
  */
 #ifndef PPST_HIP_H
 #define PPST_HIP_H
@@ -39,6 +42,14 @@ enum { PPST_PAD_ZERO = 0, PPST_PAD_REFLECT = 1, PPST_PAD_REPLICATE = 2 };
 enum { PPST_ACT_NONE = 0, PPST_ACT_LRELU = 1 /* lrelu(0.2)*sqrt2 */, PPST_ACT_PRELU = 2 };
 
 int ppst_version(void);
+
+/* Storage type of an NHWC activation tensor at the entry points that take one (`*_st` twins and ppst_conv_args.io_st; round 4):
+ * fp32, IEEE half or bfloat16.  A kernel given a half type computes in fp32 exactly as its fp32 form and rounds once, to nearest
+ * even, when it stores: f_st(x_half) == round(f(float(x_half))).  Leading dimensions stay in ELEMENTS; half tensors must be 8-byte
+ * aligned and have a channel count (and leading dimensions) divisible by 4.  Each `_st` twin with every type 0 IS its plain form. */
+#define PPST_ST_F32 0   /* == PPST_F32 */
+#define PPST_ST_F16 1   /* == PPST_F16 */
+#define PPST_ST_BF16 2  /* == PPST_BF16 */
 
 /* ---------------------------------------------------------------- ops ----
  * upfirdn2d_op.upfirdn2d(input[major,H,W,minor], kernel[kh,kw], up_x, up_y,
@@ -72,6 +83,9 @@ int ppst_upfirdn2d(const void* x, const void* k, void* y,
 int ppst_blur_nhwc(const void* x, const void* k, void* y, int B, int in_h, int in_w, int C,
                    int ksize, int pad0, int pad1, int pad_mode, int down, int s2d,
                    const void* in_scale_shift, int in_act, void* stream);
+int ppst_blur_nhwc_st(const void* x, const void* k, void* y, int B, int in_h, int in_w, int C,
+                      int ksize, int pad0, int pad1, int pad_mode, int down, int s2d,
+                      const void* in_scale_shift, int in_act, int st /* of x and y */, void* stream);
 
 /* fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)
  *   -- stylegan2_op/fused_bias_act.cpp:4-20, fused_bias_act_kernel.cu:19-49.
@@ -241,6 +255,12 @@ typedef struct ppst_conv_args {
                                     ppst_conv_pack_dual, steps[i].dx = (dx of phase 0 + 1) | (dx of phase 1 + 1) << 8.  The
                                     activation tile is staged once for two phases and the layer runs on the 128 x 64 wave
                                     tiles; outputs bit-identical to the four-group form, stats [B][4 * tiles][cout][2] as there. */
+  int32_t io_st;                 /* storage type of x, residual and y (PPST_ST_*): 0 fp32; PPST_ST_F16 with precision 3 / PPST_ST_BF16
+                                    with precision 1 only -- "half-precision activation storage": the generator / encoder activations
+                                    of the fp16 and bf16 modes (BASELINE configs[4] / [3]) live in HBM in the operand type of the mode.
+                                    Accumulation, bias / noise / activation, the instance-norm statistics and (a, s) of
+                                    normalise-on-load stay fp32; the output is rounded once, to nearest even, at the store.
+                                    variant 0 (tile_rows 16), 2, 4, 5, 6; pointers 8-byte aligned; in_ld / out_ld / res_ld in ELEMENTS. */
 } ppst_conv_args;
 
 int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream);
@@ -273,9 +293,14 @@ int ppst_conv_tiles(int tile_h, int tile_w, int tile_rows);
 int ppst_conv1x1_small_cin(const void* x, const void* w, const void* bias, void* y,
                            int64_t npix, int cin, int in_ld, int cout, float wscale,
                            int act, void* stream);
+int ppst_conv1x1_small_cin_st(const void* x, const void* w, const void* bias, void* y,
+                              int64_t npix, int cin, int in_ld, int cout, float wscale,
+                              int act, int y_st /* x stays fp32: the image */, void* stream);
 /* ToRGB-type conv: 1x1, Cout <= 4 (stylegan2_layers.py:487-489); y NHWC [npix][cout] */
 int ppst_conv1x1_small_cout(const void* x, const void* w, const void* bias, void* y,
                             int64_t npix, int cin, int cout, float wscale, void* stream);
+int ppst_conv1x1_small_cout_st(const void* x, const void* w, const void* bias, void* y,
+                               int64_t npix, int cin, int cout, float wscale, int x_st /* y stays fp32 */, void* stream);
 
 /* ------------------------------------------- instance norm / style mod ---
  * nn.InstanceNorm2d (eps 1e-5, biased var) + StyleMod (stylegan2_layers.py:361-374,
@@ -303,6 +328,10 @@ int ppst_affine_act(const void* x, const void* scale_shift, const void* res,
                     int res_up2_w /* >0: res is a HALF-resolution tensor, upsampled x2 bilinearly on the
                                      fly (resnet skip, generator.py:75); value = output width W */,
                     void* stream);
+/* x_st: storage of x and res; y_st: of y (either may be fp32 beside a half type; two different half types are refused) */
+int ppst_affine_act_st(const void* x, const void* scale_shift, const void* res, const void* res_scale_shift, void* y,
+                       int B, int64_t hw, int C, int x_ld, int res_ld, int y_ld, int act, const void* prelu,
+                       float out_scale, int res_up2_w, int x_st, int y_st, void* stream);
 /* ppst_affine_act that also emits the instance-norm partials of its OUTPUT (the layout
  * ppst_in_stats produces for (H, W); rep_pad as there), so the norm that follows needs no
  * read pass of its own.  C % 4 == 0. */
@@ -313,6 +342,7 @@ int ppst_affine_act_stats(const void* x, const void* scale_shift, const void* re
                           int res_up2 /* as res_up2_w, boolean */, void* stream);
 /* nearest x2 upsample NHWC (Upscale2d, stylegan2_layers.py:86-97) */
 int ppst_upsample_nearest2(const void* x, void* y, int B, int H, int W, int C, void* stream);
+int ppst_upsample_nearest2_st(const void* x, void* y, int B, int H, int W, int C, int st, void* stream); /* C % 8 == 0 for half */
 
 /* ------------------------------------------------- pooling / resizing ---- */
 /* GAP + GMP over HxW per (b,c): out [B][2C] = cat(mean, max)  (encoder_col.py:159-161).
@@ -320,6 +350,8 @@ int ppst_upsample_nearest2(const void* x, void* y, int B, int H, int W, int C, v
 int64_t ppst_gap_gmp_ws(int B, int64_t hw, int C); /* workspace bytes */
 int ppst_gap_gmp(const void* x, const void* mask, void* out, void* ws, int B, int H, int W,
                  int C, int ld, void* stream);
+int ppst_gap_gmp_st(const void* x, const void* mask, void* out, void* ws, int B, int H, int W,
+                    int C, int ld, int x_st, void* stream);
 /* integer-factor average pool (adaptive_avg_pool2d to H/f) NHWC -> dst slice */
 int ppst_avgpool(const void* x, void* y, int B, int H, int W, int C, int x_ld, int f,
                  int y_ld, void* stream);
@@ -353,6 +385,8 @@ int ppst_lerp(const void* a, const void* b, void* y, int64_t n, float r, void* s
 /* GeneratorModulation (generator.py:80-91): y[b,p,c] = x[b,p,c]*scale[b,c] + bias[b,c] */
 int ppst_spatial_modulation(const void* x, const void* scale, const void* bias, void* y,
                             int B, int64_t hw, int C, void* stream);
+int ppst_spatial_modulation_st(const void* x, const void* scale, const void* bias, void* y,
+                               int B, int64_t hw, int C, int y_st /* x (the spatial code) stays fp32 */, void* stream);
 
 /* ------------------------------------------------------ correspondence --- */
 /* PPSTModel.Rselfcorr (ppst_model.py:330-339): fea NHWC [B][H][W][C] ->

@@ -52,7 +52,7 @@ class ConvArgs(ctypes.Structure):
         ("in_off_y", i32), ("in_off_x", i32), ("out_sy", i32), ("out_sx", i32),
         ("act", i32), ("precision", i32), ("res_ld", i32), ("tile_h", i32), ("tile_w", i32),
         ("halo", i32), ("bn", i32), ("in_scale_shift", vp), ("in_prelu", vp), ("in_c", i32), ("in_act", i32),
-        ("flop_steps", i32), ("tile_rows", i32), ("a_slots", i32), ("early_a", i32), ("variant", i32), ("in_presplit", i32), ("dual_b", i32),
+        ("flop_steps", i32), ("tile_rows", i32), ("a_slots", i32), ("early_a", i32), ("variant", i32), ("in_presplit", i32), ("dual_b", i32), ("io_st", i32),
     ]
 
 
@@ -60,6 +60,7 @@ _SIGS = {
     "ppst_version": (i32, []),
     "ppst_upfirdn2d": (i32, [vp, vp, vp] + [i32] * 14 + [i32, vp]),
     "ppst_blur_nhwc": (i32, [vp, vp, vp] + [i32] * 10 + [vp, i32, vp]),
+    "ppst_blur_nhwc_st": (i32, [vp, vp, vp] + [i32] * 10 + [vp, i32, i32, vp]),
     "ppst_fused_bias_act": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, i32, vp]),
     "ppst_nchw_to_nhwc": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ppst_nhwc_to_nchw": (i32, [vp, vp, i32, i32, i32, i32, vp]),
@@ -77,14 +78,19 @@ _SIGS = {
     "ppst_conv2d_f32": (i32, [ctypes.POINTER(ConvArgs), vp, i64, i64, i64, i64, f32, vp, vp, vp, vp]),
     "ppst_conv_tiles": (i32, [i32, i32, i32]),
     "ppst_conv1x1_small_cin": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp]),
+    "ppst_conv1x1_small_cin_st": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, i32, vp]),
     "ppst_conv1x1_small_cout": (i32, [vp, vp, vp, vp, i64, i32, i32, f32, vp]),
+    "ppst_conv1x1_small_cout_st": (i32, [vp, vp, vp, vp, i64, i32, i32, f32, i32, vp]),
     "ppst_in_stats": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(i32), vp]),
     "ppst_in_finalize": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, f64, f32, vp]),
     "ppst_affine_act": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, f32, i32, vp]),
+    "ppst_affine_act_st": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, f32, i32, i32, i32, vp]),
     "ppst_affine_act_stats": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, f32, i32, i32, vp]),
     "ppst_upsample_nearest2": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ppst_upsample_nearest2_st": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ppst_gap_gmp_ws": (i64, [i32, i64, i32]),
     "ppst_gap_gmp": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ppst_gap_gmp_st": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ppst_avgpool": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ppst_bilinear": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ppst_head_tail": (i32, [vp, vp, vp, vp, vp] + [i32] * 10 + [vp]),
@@ -93,6 +99,7 @@ _SIGS = {
     "ppst_l2norm_rows": (i32, [vp, vp, i32, i32, f32, i32, vp]),
     "ppst_lerp": (i32, [vp, vp, vp, i64, f32, vp]),
     "ppst_spatial_modulation": (i32, [vp, vp, vp, vp, i32, i64, i32, vp]),
+    "ppst_spatial_modulation_st": (i32, [vp, vp, vp, vp, i32, i64, i32, i32, vp]),
     "ppst_rselfcorr": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ppst_corr_prep": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ppst_gemm_nt_f32": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp]),

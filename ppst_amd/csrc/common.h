@@ -92,6 +92,58 @@ __device__ __forceinline__ uint2 f2bf_x4(float4 v) {        // single-pass bf16:
   return make_uint2(f2bf_pk((ppst_f2){v.x, v.y}), f2bf_pk((ppst_f2){v.z, v.w}));
 }
 
+// ---- activation storage type (round 4: half-precision activation storage of precision modes 1 / 3) ------------------------
+// An NHWC activation tensor at the ABI is fp32 (PPST_ST_F32), IEEE half (PPST_ST_F16, mode 3) or bfloat16 (PPST_ST_BF16,
+// mode 1).  Kernels that take a storage type compute in fp32 exactly as their fp32 form and round ONCE, to nearest even, when
+// they store: a half-storage launch == the fp32 launch on the widened inputs, rounded (tests/gpu_diag.py t_half_storage).
+// Indices of the helpers are ELEMENT offsets (multiples of 4 for the vector forms).
+// (PPST_ST_F32 / PPST_ST_F16 / PPST_ST_BF16 = 0 / 1 / 2: include/ppst_hip.h)
+template <int ST> __device__ __forceinline__ float4 st_unpack4(uint2 u) {
+  if (ST == PPST_ST_F16) {
+    typedef _Float16 __attribute__((ext_vector_type(2))) h2;
+    const h2 a = __builtin_bit_cast(h2, u.x), b = __builtin_bit_cast(h2, u.y);
+    return make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+  }
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+template <int ST> __device__ __forceinline__ uint2 st_pack4(float4 v) {
+  if (ST == PPST_ST_F16) {
+    typedef _Float16 __attribute__((ext_vector_type(2))) h2;
+    typedef float __attribute__((ext_vector_type(2))) f2;
+    const h2 a = __builtin_convertvector((f2){v.x, v.y}, h2), b = __builtin_convertvector((f2){v.z, v.w}, h2);
+    return make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+  }
+  return f2bf_x4(v);
+}
+template <int ST> __device__ __forceinline__ float4 st_ld4(const void* base, int64_t i) {
+  if (ST == PPST_ST_F32) return *(const float4*)((const float*)base + i);
+  return st_unpack4<ST>(*(const uint2*)((const unsigned short*)base + i));
+}
+template <int ST> __device__ __forceinline__ void st_st4(void* base, int64_t i, float4 v) {
+  if (ST == PPST_ST_F32) *(float4*)((float*)base + i) = v;
+  else *(uint2*)((unsigned short*)base + i) = st_pack4<ST>(v);
+}
+template <int ST> __device__ __forceinline__ float st_ld1(const void* base, int64_t i) {
+  if (ST == PPST_ST_F32) return ((const float*)base)[i];
+  const unsigned short h = ((const unsigned short*)base)[i];
+  if (ST == PPST_ST_F16) return (float)__builtin_bit_cast(_Float16, h);
+  return bf2f(h);
+}
+template <int ST> __device__ __forceinline__ void st_st1(void* base, int64_t i, float v) {
+  if (ST == PPST_ST_F32) ((float*)base)[i] = v;
+  else if (ST == PPST_ST_F16) ((unsigned short*)base)[i] = __builtin_bit_cast(unsigned short, (_Float16)v);
+  else ((unsigned short*)base)[i] = f2bf(v);
+}
+static inline int st_bytes(int st) { return st == PPST_ST_F32 ? 4 : 2; }
+// run `BODY` with the compile-time constant ST_ = st (host-side dispatch of the templated launches)
+#define PPST_ST_SWITCH(st, BODY)                                              \
+  do {                                                                        \
+    if ((st) == PPST_ST_F16) { constexpr int ST_ = PPST_ST_F16; BODY; }       \
+    else if ((st) == PPST_ST_BF16) { constexpr int ST_ = PPST_ST_BF16; BODY; } \
+    else { constexpr int ST_ = PPST_ST_F32; BODY; }                           \
+  } while (0)
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -76,6 +76,13 @@ __device__ __forceinline__ void c1_cvt8(const float (&v)[8], bf16x8& hi, bf16x8&
   hi = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
   lo = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
 }
+// 8 stored half elements (one 16-byte load, riding in a float4) -> fp32
+template <int IOS>
+__device__ __forceinline__ void c1_unpack8(float4 r, float (&v)[8]) {
+  const float4 a = st_unpack4<IOS>(make_uint2(__float_as_uint(r.x), __float_as_uint(r.y)));
+  const float4 b = st_unpack4<IOS>(make_uint2(__float_as_uint(r.z), __float_as_uint(r.w)));
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
 template <int PREC>
 __device__ __forceinline__ f32x4 c1_mfma(bf16x8 bh, bf16x8 bl, bf16x8 xh, bf16x8 xl, f32x4 acc) {
   if (PREC == 0) {
@@ -97,7 +104,7 @@ __device__ __forceinline__ int c1_pad(int i, int n, int mode) {
 
 // Epilogue shared by the kernels of this file: lane = pixel r16 of each m-tile, channels n0 + 4g .. 4g+3 of each n-tile
 // (operands swapped in the MFMAs), everything a 16-B access straight from the accumulators; tile statistics through `red`.
-template <int MT, int NT, bool TAPS, bool SPEC = true>
+template <int MT, int NT, bool TAPS, bool SPEC = true, int IOS = PPST_ST_F32>
 __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT], float (&red)[8][NT > 4 ? 128 : 64][2], int b, int mblk,
                                             int ntile, int pbase, int oy0, int ox, int tid, int wave, int r16, int g) {
   const int act = a.act & 0xff;
@@ -110,9 +117,10 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT
   // store (vmcnt counts stores and retires in order: a load behind a store waits for that store's acknowledgement) -- as in
   // conv_mfma.hip.
   const int64_t img = (int64_t)b * (TAPS ? a.out_h * a.out_w : a.hw);
-  float* const yb = a.y + img * a.out_ld;
+  constexpr int ES = IOS == PPST_ST_F32 ? 4 : 2;     // storage type of residual / y: ppst_conv_args.io_st
+  unsigned char* const yb = (unsigned char*)a.y + img * a.out_ld * ES;
   const float* const nzb = a.noise ? a.noise + img : nullptr;
-  const float* const rb = a.residual ? a.residual + img * a.res_ld : nullptr;
+  const unsigned char* const rb = a.residual ? (const unsigned char*)a.residual + img * a.res_ld * ES : nullptr;
   const int nbase = ntile * (NT > 4 ? 128 : 64) + g * 4;
   float nzv[MT];
   float4 bva[NT];
@@ -142,7 +150,7 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT
       if (n0 >= a.cout) continue;
       float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
       const float4 bv = bva[nt];
-      if (RES) rv = *(const float4*)(rb + (ro + n0));
+      if (RES) rv = st_ld4<IOS>(rb, ro + n0);
       float o[4] = {acc[mt][nt][0] + bv.x + nz, acc[mt][nt][1] + bv.y + nz, acc[mt][nt][2] + bv.z + nz, acc[mt][nt][3] + bv.w + nz};
       const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
@@ -154,7 +162,7 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT
         if (RES == 2) t += r4[c];
         o[c] = t * a.out_scale;
       }
-      *(float4*)(yb + (yo + n0)) = make_float4(o[0], o[1], o[2], o[3]);
+      st_st4<IOS>(yb, yo + n0, make_float4(o[0], o[1], o[2], o[3]));
       s1[nt].x += o[0]; s1[nt].y += o[1]; s1[nt].z += o[2]; s1[nt].w += o[3];
       s2[nt].x += o[0] * o[0]; s2[nt].y += o[1] * o[1]; s2[nt].z += o[2] * o[2]; s2[nt].w += o[3] * o[3];
     }
@@ -219,10 +227,13 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT
 //               HBM-bound layers have to spare, and removes the tile's serial prologue (load -> split -> LDS -> barrier) and
 //               the per-step barriers that left these layers at 0.10-0.25 of the MFMA ceiling.
 // NT_: 16-channel tiles per wave (2 when Cout <= 32).
-template <bool INSS, bool TAPS = false, int NT_ = 4, int PREC = 0>
+template <bool INSS, bool TAPS = false, int NT_ = 4, int PREC = 0, int IOS = PPST_ST_F32>
 __global__ __launch_bounds__(512, 4) void conv1x1_stream_kernel(C1Args a) {
   constexpr int MT = 2, NT = NT_;
   constexpr bool X3 = PREC == 0;
+  // IOS: storage type of x, residual and y (ppst_conv_args.io_st): the single-pass modes, in their operand type
+  static_assert(IOS == PPST_ST_F32 || IOS == (PREC == 3 ? PPST_ST_F16 : PREC == 1 ? PPST_ST_BF16 : -1), "half storage: single-pass modes");
+  constexpr int ES = IOS == PPST_ST_F32 ? 4 : 2;
   constexpr int BLOB1 = X3 ? C1_BLOB : C1_BLOB / 2;      // single-pass blobs carry the hi planes only
   __shared__ uint4 sB[C1_GROUP * BLOB1 / 16];
   __shared__ float red[8][64][2];
@@ -243,7 +254,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_stream_kernel(C1Args a) {
   const int pbase = mblk * 256 + wave * 32;
   const int tyi = TAPS ? mblk / a.tiles_x : 0, txi = TAPS ? mblk - tyi * a.tiles_x : 0;
   const int oy0 = tyi * 16 + wave * 2, ox = txi * 16 + r16;       // TAPS: output pixel of m-tile mt = (oy0 + mt, ox)
-  const float* xb = a.x + (int64_t)b * (TAPS ? a.in_h * a.in_w : a.hw) * a.in_ld;
+  const unsigned char* xb = (const unsigned char*)a.x + (int64_t)b * (TAPS ? a.in_h * a.in_w : a.hw) * a.in_ld * ES;
   const unsigned char* wblob = a.wpack + (int64_t)ntile * a.nsteps * BLOB1;
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef const __attribute__((address_space(4))) int4* StepPtr;
@@ -291,9 +302,9 @@ __global__ __launch_bounds__(512, 4) void conv1x1_stream_kernel(C1Args a) {
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const float4* p = (const float4*)(xb + aoff[mt] + chan);
-      raw[mt][0] = p[0];
-      raw[mt][1] = p[1];
+      const float4* p = (const float4*)(xb + (aoff[mt] + chan) * ES);
+      raw[mt][0] = p[0];                                  // (half storage: the lane's 8 channels are these 16 bytes)
+      if (IOS == PPST_ST_F32) raw[mt][1] = p[1];
     }
     if (INSS) {
       const float4* q = (const float4*)(a.in_ss + ((int64_t)b * a.in_c + chan + g * 8) * 2);
@@ -316,7 +327,14 @@ __global__ __launch_bounds__(512, 4) void conv1x1_stream_kernel(C1Args a) {
       for (int mt = 0; mt < MT; ++mt) vok[mt] = pok[mt];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
+        if (IOS != PPST_ST_F32 && !INSS) {        // stored in the operand type already: the fragment is the loaded 16 bytes
+          const float4 z = vok[mt] ? raw[mt][0] : make_float4(0.f, 0.f, 0.f, 0.f);
+          ah[mt] = __builtin_bit_cast(bf16x8, z);
+          al[mt] = ah[mt];
+          continue;
+        }
         float v[8] = {raw[mt][0].x, raw[mt][0].y, raw[mt][0].z, raw[mt][0].w, raw[mt][1].x, raw[mt][1].y, raw[mt][1].z, raw[mt][1].w};
+        if (IOS != PPST_ST_F32) c1_unpack8<IOS>(raw[mt][0], v);
         if (INSS) {
           const float sc[8] = {ss[0].x, ss[0].z, ss[1].x, ss[1].z, ss[2].x, ss[2].z, ss[3].x, ss[3].z};
           const float sh[8] = {ss[0].y, ss[0].w, ss[1].y, ss[1].w, ss[2].y, ss[2].w, ss[3].y, ss[3].w};
@@ -341,7 +359,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_stream_kernel(C1Args a) {
     }
   }
 
-  c1_epilogue<MT, NT, TAPS, X3>(a, acc, red, b, mblk, ntile, pbase, oy0, ox, tid, wave, r16, g);
+  c1_epilogue<MT, NT, TAPS, X3, IOS>(a, acc, red, b, mblk, ntile, pbase, oy0, ox, tid, wave, r16, g);
 }
 
 // Plain 3x3 stride-1 layers with few channels (variant 6): the direct form above re-reads every pixel 9 times through
@@ -365,10 +383,12 @@ __device__ __forceinline__ bf16x8 c3_shift(bf16x8 edge, bf16x8 centre) {
 // NT_ = 8 (Cout = 65..128, blobs packed for bn = 128): wave tile 32 px x 128 ch, 256 registers, one block per CU (152 KB of
 // LDS) -- the generator's 128 -> 128 @512^2 StyledConv, which the tile kernel ran at 0.43 of the ceiling (36-step tiles
 // pay 20 % for their serial prologue + epilogue): here the two waves of a SIMD overlap one's conversions with the other's MFMAs.
-template <bool INSS, int NT_, int PREC = 0>
+template <bool INSS, int NT_, int PREC = 0, int IOS = PPST_ST_F32>
 __global__ __launch_bounds__(512, NT_ > 4 ? 2 : 4) void conv3x3_direct_kernel(C1Args a) {
   constexpr int MT = 2, NT = NT_;
   constexpr bool X3 = PREC == 0;
+  static_assert(IOS == PPST_ST_F32 || IOS == (PREC == 3 ? PPST_ST_F16 : PREC == 1 ? PPST_ST_BF16 : -1), "half storage: single-pass modes");
+  constexpr int ES = IOS == PPST_ST_F32 ? 4 : 2;
   constexpr int PSTR = (NT > 4 ? 128 : 64) * 16;          // bytes per plane of a step blob (bn x 16 B)
   constexpr int BLOB = (X3 ? 8 : 4) * PSTR;               // hi planes g0..3 [, lo planes]
   __shared__ uint4 sB[C3_GROUP * BLOB / 16];
@@ -390,7 +410,7 @@ __global__ __launch_bounds__(512, NT_ > 4 ? 2 : 4) void conv3x3_direct_kernel(C1
   mblk -= b * a.tiles;
   const int tyi = mblk / a.tiles_x, txi = mblk - tyi * a.tiles_x;
   const int oy0 = tyi * 16 + wave * 2, ox = txi * 16 + r16;
-  const float* xb = a.x + (int64_t)b * a.in_h * a.in_w * a.in_ld;
+  const unsigned char* xb = (const unsigned char*)a.x + (int64_t)b * a.in_h * a.in_w * a.in_ld * ES;
   const unsigned char* wblob = a.wpack + (int64_t)ntile * a.nsteps * BLOB;
   if (wid > w_beg) __syncthreads();            // `red` and (unless kept) the weight blobs of the previous tile are free
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -424,10 +444,11 @@ __global__ __launch_bounds__(512, NT_ > 4 ? 2 : 4) void conv3x3_direct_kernel(C1
     iy = c1_pad(iy, a.in_h, a.pad_mode);
     okc = a.pad_mode != PPST_PAD_ZERO || (yok && cx_ok);
     oke = a.pad_mode != PPST_PAD_ZERO || (yok && ex_ok);
-    const float4* pc = (const float4*)(xb + ((int64_t)iy * a.in_w + cx) * a.in_ld + chan + g * 8);
-    const float4* pe = (const float4*)(xb + ((int64_t)iy * a.in_w + ex) * a.in_ld + chan + g * 8);
-    rawc[0] = pc[0]; rawc[1] = pc[1];
-    rawe[0] = pe[0]; rawe[1] = pe[1];      // (predicating this load to the 8 lanes that need it measured SLOWER: the branch costs
+    const float4* pc = (const float4*)(xb + (((int64_t)iy * a.in_w + cx) * a.in_ld + chan + g * 8) * ES);
+    const float4* pe = (const float4*)(xb + (((int64_t)iy * a.in_w + ex) * a.in_ld + chan + g * 8) * ES);
+    rawc[0] = pc[0];
+    rawe[0] = pe[0];
+    if (IOS == PPST_ST_F32) { rawc[1] = pc[1]; rawe[1] = pe[1]; }      // (predicating this load to the 8 lanes that need it measured SLOWER: the branch costs
                                            //  more than re-reading the row from L1)
   };
   auto ss_load = [&](int chan) {
@@ -437,7 +458,13 @@ __global__ __launch_bounds__(512, NT_ > 4 ? 2 : 4) void conv3x3_direct_kernel(C1
     }
   };
   auto convert = [&](const float4 (&raw)[2], bool ok, bf16x8& hi, bf16x8& lo) {
+    if (IOS != PPST_ST_F32 && !INSS) {          // stored in the operand type already
+      hi = __builtin_bit_cast(bf16x8, ok ? raw[0] : make_float4(0.f, 0.f, 0.f, 0.f));
+      lo = hi;
+      return;
+    }
     float v[8] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y, raw[1].z, raw[1].w};
+    if (IOS != PPST_ST_F32) c1_unpack8<IOS>(raw[0], v);
     if (INSS) {
       const float sc[8] = {ss[0].x, ss[0].z, ss[1].x, ss[1].z, ss[2].x, ss[2].z, ss[3].x, ss[3].z};
       const float sh[8] = {ss[0].y, ss[0].w, ss[1].y, ss[1].w, ss[2].y, ss[2].w, ss[3].y, ss[3].w};
@@ -491,7 +518,7 @@ __global__ __launch_bounds__(512, NT_ > 4 ? 2 : 4) void conv3x3_direct_kernel(C1
     }
     chan = chan_next;
   }
-  c1_epilogue<MT, NT, true, (X3 && NT <= 4)>(a, acc, red, b, mblk, ntile, 0, oy0, ox, tid, wave, r16, g);
+  c1_epilogue<MT, NT, true, (X3 && NT <= 4), IOS>(a, acc, red, b, mblk, ntile, 0, oy0, ox, tid, wave, r16, g);
   }
 }
 
@@ -509,12 +536,14 @@ int ppst_conv1x1_stream_launch(const ppst_conv_args* a, int n_tiles, int tiles, 
   if ((int64_t)tiles * 256 < k.hw) return PPST_EINVAL;
   const int64_t blocks = (int64_t)a->B * tiles * n_tiles;
   if (blocks > 0x7fffffff) return PPST_EINVAL;
-#define LS(PREC_)                                                                                                     \
+#define LS(PREC_, IOS_)                                                                                               \
   do {                                                                                                                \
-    if (k.in_ss) PPST_LAUNCH((conv1x1_stream_kernel<true, false, 4, PREC_>), dim3((unsigned)blocks), dim3(512), 0, st, k);   \
-    else PPST_LAUNCH((conv1x1_stream_kernel<false, false, 4, PREC_>), dim3((unsigned)blocks), dim3(512), 0, st, k);          \
+    if (k.in_ss) PPST_LAUNCH((conv1x1_stream_kernel<true, false, 4, PREC_, IOS_>), dim3((unsigned)blocks), dim3(512), 0, st, k);   \
+    else PPST_LAUNCH((conv1x1_stream_kernel<false, false, 4, PREC_, IOS_>), dim3((unsigned)blocks), dim3(512), 0, st, k);          \
   } while (0)
-  if (a->precision == 1) LS(1); else if (a->precision == 3) LS(3); else LS(0);
+  if (a->precision == 1) { if (a->io_st) LS(1, PPST_ST_BF16); else LS(1, PPST_ST_F32); }
+  else if (a->precision == 3) { if (a->io_st) LS(3, PPST_ST_F16); else LS(3, PPST_ST_F32); }
+  else LS(0, PPST_ST_F32);
 #undef LS
   return PPST_LAUNCH_CHECK();
 }
@@ -533,13 +562,15 @@ int ppst_conv_direct_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, i
   const int64_t blocks = (int64_t)a->B * k.tiles * n_tiles;
   if (blocks > 0x7fffffff) return PPST_EINVAL;
   const bool nt2 = a->cout <= 32;
-#define LD(INSS_, PREC_)                                                                                             \
+#define LD(INSS_, PREC_, IOS_)                                                                                       \
   do {                                                                                                               \
-    if (nt2) PPST_LAUNCH((conv1x1_stream_kernel<INSS_, true, 2, PREC_>), dim3((unsigned)blocks), dim3(512), 0, st, k);       \
-    else PPST_LAUNCH((conv1x1_stream_kernel<INSS_, true, 4, PREC_>), dim3((unsigned)blocks), dim3(512), 0, st, k);           \
+    if (nt2) PPST_LAUNCH((conv1x1_stream_kernel<INSS_, true, 2, PREC_, IOS_>), dim3((unsigned)blocks), dim3(512), 0, st, k);       \
+    else PPST_LAUNCH((conv1x1_stream_kernel<INSS_, true, 4, PREC_, IOS_>), dim3((unsigned)blocks), dim3(512), 0, st, k);           \
   } while (0)
-#define LDP(PREC_) do { if (k.in_ss) LD(true, PREC_); else LD(false, PREC_); } while (0)
-  if (a->precision == 1) LDP(1); else if (a->precision == 3) LDP(3); else LDP(0);
+#define LDP(PREC_, IOS_) do { if (k.in_ss) LD(true, PREC_, IOS_); else LD(false, PREC_, IOS_); } while (0)
+  if (a->precision == 1) { if (a->io_st) LDP(1, PPST_ST_BF16); else LDP(1, PPST_ST_F32); }
+  else if (a->precision == 3) { if (a->io_st) LDP(3, PPST_ST_F16); else LDP(3, PPST_ST_F32); }
+  else LDP(0, PPST_ST_F32);
 #undef LDP
 #undef LD
   return PPST_LAUNCH_CHECK();
@@ -562,15 +593,17 @@ int ppst_conv3x3_direct_launch(const ppst_conv_args* a, int n_tiles, int tiles_y
   // single-chunk layers: persistent blocks (two 8-wave blocks per CU, 72 KB of LDS each) that keep the weights resident
   if (a->nsteps == 9 && n_tiles == 1 && blocks > 512) blocks = 512;
   const bool nt2 = a->cout <= 32, nt8 = a->bn == 128;
-#define LD3(INSS_, PREC_)                                                                                            \
+#define LD3(INSS_, PREC_, IOS_)                                                                                      \
   do {                                                                                                               \
     if (nt8 && PREC_ == 0) PPST_LAUNCH((conv3x3_direct_kernel<INSS_, 8, 0>), dim3((unsigned)blocks), dim3(512), 0, st, k);   \
     else if (nt8) return PPST_EUNSUPPORTED;                                                                          \
-    else if (nt2) PPST_LAUNCH((conv3x3_direct_kernel<INSS_, 2, PREC_>), dim3((unsigned)blocks), dim3(512), 0, st, k); \
-    else PPST_LAUNCH((conv3x3_direct_kernel<INSS_, 4, PREC_>), dim3((unsigned)blocks), dim3(512), 0, st, k);          \
+    else if (nt2) PPST_LAUNCH((conv3x3_direct_kernel<INSS_, 2, PREC_, IOS_>), dim3((unsigned)blocks), dim3(512), 0, st, k); \
+    else PPST_LAUNCH((conv3x3_direct_kernel<INSS_, 4, PREC_, IOS_>), dim3((unsigned)blocks), dim3(512), 0, st, k);          \
   } while (0)
-#define LD3P(PREC_) do { if (k.in_ss) LD3(true, PREC_); else LD3(false, PREC_); } while (0)
-  if (a->precision == 1) LD3P(1); else if (a->precision == 3) LD3P(3); else LD3P(0);
+#define LD3P(PREC_, IOS_) do { if (k.in_ss) LD3(true, PREC_, IOS_); else LD3(false, PREC_, IOS_); } while (0)
+  if (a->precision == 1) { if (a->io_st) LD3P(1, PPST_ST_BF16); else LD3P(1, PPST_ST_F32); }
+  else if (a->precision == 3) { if (a->io_st) LD3P(3, PPST_ST_F16); else LD3P(3, PPST_ST_F32); }
+  else LD3P(0, PPST_ST_F32);
 #undef LD3P
 #undef LD3
   return PPST_LAUNCH_CHECK();

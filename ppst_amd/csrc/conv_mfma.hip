@@ -47,6 +47,8 @@ struct ConvKArgs {
   int early_a;              // step table guarantees chunks of >= 2 steps: a chunk's global loads go out one step early
   unsigned long long* dbg;  // stamp build: [block][wave][8] cycle sums (else unused)
 };
+// (the storage type of x / residual / y -- ppst_conv_args.io_st, single-pass precision modes only -- is a template parameter IOS of
+// the kernels, not a field: the pointers above are then half / bfloat16 tensors behind their `float*` type)
 
 __device__ __forceinline__ int pad_index(int i, int n, int mode) {
   if (mode == PPST_PAD_REFLECT) {
@@ -86,9 +88,14 @@ __device__ __forceinline__ void split_f16(float x, unsigned short& hi, unsigned 
 // bytes [hi x 8 | lo x 8] bf16, same bytes and pixel stride as the fp32 tensor (ppst_presplit) -- and the activation tile is
 // staged by LDS-DMA like the weights: no registers, no conversion, no staging store.  Two activation slots (needs chunks of
 // >= 4 steps), no normalise-on-load.
-template <int WM, int WN, int HALO, bool X3, bool INSS, int NAS = 0, bool F16 = false, bool X2 = false, bool PRES = false>
+template <int WM, int WN, int HALO, bool X3, bool INSS, int NAS = 0, bool F16 = false, bool X2 = false, bool PRES = false,
+          int IOS = PPST_ST_F32>
 __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(ConvKArgs a) {
   constexpr bool ALO = X3 || X2;                         // the activation tile has lo planes
+  // IOS: storage type of x, residual and y (common.h).  Half storage exists for the single-pass modes only, in the operand type of
+  // the mode: a staged element then reaches LDS as loaded (no conversion) unless normalise-on-load rewrites it.
+  static_assert(IOS == PPST_ST_F32 || (!X3 && !X2 && !PRES && IOS == (F16 ? PPST_ST_F16 : PPST_ST_BF16)), "half storage: single-pass modes");
+  constexpr int ES = IOS == PPST_ST_F32 ? 4 : 2;         // bytes per stored element
   constexpr int NT = 64 * WM * WN;
   constexpr int TH = 4 * WM, TW = 16;
   constexpr int HH = TH + 2 * HALO, HW = TW + 2 * HALO, HP = HH * HW;
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
 #endif
   StepPtr steps = (StepPtr)(a.steps + (int64_t)group * a.nsteps);
   const unsigned char* wblob = (const unsigned char*)a.wpack + ((int64_t)nidx * a.nsteps) * BBUF;
-  const float* xb = a.x + (int64_t)b * a.in_h * a.in_w * a.in_ld;
+  const unsigned char* xb = (const unsigned char*)a.x + (int64_t)b * a.in_h * a.in_w * a.in_ld * ES;
 
   constexpr int A_WCH = (HP + 7) / 8;                      // wave-chunks of 8 pixels x 8 float4
   constexpr int A_IT2 = (A_WCH * 64 + NT - 1) / NT;
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
       if (inb || a.pad_mode != PPST_PAD_ZERO) {
         iy = pad_index(iy, a.in_h, a.pad_mode);
         ix = pad_index(ix, a.in_w, a.pad_mode);
-        o = ((iy * a.in_w + ix) * a.in_ld + q4 * 4) * 4;  // bytes, < 2^31: the entry point rejects larger images
+        o = ((iy * a.in_w + ix) * a.in_ld + q4 * 4) * ES;  // bytes, < 2^31: the entry point rejects larger images
       }
     }
     aoff[it] = o;
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   // in the load's own destination registers, and that VALU write to registers of a possibly pending load cost a `s_waitcnt vmcnt(0)`
   // right behind the weight DMA of the step (one L2 round trip per chunk).  Padding items carry the offset -1 (0xffffffff): out of
   // the descriptor's range, the hardware returns zeros and the staging store needs no select.
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, a.in_h * a.in_w * a.in_ld * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, a.in_h * a.in_w * a.in_ld * ES, 0x00020000);
   // PRES: piece k (0..5) of this wave is plane (wave + 8k) / 6, pixels 64 j .. 64 j + 63 with j = (wave + 8k) % 6; a piece is one
   // global_load_lds_dwordx4 (1 KB of one plane); out-of-image pixels of a zero-padded conv read a 16-byte zero word
   int poff[6];
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     for (int k = 0; k < 6; ++k) {
       const int i = wave + 8 * k, pl = i / 6, j = i - pl * 6;       // wave-uniform
       const unsigned char* src = (const unsigned char*)g_conv_zero;
-      if (poff[k] >= 0) src = (const unsigned char*)xb + poff[k] + chan_off * 4 + (pl & 3) * 32 + (pl >> 2) * 16;
+      if (poff[k] >= 0) src = xb + poff[k] + chan_off * 4 + (pl & 3) * 32 + (pl >> 2) * 16;
       if (64 * j + lane < HP)
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                          (void __attribute__((address_space(3)))*)(smA + slot * ABUF + pl * PLANE + j * 1024), 16, 0, 0);
@@ -232,7 +239,12 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     for (int it = 0; it < A_IT2; ++it) {
       // always issued: the count of outstanding vector-memory operations must be a compile-time constant for the counted
       // vmcnt wait that lets an early load stay in flight across the step barrier
-      ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, aoff[it], chan_off * 4, 0));
+      if (IOS == PPST_ST_F32) {
+        ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, aoff[it], chan_off * 4, 0));
+      } else {       // four half elements: the raw 8 bytes ride in .x / .y until a_store
+        const uint2 u = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xrs, aoff[it], chan_off * 2, 0));
+        ra[it].x = __uint_as_float(u.x); ra[it].y = __uint_as_float(u.y);
+      }
     }
     if (INSS) {
       const float4* p = (const float4*)(a.in_ss + ((int64_t)b * a.in_c + chan_off + q4lane * 4) * 2);
@@ -254,12 +266,16 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
       int pix = (i >> 6) * 8 + ((l >> 1) & 7);
       if (pix < HP) {
         float4 v = ra[it];                // (padding items: zeros from the out-of-range buffer load)
+        const uint2 raw = make_uint2(__float_as_uint(ra[it].x), __float_as_uint(ra[it].y));
+        if (IOS != PPST_ST_F32) v = st_unpack4<IOS>(raw);
         if (INSS && aoff[it] >= 0) {  // padding zeros stay zeros (they pad the normalised tensor)
           v.x = in_act(ras0.x * v.x + ras0.y); v.y = in_act(ras0.z * v.y + ras0.w);
           v.z = in_act(ras1.x * v.z + ras1.y); v.w = in_act(ras1.z * v.w + ras1.w);
         }
         uint2 hv, lv;
-        if (F16) {
+        if (IOS != PPST_ST_F32 && !INSS) {
+          hv = raw; lv = make_uint2(0u, 0u);       // stored in the operand type already
+        } else if (F16) {
           unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
           if (X2) { split_f16(v.x, h0, l0); split_f16(v.y, h1, l1); split_f16(v.z, h2, l2); split_f16(v.w, h3, l3); }
           else { h0 = f2h(v.x); h1 = f2h(v.y); h2 = f2h(v.z); h3 = f2h(v.w); l0 = l1 = l2 = l3 = 0; }
@@ -543,9 +559,9 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   const bool okx0 = txl < a.tile_w && oxl < a.out_w, okx1 = txl + 8 < a.tile_w && oxl + 8 * a.out_sx < a.out_w;
   const int pix0 = oyb * a.out_w + oxl, rs_pix = a.out_sy * a.out_w;
   const int64_t img = (int64_t)b * a.out_h * a.out_w;
-  float* const yb = a.y + img * a.out_ld;
+  unsigned char* const yb = (unsigned char*)a.y + img * a.out_ld * ES;
   const float* const nzb = a.noise ? a.noise + img : nullptr;
-  const float* const rb = a.residual ? a.residual + img * a.res_ld : nullptr;
+  const unsigned char* const rb = a.residual ? (const unsigned char*)a.residual + img * a.res_ld * ES : nullptr;
   // Bias and noise of the whole wave tile are fetched BEFORE the first store: vmcnt counts stores too and retires in order, so a
   // load issued behind a pass's stores made its s_waitcnt sit out their acknowledgements (one HBM round trip per pass).
   float nzv[8];
@@ -593,7 +609,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
         const int d = r * rs_pix + c8 * 8 * a.out_sx;  // uniform pixel step from (row 0, even column half)
         const float nz = nzv[it];
         float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (RES) rv = *(const float4*)(rb + (ro0 + d * a.res_ld));
+        if (RES) rv = st_ld4<IOS>(rb, ro0 + d * a.res_ld);
         float o[4] = {v.x + bv.x + nz, v.y + bv.y + nz, v.z + bv.z + nz, v.w + bv.w + nz};
         const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
@@ -605,7 +621,8 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
           if (RES == 2) t += r4[c];
           o[c] = t * a.out_scale;
         }
-        PPST_EPI_STORE(yb + (yo0 + d * a.out_ld), o);
+        if (IOS == PPST_ST_F32) PPST_EPI_STORE((float*)yb + (yo0 + d * a.out_ld), o);
+        else st_st4<IOS>(yb, yo0 + d * a.out_ld, make_float4(o[0], o[1], o[2], o[3]));
         s1.x += o[0]; s1.y += o[1]; s1.z += o[2]; s1.w += o[3];
         s2.x += o[0] * o[0]; s2.y += o[1] * o[1]; s2.z += o[2] * o[2]; s2.w += o[3] * o[3];
       }
@@ -955,10 +972,10 @@ extern "C" int ppst_has_experiments(void) {
 
 extern "C" int ppst_conv_tiles(int tile_h, int tile_w, int tile_rows) { return cdiv(tile_h, tile_rows) * cdiv(tile_w, 16); }
 
-template <int WM, int WN, int HALO, bool X3, int NAS = 0, bool F16 = false, bool X2 = false>
+template <int WM, int WN, int HALO, bool X3, int NAS = 0, bool F16 = false, bool X2 = false, int IOS = PPST_ST_F32>
 static void launch_conv(const ConvKArgs& k, int blocks, hipStream_t st) {
-  if (k.in_ss) PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, true, NAS, F16, X2>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
-  else PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, false, NAS, F16, X2>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
+  if (k.in_ss) PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, true, NAS, F16, X2, false, IOS>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
+  else PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, false, NAS, F16, X2, false, IOS>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
 }
 
 extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
@@ -1003,6 +1020,11 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
 #endif
   // pre-split input (experiment): the 8-wave tile kernel only, chunks of >= 4 steps (the caller's promise with early_a), no
   // normalise-on-load
+  // half-precision activation storage (x, residual, y): the single-pass modes, in the operand type of the mode (1 -> bfloat16,
+  // 3 -> IEEE half); kernel families 0 (16-row tiles), 2 (N-256), 4 / 5 / 6 (streaming 1x1 / direct)
+  if (a->io_st && (a->io_st != (a->precision == 3 ? PPST_ST_F16 : a->precision == 1 ? PPST_ST_BF16 : -1) || a->tile_rows != 16 ||
+                   a->in_presplit || !(a->variant == 0 || a->variant == 2 || a->variant == 4 || a->variant == 5 || a->variant == 6)))
+    return PPST_EINVAL;
   if (a->in_presplit && (a->variant != 0 || a->bn != 128 || a->halo != 1 || a->precision != 0 || !a->early_a || a->tile_rows != 16 ||
                          a->in_scale_shift))
     return PPST_EINVAL;
@@ -1014,6 +1036,9 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   }
   // the input side: every kernel family addresses one input image with 32-bit BYTE offsets (buffer loads / int offsets)
   if ((int64_t)a->in_h * a->in_w * a->in_ld * 4 > 0x7fffffff) return PPST_EINVAL;
+  if (a->io_st && (((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->residual) % 8)) return PPST_EINVAL;
+  // (the streaming kernels read a lane's 8 channels as one 16-byte item)
+  if (a->io_st && a->variant >= 4 && a->variant <= 6 && (a->in_ld % 8 || (uintptr_t)a->x % 16)) return PPST_EINVAL;
   // the scattered output must reach into the output tensor (elements beyond it are dropped)
   if ((a->tile_h - 1) * a->out_sy >= a->out_h || (a->tile_w - 1) * a->out_sx >= a->out_w) return PPST_EINVAL;
   if (a->B == 0) return PPST_OK;
@@ -1060,7 +1085,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
     return e2;
   }
   const bool x3 = a->precision == 0;
-  const bool f16 = a->precision == 3, x2 = a->precision == 4;
+  const bool f16 = a->precision == 3, x2 = a->precision == 4, hs = a->io_st != 0;
 #ifdef PPST_EXPERIMENTS
 #define X2_LAUNCH(WM_, WN_, H_) launch_conv<WM_, WN_, H_, false, 0, true, true>(k, blocks, st)
 #else
@@ -1068,8 +1093,8 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
 #endif
 #define DISPATCH(WM_, WN_)                                                                                         \
   do {                                                                                                             \
-    if (a->halo) { if (x3) launch_conv<WM_, WN_, 1, true>(k, blocks, st); else if (x2) X2_LAUNCH(WM_, WN_, 1); else if (f16) launch_conv<WM_, WN_, 1, false, 0, true>(k, blocks, st); else launch_conv<WM_, WN_, 1, false>(k, blocks, st); } \
-    else         { if (x3) launch_conv<WM_, WN_, 0, true>(k, blocks, st); else if (x2) X2_LAUNCH(WM_, WN_, 0); else if (f16) launch_conv<WM_, WN_, 0, false, 0, true>(k, blocks, st); else launch_conv<WM_, WN_, 0, false>(k, blocks, st); } \
+    if (a->halo) { if (x3) launch_conv<WM_, WN_, 1, true>(k, blocks, st); else if (x2) X2_LAUNCH(WM_, WN_, 1); else if (f16 && hs) launch_conv<WM_, WN_, 1, false, 0, true, false, PPST_ST_F16>(k, blocks, st); else if (f16) launch_conv<WM_, WN_, 1, false, 0, true>(k, blocks, st); else if (hs) launch_conv<WM_, WN_, 1, false, 0, false, false, PPST_ST_BF16>(k, blocks, st); else launch_conv<WM_, WN_, 1, false>(k, blocks, st); } \
+    else         { if (x3) launch_conv<WM_, WN_, 0, true>(k, blocks, st); else if (x2) X2_LAUNCH(WM_, WN_, 0); else if (f16 && hs) launch_conv<WM_, WN_, 0, false, 0, true, false, PPST_ST_F16>(k, blocks, st); else if (f16) launch_conv<WM_, WN_, 0, false, 0, true>(k, blocks, st); else if (hs) launch_conv<WM_, WN_, 0, false, 0, false, false, PPST_ST_BF16>(k, blocks, st); else launch_conv<WM_, WN_, 0, false>(k, blocks, st); } \
   } while (0)
   // (round 1 measured 8-row tiles -- two 80-KB blocks per CU -- 35 % slower: only one block was ever resident.  Round 3
   //  re-instantiates them at 77 KB with the two-slot ring of the early_a tables: see ops.TWO_BLOCK_8ROW.)

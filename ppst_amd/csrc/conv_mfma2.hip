@@ -90,9 +90,13 @@ __device__ __forceinline__ unsigned short f2h_2(float f) { return __builtin_bit_
 // step is a tap ROW dy with one tap COLUMN per b (steps[i].z = (dx_b0 + 1) | (dx_b1 + 1) << 8): every wave multiplies in every
 // step, the activation tile is staged once for two phases, and the layer runs on this kernel's 128 x 64 wave tiles instead of
 // the tile kernel's 64 x 64.  Per output element the MFMA sequence is the tile kernel's (dy-major taps): bit-identical outputs.
-template <int NT, int HALO, bool INSS, int WNW = 2, bool BDB = true, int NA_ = 2, int WMW = 2, int PREC = 0, int MT_ = 8, bool DUAL = false>
+template <int NT, int HALO, bool INSS, int WNW = 2, bool BDB = true, int NA_ = 2, int WMW = 2, int PREC = 0, int MT_ = 8, bool DUAL = false,
+          int IOS = PPST_ST_F32>
 __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW == 8 || NA_ == 1) ? 2 : 1)) void conv_mfma2_kernel(Conv2KArgs a) {
   constexpr bool X3 = PREC == 0;
+  // IOS: storage type of x, residual and y (ppst_conv_args.io_st; conv_mfma.hip): the single-pass modes, in their operand type
+  static_assert(IOS == PPST_ST_F32 || IOS == (PREC == 3 ? PPST_ST_F16 : PREC == 1 ? PPST_ST_BF16 : -1), "half storage: single-pass modes");
+  constexpr int ES = IOS == PPST_ST_F32 ? 4 : 2;
   constexpr int NWV = WMW * WNW;                          // waves per block
   constexpr int NTH = 64 * NWV;
   constexpr int MT = MT_;                                 // m-tiles (16-pixel rows) per wave
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
 #endif
   StepPtr steps = (StepPtr)(a.steps + (int64_t)group * a.nsteps);
   const unsigned char* wblob = (const unsigned char*)a.wpack + ((int64_t)nidx * a.nsteps) * BBUF;
-  const float* xb = a.x + (int64_t)b * a.in_h * a.in_w * a.in_ld;
+  const unsigned char* xb = (const unsigned char*)a.x + (int64_t)b * a.in_h * a.in_w * a.in_ld * ES;
 
   // ---- A staging (as conv_mfma.hip: one wave-instruction = 8 pixels x 128 B; fp32 -> bf16 hi/lo planes)
   constexpr int A_WCH = (HP + 7) / 8;
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
       if (inb || a.pad_mode != PPST_PAD_ZERO) {
         iy = pad_index2(iy, a.in_h, a.pad_mode);
         ix = pad_index2(ix, a.in_w, a.pad_mode);
-        o = ((iy * a.in_w + ix) * a.in_ld + q4 * 4) * 4;  // bytes, < 2^31: the entry point rejects larger images
+        o = ((iy * a.in_w + ix) * a.in_ld + q4 * 4) * ES;  // bytes, < 2^31: the entry point rejects larger images
       }
     }
     aoff[it] = o;
@@ -172,10 +176,17 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   const int q4lane = ((tid & 63) >> 4) * 2 + (tid & 1);
   const float in_slope = (INSS && a.in_act == PPST_ACT_PRELU && a.in_prelu) ? a.in_prelu[0] : 0.f;
   // buffer loads (SGPR descriptor + per-item byte offset + SGPR chunk offset; padding items out of range -> zeros): conv_mfma.hip
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, a.in_h * a.in_w * a.in_ld * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, a.in_h * a.in_w * a.in_ld * ES, 0x00020000);
   auto a_load = [&](int chan_off) {
 #pragma unroll
-    for (int it = 0; it < A_IT2; ++it) ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, aoff[it], chan_off * 4, 0));
+    for (int it = 0; it < A_IT2; ++it) {
+      if (IOS == PPST_ST_F32) {
+        ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, aoff[it], chan_off * 4, 0));
+      } else {       // four half elements: the raw 8 bytes ride in .x / .y until a_store
+        const uint2 u = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xrs, aoff[it], chan_off * 2, 0));
+        ra[it].x = __uint_as_float(u.x); ra[it].y = __uint_as_float(u.y);
+      }
+    }
     if (INSS) {
       const float4* p = (const float4*)(a.in_ss + ((int64_t)b * a.in_c + chan_off + q4lane * 4) * 2);
       ras0 = p[0];
@@ -196,12 +207,15 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
       int pix = (i >> 6) * 8 + ((l >> 1) & 7);
       if (pix < HP) {
         float4 v = ra[it];                // (padding items: zeros from the out-of-range buffer load)
+        const uint2 raw = make_uint2(__float_as_uint(ra[it].x), __float_as_uint(ra[it].y));
+        if (IOS != PPST_ST_F32) v = st_unpack4<IOS>(raw);
         if (INSS && aoff[it] >= 0) {
           v.x = in_act(ras0.x * v.x + ras0.y); v.y = in_act(ras0.z * v.y + ras0.w);
           v.z = in_act(ras1.x * v.z + ras1.y); v.w = in_act(ras1.z * v.w + ras1.w);
         }
         uint2 hv, lv = make_uint2(0u, 0u);
         if (X3) split_bf16x4(v, hv, lv);     // two elements per conversion / subtraction instruction (common.h)
+        else if (IOS != PPST_ST_F32 && !INSS) hv = raw;      // stored in the operand type already
         else if (PREC == 3) {
           const unsigned short h0 = f2h_2(v.x), h1 = f2h_2(v.y), h2 = f2h_2(v.z), h3 = f2h_2(v.w);
           hv = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
@@ -407,9 +421,9 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   const bool okx0 = txl < a.tile_w && oxl < a.out_w, okx1 = txl + 8 < a.tile_w && oxl + 8 * a.out_sx < a.out_w;
   const int pix0 = oyb * a.out_w + oxl, rs_pix = a.out_sy * a.out_w;
   const int64_t img = (int64_t)b * a.out_h * a.out_w;
-  float* const yb = a.y + img * a.out_ld;
+  unsigned char* const yb = (unsigned char*)a.y + img * a.out_ld * ES;
   const float* const nzb = a.noise ? a.noise + img : nullptr;
-  const float* const rb = a.residual ? a.residual + img * a.res_ld : nullptr;
+  const unsigned char* const rb = a.residual ? (const unsigned char*)a.residual + img * a.res_ld * ES : nullptr;
   // bias and noise of the whole wave tile fetched before the first store (vmcnt counts stores and retires in order: conv_mfma.hip)
   float nzv[2 * MT];
   float4 bva[NT / 2];
@@ -463,7 +477,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
           const int d = r * rs_pix + c8 * 8 * a.out_sx;
           const float nz = nzv[mh * 8 + it];
           float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (RES) rv = *(const float4*)(rb + (ro0 + d * a.res_ld));
+          if (RES) rv = st_ld4<IOS>(rb, ro0 + d * a.res_ld);
           float o[4] = {v.x + bv.x + nz, v.y + bv.y + nz, v.z + bv.z + nz, v.w + bv.w + nz};
           const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
@@ -475,7 +489,8 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
             if (RES == 2) t += r4[c];
             o[c] = t * a.out_scale;
           }
-          PPST_EPI_STORE(yb + (yo0 + d * a.out_ld), o);
+          if (IOS == PPST_ST_F32) PPST_EPI_STORE((float*)yb + (yo0 + d * a.out_ld), o);
+          else st_st4<IOS>(yb, yo0 + d * a.out_ld, make_float4(o[0], o[1], o[2], o[3]));
           s1a[pass].x += o[0]; s1a[pass].y += o[1]; s1a[pass].z += o[2]; s1a[pass].w += o[3];
           s2a[pass].x += o[0] * o[0]; s2a[pass].y += o[1] * o[1]; s2a[pass].z += o[2] * o[2]; s2a[pass].w += o[3] * o[3];
         }
@@ -576,10 +591,14 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
     if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 2, 4, 0, 6>), dim3(blocks), dim3(512), 0, st, k);   \
     else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 2, 4, 0, 6>), dim3(blocks), dim3(512), 0, st, k);          \
   } while (0)
+#define L2Q(HALO_, PREC_, IOS_)                                                                                 \
+  do {                                                                                                          \
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 4, false, 2, 2, PREC_, 8, false, IOS_>), dim3(blocks), dim3(512), 0, st, k);   \
+    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 4, false, 2, 2, PREC_, 8, false, IOS_>), dim3(blocks), dim3(512), 0, st, k);          \
+  } while (0)
 #define L2P(HALO_, PREC_)                                                                                       \
   do {                                                                                                          \
-    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 4, false, 2, 2, PREC_>), dim3(blocks), dim3(512), 0, st, k);   \
-    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 4, false, 2, 2, PREC_>), dim3(blocks), dim3(512), 0, st, k);          \
+    if (a->io_st) L2Q(HALO_, PREC_, (PREC_ == 3 ? PPST_ST_F16 : PPST_ST_BF16)); else L2Q(HALO_, PREC_, PPST_ST_F32); \
   } while (0)
   if (a->variant == 2 && a->dual_b) {     // Cout = 128 fused upscale as two phase pairs (halo 1, precision 0, no normalise-on-load needed twice: both built)
     if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, 1, true, 4, false, 2, 2, 0, 8, true>), dim3(blocks), dim3(512), 0, st, k);

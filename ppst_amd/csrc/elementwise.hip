@@ -17,18 +17,19 @@ __device__ __forceinline__ float act_apply(float t, int act, float slope);
 // residual that is a half-resolution tensor, bilinearly upsampled x2 on the fly
 // (F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) of the resnet skip,
 // generator.py:75): output pixel (oy, ox) of an H x W image, res is [B][H/2][W/2][res_ld]
-__device__ __forceinline__ float4 res_up2_sample(const float* __restrict__ res, int b, int oy, int ox, int H, int W, int res_ld,
+template <int ST = PPST_ST_F32>
+__device__ __forceinline__ float4 res_up2_sample(const void* __restrict__ res, int b, int oy, int ox, int H, int W, int res_ld,
                                                  int c) {
   const int h = H >> 1, w = W >> 1;
   float fy = fmaxf(((float)oy + 0.5f) * 0.5f - 0.5f, 0.f), fx = fmaxf(((float)ox + 0.5f) * 0.5f - 0.5f, 0.f);
   int y0 = (int)fy, x0 = (int)fx;
   int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
   float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
-  const float* base = res + (int64_t)b * h * w * res_ld + c;
-  float4 v00 = *(const float4*)(base + ((int64_t)y0 * w + x0) * res_ld);
-  float4 v01 = *(const float4*)(base + ((int64_t)y0 * w + x1) * res_ld);
-  float4 v10 = *(const float4*)(base + ((int64_t)y1 * w + x0) * res_ld);
-  float4 v11 = *(const float4*)(base + ((int64_t)y1 * w + x1) * res_ld);
+  const int64_t base = (int64_t)b * h * w * res_ld + c;
+  float4 v00 = st_ld4<ST>(res, base + ((int64_t)y0 * w + x0) * res_ld);
+  float4 v01 = st_ld4<ST>(res, base + ((int64_t)y0 * w + x1) * res_ld);
+  float4 v10 = st_ld4<ST>(res, base + ((int64_t)y1 * w + x0) * res_ld);
+  float4 v11 = st_ld4<ST>(res, base + ((int64_t)y1 * w + x1) * res_ld);
   float4 o;
   o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
   o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
@@ -189,8 +190,8 @@ struct ApplyArgs {
   int res_ld, y_ld, actf; float out_scale;
   int res_up2;  // residual is half-resolution, bilinearly upsampled x2 on the fly
 };
-template <int MODE, bool APPLY>
-__global__ __launch_bounds__(256) void chan_reduce4_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+template <int MODE, bool APPLY, int XS = PPST_ST_F32>
+__global__ __launch_bounds__(256) void chan_reduce4_kernel(const void* __restrict__ x, const float* __restrict__ mask,
                                                            float* __restrict__ partial, int H, int W, int C, int ld,
                                                            int rep_pad, int nchunks, ApplyArgs ap, int PIX_CHUNK, FastDiv d_w) {
   __shared__ float4 s0[256], s1[256];
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void chan_reduce4_kernel(const float* __restri
         const int64_t bp = (int64_t)b * P + p;
         unsigned pxu = 0;
         const int py = (APPLY || MODE == 0) ? (int)fd_divmod((unsigned)p, d_w, pxu) : 0, px = (int)pxu;
-        float4 v = *(const float4*)(x + bp * ld + c);
+        float4 v = st_ld4<XS>(x, bp * ld + c);
         if (APPLY) {
           float t[4] = {sa.x * v.x + sb.x, sa.y * v.y + sb.y, sa.z * v.z + sb.z, sa.w * v.w + sb.w};
           float r[4] = {0.f, 0.f, 0.f, 0.f};
@@ -290,7 +291,7 @@ extern "C" int ppst_in_stats(const void* x, void* partial, int B, int H, int W, 
   if (!x || !partial) return PPST_ENULL;
   if (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0) {
     ApplyArgs ap = {};
-    PPST_LAUNCH((chan_reduce4_kernel<0, false>), dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
+    PPST_LAUNCH((chan_reduce4_kernel<0, false>), dim3(nchunks, B), dim3(256), 0, as_stream(stream), x,
                 (const float*)nullptr, (float*)partial, H, W, C, ld, rep_pad, nchunks, ap, chunk, make_fastdiv(W));
   } else {
     PPST_LAUNCH(chan_reduce_kernel<0>, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
@@ -386,10 +387,11 @@ __device__ __forceinline__ float act_apply(float t, int act, float slope) {
   if (act == PPST_ACT_PRELU) return t >= 0.f ? t : t * slope;
   return t;
 }
-template <bool VEC>
-__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ ss,
-                                                         const float* __restrict__ res, const float* __restrict__ rss,
-                                                         float* __restrict__ y, unsigned hw, int C, int x_ld, int res_ld,
+// XS: storage type of x and res, YS: of y (common.h; the scalar form is fp32 only)
+template <bool VEC, int XS = PPST_ST_F32, int YS = PPST_ST_F32>
+__global__ __launch_bounds__(256) void affine_act_kernel(const void* __restrict__ xv_, const float* __restrict__ ss,
+                                                         const void* __restrict__ res, const float* __restrict__ rss,
+                                                         void* __restrict__ yv_, unsigned hw, int C, int x_ld, int res_ld,
                                                          int y_ld, int actf,
                                                          const float* __restrict__ prelu, float out_scale, unsigned total,
                                                          int up2_w, FastDiv d_cv, FastDiv d_hw, FastDiv d_w) {
@@ -397,6 +399,9 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
   const bool res_first = (actf >> 8) & 1;
   const float slope = (act == PPST_ACT_PRELU && prelu) ? prelu[0] : 0.f;
   constexpr int V = VEC ? 4 : 1;
+  static_assert(VEC || (XS == PPST_ST_F32 && YS == PPST_ST_F32), "scalar form: fp32 storage only");
+  const float* x = (const float*)xv_;
+  float* y = (float*)yv_;
   const int cv = C / V;
   (void)cv;
   // 32-bit indices + multiplier division (host guarantees total <= PPST_IDX32_MAX)
@@ -411,22 +416,22 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
     const float* rp = (res && rss) ? rss + ((int64_t)b * C + c) * 2 : nullptr;
     float xv[V], rv[V], o[V];
     if (VEC) {
-      float4 v = *(const float4*)(x + bp * x_ld + c);
+      float4 v = st_ld4<XS>(xv_, bp * x_ld + c);
       xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
       if (res) {
         float4 r;
         if (up2_w > 0) {
           unsigned oxu;
           const int oy = (int)fd_divmod(bpu - (unsigned)b * hw, d_w, oxu), ox = (int)oxu;
-          r = res_up2_sample(res, b, oy, ox, (int)(hw / (unsigned)up2_w), up2_w, res_ld, c);
+          r = res_up2_sample<XS>(res, b, oy, ox, (int)(hw / (unsigned)up2_w), up2_w, res_ld, c);
         } else {
-          r = *(const float4*)(res + bp * res_ld + c);
+          r = st_ld4<XS>(res, bp * res_ld + c);
         }
         rv[0] = r.x; rv[1] = r.y; rv[2] = r.z; rv[3] = r.w;
       }
     } else {
       xv[0] = x[bp * x_ld + c];
-      if (res) rv[0] = res[bp * res_ld + c];
+      if (res) rv[0] = ((const float*)res)[bp * res_ld + c];
     }
 #pragma unroll
     for (int i = 0; i < V; ++i) {
@@ -437,33 +442,50 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
       if (res && !res_first) tt += rv[i];
       o[i] = tt * out_scale;
     }
-    if (VEC) *(float4*)(y + bp * y_ld + c) = make_float4(o[0], o[1], o[2], o[3]);
+    if (VEC) st_st4<YS>(yv_, bp * y_ld + c, make_float4(o[0], o[1], o[2], o[3]));
     else y[bp * y_ld + c] = o[0];
   }
 }
-extern "C" int ppst_affine_act(const void* x, const void* scale_shift, const void* res, const void* res_scale_shift, void* y,
-                               int B, int64_t hw, int C, int x_ld, int res_ld, int y_ld, int act, const void* prelu,
-                               float out_scale, int res_up2_w, void* stream) {
+extern "C" int ppst_affine_act_st(const void* x, const void* scale_shift, const void* res, const void* res_scale_shift, void* y,
+                                  int B, int64_t hw, int C, int x_ld, int res_ld, int y_ld, int act, const void* prelu,
+                                  float out_scale, int res_up2_w, int x_st, int y_st, void* stream) {
+  if ((unsigned)x_st > 2u || (unsigned)y_st > 2u || (x_st && y_st && x_st != y_st)) return PPST_EINVAL;
   if (res_up2_w < 0 || (res_up2_w > 0 && (!res || hw % res_up2_w || res_up2_w % 2 || (hw / res_up2_w) % 2 || C % 4))) return PPST_EINVAL;
   if (B < 0 || hw <= 0 || C <= 0 || x_ld < C || y_ld < C || (res && res_ld < C)) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!x || !y) return PPST_ENULL;
   if (res_up2_w > 0 && (x_ld % 4 || y_ld % 4 || res_ld % 4)) return PPST_EINVAL;
   bool vec = C % 4 == 0 && x_ld % 4 == 0 && y_ld % 4 == 0 && (!res || res_ld % 4 == 0) &&
-             (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) % 16 == 0);
+             (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) % (x_st || y_st ? 8 : 16) == 0);
+  if ((x_st || y_st) && !vec) return PPST_EINVAL;     // half storage: the 4-channel form only
   int64_t total = (int64_t)B * hw * (vec ? C / 4 : C);
   if (total > PPST_IDX32_MAX) return PPST_EINVAL;
   const FastDiv d_cv = make_fastdiv((unsigned)(vec ? C / 4 : C)), d_hw = make_fastdiv((unsigned)hw),
                 d_w = make_fastdiv(res_up2_w > 0 ? (unsigned)res_up2_w : 1u);
-  if (vec)
-    PPST_LAUNCH(affine_act_kernel<true>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
-                       (const float*)scale_shift, (const float*)res, (const float*)res_scale_shift, (float*)y, (unsigned)hw, C, x_ld,
-                       res_ld, y_ld, act, (const float*)prelu, out_scale, (unsigned)total, res_up2_w, d_cv, d_hw, d_w);
-  else
-    PPST_LAUNCH(affine_act_kernel<false>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
-                       (const float*)scale_shift, (const float*)res, (const float*)res_scale_shift, (float*)y, (unsigned)hw, C, x_ld,
+#define AA_GO(XS_, YS_)                                                                                                   \
+  PPST_LAUNCH((affine_act_kernel<true, XS_, YS_>), dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x,                \
+              (const float*)scale_shift, res, (const float*)res_scale_shift, y, (unsigned)hw, C, x_ld, res_ld, y_ld, act,   \
+              (const float*)prelu, out_scale, (unsigned)total, res_up2_w, d_cv, d_hw, d_w)
+  if (vec) {
+    if (x_st == PPST_ST_F16 && y_st == PPST_ST_F16) AA_GO(PPST_ST_F16, PPST_ST_F16);
+    else if (x_st == PPST_ST_F16) AA_GO(PPST_ST_F16, PPST_ST_F32);
+    else if (x_st == PPST_ST_BF16 && y_st == PPST_ST_BF16) AA_GO(PPST_ST_BF16, PPST_ST_BF16);
+    else if (x_st == PPST_ST_BF16) AA_GO(PPST_ST_BF16, PPST_ST_F32);
+    else if (y_st == PPST_ST_F16) AA_GO(PPST_ST_F32, PPST_ST_F16);
+    else if (y_st == PPST_ST_BF16) AA_GO(PPST_ST_F32, PPST_ST_BF16);
+    else AA_GO(PPST_ST_F32, PPST_ST_F32);
+  } else
+    PPST_LAUNCH(affine_act_kernel<false>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x,
+                       (const float*)scale_shift, res, (const float*)res_scale_shift, y, (unsigned)hw, C, x_ld,
                        res_ld, y_ld, act, (const float*)prelu, out_scale, (unsigned)total, 0, d_cv, d_hw, d_w);
+#undef AA_GO
   return PPST_LAUNCH_CHECK();
+}
+extern "C" int ppst_affine_act(const void* x, const void* scale_shift, const void* res, const void* res_scale_shift, void* y,
+                               int B, int64_t hw, int C, int x_ld, int res_ld, int y_ld, int act, const void* prelu,
+                               float out_scale, int res_up2_w, void* stream) {
+  return ppst_affine_act_st(x, scale_shift, res, res_scale_shift, y, B, hw, C, x_ld, res_ld, y_ld, act, prelu, out_scale, res_up2_w,
+                            PPST_ST_F32, PPST_ST_F32, stream);
 }
 
 // ppst_affine_act that also emits the instance-norm partials of its OUTPUT
@@ -484,7 +506,7 @@ extern "C" int ppst_affine_act_stats(const void* x, const void* scale_shift, con
   ap.prelu = (const float*)prelu; ap.res_ld = res_ld; ap.y_ld = y_ld; ap.actf = act; ap.out_scale = out_scale;
   ap.res_up2 = (res && res_up2) ? 1 : 0;
   if (ap.res_up2 && (H % 2 || W % 2)) return PPST_EINVAL;
-  PPST_LAUNCH((chan_reduce4_kernel<0, true>), dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
+  PPST_LAUNCH((chan_reduce4_kernel<0, true>), dim3(nchunks, B), dim3(256), 0, as_stream(stream), x,
               (const float*)nullptr, (float*)partial, H, W, C, x_ld, rep_pad, nchunks, ap, chunk, make_fastdiv(W));
   return PPST_LAUNCH_CHECK();
 }
@@ -530,17 +552,26 @@ extern "C" int64_t ppst_gap_gmp_ws(int B, int64_t hw, int C) {
   if (B <= 0 || hw <= 0) return 0;
   return cdiv64(hw, pix_chunk(B, hw)) * C * 2 * B * (int64_t)sizeof(float);
 }
-extern "C" int ppst_gap_gmp(const void* x, const void* mask, void* out, void* ws, int B, int H, int W, int C, int ld,
-                             void* stream) {
+extern "C" int ppst_gap_gmp_st(const void* x, const void* mask, void* out, void* ws, int B, int H, int W, int C, int ld,
+                                int x_st, void* stream) {
+  if ((unsigned)x_st > 2u || (x_st && (C % 4 || ld % 4 || (uintptr_t)x % 8))) return PPST_EINVAL;
   if (B < 0 || H <= 0 || W <= 0 || C <= 0 || ld < C) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!x || !out || !ws) return PPST_ENULL;
   if ((int64_t)H * W > 0x7fffffffll) return PPST_EINVAL;
   const int chunk = pix_chunk(B, (int64_t)H * W);
   int nchunks = (int)cdiv64((int64_t)H * W, chunk);
-  if (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0) {
+  if (x_st) {
     ApplyArgs ap = {};
-    PPST_LAUNCH((chan_reduce4_kernel<1, false>), dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
+    if (x_st == PPST_ST_F16)
+      PPST_LAUNCH((chan_reduce4_kernel<1, false, PPST_ST_F16>), dim3(nchunks, B), dim3(256), 0, as_stream(stream), x,
+                  (const float*)mask, (float*)ws, H, W, C, ld, 0, nchunks, ap, chunk, make_fastdiv(W));
+    else
+      PPST_LAUNCH((chan_reduce4_kernel<1, false, PPST_ST_BF16>), dim3(nchunks, B), dim3(256), 0, as_stream(stream), x,
+                  (const float*)mask, (float*)ws, H, W, C, ld, 0, nchunks, ap, chunk, make_fastdiv(W));
+  } else if (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0) {
+    ApplyArgs ap = {};
+    PPST_LAUNCH((chan_reduce4_kernel<1, false>), dim3(nchunks, B), dim3(256), 0, as_stream(stream), x,
                 (const float*)mask, (float*)ws, H, W, C, ld, 0, nchunks, ap, chunk, make_fastdiv(W));
   } else {
     PPST_LAUNCH(chan_reduce_kernel<1>, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x,
@@ -551,6 +582,10 @@ extern "C" int ppst_gap_gmp(const void* x, const void* mask, void* out, void* ws
   PPST_LAUNCH(gap_gmp_finalize_kernel, dim3(B * cdiv(C, FIN_CH)), dim3(256), 0, as_stream(stream),
                      (const float*)ws, nchunks, (float*)out, B, C, (double)H * W);
   return PPST_LAUNCH_CHECK();
+}
+extern "C" int ppst_gap_gmp(const void* x, const void* mask, void* out, void* ws, int B, int H, int W, int C, int ld,
+                             void* stream) {
+  return ppst_gap_gmp_st(x, mask, out, ws, B, H, W, C, ld, PPST_ST_F32, stream);
 }
 
 // ------------------------------------------------------ pooling / resize ---
@@ -717,7 +752,12 @@ __global__ __launch_bounds__(256) void upsample_nearest2_kernel(const float4* __
     y[t] = x[((b * H + (oy >> 1)) * W + (ox >> 1)) * c4n + c];
   }
 }
-extern "C" int ppst_upsample_nearest2(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+extern "C" int ppst_upsample_nearest2_st(const void* x, void* y, int B, int H, int W, int C, int st, void* stream) {
+  if ((unsigned)st > 2u) return PPST_EINVAL;
+  if (st) {                      // a copy: 8 half channels are one 16-byte item
+    if (C % 8) return PPST_EINVAL;
+    C /= 2;
+  }
   if (B < 0 || H <= 0 || W <= 0 || C <= 0 || C % 4) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!x || !y) return PPST_ENULL;
@@ -726,6 +766,9 @@ extern "C" int ppst_upsample_nearest2(const void* x, void* y, int B, int H, int 
   PPST_LAUNCH(upsample_nearest2_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float4*)x,
                      (float4*)y, H, W, C / 4, (unsigned)total, make_fastdiv(C / 4), make_fastdiv(2 * W), make_fastdiv(2 * H));
   return PPST_LAUNCH_CHECK();
+}
+extern "C" int ppst_upsample_nearest2(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+  return ppst_upsample_nearest2_st(x, y, B, H, W, C, PPST_ST_F32, stream);
 }
 
 __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C,
@@ -756,8 +799,9 @@ extern "C" int ppst_maxpool2(const void* x, void* y, int B, int H, int W, int C,
 // Cin <= 4 (FromRGB): thread = (pixel, 4 output channels).  The grid stride is a multiple of
 // cout/4, so a thread keeps its output-channel group: its 4 x cin weights and biases are loaded
 // once, the loop is one pixel read + one 16-B store.
+template <int YS = PPST_ST_F32>
 __global__ __launch_bounds__(256) void conv1x1_small_cin_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                const float* __restrict__ bias, float* __restrict__ y,
+                                                                const float* __restrict__ bias, void* __restrict__ y,
                                                                 int64_t npix, int cin, int in_ld, int cout, float wscale,
                                                                 int act, FastDiv d_c) {
   const unsigned t0 = blockIdx.x * 256 + threadIdx.x;
@@ -784,11 +828,12 @@ __global__ __launch_bounds__(256) void conv1x1_small_cin_kernel(const float* __r
       for (int ci = 0; ci < 4; ++ci) acc += xv[ci] * wr[j][ci];  // ci >= cin adds +0 (same sum as the cin-term loop)
       o[j] = act_apply(acc + br[j], act, 0.f);
     }
-    *(float4*)(y + p * cout + co) = make_float4(o[0], o[1], o[2], o[3]);
+    st_st4<YS>(y, p * cout + co, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
-extern "C" int ppst_conv1x1_small_cin(const void* x, const void* w, const void* bias, void* y, int64_t npix, int cin,
-                                      int in_ld, int cout, float wscale, int act, void* stream) {
+extern "C" int ppst_conv1x1_small_cin_st(const void* x, const void* w, const void* bias, void* y, int64_t npix, int cin,
+                                         int in_ld, int cout, float wscale, int act, int y_st, void* stream) {
+  if ((unsigned)y_st > 2u) return PPST_EINVAL;
   if (npix < 0 || cin <= 0 || cin > 4 || in_ld < cin || cout <= 0 || cout % 4) return PPST_EINVAL;
   if (npix == 0) return PPST_OK;
   if (!x || !w || !y) return PPST_ENULL;
@@ -800,14 +845,19 @@ extern "C" int ppst_conv1x1_small_cin(const void* x, const void* w, const void* 
   const int unit = c4n / g;
   int64_t blocks = (int64_t)grid_for(total);
   blocks = ((blocks + unit - 1) / unit) * unit;
-  PPST_LAUNCH(conv1x1_small_cin_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)x,
-                     (const float*)w, (const float*)bias, (float*)y, npix, cin, in_ld, cout, wscale, act, make_fastdiv(c4n));
+  PPST_ST_SWITCH(y_st, PPST_LAUNCH(conv1x1_small_cin_kernel<ST_>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)x,
+                                   (const float*)w, (const float*)bias, y, npix, cin, in_ld, cout, wscale, act, make_fastdiv(c4n)));
   return PPST_LAUNCH_CHECK();
+}
+extern "C" int ppst_conv1x1_small_cin(const void* x, const void* w, const void* bias, void* y, int64_t npix, int cin,
+                                      int in_ld, int cout, float wscale, int act, void* stream) {
+  return ppst_conv1x1_small_cin_st(x, w, bias, y, npix, cin, in_ld, cout, wscale, act, PPST_ST_F32, stream);
 }
 
 // Cout <= 4 (ToRGB): 32 lanes cooperate on one pixel (float4 of channels each, strided over
 // Cin), xor-shuffle reduction inside the half wave.
-__global__ __launch_bounds__(256) void conv1x1_small_cout_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int XS = PPST_ST_F32>
+__global__ __launch_bounds__(256) void conv1x1_small_cout_kernel(const void* __restrict__ x, const float* __restrict__ w,
                                                                  const float* __restrict__ bias, float* __restrict__ y,
                                                                  int64_t npix, int cin, int cout, float wscale) {
   const int hl = threadIdx.x & 31;
@@ -816,7 +866,7 @@ __global__ __launch_bounds__(256) void conv1x1_small_cout_kernel(const float* __
   for (int64_t p = half_id; p < npix; p += nhalf) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c = hl * 4; c < cin; c += 128) {
-      float4 v = *(const float4*)(x + p * cin + c);
+      float4 v = st_ld4<XS>(x, p * cin + c);
       for (int j = 0; j < cout; ++j) {
         float4 ww = *(const float4*)(w + (int64_t)j * cin + c);
         acc[j] += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
@@ -835,7 +885,8 @@ __global__ __launch_bounds__(256) void conv1x1_small_cout_kernel(const float* __
 // Cout == 3 (ToRGB): 32 lanes x 8 pixels per iteration.  Each lane keeps 8 x 3 partial dot products over its
 // channel slice; the cross-lane sum is a transposing butterfly that halves the value count at offsets 16, 8, 4
 // (24 -> 12 -> 6 -> 3 values) and finishes with a 2-stage butterfly: 27 shuffles per 8 pixels instead of 15 per pixel.
-__global__ __launch_bounds__(256) void conv1x1_cout3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int XS = PPST_ST_F32>
+__global__ __launch_bounds__(256) void conv1x1_cout3_kernel(const void* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ y,
                                                             int64_t npix, int cin, float wscale) {
   const int hl = threadIdx.x & 31;
@@ -852,7 +903,7 @@ __global__ __launch_bounds__(256) void conv1x1_cout3_kernel(const float* __restr
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int64_t p = p0 + k < npix ? p0 + k : npix - 1;
-        xv[k] = *(const float4*)(x + p * cin + c);
+        xv[k] = st_ld4<XS>(x, p * cin + c);
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -889,19 +940,24 @@ __global__ __launch_bounds__(256) void conv1x1_cout3_kernel(const float* __restr
   }
 }
 
-extern "C" int ppst_conv1x1_small_cout(const void* x, const void* w, const void* bias, void* y, int64_t npix, int cin,
-                                       int cout, float wscale, void* stream) {
+extern "C" int ppst_conv1x1_small_cout_st(const void* x, const void* w, const void* bias, void* y, int64_t npix, int cin,
+                                          int cout, float wscale, int x_st, void* stream) {
+  if ((unsigned)x_st > 2u || (x_st && (uintptr_t)x % 8)) return PPST_EINVAL;
   if (npix < 0 || cin <= 0 || cin % 4 || cout <= 0 || cout > 4) return PPST_EINVAL;
   if (npix == 0) return PPST_OK;
   if (!x || !w || !y) return PPST_ENULL;
-  if (cout == 3 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0) {
-    PPST_LAUNCH(conv1x1_cout3_kernel, dim3(grid_for(cdiv64(npix, 8) * 32)), dim3(256), 0, as_stream(stream), (const float*)x,
-                (const float*)w, (const float*)bias, (float*)y, npix, cin, wscale);
+  if (cout == 3 && ((uintptr_t)x % (x_st ? 8 : 16)) == 0 && ((uintptr_t)w % 16) == 0) {
+    PPST_ST_SWITCH(x_st, PPST_LAUNCH(conv1x1_cout3_kernel<ST_>, dim3(grid_for(cdiv64(npix, 8) * 32)), dim3(256), 0, as_stream(stream), x,
+                                     (const float*)w, (const float*)bias, (float*)y, npix, cin, wscale));
     return PPST_LAUNCH_CHECK();
   }
-  PPST_LAUNCH(conv1x1_small_cout_kernel, dim3(grid_for(npix * 32)), dim3(256), 0, as_stream(stream),
-                     (const float*)x, (const float*)w, (const float*)bias, (float*)y, npix, cin, cout, wscale);
+  PPST_ST_SWITCH(x_st, PPST_LAUNCH(conv1x1_small_cout_kernel<ST_>, dim3(grid_for(npix * 32)), dim3(256), 0, as_stream(stream),
+                                   x, (const float*)w, (const float*)bias, (float*)y, npix, cin, cout, wscale));
   return PPST_LAUNCH_CHECK();
+}
+extern "C" int ppst_conv1x1_small_cout(const void* x, const void* w, const void* bias, void* y, int64_t npix, int cin,
+                                       int cout, float wscale, void* stream) {
+  return ppst_conv1x1_small_cout_st(x, w, bias, y, npix, cin, cout, wscale, PPST_ST_F32, stream);
 }
 
 // --------------------------------------------------------------- misc glue --
@@ -918,8 +974,9 @@ extern "C" int ppst_lerp(const void* a, const void* b, void* y, int64_t n, float
   return PPST_LAUNCH_CHECK();
 }
 
+template <int YS = PPST_ST_F32>
 __global__ __launch_bounds__(256) void spatial_mod_kernel(const float* __restrict__ x, const float* __restrict__ sc,
-                                                          const float* __restrict__ bi, float* __restrict__ y,
+                                                          const float* __restrict__ bi, void* __restrict__ y,
                                                           int C, unsigned total, FastDiv d_c, FastDiv d_hw) {
   for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
     unsigned cq;
@@ -929,20 +986,25 @@ __global__ __launch_bounds__(256) void spatial_mod_kernel(const float* __restric
     float4 v = *(const float4*)(x + bp * C + c);
     float4 s = *(const float4*)(sc + (int64_t)b * C + c);
     float4 o = *(const float4*)(bi + (int64_t)b * C + c);
-    *(float4*)(y + bp * C + c) = make_float4(v.x * s.x + o.x, v.y * s.y + o.y, v.z * s.z + o.z, v.w * s.w + o.w);
+    st_st4<YS>(y, bp * C + c, make_float4(v.x * s.x + o.x, v.y * s.y + o.y, v.z * s.z + o.z, v.w * s.w + o.w));
   }
 }
-extern "C" int ppst_spatial_modulation(const void* x, const void* scale, const void* bias, void* y, int B, int64_t hw, int C,
-                                       void* stream) {
+extern "C" int ppst_spatial_modulation_st(const void* x, const void* scale, const void* bias, void* y, int B, int64_t hw, int C,
+                                          int y_st, void* stream) {
+  if ((unsigned)y_st > 2u) return PPST_EINVAL;
   if (B < 0 || hw <= 0 || C <= 0 || C % 4) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!x || !scale || !bias || !y) return PPST_ENULL;
   int64_t total = (int64_t)B * hw * (C / 4);
   if (total > PPST_IDX32_MAX || hw > PPST_IDX32_MAX) return PPST_EINVAL;
-  PPST_LAUNCH(spatial_mod_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
-                     (const float*)scale, (const float*)bias, (float*)y, C, (unsigned)total, make_fastdiv(C / 4),
-                     make_fastdiv((unsigned)hw));
+  PPST_ST_SWITCH(y_st, PPST_LAUNCH(spatial_mod_kernel<ST_>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x,
+                                   (const float*)scale, (const float*)bias, y, C, (unsigned)total, make_fastdiv(C / 4),
+                                   make_fastdiv((unsigned)hw)));
   return PPST_LAUNCH_CHECK();
+}
+extern "C" int ppst_spatial_modulation(const void* x, const void* scale, const void* bias, void* y, int B, int64_t hw, int C,
+                                       void* stream) {
+  return ppst_spatial_modulation_st(x, scale, bias, y, B, hw, C, PPST_ST_F32, stream);
 }
 
 // util.tensor2im (util/util.py:125-131): NCHW [-1,1] -> HWC uint8, clip then truncate.

@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256) void upfirdn2d_planes(const float* __restrict_
 // DOWN = 2 keeps every second sample (the blur in front of a stride-2 1x1 conv only needs
 // those).  S2D writes the output space-to-depth: out[m][oy>>1][ox>>1][((oy&1)*2+(ox&1))*C + c]
 // with spatial extent ceil(out/2) -- the layout the fused conv consumes for stride-2 3x3 convs.
-template <int KH, int KW, int DOWN, bool S2D>
-__global__ __launch_bounds__(256) void upfirdn2d_chan(const float4* __restrict__ x, float4* __restrict__ y, UfParams p, unsigned nwork,
+// ST: storage type of x and y (common.h): the taps are accumulated in fp32 either way, rounded once at the store
+template <int KH, int KW, int DOWN, bool S2D, int ST = PPST_ST_F32>
+__global__ __launch_bounds__(256) void upfirdn2d_chan(const void* __restrict__ x, void* __restrict__ y, UfParams p, unsigned nwork,
                                                       FastDiv d_c, FastDiv d_xs, FastDiv d_oh) {
   // One thread = PX x PY output pixels x 4 channels: the (PY-1+KH) x ((PX-1)*DOWN+KW) input patch is read once into
   // registers (DOWN = 1, PY = 4: 6 x 6 loads for 16 outputs; the rows shared with the thread above / below come through L2).
@@ -130,14 +131,14 @@ __global__ __launch_bounds__(256) void upfirdn2d_chan(const float4* __restrict__
       int iy = oy0 * DOWN + ry - p.pad_y0;
       if (p.pad_mode == PPST_PAD_REFLECT) iy = uf_reflect(iy, p.in_h);
       bool yok = any_row && iy >= 0 && iy < p.in_h;
-      const float4* row = x + ((int64_t)m * p.in_h + (yok ? iy : 0)) * p.in_w * c4n + c4;
+      const int64_t row = ((int64_t)m * p.in_h + (yok ? iy : 0)) * p.in_w * c4n + c4;      // (units of 4 channels)
 #pragma unroll
       for (int j = 0; j < (PX - 1) * DOWN + KW; ++j) {
         int ix = ox0 * DOWN + j - p.pad_x0;
         if (p.pad_mode == PPST_PAD_REFLECT) ix = uf_reflect(ix, p.in_w);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (yok && ix >= 0 && ix < p.in_w) {
-          v = row[(int64_t)ix * c4n];
+          v = st_ld4<ST>(x, (row + (int64_t)ix * c4n) * 4);
           if (p.in_ss) {  // normalise on load; zero padding stays zero (it pads the normalised tensor)
             v.x = sa.x * v.x + sb.x; v.y = sa.y * v.y + sb.y; v.z = sa.z * v.z + sb.z; v.w = sa.w * v.w + sb.w;
             if (p.in_act == PPST_ACT_LRELU) {
@@ -172,15 +173,15 @@ __global__ __launch_bounds__(256) void upfirdn2d_chan(const float4* __restrict__
         for (int i = 0; i < PX; ++i) {
           int ox = ox0 + i;
           if (ox < ew)
-            y[((((int64_t)m * oh2 + (oy >> 1)) * ow2 + (ox >> 1)) * 4 + (oy & 1) * 2 + (ox & 1)) * c4n + c4] =
-                (row_ok && ox < p.out_w) ? acc[py][i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            st_st4<ST>(y, (((((int64_t)m * oh2 + (oy >> 1)) * ow2 + (ox >> 1)) * 4 + (oy & 1) * 2 + (ox & 1)) * c4n + c4) * 4,
+                       (row_ok && ox < p.out_w) ? acc[py][i] : make_float4(0.f, 0.f, 0.f, 0.f));
         }
       } else {
         if (!row_ok) continue;
-        float4* orow = y + ((int64_t)m * p.out_h + oy) * p.out_w * c4n + c4;
+        const int64_t orow = ((int64_t)m * p.out_h + oy) * p.out_w * c4n + c4;
 #pragma unroll
         for (int i = 0; i < PX; ++i)
-          if (ox0 + i < p.out_w) orow[(int64_t)(ox0 + i) * c4n] = acc[py][i];
+          if (ox0 + i < p.out_w) st_st4<ST>(y, (orow + (int64_t)(ox0 + i) * c4n) * 4, acc[py][i]);
       }
     }
   }
@@ -242,8 +243,8 @@ __global__ __launch_bounds__(256) void upfirdn2d_up2_chan(const float4* __restri
   }
 }
 
-template <int KH, int KW>
-static int launch_chan(const float* x, float* y, const UfParams& p, int down, bool s2d, hipStream_t st) {
+template <int KH, int KW, int ST = PPST_ST_F32>
+static int launch_chan(const void* x, void* y, const UfParams& p, int down, bool s2d, hipStream_t st) {
   const int eh = s2d ? ((p.out_h + 1) & ~1) : p.out_h, ew = s2d ? ((p.out_w + 1) & ~1) : p.out_w;
   const int rows = down == 1 ? cdiv(eh, UF_PY) : eh;   // row groups: UF_PY output rows per thread when down == 1
   int64_t nwork = (int64_t)p.major * rows * cdiv(ew, 4) * (p.minor / 4);
@@ -253,9 +254,9 @@ static int launch_chan(const float* x, float* y, const UfParams& p, int down, bo
   dim3 g((unsigned)blocks), b(256);
   const FastDiv d_c = make_fastdiv(p.minor / 4), d_xs = make_fastdiv(cdiv(ew, 4)), d_oh = make_fastdiv(rows);
   const unsigned nw = (unsigned)nwork;
-  if (s2d) PPST_LAUNCH((upfirdn2d_chan<KH, KW, 1, true>), g, b, 0, st, (const float4*)x, (float4*)y, p, nw, d_c, d_xs, d_oh);
-  else if (down == 2) PPST_LAUNCH((upfirdn2d_chan<KH, KW, 2, false>), g, b, 0, st, (const float4*)x, (float4*)y, p, nw, d_c, d_xs, d_oh);
-  else PPST_LAUNCH((upfirdn2d_chan<KH, KW, 1, false>), g, b, 0, st, (const float4*)x, (float4*)y, p, nw, d_c, d_xs, d_oh);
+  if (s2d) PPST_LAUNCH((upfirdn2d_chan<KH, KW, 1, true, ST>), g, b, 0, st, x, y, p, nw, d_c, d_xs, d_oh);
+  else if (down == 2) PPST_LAUNCH((upfirdn2d_chan<KH, KW, 2, false, ST>), g, b, 0, st, x, y, p, nw, d_c, d_xs, d_oh);
+  else PPST_LAUNCH((upfirdn2d_chan<KH, KW, 1, false, ST>), g, b, 0, st, x, y, p, nw, d_c, d_xs, d_oh);
   return PPST_LAUNCH_CHECK();
 }
 
@@ -317,9 +318,11 @@ extern "C" int ppst_upfirdn2d(const void* x, const void* k, void* y, int major, 
 // runs nn.ReflectionPad2d first, :151-159), optional decimation by 2 (all a following
 // stride-2 1x1 conv reads) or space-to-depth output for a following stride-2 3x3 conv:
 //   s2d: y [B][ceil(oh/2)][ceil(ow/2)][4*C], phase (oy&1)*2+(ox&1) major over channels.
-extern "C" int ppst_blur_nhwc(const void* x, const void* k, void* y, int B, int in_h, int in_w, int C, int ksize, int pad0,
-                              int pad1, int pad_mode, int down, int s2d, const void* in_scale_shift, int in_act, void* stream) {
+extern "C" int ppst_blur_nhwc_st(const void* x, const void* k, void* y, int B, int in_h, int in_w, int C, int ksize, int pad0,
+                                 int pad1, int pad_mode, int down, int s2d, const void* in_scale_shift, int in_act, int st,
+                                 void* stream) {
   if (!x || !k || !y) return PPST_ENULL;
+  if ((unsigned)st > 2u) return PPST_EINVAL;
   if (B < 0 || in_h <= 0 || in_w <= 0 || C <= 0 || C % 4 || (ksize != 3 && ksize != 4) || (down != 1 && down != 2) ||
       (s2d && down != 1) || (pad_mode != PPST_PAD_ZERO && pad_mode != PPST_PAD_REFLECT) ||
       (in_act != PPST_ACT_NONE && in_act != PPST_ACT_LRELU) || (in_act != PPST_ACT_NONE && !in_scale_shift))
@@ -334,6 +337,11 @@ extern "C" int ppst_blur_nhwc(const void* x, const void* k, void* y, int B, int 
   p.in_ss = (const float*)in_scale_shift; p.in_act = in_act;
   if (p.out_h <= 0 || p.out_w <= 0) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
-  if (ksize == 3) return launch_chan<3, 3>((const float*)x, (float*)y, p, down, s2d != 0, as_stream(stream));
-  return launch_chan<4, 4>((const float*)x, (float*)y, p, down, s2d != 0, as_stream(stream));
+  if (ksize == 3) PPST_ST_SWITCH(st, return (launch_chan<3, 3, ST_>(x, y, p, down, s2d != 0, as_stream(stream))));
+  PPST_ST_SWITCH(st, return (launch_chan<4, 4, ST_>(x, y, p, down, s2d != 0, as_stream(stream))));
+  return PPST_EINVAL;
+}
+extern "C" int ppst_blur_nhwc(const void* x, const void* k, void* y, int B, int in_h, int in_w, int C, int ksize, int pad0,
+                              int pad1, int pad_mode, int down, int s2d, const void* in_scale_shift, int in_act, void* stream) {
+  return ppst_blur_nhwc_st(x, k, y, B, in_h, in_w, C, ksize, pad0, pad1, pad_mode, down, s2d, in_scale_shift, in_act, PPST_ST_F32, stream);
 }

@@ -131,10 +131,12 @@ class BaseNetwork(nn.Module):
         print("[Network %s] Total number of parameters : %.3f M" % (type(self).__name__, n / 1e6))
 
     # -- ConvLayer / ResBlock of stylegan2_layers.py:497-579 on NHWC ---------
-    def from_rgb(self, x, p):
-        """ConvLayer(3, C, 1): 1x1 conv (no bias) + FusedLeakyReLU (HBM-bound kernel)."""
+    def from_rgb(self, x, p, out_dtype=torch.float32):
+        """ConvLayer(3, C, 1): 1x1 conv (no bias) + FusedLeakyReLU (HBM-bound kernel).  out_dtype: storage type the network's
+        trunk runs in (half-precision activation storage, ops.HALF_STORE: E1 / E2 pass ops.act_dtype(); every kernel downstream
+        keeps its input's type)."""
         w = self.p(p + "Conv.weight")
-        return ops.conv1x1_small_cin(x, w, self.p(p + "Act.bias"), 1.0 / math.sqrt(w.shape[1]), ops.ACT_LRELU)
+        return ops.conv1x1_small_cin(x, w, self.p(p + "Act.bias"), 1.0 / math.sqrt(w.shape[1]), ops.ACT_LRELU, out_dtype=out_dtype)
 
     def _norm_act(self, y, st, count, act_bias=None, act=ops.ACT_NONE, **kw):
         ss = ops.in_finalize(st, count, post_bias=act_bias)

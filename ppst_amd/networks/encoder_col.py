@@ -28,8 +28,8 @@ class StyleGAN2ResnetEncodercol(BaseNetwork):
         v = ops.linear(v, self.p(q + "5.weight"), self.p(q + "5.bias"), relu_in=True)
         return ops.l2norm_rows(v, 1e-12, 1)
 
-    def trunk(self, x):
-        feats = [self.from_rgb(to_nhwc(x), "FromRGB.")]
+    def trunk(self, x, dtype=torch.float32):
+        feats = [self.from_rgb(to_nhwc(x), "FromRGB.", out_dtype=dtype)]
         for i in range(3):
             feats.append(self.res_block(feats[-1], "DownToGlobalCode1.ResBlockDownBy%d." % (2 ** i), ops.PAD_REFLECT, norm=False))
         return feats
@@ -63,7 +63,9 @@ class StyleGAN2ResnetEncodercol(BaseNetwork):
         return levels
 
     def forward(self, x=None, extract_features=False, mask=None, corrmatrix=None):
-        feats = self.trunk(x)
+        # half-precision activation storage (ops.HALF_STORE) for the plain code pass; the warp / masked heads (pooling,
+        # bilinear resize, the correspondence GEMM) read fp32 features
+        feats = self.trunk(x, ops.act_dtype() if (corrmatrix is None and mask is None) else torch.float32)
         vectors = [self._head(t, f) for t, f in zip(TAGS, feats)]
         vectors_w, pm, pmw = [], [], []
         warped = None

@@ -4,6 +4,8 @@ padding, [1,2,1] blur and InstanceNorm (32->64->128->256), ToSpatialCode = two 1
 InstanceNorm.  forward(x NCHW) -> sp (B,256,H/8,W/8)."""
 import math
 
+import torch
+
 from .. import ops
 from .base_network import BaseNetwork, as_nchw, to_nhwc
 
@@ -12,7 +14,7 @@ class StyleGAN2ResnetEncodercon(BaseNetwork):
     prefix = "E1."
 
     def forward(self, x, extract_features=False, patch_ids=None):
-        x = self.from_rgb(to_nhwc(x), "FromRGB.")
+        x = self.from_rgb(to_nhwc(x), "FromRGB.", out_dtype=ops.act_dtype())
         for i in range(3):
             x = self.res_block(x, "DownToSpatialCode.ResBlockDownBy%d." % (2 ** i), ops.PAD_REFLECT, norm=True)
         B, H, W, C = x.shape
@@ -20,5 +22,5 @@ class StyleGAN2ResnetEncodercon(BaseNetwork):
         y, st = self.plan("ToSpatialCode.0.Conv.weight", scale=sc)(x, stats=True)
         x, _ = self._norm_act(y, st, H * W, self.p("ToSpatialCode.0.Act.bias"), ops.ACT_LRELU)
         y, st = self.plan("ToSpatialCode.1.Conv.weight", scale=sc)(x, bias=self.p("ToSpatialCode.1.Conv.bias"), stats=True)
-        sp, _ = self._norm_act(y, st, H * W)
+        sp, _ = self._norm_act(y, st, H * W, out_dtype=torch.float32)    # the spatial code leaves the network as fp32
         return as_nchw(sp)

@@ -160,7 +160,10 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
         inv = 1.0 / math.sqrt(ws.shape[1])
         scale = ops.linear(g, ws, self.p("SpatialCodeModulation.scale.bias"), wscale=inv)
         shift = ops.linear(g, self.p("SpatialCodeModulation.bias.weight"), self.p("SpatialCodeModulation.bias.bias"), wscale=inv)
-        x = ops.spatial_modulation(sp if sp.is_contiguous() else sp.contiguous(), scale, shift)
+        # half-precision activation storage (ops.HALF_STORE): the plain image pass runs in ops.act_dtype(); the feature-extraction
+        # pass (correspondence heads, pooled / resized copies) keeps fp32 storage
+        adt = torch.float32 if extract_features else ops.act_dtype()
+        x = ops.spatial_modulation(sp if sp.is_contiguous() else sp.contiguous(), scale, shift, out_dtype=adt)
         for i, (ci, co) in enumerate(HEAD_CH):
             q = "HeadResnetBlock%d." % i
             skip = x if ci == co else self.plan(q + "skip.Conv.weight", scale=1.0 / math.sqrt(ci))(x)

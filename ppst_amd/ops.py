@@ -7,6 +7,7 @@ of such tensors: pixel stride ``ld`` = stride(2)).
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -120,9 +121,38 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def _nhwc_ld(t, name="activation"):
-    """validate a (B,H,W,C) tensor or channel-slice view; return pixel stride."""
-    _chk(t, name)
+_ST = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}       # PPST_ST_* of include/ppst_hip.h
+# Half-precision activation storage (round 4, ppst_conv_args.io_st and the `_st` entry points): in the single-pass precision modes
+# the NHWC activations of the inference networks (E1, E2, the generator without feature extraction) live in HBM in the operand
+# type of the mode -- IEEE half in mode 3, bfloat16 in mode 1 -- instead of fp32: every elementwise pass, blur and HBM-bound conv
+# of those paths moves half the bytes.  Accumulation, statistics and the (scale, shift) pairs stay fp32; a kernel rounds once, at
+# its store.  Off: fp32 storage in every mode (the round-3 behaviour).  Training keeps fp32 storage either way.
+HALF_STORE = {"value": os.environ.get("PPST_HALF_STORE", "1") != "0"}     # (the env switch: A/B runs of bench.py / the tests)
+
+
+def act_dtype():
+    """storage type of the inference networks' activations in the current precision mode"""
+    if HALF_STORE["value"] and not torch.is_grad_enabled():
+        return {1: torch.bfloat16, 3: torch.float16}.get(PRECISION["value"], torch.float32)
+    return torch.float32
+
+
+def _chk_act(t, name="activation"):
+    if t is None:
+        return
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA (HIP) tensor" % name)
+    if t.dtype not in _ST:
+        raise RuntimeError("%s must be float32, float16 or bfloat16, got %s" % (name, t.dtype))
+
+
+def _nhwc_ld(t, name="activation", half_ok=False):
+    """validate a (B,H,W,C) tensor or channel-slice view; return pixel stride (elements).  half_ok: the caller's kernel takes a
+    storage type (fp16 / bf16 tensors allowed); everything else insists on float32."""
+    if half_ok:
+        _chk_act(t, name)
+    else:
+        _chk(t, name)
     B, H, W, C = t.shape
     ld = t.stride(2)
     if t.stride(3) != 1 or t.stride(1) != W * ld or (B > 1 and t.stride(0) != H * W * ld):
@@ -172,7 +202,7 @@ def upfirdn2d_raw(x4, kernel, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
 
 
 def blur_nhwc(x, kernel, pad0, pad1, pad_mode=PAD_ZERO, down=1, s2d=False, in_ss=None, in_act=ACT_NONE):
-    ld = _nhwc_ld(x)
+    ld = _nhwc_ld(x, half_ok=True)
     B, H, W, C = x.shape
     if ld != C:
         raise RuntimeError("blur_nhwc needs a dense tensor")
@@ -181,12 +211,12 @@ def blur_nhwc(x, kernel, pad0, pad1, pad_mode=PAD_ZERO, down=1, s2d=False, in_ss
     oh = (H + pad0 + pad1 - ks + down) // down
     ow = (W + pad0 + pad1 - ks + down) // down
     if s2d:
-        y = torch.empty((B, (oh + 1) // 2, (ow + 1) // 2, 4 * C), device=x.device, dtype=torch.float32)
+        y = torch.empty((B, (oh + 1) // 2, (ow + 1) // 2, 4 * C), device=x.device, dtype=x.dtype)
     else:
-        y = torch.empty((B, oh, ow, C), device=x.device, dtype=torch.float32)
+        y = torch.empty((B, oh, ow, C), device=x.device, dtype=x.dtype)
     _chk(in_ss, "in_ss")
-    check(lib.ppst_blur_nhwc(_p(x), _p(kernel.contiguous()), _p(y), B, H, W, C, ks, pad0, pad1, pad_mode, down,
-                             1 if s2d else 0, _p(in_ss), in_act, _stream()), "ppst_blur_nhwc")
+    check(lib.ppst_blur_nhwc_st(_p(x), _p(kernel.contiguous()), _p(y), B, H, W, C, ks, pad0, pad1, pad_mode, down,
+                                1 if s2d else 0, _p(in_ss), in_act, _ST[x.dtype], _stream()), "ppst_blur_nhwc")
     return y, (oh, ow)
 
 
@@ -581,8 +611,11 @@ class ConvPlan:
     def __call__(self, x, bias=None, noise=None, noise_weight=0.0, act=ACT_NONE, prelu=None, stats=False,
                  residual=None, out=None, out_scale=1.0, pad_mode=PAD_ZERO, out_hw=None, res_after_act=False,
                  in_ss=None, in_act=ACT_NONE, in_prelu=None, presplit=False):
-        in_ld = _nhwc_ld(x, "conv input")
+        in_ld = _nhwc_ld(x, "conv input", half_ok=True)
         B, H, W, xc = x.shape
+        if x.dtype != torch.float32 and {torch.float16: 3, torch.bfloat16: 1}[x.dtype] != self.precision:
+            raise RuntimeError("conv input stored as %s needs a plan of the matching single-pass precision mode (plan: mode %d)"
+                               % (x.dtype, self.precision))
         # the step table lives on the device: the C ABI cannot check these, and the kernel indexes
         # x[.. + chan + 32), in_ss[b][chan][2] and noise[(b*oh+oy)*ow+ox] blindly
         need_c = self.max_chan + 32
@@ -602,15 +635,18 @@ class ConvPlan:
         else:
             th, tw, oh, ow, osy = H, W, H, W, 1
         if out is None:
-            out = torch.empty((B, oh, ow, self.cout), device=x.device, dtype=torch.float32)
-        out_ld = _nhwc_ld(out, "conv output")
+            out = torch.empty((B, oh, ow, self.cout), device=x.device, dtype=x.dtype)
+        out_ld = _nhwc_ld(out, "conv output", half_ok=True)
+        if out.dtype != x.dtype or (residual is not None and residual.dtype != x.dtype):
+            raise RuntimeError("conv input, residual and output share one storage type (ppst_conv_args.io_st): got %s / %s / %s"
+                               % (x.dtype, None if residual is None else residual.dtype, out.dtype))
         if tuple(out.shape) != (B, oh, ow, self.cout):
             raise RuntimeError("conv output must be %s, got %s" % ((B, oh, ow, self.cout), tuple(out.shape)))
         if noise is not None and (noise.numel() != B * oh * ow or not noise.is_contiguous()):
             raise RuntimeError("noise must be a contiguous (B,1,%d,%d) tensor with B = %d rows, got %s" % (oh, ow, B, tuple(noise.shape)))
         if residual is not None and tuple(residual.shape) != (B, oh, ow, self.cout):
             raise RuntimeError("residual must match the output shape %s, got %s" % ((B, oh, ow, self.cout), tuple(residual.shape)))
-        for t, n in ((bias, "bias"), (noise, "noise"), (prelu, "prelu"), (residual, "residual")):
+        for t, n in ((bias, "bias"), (noise, "noise"), (prelu, "prelu")):
             _chk(t, n)
         variant, bn, rows = self.choose_kernel(th, tw, oh, ow, H, W, osy, B)
         st = None
@@ -627,7 +663,8 @@ class ConvPlan:
         a.dual_b = 1 if dual else 0
         a.bias, a.noise, a.prelu, a.stats = _p(bias), _p(noise), _p(prelu), _p(st)
         a.residual = _p(residual)
-        a.res_ld = _nhwc_ld(residual, "residual") if residual is not None else 0
+        a.res_ld = _nhwc_ld(residual, "residual", half_ok=True) if residual is not None else 0
+        a.io_st = _ST[x.dtype]
         a.noise_weight, a.out_scale = float(noise_weight), float(out_scale)
         a.B, a.in_h, a.in_w, a.in_ld = B, H, W, in_ld
         a.out_h, a.out_w, a.out_ld, a.cout = oh, ow, out_ld, self.cout
@@ -936,25 +973,25 @@ def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step):
                              _stream()), "ppst_adam_step")
 
 
-def conv1x1_small_cin(x, w, bias, wscale, act):
+def conv1x1_small_cin(x, w, bias, wscale, act, out_dtype=torch.float32):
     ld = _nhwc_ld(x)
     B, H, W, cin = x.shape
     cout = w.shape[0]
-    y = torch.empty((B, H, W, cout), device=x.device, dtype=torch.float32)
+    y = torch.empty((B, H, W, cout), device=x.device, dtype=out_dtype)
     w2 = w.detach().reshape(cout, cin).contiguous()
-    check(lib.ppst_conv1x1_small_cin(_p(x), _p(w2), _p(bias), _p(y), B * H * W, cin, ld, cout, float(wscale), act,
-                                     _stream()), "ppst_conv1x1_small_cin")
+    check(lib.ppst_conv1x1_small_cin_st(_p(x), _p(w2), _p(bias), _p(y), B * H * W, cin, ld, cout, float(wscale), act,
+                                        _ST[out_dtype], _stream()), "ppst_conv1x1_small_cin")
     return y
 
 
 def conv1x1_small_cout(x, w, bias, wscale):
-    ld = _nhwc_ld(x)
+    ld = _nhwc_ld(x, half_ok=True)
     B, H, W, cin = x.shape
     assert ld == cin
     cout = w.shape[0]
     y = torch.empty((B, H, W, cout), device=x.device, dtype=torch.float32)
     w2 = w.detach().reshape(cout, cin).contiguous()
-    check(lib.ppst_conv1x1_small_cout(_p(x), _p(w2), _p(bias), _p(y), B * H * W, cin, cout, float(wscale), _stream()),
+    check(lib.ppst_conv1x1_small_cout_st(_p(x), _p(w2), _p(bias), _p(y), B * H * W, cin, cout, float(wscale), _ST[x.dtype], _stream()),
           "ppst_conv1x1_small_cout")
     return y
 
@@ -1211,22 +1248,26 @@ def noise_wgrad(dpre, noise, out=None, accumulate=False):
 
 
 def affine_act(x, scale_shift=None, res=None, act=ACT_NONE, prelu=None, out_scale=1.0, res_before_act=False, out=None,
-               res_scale_shift=None, res_up2=False):
-    """res_up2: ``res`` is a half-resolution tensor, bilinearly upsampled x2 on the fly."""
-    x_ld = _nhwc_ld(x)
+               res_scale_shift=None, res_up2=False, out_dtype=None):
+    """res_up2: ``res`` is a half-resolution tensor, bilinearly upsampled x2 on the fly.  x (and res, which must share its type)
+    may be half-stored; the output takes out_dtype (default: x's type)."""
+    x_ld = _nhwc_ld(x, half_ok=True)
     B, H, W, C = x.shape
     if out is None:
-        out = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
-    y_ld = _nhwc_ld(out)
-    res_ld = _nhwc_ld(res, "res") if res is not None else 0
+        out = torch.empty((B, H, W, C), device=x.device, dtype=out_dtype or x.dtype)
+    y_ld = _nhwc_ld(out, half_ok=True)
+    res_ld = _nhwc_ld(res, "res", half_ok=True) if res is not None else 0
+    if res is not None and res.dtype != x.dtype:
+        raise RuntimeError("affine_act: res must have the storage type of x (%s), got %s" % (x.dtype, res.dtype))
     _chk(scale_shift, "scale_shift")
     _chk(res_scale_shift, "res_scale_shift")
     _chk(prelu, "prelu")
     if res_up2:
         assert res.shape[1] * 2 == H and res.shape[2] * 2 == W
     flag = act | (RES_BEFORE_ACT if res_before_act else 0)
-    check(lib.ppst_affine_act(_p(x), _p(scale_shift), _p(res), _p(res_scale_shift), _p(out), B, H * W, C, x_ld, res_ld, y_ld,
-                              flag, _p(prelu), float(out_scale), W if res_up2 else 0, _stream()), "ppst_affine_act")
+    check(lib.ppst_affine_act_st(_p(x), _p(scale_shift), _p(res), _p(res_scale_shift), _p(out), B, H * W, C, x_ld, res_ld, y_ld,
+                                 flag, _p(prelu), float(out_scale), W if res_up2 else 0, _ST[x.dtype], _ST[out.dtype], _stream()),
+          "ppst_affine_act")
     return out
 
 
@@ -1251,23 +1292,23 @@ def affine_act_stats(x, scale_shift=None, res=None, act=ACT_NONE, prelu=None, ou
 
 
 def upsample_nearest2(x):
-    ld = _nhwc_ld(x)
+    ld = _nhwc_ld(x, half_ok=True)
     B, H, W, C = x.shape
     assert ld == C
-    y = torch.empty((B, 2 * H, 2 * W, C), device=x.device, dtype=torch.float32)
-    check(lib.ppst_upsample_nearest2(_p(x), _p(y), B, H, W, C, _stream()), "ppst_upsample_nearest2")
+    y = torch.empty((B, 2 * H, 2 * W, C), device=x.device, dtype=x.dtype)
+    check(lib.ppst_upsample_nearest2_st(_p(x), _p(y), B, H, W, C, _ST[x.dtype], _stream()), "ppst_upsample_nearest2")
     return y
 
 
 # ------------------------------------------------------- pooling / resize ----
 def gap_gmp(x, mask=None):
     """(B,H,W,C) -> (B, 2C) = cat(mean, max) over pixels; mask (B,H,W) optional multiplier."""
-    ld = _nhwc_ld(x)
+    ld = _nhwc_ld(x, half_ok=True)
     B, H, W, C = x.shape
     _chk(mask, "mask")
     ws = torch.empty(lib.ppst_gap_gmp_ws(B, H * W, C) // 4, device=x.device, dtype=torch.float32)
     out = torch.empty((B, 2 * C), device=x.device, dtype=torch.float32)
-    check(lib.ppst_gap_gmp(_p(x), _p(mask), _p(out), _p(ws), B, H, W, C, ld, _stream()), "ppst_gap_gmp")
+    check(lib.ppst_gap_gmp_st(_p(x), _p(mask), _p(out), _p(ws), B, H, W, C, ld, _ST[x.dtype], _stream()), "ppst_gap_gmp")
     return out
 
 
@@ -1341,13 +1382,13 @@ def lerp(a, b, r):
     return y
 
 
-def spatial_modulation(x, scale, bias):
+def spatial_modulation(x, scale, bias, out_dtype=torch.float32):
     ld = _nhwc_ld(x)
     B, H, W, C = x.shape
     assert ld == C
-    y = torch.empty_like(x)
-    check(lib.ppst_spatial_modulation(_p(x), _p(scale.contiguous()), _p(bias.contiguous()), _p(y), B, H * W, C, _stream()),
-          "ppst_spatial_modulation")
+    y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    check(lib.ppst_spatial_modulation_st(_p(x), _p(scale.contiguous()), _p(bias.contiguous()), _p(y), B, H * W, C, _ST[out_dtype],
+                                         _stream()), "ppst_spatial_modulation")
     return y
 
 

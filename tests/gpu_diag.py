@@ -574,6 +574,97 @@ def t_conv_variants_single_pass():
             report("single-pass prec %d %s stats" % (prec, name), outs[1][1], outs[0][1], 1e-5)
 
 
+def t_half_storage():
+    """Half-precision activation storage (ppst_conv_args.io_st and the `_st` entry points; include/ppst_hip.h): a kernel given
+    IEEE-half (mode 3) / bfloat16 (mode 1) tensors computes in fp32 exactly as its fp32 form and rounds once, to nearest even, at
+    its store -- so every launch must equal, BIT FOR BIT, the fp32-storage launch on the widened inputs, rounded by torch.
+    Covers each kernel of the inference networks' paths: the four conv families in both single-pass modes (plain, normalise-on-load,
+    residual before / after the activation, noise, the scattered output of the fused upscale), blur (plain / decimating / space-to-
+    depth, normalise-on-load), affine_act (residual, residual affine, on-the-fly bilinear skip, fp32 output), FromRGB / ToRGB,
+    GAP+GMP, SpatialCodeModulation, nearest upsample."""
+    torch.manual_seed(21)
+    nz_ = torch.randn
+
+    def same(name, a, b):
+        ok = a.dtype == b.dtype and bool(torch.equal(a, b))
+        RES.append((name, ok))
+        d = (a.float() - b.float()).abs().max().item() if a.shape == b.shape else float("nan")
+        print("half storage %-58s %s max diff %.3e" % (name, "ok  " if ok else "FAIL", d), flush=True)
+
+    for prec, dt in ((3, torch.float16), (1, torch.bfloat16)):
+        tag = "fp16" if prec == 3 else "bf16"
+        h = lambda t: g(t).to(dt)                       # a stored activation
+        # ---- elementwise / blur / small convs
+        x = h(nz_(2, 24, 20, 64)); r = h(nz_(2, 24, 20, 64)); rh = h(nz_(2, 12, 10, 64))
+        ss = g(torch.rand(2, 64, 2) + 0.5); rss = g(torch.rand(2, 64, 2) + 0.5)
+        pre = g(torch.tensor([0.25]))
+        for name, kw in (("plain", {}), ("res", dict(res=r, out_scale=0.7)), ("res affine lrelu", dict(res=r, res_scale_shift=rss, act=ops.ACT_LRELU)),
+                         ("res before prelu", dict(res=r, res_before_act=True, act=ops.ACT_PRELU, prelu=pre)),
+                         ("res_up2", dict(res=rh, res_up2=True, out_scale=0.7))):
+            kwf = {k: (v.float() if isinstance(v, torch.Tensor) and v.dtype == dt else v) for k, v in kw.items()}
+            same("%s affine_act %s" % (tag, name), ops.affine_act(x, ss, **kw), ops.affine_act(x.float(), ss, **kwf).to(dt))
+        same("%s affine_act -> fp32" % tag, ops.affine_act(x, ss, res=r, out_dtype=torch.float32), ops.affine_act(x.float(), ss, res=r.float()))
+        same("%s affine_act fp32 -> half" % tag, ops.affine_act(x.float(), ss, out_dtype=dt), ops.affine_act(x.float(), ss).to(dt))
+        k3 = g(torch.tensor([1., 2., 1.])); k3 = (k3[:, None] * k3[None, :] / 16).contiguous()
+        k4 = g(torch.tensor([1., 3., 3., 1.])); k4 = (k4[:, None] * k4[None, :] / 64).contiguous()
+        xb = h(nz_(2, 37, 41, 32)); bss = g(torch.rand(2, 32, 2) + 0.5)
+        for name, kk, a_ in (("3x3 reflect s2d", k3, dict(pad0=1, pad1=1, pad_mode=ops.PAD_REFLECT, s2d=True)),
+                             ("3x3 reflect s2d in_ss lrelu", k3, dict(pad0=1, pad1=1, pad_mode=ops.PAD_REFLECT, s2d=True, in_ss=bss, in_act=ops.ACT_LRELU)),
+                             ("3x3 zero down 2", k3, dict(pad0=1, pad1=0, pad_mode=ops.PAD_ZERO, down=2)),
+                             ("4x4 zero", k4, dict(pad0=2, pad1=1, pad_mode=ops.PAD_ZERO)),
+                             ("4x4 zero s2d", k4, dict(pad0=2, pad1=2, pad_mode=ops.PAD_ZERO, s2d=True))):
+            p0, p1 = a_.pop("pad0"), a_.pop("pad1")
+            ya, hwa = ops.blur_nhwc(xb, kk, p0, p1, **a_)
+            yb, hwb = ops.blur_nhwc(xb.float(), kk, p0, p1, **a_)
+            same("%s blur %s" % (tag, name), ya, yb.to(dt))
+        img = g(nz_(2, 19, 23, 3)); w_in = g(nz_(32, 3, 1, 1)); b_in = g(nz_(32) * 0.1)
+        same("%s FromRGB (small cin) -> half" % tag, ops.conv1x1_small_cin(img, w_in, b_in, 0.5, ops.ACT_LRELU, out_dtype=dt),
+             ops.conv1x1_small_cin(img, w_in, b_in, 0.5, ops.ACT_LRELU).to(dt))
+        xr = h(nz_(2, 19, 23, 64)); w_out = g(nz_(3, 64, 1, 1)); b_out = g(nz_(3) * 0.1)
+        # (a 64-term dot product per output: the compiler contracts the two instantiations' multiply-adds differently -- last-bit
+        #  differences of an fp32 output, not a storage rounding)
+        report("half storage %s ToRGB (cout 3) from half" % tag, ops.conv1x1_small_cout(xr, w_out, b_out, 0.125),
+               ops.conv1x1_small_cout(xr.float(), w_out, b_out, 0.125), 1e-6)
+        same("%s gap_gmp" % tag, ops.gap_gmp(xr), ops.gap_gmp(xr.float()))
+        sp = g(nz_(2, 9, 7, 256)); sc = g(nz_(2, 256)); sh = g(nz_(2, 256))
+        same("%s spatial_modulation -> half" % tag, ops.spatial_modulation(sp, sc, sh, out_dtype=dt), ops.spatial_modulation(sp, sc, sh).to(dt))
+        same("%s upsample_nearest2" % tag, ops.upsample_nearest2(xr), ops.upsample_nearest2(xr.float()).to(dt))
+        # ---- the conv families of the mode
+        cases = (("tile 3x3 reflect 64->128 33x47", 2, 64, 128, 33, 47, "conv", 3, 1),
+                 ("tile convT 64->128 20x12", 2, 64, 128, 20, 12, "convT", 3, 0),
+                 ("N-256 3x3 zero 128->256 64x64", 2, 128, 256, 64, 64, "conv", 3, 0),
+                 ("N-256 convT 64->512 20x12", 2, 64, 512, 20, 12, "convT", 3, 0),
+                 ("stream 1x1 128->64 40x48", 2, 128, 64, 40, 48, "conv", 1, 0),
+                 ("stream 1x1 64->256 17x19", 2, 64, 256, 17, 19, "conv", 1, 0),
+                 ("direct 3x3 reflect 32->32 33x47", 2, 32, 32, 33, 47, "conv", 3, 1),
+                 ("direct 3x3 zero 64->64 40x40", 1, 64, 64, 40, 40, "conv", 3, 0),
+                 ("direct s2d 32->64 -> 20x23", 2, 32, 64, 20, 23, "s2d", 3, 0))
+        fm = ops.FAT_MIN_BLOCKS
+        ops.FAT_MIN_BLOCKS = 0
+        try:
+            for name, B, ci, co, H, Wd, kind, k, pm in cases:
+                w = g(nz_(co, ci, k, k) / math.sqrt(ci * k * k))
+                plan = ops.ConvPlan(w, kind=kind, precision=prec)
+                cx = plan.max_chan + 32
+                x = h(nz_(B, H + 1, Wd + 1, cx)) if kind == "s2d" else h(nz_(B, H, Wd, cx))
+                oh, ow = (2 * H, 2 * Wd) if kind == "convT" else (H, Wd)
+                kw0 = dict(out_hw=(H, Wd)) if kind == "s2d" else {}
+                bias = g(torch.arange(co, dtype=torch.float32) * 0.01)
+                res = h(nz_(B, oh, ow, co)); nzp = g(nz_(B, 1, oh, ow)); iss = g(torch.rand(B, cx, 2) + 0.5)
+                for vname, kw in (("", dict(bias=bias, act=ops.ACT_LRELU)),
+                                  ("in_ss prelu + res", dict(bias=bias, in_ss=iss, in_act=ops.ACT_PRELU, in_prelu=pre, residual=res, out_scale=0.7)),
+                                  ("noise + res after act", dict(bias=bias, noise=nzp, noise_weight=0.3, act=ops.ACT_LRELU, residual=res, res_after_act=True))):
+                    kwf = dict(kw)
+                    if "residual" in kwf:
+                        kwf["residual"] = kwf["residual"].float()
+                    ya, sa = plan(x, pad_mode=pm, stats=True, **kw, **kw0)
+                    yb, sb = plan(x.float(), pad_mode=pm, stats=True, **kwf, **kw0)
+                    same("%s conv %s %s" % (tag, name, vname), ya, yb.to(dt))
+                    same("%s conv %s %s stats" % (tag, name, vname), sa, sb)
+        finally:
+            ops.FAT_MIN_BLOCKS = fm
+
+
 @direct_kernels_only
 def t_conv1x1_stream():
     """conv1x1.hip (streaming 1x1 kernel and its direct form for thin 3x3 / stride-2 layers; operands swapped) against
@@ -1086,7 +1177,7 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     print("device:", torch.cuda.get_device_name(0), flush=True)
     if which in ("ops", "all"):
-        for fn in (t_upfirdn2d, t_fused_act, t_layout_misc, t_conv, t_conv_variants, t_conv_variants_single_pass, t_conv1x1_stream, t_norm_pool, t_corr, t_guided):
+        for fn in (t_upfirdn2d, t_fused_act, t_layout_misc, t_conv, t_conv_variants, t_conv_variants_single_pass, t_half_storage, t_conv1x1_stream, t_norm_pool, t_corr, t_guided):
             print("== " + fn.__name__, flush=True)
             run(fn)
             torch.cuda.synchronize()
@@ -1095,6 +1186,8 @@ def main():
         run(t_networks)
     if which == "prec":
         run(t_precision)
+    if which == "half":
+        run(t_half_storage)
     if which == "corr":
         run(t_corr)
     if which == "convv":
