@@ -249,7 +249,7 @@ typedef struct ppst_conv_args {
                                     [hi x 8 | lo x 8] bf16 (ppst_presplit), same pixel stride in_ld -- and the activation tile is
                                     staged by LDS-DMA.  variant 0, bn 128, halo 1, precision 0, no in_scale_shift, every chunk of
                                     the step table >= 4 steps (the caller's promise, like early_a). */
-  int32_t dual_b;                /* 1 (variant 2, bn 256, n_groups 2, halo 1, precision 0, out_sy = out_sx = 2): the fused 4x4 stride-2
+  int32_t dual_b;                /* 1 (variant 2, bn 256, n_groups 2, halo 1, precision 0 / 1 / 3, out_sy = out_sx = 2): the fused 4x4 stride-2
                                     upscale (stylegan2_layers.py:312-321) with Cout % 128 == 0 as TWO row phases whose N tile of 256
                                     is [column phase 0: 128 channels | column phase 1: 128 channels] -- wpack from
                                     ppst_conv_pack_dual, steps[i].dx = (dx of phase 0 + 1) | (dx of phase 1 + 1) << 8.  The

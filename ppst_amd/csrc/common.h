@@ -124,6 +124,26 @@ template <int ST> __device__ __forceinline__ void st_st4(void* base, int64_t i, 
   if (ST == PPST_ST_F32) *(float4*)((float*)base + i) = v;
   else *(uint2*)((unsigned short*)base + i) = st_pack4<ST>(v);
 }
+// eight consecutive elements: one 16-byte access of a half tensor (two of an fp32 one); i a multiple of 8, base 16-byte aligned
+template <int ST> __device__ __forceinline__ void st_ld8(const void* base, int64_t i, float4& a, float4& b) {
+  if (ST == PPST_ST_F32) {
+    a = *(const float4*)((const float*)base + i);
+    b = *(const float4*)((const float*)base + i + 4);
+  } else {
+    const uint4 u = *(const uint4*)((const unsigned short*)base + i);
+    a = st_unpack4<ST>(make_uint2(u.x, u.y));
+    b = st_unpack4<ST>(make_uint2(u.z, u.w));
+  }
+}
+template <int ST> __device__ __forceinline__ void st_st8(void* base, int64_t i, float4 a, float4 b) {
+  if (ST == PPST_ST_F32) {
+    *(float4*)((float*)base + i) = a;
+    *(float4*)((float*)base + i + 4) = b;
+  } else {
+    const uint2 p = st_pack4<ST>(a), q = st_pack4<ST>(b);
+    *(uint4*)((unsigned short*)base + i) = make_uint4(p.x, p.y, q.x, q.y);
+  }
+}
 template <int ST> __device__ __forceinline__ float st_ld1(const void* base, int64_t i) {
   if (ST == PPST_ST_F32) return ((const float*)base)[i];
   const unsigned short h = ((const unsigned short*)base)[i];

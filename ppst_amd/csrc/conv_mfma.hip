@@ -819,12 +819,12 @@ extern "C" int ppst_conv_pack(const void* w, int64_t sn, int64_t sc, int64_t sy,
 extern "C" int ppst_conv_pack_dual(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx, float scale, int cout,
                                    const int32_t* src_c, const int32_t* src_ky, const int32_t* src_kx, int nsteps, int n_groups,
                                    int precision, void* out, void* stream) {
-  if (cout <= 0 || nsteps <= 0 || n_groups != 2 || precision != 0) return PPST_EINVAL;
+  if (cout <= 0 || nsteps <= 0 || n_groups != 2 || (precision != 0 && precision != 1 && precision != 3)) return PPST_EINVAL;
   if (!w || !src_c || !src_ky || !src_kx || !out) return PPST_ENULL;
   PackJob j;
   j.w = (const float*)w; j.sn = sn; j.sc = sc; j.sy = sy; j.sx = sx; j.src_c = src_c; j.src_ky = src_ky; j.src_kx = src_kx;
   j.out = (unsigned short*)out; j.total = (int64_t)n_groups * cdiv(cout, 128) * nsteps * 4 * 256; j.block0 = 0; j.scale = scale;
-  j.cout = cout; j.bn = 256; j.nsteps = nsteps; j.n_groups = n_groups; j.x3 = 1; j.f16 = 0; j.dual = 1;
+  j.cout = cout; j.bn = 256; j.nsteps = nsteps; j.n_groups = n_groups; j.x3 = precision == 0 ? 1 : 0; j.f16 = precision == 3 ? 1 : 0; j.dual = 1;
   j.nblocks = pack_blocks(j.total);
   PPST_LAUNCH(conv_pack_kernel, dim3((unsigned)j.nblocks), dim3(256), 0, as_stream(stream), j);
   return PPST_LAUNCH_CHECK();
@@ -983,7 +983,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   if (a->B < 0 || a->in_h <= 0 || a->in_w <= 0 || a->in_ld <= 0 || a->in_ld % 4 || a->out_h <= 0 || a->out_w <= 0 ||
       a->out_ld < a->cout || a->cout <= 0 || a->cout % 4 || a->out_ld % 4 || (a->residual && a->res_ld % 4) || a->nsteps <= 0 ||
       (a->n_groups != 1 && a->n_groups != 4 && !(a->n_groups == 2 && a->dual_b)) || a->pad_mode < 0 ||
-      (a->dual_b && (a->variant != 2 || a->bn != 256 || a->n_groups != 2 || a->halo != 1 || a->precision != 0 || a->out_sy != 2 || a->out_sx != 2 || !a->early_a)) ||
+      (a->dual_b && (a->variant != 2 || a->bn != 256 || a->n_groups != 2 || a->halo != 1 || (a->precision != 0 && a->precision != 1 && a->precision != 3) || a->out_sy != 2 || a->out_sx != 2 || !a->early_a)) ||
       a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 ||
       (a->precision != 0 && a->precision != 1 && a->precision != 3 && a->precision != 4) || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128 && a->bn != 256) || (a->residual && a->res_ld < a->cout) ||
       a->variant < 0 || a->variant > 10 || (a->variant == 0 && a->bn == 256) ||

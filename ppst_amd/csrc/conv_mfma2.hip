@@ -600,9 +600,15 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
   do {                                                                                                          \
     if (a->io_st) L2Q(HALO_, PREC_, (PREC_ == 3 ? PPST_ST_F16 : PPST_ST_BF16)); else L2Q(HALO_, PREC_, PPST_ST_F32); \
   } while (0)
-  if (a->variant == 2 && a->dual_b) {     // Cout = 128 fused upscale as two phase pairs (halo 1, precision 0, no normalise-on-load needed twice: both built)
-    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, 1, true, 4, false, 2, 2, 0, 8, true>), dim3(blocks), dim3(512), 0, st, k);
-    else PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 4, false, 2, 2, 0, 8, true>), dim3(blocks), dim3(512), 0, st, k);
+#define L2D(PREC_, IOS_)                                                                                        \
+  do {                                                                                                          \
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, 1, true, 4, false, 2, 2, PREC_, 8, true, IOS_>), dim3(blocks), dim3(512), 0, st, k);   \
+    else PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 4, false, 2, 2, PREC_, 8, true, IOS_>), dim3(blocks), dim3(512), 0, st, k);          \
+  } while (0)
+  if (a->variant == 2 && a->dual_b) {     // Cout % 128 == 0 fused upscale as two phase pairs (halo 1)
+    if (a->precision == 3) { if (a->io_st) L2D(3, PPST_ST_F16); else L2D(3, PPST_ST_F32); }
+    else if (a->precision == 1) { if (a->io_st) L2D(1, PPST_ST_BF16); else L2D(1, PPST_ST_F32); }
+    else L2D(0, PPST_ST_F32);
   } else
   if (a->variant == 2 && a->precision == 1) { if (a->halo) L2P(1, 1); else L2P(0, 1); }
   else if (a->variant == 2 && a->precision == 3) { if (a->halo) L2P(1, 3); else L2P(0, 3); }

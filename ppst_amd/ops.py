@@ -519,9 +519,10 @@ class ConvPlan:
         sn, sc, sy, sx = self.wstrides
         c_, ky_, kx_ = self.src_dual
         n_tiles = (self.cout + 127) // 128
-        wpack = torch.empty(2 * n_tiles * self.nsteps * 8 * 256 * 8, dtype=torch.int16, device=self.steps.device)
+        npl = 8 if self.precision == 0 else 4                # hi + lo planes, or the hi planes of a single-pass mode
+        wpack = torch.empty(2 * n_tiles * self.nsteps * npl * 256 * 8, dtype=torch.int16, device=self.steps.device)
         check(lib.ppst_conv_pack_dual(_p(self.wsrc), sn, sc, sy, sx, float(self.scale), self.cout, _p(c_), _p(ky_), _p(kx_),
-                                      self.nsteps, 2, 0, _p(wpack), _stream()), "ppst_conv_pack_dual")
+                                      self.nsteps, 2, self.precision, _p(wpack), _stream()), "ppst_conv_pack_dual")
         self._packs["dual"] = wpack
         return wpack
 
@@ -564,7 +565,7 @@ class ConvPlan:
         cv = CONV_VARIANT["value"]
         if cv in (1, 3) or TWO_BLOCK_128["value"] or KSPLIT_128["value"] or TILE24_128["value"] or TALL_TILE_128["value"]:
             _need_experiments("the requested conv variant")
-        if (DUAL_CONVT["value"] and self.kind == "convT" and self.precision == 0 and getattr(self, "steps_dual", None) is not None
+        if (DUAL_CONVT["value"] and self.kind == "convT" and getattr(self, "steps_dual", None) is not None
                 and self.cout % 256 != 0 and CONV_VARIANT["value"] == 2 and self.early_a
                 and ((th + 15) // 16) * ((tw + 15) // 16) * 2 * (self.cout // 128) >= DUAL_CONVT["min_blocks"]):
             return "dual", 256, 16
@@ -718,7 +719,8 @@ def repack_plans(plans):
             if bn == "dual":                     # two-phase-pair pack of the fused upscale: a job of the batched pack kernel
                 dc, dky, dkx = pl.src_dual
                 pk.append((pl.wsrc.data_ptr(), sn, sc, sy, sx, dc.data_ptr(), dky.data_ptr(), dkx.data_ptr(), wpack.data_ptr(),
-                           2 * ((pl.cout + 127) // 128) * pl.nsteps * 4 * 256, float(pl.scale), pl.cout, 256, pl.nsteps, 2, 1, 0, 1))
+                           2 * ((pl.cout + 127) // 128) * pl.nsteps * 4 * 256, float(pl.scale), pl.cout, 256, pl.nsteps, 2,
+                           1 if pl.precision == 0 else 0, 1 if pl.precision == 3 else 0, 1))
                 continue
             n_tiles = (pl.cout + bn - 1) // bn
             pk.append((pl.wsrc.data_ptr(), sn, sc, sy, sx, c_.data_ptr(), ky_.data_ptr(), kx_.data_ptr(), wpack.data_ptr(),

@@ -493,35 +493,36 @@ def t_conv_wino():
 def t_conv_dual():
     """The fused 4x4 stride-2 upscale with Cout % 128 == 0 as two phase pairs on the N-256 kernel (ppst_conv_args.dual_b) against
     the four-group tile-kernel form of the same plan: the per-element MFMA sequence is the same, so outputs are bit-identical;
-    tile statistics to rounding; and against float64 torch."""
+    tile statistics to rounding; and against float64 torch.  The same identity in the single-pass modes (precision 1 / 3)."""
     torch.manual_seed(9)
     prev = dict(ops.DUAL_CONVT)
     try:
+      for prec in (0, 1, 3):
         for name, B, ci, co, H, Wd, feat in [("convT 64->128 40x24 full", 2, 64, 128, 40, 24, "full"), ("convT 256->128 64x64 plain", 1, 256, 128, 64, 64, "plain"),
-                                             ("convT 128->384 17x33 inss (ragged)", 2, 128, 384, 17, 33, "inss"), ("convT 32->128 16x16 res", 1, 32, 128, 16, 16, "res")]:
-            w = g(torch.randn(co, ci, 3, 3) / math.sqrt(ci * 9))
-            x = g(torch.randn(B, H, Wd, ci))
-            kw = {}
-            if feat == "full":
-                kw = dict(bias=g(torch.randn(co)), noise=g(torch.randn(B, 1, 2 * H, 2 * Wd)), noise_weight=0.3, act=ops.ACT_LRELU)
-            elif feat == "inss":
-                kw = dict(in_ss=g(torch.rand(B, ci, 2) + 0.5), in_act=ops.ACT_PRELU, in_prelu=g(torch.tensor([0.25])))
-            elif feat == "res":
-                kw = dict(residual=g(torch.randn(B, 2 * H, 2 * Wd, co)), res_after_act=True, act=ops.ACT_LRELU, out_scale=0.7)
-            outs = []
-            for on in (False, True):
-                ops.DUAL_CONVT.update(value=on, min_blocks=0)
-                plan = ops.ConvPlan(w, kind="convT")
-                assert (plan.choose_kernel(H, Wd, 2 * H, 2 * Wd, H, Wd, 2)[0] == "dual") == on
-                y, st = plan(x, stats=True, **kw)
-                outs.append((y.cpu(), st.sum(1).cpu(), st.shape))
-            ok = bool(torch.equal(outs[0][0], outs[1][0])) and outs[0][2] == outs[1][2]
-            RES.append(("dual-phase upscale %s bit-identical to the four-group form" % name, ok))
-            print("dual convT %-44s %s max diff %.3e" % (name, "ok  " if ok else "FAIL", (outs[0][0] - outs[1][0]).abs().max().item()), flush=True)
-            report("dual convT %s stats" % name, outs[1][1], outs[0][1], 1e-5)
-            if feat == "plain":
-                ref = conv_ref(nchw(x.cpu()).double(), w.cpu().double(), "convT", 0)
-                report("dual convT %s vs float64" % name, nchw(outs[1][0]), ref, 3e-5)
+                                               ("convT 128->384 17x33 inss (ragged)", 2, 128, 384, 17, 33, "inss"), ("convT 32->128 16x16 res", 1, 32, 128, 16, 16, "res")]:
+              w = g(torch.randn(co, ci, 3, 3) / math.sqrt(ci * 9))
+              x = g(torch.randn(B, H, Wd, ci))
+              kw = {}
+              if feat == "full":
+                  kw = dict(bias=g(torch.randn(co)), noise=g(torch.randn(B, 1, 2 * H, 2 * Wd)), noise_weight=0.3, act=ops.ACT_LRELU)
+              elif feat == "inss":
+                  kw = dict(in_ss=g(torch.rand(B, ci, 2) + 0.5), in_act=ops.ACT_PRELU, in_prelu=g(torch.tensor([0.25])))
+              elif feat == "res":
+                  kw = dict(residual=g(torch.randn(B, 2 * H, 2 * Wd, co)), res_after_act=True, act=ops.ACT_LRELU, out_scale=0.7)
+              outs = []
+              for on in (False, True):
+                  ops.DUAL_CONVT.update(value=on, min_blocks=0)
+                  plan = ops.ConvPlan(w, kind="convT", precision=prec)
+                  assert (plan.choose_kernel(H, Wd, 2 * H, 2 * Wd, H, Wd, 2)[0] == "dual") == on
+                  y, st = plan(x, stats=True, **kw)
+                  outs.append((y.cpu(), st.sum(1).cpu(), st.shape))
+              ok = bool(torch.equal(outs[0][0], outs[1][0])) and outs[0][2] == outs[1][2]
+              RES.append(("dual-phase upscale %s precision %d bit-identical to the four-group form" % (name, prec), ok))
+              print("dual convT prec %d %-44s %s max diff %.3e" % (prec, name, "ok  " if ok else "FAIL", (outs[0][0] - outs[1][0]).abs().max().item()), flush=True)
+              report("dual convT prec %d %s stats" % (prec, name), outs[1][1], outs[0][1], 1e-5)
+              if feat == "plain" and prec == 0:
+                  ref = conv_ref(nchw(x.cpu()).double(), w.cpu().double(), "convT", 0)
+                  report("dual convT %s vs float64" % name, nchw(outs[1][0]), ref, 3e-5)
     finally:
         ops.DUAL_CONVT.update(prev)
 
@@ -603,6 +604,9 @@ def t_half_storage():
                          ("res_up2", dict(res=rh, res_up2=True, out_scale=0.7))):
             kwf = {k: (v.float() if isinstance(v, torch.Tensor) and v.dtype == dt else v) for k, v in kw.items()}
             same("%s affine_act %s" % (tag, name), ops.affine_act(x, ss, **kw), ops.affine_act(x.float(), ss, **kwf).to(dt))
+        x12 = h(nz_(2, 9, 7, 12)); r12 = h(nz_(2, 9, 7, 12)); ss12 = g(torch.rand(2, 12, 2) + 0.5)     # C % 8 != 0: the 4-channel form
+        same("%s affine_act 12 channels" % tag, ops.affine_act(x12, ss12, res=r12, act=ops.ACT_LRELU),
+             ops.affine_act(x12.float(), ss12, res=r12.float(), act=ops.ACT_LRELU).to(dt))
         same("%s affine_act -> fp32" % tag, ops.affine_act(x, ss, res=r, out_dtype=torch.float32), ops.affine_act(x.float(), ss, res=r.float()))
         same("%s affine_act fp32 -> half" % tag, ops.affine_act(x.float(), ss, out_dtype=dt), ops.affine_act(x.float(), ss).to(dt))
         k3 = g(torch.tensor([1., 2., 1.])); k3 = (k3[:, None] * k3[None, :] / 16).contiguous()
@@ -617,6 +621,9 @@ def t_half_storage():
             ya, hwa = ops.blur_nhwc(xb, kk, p0, p1, **a_)
             yb, hwb = ops.blur_nhwc(xb.float(), kk, p0, p1, **a_)
             same("%s blur %s" % (tag, name), ya, yb.to(dt))
+        xb12 = h(nz_(2, 21, 18, 12))
+        same("%s blur 3x3 reflect s2d 12 channels" % tag, ops.blur_nhwc(xb12, k3, 1, 1, pad_mode=ops.PAD_REFLECT, s2d=True)[0],
+             ops.blur_nhwc(xb12.float(), k3, 1, 1, pad_mode=ops.PAD_REFLECT, s2d=True)[0].to(dt))
         img = g(nz_(2, 19, 23, 3)); w_in = g(nz_(32, 3, 1, 1)); b_in = g(nz_(32) * 0.1)
         same("%s FromRGB (small cin) -> half" % tag, ops.conv1x1_small_cin(img, w_in, b_in, 0.5, ops.ACT_LRELU, out_dtype=dt),
              ops.conv1x1_small_cin(img, w_in, b_in, 0.5, ops.ACT_LRELU).to(dt))
@@ -632,6 +639,7 @@ def t_half_storage():
         # ---- the conv families of the mode
         cases = (("tile 3x3 reflect 64->128 33x47", 2, 64, 128, 33, 47, "conv", 3, 1),
                  ("tile convT 64->128 20x12", 2, 64, 128, 20, 12, "convT", 3, 0),
+                 ("dual convT 64->128 64x48", 2, 64, 128, 64, 48, "convT", 3, 0),
                  ("N-256 3x3 zero 128->256 64x64", 2, 128, 256, 64, 64, "conv", 3, 0),
                  ("N-256 convT 64->512 20x12", 2, 64, 512, 20, 12, "convT", 3, 0),
                  ("stream 1x1 128->64 40x48", 2, 128, 64, 40, 48, "conv", 1, 0),
@@ -1188,6 +1196,7 @@ def main():
         run(t_precision)
     if which == "half":
         run(t_half_storage)
+        run(t_conv_dual)
     if which == "corr":
         run(t_corr)
     if which == "convv":
