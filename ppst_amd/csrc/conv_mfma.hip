@@ -993,7 +993,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
                             a->in_off_y != 0 || a->in_off_x != 0 || a->tile_h != a->out_h || a->tile_w != a->out_w ||
                             a->in_h != a->out_h || a->in_w != a->out_w || a->nsteps % 9 != 0 || a->tile_rows != 16)) ||
       ((a->variant >= 1 && a->variant <= 3 || a->variant == 7 || a->variant == 9) &&
-       ((a->precision != 0 && !(a->variant == 2 && (a->precision == 1 || a->precision == 3))) || a->bn == 64 || !a->early_a)) ||
+       ((a->precision != 0 && !((a->variant == 2 || a->variant == 7) && (a->precision == 1 || a->precision == 3))) || a->bn == 64 || !a->early_a)) ||
       (a->variant == 7 && (a->bn != 128 || a->tile_rows != 32)) ||
       // variant 9 = conv_mfma2.hip with 6 m-tiles per wave: block tile 24 x 16 px x 128 ch, two activation slots
       (a->variant == 9 && (a->bn != 128 || a->tile_rows != 24)) ||
@@ -1015,15 +1015,17 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
        !(a->variant == 0 && a->tile_rows == 8 && a->bn == 128 && a->halo == 1 && a->early_a && a->precision == 0)) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
     return PPST_EINVAL;
 #ifndef PPST_EXPERIMENTS
-  if (a->variant == 1 || a->variant == 3 || a->variant == 7 || a->variant == 8 || a->variant == 9 || a->precision == 4 || a->in_presplit)
-    return PPST_EINVAL;          // experiment forms: not in this build
+  if (a->variant == 1 || a->variant == 3 || (a->variant == 7 && a->precision == 0) || a->variant == 8 || a->variant == 9 || a->precision == 4 ||
+      a->in_presplit)
+    return PPST_EINVAL;          // experiment forms: not in this build (variant 7 is a production form in the single-pass modes)
 #endif
   // pre-split input (experiment): the 8-wave tile kernel only, chunks of >= 4 steps (the caller's promise with early_a), no
   // normalise-on-load
   // half-precision activation storage (x, residual, y): the single-pass modes, in the operand type of the mode (1 -> bfloat16,
   // 3 -> IEEE half); kernel families 0 (16-row tiles), 2 (N-256), 4 / 5 / 6 (streaming 1x1 / direct)
-  if (a->io_st && (a->io_st != (a->precision == 3 ? PPST_ST_F16 : a->precision == 1 ? PPST_ST_BF16 : -1) || a->tile_rows != 16 ||
-                   a->in_presplit || !(a->variant == 0 || a->variant == 2 || a->variant == 4 || a->variant == 5 || a->variant == 6)))
+  if (a->io_st && (a->io_st != (a->precision == 3 ? PPST_ST_F16 : a->precision == 1 ? PPST_ST_BF16 : -1) ||
+                   (a->tile_rows != 16 && a->variant != 7) || a->in_presplit ||
+                   !(a->variant == 0 || a->variant == 2 || a->variant == 4 || a->variant == 5 || a->variant == 6 || a->variant == 7)))
     return PPST_EINVAL;
   if (a->in_presplit && (a->variant != 0 || a->bn != 128 || a->halo != 1 || a->precision != 0 || !a->early_a || a->tile_rows != 16 ||
                          a->in_scale_shift))

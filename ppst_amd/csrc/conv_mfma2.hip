@@ -610,6 +610,22 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
     else if (a->precision == 1) { if (a->io_st) L2D(1, PPST_ST_BF16); else L2D(1, PPST_ST_F32); }
     else L2D(0, PPST_ST_F32);
   } else
+  // single-pass modes, Cout = 128-class layers: block tile 32 x 16 px x 128 ch on this kernel's 128 px x 64 ch wave tiles with TWO
+  // activation slots (the hi planes alone are 39 KB per slot) -- the tile kernel's 64 x 64 wave tiles reach 0.22 of the single-pass
+  // ceiling on 128 -> 128 @1024^2, bound by fragment reads and barriers per MFMA
+#define L7Q(HALO_, PREC_, IOS_)                                                                                 \
+  do {                                                                                                          \
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 2, 4, PREC_, 8, false, IOS_>), dim3(blocks), dim3(512), 0, st, k);   \
+    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 2, 4, PREC_, 8, false, IOS_>), dim3(blocks), dim3(512), 0, st, k);          \
+  } while (0)
+#define L7P(PREC_)                                                                                              \
+  do {                                                                                                          \
+    if (!a->halo) return PPST_EINVAL;                                                                           \
+    if (a->io_st) L7Q(1, PREC_, (PREC_ == 3 ? PPST_ST_F16 : PPST_ST_BF16)); else L7Q(1, PREC_, PPST_ST_F32);   \
+  } while (0)
+  if (a->variant == 7 && a->precision == 1) L7P(1);
+  else if (a->variant == 7 && a->precision == 3) L7P(3);
+  else
   if (a->variant == 2 && a->precision == 1) { if (a->halo) L2P(1, 1); else L2P(0, 1); }
   else if (a->variant == 2 && a->precision == 3) { if (a->halo) L2P(1, 3); else L2P(0, 3); }
   else if (a->variant == 2) {            // 8 waves, wave tile 128 px x 64 ch, N tile 256: the production form

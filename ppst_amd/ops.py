@@ -44,6 +44,9 @@ KSPLIT_128 = {"value": False, "min_blocks": 32}
 # variant 7 (32 x 16 px x 128 ch blocks, conv_mfma2.hip WMW = 4) when one image gives >= min_blocks: measured 3-5 % SLOWER than
 # the tile kernel on the Cout = 128 layers (one activation slot: the chunk store sits between two barriers; 33-44 spills) -- off
 TALL_TILE_128 = {"value": False, "min_blocks": 32}
+# the same geometry in the single-pass modes (two activation slots fit there): the Cout = 128-class 3x3 layers, which the tile
+# kernel runs at 0.22 of the single-pass ceiling (128 -> 128 @1024^2 fp16)
+TALL_TILE_SINGLE = {"value": True, "min_blocks": 64}
 # variant 9 (24 x 16 px x 128 ch blocks, wave tile 96 px x 64 ch, TWO activation slots: conv_mfma2.hip MT_ = 6) for the Cout = 128-class
 # layers whose tile height wastes <= max_waste of the rows (512 -> 528, 256 -> 264: 3.1 %; 128 -> 144 would be 12.5 %)
 TILE24_128 = {"value": False, "min_blocks": 32, "max_waste": 0.04}
@@ -581,7 +584,10 @@ class ConvPlan:
             if n256_ok and not force3:
                 variant, bn = 2, 256                     # 8 waves x (128 px x 64 ch), N tile 256 (conv_mfma2.hip, WNW = 4)
             elif single:
-                pass                                     # single-pass modes: only the N-256 geometry is built for them
+                # single-pass modes: the N-256 geometry, and for Cout = 128-class layers with a halo the 32 x 16 px x 128 ch tile
+                if (self.bn == 128 and self.halo == 1 and self.n_groups == 1 and TALL_TILE_SINGLE["value"] and
+                        ((th + 31) // 32) * ((tw + 15) // 16) * ((self.cout + 127) // 128) >= TALL_TILE_SINGLE["min_blocks"]):
+                    variant, rows = 7, 32
             elif self.bn == 128 and (force3 or (TWO_BLOCK_128["value"] and
                                                 tiles16 * ((self.cout + 127) // 128) >= 2 * FAT_MIN_BLOCKS)):
                 variant = 3                              # two 4-wave blocks per CU, N tile 128, one activation slot

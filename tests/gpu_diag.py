@@ -550,6 +550,34 @@ def t_conv_variants_single_pass():
             RES.append(("single-pass precision %d N=256 %s bit-identical" % (prec, name), ok))
             print("single-pass prec %d %-30s %s max diff %.3e" % (prec, name, "ok  " if ok else "FAIL", (outs[0][0] - outs[1][0]).abs().max().item()), flush=True)
             report("single-pass prec %d %s stats" % (prec, name), outs[1][1], outs[0][1], 1e-5)
+        # the 32 x 16 px x 128 ch tile of the Cout = 128-class layers (variant 7, production form in the single-pass modes), fp32 and
+        # half storage, against the 16-row tile kernel
+        tt = dict(ops.TALL_TILE_SINGLE)
+        for name, B, ci, co, H, Wd, kind, pm, feat in (("3x3 reflect 64->128 33x47", 2, 64, 128, 33, 47, "conv", 1, "plain"),
+                                                        ("3x3 zero 128->128 70x40 in_ss + res", 1, 128, 128, 70, 40, "conv", 0, "inss"),
+                                                        ("s2d 64->128 -> 37x20", 2, 64, 128, 37, 20, "s2d", 0, "plain")):
+            w = g(nz_(co, ci, 3, 3) / math.sqrt(ci * 9))
+            for dt in (torch.float32, torch.float16 if prec == 3 else torch.bfloat16):
+                outs = []
+                for tall in (False, True):
+                    ops.TALL_TILE_SINGLE.update(value=tall, min_blocks=0)
+                    plan = ops.ConvPlan(w, kind=kind, precision=prec)
+                    torch.manual_seed(17)
+                    cx = plan.max_chan + 32
+                    x = (g(nz_(B, H + 1, Wd + 1, cx)) if kind == "s2d" else g(nz_(B, H, Wd, cx))).to(dt)
+                    kw = dict(out_hw=(H, Wd)) if kind == "s2d" else {}
+                    if feat == "inss":
+                        kw.update(in_ss=g(torch.rand(B, cx, 2) + 0.5), in_act=ops.ACT_PRELU, in_prelu=g(torch.tensor([0.25])),
+                                  residual=g(nz_(B, H, Wd, co)).to(dt), out_scale=0.7)
+                    assert (plan.choose_kernel(H, Wd, H, Wd, x.shape[1], x.shape[2], 1)[0] == 7) == tall
+                    y, st = plan(x, pad_mode=pm, stats=True, bias=g(torch.arange(co, dtype=torch.float32) * 0.01), act=ops.ACT_LRELU, **kw)
+                    outs.append((y.cpu(), st.sum(1).cpu()))
+                ops.TALL_TILE_SINGLE.update(tt)
+                ok = bool(torch.equal(outs[0][0], outs[1][0]))
+                nm = "single-pass precision %d tall tile %s %s" % (prec, name, str(dt).split(".")[-1])
+                RES.append((nm + " bit-identical", ok))
+                print("%-80s %s max diff %.3e" % (nm, "ok  " if ok else "FAIL", (outs[0][0].float() - outs[1][0].float()).abs().max().item()), flush=True)
+                report(nm + " stats", outs[1][1], outs[0][1], 1e-5)
         # the streaming kernels (1x1, thin stride-2, thin 3x3) in the same mode
         dmax, st1 = dict(ops.DIRECT_MAX), ops.STREAM_1X1["value"]
         for name, B, ci, co, H, Wd, kind, k, pm in (("1x1 128->64 40x48", 2, 128, 64, 40, 48, "conv", 1, 0),
@@ -1197,6 +1225,7 @@ def main():
     if which == "half":
         run(t_half_storage)
         run(t_conv_dual)
+        run(t_conv_variants_single_pass)
     if which == "corr":
         run(t_corr)
     if which == "convv":
