@@ -105,7 +105,9 @@ def conv_mfma_busy():
     """Matrix-pipe busy fraction of the conv launches from the committed SQ_VALU_MFMA_BUSY_CYCLES pass (profiles/rNN_pmc_mfma.json,
     tests/pmc_mfma_summary.py): a hardware-counter companion of roofline.frac, at the clock the kernels ran at."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_swap_pmc_mfma.json")))
+    if not files:       # (rounds 2-3 committed the swap line's as profiles/rNN_pmc_mfma.json)
+        files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")) if "_bench_" not in f)
     if not files:
         return None
     try:
