@@ -129,6 +129,13 @@ typedef struct ppst_conv_step {
  *  out      n_groups * ceil(cout/bn) * nsteps * (precision==0 ? 8 : 4) * bn * 8 bf16 */
 /* The same for ppst_conv_args.dual_b: bn = 256 = two column phases x 128 channels of N tile t (channels 128 t ..); src_kx[i] holds
  * (kx of phase 0) | (kx of phase 1) << 8.  out: n_groups * ceil(cout/128) * nsteps * (precision==0 ? 8 : 4) * 256 * 8 bf16. */
+/* Weights for ppst_conv_args.variant 11 (the fused upscale of stylegan2_layers.py:312-321 as the UN-BLURRED 3x3 stride-2
+ * transposed conv -- nine products per input pixel instead of the sixteen of the 4x4 kernel -- with the 2x2 box sum of the weight
+ * blur applied to the OUTPUT in the kernel's epilogue): w = the layer's 3x3 weight (Cout, Cin, 3, 3) with element strides
+ * sn / sc / sy / sx, scaled by ``scale``; cout % 64 == 0, cin % 32 == 0; out: ppst_conv_pack_up9_bytes(cout, cin) bytes. */
+int64_t ppst_conv_pack_up9_bytes(int cout, int cin);
+int ppst_conv_pack_up9(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx, float scale, int cout, int cin,
+                       void* out, void* stream);
 int ppst_conv_pack_dual(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx, float scale, int cout,
                         const int32_t* src_c, const int32_t* src_ky, const int32_t* src_kx, int nsteps, int n_groups,
                         int precision, void* out, void* stream);
@@ -238,6 +245,14 @@ typedef struct ppst_conv_args {
                                        steps[9c].x = first channel of chunk c), wpack from ppst_conv_pack_wino, bn = 128,
                                        tile_rows = 16, one group, unit strides, precision 0.  Winograd F(2,3) along x: fp32-class
                                        like the others (<= 3e-5 against float64) but NOT bit-identical to them.
+                                   11: conv_mfma2.hip "UP9" -- the fused 4x4 stride-2 upscale computed as the un-blurred 3x3 transposed
+                                       conv (u types ee / eo / oe / oo of 4 / 2 / 2 / 1 taps: 9 products per input pixel instead of
+                                       16) whose 2x2 box sum runs in the epilogue; bn = 256 = 4 N-waves x 4 types x 16 channels,
+                                       n_groups 1, tile_rows 15 (blocks of 15 x 15 input positions: the 16 x 16 grid of a block
+                                       feeds its neighbours' row / column), halo 1, zero padding, out_sy = out_sx = 2, precision
+                                       0, no normalise-on-load / residual / PReLU; wpack from ppst_conv_pack_up9, steps = per
+                                       32-channel chunk the shifts (0,0), (-1,0), (0,-1), (-1,-1).  fp32-class (<= 3e-5 against
+                                       float64), NOT bit-identical to the 4x4 forms (other summation order).
                                     9: conv_mfma2.hip with 6 m-tiles per wave: block tile 24 x 16 px x 128 ch (wave tile 96 px x 64 ch),
                                        TWO activation slots; bn = 128, tile_rows = 24, the early_a promise, precision 0
                                        (experiment: bit-identical, +-1.5 % of variant 0 -- the 36-step tiles of the Cout = 128

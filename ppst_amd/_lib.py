@@ -65,6 +65,8 @@ _SIGS = {
     "ppst_nchw_to_nhwc": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ppst_nhwc_to_nchw": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ppst_conv_pack": (i32, [vp, i64, i64, i64, i64, f32, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "ppst_conv_pack_up9_bytes": (i64, [i32, i32]),
+    "ppst_conv_pack_up9": (i32, [vp, i64, i64, i64, i64, f32, i32, i32, vp, vp]),
     "ppst_conv_pack_wino_bytes": (i64, [i32, i32]),
     "ppst_conv_pack_wino": (i32, [vp, i64, i64, i64, i64, f32, i32, i32, vp, vp]),
     "ppst_conv_pack_dual": (i32, [vp, i64, i64, i64, i64, f32, i32, vp, vp, vp, i32, i32, i32, vp, vp]),

@@ -829,6 +829,49 @@ extern "C" int ppst_conv_pack_dual(const void* w, int64_t sn, int64_t sc, int64_
   PPST_LAUNCH(conv_pack_kernel, dim3((unsigned)j.nblocks), dim3(256), 0, as_stream(stream), j);
   return PPST_LAUNCH_CHECK();
 }
+// Weights for ppst_conv_args.variant 11 (conv_mfma2.hip UP9): blob of step s = 4 * chunk + shift in the N-256 kernel's LDS image
+// [hi | lo][k-group g][256 columns][8 k], column = N-wave wn * 64 + u type t * 16 + r <-> output channel 64 * ntile + 16 * wn + r; the
+// tap of (shift, type) -- shift (0,0): ee w[0][0], eo w[0][1], oe w[1][0], oo w[1][1]; (-1,0): ee w[2][0], eo w[2][1]; (0,-1): ee
+// w[0][2], oe w[1][2]; (-1,-1): ee w[2][2] -- of the UN-BLURRED 3x3 kernel w (Cout, Cin, 3, 3) * scale; zeros elsewhere.
+__global__ __launch_bounds__(256) void conv_pack_up9_kernel(const float* __restrict__ w, int64_t sn, int64_t sc, int64_t sy, int64_t sx, float scale,
+                                                            int cout, int cin, unsigned short* __restrict__ out, int64_t total) {
+  const int nsteps = (cin / 32) * 4;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int col = (int)(t % 256);
+    int64_t r = t / 256;
+    const int g = (int)(r % 4); r /= 4;
+    const int s = (int)(r % nsteps);
+    const int ntile = (int)(r / nsteps);
+    const int chunk = s >> 2, sh = s & 3, wn = col >> 6, ty = (col >> 4) & 3, n = ntile * 64 + wn * 16 + (col & 15);
+    // (ky, kx) of (shift, type), -1: no tap
+    const int kyt[4][4] = {{0, 0, 1, 1}, {2, 2, -1, -1}, {0, -1, 1, -1}, {2, -1, -1, -1}};
+    const int kxt[4][4] = {{0, 1, 0, 1}, {0, 1, -1, -1}, {2, -1, 2, -1}, {2, -1, -1, -1}};
+    const int ky = kyt[sh][ty], kx = kxt[sh][ty];
+    unsigned short hi[8], lo[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = 0.f;
+      if (ky >= 0 && n < cout) v = w[n * sn + (int64_t)(chunk * 32 + g * 8 + q) * sc + ky * sy + kx * sx] * scale;
+      split_bf16(v, hi[q], lo[q]);
+    }
+    unsigned short* oh = out + (((int64_t)ntile * nsteps + s) * 8 * 256 + (int64_t)g * 256 + col) * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { oh[q] = hi[q]; oh[(int64_t)4 * 256 * 8 + q] = lo[q]; }
+  }
+}
+extern "C" int64_t ppst_conv_pack_up9_bytes(int cout, int cin) {
+  if (cout <= 0 || cin <= 0 || cout % 64 || cin % 32) return 0;
+  return (int64_t)(cout / 64) * (cin / 32) * 4 * 8 * 256 * 16;
+}
+extern "C" int ppst_conv_pack_up9(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx, float scale, int cout, int cin, void* out,
+                                  void* stream) {
+  if (cout <= 0 || cin <= 0 || cout % 64 || cin % 32) return PPST_EINVAL;
+  if (!w || !out) return PPST_ENULL;
+  const int64_t total = (int64_t)(cout / 64) * (cin / 32) * 4 * 4 * 256;
+  PPST_LAUNCH(conv_pack_up9_kernel, dim3((unsigned)pack_blocks(total)), dim3(256), 0, as_stream(stream), (const float*)w, sn, sc, sy, sx, scale,
+              cout, cin, (unsigned short*)out, total);
+  return PPST_LAUNCH_CHECK();
+}
 // jobs: DEVICE array of ppst_pack_job (block0 / nblocks filled by the caller: consecutive ranges, nblocks = ppst_pack_job_blocks(total))
 extern "C" int ppst_pack_job_blocks(int64_t total) { return total > 0 ? pack_blocks(total) : 0; }
 extern "C" int ppst_conv_pack_batch(const void* jobs, int njobs, int total_blocks, void* stream) {
@@ -970,7 +1013,8 @@ extern "C" int ppst_has_experiments(void) {
 #endif
 }
 
-extern "C" int ppst_conv_tiles(int tile_h, int tile_w, int tile_rows) { return cdiv(tile_h, tile_rows) * cdiv(tile_w, 16); }
+// (tile_rows 15 = variant 11: blocks of 15 x 15 input positions)
+extern "C" int ppst_conv_tiles(int tile_h, int tile_w, int tile_rows) { return cdiv(tile_h, tile_rows) * cdiv(tile_w, tile_rows == 15 ? 15 : 16); }
 
 template <int WM, int WN, int HALO, bool X3, int NAS = 0, bool F16 = false, bool X2 = false, int IOS = PPST_ST_F32>
 static void launch_conv(const ConvKArgs& k, int blocks, hipStream_t st) {
@@ -986,7 +1030,14 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       (a->dual_b && (a->variant != 2 || a->bn != 256 || a->n_groups != 2 || a->halo != 1 || (a->precision != 0 && a->precision != 1 && a->precision != 3) || a->out_sy != 2 || a->out_sx != 2 || !a->early_a)) ||
       a->pad_mode > 2 || a->tile_h <= 0 || a->tile_w <= 0 || a->out_sy <= 0 || a->out_sx <= 0 ||
       (a->precision != 0 && a->precision != 1 && a->precision != 3 && a->precision != 4) || a->halo < 0 || a->halo > 1 || (a->bn != 64 && a->bn != 128 && a->bn != 256) || (a->residual && a->res_ld < a->cout) ||
-      a->variant < 0 || a->variant > 10 || (a->variant == 0 && a->bn == 256) ||
+      a->variant < 0 || a->variant > 11 || (a->variant == 0 && a->bn == 256) ||
+      // variant 11 = conv_mfma2.hip UP9: the fused 4x4 stride-2 upscale as the un-blurred 3x3 transposed conv (nine products per input
+      // pixel instead of sixteen) + its 2x2 box sum in the epilogue; wpack from ppst_conv_pack_up9, steps = per 32-channel chunk the
+      // four input shifts (0,0), (-1,0), (0,-1), (-1,-1) in this order (the CALLER's promise); blocks of 15 x 15 input positions
+      (a->variant == 11 && (a->precision != 0 || a->bn != 256 || a->halo != 1 || a->n_groups != 1 || a->out_sy != 2 || a->out_sx != 2 ||
+                            !a->early_a || a->tile_rows != 15 || a->pad_mode != PPST_PAD_ZERO || a->in_scale_shift || a->residual ||
+                            (a->act & 0xff) == PPST_ACT_PRELU || a->cout % 64 || a->nsteps % 4 || a->in_off_y || a->in_off_x ||
+                            a->tile_h != a->in_h || a->tile_w != a->in_w || a->out_h != 2 * a->in_h || a->out_w != 2 * a->in_w || a->io_st)) ||
       // variant 10 = conv_wino.hip: Winograd F(2,3) along x for plain 3x3 stride-1 tables (the CALLER promises the (chunk, dy, dx)
       // step order, as with variant 6, and a wpack from ppst_conv_pack_wino); bf16x3, bn 128, 16-row tiles, one group, unit strides
       (a->variant == 10 && (a->precision != 0 || a->bn != 128 || a->halo != 1 || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
@@ -1011,7 +1062,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
                                                 (a->bn != 64 && !(a->variant == 6 && a->bn == 128 && a->precision == 0)) || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
                            a->in_off_y != 0 || a->in_off_x != 0 || a->tile_h != a->out_h || a->tile_w != a->out_w)) ||
       // tile_rows 8 = two 4-wave blocks per CU (8 x 16 px x 128 ch, two activation slots): variant 0, bn 128, halo 1, early_a, bf16x3
-      (a->tile_rows != 16 && !(a->variant == 7 && a->tile_rows == 32) && !(a->variant == 9 && a->tile_rows == 24) &&
+      (a->tile_rows != 16 && !(a->variant == 7 && a->tile_rows == 32) && !(a->variant == 9 && a->tile_rows == 24) && !(a->variant == 11 && a->tile_rows == 15) &&
        !(a->variant == 0 && a->tile_rows == 8 && a->bn == 128 && a->halo == 1 && a->early_a && a->precision == 0)) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
     return PPST_EINVAL;
 #ifndef PPST_EXPERIMENTS
@@ -1054,8 +1105,8 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   k.out_ld = a->out_ld; k.cout = a->cout; k.nsteps = a->nsteps; k.n_groups = a->n_groups; k.pad_mode = a->pad_mode;
   k.in_off_y = a->in_off_y; k.in_off_x = a->in_off_x; k.out_sy = a->out_sy; k.out_sx = a->out_sx; k.act = a->act;
   k.res_ld = a->res_ld; k.tile_h = a->tile_h; k.tile_w = a->tile_w;
-  k.tiles_y = cdiv(a->tile_h, a->tile_rows); k.tiles_x = cdiv(a->tile_w, 16);
-  k.n_tiles = cdiv(a->cout, a->dual_b ? a->bn / 2 : a->bn);
+  k.tiles_y = cdiv(a->tile_h, a->tile_rows); k.tiles_x = cdiv(a->tile_w, a->variant == 11 ? 15 : 16);
+  k.n_tiles = cdiv(a->cout, a->variant == 11 ? 64 : a->dual_b ? a->bn / 2 : a->bn);
   k.in_ss = (const float*)a->in_scale_shift; k.in_prelu = (const float*)a->in_prelu;
   k.in_c = a->in_c; k.in_act = a->in_act;
   k.early_a = a->early_a ? 1 : 0;
@@ -1071,7 +1122,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   int slot = -1;
   if (g_prof_on) {
     const int inf[8] = {a->B, a->tile_h, a->tile_w, a->nsteps, a->cout, a->n_groups, a->halo, a->bn};
-    slot = ppst_prof_begin_(2.0 * 32.0 * (a->flop_steps > 0 ? a->flop_steps : a->nsteps) * (double)(a->dual_b ? 4 : a->n_groups) * a->cout * (double)a->B * a->tile_h * a->tile_w,
+    slot = ppst_prof_begin_(2.0 * 32.0 * (a->flop_steps > 0 ? a->flop_steps : a->nsteps) * (double)((a->dual_b || a->variant == 11) ? 4 : a->n_groups) * a->cout * (double)a->B * a->tile_h * a->tile_w,
                             inf, st);
   }
   if (a->variant >= 1) {

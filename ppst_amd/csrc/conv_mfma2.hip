@@ -91,9 +91,11 @@ __device__ __forceinline__ unsigned short f2h_2(float f) { return __builtin_bit_
 // step, the activation tile is staged once for two phases, and the layer runs on this kernel's 128 x 64 wave tiles instead of
 // the tile kernel's 64 x 64.  Per output element the MFMA sequence is the tile kernel's (dy-major taps): bit-identical outputs.
 template <int NT, int HALO, bool INSS, int WNW = 2, bool BDB = true, int NA_ = 2, int WMW = 2, int PREC = 0, int MT_ = 8, bool DUAL = false,
-          int IOS = PPST_ST_F32>
+          int IOS = PPST_ST_F32, bool UP9 = false>
 __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW == 8 || NA_ == 1) ? 2 : 1)) void conv_mfma2_kernel(Conv2KArgs a) {
   constexpr bool X3 = PREC == 0;
+  static_assert(!UP9 || (NT == 4 && HALO == 1 && !INSS && WNW == 4 && !BDB && NA_ == 2 && WMW == 2 && PREC == 0 && MT_ == 8 && !DUAL &&
+                         IOS == PPST_ST_F32), "UP9: the production geometry, fp32-class, fp32 storage");
   // IOS: storage type of x, residual and y (ppst_conv_args.io_st; conv_mfma.hip): the single-pass modes, in their operand type
   static_assert(IOS == PPST_ST_F32 || IOS == (PREC == 3 ? PPST_ST_F16 : PREC == 1 ? PPST_ST_BF16 : -1), "half storage: single-pass modes");
   constexpr int ES = IOS == PPST_ST_F32 ? 4 : 2;
@@ -133,7 +135,8 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   const int b = midx / (a.tiles_y * a.tiles_x);
   midx -= b * a.tiles_y * a.tiles_x;
   const int tyi = midx / a.tiles_x, txi = midx - tyi * a.tiles_x;
-  const int ty0 = tyi * TH, tx0 = txi * TW;
+  // (UP9: a block's 16 x 16 grid of u values yields the outputs of 15 x 15 input positions: the tiles overlap by one row / column)
+  const int ty0 = tyi * (UP9 ? 15 : TH), tx0 = txi * (UP9 ? 15 : TW);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WNW, wm = wave / WNW;
@@ -295,7 +298,8 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
 #else
 #define HALFBAR_IF(s)
 #endif
-#define STEP2(bch, bcl, bnh, bnl, s, D2, D3, H1, H2)                                                        \
+#define STEP2(bch, bcl, bnh, bnl, s, D2, D3, H1, H2) STEP2M(bch, bcl, bnh, bnl, s, D2, D3, H1, H2, 0xF, 0xF)
+#define STEP2M(bch, bcl, bnh, bnl, s, D2, D3, H1, H2, MASK, MASKN)   /* MASK / MASKN: n-tiles this / the next step multiplies (UP9) */ \
   {                                                                                                           \
     const bool has1 = (H1), has2 = (H2);                                                                      \
     TR2_DECL TR2(0)                                                                                           \
@@ -324,6 +328,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
         if (X3) bnl[NT - 1] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, NT - 1) + 4 * BPLANE);                           \
       }                                                                                                       \
       _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                     \
+        if (!(((MASK) >> nt) & 1)) continue;                                                                  \
         if (X3) {                                                                                             \
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bch[nt], acc[mt][nt], 0, 0, 0);           \
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcl[nt], acc[mt][nt], 0, 0, 0);           \
@@ -362,6 +367,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
     }                                                                                                         \
     if (!BDB && has1) {   /* single register set: the next step's weight fragments replace this step's, now dead */ \
       _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                     \
+        if (!(((MASKN) >> nt) & 1)) continue;                                                                 \
         bnh[nt] = *(const bf16x8*)B_ADDR(((s) + 1) & 1, nt);                                                  \
         if (X3) bnl[nt] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, nt) + 4 * BPLANE);                                   \
       }                                                                                                       \
@@ -380,6 +386,23 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   }
   int s = 0;
   bool freshA = false, pendA = false;
+  if (UP9) {
+    // chunks of four steps = the four input shifts (0,0), (-1,0), (0,-1), (-1,-1); the n-tiles of a wave are the four u types
+    // [ee, eo, oe, oo] of its 16 channels, and a shift feeds 4 / 2 / 2 / 1 of them: nine products per input pixel instead of the
+    // sixteen of the four-phase form (masks are compile-time: the skipped MFMAs and fragment reads are not in the code)
+    for (; s + 5 < a.nsteps; s += 4) {
+      STEP2M(b0h, b0l, b0h, b0l, s, dE, dO, true, true, 0xF, 0x3)
+      STEP2M(b0h, b0l, b0h, b0l, s + 1, dO, dE, true, true, 0x3, 0x5)
+      STEP2M(b0h, b0l, b0h, b0l, s + 2, dE, dO, true, true, 0x5, 0x1)
+      STEP2M(b0h, b0l, b0h, b0l, s + 3, dO, dE, true, true, 0x1, 0xF)
+    }
+    for (; s < a.nsteps; s += 4) {
+      STEP2M(b0h, b0l, b0h, b0l, s, dE, dO, s + 1 < a.nsteps, s + 2 < a.nsteps, 0xF, 0x3)
+      STEP2M(b0h, b0l, b0h, b0l, s + 1, dO, dE, s + 2 < a.nsteps, s + 3 < a.nsteps, 0x3, 0x5)
+      STEP2M(b0h, b0l, b0h, b0l, s + 2, dE, dO, s + 3 < a.nsteps, s + 4 < a.nsteps, 0x5, 0x1)
+      STEP2M(b0h, b0l, b0h, b0l, s + 3, dO, dE, s + 4 < a.nsteps, s + 5 < a.nsteps, 0x1, 0xF)
+    }
+  } else
   if (BDB) {
     for (; s + 3 < a.nsteps; s += 2) {
       STEP2(b0h, b0l, b1h, b1l, s, dE, dO, true, true)
@@ -400,10 +423,149 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
     }
   }
 #undef STEP2
+#undef STEP2M
 #undef A_OFF
 #undef DXW
 #undef B_ADDR
 
+  if constexpr (UP9) {
+    // ---- UP9 epilogue.  acc[mt][t][j] = u_t at grid position (row wm * 8 + mt, column g * 4 + j) for channel ntile * 64 + wn * 16 +
+    // r16, t = 0 ee (u[2y][2x]), 1 eo (u[2y][2x+1]), 2 oe (u[2y+1][2x]), 3 oo (u[2y+1][2x+1]) of the un-blurred transposed conv;
+    // the fused upscale (stylegan2_layers.py:312-321: weights = sum of the four unit shifts of the padded kernel) is its 2 x 2 box sum
+    //   out[2y][2x]     = ee[y][x] + eo[y][x]   + oe[y][x]   + oo[y][x]
+    //   out[2y][2x+1]   = eo[y][x] + ee[y][x+1] + oo[y][x]   + oe[y][x+1]
+    //   out[2y+1][2x]   = oe[y][x] + oo[y][x]   + ee[y+1][x] + eo[y+1][x]
+    //   out[2y+1][2x+1] = oo[y][x] + oe[y][x+1] + eo[y+1][x] + ee[y+1][x+1]
+    // for y, x = 0 .. 14 of the block's grid (row / column 15 only feed their neighbours).  The sums run in registers -- x + 1 is the
+    // next register or lane + 16, y + 1 the next m-tile; row 8 comes from the upper M-wave through LDS -- then, row by row, the four
+    // N-waves' 16-channel slices meet in an LDS tile [2 M-waves][2 output rows][32 output columns][64 ch] so that 16 lanes store the
+    // 256 contiguous bytes of one output pixel; bias, noise, activation and the tile statistics ride on that store pass.
+    constexpr int TST = 68;                              // floats per pixel of the pass tile (64 + 4: 16-byte aligned rows)
+    constexpr int TPASS = 2 * 2 * 32 * TST;              // floats per pass buffer
+    float* const xch = (float*)smem;                     // [wn][2 types][16 columns][16 ch]   (main-loop buffers are dead)
+    float* const tile = (float*)smem + 4 * 2 * 16 * 16;  // two pass buffers
+    float* const red = tile + 2 * TPASS;                 // [8 waves][64 ch][2]
+    static_assert((4 * 2 * 16 * 16 + 2 * TPASS + 8 * 64 * 2) * 4 <= MAIN_BYTES, "UP9 epilogue buffers");
+    if (wm == 1) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xch[((wn * 2 + t) * 16 + g * 4 + j) * 16 + r16] = acc[0][t][j];
+    }
+    __syncthreads();
+    float e8[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e8[t][j] = wm == 0 ? xch[((wn * 2 + t) * 16 + g * 4 + j) * 16 + r16] : 0.f;
+    const int act = a.act & 0xff;
+    // store pass: thread = (output column ox = tid >> 4, channel quad c4 = tid & 15); per pass 2 M-waves x 2 output rows
+    const int c4 = tid & 15, sox = tid >> 4;
+    const int n0 = ntile * 64 + c4 * 4;
+    const float4 bv = a.bias ? *(const float4*)(a.bias + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t img = (int64_t)b * a.out_h * a.out_w;
+    float* const yb = a.y + img * a.out_ld;
+    const float* const nzb = a.noise ? a.noise + img : nullptr;
+    const int oxg = 2 * tx0 + sox;                        // global output column of this thread
+    const bool okx = (sox >> 1) < 15 && tx0 + (sox >> 1) < a.tile_w && oxg < a.out_w;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    // the noise of this thread's 32 output pixels, all requested before the first store (vmcnt counts stores and retires in order:
+    // a load behind a pass's stores waits for their acknowledgement -- and a load per pass sat in front of its own use)
+    // (buffer loads: every request is unconditional -- pixels outside the tile / image and a launch without noise read out of range
+    //  and get zeros; as conditional global loads hipcc waited for each of the 32 in turn)
+    float nzv[8][4];
+    const __amdgpu_buffer_rsrc_t nrs = __builtin_amdgcn_make_buffer_rsrc((void*)(nzb ? nzb : (const float*)yb), 0,
+                                                                         nzb ? a.out_h * a.out_w * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int yl = (q >> 1) * 8 + mt, oy = 2 * (ty0 + yl) + (q & 1);
+        const bool ok = okx && yl < 15 && ty0 + yl < a.tile_h && oy < a.out_h;
+        nzv[mt][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(nrs, ok ? (oy * a.out_w + oxg) * 4 : (int)0x80000000, 0, 0));
+      }
+#ifdef UP9_ABL_NOEPI
+    if (a.out_scale != 123.f) return;
+#endif
+    // x + 1 neighbours of the first row
+    float ee_n = __shfl_down(acc[0][0][0], 16, 64);       // ee[y][column 4 (g + 1)] for j = 3
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+#pragma clang fp contract(off)
+      float een[4], eon[4];                               // ee / eo of row y + 1
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        een[j] = mt < 7 ? acc[mt < 7 ? mt + 1 : 7][0][j] : e8[0][j];
+        eon[j] = mt < 7 ? acc[mt < 7 ? mt + 1 : 7][1][j] : e8[1][j];
+      }
+      const float ee_x = ee_n;                                          // ee[y][x + 1] for j = 3
+      const float oe_x = __shfl_down(acc[mt][2][0], 16, 64);            // oe[y][x + 1] for j = 3
+      const float een_x = __shfl_down(een[0], 16, 64);                  // ee[y + 1][x + 1] for j = 3
+      ee_n = een_x;
+      float* tb = tile + (mt & 1) * TPASS + (wm * 2 * 32) * TST + wn * 16 + r16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float ee = acc[mt][0][j], eo = acc[mt][1][j], oe = acc[mt][2][j], oo = acc[mt][3][j];
+        const float ee1 = j < 3 ? acc[mt][0][j < 3 ? j + 1 : 3] : ee_x, oe1 = j < 3 ? acc[mt][2][j < 3 ? j + 1 : 3] : oe_x;
+        const float een1 = j < 3 ? een[j < 3 ? j + 1 : 3] : een_x;
+        const float o00 = ((ee + eo) + oe) + oo;
+        const float o01 = ((eo + ee1) + oo) + oe1;
+        const float o10 = ((oe + oo) + een[j]) + eon[j];
+        const float o11 = ((oo + oe1) + eon[j]) + een1;
+        const int ox = 2 * (g * 4 + j);
+        tb[(0 * 32 + ox) * TST] = o00;
+        tb[(0 * 32 + ox + 1) * TST] = o01;
+        tb[(1 * 32 + ox) * TST] = o10;
+        tb[(1 * 32 + ox + 1) * TST] = o11;
+      }
+      // (LDS only: __syncthreads() would also wait for the previous pass's global stores -- one HBM round trip per pass, 3 k cycles)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // (one barrier per pass: the buffer of pass mt is rewritten by pass mt + 2, behind the barrier of pass mt + 1)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int wq = q >> 1, aq = q & 1;                 // M-wave, output row phase
+        const int yl = wq * 8 + mt;                        // grid row
+        const int oy = 2 * (ty0 + yl) + aq;
+        if (okx && yl < 15 && ty0 + yl < a.tile_h && oy < a.out_h) {
+          const float4 v = *(const float4*)(tile + (mt & 1) * TPASS + ((wq * 2 + aq) * 32 + sox) * TST + c4 * 4);
+          const int pix = oy * a.out_w + oxg;
+          const float nz = a.noise_weight * nzv[mt][q];
+          float o[4] = {v.x + bv.x + nz, v.y + bv.y + nz, v.z + bv.z + nz, v.w + bv.w + nz};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float t = o[c];
+            if (act == PPST_ACT_LRELU) t = (t > 0.f ? t : t * 0.2f) * 1.41421356237309515f;
+            o[c] = t * a.out_scale;
+          }
+          PPST_EPI_STORE(yb + ((int64_t)pix * a.out_ld + n0), o);
+          s1.x += o[0]; s1.y += o[1]; s1.z += o[2]; s1.w += o[3];
+          s2.x += o[0] * o[0]; s2.y += o[1] * o[1]; s2.z += o[2] * o[2]; s2.w += o[3] * o[3];
+        }
+      }
+    }
+    if (a.stats) {
+      // lanes of a wave with equal c4 (lane & 15): xor 16, 32; then the eight waves through LDS
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64); s1.z += __shfl_xor(s1.z, o, 64); s1.w += __shfl_xor(s1.w, o, 64);
+        s2.x += __shfl_xor(s2.x, o, 64); s2.y += __shfl_xor(s2.y, o, 64); s2.z += __shfl_xor(s2.z, o, 64); s2.w += __shfl_xor(s2.w, o, 64);
+      }
+      if (lane < 16) {
+        float* r = red + (wave * 64 + c4 * 4) * 2;
+        r[0] = s1.x; r[1] = s2.x; r[2] = s1.y; r[3] = s2.y; r[4] = s1.z; r[5] = s2.z; r[6] = s1.w; r[7] = s2.w;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { t0 += red[(w * 64 + tid) * 2]; t1 += red[(w * 64 + tid) * 2 + 1]; }
+        float* o = a.stats + ((((int64_t)b * a.tiles_y + tyi) * a.tiles_x + txi) * a.cout + ntile * 64 + tid) * 2;
+        o[0] = t0;
+        o[1] = t1;
+      }
+    }
+    return;
+  }
   // ---- epilogue (as conv_mfma.hip): per wave, passes of 64 pixels x 32 channels through an LDS transposition tile
   const int gy = DUAL ? group : group >> 1, gx = DUAL ? wn / (WNW / 2) : group & 1;   // output row / column phase
   constexpr int BNC = DUAL ? BN / 2 : BN;                                              // channels per N tile
@@ -576,6 +738,10 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
   k.prelu = nullptr;
 #endif
   const int blocks = a->n_groups * n_tiles * a->B * tiles_y * tiles_x;
+  if (a->variant == 11) {     // the fused upscale as nine products per input pixel + box sum (UP9); shape conditions checked by the entry point
+    PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 4, false, 2, 2, 0, 8, false, PPST_ST_F32, true>), dim3(blocks), dim3(512), 0, st, k);
+    return PPST_LAUNCH_CHECK();
+  }
 #define L2(NT_, HALO_, WNW_, BDB_, NA_)                                                                         \
   do {                                                                                                          \
     if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<NT_, HALO_, true, WNW_, BDB_, NA_>), dim3(blocks), dim3(128 * WNW_), 0, st, k);  \

@@ -32,6 +32,11 @@ CONV_VARIANT = {"value": 2}
 # the fused upscale with Cout % 128 == 0 (and not % 256: those run the N-256 kernel as four phases) as two phase pairs on the N-256
 # kernel (ppst_conv_args.dual_b): 256 -> 128 up 2 was the slowest StyledConv layer on the tile kernel (0.42 of the ceiling)
 DUAL_CONVT = {"value": True, "min_blocks": 32}
+# the fused upscale (Cout % 64 == 0) as the un-blurred 3x3 transposed conv + 2x2 box sum in the epilogue (ppst_conv_args.variant 11,
+# conv_mfma2.hip UP9): nine products per input pixel instead of the sixteen of the 4x4 kernel; fp32-class, not bit-identical to the
+# four-phase forms (the bit-identity tests of those run with it off)
+# (blocks cover 15 x 15 input positions: an extent that fills its last tile badly -- 64 = 4.27 tiles -- stays on the four-phase form)
+UP9 = {"value": True, "min_blocks": 64, "min_fill": 0.9}
 DIRECT_MAX = {"cout": 64, "nsteps": 40, "cout3x3": 64}   # cout3x3 = 128 was measured: 128->128 @512^2 230 vs 357 TFLOP/s
 # thin layers (few channels in and out) on the direct form of that kernel
 WGRAD_SPLIT = {"blocks": 1024, "min_tiles": 4}   # conv_wgrad: target block count of a launch, fewest pixel tiles per block
@@ -256,7 +261,7 @@ class ConvPlan:
     _GEOMETRY = {}
     _GEOM_ATTRS = ("kind", "cout", "cin", "k", "bn", "n_groups", "halo", "src", "max_chan", "wstrides", "nsteps", "flop_steps",
                    "early_a", "ksplit_ok", "steps", "src_dev", "chunk_start", "chunks_per_group", "w4_shape", "max_chunk_steps",
-                   "min_chunk_steps", "full_cover", "steps_dual", "src_dual")
+                   "min_chunk_steps", "full_cover", "steps_dual", "src_dual", "steps_up9")
 
     def __init__(self, weight, kind="conv", scale=1.0, chan_base=0, precision=None):
         _chk(weight, "weight")
@@ -368,6 +373,10 @@ class ConvPlan:
                                 dsrc.append((32 * c, ky, kx0 | (kx1 << 8)))
                                 first = False
                 self._dual_tmp = (dsteps, dsrc)
+            if cout % 64 == 0:
+                # variant 11: per chunk the four input shifts; the u types each shift feeds are the kernel's (ppst_hip.h)
+                self._up9_tmp = [(chan_base + 32 * c, dy, dx, 1 if (dy, dx) == (0, 0) else 0)
+                                 for c in range(nchunk) for dy, dx in ((0, 0), (-1, 0), (0, -1), (-1, -1))]
         elif kind == "dgrad":
             # input gradient of a stride-1 conv (zero padding): a conv of dY with the transposed,
             # flipped weights  Wd[c][n][ky][kx] = W[n][c][k-1-ky][k-1-kx]  -- same memory, other strides
@@ -483,6 +492,10 @@ class ConvPlan:
             self.steps_dual = torch.tensor(encode(dual[0]) + [(0, 0, 0, 0)] * 4, dtype=torch.int32, device=dev).contiguous()
             sd_ = torch.tensor(dual[1], dtype=torch.int32, device=dev)
             self.src_dual = (sd_[:, 0].contiguous(), sd_[:, 1].contiguous(), sd_[:, 2].contiguous())
+        up9 = self.__dict__.pop("_up9_tmp", None)
+        self.steps_up9 = None
+        if up9 is not None:
+            self.steps_up9 = torch.tensor(encode(up9) + [(0, 0, 0, 0)] * 4, dtype=torch.int32, device=dev).contiguous()
         s = torch.tensor(src, dtype=torch.int32, device=dev)
         src_c, src_ky, src_kx = s[:, 0].contiguous(), s[:, 1].contiguous(), s[:, 2].contiguous()
         self.src_dev = (src_c, src_ky, src_kx)
@@ -529,6 +542,19 @@ class ConvPlan:
         self._packs["dual"] = wpack
         return wpack
 
+    def pack_up9(self):
+        """weights for variant 11 (ppst_conv_pack_up9: the un-blurred 3x3 kernel), built on first use."""
+        hit = self._packs.get("up9")
+        if hit is not None:
+            return hit
+        w = self.wparam                                          # (Cout, Cin, 3, 3) fp32, the layer's own parameter
+        nbytes = lib.ppst_conv_pack_up9_bytes(self.cout, self.cin)
+        wpack = torch.empty(nbytes // 2, dtype=torch.int16, device=self.steps.device)
+        check(lib.ppst_conv_pack_up9(_p(w), self.cin * 9, 9, 3, 1, float(self.up_scale), self.cout, self.cin, _p(wpack), _stream()),
+              "ppst_conv_pack_up9")
+        self._packs["up9"] = wpack
+        return wpack
+
     def pack_wino(self):
         """transformed weights for variant 10 (ppst_conv_pack_wino), built on first use."""
         hit = self._packs.get("wino")
@@ -568,6 +594,10 @@ class ConvPlan:
         cv = CONV_VARIANT["value"]
         if cv in (1, 3) or TWO_BLOCK_128["value"] or KSPLIT_128["value"] or TILE24_128["value"] or TALL_TILE_128["value"]:
             _need_experiments("the requested conv variant")
+        if (UP9["value"] and self.kind == "convT" and self.precision == 0 and getattr(self, "steps_up9", None) is not None
+                and self.early_a and ((th + 14) // 15) * ((tw + 14) // 15) * (self.cout // 64) >= UP9["min_blocks"]
+                and th * tw >= UP9["min_fill"] * (((th + 14) // 15) * 15) * (((tw + 14) // 15) * 15)):
+            return "up9", 256, 15
         if (DUAL_CONVT["value"] and self.kind == "convT" and getattr(self, "steps_dual", None) is not None
                 and self.cout % 256 != 0 and CONV_VARIANT["value"] == 2 and self.early_a
                 and ((th + 15) // 16) * ((tw + 15) // 16) * 2 * (self.cout // 128) >= DUAL_CONVT["min_blocks"]):
@@ -659,13 +689,19 @@ class ConvPlan:
         st = None
         if stats:
             tiles = lib.ppst_conv_tiles(th, tw, rows)
-            st = torch.empty((B, self.n_groups * tiles, self.cout, 2), device=x.device, dtype=torch.float32)
+            st = torch.empty((B, (1 if variant == "up9" else self.n_groups) * tiles, self.cout, 2), device=x.device, dtype=torch.float32)
+            # (a block of variant 11 writes its row only for channels it owns and every block of the grid writes: no zero fill needed)
         a = _lib.ConvArgs()
-        dual = variant == "dual"
+        dual, up9 = variant == "dual", variant == "up9"
         if dual:
             variant = 2
-        wp = None if self.precision == 2 else (self.pack_wino() if variant == 10 else self.pack_dual() if dual else self.pack_for(bn))
-        a.x, a.wpack, a.steps, a.y = _p(x), _p(wp), _p(self.steps_dual if dual else self.steps), _p(out)
+        if up9:
+            variant = 11
+            if in_ss is not None or residual is not None or act == ACT_PRELU or pad_mode != PAD_ZERO:
+                raise RuntimeError("the nine-product upscale (ops.UP9) takes no normalise-on-load, residual, PReLU or non-zero padding")
+        wp = None if self.precision == 2 else (self.pack_wino() if variant == 10 else self.pack_up9() if up9 else self.pack_dual() if dual
+                                               else self.pack_for(bn))
+        a.x, a.wpack, a.steps, a.y = _p(x), _p(wp), _p(self.steps_up9 if up9 else self.steps_dual if dual else self.steps), _p(out)
         a.variant = variant
         a.dual_b = 1 if dual else 0
         a.bias, a.noise, a.prelu, a.stats = _p(bias), _p(noise), _p(prelu), _p(st)
@@ -675,7 +711,7 @@ class ConvPlan:
         a.noise_weight, a.out_scale = float(noise_weight), float(out_scale)
         a.B, a.in_h, a.in_w, a.in_ld = B, H, W, in_ld
         a.out_h, a.out_w, a.out_ld, a.cout = oh, ow, out_ld, self.cout
-        a.nsteps, a.n_groups, a.pad_mode = self.nsteps, (2 if dual else self.n_groups), pad_mode
+        a.nsteps, a.n_groups, a.pad_mode = self.nsteps, (1 if up9 else 2 if dual else self.n_groups), pad_mode
         a.in_off_y = a.in_off_x = 0
         a.out_sy = a.out_sx = osy
         a.act, a.precision = act | (0x100 if res_after_act else 0), self.precision
@@ -722,6 +758,9 @@ def repack_plans(plans):
             if bn == "wino":                     # variant-10 pack: its own transform kernel, one launch per plan
                 wino.append((pl.wsrc, pl.wstrides, float(pl.scale), pl.cout, pl.cin, wpack))
                 continue
+            if bn == "up9":                      # variant-11 pack: from the 3x3 parameter itself, one launch per plan
+                wino.append(("up9", pl.wparam, float(pl.up_scale), pl.cout, pl.cin, wpack))
+                continue
             if bn == "dual":                     # two-phase-pair pack of the fused upscale: a job of the batched pack kernel
                 dc, dky, dkx = pl.src_dual
                 pk.append((pl.wsrc.data_ptr(), sn, sc, sy, sx, dc.data_ptr(), dky.data_ptr(), dkx.data_ptr(), wpack.data_ptr(),
@@ -767,7 +806,11 @@ def run_repack(tables):
         check(lib.ppst_upscale_weight_batch(_p(tu), nu, nbu, _stream()), "ppst_upscale_weight_batch")
     if npk:
         check(lib.ppst_conv_pack_batch(_p(tp), npk, nbp, _stream()), "ppst_conv_pack_batch")
-    for wsrc, (sn, sc, sy, sx), scale, cout, cin, wpack in wino:
+    for wsrc, strides, scale, cout, cin, wpack in wino:
+        if isinstance(wsrc, str):                # ("up9", the 3x3 parameter, ...): variant 11
+            check(lib.ppst_conv_pack_up9(_p(strides), cin * 9, 9, 3, 1, scale, cout, cin, _p(wpack), _stream()), "ppst_conv_pack_up9")
+            continue
+        sn, sc, sy, sx = strides
         check(lib.ppst_conv_pack_wino(_p(wsrc), sn, sc, sy, sx, scale, cout, cin, _p(wpack), _stream()), "ppst_conv_pack_wino")
 
 

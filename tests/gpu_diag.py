@@ -316,12 +316,12 @@ def direct_kernels_only(fn):
 
     @functools.wraps(fn)
     def wrapped(*a, **k):
-        prev = ops.WINO["value"], ops.DUAL_CONVT["value"]
-        ops.WINO["value"] = ops.DUAL_CONVT["value"] = False
+        prev = ops.WINO["value"], ops.DUAL_CONVT["value"], ops.UP9["value"]
+        ops.WINO["value"] = ops.DUAL_CONVT["value"] = ops.UP9["value"] = False
         try:
             return fn(*a, **k)
         finally:
-            ops.WINO["value"], ops.DUAL_CONVT["value"] = prev
+            ops.WINO["value"], ops.DUAL_CONVT["value"], ops.UP9["value"] = prev
     return wrapped
 
 
@@ -496,6 +496,8 @@ def t_conv_dual():
     tile statistics to rounding; and against float64 torch.  The same identity in the single-pass modes (precision 1 / 3)."""
     torch.manual_seed(9)
     prev = dict(ops.DUAL_CONVT)
+    up9_prev = ops.UP9["value"]
+    ops.UP9["value"] = False             # (variant 11 is a different sum: t_conv_up9)
     try:
       for prec in (0, 1, 3):
         for name, B, ci, co, H, Wd, feat in [("convT 64->128 40x24 full", 2, 64, 128, 40, 24, "full"), ("convT 256->128 64x64 plain", 1, 256, 128, 64, 64, "plain"),
@@ -525,6 +527,43 @@ def t_conv_dual():
                   report("dual convT %s vs float64" % name, nchw(outs[1][0]), ref, 3e-5)
     finally:
         ops.DUAL_CONVT.update(prev)
+        ops.UP9["value"] = up9_prev
+
+
+def t_conv_up9():
+    """The fused 4x4 stride-2 upscale as the un-blurred 3x3 transposed conv + 2x2 box sum in the epilogue (ppst_conv_args.variant 11:
+    nine products per input pixel instead of sixteen) against float64 torch (the reference's own formula, stylegan2_layers.py:312-321)
+    at the fp32-class bar of the other conv kernels, and against the four-phase kernels of the same plan; every epilogue option it
+    takes (bias, noise, leaky ReLU, out_scale, statistics), ragged extents (not multiples of 15 / 16), Cout 128 / 256 / 512."""
+    torch.manual_seed(11)
+    prev = dict(ops.UP9)
+    try:
+        for name, B, ci, co, H, Wd, feat in [("convT 64->128 40x24 full", 2, 64, 128, 40, 24, "full"), ("convT 256->128 64x64 plain", 1, 256, 128, 64, 64, "plain"),
+                                             ("convT 128->256 17x33 full (ragged)", 2, 128, 256, 17, 33, "full"), ("convT 32->512 31x30 scale", 1, 32, 512, 31, 30, "scale"),
+                                             ("convT 512->256 128x128 full", 2, 512, 256, 128, 128, "full")]:
+            w = g(torch.randn(co, ci, 3, 3) / math.sqrt(ci * 9))
+            x = g(torch.randn(B, H, Wd, ci))
+            kw = {}
+            if feat == "full":
+                kw = dict(bias=g(torch.randn(co)), noise=g(torch.randn(B, 1, 2 * H, 2 * Wd)), noise_weight=0.3, act=ops.ACT_LRELU)
+            elif feat == "scale":
+                kw = dict(bias=g(torch.randn(co)), out_scale=0.7)
+            outs = []
+            for on in (False, True):
+                ops.UP9.update(value=on, min_blocks=0, min_fill=0.0)
+                plan = ops.ConvPlan(w, kind="convT", scale=0.5)
+                assert (plan.choose_kernel(H, Wd, 2 * H, 2 * Wd, H, Wd, 2)[0] == "up9") == on
+                y, st = plan(x, stats=True, **kw)
+                outs.append((y.cpu(), st.sum(1).cpu()))
+            report("nine-product upscale %s vs the four-phase form" % name, outs[1][0], outs[0][0], 1e-5)
+            report("nine-product upscale %s stats" % name, outs[1][1], outs[0][1], 2e-5)
+            if feat != "full":
+                ref = conv_ref(nchw(x.cpu()).double(), (w.cpu().double() * 0.5), "convT", 0)
+                if feat == "scale":
+                    ref = (ref + kw["bias"].cpu().double().view(1, -1, 1, 1)) * 0.7
+                report("nine-product upscale %s vs float64" % name, nchw(outs[1][0]), ref, 3e-5)
+    finally:
+        ops.UP9.update(prev)
 
 
 @direct_kernels_only
@@ -1222,6 +1261,8 @@ def main():
         run(t_networks)
     if which == "prec":
         run(t_precision)
+    if which == "up9":
+        run(t_conv_up9)
     if which == "half":
         run(t_half_storage)
         run(t_conv_dual)

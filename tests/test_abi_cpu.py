@@ -355,13 +355,22 @@ def test_conv_kernel_choice_is_a_function_of_one_image():
     pd.steps_dual = object()
     assert ck(pd, 256, osy=2, out=(512, 512)) == ("dual", 256, 16)
     assert ck(pd, 32, osy=2, out=(64, 64)) == (0, 128, 16)                        # 8 blocks per image: the four-group tile kernel
-    # the DIRECT kernels' table (what runs with the two switches off, and what the bit-identity tests compare)
-    wino_prev, dual_prev = ops.WINO["value"], ops.DUAL_CONVT["value"]
-    ops.WINO["value"] = ops.DUAL_CONVT["value"] = False
+    # the fused upscale as nine products per input pixel (variant 11) where one image gives >= 64 blocks of 15 x 15 positions
+    assert ops.UP9["value"]
+    for cout, ng in ((128, 4), (256, 4), (512, 4)):
+        pu = plan("convT", 256, cout, 3, 32, 1, n_groups=ng)
+        pu.steps_dual, pu.steps_up9 = object(), object()
+        assert ck(pu, 256, osy=2, out=(512, 512)) == ("up9", 256, 15)
+        assert ck(pu, 30, osy=2, out=(60, 60))[0] != "up9"                        # 4 x cout / 64 blocks per image
+        assert ck(pu, 64, osy=2, out=(128, 128))[0] != "up9" and ck(pu, 128, osy=2, out=(256, 256))[0] == "up9"   # 64 = 4.27 tiles of 15
+        assert ck(plan("convT", 256, cout, 3, 32, 1, n_groups=ng, precision=3), 256, osy=2, out=(512, 512))[0] != "up9"
+    # the DIRECT kernels' table (what runs with the three switches off, and what the bit-identity tests compare)
+    prev = ops.WINO["value"], ops.DUAL_CONVT["value"], ops.UP9["value"]
+    ops.WINO["value"] = ops.DUAL_CONVT["value"] = ops.UP9["value"] = False
     try:
         _direct_kernel_table(ops, plan, ck)
     finally:
-        ops.WINO["value"], ops.DUAL_CONVT["value"] = wino_prev, dual_prev
+        ops.WINO["value"], ops.DUAL_CONVT["value"], ops.UP9["value"] = prev
 
 
 def _direct_kernel_table(ops, plan, ck):
