@@ -36,7 +36,7 @@ DUAL_CONVT = {"value": True, "min_blocks": 32}
 # conv_mfma2.hip UP9): nine products per input pixel instead of the sixteen of the 4x4 kernel; fp32-class, not bit-identical to the
 # four-phase forms (the bit-identity tests of those run with it off)
 # (blocks cover 15 x 15 input positions: an extent that fills its last tile badly -- 64 = 4.27 tiles -- stays on the four-phase form)
-UP9 = {"value": True, "min_blocks": 64, "min_fill": 0.9}
+UP9 = {"value": True, "min_blocks": 64, "min_fill": 0.85}
 DIRECT_MAX = {"cout": 64, "nsteps": 40, "cout3x3": 64}   # cout3x3 = 128 was measured: 128->128 @512^2 230 vs 357 TFLOP/s
 # thin layers (few channels in and out) on the direct form of that kernel
 WGRAD_SPLIT = {"blocks": 1024, "min_tiles": 4}   # conv_wgrad: target block count of a launch, fewest pixel tiles per block
