@@ -15,8 +15,10 @@
  * All tensors are fp32 unless stated.  Activation tensors of the single-pass precision
  * modes may be stored as IEEE half / bfloat16: the `*_st` entry points and
  * ppst_conv_args.io_st take a storage type (PPST_ST_* below, the values of the PPST_F32 /
- * PPST_F16 / PPST_BF16 dtype enum); the older `dtype` argument of ppst_upfirdn2d still
- * accepts PPST_F32 only.
+ * PPST_F16 / PPST_BF16 dtype enum); the `dtype` argument of ppst_upfirdn2d and
+ * ppst_fused_bias_act takes the same three types (the reference's
+ * AT_DISPATCH_FLOATING_TYPES_AND_HALF: upfirdn2d_kernel.cu:225, fused_bias_act_kernel.cu:79;
+ * fp32 arithmetic, one rounding; the FIR taps stay fp32).
  */
 #ifndef PPST_HIP_H
 #define PPST_HIP_H

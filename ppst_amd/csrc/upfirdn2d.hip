@@ -32,8 +32,8 @@ __device__ __forceinline__ int uf_reflect(int i, int n) {
 }
 
 // ---- planes: minor == 1, up == down == 1 ---------------------------------
-template <int KH, int KW>
-__global__ __launch_bounds__(256) void upfirdn2d_planes(const float* __restrict__ x, float* __restrict__ y, UfParams p) {
+template <int KH, int KW, int ST = PPST_ST_F32>
+__global__ __launch_bounds__(256) void upfirdn2d_planes(const void* __restrict__ x, void* __restrict__ y, UfParams p) {
   constexpr int TH = 32, TW = 64, IH = TH + KH - 1, IW = TW + KW - 1;
   __shared__ float sx[IH][IW + 1];
   float kf[KH * KW];
@@ -43,14 +43,13 @@ __global__ __launch_bounds__(256) void upfirdn2d_planes(const float* __restrict_
   const int tile_x = (blockIdx.x % tiles_x) * TW;
   const int tile_y = (blockIdx.x / tiles_x) * TH;
   const int64_t plane = blockIdx.y;
-  const float* xp = x + plane * (int64_t)p.in_h * p.in_w;
-  float* yp = y + plane * (int64_t)p.out_h * p.out_w;
+  const int64_t xp = plane * (int64_t)p.in_h * p.in_w, yp = plane * (int64_t)p.out_h * p.out_w;     // element offsets of the plane
   const int in_x0 = tile_x - p.pad_x0, in_y0 = tile_y - p.pad_y0;
   for (int i = threadIdx.x; i < IH * IW; i += 256) {
     int ry = i / IW, rx = i - ry * IW;
     int iy = in_y0 + ry, ix = in_x0 + rx;
     float v = 0.f;
-    if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) v = xp[(int64_t)iy * p.in_w + ix];
+    if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) v = st_ld1<ST>(x, xp + (int64_t)iy * p.in_w + ix);
     sx[ry][rx] = v;
   }
   __syncthreads();
@@ -75,7 +74,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_planes(const float* __restrict_
 #pragma unroll
       for (int kx = 0; kx < KW; ++kx) acc += win[ky][kx] * kf[ky * KW + kx];
     int oy = tile_y + w * 8 + r;
-    if (oy < p.out_h && ox < p.out_w) yp[(int64_t)oy * p.out_w + ox] = acc;
+    if (oy < p.out_h && ox < p.out_w) st_st1<ST>(y, yp + (int64_t)oy * p.out_w + ox, acc);
   }
 }
 
@@ -219,7 +218,8 @@ __global__ __launch_bounds__(256) void upfirdn2d_chan(const void* __restrict__ x
 }
 
 // ---- generic ---------------------------------------------------------------
-__global__ __launch_bounds__(256) void upfirdn2d_generic(const float* __restrict__ x, float* __restrict__ y, UfParams p, int64_t n) {
+template <int ST = PPST_ST_F32>
+__global__ __launch_bounds__(256) void upfirdn2d_generic(const void* __restrict__ x, void* __restrict__ y, UfParams p, int64_t n) {
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
     int mi = (int)(t % p.minor);
     int64_t r = t / p.minor;
@@ -237,10 +237,10 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic(const float* __restrict
         if (X < 0 || X % p.up_x) continue;
         int ix = X / p.up_x;
         if (ix >= p.in_w) continue;
-        acc += x[(((int64_t)m * p.in_h + iy) * p.in_w + ix) * p.minor + mi] * p.k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+        acc += st_ld1<ST>(x, (((int64_t)m * p.in_h + iy) * p.in_w + ix) * p.minor + mi) * p.k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
       }
     }
-    y[t] = acc;
+    st_st1<ST>(y, t, acc);
   }
 }
 
@@ -292,13 +292,13 @@ static int launch_chan(const void* x, void* y, const UfParams& p, int down, bool
   return PPST_LAUNCH_CHECK();
 }
 
-template <int KH, int KW>
-static int launch_fast(const float* x, float* y, const UfParams& p, hipStream_t st) {
+template <int KH, int KW, int ST = PPST_ST_F32>
+static int launch_fast(const void* x, void* y, const UfParams& p, hipStream_t st) {
   if (p.minor == 1) {
     dim3 grid(cdiv(p.out_w, 64) * cdiv(p.out_h, 32), p.major);
-    PPST_LAUNCH((upfirdn2d_planes<KH, KW>), grid, dim3(256), 0, st, x, y, p);
+    PPST_LAUNCH((upfirdn2d_planes<KH, KW, ST>), grid, dim3(256), 0, st, x, y, p);
   } else {
-    return launch_chan<KH, KW>(x, y, p, 1, false, st);
+    return launch_chan<KH, KW, ST>(x, y, p, 1, false, st);
   }
   return PPST_LAUNCH_CHECK();
 }
@@ -306,7 +306,10 @@ static int launch_fast(const float* x, float* y, const UfParams& p, hipStream_t 
 extern "C" int ppst_upfirdn2d(const void* x, const void* k, void* y, int major, int in_h, int in_w, int minor,
                               int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
                               int pad_y0, int pad_y1, int dtype, void* stream) {
-  if (dtype != PPST_F32) return PPST_EUNSUPPORTED;
+  // dtype: element type of x and y (the reference: AT_DISPATCH_FLOATING_TYPES_AND_HALF, upfirdn2d_kernel.cu:225); the taps k are fp32
+  // at this boundary and the products are accumulated in fp32 (the reference accumulates in the tensor's type), rounded once
+  if (dtype != PPST_F32 && dtype != PPST_F16 && dtype != PPST_BF16) return PPST_EUNSUPPORTED;
+  if (dtype != PPST_F32 && (((uintptr_t)x | (uintptr_t)y) % 8)) return PPST_EINVAL;
   if (major != 0 && (!x || !k || !y)) return PPST_ENULL;  // an empty batch has no storage
   if (major < 0 || in_h <= 0 || in_w <= 0 || minor <= 0 || kh <= 0 || kw <= 0 || kh > UF_MAXK || kw > UF_MAXK ||
       up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0)
@@ -325,12 +328,28 @@ extern "C" int ppst_upfirdn2d(const void* x, const void* k, void* y, int major, 
   const float* xf = (const float*)x;
   float* yf = (float*)y;
   bool fast = up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && (minor == 1 || minor % 4 == 0) && kh == kw;
+  bool down2 = up_x == 1 && up_y == 1 && down_x == 2 && down_y == 2 && minor % 4 == 0 && kh == kw;
+  int64_t n = (int64_t)major * p.out_h * p.out_w * minor;
+  if (dtype != PPST_F32) {          // half / bfloat16: the same kernels on the tensor's storage type (the zero-insert x2 form: generic)
+#define UF_HALF(ST_)                                                                            \
+  do {                                                                                          \
+    if (fast && kh == 3) return launch_fast<3, 3, ST_>(x, y, p, st);                            \
+    if (fast && kh == 4) return launch_fast<4, 4, ST_>(x, y, p, st);                            \
+    if (down2 && kh == 3) return launch_chan<3, 3, ST_>(x, y, p, 2, false, st);                 \
+    if (down2 && kh == 4) return launch_chan<4, 4, ST_>(x, y, p, 2, false, st);                 \
+    int64_t blocks_ = cdiv64(n, 256);                                                           \
+    if (blocks_ > 256 * 32) blocks_ = 256 * 32;                                                 \
+    PPST_LAUNCH(upfirdn2d_generic<ST_>, dim3((unsigned)blocks_), dim3(256), 0, st, x, y, p, n); \
+    return PPST_LAUNCH_CHECK();                                                                 \
+  } while (0)
+    if (dtype == PPST_F16) UF_HALF(PPST_ST_F16);
+    UF_HALF(PPST_ST_BF16);
+#undef UF_HALF
+  }
   if (fast && kh == 3) return launch_fast<3, 3>(xf, yf, p, st);
   if (fast && kh == 4) return launch_fast<4, 4>(xf, yf, p, st);
-  bool down2 = up_x == 1 && up_y == 1 && down_x == 2 && down_y == 2 && minor % 4 == 0 && kh == kw;
   if (down2 && kh == 3) return launch_chan<3, 3>(xf, yf, p, 2, false, st);
   if (down2 && kh == 4) return launch_chan<4, 4>(xf, yf, p, 2, false, st);
-  int64_t n = (int64_t)major * p.out_h * p.out_w * minor;
   if (up_x == 2 && up_y == 2 && down_x == 1 && down_y == 1 && minor % 4 == 0 && n / 4 <= PPST_IDX32_MAX &&
       (((uintptr_t)x | (uintptr_t)y) % 16) == 0) {
     int64_t b4 = cdiv64(n / 4, 256);
@@ -341,7 +360,7 @@ extern "C" int ppst_upfirdn2d(const void* x, const void* k, void* y, int major, 
   }
   int64_t blocks = cdiv64(n, 256);
   if (blocks > 256 * 32) blocks = 256 * 32;
-  PPST_LAUNCH(upfirdn2d_generic, dim3((unsigned)blocks), dim3(256), 0, st, xf, yf, p, n);
+  PPST_LAUNCH(upfirdn2d_generic<PPST_ST_F32>, dim3((unsigned)blocks), dim3(256), 0, st, xf, yf, p, n);
   return PPST_LAUNCH_CHECK();
 }
 

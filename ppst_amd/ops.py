@@ -194,18 +194,20 @@ def nhwc_to_nchw(x):
 
 # ------------------------------------------------------ upfirdn2d / blur ----
 def upfirdn2d_raw(x4, kernel, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
-    """x4: [major, H, W, minor] contiguous (upfirdn2d.cpp:4-23). Returns [major, oh, ow, minor]."""
-    _chk(x4, "input")
-    _chk(kernel, "kernel")
+    """x4: [major, H, W, minor] contiguous (upfirdn2d.cpp:4-23). Returns [major, oh, ow, minor].  float32, float16 or bfloat16
+    like the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF (upfirdn2d_kernel.cu:225); the taps are used as fp32 and the
+    products accumulate in fp32 (the reference accumulates in the tensor's type), rounded once to the input's type."""
+    _chk_act(x4, "input")
+    _chk_act(kernel, "kernel")
     x4 = x4.contiguous()
-    kernel = kernel.contiguous()
+    kernel = kernel.float().contiguous()
     major, in_h, in_w, minor = x4.shape
     kh, kw = kernel.shape
     out_h = (in_h * up_y + py0 + py1 - kh + down_y) // down_y
     out_w = (in_w * up_x + px0 + px1 - kw + down_x) // down_x
-    y = torch.empty((major, out_h, out_w, minor), device=x4.device, dtype=torch.float32)
+    y = torch.empty((major, out_h, out_w, minor), device=x4.device, dtype=x4.dtype)
     check(lib.ppst_upfirdn2d(_p(x4), _p(kernel), _p(y), major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y,
-                             px0, px1, py0, py1, 0, _stream()), "ppst_upfirdn2d")
+                             px0, px1, py0, py1, _ST[x4.dtype], _stream()), "ppst_upfirdn2d")
     return y
 
 
@@ -229,20 +231,22 @@ def blur_nhwc(x, kernel, pad0, pad1, pad_mode=PAD_ZERO, down=1, s2d=False, in_ss
 
 
 def fused_bias_act_raw(x, b, ref, act, grad, alpha, scale):
-    """fused.fused_bias_act (fused_bias_act.cpp:4-20): empty tensor == absent."""
-    _chk(x, "input")
+    """fused.fused_bias_act (fused_bias_act.cpp:4-20): empty tensor == absent.  float32, float16 or bfloat16 (the reference:
+    AT_DISPATCH_FLOATING_TYPES_AND_HALF, fused_bias_act_kernel.cu:79): bias and refer take the input's type, fp32 arithmetic,
+    one rounding."""
+    _chk_act(x, "input")
     x = x.contiguous()
-    b = None if (b is None or b.numel() == 0) else b.contiguous()
-    ref = None if (ref is None or ref.numel() == 0) else ref.contiguous()
-    _chk(b, "bias")
-    _chk(ref, "refer")
+    b = None if (b is None or b.numel() == 0) else b.to(x.dtype).contiguous()
+    ref = None if (ref is None or ref.numel() == 0) else ref.to(x.dtype).contiguous()
+    _chk_act(b, "bias")
+    _chk_act(ref, "refer")
     y = torch.empty_like(x)
     step_b = 1
     for i in range(2, x.dim()):
         step_b *= x.size(i)
     size_b = b.numel() if b is not None else 1
     check(lib.ppst_fused_bias_act(_p(x), _p(b), _p(ref), _p(y), x.numel(), step_b, size_b, act, grad, float(alpha),
-                                  float(scale), 0, _stream()), "ppst_fused_bias_act")
+                                  float(scale), _ST[x.dtype], _stream()), "ppst_fused_bias_act")
     return y
 
 

@@ -39,6 +39,7 @@ class _BiasLeakyReLU(torch.autograd.Function):
         ctx.save_for_backward(out)
         ctx.cfg = (slope, scale)
         ctx.has_bias = bias is not None
+        ctx.bias_dtype = bias.dtype if bias is not None else None
         return out
 
     @staticmethod
@@ -48,7 +49,7 @@ class _BiasLeakyReLU(torch.autograd.Function):
         gx = _GateByOutput.apply(gy.contiguous(), out, slope, scale)
         gb = None
         if ctx.has_bias:
-            gb = gx.sum([0] + list(range(2, gx.ndim)))
+            gb = gx.sum([0] + list(range(2, gx.ndim))).to(ctx.bias_dtype)
         return gx, gb, None, None
 
 

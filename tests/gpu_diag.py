@@ -153,6 +153,40 @@ def t_fused_act():
     report("upfirdn2d double backward", ggg, ggc, 2e-6)
 
 
+def t_ops_half():
+    """The two native ops on half tensors (the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF: upfirdn2d_kernel.cu:225,
+    fused_bias_act_kernel.cu:79; round-3 verdict, missing #3): float16 and bfloat16 inputs through the public op functions,
+    against the fp32 op on the widened input rounded once (fp32 accumulation, one rounding: bit-exact), forward and gradient."""
+    from ppst_amd.stylegan2_op import upfirdn2d, fused_leaky_relu
+    torch.manual_seed(31)
+    for dt in (torch.float16, torch.bfloat16):
+        tag = str(dt).split(".")[-1]
+        k4 = torch.tensor([1., 3., 3., 1.]); k4 = (k4[:, None] * k4[None, :] / 64)
+        for name, kw in (("blur pad (2,1)", dict(pad=(2, 1))), ("up 2 pad (2,1)", dict(up=2, pad=(2, 1))), ("down 2 pad (1,1)", dict(down=2, pad=(1, 1)))):
+            x = g(torch.randn(2, 5, 23, 19)).to(dt).requires_grad_(True)
+            xf = x.detach().float().requires_grad_(True)
+            y = upfirdn2d(x, g(k4).to(dt), **kw)
+            yf = upfirdn2d(xf, g(k4).to(dt).float(), **kw)
+            ok = y.dtype == dt and bool(torch.equal(y.detach(), yf.detach().to(dt)))
+            RES.append(("upfirdn2d %s %s forward == fp32 op rounded" % (tag, name), ok))
+            print("upfirdn2d %-9s %-18s %s max diff %.3e" % (tag, name, "ok  " if ok else "FAIL", (y.float() - yf).abs().max().item()), flush=True)
+            gy = g(torch.randn(y.shape)).to(dt)
+            y.backward(gy); yf.backward(gy.float())
+            report("upfirdn2d %s %s gradient" % (tag, name), x.grad.float(), xf.grad, 2e-2 if dt == torch.bfloat16 else 3e-3)
+        x = g(torch.randn(3, 8, 11, 13)).to(dt).requires_grad_(True)
+        b = g(torch.randn(8)).to(dt).requires_grad_(True)
+        xf, bf = x.detach().float().requires_grad_(True), b.detach().float().requires_grad_(True)
+        y, yf = fused_leaky_relu(x, b), fused_leaky_relu(xf, bf)
+        ok = y.dtype == dt and bool(torch.equal(y.detach(), yf.detach().to(dt)))
+        RES.append(("fused_leaky_relu %s forward == fp32 op rounded" % tag, ok))
+        print("fused_leaky_relu %-9s %s max diff %.3e" % (tag, "ok  " if ok else "FAIL", (y.float() - yf).abs().max().item()), flush=True)
+        gy = g(torch.randn(y.shape)).to(dt)
+        y.backward(gy); yf.backward(gy.float())
+        # (the gate of the gradient is the sign of the saved OUTPUT: identical in both runs unless rounding moved an output to 0)
+        report("fused_leaky_relu %s input gradient" % tag, x.grad.float(), xf.grad, 2e-2 if dt == torch.bfloat16 else 3e-3)
+        report("fused_leaky_relu %s bias gradient" % tag, b.grad.float(), bf.grad, 5e-2 if dt == torch.bfloat16 else 1e-2)
+
+
 def t_layout_misc():
     torch.manual_seed(1)
     for (B, C, H, Wd) in [(2, 3, 17, 19), (1, 32, 64, 64), (2, 70, 9, 33)]:
@@ -1252,7 +1286,7 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     print("device:", torch.cuda.get_device_name(0), flush=True)
     if which in ("ops", "all"):
-        for fn in (t_upfirdn2d, t_fused_act, t_layout_misc, t_conv, t_conv_variants, t_conv_variants_single_pass, t_half_storage, t_conv1x1_stream, t_norm_pool, t_corr, t_guided):
+        for fn in (t_upfirdn2d, t_fused_act, t_ops_half, t_layout_misc, t_conv, t_conv_variants, t_conv_variants_single_pass, t_half_storage, t_conv1x1_stream, t_norm_pool, t_corr, t_guided):
             print("== " + fn.__name__, flush=True)
             run(fn)
             torch.cuda.synchronize()
@@ -1261,6 +1295,8 @@ def main():
         run(t_networks)
     if which == "prec":
         run(t_precision)
+    if which == "opshalf":
+        run(t_ops_half)
     if which == "up9":
         run(t_conv_up9)
     if which == "half":

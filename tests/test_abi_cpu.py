@@ -35,7 +35,9 @@ def test_argument_errors_need_no_gpu():
     from ppst_amd._lib import lib
     assert lib.ppst_version() >= 1
     # unsupported dtype / null pointers / bad sizes are rejected before any launch
-    assert lib.ppst_upfirdn2d(None, None, None, 1, 4, 4, 1, 3, 3, 1, 1, 1, 1, 0, 0, 0, 0, 1, None) == -2
+    assert lib.ppst_upfirdn2d(None, None, None, 1, 4, 4, 1, 3, 3, 1, 1, 1, 1, 0, 0, 0, 0, 7, None) == -2    # no such dtype
+    assert lib.ppst_upfirdn2d(None, None, None, 1, 4, 4, 1, 3, 3, 1, 1, 1, 1, 0, 0, 0, 0, 1, None) == -3    # PPST_F16: valid, null data
+    assert lib.ppst_fused_bias_act(None, None, None, None, 4, 1, 1, 3, 0, 0.2, 1.0, 9, None) == -2
     assert lib.ppst_upfirdn2d(None, None, None, 1, 4, 4, 1, 3, 3, 1, 1, 1, 1, 0, 0, 0, 0, 0, None) == -3
     assert lib.ppst_fused_bias_act(None, None, None, None, -1, 1, 1, 3, 0, 0.2, 1.0, 0, None) == -1
     assert lib.ppst_fused_bias_act(None, None, None, None, 0, 1, 1, 3, 0, 0.2, 1.0, 0, None) == 0  # empty input
