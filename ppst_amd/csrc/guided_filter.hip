@@ -303,6 +303,235 @@ __global__ __launch_bounds__(256) void gf_v1_solve_slide_kernel(const float* __r
   }
 }
 
+// ---- stage 1 in the other order (round 4, later): V pass FIRST, on the raw uint8 rows -------------------------------------------
+// The H-then-V order above makes the V pass slide over 21 fp32 planes: a thread's window start (61 rows) and every leaving row are
+// re-read -- 3.9 row visits per output at 84 bytes each (PMC: 1.34 GB of fetches per batch of four 1024^2 images for 352 MB of
+// planes).  With the V pass first, what is re-read is the 6 bytes of a pixel (guide + source): the 21 moments of the entering /
+// leaving row are formed on the fly and the 21 column sums (< 2^22: exact as fp32) written once; the H pass then stages each row of
+// column sums once in LDS, slides in uint32 (< 2^28: exact) and solves the pixel's 3x3 system from LDS.  Same integers as the H-then-V
+// order, so the same (a, b) bit for bit.
+template <int RR>
+__global__ __launch_bounds__(256) void gf_v1m_slide_kernel(const unsigned char* __restrict__ guide, const unsigned char* __restrict__ src,
+                                                           float* __restrict__ out, int H, int W) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= W) return;
+  const int y0 = blockIdx.y * GF_VSEG, b = blockIdx.z;
+  const int64_t P = (int64_t)H * W;
+  const unsigned char* gp = guide + ((int64_t)b * P + x) * 3;
+  const unsigned char* sp = src + ((int64_t)b * P + x) * 3;
+  unsigned s[21];
+#pragma unroll
+  for (int pl = 0; pl < 21; ++pl) s[pl] = 0;
+  auto row = [&](int y, bool add) __attribute__((always_inline)) {
+    const int64_t o = (int64_t)reflect_idx(y, H) * W * 3;
+    const unsigned I0 = gp[o], I1 = gp[o + 1], I2 = gp[o + 2], P0 = sp[o], P1 = sp[o + 1], P2 = sp[o + 2];
+#define GFM(a_, b_) ((unsigned)__umul24(a_, b_))
+    const unsigned m[21] = {I0, I1, I2, P0, P1, P2, GFM(I0, I0), GFM(I0, I1), GFM(I0, I2), GFM(I1, I1), GFM(I1, I2), GFM(I2, I2),
+                            GFM(I0, P0), GFM(I1, P0), GFM(I2, P0), GFM(I0, P1), GFM(I1, P1), GFM(I2, P1), GFM(I0, P2), GFM(I1, P2), GFM(I2, P2)};
+#undef GFM
+#pragma unroll
+    for (int pl = 0; pl < 21; ++pl) s[pl] = add ? s[pl] + m[pl] : s[pl] - m[pl];
+  };
+  for (int k = -RR; k <= RR; ++k) row(y0 + k, true);
+  const int y1 = min(y0 + GF_VSEG, H);
+  float* op = out + (int64_t)b * 21 * P + x;
+  for (int y = y0; y < y1; ++y) {
+    const int64_t po = (int64_t)y * W;
+#pragma unroll
+    for (int pl = 0; pl < 21; ++pl) op[pl * P + po] = (float)s[pl];
+    if (y + 1 < y1) {
+      row(y + 1 + RR, true);
+      row(y - RR, false);
+    }
+  }
+}
+
+// H pass over the 21 planes of column sums + the per-pixel 3x3 solve: grid (H, column chunks of GF_HCW outputs, B), 256 threads.
+// Phase 1: the row of every plane (+ RR on both sides, reflected) into LDS as uint32; phase 2: thread = (plane group, 16-output
+// segment) slides the window, keeps its outputs in registers; phase 3 (behind a barrier: every window has been read) the window sums
+// replace the row in LDS; phase 4: thread = pixel reads its 21 sums and solves: cs [B][21][P] -> ab [B][12][P].
+template <int RR>
+__global__ __launch_bounds__(256) void gf_h1s_solve_kernel(const float* __restrict__ cs, float* __restrict__ ab, int H, int W, float eps) {
+  __shared__ unsigned mom[21][GF_HROWLEN];
+  const int y = blockIdx.x, xc0 = blockIdx.y * GF_HCW, b = blockIdx.z;
+  const int cw = min(GF_HCW, W - xc0);
+  const int64_t P = (int64_t)H * W;
+  {
+    const float* ip = cs + (int64_t)b * 21 * P + (int64_t)y * W;
+    for (int i = threadIdx.x; i < cw + 2 * RR; i += 256) {       // the 21 planes' loads of a pixel go out together
+      const int x = reflect_idx(xc0 + i - RR, W);
+      float v[21];
+#pragma unroll
+      for (int pl = 0; pl < 21; ++pl) v[pl] = ip[pl * P + x];
+#pragma unroll
+      for (int pl = 0; pl < 21; ++pl) mom[pl][GF_ROW(i)] = (unsigned)v[pl];
+    }
+  }
+  __syncthreads();
+  const int seg = threadIdx.x & 31, pg = threadIdx.x >> 5;        // 8 plane groups x 32 segments
+  const int x0 = seg * GF_SEG;
+  unsigned o[3][GF_SEG];
+  if (x0 < cw) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int pl = pg + 8 * q;
+      if (pl >= 21) break;
+      const unsigned* row = mom[pl];
+      unsigned sum = 0;
+      for (int k = 0; k <= 2 * RR; ++k) sum += row[GF_ROW(x0 + k)];
+      o[q][0] = sum;
+#pragma unroll
+      for (int j = 1; j < GF_SEG; ++j) {
+        sum += row[GF_ROW(min(x0 + j + 2 * RR, cw + 2 * RR - 1))] - row[GF_ROW(x0 + j - 1)];
+        o[q][j] = sum;
+      }
+    }
+  }
+  __syncthreads();
+  if (x0 < cw) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int pl = pg + 8 * q;
+      if (pl >= 21) break;
+#pragma unroll
+      for (int j = 0; j < GF_SEG; ++j) mom[pl][GF_ROW(x0 + j)] = o[q][j];
+    }
+  }
+  __syncthreads();
+  const float inv = 1.f / (float)((2 * RR + 1) * (2 * RR + 1));
+  float* op = ab + (int64_t)b * 12 * P + (int64_t)y * W + xc0;
+  for (int px = threadIdx.x; px < cw; px += 256) {
+    float m[21];
+#pragma unroll
+    for (int pl = 0; pl < 21; ++pl) m[pl] = (float)mom[pl][GF_ROW(px)] * inv;
+    const float mI0 = m[0], mI1 = m[1], mI2 = m[2];
+    const float a00 = m[6] - mI0 * mI0 + eps, a01 = m[7] - mI0 * mI1, a02 = m[8] - mI0 * mI2;
+    const float a11 = m[9] - mI1 * mI1 + eps, a12 = m[10] - mI1 * mI2, a22 = m[11] - mI2 * mI2 + eps;
+    const float c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+    const float c11 = a00 * a22 - a02 * a02, c12 = a02 * a01 - a00 * a12, c22 = a00 * a11 - a01 * a01;
+    const float det = a00 * c00 + a01 * c01 + a02 * c02;
+    const float i00 = c00 / det, i01 = c01 / det, i02 = c02 / det, i11 = c11 / det, i12 = c12 / det, i22 = c22 / det;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float mp_c = m[3 + c];
+      const float cp0 = m[12 + c * 3 + 0] - mI0 * mp_c, cp1 = m[12 + c * 3 + 1] - mI1 * mp_c, cp2 = m[12 + c * 3 + 2] - mI2 * mp_c;
+      const float A0 = i00 * cp0 + i01 * cp1 + i02 * cp2;
+      const float A1 = i01 * cp0 + i11 * cp1 + i12 * cp2;
+      const float A2 = i02 * cp0 + i12 * cp1 + i22 * cp2;
+      const float bb = mp_c - A0 * mI0 - A1 * mI1 - A2 * mI2;
+      op[(c * 4 + 0) * P + px] = A0; op[(c * 4 + 1) * P + px] = A1; op[(c * 4 + 2) * P + px] = A2; op[(c * 4 + 3) * P + px] = bb;
+    }
+  }
+}
+
+// The same kernel carried one pass further: the H pass of STAGE 2 rides on it.  The block solves (a, b) for its GF_HCW outputs AND
+// the RR positions on either side (the values gf_h2_slide_kernel would read back, at reflected positions: a virtual position's
+// window over the reflection-staged row holds the same columns as the window of the pixel it reflects to), keeps them in LDS in
+// place of the window sums (a thread reads the 21 sums of ITS pixel, then writes that pixel's 12 values), and slides the 12 rows
+// exactly as gf_h2_slide_kernel does (same summation order: bit-identical).  The 12 (a, b) planes are neither written nor read
+// back (96 bytes per pixel) and one launch goes: cs [B][21][P] -> row sums of (a, b) [B][12][P].
+template <int RR>
+__global__ __launch_bounds__(256) void gf_h1s_solve_h2_kernel(const float* __restrict__ cs, float* __restrict__ out, int H, int W, float eps) {
+  __shared__ unsigned mom[21][GF_ROW(GF_HCW + 4 * RR) + 1];       // 56 KB at RR = 30: two blocks per CU
+  const int y = blockIdx.x, xc0 = blockIdx.y * GF_HCW, b = blockIdx.z;
+  const int cw = min(GF_HCW, W - xc0);
+  const int64_t P = (int64_t)H * W;
+  const int ns = cw + 4 * RR, na = cw + 2 * RR;          // staged columns, (a, b) positions
+  {
+    const float* ip = cs + (int64_t)b * 21 * P + (int64_t)y * W;
+    for (int i = threadIdx.x; i < ns; i += 256) {
+      const int x = reflect_idx(xc0 + i - 2 * RR, W);
+      float v[21];
+#pragma unroll
+      for (int pl = 0; pl < 21; ++pl) v[pl] = ip[pl * P + x];
+#pragma unroll
+      for (int pl = 0; pl < 21; ++pl) mom[pl][GF_ROW(i)] = (unsigned)v[pl];
+    }
+  }
+  __syncthreads();
+  // window sums of the na positions: thread = (plane group, 16-position segment); 37 segments of 16 cover 572 + 20
+  constexpr int NSEG = (GF_HCW + 2 * RR + GF_SEG - 1) / GF_SEG;
+  static_assert(21 * NSEG <= 4 * 256, "four (plane, segment) items per thread");
+  unsigned o[4][GF_SEG];
+  int items[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int it = threadIdx.x + 256 * q;           // item = plane * NSEG + segment
+    items[q] = it < 21 * NSEG ? it : -1;
+    if (items[q] < 0) continue;
+    const int pl = it / NSEG, x0 = (it - pl * NSEG) * GF_SEG;
+    if (x0 >= na) { items[q] = -1; continue; }
+    const unsigned* row = mom[pl];
+    unsigned sum = 0;
+    for (int k = 0; k <= 2 * RR; ++k) sum += row[GF_ROW(x0 + k)];
+    o[q][0] = sum;
+#pragma unroll
+    for (int j = 1; j < GF_SEG; ++j) {
+      sum += row[GF_ROW(min(x0 + j + 2 * RR, ns - 1))] - row[GF_ROW(x0 + j - 1)];
+      o[q][j] = sum;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (items[q] < 0) continue;
+    const int pl = items[q] / NSEG, x0 = (items[q] - pl * NSEG) * GF_SEG;
+#pragma unroll
+    for (int j = 0; j < GF_SEG; ++j) mom[pl][GF_ROW(x0 + j)] = o[q][j];
+  }
+  __syncthreads();
+  const float inv = 1.f / (float)((2 * RR + 1) * (2 * RR + 1));
+  for (int px = threadIdx.x; px < na; px += 256) {
+    float m[21];
+#pragma unroll
+    for (int pl = 0; pl < 21; ++pl) m[pl] = (float)mom[pl][GF_ROW(px)] * inv;
+    const float mI0 = m[0], mI1 = m[1], mI2 = m[2];
+    const float a00 = m[6] - mI0 * mI0 + eps, a01 = m[7] - mI0 * mI1, a02 = m[8] - mI0 * mI2;
+    const float a11 = m[9] - mI1 * mI1 + eps, a12 = m[10] - mI1 * mI2, a22 = m[11] - mI2 * mI2 + eps;
+    const float c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+    const float c11 = a00 * a22 - a02 * a02, c12 = a02 * a01 - a00 * a12, c22 = a00 * a11 - a01 * a01;
+    const float det = a00 * c00 + a01 * c01 + a02 * c02;
+    const float i00 = c00 / det, i01 = c01 / det, i02 = c02 / det, i11 = c11 / det, i12 = c12 / det, i22 = c22 / det;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float mp_c = m[3 + c];
+      const float cp0 = m[12 + c * 3 + 0] - mI0 * mp_c, cp1 = m[12 + c * 3 + 1] - mI1 * mp_c, cp2 = m[12 + c * 3 + 2] - mI2 * mp_c;
+      const float A0 = i00 * cp0 + i01 * cp1 + i02 * cp2;
+      const float A1 = i01 * cp0 + i11 * cp1 + i12 * cp2;
+      const float A2 = i02 * cp0 + i12 * cp1 + i22 * cp2;
+      const float bb = mp_c - A0 * mI0 - A1 * mI1 - A2 * mI2;
+      mom[c * 4 + 0][GF_ROW(px)] = __float_as_uint(A0); mom[c * 4 + 1][GF_ROW(px)] = __float_as_uint(A1);
+      mom[c * 4 + 2][GF_ROW(px)] = __float_as_uint(A2); mom[c * 4 + 3][GF_ROW(px)] = __float_as_uint(bb);
+    }
+  }
+  __syncthreads();
+  // stage-2 H pass over the 12 rows (positions 0 .. na - 1 = image columns xc0 - RR ..): as gf_h2_slide_kernel
+  const int seg = threadIdx.x & 31, pg = threadIdx.x >> 5;        // 8 plane groups x 32 segments
+  const int x0 = seg * GF_SEG;
+  if (x0 >= cw) return;
+  for (int pl = pg; pl < 12; pl += 8) {
+    const float* row = (const float*)mom[pl];
+    float sum = 0.f;
+    for (int k = 0; k <= 2 * RR; ++k) sum += row[GF_ROW(x0 + k)];
+    float ov[GF_SEG];
+    ov[0] = sum;
+#pragma unroll
+    for (int j = 1; j < GF_SEG; ++j) {
+      sum += row[GF_ROW(min(x0 + j + 2 * RR, cw + 2 * RR - 1))] - row[GF_ROW(x0 + j - 1)];
+      ov[j] = sum;
+    }
+    float* op = out + ((int64_t)b * 12 + pl) * P + (int64_t)y * W + xc0 + x0;
+    if (x0 + GF_SEG <= cw && (W & 3) == 0) {
+#pragma unroll
+      for (int j = 0; j < GF_SEG; j += 4) *(float4*)(op + j) = make_float4(ov[j], ov[j + 1], ov[j + 2], ov[j + 3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < GF_SEG; ++j)
+        if (x0 + j < cw) op[j] = ov[j];
+    }
+  }
+}
+
 // H pass of stage 2 (12 float planes): grid (H, column chunks, B), 128 threads = 4 plane groups x 32 segments; the chunk's 12 rows
 // are staged at once.
 template <int RR>
@@ -402,10 +631,25 @@ extern "C" int ppst_guided_filter(const void* guide_u8, const void* src_u8, void
   auto blocks_for = [](int64_t total) { int64_t b = cdiv64(total, 256); return (unsigned)(b > 256 * 32 ? 256 * 32 : b); };
   int e;
   if (r == 30) {       // the path's radius (photo_gif.py:43): sliding-window passes (round 4)
+#ifdef GF_STAGE1_HV      // (the first sliding form: H pass over the moments, then V pass + solve; kept for A/B)
     PPST_LAUNCH(gf_h1_slide_kernel<30>, dim3(H, cdiv(W, GF_HCW), B), dim3(256), 0, st, g, s, bufA, H, W);
     if ((e = PPST_LAUNCH_CHECK())) return e;
     PPST_LAUNCH(gf_v1_solve_slide_kernel<30>, dim3(cdiv(W, 256), cdiv(H, GF_VSEG), B), dim3(256), 0, st, (const float*)bufA, bufB, H, W, eps);
     if ((e = PPST_LAUNCH_CHECK())) return e;
+#else
+    PPST_LAUNCH(gf_v1m_slide_kernel<30>, dim3(cdiv(W, 256), cdiv(H, GF_VSEG), B), dim3(256), 0, st, g, s, bufA, H, W);
+    if ((e = PPST_LAUNCH_CHECK())) return e;
+#ifdef GF_STAGE1_SPLIT   // (the solve and the stage-2 H pass as two launches; kept for A/B)
+    PPST_LAUNCH(gf_h1s_solve_kernel<30>, dim3(H, cdiv(W, GF_HCW), B), dim3(256), 0, st, (const float*)bufA, bufB, H, W, eps);
+    if ((e = PPST_LAUNCH_CHECK())) return e;
+#else
+    PPST_LAUNCH(gf_h1s_solve_h2_kernel<30>, dim3(H, cdiv(W, GF_HCW), B), dim3(256), 0, st, (const float*)bufA, bufB, H, W, eps);
+    if ((e = PPST_LAUNCH_CHECK())) return e;
+    PPST_LAUNCH(gf_v2_final_slide_kernel<30>, dim3(cdiv(W, 256), cdiv(H, GF_VSEG), B), dim3(256), 0, st, (const float*)bufB, g, (float*)out,
+                (unsigned char*)out_u8, H, W);
+    return PPST_LAUNCH_CHECK();
+#endif
+#endif
     PPST_LAUNCH(gf_h2_slide_kernel<30>, dim3(H, cdiv(W, GF_HCW), B), dim3(128), 0, st, (const float*)bufB, bufA, H, W);
     if ((e = PPST_LAUNCH_CHECK())) return e;
     PPST_LAUNCH(gf_v2_final_slide_kernel<30>, dim3(cdiv(W, 256), cdiv(H, GF_VSEG), B), dim3(256), 0, st, (const float*)bufA, g, (float*)out,

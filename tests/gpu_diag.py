@@ -947,6 +947,16 @@ def t_guided():
     reff = (torch.from_numpy(ref).permute(0, 3, 1, 2).float() / 255.0 - 0.5) * 2
     # one uint8 step is 2/255 in [-1,1]; relative to refmax ~0.6
     report("guided_filter fp32 out (vs oracle, 1 LSB)", out, reff, (2.0 / 255 + 1e-6) / reff.abs().max().item())
+    # a ragged extent: two column chunks of the H passes (the second 18 wide), W % 4 != 0, a last row segment of 24 rows
+    H2, W2 = 600, 530
+    yy, xx = np.meshgrid(np.arange(H2), np.arange(W2), indexing="ij")
+    guide2 = np.stack([(128 + 100 * np.sin(xx / 19.0 + c) * np.cos(yy / 13.0)) for c in range(3)], -1)
+    guide2 = np.clip(guide2 + rng.normal(0, 12, guide2.shape), 0, 255).astype(np.uint8)
+    src2 = np.clip(guide2.astype(np.float64) * 0.6 + 50 + rng.normal(0, 25, guide2.shape), 0, 255).astype(np.uint8)
+    _, u82 = ops.guided_filter(torch.from_numpy(guide2[None]).to(dev), torch.from_numpy(src2[None]).to(dev), 30, (0.02 * 255) ** 2, want_u8=True)
+    d2 = np.abs(u82.cpu().numpy().astype(int)[0] - O.guided_filter_color(guide2, src2, 30).astype(int))
+    print("guided_filter u8 600x530: max |diff| %d, frac != %.4f" % (d2.max(), (d2 > 0).mean()), flush=True)
+    RES.append(("guided filter u8 600x530 within 1 LSB", bool(d2.max() <= 1 and (d2 > 0).mean() < 0.02)))
 
 
 # ----------------------------------------------------------------- nets ----
@@ -1295,6 +1305,8 @@ def main():
         run(t_networks)
     if which == "prec":
         run(t_precision)
+    if which == "guided":
+        run(t_guided)
     if which == "opshalf":
         run(t_ops_half)
     if which == "up9":
