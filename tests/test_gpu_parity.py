@@ -345,9 +345,12 @@ def test_edge_cases():
     from ppst_amd import glue
     with pytest.raises(AssertionError):
         glue.swap(torch.zeros(3, 2, device=dev))
-    # non-float input is rejected
+    # float64 / integer input is rejected (the library takes float32, float16, bfloat16: t_ops_half), half input is not
     with pytest.raises(RuntimeError):
-        upfirdn2d(torch.zeros(1, 1, 8, 8, device=dev, dtype=torch.float16), k)
+        upfirdn2d(torch.zeros(1, 1, 8, 8, device=dev, dtype=torch.float64), k)
+    with pytest.raises(RuntimeError):
+        upfirdn2d(torch.zeros(1, 1, 8, 8, device=dev, dtype=torch.int32), k)
+    assert upfirdn2d(torch.zeros(1, 1, 8, 8, device=dev, dtype=torch.float16), k).dtype == torch.float16
 
 
 def test_corrm_match_kernel_vs_reference_golden():
