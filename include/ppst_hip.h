@@ -138,6 +138,11 @@ typedef struct ppst_conv_step {
 int64_t ppst_conv_pack_up9_bytes(int cout, int cin);
 int ppst_conv_pack_up9(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx, float scale, int cout, int cin,
                        void* out, void* stream);
+/* Weights for ppst_conv_args.k64: as ppst_conv_pack (dual = 0) / ppst_conv_pack_dual (dual = 1) with precision 1 / 3, but step i of
+ * the table covers channels src_c[i] .. src_c[i] + 63; out: n_groups * n_tiles * nsteps * 8 * bn * 8 elements of the operand type. */
+int ppst_conv_pack_k64(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx, float scale, int cout, int bn,
+                       const int32_t* src_c, const int32_t* src_ky, const int32_t* src_kx, int nsteps, int n_groups,
+                       int precision, int dual, void* out, void* stream);
 int ppst_conv_pack_dual(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx, float scale, int cout,
                         const int32_t* src_c, const int32_t* src_ky, const int32_t* src_kx, int nsteps, int n_groups,
                         int precision, void* out, void* stream);
@@ -160,6 +165,7 @@ typedef struct ppst_pack_job {
   float scale;
   int32_t cout, bn, nsteps, n_groups, x3, f16, nblocks;   /* x3: precision 0 (hi + lo planes); f16: precision 3 / 4 */
   int32_t dual;               /* 1: ppst_conv_pack_dual semantics (the N tile holds two output column phases) */
+                              /* (x3 = 2 with f16 = 0 / 1: ppst_conv_pack_k64 semantics -- the lo planes hold channels 32-63 of a 64-channel step) */
 } ppst_pack_job;
 typedef struct ppst_upscale_job {
   const void* w;
@@ -278,6 +284,12 @@ typedef struct ppst_conv_args {
                                     Accumulation, bias / noise / activation, the instance-norm statistics and (a, s) of
                                     normalise-on-load stay fp32; the output is rounded once, to nearest even, at the store.
                                     variant 0 (tile_rows 16), 2, 4, 5, 6; pointers 8-byte aligned; in_ld / out_ld / res_ld in ELEMENTS. */
+  int32_t k64;                   /* 1 (io_st != 0, precision 1 / 3, halo 1, variant 2 [also with dual_b] or variant 9 with tile_rows 24):
+                                    a step of the table covers SIXTY-FOUR input channels (steps[i].chan .. + 63; wpack from
+                                    ppst_conv_pack_k64: channels 0-31 of the chunk where the fp32-class blob keeps its hi planes,
+                                    32-63 where it keeps its lo planes) -- half the steps per MFMA of the 32-channel single-pass
+                                    form.  Outputs equal that form's up to fp32 summation order (the two halves of a chunk are
+                                    accumulated alternately instead of chunk after chunk). */
 } ppst_conv_args;
 
 int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream);

@@ -52,7 +52,7 @@ class ConvArgs(ctypes.Structure):
         ("in_off_y", i32), ("in_off_x", i32), ("out_sy", i32), ("out_sx", i32),
         ("act", i32), ("precision", i32), ("res_ld", i32), ("tile_h", i32), ("tile_w", i32),
         ("halo", i32), ("bn", i32), ("in_scale_shift", vp), ("in_prelu", vp), ("in_c", i32), ("in_act", i32),
-        ("flop_steps", i32), ("tile_rows", i32), ("a_slots", i32), ("early_a", i32), ("variant", i32), ("in_presplit", i32), ("dual_b", i32), ("io_st", i32),
+        ("flop_steps", i32), ("tile_rows", i32), ("a_slots", i32), ("early_a", i32), ("variant", i32), ("in_presplit", i32), ("dual_b", i32), ("io_st", i32), ("k64", i32),
     ]
 
 
@@ -65,6 +65,7 @@ _SIGS = {
     "ppst_nchw_to_nhwc": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ppst_nhwc_to_nchw": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ppst_conv_pack": (i32, [vp, i64, i64, i64, i64, f32, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "ppst_conv_pack_k64": (i32, [vp, i64, i64, i64, i64, f32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "ppst_conv_pack_up9_bytes": (i64, [i32, i32]),
     "ppst_conv_pack_up9": (i32, [vp, i64, i64, i64, i64, f32, i32, i32, vp, vp]),
     "ppst_conv_pack_wino_bytes": (i64, [i32, i32]),

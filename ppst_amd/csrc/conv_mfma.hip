@@ -764,7 +764,12 @@ __device__ __forceinline__ void pack_item(const PackJob& j, int64_t t) {
   for (int q = 0; q < 8; ++q) {
     float v = 0.f;
     if (n < cout && j.src_c[gs] >= 0) v = w[n * j.sn + (int64_t)(c0 + q) * j.sc + ky * j.sy + kx * j.sx] * j.scale;  // src_c < 0: zero-weight pad step
-    if (j.f16) { hi[q] = __builtin_bit_cast(unsigned short, (_Float16)v); lo[q] = 0; }
+    if (j.x3 == 2) {      // K64: one rounding to the operand type; the "lo" planes hold channels 32-63 of the step
+      float v2 = 0.f;
+      if (n < cout && j.src_c[gs] >= 0) v2 = w[n * j.sn + (int64_t)(c0 + 32 + q) * j.sc + ky * j.sy + kx * j.sx] * j.scale;
+      hi[q] = j.f16 ? __builtin_bit_cast(unsigned short, (_Float16)v) : f2bf(v);
+      lo[q] = j.f16 ? __builtin_bit_cast(unsigned short, (_Float16)v2) : f2bf(v2);
+    } else if (j.f16) { hi[q] = __builtin_bit_cast(unsigned short, (_Float16)v); lo[q] = 0; }
     else split_bf16(v, hi[q], lo[q]);
   }
   int64_t blob = (((int64_t)group * n_tiles + ntile) * nsteps + s) * ((int64_t)npl * bn * 8);
@@ -870,6 +875,20 @@ extern "C" int ppst_conv_pack_up9(const void* w, int64_t sn, int64_t sc, int64_t
   const int64_t total = (int64_t)(cout / 64) * (cin / 32) * 4 * 4 * 256;
   PPST_LAUNCH(conv_pack_up9_kernel, dim3((unsigned)pack_blocks(total)), dim3(256), 0, as_stream(stream), (const float*)w, sn, sc, sy, sx, scale,
               cout, cin, (unsigned short*)out, total);
+  return PPST_LAUNCH_CHECK();
+}
+extern "C" int ppst_conv_pack_k64(const void* w, int64_t sn, int64_t sc, int64_t sy, int64_t sx, float scale, int cout, int bn,
+                                  const int32_t* src_c, const int32_t* src_ky, const int32_t* src_kx, int nsteps, int n_groups,
+                                  int precision, int dual, void* out, void* stream) {
+  if (cout <= 0 || nsteps <= 0 || (precision != 1 && precision != 3) || (dual ? (bn != 256 || n_groups != 2) : ((bn != 128 && bn != 256) || (n_groups != 1 && n_groups != 4))))
+    return PPST_EINVAL;
+  if (!w || !src_c || !src_ky || !src_kx || !out) return PPST_ENULL;
+  PackJob j;
+  j.w = (const float*)w; j.sn = sn; j.sc = sc; j.sy = sy; j.sx = sx; j.src_c = src_c; j.src_ky = src_ky; j.src_kx = src_kx;
+  j.out = (unsigned short*)out; j.total = (int64_t)n_groups * cdiv(cout, dual ? bn / 2 : bn) * nsteps * 4 * bn; j.block0 = 0; j.scale = scale;
+  j.cout = cout; j.bn = bn; j.nsteps = nsteps; j.n_groups = n_groups; j.x3 = 2; j.f16 = precision == 3 ? 1 : 0; j.dual = dual ? 1 : 0;
+  j.nblocks = pack_blocks(j.total);
+  PPST_LAUNCH(conv_pack_kernel, dim3((unsigned)j.nblocks), dim3(256), 0, as_stream(stream), j);
   return PPST_LAUNCH_CHECK();
 }
 // jobs: DEVICE array of ppst_pack_job (block0 / nblocks filled by the caller: consecutive ranges, nblocks = ppst_pack_job_blocks(total))
@@ -1044,7 +1063,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
                             a->in_off_y != 0 || a->in_off_x != 0 || a->tile_h != a->out_h || a->tile_w != a->out_w ||
                             a->in_h != a->out_h || a->in_w != a->out_w || a->nsteps % 9 != 0 || a->tile_rows != 16)) ||
       ((a->variant >= 1 && a->variant <= 3 || a->variant == 7 || a->variant == 9) &&
-       ((a->precision != 0 && !((a->variant == 2 || a->variant == 7) && (a->precision == 1 || a->precision == 3))) || a->bn == 64 || !a->early_a)) ||
+       ((a->precision != 0 && !((a->variant == 2 || a->variant == 7 || (a->variant == 9 && a->k64)) && (a->precision == 1 || a->precision == 3))) || a->bn == 64 || !a->early_a)) ||
       (a->variant == 7 && (a->bn != 128 || a->tile_rows != 32)) ||
       // variant 9 = conv_mfma2.hip with 6 m-tiles per wave: block tile 24 x 16 px x 128 ch, two activation slots
       (a->variant == 9 && (a->bn != 128 || a->tile_rows != 24)) ||
@@ -1066,7 +1085,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
        !(a->variant == 0 && a->tile_rows == 8 && a->bn == 128 && a->halo == 1 && a->early_a && a->precision == 0)) || (a->in_scale_shift && a->in_c <= 0) || a->a_slots < 0 || a->a_slots > 3)
     return PPST_EINVAL;
 #ifndef PPST_EXPERIMENTS
-  if (a->variant == 1 || a->variant == 3 || (a->variant == 7 && a->precision == 0) || a->variant == 8 || a->variant == 9 || a->precision == 4 ||
+  if (a->variant == 1 || a->variant == 3 || (a->variant == 7 && a->precision == 0) || a->variant == 8 || (a->variant == 9 && !a->k64) || a->precision == 4 ||
       a->in_presplit)
     return PPST_EINVAL;          // experiment forms: not in this build (variant 7 is a production form in the single-pass modes)
 #endif
@@ -1075,8 +1094,12 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   // half-precision activation storage (x, residual, y): the single-pass modes, in the operand type of the mode (1 -> bfloat16,
   // 3 -> IEEE half); kernel families 0 (16-row tiles), 2 (N-256), 4 / 5 / 6 (streaming 1x1 / direct)
   if (a->io_st && (a->io_st != (a->precision == 3 ? PPST_ST_F16 : a->precision == 1 ? PPST_ST_BF16 : -1) ||
-                   (a->tile_rows != 16 && a->variant != 7) || a->in_presplit ||
-                   !(a->variant == 0 || a->variant == 2 || a->variant == 4 || a->variant == 5 || a->variant == 6 || a->variant == 7)))
+                   (a->tile_rows != 16 && a->variant != 7 && !(a->variant == 9 && a->k64)) || a->in_presplit ||
+                   !(a->variant == 0 || a->variant == 2 || a->variant == 4 || a->variant == 5 || a->variant == 6 || a->variant == 7 || (a->variant == 9 && a->k64))))
+    return PPST_EINVAL;
+  // 64 input channels per step (conv_mfma2.hip K64): single-pass modes on half-stored activations, the N-256 geometry (plain or phase
+  // pairs) or the 24 x 16 px x 128 ch tile
+  if (a->k64 && (!a->io_st || !a->halo || !((a->variant == 2 && a->bn == 256) || (a->variant == 9 && a->bn == 128 && a->tile_rows == 24)) || !a->early_a))
     return PPST_EINVAL;
   if (a->in_presplit && (a->variant != 0 || a->bn != 128 || a->halo != 1 || a->precision != 0 || !a->early_a || a->tile_rows != 16 ||
                          a->in_scale_shift))

@@ -91,9 +91,16 @@ __device__ __forceinline__ unsigned short f2h_2(float f) { return __builtin_bit_
 // step, the activation tile is staged once for two phases, and the layer runs on this kernel's 128 x 64 wave tiles instead of
 // the tile kernel's 64 x 64.  Per output element the MFMA sequence is the tile kernel's (dy-major taps): bit-identical outputs.
 template <int NT, int HALO, bool INSS, int WNW = 2, bool BDB = true, int NA_ = 2, int WMW = 2, int PREC = 0, int MT_ = 8, bool DUAL = false,
-          int IOS = PPST_ST_F32, bool UP9 = false>
+          int IOS = PPST_ST_F32, bool UP9 = false, bool K64 = false>
 __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW == 8 || NA_ == 1) ? 2 : 1)) void conv_mfma2_kernel(Conv2KArgs a) {
   constexpr bool X3 = PREC == 0;
+  // K64 (single-pass modes on half-stored activations): a step covers 64 input channels instead of 32 -- channels 0-31 of the chunk sit
+  // where the x3 form keeps its hi planes, channels 32-63 where it keeps its lo planes (activation tile and weight blob alike), and a
+  // product is two MFMAs (first half x first half + second half x second half) instead of three.  Same LDS image sizes, registers
+  // and step pipeline as the fp32-class kernel; half the steps (barriers, fragment waits, DMA issues) per MFMA of the 32-channel
+  // single-pass form, which spent two thirds of a step beside its matrix work (0.27-0.41 of the single-pass ceiling at 1024^2).
+  static_assert(!K64 || (PREC != 0 && IOS != PPST_ST_F32 && !UP9 && !BDB), "K64: single-pass precision on half-stored activations");
+  constexpr bool X3L = X3 || K64;                          // the LDS images have eight planes
   static_assert(!UP9 || (NT == 4 && HALO == 1 && !INSS && WNW == 4 && !BDB && NA_ == 2 && WMW == 2 && PREC == 0 && MT_ == 8 && !DUAL &&
                          IOS == PPST_ST_F32), "UP9: the production geometry, fp32-class, fp32 storage");
   // IOS: storage type of x, residual and y (ppst_conv_args.io_st; conv_mfma.hip): the single-pass modes, in their operand type
@@ -105,10 +112,10 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   constexpr int TH = MT * WMW, TW = 16;
   constexpr int HH = TH + 2 * HALO, HW = TW + 2 * HALO, HP = HH * HW;
   constexpr int PLANE = ((HP * 16 + 255) / 256) * 256;    // bytes
-  constexpr int ABUF = (X3 ? 8 : 4) * PLANE;              // hi g0..3 [, lo g0..3]
+  constexpr int ABUF = (X3L ? 8 : 4) * PLANE;             // hi g0..3 [, lo g0..3]
   constexpr int BN = WNW * 16 * NT;                       // WNW N-waves
   constexpr int BPLANE = BN * 16;
-  constexpr int BBUF = (X3 ? 8 : 4) * BPLANE;
+  constexpr int BBUF = (X3L ? 8 : 4) * BPLANE;
   constexpr int NA = NA_;
   constexpr int EPI_TILE = 64 * 36;
   constexpr int EPI_BYTES = NWV * EPI_TILE * 4 + WMW * BN * 2 * 4;
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   constexpr int A_WCH = (HP + 7) / 8;
   constexpr int A_IT2 = (A_WCH * 64 + NTH - 1) / NTH;
   float4 ra[A_IT2];
-  constexpr int A_NLOADS = A_IT2 + (INSS ? 2 : 0);
+  constexpr int A_NLOADS = (K64 ? 2 : 1) * (A_IT2 + (INSS ? 2 : 0));
   int aoff[A_IT2];
 #pragma unroll
   for (int it = 0; it < A_IT2; ++it) {
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
     }
     aoff[it] = o;
   }
-  float4 ras0 = make_float4(1.f, 0.f, 1.f, 0.f), ras1 = ras0;
+  float4 ras0 = make_float4(1.f, 0.f, 1.f, 0.f), ras1 = ras0, ras2 = ras0, ras3 = ras0;    // (ras2 / ras3: K64, channels + 32)
   const int q4lane = ((tid & 63) >> 4) * 2 + (tid & 1);
   const float in_slope = (INSS && a.in_act == PPST_ACT_PRELU && a.in_prelu) ? a.in_prelu[0] : 0.f;
   // buffer loads (SGPR descriptor + per-item byte offset + SGPR chunk offset; padding items out of range -> zeros): conv_mfma.hip
@@ -188,12 +195,17 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
       } else {       // four half elements: the raw 8 bytes ride in .x / .y until a_store
         const uint2 u = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xrs, aoff[it], chan_off * 2, 0));
         ra[it].x = __uint_as_float(u.x); ra[it].y = __uint_as_float(u.y);
+        if (K64) {   // the same four channel positions of the chunk's second half (channels 32-63) in .z / .w
+          const uint2 u2 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xrs, aoff[it], (chan_off + 32) * 2, 0));
+          ra[it].z = __uint_as_float(u2.x); ra[it].w = __uint_as_float(u2.y);
+        }
       }
     }
     if (INSS) {
       const float4* p = (const float4*)(a.in_ss + ((int64_t)b * a.in_c + chan_off + q4lane * 4) * 2);
       ras0 = p[0];
       ras1 = p[1];
+      if (K64) { ras2 = p[16]; ras3 = p[17]; }      // (32 channels = 16 float4 of (a, s) pairs further)
     }
   };
   auto in_act = [&](float t) -> float {
@@ -223,9 +235,21 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
           const unsigned short h0 = f2h_2(v.x), h1 = f2h_2(v.y), h2 = f2h_2(v.z), h3 = f2h_2(v.w);
           hv = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
         } else hv = f2bf_x4(v);
+        if (K64) {      // the chunk's second 32 channels take the place of the lo planes
+          const uint2 raw2 = make_uint2(__float_as_uint(ra[it].z), __float_as_uint(ra[it].w));
+          if (!INSS) lv = raw2;
+          else {
+            float4 w = st_unpack4<IOS>(raw2);
+            if (aoff[it] >= 0) {
+              w.x = in_act(ras2.x * w.x + ras2.y); w.y = in_act(ras2.z * w.y + ras2.w);
+              w.z = in_act(ras3.x * w.z + ras3.y); w.w = in_act(ras3.z * w.w + ras3.w);
+            }
+            lv = st_pack4<IOS>(w);
+          }
+        }
         int off = (l >> 4) * PLANE + pix * 16 + (l & 1) * 8;
         *(uint2*)(base + off) = hv;
-        if (X3) *(uint2*)(base + 4 * PLANE + off) = lv;
+        if (X3L) *(uint2*)(base + 4 * PLANE + off) = lv;
       }
     }
   };
@@ -280,10 +304,10 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     b0h[nt] = *(const bf16x8*)B_ADDR(0, nt);
-    if (X3) b0l[nt] = *(const bf16x8*)(B_ADDR(0, nt) + 4 * BPLANE);
+    if (X3L) b0l[nt] = *(const bf16x8*)(B_ADDR(0, nt) + 4 * BPLANE);
   }
   ah = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, 0));
-  if (X3) al = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, 0) + 4 * PLANE);
+  if (X3L) al = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, 0) + 4 * PLANE);
   __builtin_amdgcn_s_waitcnt(0xC07F);
 
   // One K-step.  bc* = this step's weight fragments (read during the previous step); bn* receive the next step's:
@@ -307,31 +331,37 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
     int sl2 = sl1;                                                                                            \
     if (NA == 1 && freshA) {   /* this step's chunk was stored at the end of the previous step */             \
       ah = *(const bf16x8*)(smA + A_OFF(0, dy0, dx0, 0));                                                     \
-      if (X3) al = *(const bf16x8*)(smA + A_OFF(0, dy0, dx0, 0) + 4 * PLANE);                                         \
+      if (X3L) al = *(const bf16x8*)(smA + A_OFF(0, dy0, dx0, 0) + 4 * PLANE);                                         \
     }                                                                                                         \
     const bool storeA = NA == 1 && pendA;   /* the next step opens a chunk: store it at the end of this one */ \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                       \
       bf16x8 nh, nl;                                                                                          \
       if (mt < MT - 1) {                                                                                      \
         nh = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1));                                            \
-        if (X3) nl = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1) + 4 * PLANE);                                \
+        if (X3L) nl = *(const bf16x8*)(smA + A_OFF(sl0, dy0, dx0, mt + 1) + 4 * PLANE);                                \
       } else if (has1 && !storeA) {                                                                           \
         nh = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0));                                                 \
-        if (X3) nl = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0) + 4 * PLANE);                                     \
+        if (X3L) nl = *(const bf16x8*)(smA + A_OFF(sl1, dy1, dx1, 0) + 4 * PLANE);                                     \
       }                                                                                                       \
       if (BDB && has1 && mt >= 1 && mt - 1 < NT) {   /* next step's B fragment pair nt = mt - 1 */            \
         bnh[mt - 1] = *(const bf16x8*)B_ADDR(((s) + 1) & 1, mt - 1);                                          \
-        if (X3) bnl[mt - 1] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, mt - 1) + 4 * BPLANE);                           \
+        if (X3L) bnl[mt - 1] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, mt - 1) + 4 * BPLANE);                           \
       }                                                                                                       \
       if (BDB && NT == 8 && has1 && mt == MT - 1) {                                                           \
         bnh[NT - 1] = *(const bf16x8*)B_ADDR(((s) + 1) & 1, NT - 1);                                          \
-        if (X3) bnl[NT - 1] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, NT - 1) + 4 * BPLANE);                           \
+        if (X3L) bnl[NT - 1] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, NT - 1) + 4 * BPLANE);                           \
       }                                                                                                       \
       _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                     \
         if (!(((MASK) >> nt) & 1)) continue;                                                                  \
         if (X3) {                                                                                             \
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bch[nt], acc[mt][nt], 0, 0, 0);           \
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcl[nt], acc[mt][nt], 0, 0, 0);           \
+        }                                                                                                     \
+        if (K64) {   /* channels 32-63 of the chunk: the "lo" images */                                       \
+          if (PREC == 3)                                                                                      \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_2, al), __builtin_bit_cast(half8_2, bcl[nt]), acc[mt][nt], 0, 0, 0); \
+          else                                                                                                \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bcl[nt], acc[mt][nt], 0, 0, 0);         \
         }                                                                                                     \
         if (PREC == 3)                                                                                        \
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_2, ah), __builtin_bit_cast(half8_2, bch[nt]), acc[mt][nt], 0, 0, 0); \
@@ -369,7 +399,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
       _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                     \
         if (!(((MASKN) >> nt) & 1)) continue;                                                                 \
         bnh[nt] = *(const bf16x8*)B_ADDR(((s) + 1) & 1, nt);                                                  \
-        if (X3) bnl[nt] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, nt) + 4 * BPLANE);                                   \
+        if (X3L) bnl[nt] = *(const bf16x8*)(B_ADDR(((s) + 1) & 1, nt) + 4 * BPLANE);                                   \
       }                                                                                                       \
     }                                                                                                         \
     TR2(4)                                                                                                    \
@@ -738,6 +768,24 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
   k.prelu = nullptr;
 #endif
   const int blocks = a->n_groups * n_tiles * a->B * tiles_y * tiles_x;
+  if (a->k64) {               // single-pass modes on half-stored activations, 64 input channels per step (the entry point checked the shape)
+#define LK(PREC_, IOS_)                                                                                          \
+  do {                                                                                                          \
+    if (a->variant == 2 && a->dual_b) {                                                                         \
+      if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, 1, true, 4, false, 2, 2, PREC_, 8, true, IOS_, false, true>), dim3(blocks), dim3(512), 0, st, k);   \
+      else PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 4, false, 2, 2, PREC_, 8, true, IOS_, false, true>), dim3(blocks), dim3(512), 0, st, k);          \
+    } else if (a->variant == 2 && a->halo) {                                                                    \
+      if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, 1, true, 4, false, 2, 2, PREC_, 8, false, IOS_, false, true>), dim3(blocks), dim3(512), 0, st, k);  \
+      else PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 4, false, 2, 2, PREC_, 8, false, IOS_, false, true>), dim3(blocks), dim3(512), 0, st, k);         \
+    } else if (a->variant == 9 && a->halo) {   /* Cout = 128-class layers: 24 x 16 px x 128 ch tiles (two 61-KB activation slots) */ \
+      if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, 1, true, 2, false, 2, 4, PREC_, 6, false, IOS_, false, true>), dim3(blocks), dim3(512), 0, st, k);  \
+      else PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 2, false, 2, 4, PREC_, 6, false, IOS_, false, true>), dim3(blocks), dim3(512), 0, st, k);         \
+    } else return PPST_EINVAL;                                                                                  \
+  } while (0)
+    if (a->precision == 3) LK(3, PPST_ST_F16); else LK(1, PPST_ST_BF16);
+#undef LK
+    return PPST_LAUNCH_CHECK();
+  }
   if (a->variant == 11) {     // the fused upscale as nine products per input pixel + box sum (UP9); shape conditions checked by the entry point
     PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 4, false, 2, 2, 0, 8, false, PPST_ST_F32, true>), dim3(blocks), dim3(512), 0, st, k);
     return PPST_LAUNCH_CHECK();

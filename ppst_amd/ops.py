@@ -52,6 +52,9 @@ TALL_TILE_128 = {"value": False, "min_blocks": 32}
 # the same geometry in the single-pass modes (two activation slots fit there): the Cout = 128-class 3x3 layers, which the tile
 # kernel runs at 0.22 of the single-pass ceiling (128 -> 128 @1024^2 fp16)
 TALL_TILE_SINGLE = {"value": True, "min_blocks": 64}
+# single-pass modes on half-stored activations: 64 input channels per step on the N-256 kernel family (ppst_conv_args.k64) -- half the
+# steps (barriers, fragment waits, DMA issues) per MFMA; the Cout = 128-class layers then take 24 x 16 px tiles (variant 9)
+K64 = {"value": True}
 # variant 9 (24 x 16 px x 128 ch blocks, wave tile 96 px x 64 ch, TWO activation slots: conv_mfma2.hip MT_ = 6) for the Cout = 128-class
 # layers whose tile height wastes <= max_waste of the rows (512 -> 528, 256 -> 264: 3.1 %; 128 -> 144 would be 12.5 %)
 TILE24_128 = {"value": False, "min_blocks": 32, "max_waste": 0.04}
@@ -265,7 +268,8 @@ class ConvPlan:
     _GEOMETRY = {}
     _GEOM_ATTRS = ("kind", "cout", "cin", "k", "bn", "n_groups", "halo", "src", "max_chan", "wstrides", "nsteps", "flop_steps",
                    "early_a", "ksplit_ok", "steps", "src_dev", "chunk_start", "chunks_per_group", "w4_shape", "max_chunk_steps",
-                   "min_chunk_steps", "full_cover", "steps_dual", "src_dual", "steps_up9")
+                   "min_chunk_steps", "full_cover", "steps_dual", "src_dual", "steps_up9", "steps_k64", "src_k64", "steps_dual_k64",
+                   "src_dual_k64")
 
     def __init__(self, weight, kind="conv", scale=1.0, chan_base=0, precision=None):
         _chk(weight, "weight")
@@ -496,6 +500,35 @@ class ConvPlan:
             self.steps_dual = torch.tensor(encode(dual[0]) + [(0, 0, 0, 0)] * 4, dtype=torch.int32, device=dev).contiguous()
             sd_ = torch.tensor(dual[1], dtype=torch.int32, device=dev)
             self.src_dual = (sd_[:, 0].contiguous(), sd_[:, 1].contiguous(), sd_[:, 2].contiguous())
+        # K64 tables: every second 32-channel chunk of a group opens a 64-channel step group with the same taps (needs an even chunk
+        # count per group and plain 32-channel chunk order: conv k = 3, s2d, convT and its phase-pair form)
+        self.steps_k64 = self.src_k64 = self.steps_dual_k64 = self.src_dual_k64 = None
+
+        def k64_tables(steps_, src_, ngroups):
+            per = len(steps_) // ngroups
+            keep, chunk = [], -1
+            for i, t in enumerate(steps_):
+                if i % per == 0:
+                    chunk = -1
+                chunk += 1 if t[3] else 0
+                if chunk % 2 == 0:
+                    keep.append(i)
+            st = [steps_[i] for i in keep]
+            per2 = len(st) // ngroups
+            enc2, ci = [], -1
+            for i, (c_, dy_, dx_, f_) in enumerate(st):
+                if i % per2 == 0:
+                    ci = -1
+                ci += 1 if f_ else 0
+                nxt = st[i + 1] if (i + 1) % per2 != 0 else None
+                enc2.append((c_, dy_, dx_, f_ | ((2 | (nxt[0] << 8)) if (nxt is not None and nxt[3]) else 0) | ((ci & 1) << 2)))
+            sr = torch.tensor([src_[i] for i in keep], dtype=torch.int32, device=dev)
+            return (torch.tensor(enc2 + [(0, 0, 0, 0)] * 4, dtype=torch.int32, device=dev).contiguous(),
+                    (sr[:, 0].contiguous(), sr[:, 1].contiguous(), sr[:, 2].contiguous()))
+        if kind in ("conv", "s2d", "convT") and self.halo == 1 and cin % 64 == 0 and cout >= 128 and self.early_a:
+            self.steps_k64, self.src_k64 = k64_tables(steps, src, self.n_groups)
+            if dual is not None:
+                self.steps_dual_k64, self.src_dual_k64 = k64_tables(dual[0], dual[1], 2)
         up9 = self.__dict__.pop("_up9_tmp", None)
         self.steps_up9 = None
         if up9 is not None:
@@ -544,6 +577,23 @@ class ConvPlan:
         check(lib.ppst_conv_pack_dual(_p(self.wsrc), sn, sc, sy, sx, float(self.scale), self.cout, _p(c_), _p(ky_), _p(kx_),
                                       self.nsteps, 2, self.precision, _p(wpack), _stream()), "ppst_conv_pack_dual")
         self._packs["dual"] = wpack
+        return wpack
+
+    def pack_k64(self, bn, dual=False):
+        """weights for ppst_conv_args.k64 (ppst_conv_pack_k64), built on first use."""
+        key = "k64_dual" if dual else "k64_%d" % bn
+        hit = self._packs.get(key)
+        if hit is not None:
+            return hit
+        sn, sc, sy, sx = self.wstrides
+        c_, ky_, kx_ = self.src_dual_k64 if dual else self.src_k64
+        ng = 2 if dual else self.n_groups
+        nst = c_.numel() // ng
+        n_tiles = (self.cout + (bn // 2 if dual else bn) - 1) // (bn // 2 if dual else bn)
+        wpack = torch.empty(ng * n_tiles * nst * 8 * bn * 8, dtype=torch.int16, device=self.steps.device)
+        check(lib.ppst_conv_pack_k64(_p(self.wsrc), sn, sc, sy, sx, float(self.scale), self.cout, bn, _p(c_), _p(ky_), _p(kx_), nst, ng,
+                                     self.precision, 1 if dual else 0, _p(wpack), _stream()), "ppst_conv_pack_k64")
+        self._packs[key] = wpack
         return wpack
 
     def pack_up9(self):
@@ -690,6 +740,11 @@ class ConvPlan:
         for t, n in ((bias, "bias"), (noise, "noise"), (prelu, "prelu")):
             _chk(t, n)
         variant, bn, rows = self.choose_kernel(th, tw, oh, ow, H, W, osy, B)
+        # single-pass modes on half-stored activations: 64 input channels per step where the N-256 kernel family runs the layer
+        k64 = (K64["value"] and x.dtype != torch.float32 and self.precision in (1, 3) and variant in (2, 7, "dual")
+               and (self.steps_dual_k64 if variant == "dual" else self.steps_k64) is not None)
+        if k64 and variant == 7:
+            variant, rows = 9, 24                # the Cout = 128-class layers: 24 x 16 px x 128 ch tiles (two activation slots fit)
         st = None
         if stats:
             tiles = lib.ppst_conv_tiles(th, tw, rows)
@@ -703,9 +758,15 @@ class ConvPlan:
             variant = 11
             if in_ss is not None or residual is not None or act == ACT_PRELU or pad_mode != PAD_ZERO:
                 raise RuntimeError("the nine-product upscale (ops.UP9) takes no normalise-on-load, residual, PReLU or non-zero padding")
-        wp = None if self.precision == 2 else (self.pack_wino() if variant == 10 else self.pack_up9() if up9 else self.pack_dual() if dual
-                                               else self.pack_for(bn))
-        a.x, a.wpack, a.steps, a.y = _p(x), _p(wp), _p(self.steps_up9 if up9 else self.steps_dual if dual else self.steps), _p(out)
+        if k64:
+            wp = self.pack_k64(bn, dual)
+            steps_t = self.steps_dual_k64 if dual else self.steps_k64
+        else:
+            wp = None if self.precision == 2 else (self.pack_wino() if variant == 10 else self.pack_up9() if up9 else self.pack_dual() if dual
+                                                   else self.pack_for(bn))
+            steps_t = self.steps_up9 if up9 else self.steps_dual if dual else self.steps
+        a.x, a.wpack, a.steps, a.y = _p(x), _p(wp), _p(steps_t), _p(out)
+        a.k64 = 1 if k64 else 0
         a.variant = variant
         a.dual_b = 1 if dual else 0
         a.bias, a.noise, a.prelu, a.stats = _p(bias), _p(noise), _p(prelu), _p(st)
@@ -715,7 +776,7 @@ class ConvPlan:
         a.noise_weight, a.out_scale = float(noise_weight), float(out_scale)
         a.B, a.in_h, a.in_w, a.in_ld = B, H, W, in_ld
         a.out_h, a.out_w, a.out_ld, a.cout = oh, ow, out_ld, self.cout
-        a.nsteps, a.n_groups, a.pad_mode = self.nsteps, (1 if up9 else 2 if dual else self.n_groups), pad_mode
+        a.nsteps, a.n_groups, a.pad_mode = (self.nsteps // 2 if k64 else self.nsteps), (1 if up9 else 2 if dual else self.n_groups), pad_mode
         a.in_off_y = a.in_off_x = 0
         a.out_sy = a.out_sx = osy
         a.act, a.precision = act | (0x100 if res_after_act else 0), self.precision
@@ -761,6 +822,16 @@ def repack_plans(plans):
         for bn, wpack in pl._packs.items():
             if bn == "wino":                     # variant-10 pack: its own transform kernel, one launch per plan
                 wino.append((pl.wsrc, pl.wstrides, float(pl.scale), pl.cout, pl.cin, wpack))
+                continue
+            if isinstance(bn, str) and bn.startswith("k64_"):     # 64-channel-step packs: jobs of the batched pack kernel (x3 = 2)
+                kd = bn == "k64_dual"
+                kc, kky, kkx = pl.src_dual_k64 if kd else pl.src_k64
+                kbn = 256 if kd else int(bn[4:])
+                kng = 2 if kd else pl.n_groups
+                knt = (pl.cout + (kbn // 2 if kd else kbn) - 1) // (kbn // 2 if kd else kbn)
+                pk.append((pl.wsrc.data_ptr(), sn, sc, sy, sx, kc.data_ptr(), kky.data_ptr(), kkx.data_ptr(), wpack.data_ptr(),
+                           kng * knt * (kc.numel() // kng) * 4 * kbn, float(pl.scale), pl.cout, kbn, kc.numel() // kng, kng,
+                           2, 1 if pl.precision == 3 else 0, 1 if kd else 0))
                 continue
             if bn == "up9":                      # variant-11 pack: from the 3x3 parameter itself, one launch per plan
                 wino.append(("up9", pl.wparam, float(pl.up_scale), pl.cout, pl.cin, wpack))

@@ -676,6 +676,71 @@ def t_conv_variants_single_pass():
             report("single-pass prec %d %s stats" % (prec, name), outs[1][1], outs[0][1], 1e-5)
 
 
+def t_conv_k64():
+    """64 input channels per step in the single-pass modes on half-stored activations (ppst_conv_args.k64: the chunk's second 32 channels
+    where the fp32-class kernel keeps its lo planes, two MFMAs per product) against the 32-channel-step form of the same plan: the same
+    products in another fp32 summation order, so outputs agree to a rounding of the stored type and statistics to 1e-5; every kernel
+    geometry that takes it (N-256 plain / four phases / phase pairs, the 24-row tile of the Cout = 128 layers), with normalise-on-load,
+    residual and noise; and the plain case against float64."""
+    torch.manual_seed(23)
+    nz_ = torch.randn
+    prev = ops.K64["value"], ops.FAT_MIN_BLOCKS, dict(ops.TALL_TILE_SINGLE), dict(ops.DUAL_CONVT)
+    ops.FAT_MIN_BLOCKS = 0
+    ops.TALL_TILE_SINGLE.update(min_blocks=0)
+    ops.DUAL_CONVT.update(min_blocks=0)
+    pre = g(torch.tensor([0.25]))
+    try:
+        for prec, dt in ((3, torch.float16), (1, torch.bfloat16)):
+            tag, tol = ("fp16", 2e-3) if prec == 3 else ("bf16", 1.6e-2)
+            for name, B, ci, co, H, Wd, kind, pm, want in (("N-256 3x3 zero 128->256 64x64", 2, 128, 256, 64, 64, "conv", 0, 2),
+                                                            ("N-256 3x3 reflect 256->256 33x47", 1, 256, 256, 33, 47, "conv", 1, 2),
+                                                            ("N-256 convT 128->512 20x12", 2, 128, 512, 20, 12, "convT", 0, 2),
+                                                            ("dual convT 64->128 64x48", 2, 64, 128, 64, 48, "convT", 0, "dual"),
+                                                            ("24-row tile 3x3 reflect 64->128 50x47", 2, 64, 128, 50, 47, "conv", 1, 7),
+                                                            ("24-row tile s2d 64->128 -> 37x20", 2, 64, 128, 37, 20, "s2d", 0, 7)):
+                w = g(nz_(co, ci, 3, 3) / math.sqrt(ci * 9))
+                plan = ops.ConvPlan(w, kind=kind, precision=prec)
+                cx = plan.max_chan + 32
+                x = (g(nz_(B, H + 1, Wd + 1, cx)) if kind == "s2d" else g(nz_(B, H, Wd, cx))).to(dt)
+                oh, ow = (2 * H, 2 * Wd) if kind == "convT" else (H, Wd)
+                kw0 = dict(out_hw=(H, Wd)) if kind == "s2d" else {}
+                assert plan.choose_kernel(H, Wd, oh, ow, x.shape[1], x.shape[2], 2 if kind == "convT" else 1)[0] == want, name
+                bias = g(torch.arange(co, dtype=torch.float32) * 0.01)
+                res = g(nz_(B, oh, ow, co)).to(dt); nzp = g(nz_(B, 1, oh, ow)); iss = g(torch.rand(B, cx, 2) + 0.5)
+                for vname, kw in (("", dict(bias=bias, act=ops.ACT_LRELU)),
+                                  ("in_ss prelu + res", dict(bias=bias, in_ss=iss, in_act=ops.ACT_PRELU, in_prelu=pre, residual=res, out_scale=0.7)),
+                                  ("noise + res after act", dict(bias=bias, noise=nzp, noise_weight=0.3, act=ops.ACT_LRELU, residual=res, res_after_act=True))):
+                    outs = []
+                    for on in (False, True):
+                        ops.K64["value"] = on
+                        y, st = plan(x, pad_mode=pm, stats=True, **kw, **kw0)
+                        outs.append((y.float().cpu(), st.sum(1).cpu()))
+                    report("k64 %s %s %s" % (tag, name, vname), outs[1][0], outs[0][0], tol)
+                    report("k64 %s %s %s stats" % (tag, name, vname), outs[1][1], outs[0][1], 1e-5)
+                if kind == "conv" and prec == 3:
+                    ops.K64["value"] = True
+                    ref = conv_ref(nchw(x.float().cpu()).double(), w.cpu().double().half().double(), "conv", pm)      # operands as the kernel sees them
+                    report("k64 %s %s vs float64 (fp16 operands)" % (tag, name), nchw(plan(x, pad_mode=pm).float()), ref, 2e-3)
+    finally:
+        ops.K64["value"], ops.FAT_MIN_BLOCKS = prev[0], prev[1]
+        ops.TALL_TILE_SINGLE.update(prev[2]); ops.DUAL_CONVT.update(prev[3])
+
+
+def _k64_off(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        prev = ops.K64["value"]
+        ops.K64["value"] = False        # (bit-exactness against the fp32-storage form needs the same 32-channel step order)
+        try:
+            return fn(*a, **k)
+        finally:
+            ops.K64["value"] = prev
+    return wrapped
+
+
+@_k64_off
 def t_half_storage():
     """Half-precision activation storage (ppst_conv_args.io_st and the `_st` entry points; include/ppst_hip.h): a kernel given
     IEEE-half (mode 3) / bfloat16 (mode 1) tensors computes in fp32 exactly as its fp32 form and rounds once, to nearest even, at
@@ -1296,7 +1361,7 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     print("device:", torch.cuda.get_device_name(0), flush=True)
     if which in ("ops", "all"):
-        for fn in (t_upfirdn2d, t_fused_act, t_ops_half, t_layout_misc, t_conv, t_conv_variants, t_conv_variants_single_pass, t_half_storage, t_conv1x1_stream, t_norm_pool, t_corr, t_guided):
+        for fn in (t_upfirdn2d, t_fused_act, t_ops_half, t_layout_misc, t_conv, t_conv_variants, t_conv_variants_single_pass, t_half_storage, t_conv_k64, t_conv1x1_stream, t_norm_pool, t_corr, t_guided):
             print("== " + fn.__name__, flush=True)
             run(fn)
             torch.cuda.synchronize()
@@ -1311,6 +1376,8 @@ def main():
         run(t_ops_half)
     if which == "up9":
         run(t_conv_up9)
+    if which == "k64":
+        run(t_conv_k64)
     if which == "half":
         run(t_half_storage)
         run(t_conv_dual)
