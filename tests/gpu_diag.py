@@ -344,18 +344,19 @@ CONV_DEFAULTS = (ops.CONV_VARIANT["value"], ops.FAT_MIN_BLOCKS)
 
 
 def direct_kernels_only(fn):
-    """Run ``fn`` with the Winograd kernel (variant 10) switched off: the bit-identity checks below compare the DIRECT kernel
-    families with each other (same MFMA sequence per output element); variant 10 is fp32-class but a different sum."""
+    """Run ``fn`` with the Winograd kernel (variant 10), the phase-pair / nine-product upscales and the 64-channel steps switched
+    off: the bit-identity checks below compare the DIRECT kernel families with each other (same MFMA sequence per output element);
+    those forms are other sums of the same products (each has its own test)."""
     import functools
 
     @functools.wraps(fn)
     def wrapped(*a, **k):
-        prev = ops.WINO["value"], ops.DUAL_CONVT["value"], ops.UP9["value"]
-        ops.WINO["value"] = ops.DUAL_CONVT["value"] = ops.UP9["value"] = False
+        prev = ops.WINO["value"], ops.DUAL_CONVT["value"], ops.UP9["value"], ops.K64["value"]
+        ops.WINO["value"] = ops.DUAL_CONVT["value"] = ops.UP9["value"] = ops.K64["value"] = False
         try:
             return fn(*a, **k)
         finally:
-            ops.WINO["value"], ops.DUAL_CONVT["value"], ops.UP9["value"] = prev
+            ops.WINO["value"], ops.DUAL_CONVT["value"], ops.UP9["value"], ops.K64["value"] = prev
     return wrapped
 
 
