@@ -242,7 +242,9 @@ typedef struct ppst_conv_args {
                                        is tap (dy, dx) of chunk c; bn = 64, or 128 for Cout in 65..128.  The table lives on
                                        the device and is not re-read: the CALLER owns this promise (as with a_slots).
                                     7: conv_mfma2.hip with 8 waves as 4 (M) x 2 (N): block tile 32 x 16 px x 128 ch, one
-                                       activation slot; bn = 128, tile_rows = 32, the early_a promise (experiment, measured slower).
+                                       activation slot; bn = 128, tile_rows = 32, the early_a promise (precision 0: experiment, measured
+                                       slower; precision 1 / 3: a production form with TWO activation slots -- the Cout = 128-class
+                                       layers of the single-pass modes).
                                     8: conv_ksplit.hip -- bn = 128, the block's 8 waves as 2 (K) x 2 (M) x 2 (N): wave group k
                                        takes the steps of parity k (wave tile 128 px x 64 ch), the two partial sums meet in
                                        LDS before the epilogue.  Needs the early_a promise, precision 0, unit output stride
@@ -265,6 +267,8 @@ typedef struct ppst_conv_args {
                                        TWO activation slots; bn = 128, tile_rows = 24, the early_a promise, precision 0
                                        (experiment: bit-identical, +-1.5 % of variant 0 -- the 36-step tiles of the Cout = 128
                                        layers are prologue / epilogue bound, not wave-tile bound).
+                                       With k64 (precision 1 / 3, io_st != 0) a production form: the Cout = 128-class layers of the
+                                       single-pass modes on half-stored activations.
                                     Variants 0-7 and 9 give bit-identical outputs; the per-tile statistics differ in the last
                                     bit between variants (other summation tree).  The library returns PPST_EINVAL for a
                                     variant whose shape conditions do not hold. */
