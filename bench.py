@@ -654,7 +654,8 @@ def main():
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "peak_note": "bf16 dense MFMA 2500 TF / %d MFMA passes per algorithmic MAC" % passes,
                 "frac_note": "achieved = ALGORITHMIC conv flop (2 * MACs of the direct form) / kernel time.  conv_wino_kernel issues 2/3 "
-                             "of the direct form's MFMAs for the same algorithmic MACs, so since round 4 this fraction and the matrix-pipe "
+                             "of the direct form's MFMAs for the same algorithmic MACs (and the nine-product fused upscale, "
+                             "ppst_conv_args.variant 11, 0.64 of its four-phase form's), so since round 4 this fraction and the matrix-pipe "
                              "busy counter (mfma_busy_frac_pmc) no longer move together: the counter is what the pipe did, frac is what "
                              "the path got done against the direct form's ceiling",
                 "frac_vs_dense_bf16": achieved / PEAK_BF16_DENSE_TF,
