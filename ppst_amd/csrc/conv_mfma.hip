@@ -835,7 +835,7 @@ extern "C" int ppst_conv_pack_dual(const void* w, int64_t sn, int64_t sc, int64_
   return PPST_LAUNCH_CHECK();
 }
 // Weights for ppst_conv_args.variant 11 (conv_mfma2.hip UP9): blob of step s = 4 * chunk + shift in the N-256 kernel's LDS image
-// [hi | lo][k-group g][256 columns][8 k], column = N-wave wn * 64 + u type t * 16 + r <-> output channel 64 * ntile + 16 * wn + r; the
+// [hi | lo][k-group g][256 columns][8 k], column = u type t * 64 + N-wave wn * 16 + r <-> output channel 64 * ntile + 16 * wn + r; the
 // tap of (shift, type) -- shift (0,0): ee w[0][0], eo w[0][1], oe w[1][0], oo w[1][1]; (-1,0): ee w[2][0], eo w[2][1]; (0,-1): ee
 // w[0][2], oe w[1][2]; (-1,-1): ee w[2][2] -- of the UN-BLURRED 3x3 kernel w (Cout, Cin, 3, 3) * scale; zeros elsewhere.
 __global__ __launch_bounds__(256) void conv_pack_up9_kernel(const float* __restrict__ w, int64_t sn, int64_t sc, int64_t sy, int64_t sx, float scale,
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(256) void conv_pack_up9_kernel(const float* __restr
     const int g = (int)(r % 4); r /= 4;
     const int s = (int)(r % nsteps);
     const int ntile = (int)(r / nsteps);
-    const int chunk = s >> 2, sh = s & 3, wn = col >> 6, ty = (col >> 4) & 3, n = ntile * 64 + wn * 16 + (col & 15);
+    const int chunk = s >> 2, sh = s & 3, ty = col >> 6, wn = (col >> 4) & 3, n = ntile * 64 + wn * 16 + (col & 15);   // columns: [type][N-wave][16 ch]
     // (ky, kx) of (shift, type), -1: no tap
     const int kyt[4][4] = {{0, 0, 1, 1}, {2, 2, -1, -1}, {0, -1, 1, -1}, {2, -1, -1, -1}};
     const int kxt[4][4] = {{0, 1, 0, 1}, {0, 1, -1, -1}, {2, -1, 2, -1}, {2, -1, -1, -1}};

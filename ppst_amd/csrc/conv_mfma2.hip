@@ -256,7 +256,10 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   // ---- B staging: LDS-DMA of the pre-packed step blob (global_load_lds_dwordx4, 1 KB per wave-instruction)
   constexpr int B_WI = BBUF / 1024;
   constexpr int B_PER_WAVE = (B_WI + NWV - 1) / NWV;     // (12 waves: the last round is issued by the first B_WI % NWV waves only)
-  auto b_dma = [&](int s, int slot) {
+  // (UP9: the blob's columns are u-type major -- [type][N-wave][16 ch], so a 1-KB piece is ONE type of one plane and wave w moves the
+  //  pieces of type w & 3: a step that feeds fewer types moves only their pieces, `tmask` = the types of the step being fetched)
+  auto b_dma = [&](int s, int slot, int tmask = 0xF) {
+    if (UP9 && !((tmask >> (wave & 3)) & 1)) return;
     const unsigned char* src = wblob + (int64_t)s * BBUF + lane * 16;
     unsigned char* dst = smB + slot * BBUF;
 #pragma unroll
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
     }
   };
   // fragment addresses
-#define B_ADDR(slot, nt) (smB + (slot) * BBUF + g * BPLANE + ((wn * NT + (nt)) * 16 + r16) * 16)
+#define B_ADDR(slot, nt) (smB + (slot) * BBUF + g * BPLANE + ((UP9 ? (nt) * 4 + wn : wn * NT + (nt)) * 16 + r16) * 16)
 #define A_OFF(slot, dy, dx, mt) ((slot) * ABUF + g * PLANE + (((wm * MT + (mt) + HALO + (dy)) * HW + HALO + (dx) + r16) * 16))
 #define DXW(z) (DUAL ? ((((z) >> (wn >= WNW / 2 ? 8 : 0)) & 0xff) - 1) : (z))   /* this wave's tap column of the step */
 
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
     d = steps[1];
     dy1 = d.y; dx1 = DXW(d.z);
     sl1 = (d.w & 1) ? 1 : 0;
-    b_dma(1, 1);
+    b_dma(1, 1, UP9 ? 0x3 : 0xF);
     if (d.w & 1) a_load(d.x);
     if (d.w & 1) a_store(sl1);
     if (NA > 1 && a.early_a && (d.w & 2)) a_load(d.w >> 8);
@@ -323,7 +326,8 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
 #define HALFBAR_IF(s)
 #endif
 #define STEP2(bch, bcl, bnh, bnl, s, D2, D3, H1, H2) STEP2M(bch, bcl, bnh, bnl, s, D2, D3, H1, H2, 0xF, 0xF)
-#define STEP2M(bch, bcl, bnh, bnl, s, D2, D3, H1, H2, MASK, MASKN)   /* MASK / MASKN: n-tiles this / the next step multiplies (UP9) */ \
+#define STEP2M(bch, bcl, bnh, bnl, s, D2, D3, H1, H2, MASK, MASKN) STEP2N(bch, bcl, bnh, bnl, s, D2, D3, H1, H2, MASK, MASKN, 0xF)
+#define STEP2N(bch, bcl, bnh, bnl, s, D2, D3, H1, H2, MASK, MASKN, MASK2)   /* MASK2: the types of step s + 2 (its weight DMA) */   /* MASK / MASKN: n-tiles this / the next step multiplies (UP9) */ \
   {                                                                                                           \
     const bool has1 = (H1), has2 = (H2);                                                                      \
     TR2_DECL TR2(0)                                                                                           \
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
         D3 = steps[(s) + 3];                                                                                  \
         newA2 = has2 && (D2.w & 1);                                                                           \
         if (NA > 1 && newA2) sl2 = sl1 ^ 1;                                                                   \
-        if (has2) b_dma((s) + 2, (s) & 1);                                                                    \
+        if (has2) b_dma((s) + 2, (s) & 1, (MASK2));                                                           \
         __builtin_amdgcn_sched_barrier(0);   /* DMA issued before the activation loads: counted vmcnt below */ \
         {                                                                                                     \
           const bool early_ = NA > 1 && a.early_a;                                                            \
@@ -421,16 +425,16 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
     // [ee, eo, oe, oo] of its 16 channels, and a shift feeds 4 / 2 / 2 / 1 of them: nine products per input pixel instead of the
     // sixteen of the four-phase form (masks are compile-time: the skipped MFMAs and fragment reads are not in the code)
     for (; s + 5 < a.nsteps; s += 4) {
-      STEP2M(b0h, b0l, b0h, b0l, s, dE, dO, true, true, 0xF, 0x3)
-      STEP2M(b0h, b0l, b0h, b0l, s + 1, dO, dE, true, true, 0x3, 0x5)
-      STEP2M(b0h, b0l, b0h, b0l, s + 2, dE, dO, true, true, 0x5, 0x1)
-      STEP2M(b0h, b0l, b0h, b0l, s + 3, dO, dE, true, true, 0x1, 0xF)
+      STEP2N(b0h, b0l, b0h, b0l, s, dE, dO, true, true, 0xF, 0x3, 0x5)
+      STEP2N(b0h, b0l, b0h, b0l, s + 1, dO, dE, true, true, 0x3, 0x5, 0x1)
+      STEP2N(b0h, b0l, b0h, b0l, s + 2, dE, dO, true, true, 0x5, 0x1, 0xF)
+      STEP2N(b0h, b0l, b0h, b0l, s + 3, dO, dE, true, true, 0x1, 0xF, 0x3)
     }
     for (; s < a.nsteps; s += 4) {
-      STEP2M(b0h, b0l, b0h, b0l, s, dE, dO, s + 1 < a.nsteps, s + 2 < a.nsteps, 0xF, 0x3)
-      STEP2M(b0h, b0l, b0h, b0l, s + 1, dO, dE, s + 2 < a.nsteps, s + 3 < a.nsteps, 0x3, 0x5)
-      STEP2M(b0h, b0l, b0h, b0l, s + 2, dE, dO, s + 3 < a.nsteps, s + 4 < a.nsteps, 0x5, 0x1)
-      STEP2M(b0h, b0l, b0h, b0l, s + 3, dO, dE, s + 4 < a.nsteps, s + 5 < a.nsteps, 0x1, 0xF)
+      STEP2N(b0h, b0l, b0h, b0l, s, dE, dO, s + 1 < a.nsteps, s + 2 < a.nsteps, 0xF, 0x3, 0x5)
+      STEP2N(b0h, b0l, b0h, b0l, s + 1, dO, dE, s + 2 < a.nsteps, s + 3 < a.nsteps, 0x3, 0x5, 0x1)
+      STEP2N(b0h, b0l, b0h, b0l, s + 2, dE, dO, s + 3 < a.nsteps, s + 4 < a.nsteps, 0x5, 0x1, 0xF)
+      STEP2N(b0h, b0l, b0h, b0l, s + 3, dO, dE, s + 4 < a.nsteps, s + 5 < a.nsteps, 0x1, 0xF, 0x3)
     }
   } else
   if (BDB) {
@@ -454,6 +458,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   }
 #undef STEP2
 #undef STEP2M
+#undef STEP2N
 #undef A_OFF
 #undef DXW
 #undef B_ADDR
