@@ -122,13 +122,18 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT
   const float* const nzb = a.noise ? a.noise + img : nullptr;
   const unsigned char* const rb = a.residual ? (const unsigned char*)a.residual + img * a.res_ld * ES : nullptr;
   const int nbase = ntile * (NT > 4 ? 128 : 64) + g * 4;
+  // (buffer loads, every request unconditional -- a pixel outside the tile / image and a launch without noise read out of range and
+  //  get zero: as conditional global loads hipcc issued them one by one, each with its own wait; conv_mfma2.hip's UP9 epilogue)
   float nzv[MT];
   float4 bva[NT];
+  const __amdgpu_buffer_rsrc_t nrs = __builtin_amdgcn_make_buffer_rsrc((void*)(nzb ? (const void*)nzb : (const void*)yb), 0,
+                                                                       nzb ? (TAPS ? a.out_h * a.out_w : a.hw) * 4 : 0, 0x00020000);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int p = pbase + mt * 16 + r16;
     const bool ok = TAPS ? (oy0 + mt < a.out_h && ox < a.out_w) : p < a.hw;
-    nzv[mt] = (nzb && ok) ? a.noise_weight * nzb[TAPS ? (oy0 + mt) * a.out_w + ox : p] : 0.f;
+    nzv[mt] = a.noise_weight * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                   nrs, ok ? (TAPS ? (oy0 + mt) * a.out_w + ox : p) * 4 : (int)0x80000000, 0, 0));
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)

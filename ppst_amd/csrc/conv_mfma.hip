@@ -564,13 +564,18 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   const unsigned char* const rb = a.residual ? (const unsigned char*)a.residual + img * a.res_ld * ES : nullptr;
   // Bias and noise of the whole wave tile are fetched BEFORE the first store: vmcnt counts stores too and retires in order, so a
   // load issued behind a pass's stores made its s_waitcnt sit out their acknowledgements (one HBM round trip per pass).
+  // (buffer loads, every request unconditional -- a pixel outside the tile / image and a launch without noise read out of range and
+  //  get zero: as conditional global loads hipcc issued them one by one, each with its own wait; conv_mfma2.hip's UP9 epilogue)
   float nzv[8];
   float4 bva[2];
+  const __amdgpu_buffer_rsrc_t nrs = __builtin_amdgcn_make_buffer_rsrc((void*)(nzb ? (const void*)nzb : (const void*)yb), 0,
+                                                                       nzb ? a.out_h * a.out_w * 4 : 0, 0x00020000);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int r = i >> 1, c8 = i & 1;
     const bool ok = tyb + r < a.tile_h && oyb + r * a.out_sy < a.out_h && (c8 ? okx1 : okx0);
-    nzv[i] = (nzb && ok) ? a.noise_weight * nzb[pix0 + r * rs_pix + c8 * 8 * a.out_sx] : 0.f;
+    nzv[i] = a.noise_weight * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                  nrs, ok ? (pix0 + r * rs_pix + c8 * 8 * a.out_sx) * 4 : (int)0x80000000, 0, 0));
   }
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {

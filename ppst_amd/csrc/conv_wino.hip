@@ -546,17 +546,20 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 1 : 2) void conv_wino_kernel
   // pass ph, item it: pair row m = 32 ph + 16 it + mloc -> tile row m >> 3, pair m & 7
   // bias and noise fetched before the first store (vmcnt counts stores and retires in order: conv_mfma.hip)
   const float4 bv = (nok && a.bias) ? *(const float4*)(a.bias + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // (buffer loads, every request unconditional: a pixel outside the image -- and a launch without noise -- reads out of range and gets
+  //  zero.  As conditional global loads hipcc issued them one by one, each with its own wait: found in the nine-product upscale's
+  //  epilogue, conv_mfma2.hip, where 32 of them cost 0.3 ms of a 2.6-ms launch)
   float nzv[8 * NIT];
-  if (nzb) {
+  {
+    const __amdgpu_buffer_rsrc_t nrs = __builtin_amdgcn_make_buffer_rsrc((void*)(nzb ? nzb : (const float*)yb), 0,
+                                                                         nzb ? a.in_h * a.in_w * 4 : 0, 0x00020000);
 #pragma unroll
     for (int i = 0; i < 8 * NIT; ++i) {
       const int m = 32 * (i / (2 * NIT)) + NML * ((i >> 1) % NIT) + mloc;
       const int oy = ty0 + (m >> 3), ox = tx0 + 2 * (m & 7) + (i & 1);
-      nzv[i] = (oy < a.in_h && ox < a.in_w) ? a.noise_weight * nzb[oy * a.in_w + ox] : 0.f;
+      nzv[i] = a.noise_weight * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                    nrs, (oy < a.in_h && ox < a.in_w) ? (oy * a.in_w + ox) * 4 : WINO_OOB, 0, 0));
     }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8 * NIT; ++i) nzv[i] = 0.f;
   }
   float4 s1a = make_float4(0.f, 0.f, 0.f, 0.f), s2a = s1a;
   const int resm = a.residual ? (res_after ? 2 : 1) : 0;
@@ -573,7 +576,8 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 1 : 2) void conv_wino_kernel
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
           for (int j = 0; j < 4; ++j) tw[(ml * 16 + g * 4 + j) * TROW2 + nt * 16] = acc[ph * 2 + ml][nt][j];
-      __syncthreads();
+      // (LDS only: __syncthreads() also waits for the previous pass's global stores)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       const float* tr = T + (ph & 1) * TBUF2 + f32_ * 4;
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
