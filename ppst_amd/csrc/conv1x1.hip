@@ -137,7 +137,7 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
-    bva[nt] = (a.bias && nbase + nt * 16 < a.cout) ? *(const float4*)(a.bias + nbase + nt * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bva[nt] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc((void*)(a.bias ? (const void*)a.bias : (const void*)a.y), 0, a.bias ? a.cout * 4 : 0, 0x00020000), (nbase + nt * 16) * 4, 0, 0));   // (out of range -> zeros)
   // instantiated per (activation, residual mode), as in conv_mfma.hip / conv_mfma2.hip (same arithmetic, no FMA contraction)
   auto epi_passes = [&](auto act_c, auto res_c) {
 #pragma clang fp contract(off)

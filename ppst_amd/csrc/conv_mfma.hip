@@ -580,7 +580,8 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const int n0 = ntile * BN + wn * 64 + pass * 32 + f8 * 4;
-    bva[pass] = (n0 < a.cout && a.bias) ? *(const float4*)(a.bias + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // (unconditional as the noise loads above: channels beyond cout and a launch without bias read out of range -> zeros)
+    bva[pass] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc((void*)(a.bias ? (const void*)a.bias : (const void*)a.y), 0, a.bias ? a.cout * 4 : 0, 0x00020000), n0 * 4, 0, 0));
   }
   // The passes are instantiated per (activation, residual mode): as run-time values they cost ~30 VALU instructions per element
   // (both activation branches evaluated and selected), ~10 when specialised (conv_mfma2.hip).

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
     // store pass: thread = (output column ox = tid >> 4, channel quad c4 = tid & 15); per pass 2 M-waves x 2 output rows
     const int c4 = tid & 15, sox = tid >> 4;
     const int n0 = ntile * 64 + c4 * 4;
-    const float4 bv = a.bias ? *(const float4*)(a.bias + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bv = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc((void*)(a.bias ? (const void*)a.bias : (const void*)a.y), 0, a.bias ? a.cout * 4 : 0, 0x00020000), n0 * 4, 0, 0));
     const int64_t img = (int64_t)b * a.out_h * a.out_w;
     float* const yb = a.y + img * a.out_ld;
     const float* const nzb = a.noise ? a.noise + img : nullptr;
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
 #pragma unroll
   for (int pass = 0; pass < NT / 2; ++pass) {
     const int n0 = ntile * BNC + nw0 + pass * 32 + f8 * 4;
-    bva[pass] = (n0 < a.cout && a.bias) ? *(const float4*)(a.bias + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bva[pass] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc((void*)(a.bias ? (const void*)a.bias : (const void*)a.y), 0, a.bias ? a.cout * 4 : 0, 0x00020000), n0 * 4, 0, 0));   // (out of range -> zeros)
   }
   float4 s1a[NT / 2], s2a[NT / 2];
 #pragma unroll

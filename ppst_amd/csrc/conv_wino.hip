@@ -545,7 +545,7 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 1 : 2) void conv_wino_kernel
   const float* const rb = a.residual ? a.residual + img * a.res_ld : nullptr;
   // pass ph, item it: pair row m = 32 ph + 16 it + mloc -> tile row m >> 3, pair m & 7
   // bias and noise fetched before the first store (vmcnt counts stores and retires in order: conv_mfma.hip)
-  const float4 bv = (nok && a.bias) ? *(const float4*)(a.bias + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 bv = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc((void*)(a.bias ? (const void*)a.bias : (const void*)a.y), 0, a.bias ? a.cout * 4 : 0, 0x00020000), n0 * 4, 0, 0));     // (out of range -> zeros)
   // (buffer loads, every request unconditional: a pixel outside the image -- and a launch without noise -- reads out of range and gets
   //  zero.  As conditional global loads hipcc issued them one by one, each with its own wait: found in the nine-product upscale's
   //  epilogue, conv_mfma2.hip, where 32 of them cost 0.3 ms of a 2.6-ms launch)
