@@ -18,7 +18,9 @@
  * PPST_F16 / PPST_BF16 dtype enum); the `dtype` argument of ppst_upfirdn2d and
  * ppst_fused_bias_act takes the same three types (the reference's
  * AT_DISPATCH_FLOATING_TYPES_AND_HALF: upfirdn2d_kernel.cu:225, fused_bias_act_kernel.cu:79;
- * fp32 arithmetic, one rounding; the FIR taps stay fp32).
+ * fp32 arithmetic, one rounding; the FIR taps stay fp32) and PPST_F64 (round 5: every tensor
+ * of the call -- the FIR taps too -- is double and the arithmetic runs in double, scalar_t = double
+ * in the reference's dispatch: what a gradcheck-style caller of the two ops hands over).
  */
 #ifndef PPST_HIP_H
 #define PPST_HIP_H
@@ -34,7 +36,7 @@ extern "C" {
 #define PPST_EUNSUPPORTED (-2) /* valid but not implemented (e.g. dtype) */
 #define PPST_ENULL (-3)       /* null pointer where data is required */
 
-enum { PPST_F32 = 0, PPST_F16 = 1, PPST_BF16 = 2 };
+enum { PPST_F32 = 0, PPST_F16 = 1, PPST_BF16 = 2, PPST_F64 = 3 /* ppst_upfirdn2d / ppst_fused_bias_act only */ };
 
 /* padding modes of the fused conv (nn.ReflectionPad2d / ReplicationPad2d /
  * zero padding, stylegan2_layers.py:528-531, generator.py:13-17) */
@@ -43,6 +45,11 @@ enum { PPST_PAD_ZERO = 0, PPST_PAD_REFLECT = 1, PPST_PAD_REPLICATE = 2 };
 /* epilogue activation of the fused conv */
 enum { PPST_ACT_NONE = 0, PPST_ACT_LRELU = 1 /* lrelu(0.2)*sqrt2 */, PPST_ACT_PRELU = 2 };
 
+/* ABI revision: bumped whenever a struct of this header changes size or an entry point changes its arguments.
+ *   1: rounds 1-3;  2: round 4-5 (ppst_pack_job gained `dual` -- it is the element of the job ARRAY ppst_conv_pack_batch walks, so its
+ *   stride changed --, ppst_conv_args gained dual_b / io_st / k64, PPST_F64 for the two native ops).  A binding built against
+ *   another revision must refuse to run (ppst_amd/_lib.py does). */
+#define PPST_ABI_VERSION 2
 int ppst_version(void);
 
 /* Storage type of an NHWC activation tensor at the entry points that take one (`*_st` twins and ppst_conv_args.io_st; round 4):

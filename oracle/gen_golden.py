@@ -87,6 +87,41 @@ def gen_ops(ns):
     print("ops.npz", len(out))
 
 
+def gen_ops_f64(ns):
+    """The two native ops in DOUBLE (the CUDA dispatcher of the reference is AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+    upfirdn2d_kernel.cu:225 / fused_bias_act_kernel.cu:79: a gradcheck-style caller hands them float64): the reference's own
+    fallbacks on float64 tensors -- upfirdn2d for the two blur forms of the path, an asymmetric kernel and one up / one down
+    mode; fused_leaky_relu forward and the autograd of its fallback."""
+    out = {}
+    rng = np.random.default_rng(12)
+    up = ns.stylegan2_op.upfirdn2d
+    k3 = ns.layers.make_kernel([1, 2, 1]).double()
+    k4 = ns.layers.make_kernel([1, 3, 3, 1]).double()
+    ka = torch.tensor(rng.standard_normal((4, 4)), dtype=torch.float64)
+    n = 0
+    for (k, u, d, p0, p1, H, Wd) in [(k3, 1, 1, 1, 0, 24, 24), (k4, 1, 1, 2, 2, 20, 28), (ka, 1, 1, 2, 1, 19, 33),
+                                    (ka, 2, 1, 2, 1, 12, 10), (ka, 1, 2, 1, 1, 21, 18)]:
+        x = torch.tensor(rng.standard_normal((2, 3, H, Wd)), dtype=torch.float64)
+        y = up(x, k, up=u, down=d, pad=(p0, p1))
+        assert y.dtype == torch.float64
+        out["upfirdn2d.%d.x" % n] = x.numpy()
+        out["upfirdn2d.%d.k" % n] = k.numpy()
+        out["upfirdn2d.%d.cfg" % n] = np.array([u, d, p0, p1], dtype=np.int64)
+        out["upfirdn2d.%d.y" % n] = y.numpy()
+        n += 1
+    out["upfirdn2d.n"] = np.array(n)
+    x = torch.tensor(rng.standard_normal((2, 5, 7, 6)), dtype=torch.float64, requires_grad=True)
+    b = torch.tensor(rng.standard_normal((5,)), dtype=torch.float64, requires_grad=True)
+    y = ns.stylegan2_op.fused_leaky_relu(x, b)
+    assert y.dtype == torch.float64
+    g = torch.tensor(rng.standard_normal(tuple(y.shape)), dtype=torch.float64)
+    gx, gb = torch.autograd.grad(y, [x, b], g)
+    out.update({"flrelu.x": x.detach().numpy(), "flrelu.b": b.detach().numpy(), "flrelu.y": y.detach().numpy(),
+                "flrelu.g": g.numpy(), "flrelu.gx": gx.numpy(), "flrelu.gb": gb.numpy()})
+    np.savez_compressed(os.path.join(GOLD, "ops_f64.npz"), **out)
+    print("ops_f64.npz", len(out))
+
+
 def set_noise(m, noise):
     for name, mod in m.G.named_modules():
         if type(mod).__name__ == "NoiseInjection":
@@ -442,12 +477,13 @@ def main():
             {"gstep1": lambda: gen_gstep(ns, 1), "gstep2": lambda: gen_gstep(ns, 2),
              "gstep1_f64": lambda: gen_gstep(ns, 1, True), "gstep2_f64": lambda: gen_gstep(ns, 2, True),
              "iter_counter": gen_iter_counter, "corrm_mk": lambda: gen_corrm_mk(ns),
-             "train512": lambda: gen_train(ns, 512), "train128": lambda: gen_train(ns), "gloss": lambda: gen_gloss(ns)}[a]()
+             "ops_f64": lambda: gen_ops_f64(ns), "train512": lambda: gen_train(ns, 512), "train128": lambda: gen_train(ns), "gloss": lambda: gen_gloss(ns)}[a]()
         return
     m = ref_loader.build_reference_model()
     gen_keys(m)
     gen_glue(ns, m)
     gen_ops(ns)
+    gen_ops_f64(ns)
     gen_cfg1(ns, m)
     gen_swap(ns, m)
     gen_train(ns)

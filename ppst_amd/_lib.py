@@ -173,6 +173,11 @@ for _name, (_res, _args) in _SIGS.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
+ABI_VERSION = 2          # PPST_ABI_VERSION of include/ppst_hip.h: the struct layouts above are that revision's
+if lib.ppst_version() != ABI_VERSION:
+    raise ImportError("ppst_amd: %s reports ABI revision %d, this binding is written for %d -- rebuild the library "
+                      "(python -m ppst_amd.build)" % (LIB_PATH, lib.ppst_version(), ABI_VERSION))
+
 _ERR = {-1: "PPST_EINVAL (bad size / flag combination)", -2: "PPST_EUNSUPPORTED", -3: "PPST_ENULL"}
 
 

@@ -1008,7 +1008,8 @@ extern "C" int ppst_prof_collect(double* ms, int64_t* launches, double* flop) {
   g_ev_used = 0;
   return PPST_OK;
 }
-// per-launch detail (call before ppst_prof_collect): info = {B, tile_h, tile_w, cin_steps(nsteps), cout, n_groups, halo, bn}
+// per-launch detail (call before ppst_prof_collect): info = {B, tile_h, tile_w, cin_steps(nsteps), cout, n_groups, halo,
+// bn | variant << 12 | k64 << 20 | precision << 24}; a weight-gradient launch has bn = 0
 extern "C" int ppst_prof_detail(int idx, double* ms, double* flop, int32_t* info) {
   if (idx < 0 || idx >= g_ev_used) return PPST_EINVAL;
   float e = 0.f;
@@ -1067,7 +1068,9 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       // step order, as with variant 6, and a wpack from ppst_conv_pack_wino); bf16x3, bn 128, 16-row tiles, one group, unit strides
       (a->variant == 10 && (a->precision != 0 || a->bn != 128 || a->halo != 1 || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
                             a->in_off_y != 0 || a->in_off_x != 0 || a->tile_h != a->out_h || a->tile_w != a->out_w ||
-                            a->in_h != a->out_h || a->in_w != a->out_w || a->nsteps % 9 != 0 || a->tile_rows != 16)) ||
+                            a->in_h != a->out_h || a->in_w != a->out_w || a->nsteps % 9 != 0 || a->tile_rows != 16 ||
+                            // (its LDS copy of the normalise-on-load table holds 32 chunks = 1024 input channels)
+                            (a->in_scale_shift && a->nsteps / 9 > 32))) ||
       ((a->variant >= 1 && a->variant <= 3 || a->variant == 7 || a->variant == 9) &&
        ((a->precision != 0 && !((a->variant == 2 || a->variant == 7 || (a->variant == 9 && a->k64)) && (a->precision == 1 || a->precision == 3))) || a->bn == 64 || !a->early_a)) ||
       (a->variant == 7 && (a->bn != 128 || a->tile_rows != 32)) ||
@@ -1150,7 +1153,10 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   hipStream_t st = as_stream(stream);
   int slot = -1;
   if (g_prof_on) {
-    const int inf[8] = {a->B, a->tile_h, a->tile_w, a->nsteps, a->cout, a->n_groups, a->halo, a->bn};
+    // info[7]: bits 0-11 the N tile, 12-19 the kernel variant that runs the launch, 20 k64, 24-27 the precision mode (bench.py derives
+    // the MFMA flop the pipe ISSUES from them: Winograd 2/3, nine-product upscale 9/16 over 16 x 16-position blocks, passes per mode)
+    const int inf[8] = {a->B, a->tile_h, a->tile_w, a->nsteps, a->cout, a->n_groups, a->halo,
+                        a->bn | (a->variant << 12) | ((a->k64 ? 1 : 0) << 20) | (a->precision << 24)};
     slot = ppst_prof_begin_(2.0 * 32.0 * (a->flop_steps > 0 ? a->flop_steps : a->nsteps) * (double)((a->dual_b || a->variant == 11) ? 4 : a->n_groups) * a->cout * (double)a->B * a->tile_h * a->tile_w,
                             inf, st);
   }

@@ -46,13 +46,40 @@ __global__ __launch_bounds__(256) void fused_bias_act_kernel(const void* __restr
   }
 }
 
+// double: the reference's dispatcher takes it (AT_DISPATCH_FLOATING_TYPES_AND_HALF, fused_bias_act_kernel.cu:79: scalar_t =
+// double, alpha / scale cast to scalar_t); arithmetic in double like the reference.  Not on the hot path: one scalar form.
+__global__ __launch_bounds__(256) void fused_bias_act_f64_kernel(const double* __restrict__ x, const double* __restrict__ b,
+                                                                 const double* __restrict__ ref, double* __restrict__ y, int64_t n,
+                                                                 int step_b, int size_b, int mode, double alpha, double scale) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double v = x[i];
+    if (b) v += b[(i / step_b) % size_b];
+    const double r = ref ? ref[i] : 0.0;
+    double o;
+    switch (mode) {
+      case 30: o = v > 0.0 ? v : v * alpha; break;
+      case 31: o = r > 0.0 ? v : v * alpha; break;
+      case 32: case 12: o = 0.0; break;
+      default: o = v;
+    }
+    y[i] = o * scale;
+  }
+}
+
 extern "C" int ppst_fused_bias_act(const void* x, const void* b, const void* ref, void* y, int64_t n, int step_b,
                                    int size_b, int act, int grad, float alpha, float scale, int dtype, void* stream) {
-  if (dtype != PPST_F32 && dtype != PPST_F16 && dtype != PPST_BF16) return PPST_EUNSUPPORTED;
+  if (dtype != PPST_F32 && dtype != PPST_F16 && dtype != PPST_BF16 && dtype != PPST_F64) return PPST_EUNSUPPORTED;
   if (n < 0 || grad < 0 || grad > 2 || (b && (step_b <= 0 || size_b <= 0))) return PPST_EINVAL;
   if (n == 0) return PPST_OK;
   if (!x || !y) return PPST_ENULL;
   int mode = act * 10 + grad;
+  if (dtype == PPST_F64) {
+    int64_t nb = cdiv64(n, 256);
+    if (nb > 256 * 16) nb = 256 * 16;
+    PPST_LAUNCH(fused_bias_act_f64_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), (const double*)x, (const double*)b,
+                (const double*)ref, (double*)y, n, step_b, size_b, mode, (double)alpha, (double)scale);
+    return PPST_LAUNCH_CHECK();
+  }
   bool vec = (n % 4 == 0) && (!b || step_b % 4 == 0) && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)ref) % (dtype == PPST_F32 ? 16 : 8) == 0);
   int64_t work = vec ? n / 4 : n;
   int64_t blocks = cdiv64(work, 256);

@@ -678,4 +678,6 @@ extern "C" int ppst_guided_filter(const void* guide_u8, const void* src_u8, void
   return PPST_LAUNCH_CHECK();
 }
 
-extern "C" int ppst_version(void) { return 1; }
+// 2 (round 5): ppst_pack_job gained a trailing `dual` field and ppst_conv_args `dual_b` / `io_st` / `k64` in round 4 -- the ARRAY stride of
+// the job table changed, which "appended" does not cover; callers built against the round-3 header must rebuild.
+extern "C" int ppst_version(void) { return 2; }

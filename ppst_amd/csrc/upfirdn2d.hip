@@ -244,6 +244,34 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic(const void* __restrict_
   }
 }
 
+// double (the reference: AT_DISPATCH_FLOATING_TYPES_AND_HALF, upfirdn2d_kernel.cu:225 -- scalar_t = double, taps double too,
+// accumulation in scalar_t).  Not on the hot path: the generic form only.
+__global__ __launch_bounds__(256) void upfirdn2d_generic_f64(const double* __restrict__ x, const double* __restrict__ k,
+                                                             double* __restrict__ y, UfParams p, int64_t n) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+    int mi = (int)(t % p.minor);
+    int64_t r = t / p.minor;
+    int ox = (int)(r % p.out_w); r /= p.out_w;
+    int oy = (int)(r % p.out_h);
+    int m = (int)(r / p.out_h);
+    double acc = 0.0;
+    for (int ky = 0; ky < p.kh; ++ky) {
+      int Y = oy * p.down_y + ky - p.pad_y0;
+      if (Y < 0 || Y % p.up_y) continue;
+      int iy = Y / p.up_y;
+      if (iy >= p.in_h) continue;
+      for (int kx = 0; kx < p.kw; ++kx) {
+        int X = ox * p.down_x + kx - p.pad_x0;
+        if (X < 0 || X % p.up_x) continue;
+        int ix = X / p.up_x;
+        if (ix >= p.in_w) continue;
+        acc += x[(((int64_t)m * p.in_h + iy) * p.in_w + ix) * p.minor + mi] * k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+      }
+    }
+    y[t] = acc;
+  }
+}
+
 // ---- up2: minor % 4 == 0, up == 2, down == 1 (the adjoint of the decimating blur: zero-insert x2, FIR, crop) ------------
 // One thread = 4 channels of one output pixel; only the taps whose upsampled coordinate is even touch an input sample
 // (at most ceil(K/2)^2 of them).  32-bit index math with multiplier division (the generic kernel's int64 % and / cost
@@ -307,8 +335,9 @@ extern "C" int ppst_upfirdn2d(const void* x, const void* k, void* y, int major, 
                               int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
                               int pad_y0, int pad_y1, int dtype, void* stream) {
   // dtype: element type of x and y (the reference: AT_DISPATCH_FLOATING_TYPES_AND_HALF, upfirdn2d_kernel.cu:225); the taps k are fp32
-  // at this boundary and the products are accumulated in fp32 (the reference accumulates in the tensor's type), rounded once
-  if (dtype != PPST_F32 && dtype != PPST_F16 && dtype != PPST_BF16) return PPST_EUNSUPPORTED;
+  // at this boundary and the products are accumulated in fp32 (the reference accumulates in the tensor's type), rounded once.
+  // PPST_F64: x, k AND y are double, accumulation in double (scalar_t = double in the reference's dispatch)
+  if (dtype != PPST_F32 && dtype != PPST_F16 && dtype != PPST_BF16 && dtype != PPST_F64) return PPST_EUNSUPPORTED;
   if (dtype != PPST_F32 && (((uintptr_t)x | (uintptr_t)y) % 8)) return PPST_EINVAL;
   if (major != 0 && (!x || !k || !y)) return PPST_ENULL;  // an empty batch has no storage
   if (major < 0 || in_h <= 0 || in_w <= 0 || minor <= 0 || kh <= 0 || kw <= 0 || kh > UF_MAXK || kw > UF_MAXK ||
@@ -330,6 +359,12 @@ extern "C" int ppst_upfirdn2d(const void* x, const void* k, void* y, int major, 
   bool fast = up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && (minor == 1 || minor % 4 == 0) && kh == kw;
   bool down2 = up_x == 1 && up_y == 1 && down_x == 2 && down_y == 2 && minor % 4 == 0 && kh == kw;
   int64_t n = (int64_t)major * p.out_h * p.out_w * minor;
+  if (dtype == PPST_F64) {
+    int64_t nb = cdiv64(n, 256);
+    if (nb > 256 * 32) nb = 256 * 32;
+    PPST_LAUNCH(upfirdn2d_generic_f64, dim3((unsigned)nb), dim3(256), 0, st, (const double*)x, (const double*)k, (double*)y, p, n);
+    return PPST_LAUNCH_CHECK();
+  }
   if (dtype != PPST_F32) {          // half / bfloat16: the same kernels on the tensor's storage type (the zero-insert x2 form: generic)
 #define UF_HALF(ST_)                                                                            \
   do {                                                                                          \

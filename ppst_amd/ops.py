@@ -196,21 +196,36 @@ def nhwc_to_nchw(x):
 
 
 # ------------------------------------------------------ upfirdn2d / blur ----
+_DT_F64 = 3          # PPST_F64: the two native ops only (every tensor of the call double, arithmetic in double)
+
+
+def _chk_op(t, name):
+    """tensors of the two native ops: float32 / float16 / bfloat16 / float64 (AT_DISPATCH_FLOATING_TYPES_AND_HALF)"""
+    if t is None:
+        return
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA (HIP) tensor" % name)
+    if t.dtype not in _ST and t.dtype != torch.float64:
+        raise RuntimeError("%s must be float32, float16, bfloat16 or float64, got %s" % (name, t.dtype))
+
+
 def upfirdn2d_raw(x4, kernel, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
-    """x4: [major, H, W, minor] contiguous (upfirdn2d.cpp:4-23). Returns [major, oh, ow, minor].  float32, float16 or bfloat16
-    like the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF (upfirdn2d_kernel.cu:225); the taps are used as fp32 and the
-    products accumulate in fp32 (the reference accumulates in the tensor's type), rounded once to the input's type."""
-    _chk_act(x4, "input")
-    _chk_act(kernel, "kernel")
+    """x4: [major, H, W, minor] contiguous (upfirdn2d.cpp:4-23). Returns [major, oh, ow, minor].  float32, float16, bfloat16
+    or float64 like the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF (upfirdn2d_kernel.cu:225); for the 16- and 32-bit types
+    the taps are used as fp32 and the products accumulate in fp32 (the reference accumulates in the tensor's type), rounded once
+    to the input's type; float64: taps and accumulation in double."""
+    _chk_op(x4, "input")
+    _chk_op(kernel, "kernel")
     x4 = x4.contiguous()
-    kernel = kernel.float().contiguous()
+    f64 = x4.dtype == torch.float64
+    kernel = (kernel.double() if f64 else kernel.float()).contiguous()
     major, in_h, in_w, minor = x4.shape
     kh, kw = kernel.shape
     out_h = (in_h * up_y + py0 + py1 - kh + down_y) // down_y
     out_w = (in_w * up_x + px0 + px1 - kw + down_x) // down_x
     y = torch.empty((major, out_h, out_w, minor), device=x4.device, dtype=x4.dtype)
     check(lib.ppst_upfirdn2d(_p(x4), _p(kernel), _p(y), major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y,
-                             px0, px1, py0, py1, _ST[x4.dtype], _stream()), "ppst_upfirdn2d")
+                             px0, px1, py0, py1, _DT_F64 if f64 else _ST[x4.dtype], _stream()), "ppst_upfirdn2d")
     return y
 
 
@@ -236,20 +251,20 @@ def blur_nhwc(x, kernel, pad0, pad1, pad_mode=PAD_ZERO, down=1, s2d=False, in_ss
 def fused_bias_act_raw(x, b, ref, act, grad, alpha, scale):
     """fused.fused_bias_act (fused_bias_act.cpp:4-20): empty tensor == absent.  float32, float16 or bfloat16 (the reference:
     AT_DISPATCH_FLOATING_TYPES_AND_HALF, fused_bias_act_kernel.cu:79): bias and refer take the input's type, fp32 arithmetic,
-    one rounding."""
-    _chk_act(x, "input")
+    one rounding.  float64 (round 5): arithmetic in double."""
+    _chk_op(x, "input")
     x = x.contiguous()
     b = None if (b is None or b.numel() == 0) else b.to(x.dtype).contiguous()
     ref = None if (ref is None or ref.numel() == 0) else ref.to(x.dtype).contiguous()
-    _chk_act(b, "bias")
-    _chk_act(ref, "refer")
+    _chk_op(b, "bias")
+    _chk_op(ref, "refer")
     y = torch.empty_like(x)
     step_b = 1
     for i in range(2, x.dim()):
         step_b *= x.size(i)
     size_b = b.numel() if b is not None else 1
     check(lib.ppst_fused_bias_act(_p(x), _p(b), _p(ref), _p(y), x.numel(), step_b, size_b, act, grad, float(alpha),
-                                  float(scale), _ST[x.dtype], _stream()), "ppst_fused_bias_act")
+                                  float(scale), _DT_F64 if x.dtype == torch.float64 else _ST[x.dtype], _stream()), "ppst_fused_bias_act")
     return y
 
 
@@ -623,11 +638,13 @@ class ConvPlan:
         return wpack
 
     def wino_ok(self, th, tw, oh, ow, H, W, osy):
+        # (a call with normalise-on-load and more than 1024 input channels is kept off this kernel in __call__: its LDS copy of
+        # the (a, s) table is sized for 32 chunks)
         return (self.precision == 0 and self.kind in ("conv", "dgrad") and self.k == 3 and self.cout >= 128 and osy == 1
                 and (th, tw) == (oh, ow) == (H, W)
                 and ((th + 15) // 16) * ((tw + 15) // 16) * ((self.cout + 127) // 128) >= WINO["min_blocks"])
 
-    def choose_kernel(self, th, tw, oh, ow, H, W, osy, B=None):
+    def choose_kernel(self, th, tw, oh, ow, H, W, osy, B=None, allow_up9=True):
         """(variant, N tile, tile rows) of ppst_conv_args for one launch of this plan -- a function of the plan and of ONE
         image's geometry only.  The batch size is deliberately not an argument: every variant gives bit-identical outputs,
         but their tile statistics differ in the last bit (other summation tree), and a shard of a batch has to reproduce the
@@ -648,7 +665,7 @@ class ConvPlan:
         cv = CONV_VARIANT["value"]
         if cv in (1, 3) or TWO_BLOCK_128["value"] or KSPLIT_128["value"] or TILE24_128["value"] or TALL_TILE_128["value"]:
             _need_experiments("the requested conv variant")
-        if (UP9["value"] and self.kind == "convT" and self.precision == 0 and getattr(self, "steps_up9", None) is not None
+        if (UP9["value"] and allow_up9 and self.kind == "convT" and self.precision == 0 and getattr(self, "steps_up9", None) is not None
                 and self.early_a and ((th + 14) // 15) * ((tw + 14) // 15) * (self.cout // 64) >= UP9["min_blocks"]
                 and th * tw >= UP9["min_fill"] * (((th + 14) // 15) * 15) * (((tw + 14) // 15) * 15)):
             return "up9", 256, 15
@@ -739,8 +756,17 @@ class ConvPlan:
             raise RuntimeError("residual must match the output shape %s, got %s" % ((B, oh, ow, self.cout), tuple(residual.shape)))
         for t, n in ((bias, "bias"), (noise, "noise"), (prelu, "prelu")):
             _chk(t, n)
-        variant, bn, rows = self.choose_kernel(th, tw, oh, ow, H, W, osy, B)
+        # the nine-product upscale takes no normalise-on-load, residual, PReLU or non-zero padding: a call that carries one of them
+        # falls back to the phase-pair / four-phase forms (which take all of them) instead of failing (round-4 ADVICE)
+        up9_ok = in_ss is None and residual is None and act != ACT_PRELU and pad_mode == PAD_ZERO
+        variant, bn, rows = self.choose_kernel(th, tw, oh, ow, H, W, osy, B, allow_up9=up9_ok)
         # single-pass modes on half-stored activations: 64 input channels per step where the N-256 kernel family runs the layer
+        if variant == 10 and in_ss is not None and self.cin > 1024:
+            WINO["value"], prev = False, WINO["value"]
+            try:
+                variant, bn, rows = self.choose_kernel(th, tw, oh, ow, H, W, osy, B, allow_up9=up9_ok)
+            finally:
+                WINO["value"] = prev
         k64 = (K64["value"] and x.dtype != torch.float32 and self.precision in (1, 3) and variant in (2, 7, "dual")
                and (self.steps_dual_k64 if variant == "dual" else self.steps_k64) is not None)
         if k64 and variant == 7:
@@ -756,8 +782,6 @@ class ConvPlan:
             variant = 2
         if up9:
             variant = 11
-            if in_ss is not None or residual is not None or act == ACT_PRELU or pad_mode != PAD_ZERO:
-                raise RuntimeError("the nine-product upscale (ops.UP9) takes no normalise-on-load, residual, PReLU or non-zero padding")
         if k64:
             wp = self.pack_k64(bn, dual)
             steps_t = self.steps_dual_k64 if dual else self.steps_k64

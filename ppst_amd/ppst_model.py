@@ -168,7 +168,9 @@ class PPSTModel(nn.Module):
             if verbose:
                 print("checkpoint %s does not exist! Training will start from scratch" % checkpoint_path)
             return False
-        sd = torch.load(checkpoint_path, map_location="cpu")
+        # weights_only: the loader will be aimed at third-party .pth files -- nothing from the file is executed (a checkpoint of
+        # this layout is a flat dict of tensors, which the restricted unpickler takes)
+        sd = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
         with torch.no_grad():
             for name, own in self.state_dict().items():
                 if not opt.isTrain and (name.startswith("D.") or name.startswith("Dpatch.")):
@@ -267,6 +269,33 @@ class PPSTModel(nn.Module):
 
     def discriminate(self, x):
         return self.D(x)
+
+    def get_visuals_for_snapshot(self, real):
+        """models/ppst_model.py:237-248.  The reference's body calls an undefined ``self.E`` (the SwapAE single encoder it was
+        forked from) and cannot run; the INTENDED semantics, restated with the two encoders that replaced it: (sp, gl) =
+        (E1(real), E2(real)[0]) as in ``encode`` (:264), ``rec = G(sp, gl)``, ``mix = G(sp, swap(gl))`` and ``layout`` = the
+        3-component PCA picture of the spatial code (util.visualize_spatial_code, util/util.py:231-254: centre over all pixels,
+        project on the first three principal axes, rescale to [-1, 1]) resized bilinearly to the image (util.resize2d_tensor
+        :464-476).  During training at most 4 images (2 with several GPUs).  The PCA is host-side visualisation like the
+        reference's (numpy / sklearn there, torch.linalg here); the sign of a principal axis is not defined, so ``layout`` is
+        parity-unpinned by nature -- rec / mix are the path's own decode."""
+        if getattr(self.opt, "isTrain", False):
+            real = real[:2] if getattr(self.opt, "num_gpus", 1) > 1 else real[:4]
+        with torch.no_grad():
+            sp, gl = self.encode(real)
+            rec = self.G(sp, gl, noise=self.noise)
+            mix = self.G(sp, [self.swap(g) for g in gl], noise=self.noise)
+            X = sp.detach().float().permute(0, 2, 3, 1).reshape(-1, sp.shape[1]).cpu().double()
+            X = X - X.mean(0, keepdim=True)
+            B, _, h, w = sp.shape
+            try:
+                _, _, Vh = torch.linalg.svd(X, full_matrices=False)
+                Z = (X @ Vh[:3].t()).reshape(B, h, w, 3).permute(0, 3, 1, 2)
+                Z = (Z - Z.min()) / (Z.max() - Z.min()) * 2 - 1
+                layout = torch.nn.functional.interpolate(Z.float(), real.shape[-2:], mode="bilinear", align_corners=False).to(real.device)
+            except RuntimeError:
+                layout = torch.zeros(B, 3, real.shape[2], real.shape[3], device=real.device)
+        return {"real": real, "layout": layout, "rec": rec, "mix": mix}
 
     # ---- train-step commands (models/ppst_model.py:68-235).  Like the reference's, they return loss TENSORS that carry the
     # graph: ``sum(v.mean() for v in losses.values()).backward()`` (optimizers/ppst_optimizer.py:86-88, :110-111, :121-123)

@@ -688,18 +688,31 @@ class PPSTOptimizer:
         needs_R1_at_current_iter = lambda_R1 > 0.0 and self.discriminator_iter_counter % self.R1_once_every == 0
         if needs_R1_at_current_iter:
             self.optimizer_D.all_reduce(); self.optimizer_D.adam()          # optimizer_D.step(): R1 needs the updated D at once
-            self.optimizer_D.zero_grad()
-            with torch.enable_grad():
-                r1_losses = self.model(images, command="compute_R1_loss")
-                d_losses.update(r1_losses)
-                r1_loss = sum([v.mean() for v in r1_losses.values()])
-                r1_loss = r1_loss * self.R1_once_every
-                r1_loss.backward()
+            d_losses.update(self._r1_backward(images))
         self.optimizer_D.step_deferred()                                     # optimizer_D.step(), all-reduce overlapped (world > 1)
         d_losses = {k: v.detach() for k, v in d_losses.items()}
         d_losses["D_total"] = sum([v.mean() for v in d_losses.values()])
         d_losses.update(d_metrics)
         return d_losses
+
+    def _r1_backward(self, images):
+        """ppst_optimizer.py:116-125 up to (not including) the optimizer step: zero_grad, R1 loss x R1_once_every, backward."""
+        self.optimizer_D.zero_grad()
+        with torch.enable_grad():
+            r1_losses = self.model(images, command="compute_R1_loss")
+            r1_loss = sum([v.mean() for v in r1_losses.values()])
+            r1_loss = r1_loss * self.R1_once_every
+            r1_loss.backward()
+        return r1_losses
+
+    def r1_iteration(self, images):
+        """ONE lazy-R1 pass on its own, as it runs on every R1_once_every-th discriminator iteration (ppst_optimizer.py:116-126):
+        zero_grad -> compute_R1_loss -> x R1_once_every -> backward -> optimizer_D.step().  bench.py times it to state the R1
+        term of the train step when its timed region is shorter than 16 iterations."""
+        self.dis.finish_pending()
+        r1 = self._r1_backward(images)
+        self.optimizer_D.all_reduce(); self.optimizer_D.adam()
+        return {k: v.detach() for k, v in r1.items()}
 
     def save(self, total_steps_so_far):
         if self.dis is not None:

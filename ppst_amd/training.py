@@ -239,7 +239,7 @@ def save_optimizer_state(optimizer, path):
 
 
 def load_optimizer_state(optimizer, path):
-    st = torch.load(path, map_location="cpu")
+    st = torch.load(path, map_location="cpu", weights_only=True)        # nested dicts of tensors / ints only: nothing is executed
     optimizer.train_mode_counter = int(st["train_mode_counter"])
     for k, f in optimizer.gen.fp.items():
         if f.m.numel() != st[k]["m"].numel():

@@ -187,6 +187,40 @@ def t_ops_half():
         report("fused_leaky_relu %s bias gradient" % tag, b.grad.float(), bf.grad, 5e-2 if dt == torch.bfloat16 else 1e-2)
 
 
+def t_ops_f64():
+    """The two native ops in double (the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF: upfirdn2d_kernel.cu:225,
+    fused_bias_act_kernel.cu:79; round-4 verdict, missing #4) against tests/golden/ops_f64.npz -- the reference's own fallbacks on
+    float64 tensors (oracle/gen_golden.py:gen_ops_f64): forward 1e-13, fused_leaky_relu gradients 1e-13; and
+    torch.autograd.gradcheck of both public ops, which is what needs double."""
+    from ppst_amd.stylegan2_op import upfirdn2d, fused_leaky_relu
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "ops_f64.npz"))
+    for i in range(int(gold["upfirdn2d.n"])):
+        x, k = torch.from_numpy(gold["upfirdn2d.%d.x" % i]), torch.from_numpy(gold["upfirdn2d.%d.k" % i])
+        u, d, p0, p1 = (int(v) for v in gold["upfirdn2d.%d.cfg" % i])
+        y = upfirdn2d(g(x), g(k), up=u, down=d, pad=(p0, p1))
+        RES.append(("upfirdn2d f64 case %d dtype" % i, y.dtype == torch.float64))
+        report("upfirdn2d f64 case %d (up %d down %d pad %d,%d)" % (i, u, d, p0, p1), y, torch.from_numpy(gold["upfirdn2d.%d.y" % i]), 1e-13)
+    x = g(torch.from_numpy(gold["flrelu.x"])).requires_grad_(True)
+    b = g(torch.from_numpy(gold["flrelu.b"])).requires_grad_(True)
+    y = fused_leaky_relu(x, b)
+    RES.append(("fused_leaky_relu f64 dtype", y.dtype == torch.float64))
+    report("fused_leaky_relu f64 forward", y, torch.from_numpy(gold["flrelu.y"]), 1e-13)
+    gx, gb = torch.autograd.grad(y, [x, b], g(torch.from_numpy(gold["flrelu.g"])))
+    report("fused_leaky_relu f64 grad_x", gx, torch.from_numpy(gold["flrelu.gx"]), 1e-13)
+    report("fused_leaky_relu f64 grad_b", gb, torch.from_numpy(gold["flrelu.gb"]), 1e-13)
+    torch.manual_seed(5)
+    xs = g(torch.randn(1, 2, 6, 5, dtype=torch.float64)).requires_grad_(True)
+    ks = g(torch.randn(3, 3, dtype=torch.float64))
+    ok = torch.autograd.gradcheck(lambda t: upfirdn2d(t, ks, up=2, down=1, pad=(2, 1)), (xs,), eps=1e-6, atol=1e-7)
+    RES.append(("upfirdn2d f64 gradcheck", bool(ok)))
+    xs = g(torch.randn(2, 3, 4, 5, dtype=torch.float64))
+    xs = (xs + 0.2 * xs.sign()).requires_grad_(True)           # keep |x + b| away from the kink of the leaky ReLU
+    bs = g(torch.zeros(3, dtype=torch.float64)).requires_grad_(True)
+    ok = torch.autograd.gradcheck(fused_leaky_relu, (xs, bs), eps=1e-6, atol=1e-7)
+    RES.append(("fused_leaky_relu f64 gradcheck", bool(ok)))
+    print("gradcheck upfirdn2d / fused_leaky_relu in double:", RES[-2][1], RES[-1][1], flush=True)
+
+
 def t_layout_misc():
     torch.manual_seed(1)
     for (B, C, H, Wd) in [(2, 3, 17, 19), (1, 32, 64, 64), (2, 70, 9, 33)]:
@@ -597,6 +631,26 @@ def t_conv_up9():
                 if feat == "scale":
                     ref = (ref + kw["bias"].cpu().double().view(1, -1, 1, 1)) * 0.7
                 report("nine-product upscale %s vs float64" % name, nchw(outs[1][0]), ref, 3e-5)
+        # a call that carries an option the nine-product kernel does not take (normalise-on-load, residual, PReLU, non-zero padding)
+        # FALLS BACK to the phase-pair / four-phase forms with UP9 left on (round-4 ADVICE: it used to raise) -- bit-identical to the
+        # same call with UP9 off
+        ops.UP9.update(value=True, min_blocks=0, min_fill=0.0)
+        B, ci, co, H, Wd = 2, 64, 128, 30, 30
+        w = g(torch.randn(co, ci, 3, 3) / math.sqrt(ci * 9))
+        x = g(torch.randn(B, H, Wd, ci))
+        plan = ops.ConvPlan(w, kind="convT")
+        assert plan.choose_kernel(H, Wd, 2 * H, 2 * Wd, H, Wd, 2)[0] == "up9"
+        for tag, kw in (("residual", dict(residual=g(torch.randn(B, 2 * H, 2 * Wd, co)), res_after_act=True, act=ops.ACT_LRELU, out_scale=0.7)),
+                        ("in_ss", dict(in_ss=g(torch.rand(B, ci, 2) + 0.5), in_act=ops.ACT_LRELU)),
+                        ("prelu", dict(act=ops.ACT_PRELU, prelu=g(torch.tensor([0.25])))),
+                        ("reflect pad", dict(pad_mode=ops.PAD_REFLECT))):
+            y_on = plan(x, **kw)
+            ops.UP9["value"] = False
+            y_off = ops.ConvPlan(w, kind="convT")(x, **kw)
+            ops.UP9["value"] = True
+            ok = bool(torch.equal(y_on, y_off))
+            RES.append(("upscale with %s and UP9 on falls back to the four-phase forms (bit-identical)" % tag, ok))
+            print("UP9 fallback %-12s %s" % (tag, "ok" if ok else "FAIL"), flush=True)
     finally:
         ops.UP9.update(prev)
 
@@ -1362,7 +1416,7 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     print("device:", torch.cuda.get_device_name(0), flush=True)
     if which in ("ops", "all"):
-        for fn in (t_upfirdn2d, t_fused_act, t_ops_half, t_layout_misc, t_conv, t_conv_variants, t_conv_variants_single_pass, t_half_storage, t_conv_k64, t_conv1x1_stream, t_norm_pool, t_corr, t_guided):
+        for fn in (t_upfirdn2d, t_fused_act, t_ops_half, t_ops_f64, t_layout_misc, t_conv, t_conv_variants, t_conv_variants_single_pass, t_half_storage, t_conv_k64, t_conv1x1_stream, t_norm_pool, t_corr, t_guided):
             print("== " + fn.__name__, flush=True)
             run(fn)
             torch.cuda.synchronize()
@@ -1375,6 +1429,7 @@ def main():
         run(t_guided)
     if which == "opshalf":
         run(t_ops_half)
+        run(t_ops_f64)
     if which == "up9":
         run(t_conv_up9)
     if which == "k64":

@@ -33,7 +33,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_argument_errors_need_no_gpu():
     from ppst_amd._lib import lib
-    assert lib.ppst_version() >= 1
+    assert lib.ppst_version() == 2          # PPST_ABI_VERSION (include/ppst_hip.h): bumped with the round-4 struct changes
     # unsupported dtype / null pointers / bad sizes are rejected before any launch
     assert lib.ppst_upfirdn2d(None, None, None, 1, 4, 4, 1, 3, 3, 1, 1, 1, 1, 0, 0, 0, 0, 7, None) == -2    # no such dtype
     assert lib.ppst_upfirdn2d(None, None, None, 1, 4, 4, 1, 3, 3, 1, 1, 1, 1, 0, 0, 0, 0, 1, None) == -3    # PPST_F16: valid, null data

@@ -38,7 +38,7 @@ def test_native_library_is_loaded():
     assert "libppst_hip.so" in maps
 
 
-@pytest.mark.parametrize("fn", ["t_upfirdn2d", "t_fused_act", "t_ops_half", "t_layout_misc", "t_conv", "t_conv_wino", "t_conv_dual", "t_conv_up9", "t_conv_variants", "t_conv_variants_single_pass", "t_half_storage", "t_conv_k64", "t_conv1x1_stream", "t_norm_pool", "t_corr", "t_guided"])
+@pytest.mark.parametrize("fn", ["t_upfirdn2d", "t_fused_act", "t_ops_half", "t_ops_f64", "t_layout_misc", "t_conv", "t_conv_wino", "t_conv_dual", "t_conv_up9", "t_conv_variants", "t_conv_variants_single_pass", "t_half_storage", "t_conv_k64", "t_conv1x1_stream", "t_norm_pool", "t_corr", "t_guided"])
 def test_kernels_vs_oracle(fn):
     _run(fn)
 
@@ -329,6 +329,38 @@ def test_full_size_properties():
     assert (z.var((1, 2), unbiased=False) - 1).abs().max().item() < 1e-3
 
 
+def test_grid_8x8_at_size_properties():
+    """BASELINE configs[2] at the shape it names (content_style_grid_generation_evaluator.py:81-93: 8 x 8 folder at 512^2, 64 pairs,
+    guided filter on) -- properties only, no oracle at this size: every pair is written exactly once across the ranks, the run
+    sharded over 2 simulated ranks (image passes -> exchange -> pair passes) is BIT-EQUAL to one rank's, the filtered outputs are
+    finite and inside [-1, 1] (the filter's output is a uint8 image mapped back), and distinct styles give distinct images."""
+    from ppst_amd import weights as W
+    from ppst_amd.evaluation import grid_exchange, grid_image_pass, grid_pair_pass, swapping_grid
+    from ppst_amd.ppst_model import create_model
+    sd = W.make_state_dict(1, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
+    m = create_model(state_dict=sd, device="cuda")
+    m.noise = {k: v.cuda() for k, v in W.make_noise(3, 1).items()}      # one fixed row = every batch row
+    cs, ss_ = W.synthetic_images(21, 8).cuda(), W.synthetic_images(22, 8).cuda()
+    with torch.no_grad():
+        one = swapping_grid(m, cs, ss_, rank=0, world=1, smooth=True)
+        assert sorted(one) == [(i, j) for i in range(8) for j in range(8)]
+        outs = [grid_image_pass(m, cs, ss_, r, 2) for r in range(2)]
+        tc, ts = grid_exchange(None, None, 8, 8, 2, gathered=outs)
+        got, owners = {}, {}
+        for rank in range(2):
+            part = grid_pair_pass(m, cs, ss_, tc, ts, rank, 2, smooth=True)
+            for k_ in part:
+                assert k_ not in owners, "pair %s written by ranks %d and %d" % (k_, owners[k_], rank)
+                owners[k_] = rank
+            got.update(part)
+    assert sorted(got) == sorted(one) and sorted(owners.values()).count(0) == 32
+    for k_, v in one.items():
+        assert v.shape == (3, 512, 512)
+        assert torch.isfinite(v).all() and v.min().item() >= -1.0 and v.max().item() <= 1.0
+        assert torch.equal(v, got[k_]), "pair %s: 2 simulated ranks differ from 1 rank" % (k_,)
+    assert not torch.equal(one[(0, 0)], one[(0, 1)]) and not torch.equal(one[(0, 0)], one[(1, 0)])
+
+
 def test_edge_cases():
     from ppst_amd import ops
     from ppst_amd.stylegan2_op import fused_leaky_relu, upfirdn2d
@@ -345,12 +377,40 @@ def test_edge_cases():
     from ppst_amd import glue
     with pytest.raises(AssertionError):
         glue.swap(torch.zeros(3, 2, device=dev))
-    # float64 / integer input is rejected (the library takes float32, float16, bfloat16: t_ops_half), half input is not
-    with pytest.raises(RuntimeError):
-        upfirdn2d(torch.zeros(1, 1, 8, 8, device=dev, dtype=torch.float64), k)
+    # integer input is rejected; the library takes float32, float16, bfloat16 (t_ops_half) and float64 (t_ops_f64) like the
+    # reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF
     with pytest.raises(RuntimeError):
         upfirdn2d(torch.zeros(1, 1, 8, 8, device=dev, dtype=torch.int32), k)
     assert upfirdn2d(torch.zeros(1, 1, 8, 8, device=dev, dtype=torch.float16), k).dtype == torch.float16
+    assert upfirdn2d(torch.zeros(1, 1, 8, 8, device=dev, dtype=torch.float64), k).dtype == torch.float64
+    assert fused_leaky_relu(torch.zeros(2, 4, device=dev, dtype=torch.float64), torch.zeros(4, device=dev)).dtype == torch.float64
+
+
+def test_get_visuals_for_snapshot_intended_semantics():
+    """models/ppst_model.py:237-248 (the reference's body calls an undefined self.E; the intended semantics are restated in
+    ppst_amd/ppst_model.py): rec == decode(encode(real)), mix == decode(sp, swap(gl)), layout = 3-component PCA picture of the spatial
+    code at the image size in [-1, 1], at most 4 images while training."""
+    from ppst_amd import glue
+    from ppst_amd import weights as W
+    from ppst_amd.ppst_model import Options, create_model
+    sd = W.make_state_dict(3, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
+    m = create_model(Options(isTrain=True), state_dict=sd, device="cuda")
+    m.noise = {k: v.cuda() for k, v in W.make_noise(5, 1, S=16).items()}      # one fixed row = every batch row
+    real = W.synthetic_images(9, 6, size=128).cuda()
+    with torch.no_grad():
+        vis = m(real, command="get_visuals_for_snapshot")
+        assert set(vis) == {"real", "layout", "rec", "mix"}
+        assert vis["real"].shape[0] == 4 and torch.equal(vis["real"], real[:4])
+        sp, gl = m(real[:4], command="encode")
+        rec = m(sp, gl, command="decode")
+        mix = m(sp, [glue.swap(g) for g in gl], command="decode")
+    assert torch.equal(vis["rec"], rec) and torch.equal(vis["mix"], mix)
+    lay = vis["layout"]
+    assert lay.shape == (4, 3, 128, 128) and lay.is_cuda and torch.isfinite(lay).all()
+    assert -1.0 - 1e-5 <= lay.min().item() and lay.max().item() <= 1.0 + 1e-5 and lay.max().item() - lay.min().item() > 0.5
+    m.opt.isTrain = False
+    with torch.no_grad():
+        assert m(real, command="get_visuals_for_snapshot")["rec"].shape[0] == 6
 
 
 def test_corrm_match_kernel_vs_reference_golden():

@@ -63,6 +63,23 @@ def test_fused_leaky_relu_golden(golden_dir):
     assert torch.allclose(y2, torch.from_numpy(g["flrelu2.y"]), rtol=1e-6, atol=1e-7)
 
 
+def test_native_ops_double_golden(golden_dir):
+    """ops_f64.npz: the reference's own upfirdn2d / fused_leaky_relu on float64 tensors (oracle/gen_golden.py:gen_ops_f64)."""
+    g = np.load(os.path.join(golden_dir, "ops_f64.npz"))
+    for i in range(int(g["upfirdn2d.n"])):
+        x, k = torch.from_numpy(g["upfirdn2d.%d.x" % i]), torch.from_numpy(g["upfirdn2d.%d.k" % i])
+        u, d, p0, p1 = [int(v) for v in g["upfirdn2d.%d.cfg" % i]]
+        y = O.upfirdn2d(x, k, up=u, down=d, pad=(p0, p1))
+        ref = torch.from_numpy(g["upfirdn2d.%d.y" % i])
+        assert y.dtype == torch.float64 and y.shape == ref.shape, i
+        assert torch.allclose(y, ref, rtol=1e-13, atol=1e-14), (i, (y - ref).abs().max())
+    y = O.fused_leaky_relu(torch.from_numpy(g["flrelu.x"]), torch.from_numpy(g["flrelu.b"]))
+    assert torch.allclose(y, torch.from_numpy(g["flrelu.y"]), rtol=1e-14, atol=1e-15)
+    gx, gb = O.fused_leaky_relu_grad(torch.from_numpy(g["flrelu.g"]), y)
+    assert torch.allclose(gx, torch.from_numpy(g["flrelu.gx"]), rtol=1e-14, atol=1e-15)
+    assert torch.allclose(gb, torch.from_numpy(g["flrelu.gb"]), rtol=1e-13, atol=1e-13)
+
+
 def test_exact_glue_golden(golden_dir):
     """Integer / exact items must be bit-identical."""
     g = np.load(os.path.join(golden_dir, "glue.npz"))
