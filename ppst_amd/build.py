@@ -69,7 +69,9 @@ def _mode_changed():
 
 
 def needs_build():
-    return _mode_changed() or _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
+    # (objects too: a source edited WHILE a build ran is older than the library that build linked, but newer than its own object)
+    return (_mode_changed() or _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS) or
+            any(_stale(os.path.join(OBJ, s.replace(".hip", ".o")), [os.path.join(CSRC, s)]) for s in SOURCES if os.path.isdir(OBJ)))
 
 
 def build(force=False, verbose=True):

@@ -200,14 +200,23 @@ def t_ops_f64():
         y = upfirdn2d(g(x), g(k), up=u, down=d, pad=(p0, p1))
         RES.append(("upfirdn2d f64 case %d dtype" % i, y.dtype == torch.float64))
         report("upfirdn2d f64 case %d (up %d down %d pad %d,%d)" % (i, u, d, p0, p1), y, torch.from_numpy(gold["upfirdn2d.%d.y" % i]), 1e-13)
+    # slope and scale cross the op boundary as C floats (fused_bias_act.cpp:4-20: ``float alpha, float scale``, cast to scalar_t in
+    # the kernel, fused_bias_act_kernel.cu:19-49) -- here as in the reference's CUDA op; the golden comes from the reference's
+    # Python fallback, which multiplies by the Python doubles 0.2 and 2 ** 0.5: the two differ by float(2 ** 0.5) / 2 ** 0.5 - 1 =
+    # 1.7e-8.  Bar against the golden: 3e-8; against the same formula with the float-rounded constants: 1e-15 (double arithmetic).
     x = g(torch.from_numpy(gold["flrelu.x"])).requires_grad_(True)
     b = g(torch.from_numpy(gold["flrelu.b"])).requires_grad_(True)
     y = fused_leaky_relu(x, b)
     RES.append(("fused_leaky_relu f64 dtype", y.dtype == torch.float64))
-    report("fused_leaky_relu f64 forward", y, torch.from_numpy(gold["flrelu.y"]), 1e-13)
-    gx, gb = torch.autograd.grad(y, [x, b], g(torch.from_numpy(gold["flrelu.g"])))
-    report("fused_leaky_relu f64 grad_x", gx, torch.from_numpy(gold["flrelu.gx"]), 1e-13)
-    report("fused_leaky_relu f64 grad_b", gb, torch.from_numpy(gold["flrelu.gb"]), 1e-13)
+    report("fused_leaky_relu f64 forward vs the reference fallback", y, torch.from_numpy(gold["flrelu.y"]), 3e-8)
+    sl, sc = float(np.float32(0.2)), float(np.float32(2 ** 0.5))
+    t = torch.from_numpy(gold["flrelu.x"]) + torch.from_numpy(gold["flrelu.b"]).view(1, -1, 1, 1)
+    report("fused_leaky_relu f64 forward, float-rounded slope / scale", y, torch.where(t > 0, t, t * sl) * sc, 1e-15)
+    gy = torch.from_numpy(gold["flrelu.g"])
+    gx, gb = torch.autograd.grad(y, [x, b], g(gy))
+    report("fused_leaky_relu f64 grad_x vs the reference fallback", gx, torch.from_numpy(gold["flrelu.gx"]), 3e-8)
+    report("fused_leaky_relu f64 grad_b vs the reference fallback", gb, torch.from_numpy(gold["flrelu.gb"]), 3e-8)
+    report("fused_leaky_relu f64 grad_x, float-rounded slope / scale", gx, torch.where(t > 0, gy, gy * sl) * sc, 1e-15)
     torch.manual_seed(5)
     xs = g(torch.randn(1, 2, 6, 5, dtype=torch.float64)).requires_grad_(True)
     ks = g(torch.randn(3, 3, dtype=torch.float64))
