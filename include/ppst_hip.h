@@ -301,6 +301,13 @@ typedef struct ppst_conv_args {
                                     32-63 where it keeps its lo planes) -- half the steps per MFMA of the 32-channel single-pass
                                     form.  Outputs equal that form's up to fp32 summation order (the two halves of a chunk are
                                     accumulated alternately instead of chunk after chunk). */
+  const void* in_res;            /* round 5, variant 4 with in_scale_shift only: a second input tensor of the conv's own extent and
+                                    channel count, added BEFORE in_act -- the input is read as in_act(a*x + s + in_res): the resnet
+                                    merge of generator.py:28-31 (prelu(IN(conv2) + x)) applied while the 1x1 conv that is its only
+                                    consumer loads its fragments, so the merged tensor is never written (layert1 -> layert1.1).
+                                    Same fp32 operations in the same order as ppst_affine_act(res_before_act) followed by the plain
+                                    conv (the test holds the pair to 2e-6 of each other).  fp32 storage, precision 0; NULL: none */
+  int32_t in_res_ld;             /* pixel stride of in_res in elements */
 } ppst_conv_args;
 
 int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream);
@@ -341,6 +348,13 @@ int ppst_conv1x1_small_cout(const void* x, const void* w, const void* bias, void
                             int64_t npix, int cin, int cout, float wscale, void* stream);
 int ppst_conv1x1_small_cout_st(const void* x, const void* w, const void* bias, void* y,
                                int64_t npix, int cin, int cout, float wscale, int x_st /* y stays fp32 */, void* stream);
+/* ToRGB's 1x1 conv (stylegan2_layers.py:477-495, Cout = 3) with the merge pass of the block in front of it applied ON LOAD (round 5):
+ * the input is read as (a[b][c] * x + s[b][c] + bilinear_x2(res)) * out_scale -- (IN + StyleMod of conv2 + the x2-upsampled skip) /
+ * sqrt2 of the last UpsamplingResnetBlock (generator.py:63-78), whose only consumer in the image pass is this conv.
+ * x [B][H][W][cin] dense (storage type x_st), scale_shift [B][cin][2], res [B][H/2][W/2][res_ld] (type x_st) or NULL,
+ * w [3][cin], bias [3] or NULL -> y [B][H][W][3] fp32.  Equal to ppst_affine_act (res_up2) followed by ppst_conv1x1_small_cout. */
+int ppst_torgb_apply_st(const void* x, const void* scale_shift, const void* res, int res_ld, float out_scale, const void* w,
+                        const void* bias, void* y, int B, int H, int W, int cin, float wscale, int x_st, void* stream);
 
 /* ------------------------------------------- instance norm / style mod ---
  * nn.InstanceNorm2d (eps 1e-5, biased var) + StyleMod (stylegan2_layers.py:361-374,

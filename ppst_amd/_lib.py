@@ -53,6 +53,7 @@ class ConvArgs(ctypes.Structure):
         ("act", i32), ("precision", i32), ("res_ld", i32), ("tile_h", i32), ("tile_w", i32),
         ("halo", i32), ("bn", i32), ("in_scale_shift", vp), ("in_prelu", vp), ("in_c", i32), ("in_act", i32),
         ("flop_steps", i32), ("tile_rows", i32), ("a_slots", i32), ("early_a", i32), ("variant", i32), ("in_presplit", i32), ("dual_b", i32), ("io_st", i32), ("k64", i32),
+        ("in_res", vp), ("in_res_ld", i32),
     ]
 
 
@@ -84,6 +85,7 @@ _SIGS = {
     "ppst_conv1x1_small_cin_st": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, i32, vp]),
     "ppst_conv1x1_small_cout": (i32, [vp, vp, vp, vp, i64, i32, i32, f32, vp]),
     "ppst_conv1x1_small_cout_st": (i32, [vp, vp, vp, vp, i64, i32, i32, f32, i32, vp]),
+    "ppst_torgb_apply_st": (i32, [vp, vp, vp, i32, f32, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "ppst_in_stats": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(i32), vp]),
     "ppst_in_finalize": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, f64, f32, vp]),
     "ppst_affine_act": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, f32, i32, vp]),

@@ -37,6 +37,8 @@ struct C1Args {
   const float* in_ss;
   const float* in_prelu;
   int in_c, in_act;
+  const float* in_res;           // INSS == 2: added to a*x + s before in_act (ppst_conv_args.in_res); pixel stride in_res_ld
+  int in_res_ld;
 };
 
 #define C1_GROUP 8          // step blobs resident in LDS at a time
@@ -232,7 +234,9 @@ __device__ __forceinline__ void c1_epilogue(const C1Args& a, f32x4 (&acc)[MT][NT
 //               HBM-bound layers have to spare, and removes the tile's serial prologue (load -> split -> LDS -> barrier) and
 //               the per-step barriers that left these layers at 0.10-0.25 of the MFMA ceiling.
 // NT_: 16-channel tiles per wave (2 when Cout <= 32).
-template <bool INSS, bool TAPS = false, int NT_ = 4, int PREC = 0, int IOS = PPST_ST_F32>
+// INSS: 0 input as stored; 1 normalise-on-load in_act(a*x + s); 2 (1x1 form, fp32 storage) in_act(a*x + s + in_res): the resnet merge
+// of the producer applied on load (its tensor is never written) -- the same fp32 operations in the same order as ppst_affine_act.
+template <int INSS, bool TAPS = false, int NT_ = 4, int PREC = 0, int IOS = PPST_ST_F32>
 __global__ __launch_bounds__(512, 4) void conv1x1_stream_kernel(C1Args a) {
   constexpr int MT = 2, NT = NT_;
   constexpr bool X3 = PREC == 0;
@@ -290,6 +294,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_stream_kernel(C1Args a) {
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   float4 raw[MT][2], ss[4];
+  float4 rres[INSS == 2 ? MT : 1][2];
   auto a_load = [&](int4 d) {
     const int chan = d.x;
     if (TAPS) {
@@ -310,6 +315,12 @@ __global__ __launch_bounds__(512, 4) void conv1x1_stream_kernel(C1Args a) {
       const float4* p = (const float4*)(xb + (aoff[mt] + chan) * ES);
       raw[mt][0] = p[0];                                  // (half storage: the lane's 8 channels are these 16 bytes)
       if (IOS == PPST_ST_F32) raw[mt][1] = p[1];
+      if (INSS == 2) {
+        const int pp = pbase + mt * 16 + r16;
+        const float4* q = (const float4*)(a.in_res + ((int64_t)b * a.hw + (pok[mt] ? pp : 0)) * a.in_res_ld + g * 8 + chan);
+        rres[mt][0] = q[0];
+        rres[mt][1] = q[1];
+      }
     }
     if (INSS) {
       const float4* q = (const float4*)(a.in_ss + ((int64_t)b * a.in_c + chan + g * 8) * 2);
@@ -344,7 +355,14 @@ __global__ __launch_bounds__(512, 4) void conv1x1_stream_kernel(C1Args a) {
           const float sc[8] = {ss[0].x, ss[0].z, ss[1].x, ss[1].z, ss[2].x, ss[2].z, ss[3].x, ss[3].z};
           const float sh[8] = {ss[0].y, ss[0].w, ss[1].y, ss[1].w, ss[2].y, ss[2].w, ss[3].y, ss[3].w};
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = in_act(sc[j] * v[j] + sh[j]);
+          for (int j = 0; j < 8; ++j) {
+            float t = sc[j] * v[j] + sh[j];
+            if (INSS == 2) {
+              const float4 r4 = rres[mt][j >> 2];
+              t += (j & 3) == 0 ? r4.x : (j & 3) == 1 ? r4.y : (j & 3) == 2 ? r4.z : r4.w;
+            }
+            v[j] = in_act(t);
+          }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -529,6 +547,7 @@ __global__ __launch_bounds__(512, NT_ > 4 ? 2 : 4) void conv3x3_direct_kernel(C1
 
 // Entry used by ppst_conv2d_mfma (conv_mfma.hip) for variant 4.  tiles = statistics rows per image the caller allocated
 // (ppst_conv_tiles); block i of an image covers pixels [256 i, 256 i + 256) -- rows past the last pixel come out zero.
+static inline int64_t blocks_of(const ppst_conv_args* a, int tiles, int n_tiles) { return (int64_t)a->B * tiles * n_tiles; }
 int ppst_conv1x1_stream_launch(const ppst_conv_args* a, int n_tiles, int tiles, hipStream_t st) {
   C1Args k;
   k.x = (const float*)a->x; k.wpack = (const unsigned char*)a->wpack; k.steps = (const int4*)a->steps; k.y = (float*)a->y;
@@ -538,13 +557,18 @@ int ppst_conv1x1_stream_launch(const ppst_conv_args* a, int n_tiles, int tiles, 
   k.B = a->B; k.hw = a->out_h * a->out_w; k.in_ld = a->in_ld; k.out_ld = a->out_ld; k.cout = a->cout; k.nsteps = a->nsteps;
   k.act = a->act; k.res_ld = a->res_ld; k.n_tiles = n_tiles; k.tiles = tiles;
   k.in_ss = (const float*)a->in_scale_shift; k.in_prelu = (const float*)a->in_prelu; k.in_c = a->in_c; k.in_act = a->in_act;
+  k.in_res = (const float*)a->in_res; k.in_res_ld = a->in_res_ld;
   if ((int64_t)tiles * 256 < k.hw) return PPST_EINVAL;
+  if (k.in_res) {          // (ppst_conv2d_mfma has checked: in_scale_shift given, precision 0, fp32 storage)
+    PPST_LAUNCH((conv1x1_stream_kernel<2, false, 4, 0, PPST_ST_F32>), dim3((unsigned)blocks_of(a, tiles, n_tiles)), dim3(512), 0, st, k);
+    return PPST_LAUNCH_CHECK();
+  }
   const int64_t blocks = (int64_t)a->B * tiles * n_tiles;
   if (blocks > 0x7fffffff) return PPST_EINVAL;
 #define LS(PREC_, IOS_)                                                                                               \
   do {                                                                                                                \
-    if (k.in_ss) PPST_LAUNCH((conv1x1_stream_kernel<true, false, 4, PREC_, IOS_>), dim3((unsigned)blocks), dim3(512), 0, st, k);   \
-    else PPST_LAUNCH((conv1x1_stream_kernel<false, false, 4, PREC_, IOS_>), dim3((unsigned)blocks), dim3(512), 0, st, k);          \
+    if (k.in_ss) PPST_LAUNCH((conv1x1_stream_kernel<1, false, 4, PREC_, IOS_>), dim3((unsigned)blocks), dim3(512), 0, st, k);   \
+    else PPST_LAUNCH((conv1x1_stream_kernel<0, false, 4, PREC_, IOS_>), dim3((unsigned)blocks), dim3(512), 0, st, k);          \
   } while (0)
   if (a->precision == 1) { if (a->io_st) LS(1, PPST_ST_BF16); else LS(1, PPST_ST_F32); }
   else if (a->precision == 3) { if (a->io_st) LS(3, PPST_ST_F16); else LS(3, PPST_ST_F32); }
@@ -572,7 +596,7 @@ int ppst_conv_direct_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, i
     if (nt2) PPST_LAUNCH((conv1x1_stream_kernel<INSS_, true, 2, PREC_, IOS_>), dim3((unsigned)blocks), dim3(512), 0, st, k);       \
     else PPST_LAUNCH((conv1x1_stream_kernel<INSS_, true, 4, PREC_, IOS_>), dim3((unsigned)blocks), dim3(512), 0, st, k);           \
   } while (0)
-#define LDP(PREC_, IOS_) do { if (k.in_ss) LD(true, PREC_, IOS_); else LD(false, PREC_, IOS_); } while (0)
+#define LDP(PREC_, IOS_) do { if (k.in_ss) LD(1, PREC_, IOS_); else LD(0, PREC_, IOS_); } while (0)
   if (a->precision == 1) { if (a->io_st) LDP(1, PPST_ST_BF16); else LDP(1, PPST_ST_F32); }
   else if (a->precision == 3) { if (a->io_st) LDP(3, PPST_ST_F16); else LDP(3, PPST_ST_F32); }
   else LDP(0, PPST_ST_F32);

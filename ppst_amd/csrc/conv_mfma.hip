@@ -1084,6 +1084,9 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       (a->variant == 4 && ((a->precision != 0 && a->precision != 1 && a->precision != 3) || a->bn != 64 || a->halo != 0 || a->n_groups != 1 || a->out_sy != 1 || a->out_sx != 1 ||
                            a->in_off_y != 0 || a->in_off_x != 0 || a->tile_h != a->out_h || a->tile_w != a->out_w ||
                            a->in_h != a->out_h || a->in_w != a->out_w)) ||
+      // in_res: the 1x1 streaming kernel only, beside a normalise-on-load table, fp32-class mode
+      (a->in_res && (a->variant != 4 || !a->in_scale_shift || a->precision != 0 || a->io_st || a->in_res_ld < a->in_c || a->in_res_ld % 4 ||
+                     ((uintptr_t)a->in_res % 16))) ||
       // variant 5 = the direct form of the same kernel for thin layers with taps (one group, unit output stride)
       // (6: its register-reuse form for plain 3x3 stride-1 tables: the CALLER promises the (chunk, dy, dx) step order)
       ((a->variant == 5 || a->variant == 6) && ((a->precision != 0 && a->precision != 1 && a->precision != 3) ||

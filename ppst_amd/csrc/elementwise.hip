@@ -979,6 +979,96 @@ extern "C" int ppst_conv1x1_small_cout(const void* x, const void* w, const void*
   return ppst_conv1x1_small_cout_st(x, w, bias, y, npix, cin, cout, wscale, PPST_ST_F32, stream);
 }
 
+
+// ToRGB's 1x1 conv (Cout = 3) with the producer's merge pass applied ON LOAD (round 5): the input is read as
+//   x_eff = (a[b][c] * x + s[b][c] + bilinear_up2(res)) * out_scale
+// -- the (IN + StyleMod of conv2 + x2-upsampled skip) / sqrt2 of the last UpsamplingResnetBlock (generator.py:63-78), whose only
+// consumer in the image pass is this conv: the 128-channel 512^2 tensor is neither written nor read back.  Same lane / butterfly
+// scheme as conv1x1_cout3_kernel; the apply arithmetic is affine_act_kernel's, in its order.
+template <int XS = PPST_ST_F32>
+__global__ __launch_bounds__(256) void conv1x1_cout3_apply_kernel(const void* __restrict__ x, const float* __restrict__ ss,
+                                                                  const void* __restrict__ res, int res_ld, float out_scale,
+                                                                  const float* __restrict__ w, const float* __restrict__ bias,
+                                                                  float* __restrict__ y, int64_t npix, int H, int W, int cin, float wscale,
+                                                                  FastDiv d_hw, FastDiv d_w) {
+  const int hl = threadIdx.x & 31;
+  const int64_t half_id = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
+  const int64_t nhalf = ((int64_t)gridDim.x * 256) >> 5;
+  const int b4 = (hl >> 4) & 1, b3 = (hl >> 3) & 1, b2 = (hl >> 2) & 1;
+  const unsigned hw = (unsigned)H * (unsigned)W;
+  for (int64_t p0 = half_id * 8; p0 < npix; p0 += nhalf * 8) {
+    float v[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) v[i] = 0.f;
+    for (int c = hl * 4; c < cin; c += 128) {
+      const float4 w0 = *(const float4*)(w + c), w1 = *(const float4*)(w + (int64_t)cin + c), w2 = *(const float4*)(w + 2 * (int64_t)cin + c);
+      float4 xv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int64_t p = p0 + k < npix ? p0 + k : npix - 1;
+        unsigned pix, oxu;
+        const int b = (int)fd_divmod((unsigned)p, d_hw, pix);
+        const int oy = (int)fd_divmod(pix, d_w, oxu);
+        const float4 xr = st_ld4<XS>(x, p * cin + c);
+        const float4* q = (const float4*)(ss + ((int64_t)b * cin + c) * 2);
+        const float4 q0 = q[0], q1 = q[1];
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (res) r = res_up2_sample<XS>(res, b, oy, (int)oxu, H, W, res_ld, c);
+        float t0 = q0.x * xr.x + q0.y, t1 = q0.z * xr.y + q0.w, t2 = q1.x * xr.z + q1.y, t3 = q1.z * xr.w + q1.w;
+        t0 += r.x; t1 += r.y; t2 += r.z; t3 += r.w;
+        xv[k] = make_float4(t0 * out_scale, t1 * out_scale, t2 * out_scale, t3 * out_scale);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[k * 3 + 0] += xv[k].x * w0.x + xv[k].y * w0.y + xv[k].z * w0.z + xv[k].w * w0.w;
+        v[k * 3 + 1] += xv[k].x * w1.x + xv[k].y * w1.y + xv[k].z * w1.z + xv[k].w * w1.w;
+        v[k * 3 + 2] += xv[k].x * w2.x + xv[k].y * w2.y + xv[k].z * w2.z + xv[k].w * w2.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const float keep = b4 ? v[12 + i] : v[i], send = b4 ? v[i] : v[12 + i];
+      v[i] = keep + __shfl_xor(send, 16, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const float keep = b3 ? v[6 + i] : v[i], send = b3 ? v[i] : v[6 + i];
+      v[i] = keep + __shfl_xor(send, 8, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float keep = b2 ? v[3 + i] : v[i], send = b2 ? v[i] : v[3 + i];
+      v[i] = keep + __shfl_xor(send, 4, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      v[i] += __shfl_xor(v[i], 2, 64);
+      v[i] += __shfl_xor(v[i], 1, 64);
+    }
+    const int k = b4 * 4 + b3 * 2 + b2, j = hl & 3;
+    if (j < 3 && p0 + k < npix) {
+      const float r = j == 0 ? v[0] : (j == 1 ? v[1] : v[2]);
+      y[(p0 + k) * 3 + j] = r * wscale + (bias ? bias[j] : 0.f);
+    }
+  }
+}
+// x [B][H][W][cin] (storage x_st, dense), scale_shift [B][cin][2], res [B][H/2][W/2][res_ld] or NULL (same storage type),
+// w [3][cin], bias [3] or NULL -> y [B][H][W][3] fp32
+extern "C" int ppst_torgb_apply_st(const void* x, const void* scale_shift, const void* res, int res_ld, float out_scale, const void* w,
+                                   const void* bias, void* y, int B, int H, int W, int cin, float wscale, int x_st, void* stream) {
+  if ((unsigned)x_st > 2u) return PPST_EINVAL;
+  if (B < 0 || H <= 0 || W <= 0 || cin <= 0 || cin % 4 || (res && (H % 2 || W % 2 || res_ld < cin || res_ld % 4))) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !scale_shift || !w || !y) return PPST_ENULL;
+  const int64_t npix = (int64_t)B * H * W;
+  if (npix > PPST_IDX32_MAX) return PPST_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)res) % (x_st ? 8 : 16) || ((uintptr_t)w | (uintptr_t)scale_shift) % 16) return PPST_EINVAL;
+  PPST_ST_SWITCH(x_st, PPST_LAUNCH(conv1x1_cout3_apply_kernel<ST_>, dim3(grid_for(cdiv64(npix, 8) * 32)), dim3(256), 0, as_stream(stream), x,
+                                   (const float*)scale_shift, res, res_ld, out_scale, (const float*)w, (const float*)bias, (float*)y, npix,
+                                   H, W, cin, wscale, make_fastdiv((unsigned)H * (unsigned)W), make_fastdiv((unsigned)W)));
+  return PPST_LAUNCH_CHECK();
+}
+
 // --------------------------------------------------------------- misc glue --
 __global__ __launch_bounds__(256) void lerp_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
                                                    int64_t n, float r) {

@@ -127,13 +127,28 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
             return None
         return ops.affine_act(y, ss, act=ops.ACT_PRELU, prelu=self.p(p + "8.weight"), out=out)
 
-    def _residual_block(self, x, p):
+    def _residual_block(self, x, p, defer=False):
+        """generator.py:10-32.  defer=True: returns (conv2 output, its (a, s), x, slope) instead of running the merge pass
+        prelu(IN(conv2) + x) -- the caller's 1x1 conv applies it while it loads (ConvPlan in_res)."""
         B, H, W, C = x.shape
         a = self.p(p + "prelu.weight")
         y, st = self.plan(p + "conv1.weight")(x, bias=self.p(p + "conv1.bias"), stats=True, pad_mode=ops.PAD_REPLICATE)
         y, st = self.plan(p + "conv2.weight")(y, bias=self.p(p + "conv2.bias"), stats=True, pad_mode=ops.PAD_REPLICATE,
                                               in_ss=ops.in_finalize(st, H * W), in_act=ops.ACT_PRELU, in_prelu=a)
-        return ops.affine_act(y, ops.in_finalize(st, H * W), res=x, res_before_act=True, act=ops.ACT_PRELU, prelu=a)
+        ss = ops.in_finalize(st, H * W)
+        if defer:
+            return y, ss, x, a
+        return ops.affine_act(y, ss, res=x, res_before_act=True, act=ops.ACT_PRELU, prelu=a)
+
+    def _feat1_tail(self, feat1):
+        """layert1 = ResidualBlock(256) + Conv2d(256, 64, 1) (generator.py:235-238).  The block's merged output has ONE consumer,
+        the 1x1 conv: in the fp32-class mode that conv applies the merge while it loads its fragments (round 5: the 2-GB tensor of
+        the batch-16 feature pass is neither written nor read back; ops.FUSE_TAIL)."""
+        plan = self.plan("layert1.1.weight")
+        if ops.FUSE_TAIL["value"] and feat1.dtype == torch.float32 and plan.takes_in_res(feat1.shape[1], feat1.shape[2]):
+            y, ss, x, a = self._residual_block(feat1, "layert1.0.", defer=True)
+            return plan(y, bias=self.p("layert1.1.bias"), in_ss=ss, in_act=ops.ACT_PRELU, in_prelu=a, in_res=x)
+        return plan(self._residual_block(feat1, "layert1.0."), bias=self.p("layert1.1.bias"))
 
     def make_noise(self, B, S, device):
         """the fourteen N(0,1) planes NoiseInjection draws in one pass (stylegan2_layers.py:388-390), from ONE torch.randn."""
@@ -173,7 +188,7 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
                                  out_stats=want)
             if want:
                 x, xst = x
-        feat = feat1 = None
+        feat = feat1 = last_merge = None
         if extract_features:
             h, w = x.shape[1], x.shape[2]
             feat = torch.empty((B, h, w, 256), device=x.device, dtype=torch.float32)
@@ -190,6 +205,11 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
             # (the x2 bilinear upsample of the skip is sampled on the fly by the apply pass)
             r, rss = self.styled_conv(x, q + "conv1.", styles, "UpsamplingResBlock%d.conv1" % key, noise, upsample=True, defer=True)
             want = ("rep" if j < 2 else "plain") if extract_features else None
+            if j == len(UP) - 1 and not extract_features and ops.FUSE_TAIL["value"]:
+                # image pass: the last block's merged output is read by ToRGB only -- its 1x1 conv applies the merge on load
+                x, xss = self.styled_conv(r, q + "conv2.", styles, "UpsamplingResBlock%d.conv2" % key, noise, in_ss=rss, defer=True)
+                last_merge = (xss, skip)
+                break
             x = self.styled_conv(r, q + "conv2.", styles, "UpsamplingResBlock%d.conv2" % key, noise, res=skip, out_scale=INV_SQRT2, in_ss=rss,
                                  out_stats=want, res_up2=True)
             if extract_features:
@@ -206,19 +226,20 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
         if extract_features and not want_rgb:
             for i in range(3):
                 feat = self._residual_block(feat, "layert.%d." % i)
-            feat1 = self._residual_block(feat1, "layert1.0.")
-            feat1 = self.plan("layert1.1.weight")(feat1, bias=self.p("layert1.1.bias"))
+            feat1 = self._feat1_tail(feat1)
             return None, as_nchw(feat), as_nchw(feat1)
         wr = self.p("ToRGB.conv.weight")
         brgb = self.cached(("rgbb",), [self.p("ToRGB.conv.bias"), self.p("ToRGB.bias")],
                            lambda: (self.p("ToRGB.conv.bias") + self.p("ToRGB.bias").reshape(-1)).contiguous())
-        y = ops.conv1x1_small_cout(x, wr, brgb, 1.0 / math.sqrt(wr.shape[1]))
+        if last_merge is not None:
+            y = ops.torgb_apply(x, last_merge[0], last_merge[1], INV_SQRT2, wr, brgb, 1.0 / math.sqrt(wr.shape[1]))
+        else:
+            y = ops.conv1x1_small_cout(x, wr, brgb, 1.0 / math.sqrt(wr.shape[1]))
         ss = ops.in_finalize(ops.in_stats(y), y.shape[1] * y.shape[2], style=styles["ToRGB."])
         rgb = ops.nhwc_to_nchw(ops.affine_act(y, ss))
         if not extract_features:
             return rgb
         for i in range(3):
             feat = self._residual_block(feat, "layert.%d." % i)
-        feat1 = self._residual_block(feat1, "layert1.0.")
-        feat1 = self.plan("layert1.1.weight")(feat1, bias=self.p("layert1.1.bias"))
+        feat1 = self._feat1_tail(feat1)
         return rgb, as_nchw(feat), as_nchw(feat1)

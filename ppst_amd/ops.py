@@ -85,6 +85,9 @@ class batch_aware:
 # ``fill`` (batch-aware passes only, i.e. the train step): with fewer than this many blocks in the LAUNCH the choice falls through to
 # the direct kernels' under-filled forms (8-row two-block tiles: twice the blocks)
 WINO = {"value": True, "min_blocks": 16, "fill": 0}
+# round 5: apply passes whose only consumer is a 1x1 conv are applied by that conv while it loads -- layert1's resnet merge by
+# layert1.1 (ConvPlan in_res), the last upsampling block's merge by ToRGB in the image pass (torgb_apply).  Off: the round-4 passes.
+FUSE_TAIL = {"value": os.environ.get("PPST_FUSE_TAIL", "1") != "0"}
 FAT_MIN_BLOCKS = 32         # take the 256-channel tile only when ONE image still gives >= this many blocks (B = 8: one per CU)
 
 
@@ -637,6 +640,11 @@ class ConvPlan:
         self._packs["wino"] = wpack
         return wpack
 
+    def takes_in_res(self, H, W):
+        """True when a call of this plan on an (H, W) input may carry ``in_res`` (the 1x1 streaming kernel in the fp32-class mode)."""
+        return (self.precision == 0 and self.kind == "conv" and self.k == 1 and
+                self.choose_kernel(H, W, H, W, H, W, 1)[0] == 4)
+
     def wino_ok(self, th, tw, oh, ow, H, W, osy):
         # (a call with normalise-on-load and more than 1024 input channels is kept off this kernel in __call__: its LDS copy of
         # the (a, s) table is sized for 32 chunks)
@@ -718,7 +726,7 @@ class ConvPlan:
 
     def __call__(self, x, bias=None, noise=None, noise_weight=0.0, act=ACT_NONE, prelu=None, stats=False,
                  residual=None, out=None, out_scale=1.0, pad_mode=PAD_ZERO, out_hw=None, res_after_act=False,
-                 in_ss=None, in_act=ACT_NONE, in_prelu=None, presplit=False):
+                 in_ss=None, in_act=ACT_NONE, in_prelu=None, presplit=False, in_res=None):
         in_ld = _nhwc_ld(x, "conv input", half_ok=True)
         B, H, W, xc = x.shape
         if x.dtype != torch.float32 and {torch.float16: 3, torch.bfloat16: 1}[x.dtype] != self.precision:
@@ -808,6 +816,12 @@ class ConvPlan:
         _chk(in_ss, "in_ss"); _chk(in_prelu, "in_prelu")
         a.in_scale_shift, a.in_prelu, a.in_act = _p(in_ss), _p(in_prelu), in_act
         a.in_c = in_ss.shape[1] if in_ss is not None else 0
+        if in_res is not None:       # the producer's resnet merge applied on load (ppst_conv_args.in_res): the 1x1 streaming kernel only
+            if variant != 4 or in_ss is None or self.precision != 0 or x.dtype != torch.float32:
+                raise RuntimeError("in_res needs a 1x1 plan on the streaming kernel (ops.STREAM_1X1), in_ss, precision 0 and fp32 storage")
+            if tuple(in_res.shape) != tuple(x.shape):
+                raise RuntimeError("in_res must have the conv input's shape %s, got %s" % (tuple(x.shape), tuple(in_res.shape)))
+            a.in_res, a.in_res_ld = _p(in_res), _nhwc_ld(in_res, "in_res")
         a.flop_steps = self.flop_steps
         a.a_slots = min(3, self.chunks_per_group)
         a.early_a = self.early_a
@@ -1143,6 +1157,28 @@ def conv1x1_small_cout(x, w, bias, wscale):
     w2 = w.detach().reshape(cout, cin).contiguous()
     check(lib.ppst_conv1x1_small_cout_st(_p(x), _p(w2), _p(bias), _p(y), B * H * W, cin, cout, float(wscale), _ST[x.dtype], _stream()),
           "ppst_conv1x1_small_cout")
+    return y
+
+
+def torgb_apply(x, scale_shift, res, out_scale, w, bias, wscale):
+    """ToRGB's 1x1 conv reading (a*x + s + bilinear_x2(res)) * out_scale (ppst_torgb_apply_st): x (B,H,W,C) dense, res (B,H/2,W/2,C)
+    or None (x's storage type) -> (B,H,W,3) fp32."""
+    ld = _nhwc_ld(x, half_ok=True)
+    B, H, W, cin = x.shape
+    if ld != cin or w.shape[0] != 3:
+        raise RuntimeError("torgb_apply needs a dense input and a 3-channel weight")
+    _chk(scale_shift, "scale_shift"); _chk(bias, "bias")
+    res_ld = 0
+    if res is not None:
+        res_ld = _nhwc_ld(res, "res", half_ok=True)
+        if res.dtype != x.dtype or tuple(res.shape) != (B, H // 2, W // 2, cin):
+            raise RuntimeError("torgb_apply: res must be the half-resolution tensor of x's type")
+    if tuple(scale_shift.shape) != (B, cin, 2) or not scale_shift.is_contiguous():
+        raise RuntimeError("torgb_apply: scale_shift must be a contiguous (B, C, 2) table")
+    y = torch.empty((B, H, W, 3), device=x.device, dtype=torch.float32)
+    w2 = w.detach().reshape(3, cin).contiguous()
+    check(lib.ppst_torgb_apply_st(_p(x), _p(scale_shift), _p(res), res_ld, float(out_scale), _p(w2), _p(bias), _p(y), B, H, W, cin,
+                                  float(wscale), _ST[x.dtype], _stream()), "ppst_torgb_apply")
     return y
 
 

@@ -230,6 +230,58 @@ def t_ops_f64():
     print("gradcheck upfirdn2d / fused_leaky_relu in double:", RES[-2][1], RES[-1][1], flush=True)
 
 
+def t_fuse_tail():
+    """Round 5: apply passes folded into their only consumer, a 1x1 conv (ops.FUSE_TAIL).  (1) ConvPlan(in_res): the streaming 1x1
+    kernel reading prelu(a*x + s + res) against ppst_affine_act(res_before_act, PReLU) followed by the plain conv of the same plan;
+    (2) ops.torgb_apply against ppst_affine_act(res_up2) + ppst_conv1x1_small_cout, fp32 and half storage; (3) the generator's
+    image pass and feature pass with the switch on against off.  Bars: 2e-6 (same fp32 operations; only FMA contraction may differ)."""
+    torch.manual_seed(17)
+    for (B, H, Wd, ci, co) in [(2, 64, 64, 256, 64), (1, 37, 29, 64, 64), (3, 16, 48, 128, 192)]:
+        w = g(torch.randn(co, ci, 1, 1) / math.sqrt(ci))
+        x, res = g(torch.randn(B, H, Wd, ci)), g(torch.randn(B, H, Wd, ci))
+        ss = g(torch.rand(B, ci, 2) + 0.5)
+        slope, bias = g(torch.tensor([0.25])), g(torch.randn(co))
+        plan = ops.ConvPlan(w)
+        RES.append(("in_res: %d->%d 1x1 plan takes it" % (ci, co), bool(plan.takes_in_res(H, Wd))))
+        ref = plan(ops.affine_act(x, ss, res=res, res_before_act=True, act=ops.ACT_PRELU, prelu=slope), bias=bias)
+        got = plan(x, bias=bias, in_ss=ss, in_act=ops.ACT_PRELU, in_prelu=slope, in_res=res)
+        report("conv1x1 in_res %s %d->%d vs apply pass + conv" % ((B, H, Wd), ci, co), got, ref, 2e-6)
+        xs = g(torch.randn(B, H, Wd, ci + 32))[..., 16:16 + ci]         # channel-slice views (pixel stride != channels)
+        rs = g(torch.randn(B, H, Wd, ci + 64))[..., 32:32 + ci]
+        ref = plan(ops.affine_act(xs, ss, res=rs, res_before_act=True, act=ops.ACT_LRELU), bias=bias)
+        got = plan(xs, bias=bias, in_ss=ss, in_act=ops.ACT_LRELU, in_res=rs)
+        report("conv1x1 in_res (slice views, lrelu) %d->%d" % (ci, co), got, ref, 2e-6)
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        for (B, H, Wd, C) in [(2, 64, 48, 128), (1, 18, 22, 64)]:
+            y = g(torch.randn(B, H, Wd, C)).to(dt)
+            skip = g(torch.randn(B, H // 2, Wd // 2, C)).to(dt)
+            ss = g(torch.rand(B, C, 2) + 0.5)
+            w, bias = g(torch.randn(3, C, 1, 1)), g(torch.randn(3))
+            ref = ops.conv1x1_small_cout(ops.affine_act(y, ss, res=skip, out_scale=0.7071, res_up2=True, out_dtype=torch.float32), w, bias, 0.1)
+            got = ops.torgb_apply(y, ss, skip, 0.7071, w, bias, 0.1)
+            report("torgb_apply %s %s vs apply pass + ToRGB conv" % (str(dt).split(".")[-1], (B, H, Wd, C)), got, ref, 3e-6)
+            got = ops.torgb_apply(y, ss, None, 1.0, w, bias, 0.1)
+            report("torgb_apply %s no residual" % str(dt).split(".")[-1], got, ops.conv1x1_small_cout(ops.affine_act(y, ss, out_dtype=torch.float32), w, bias, 0.1), 3e-6)
+    from ppst_amd.ppst_model import create_model
+    sd = W.make_state_dict(2, with_D=False, with_nce=False, bias_std=0.1, noise_weight=0.1)
+    m = create_model(state_dict=sd)
+    noise = {k: v.to(dev) for k, v in W.make_noise(4, 2).items()}
+    sp = g(torch.randn(2, 256, 64, 64))
+    gl = [g(torch.randn(2, 2048)) for _ in range(4)]
+    prev = ops.FUSE_TAIL["value"]
+    try:
+        outs = {}
+        for on in (False, True):
+            ops.FUSE_TAIL["value"] = on
+            with torch.no_grad():
+                outs[on] = (m.G(sp, gl, noise=noise), m.G(sp, gl, extract_features=True, noise=noise))
+        report("generator image pass, tail fused vs passes", outs[True][0], outs[False][0], 1e-5)
+        for name, a, b in zip(("rgb", "feat", "feat1"), outs[True][1], outs[False][1]):
+            report("generator feature pass %s, tail fused vs passes" % name, a, b, 1e-5)
+    finally:
+        ops.FUSE_TAIL["value"] = prev
+
+
 def t_layout_misc():
     torch.manual_seed(1)
     for (B, C, H, Wd) in [(2, 3, 17, 19), (1, 32, 64, 64), (2, 70, 9, 33)]:
@@ -1439,6 +1491,8 @@ def main():
     if which == "opshalf":
         run(t_ops_half)
         run(t_ops_f64)
+    if which == "tail":
+        run(t_fuse_tail)
     if which == "up9":
         run(t_conv_up9)
     if which == "k64":
