@@ -567,6 +567,15 @@ int ppst_linear_wgrad(const void* dy, const void* x, void* dw, int B, int N, int
 int64_t ppst_linear_dgrad_ws(int B, int N, int K);
 int ppst_linear_dgrad(const void* dy, const void* w, void* dx, void* ws, int B, int N, int K, float scale,
                       void* stream);
+/* Round 5: the two linear gradients with the passes around them folded in (the E2 projector chains, encoder_col.py:47-93, ran seven
+ * launches per linear and backward).  ppst_linear_wgrad_fused: ``relu_in`` reads x as max(x, 0) (the linear sits behind nn.ReLU);
+ * ``db`` (optional, [N]) receives bscale * sum_b dy[b][n] (written, or added with b_accumulate); K % 4 == 0, 16-byte aligned x / dw.
+ * ppst_linear_dgrad_gate: dx[b][k] = [gate[b][k] > 0] * scale * sum_n dy[b][n] w[n][k] (the ReLU's backward rides on the slice
+ * reduction); ws as ppst_linear_dgrad_ws. */
+int ppst_linear_wgrad_fused(const void* dy, const void* x, void* dw, void* db, int B, int N, int K, float scale, float bscale,
+                            int accumulate, int b_accumulate, int relu_in, void* stream);
+int ppst_linear_dgrad_gate(const void* dy, const void* w, void* dx, void* ws, const void* gate, int B, int N, int K, float scale,
+                           void* stream);
 /* LSGAN (models/networks/loss.py:11-18): loss = weight*mean((p-target)^2), grad = d loss / d p */
 /* torch.nn.L1Loss (mean |a-b|) times weight -> out[0]; ws >= ppst_l1_mean_ws(n) bytes (ppst_model.py:47,183,203). */
 int64_t ppst_l1_mean_ws(int64_t n);

@@ -135,6 +135,8 @@ _SIGS = {
     "ppst_linear_wgrad": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, vp]),
     "ppst_linear_dgrad_ws": (i64, [i32, i32, i32]),
     "ppst_linear_dgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),
+    "ppst_linear_wgrad_fused": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, f32, i32, i32, i32, vp]),
+    "ppst_linear_dgrad_gate": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "ppst_lsgan": (i32, [vp, vp, vp, i32, f32, f32, vp]),
     "ppst_l1_mean_ws": (i64, [i64]),
     "ppst_l1_mean": (i32, [vp, vp, vp, vp, i64, f32, vp]),

@@ -59,6 +59,9 @@ def prelu_bwd(g, y, prelu, scale_shift=None, res=None):
 # one backward -> step, ppst_optimizer.py:73-94) is what the trainers run; ``DIRECT["value"] = False`` restores returned
 # gradients (autograd accumulates them) for code that walks a graph more than once.
 DIRECT = {"value": True}
+# round 5: LinearFn's backward in two or three launches instead of seven (ReLU gates, relu(x) and the bias column sums folded into the
+# two gradient kernels); off while the gate tape records / replays (its gates go through gates.sign_gate)
+FUSE_LINEAR = {"value": True}
 
 
 def _direct(p):
@@ -71,6 +74,12 @@ def _noted(p):
     cb = getattr(p, "_ppst_on_grad", None)
     if cb is not None:
         cb()
+
+
+def _flipped(net, kname):
+    """the blur taps of ``kname`` flipped (the adjoint FIR, upfirdn2d.py:116-121), kept per network: one flip + copy per train step
+    and blur was 69 torch launches"""
+    return net.cached(("flip", kname), [net.p(kname)], lambda: torch.flip(net.p(kname), [0, 1]).contiguous())
 
 
 def _conv_grads(net, wname, kind, scale, pad_mode, x, gpre, need_x, need_w, out_hw=None, dw_out=None, want_bias=False, bias_out=None):
@@ -107,16 +116,21 @@ class ConvFn(Function):
     of EqualizedConv2d (stylegan2_layers.py:312-321)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, noise_w, noise, net, wname, kind, scale, pad_mode, act, noise_w_host=None, bias_params=None):
+    def forward(ctx, x, w, bias, noise_w, noise, net, wname, kind, scale, pad_mode, act, noise_w_host=None, bias_params=None,
+                gate_downstream=False):
         """``bias_params``: leaf parameters whose sum is ``bias`` (StyledConv's three biases, summed by the caller outside the
-        graph): their gradients are written directly, ``bias`` itself is then a constant."""
+        graph): their gradients are written directly, ``bias`` itself is then a constant.
+        ``gate_downstream`` (act LRELU): the ONE consumer of y is an InstanceNormFn built with ``post_gate=True`` whose backward
+        returns the gradient already multiplied by lrelu'(y) (ppst_in_bwd_apply's post gate: StyledConv's order is conv ->
+        activation -> norm) -- this node then takes its upstream as the pre-activation gradient and runs no gate pass."""
         x = _c(x)
         plan = net.plan(wname, kind, scale)
         # the kernel takes the noise weight by value: the caller's cached host copy, or (a stream sync) the tensor itself
         nw = (noise_w_host if noise_w_host is not None else float(noise_w)) if noise_w is not None else 0.0
         y, st = plan(x, bias=bias, noise=(noise if noise_w is not None else None), noise_weight=nw, act=act, pad_mode=pad_mode, stats=True)
-        ctx.save_for_backward(x, y if act != NONE else None, noise if noise_w is not None else None)
+        ctx.save_for_backward(x, y if (act != NONE and not gate_downstream) else None, noise if noise_w is not None else None)
         ctx.cfg = (net, wname, kind, scale, pad_mode, act, bias is not None, noise_w is not None)
+        ctx.gate_downstream = bool(gate_downstream and act == LRELU)
         ctx.refs = (w, bias, noise_w, bias_params)          # leaf parameters (for their flat-gradient views), not saved tensors
         ctx.mark_non_differentiable(st)
         ctx.set_materialize_grads(False)        # no zero tensor is built for the statistics output's (absent) gradient
@@ -128,7 +142,7 @@ class ConvFn(Function):
         net, wname, kind, scale, pad_mode, act, has_b, has_n = ctx.cfg
         w, bias, noise_w, bias_params = ctx.refs
         g = _c(g)
-        gpre = lrelu_bwd(g, y) if act == LRELU else g
+        gpre = lrelu_bwd(g, y) if (act == LRELU and not ctx.gate_downstream) else g
         C = gpre.shape[3]
         db = dnw = None
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -168,12 +182,12 @@ class ConvFn(Function):
                 _noted(bias)
             else:
                 db = v
-        return dx, dw, db, dnw, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dnw, None, None, None, None, None, None, None, None, None, None
 
 
 def conv(x, w, net, wname, bias=None, kind="conv", scale=1.0, pad_mode=Z, act=NONE, noise_w=None, noise=None, stats=False,
-         noise_w_host=None, bias_params=None):
-    y, st = ConvFn.apply(x, w, bias, noise_w, noise, net, wname, kind, scale, pad_mode, act, noise_w_host, bias_params)
+         noise_w_host=None, bias_params=None, gate_downstream=False):
+    y, st = ConvFn.apply(x, w, bias, noise_w, noise, net, wname, kind, scale, pad_mode, act, noise_w_host, bias_params, gate_downstream)
     return (y, st) if stats else y
 
 
@@ -222,7 +236,7 @@ class BlurConvFn(Function):
             d_xb = net.plan(wname, "dgrad_s2d", scale)(gpre, out_hw=bhw)
             k = net.p(kname)
             ks = k.shape[0]
-            kf = torch.flip(k, [0, 1]).contiguous()
+            kf = _flipped(net, kname)
             if pad_mode == Z:   # FIR with the flipped taps and g_pad = (ks-1-p0, ks-1-p1) (upfirdn2d.py:116-121)
                 dx, _ = ops.blur_nhwc(d_xb, kf, ks - 1 - p0, ks - 1 - p1, Z)
             else:               # full correlation onto the padded extent, then the adjoint of the reflection padding
@@ -257,7 +271,7 @@ class BlurDownFn(Function):
         oh, ow = g.shape[1], g.shape[2]
         # UpFirDn2dBackward (upfirdn2d.py:24-60): zero-insert x2, FIR with the flipped taps, g_pad
         gp0 = ks - p0 - 1
-        dx = ops.upfirdn2d_raw(g, torch.flip(k, [0, 1]).contiguous(), 2, 2, 1, 1, gp0, W - 2 * ow + p0, gp0, H - 2 * oh + p0)
+        dx = ops.upfirdn2d_raw(g, _flipped(net, kname), 2, 2, 1, 1, gp0, W - 2 * ow + p0, gp0, H - 2 * oh + p0)
         return dx, None, None, None, None
 
 
@@ -268,8 +282,10 @@ class InstanceNormFn(Function):
     ``st``: tile statistics of y from the producing kernel (None: computed here)."""
 
     @staticmethod
-    def forward(ctx, y, st, style, post_bias, prelu, act, eps, res=None, out_scale=1.0, res_up2=False):
-        """``res`` / ``out_scale`` (act NONE only): (IN(y) + res) * out_scale in the same pass -- the resnet merge
+    def forward(ctx, y, st, style, post_bias, prelu, act, eps, res=None, out_scale=1.0, res_up2=False, post_gate=False):
+        """``post_gate``: y is the OUTPUT of a leaky ReLU (x sqrt2) whose producer (ConvFn with gate_downstream) wants the
+        gradient at its pre-activation: the apply pass of the backward multiplies by lrelu'(y) on its way out (no separate gate pass).
+        ``res`` / ``out_scale`` (act NONE only): (IN(y) + res) * out_scale in the same pass -- the resnet merge
         (skip + res) / sqrt2 of generator.py:47-78 without materialising the normalised branch (bit-identical to
         instance_norm followed by AddScaleFn: the same fp32 operations in the same order).  ``res_up2``: ``res`` is the
         half-resolution skip tensor, sampled bilinearly (x2, align_corners=False) by the pass itself -- the upsampled skip of
@@ -287,6 +303,7 @@ class InstanceNormFn(Function):
             out = ops.affine_act(y, ss, act=act, prelu=prelu)
         ctx.save_for_backward(y, out if act == LRELU else None, mr, style, ss if act == PRELU else None, prelu)
         ctx.act = act
+        ctx.post_gate = bool(post_gate)
         ctx.refs = (post_bias,)
         ctx.out_scale = float(out_scale) if res is not None else None
         ctx.res_low = (res.shape[1], res.shape[2]) if (res is not None and res_up2) else None
@@ -310,7 +327,7 @@ class InstanceNormFn(Function):
         part = ops.dual_stats(g, y, gate)
         want = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         coef, dstyle = ops.in_bwd_finalize(part, H * W, mr, style, want_dstyle=want)
-        dy = ops.in_bwd_apply(g, y, coef, gate=gate) if ctx.needs_input_grad[0] else None
+        dy = ops.in_bwd_apply(g, y, coef, gate=gate, post_gate=ctx.post_gate) if ctx.needs_input_grad[0] else None
         dpb = None
         if ctx.needs_input_grad[3]:
             (post_bias,) = ctx.refs
@@ -318,11 +335,12 @@ class InstanceNormFn(Function):
             dpb = ops.colsum(dstyle[:, C:], out=dst, accumulate=dst is not None)
             if dst is not None:
                 _noted(post_bias); dpb = None
-        return dy, None, (dstyle if ctx.needs_input_grad[2] else None), dpb, dprelu, None, None, dres, None, None
+        return dy, None, (dstyle if ctx.needs_input_grad[2] else None), dpb, dprelu, None, None, dres, None, None, None
 
 
-def instance_norm(y, st=None, style=None, post_bias=None, prelu=None, act=NONE, eps=1e-5, res=None, out_scale=1.0, res_up2=False):
-    return InstanceNormFn.apply(y, st, style, post_bias, prelu, act, eps, res, out_scale, res_up2)
+def instance_norm(y, st=None, style=None, post_bias=None, prelu=None, act=NONE, eps=1e-5, res=None, out_scale=1.0, res_up2=False,
+                  post_gate=False):
+    return InstanceNormFn.apply(y, st, style, post_bias, prelu, act, eps, res, out_scale, res_up2, post_gate)
 
 
 class AddScaleFn(Function):
@@ -432,11 +450,29 @@ class LinearFn(Function):
             g = lrelu_bwd(g, y)
         w2 = w.reshape(w.shape[0], -1)
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = ops.linear_dgrad(g, w2, wscale)
-            if relu_in:
-                dx = relu_gate(dx, x)
         wp, bp = ctx.refs
+        fused = FUSE_LINEAR["value"] and gates.MODE["value"] is None and w2.shape[1] % 4 == 0
+        if ctx.needs_input_grad[0]:
+            if relu_in and fused:          # the ReLU's backward rides on the slice reduction of the input gradient
+                dx = ops.linear_dgrad_gate(g, w2, x, wscale)
+            else:
+                dx = ops.linear_dgrad(g, w2, wscale)
+                if relu_in:
+                    dx = relu_gate(dx, x)
+        need_b = has_b and ctx.needs_input_grad[2]
+        dst0 = _direct(wp) if ctx.needs_input_grad[1] else None
+        if ctx.needs_input_grad[1] and fused and (dst0 is None or dst0.data_ptr() % 16 == 0):
+            # one launch: relu(x) read on the fly, dW added into the flat gradient, the bias gradient from the same rows of g
+            dst, bdst = dst0, (_direct(bp) if need_b else None)
+            dw, db = ops.linear_wgrad_fused(g, x, wscale, out=dst, accumulate=dst is not None, relu_in=relu_in, bias_out=bdst,
+                                            bias_scale=bscale, bias_accumulate=bdst is not None, want_bias=need_b)
+            if dst is not None:
+                _noted(wp); dw = None
+            else:
+                dw = dw.view_as(w)
+            if need_b and bdst is not None:
+                _noted(bp); db = None
+            return dx, dw, db, None, None, None, None
         if ctx.needs_input_grad[1]:
             xin = relu_gate(x, x) if relu_in else x      # relu(x) = x * [x > 0]
             dst = _direct(wp)
@@ -445,7 +481,7 @@ class LinearFn(Function):
                 _noted(wp); dw = None
             else:
                 dw = dw.view_as(w)
-        if has_b and ctx.needs_input_grad[2]:
+        if need_b:
             dst = _direct(bp)
             db = ops.colsum(g, bscale, out=dst, accumulate=dst is not None)
             if dst is not None:

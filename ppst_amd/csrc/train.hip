@@ -1263,6 +1263,73 @@ extern "C" int ppst_linear_wgrad(const void* dy, const void* x, void* dw, int B,
               K, scale, accumulate, total);
   return PPST_LAUNCH_CHECK();
 }
+// Round 5: the same two gradients with the passes around them folded in (LinearFn of ppst_amd/autograd.py: the E2 projector chains
+// ran 7 launches per linear and backward): ``relu_in`` -- x is read as max(x, 0) (the linear sits behind nn.ReLU, encoder_col.py:47-93);
+// ``db`` -- the bias gradient bscale * sum_b dY[b][n] from the thread that owns column 0 of row n (dY's rows are read by it anyway).
+__global__ __launch_bounds__(256) void linear_wgrad4_fused_kernel(const float* __restrict__ dy, const float4* __restrict__ x, float4* __restrict__ dw,
+                                                                  float* __restrict__ db, int B, int N, int K4, float scale, float bscale,
+                                                                  int accumulate, int b_accumulate, int relu_in, int64_t total4) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total4; t += (int64_t)gridDim.x * 256) {
+    const int k4 = (int)(t % K4), n = (int)(t / K4);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sd = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float d = dy[(int64_t)b * N + n];
+      float4 v = x[(int64_t)b * K4 + k4];
+      if (relu_in) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+      s.x += d * v.x; s.y += d * v.y; s.z += d * v.z; s.w += d * v.w;
+      sd += d;
+    }
+    float4 o = make_float4(s.x * scale, s.y * scale, s.z * scale, s.w * scale);
+    if (accumulate) { const float4 p = dw[t]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+    dw[t] = o;
+    if (db && k4 == 0) db[n] = b_accumulate ? db[n] + sd * bscale : sd * bscale;
+  }
+}
+extern "C" int ppst_linear_wgrad_fused(const void* dy, const void* x, void* dw, void* db, int B, int N, int K, float scale, float bscale,
+                                       int accumulate, int b_accumulate, int relu_in, void* stream) {
+  if (B <= 0 || N <= 0 || K <= 0 || K % 4) return PPST_EINVAL;
+  if (!dy || !x || !dw) return PPST_ENULL;
+  if (((uintptr_t)x | (uintptr_t)dw) % 16) return PPST_EINVAL;
+  const int64_t total4 = (int64_t)N * K / 4;
+  int64_t blocks = cdiv64(total4, 256);
+  if (blocks > 8192) blocks = 8192;
+  PPST_LAUNCH(linear_wgrad4_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)dy, (const float4*)x,
+              (float4*)dw, (float*)db, B, N, K / 4, scale, bscale, accumulate, b_accumulate, relu_in, total4);
+  return PPST_LAUNCH_CHECK();
+}
+// ``gate`` (B x K, optional): dX is multiplied by [gate > 0] in the slice reduction (the backward of the nn.ReLU in front of the linear)
+__global__ __launch_bounds__(256) void linear_dgrad_reduce_gate_kernel(const float* __restrict__ partial, const float* __restrict__ gate,
+                                                                       float* __restrict__ dx, int nsplit, int64_t bk, float scale) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < bk; t += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    int i = 0;
+    for (; i + 8 <= nsplit; i += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(i + u) * bk + t];
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; i < nsplit; ++i) s += partial[(int64_t)i * bk + t];
+    dx[t] = gate[t] > 0.f ? s * scale : 0.f;
+  }
+}
+extern "C" int ppst_linear_dgrad_gate(const void* dy, const void* w, void* dx, void* ws, const void* gate, int B, int N, int K, float scale,
+                                      void* stream) {
+  if (B <= 0 || N <= 0 || K <= 0) return PPST_EINVAL;
+  if (!dy || !w || !dx || !ws || !gate) return PPST_ENULL;
+  const int nsplit = cdiv(N, LDG_ROWS);
+  for (int b0 = 0; b0 < B; b0 += LDG_BMAX)
+    PPST_LAUNCH(linear_dgrad_partial_kernel, dim3(cdiv(K, 256), nsplit), dim3(256), 0, as_stream(stream), (const float*)dy, (const float*)w,
+                (float*)ws, B, N, K, b0);
+  const int64_t bk = (int64_t)B * K;
+  int64_t blocks = cdiv64(bk, 256);
+  if (blocks > 4096) blocks = 4096;
+  PPST_LAUNCH(linear_dgrad_reduce_gate_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)ws, (const float*)gate,
+              (float*)dx, nsplit, bk, scale);
+  return PPST_LAUNCH_CHECK();
+}
+
 extern "C" int64_t ppst_linear_dgrad_ws(int B, int N, int K) { return (int64_t)cdiv(N, LDG_ROWS) * B * K * (int64_t)sizeof(float); }
 extern "C" int ppst_linear_dgrad(const void* dy, const void* w, void* dx, void* ws, int B, int N, int K, float scale, void* stream) {
   if (B <= 0 || N <= 0 || K <= 0) return PPST_EINVAL;

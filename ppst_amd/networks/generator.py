@@ -205,7 +205,7 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
             # (the x2 bilinear upsample of the skip is sampled on the fly by the apply pass)
             r, rss = self.styled_conv(x, q + "conv1.", styles, "UpsamplingResBlock%d.conv1" % key, noise, upsample=True, defer=True)
             want = ("rep" if j < 2 else "plain") if extract_features else None
-            if j == len(UP) - 1 and not extract_features and ops.FUSE_TAIL["value"]:
+            if j == len(UP) - 1 and not extract_features and ops.FUSE_TAIL["value"] and ops.FUSE_TAIL["torgb"]:
                 # image pass: the last block's merged output is read by ToRGB only -- its 1x1 conv applies the merge on load
                 x, xss = self.styled_conv(r, q + "conv2.", styles, "UpsamplingResBlock%d.conv2" % key, noise, in_ss=rss, defer=True)
                 last_merge = (xss, skip)

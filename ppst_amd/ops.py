@@ -87,7 +87,9 @@ class batch_aware:
 WINO = {"value": True, "min_blocks": 16, "fill": 0}
 # round 5: apply passes whose only consumer is a 1x1 conv are applied by that conv while it loads -- layert1's resnet merge by
 # layert1.1 (ConvPlan in_res), the last upsampling block's merge by ToRGB in the image pass (torgb_apply).  Off: the round-4 passes.
-FUSE_TAIL = {"value": os.environ.get("PPST_FUSE_TAIL", "1") != "0"}
+# "torgb": measured SLOWER (rocprofv3, batch-8 swap step: 1.09 ms against 0.56 + 0.23 for the pass + the conv -- the 32-lanes-per-pixel ToRGB
+# kernel becomes instruction-bound with the bilinear skip sampled per element) -- built, tested (t_fuse_tail), off
+FUSE_TAIL = {"value": os.environ.get("PPST_FUSE_TAIL", "1") != "0", "torgb": os.environ.get("PPST_FUSE_TORGB", "0") == "1"}
 FAT_MIN_BLOCKS = 32         # take the 256-channel tile only when ONE image still gives >= this many blocks (B = 8: one per CU)
 
 
@@ -957,7 +959,7 @@ def presplit(x):
     return y
 
 
-def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=None, bias_accumulate=False, want_bias=False):
+def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=None, bias_accumulate=False, want_bias=False, dy_scale=1.0):
     """Weight gradient of the conv described by forward ``plan`` ('conv' or 's2d'):
     x = the tensor the forward conv read (NHWC, or the space-to-depth tensor for 's2d'),
     dy = gradient w.r.t. the conv output (before bias/activation).  Returns dW shaped
@@ -965,8 +967,11 @@ def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=No
     ``out`` / ``accumulate``: write (or add) into a given destination -- the reduction over the pixel splits adds straight
     into the flat gradient buffer, so no separate accumulation pass (and no zero fill) runs.
     ``want_bias`` / ``bias_out``: also the column sums of dy (the bias gradient), from the fp32 values the weight-gradient kernel
-    stages anyway (no second pass over dy): returns (dW, db)."""
+    stages anyway (no second pass over dy): returns (dW, db).
+    ``dy_scale``: the gradient is that of ``dy_scale * dy`` (a constant upstream factor rides on the split reduction instead of a
+    pass that scales dy; not with the bias outputs)."""
     assert plan.kind in ("conv", "s2d", "dgradT")
+    assert dy_scale == 1.0 or not (want_bias or bias_out is not None)
     in_ld = _nhwc_ld(x, "x")
     dy_ld = _nhwc_ld(dy, "dy")
     B, H, W, _ = x.shape
@@ -1036,7 +1041,7 @@ def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=No
     if csum is not None:         # the split reduction also sums the bias partials: no launch of its own
         db = _grad_out(bias_out, (cout,), x)
     check(lib.ppst_wgrad_scatter(_p(partial), _p(c_), _p(ky_), _p(kx_), _p(dw), sn, sc, sy, sx, cout, plan.nsteps, splits,
-                                 plan.scale, 1 if (accumulate and out is not None) else 0, _p(csum), _p(db),
+                                 plan.scale * float(dy_scale), 1 if (accumulate and out is not None) else 0, _p(csum), _p(db),
                                  csum.shape[0] if csum is not None else 0, 1 if (bias_accumulate and bias_out is not None) else 0,
                                  _stream()), "ppst_wgrad_scatter")
     if not want_bias:
@@ -1081,6 +1086,35 @@ def linear_wgrad(dy, x, scale=1.0, out=None, accumulate=False):
     check(lib.ppst_linear_wgrad(_p(dy), _p(x), _p(dw), B, N, K, float(scale), 1 if (accumulate and out is not None) else 0, _stream()),
           "ppst_linear_wgrad")
     return dw
+
+
+def linear_wgrad_fused(dy, x, scale=1.0, out=None, accumulate=False, relu_in=False, bias_out=None, bias_scale=1.0, bias_accumulate=False,
+                       want_bias=False):
+    """linear_wgrad with the passes around it folded in (ppst_linear_wgrad_fused): ``relu_in`` reads x as max(x, 0); the bias
+    gradient bias_scale * sum_b dy[b] comes out of the same launch (``bias_out`` / ``want_bias``).  Returns (dW, db or None)."""
+    _chk(dy); _chk(x)
+    dy, x = dy.contiguous(), x.contiguous()
+    B, N = dy.shape
+    K = x.shape[1]
+    dw = _grad_out(out, (N, K), x)
+    db = _grad_out(bias_out, (N,), x) if (want_bias or bias_out is not None) else None
+    check(lib.ppst_linear_wgrad_fused(_p(dy), _p(x), _p(dw), _p(db), B, N, K, float(scale), float(bias_scale),
+                                      1 if (accumulate and out is not None) else 0, 1 if (bias_accumulate and bias_out is not None) else 0,
+                                      1 if relu_in else 0, _stream()), "ppst_linear_wgrad_fused")
+    return dw, db
+
+
+def linear_dgrad_gate(dy, w, gate, scale=1.0):
+    """linear_dgrad whose result is multiplied by [gate > 0] in the slice reduction (the nn.ReLU in front of the linear)."""
+    _chk(dy); _chk(w); _chk(gate)
+    dy, w, gate = dy.contiguous(), w.detach().contiguous(), gate.contiguous()
+    B, N = dy.shape
+    K = w.shape[1]
+    assert tuple(gate.shape) == (B, K)
+    dx = torch.empty((B, K), device=dy.device, dtype=torch.float32)
+    ws = torch.empty(lib.ppst_linear_dgrad_ws(B, N, K) // 4, device=dy.device, dtype=torch.float32)
+    check(lib.ppst_linear_dgrad_gate(_p(dy), _p(w), _p(dx), _p(ws), _p(gate), B, N, K, float(scale), _stream()), "ppst_linear_dgrad_gate")
+    return dx
 
 
 def linear_dgrad(dy, w, scale=1.0):

@@ -23,6 +23,8 @@ from .networks.base_network import to_nhwc
 
 SQRT2 = math.sqrt(2.0)
 INV_SQRT2 = 1.0 / SQRT2
+# round 5: elementwise passes of D's backward folded into the convs beside them (tests/train_ab.py flips them for same-process A/B)
+TRAIN_FUSE = {"d_fanin": True, "d_skip_scale": True}
 
 
 def _lrelu_bwd(g, out, scale=1.0):
@@ -183,18 +185,27 @@ class DiscriminatorTrainer:
                                bias_out=G(name + "conv2.Act.bias"), bias_accumulate=True)
             d_xb = self._dgrad(q + "conv2.Conv.weight", "dgrad_s2d", sc1)(g2, out_hw=blk["bhw"])
             # blur backward: upfirdn2d with the flipped (symmetric) taps and g_pad = (1, 1)
-            kf = torch.flip(D.p(q + "conv2.Blur.kernel"), [0, 1]).contiguous()
+            kf = D.cached(("flip", q + "conv2.Blur.kernel"), [D.p(q + "conv2.Blur.kernel")],
+                          lambda: torch.flip(D.p(q + "conv2.Blur.kernel"), [0, 1]).contiguous())
             d_y1, _ = ops.blur_nhwc(d_xb, kf, 1, 1, ops.PAD_ZERO)
             g1 = _lrelu_bwd(d_y1, blk["y1"])
             if pg:
                 ops.conv_wgrad(D.plan(q + "conv1.Conv.weight", scale=sc1), blk["x"], g1, out=G(name + "conv1.Conv.weight"), accumulate=True,
                                bias_out=G(name + "conv1.Act.bias"), bias_accumulate=True)
-            d_xa = self._dgrad(q + "conv1.Conv.weight", "dgrad", sc1)(g1)
-            # skip branch: 1x1 conv on the blurred + decimated input, no bias / activation
-            gs = ops.affine_act(dx, None, out_scale=INV_SQRT2)
-            if pg:
-                ops.conv_wgrad(D.plan(q + "skip.Conv.weight", scale=scs), blk["xs"], gs, out=G(name + "skip.Conv.weight"), accumulate=True)
-            d_xs = self._dgrad(q + "skip.Conv.weight", "dgrad", scs)(gs)
+            # skip branch: 1x1 conv on the blurred + decimated input, no bias / activation.  Its upstream gradient is dx / sqrt2: the
+            # factor rides on the two kernels that consume it (round 5: no pass that materialises gs) -- unless the R1 sweep wants
+            # gs itself (``keep``)
+            if keep is not None or not TRAIN_FUSE["d_skip_scale"]:
+                gs = ops.affine_act(dx, None, out_scale=INV_SQRT2)
+                if pg:
+                    ops.conv_wgrad(D.plan(q + "skip.Conv.weight", scale=scs), blk["xs"], gs, out=G(name + "skip.Conv.weight"), accumulate=True)
+                d_xs = self._dgrad(q + "skip.Conv.weight", "dgrad", scs)(gs)
+            else:
+                gs = None
+                if pg:
+                    ops.conv_wgrad(D.plan(q + "skip.Conv.weight", scale=scs), blk["xs"], dx, out=G(name + "skip.Conv.weight"), accumulate=True,
+                                   dy_scale=INV_SQRT2)
+                d_xs = self._dgrad(q + "skip.Conv.weight", "dgrad", scs)(dx, out_scale=INV_SQRT2)
             # blur(down=2, pad (1,1)) backward = zero-insert x2 then FIR with g_pad (upfirdn2d.py:116-121)
             S = blk["S"]
             ks = D.p(q + "skip.Blur.kernel")
@@ -202,8 +213,14 @@ class DiscriminatorTrainer:
             oh = d_xs.shape[1]
             gp0 = ksz - 1 - 1
             gp1 = S - oh * 2 + 1 - 1 + 1
-            d_xb2 = ops.upfirdn2d_raw(d_xs, torch.flip(ks, [0, 1]).contiguous(), 2, 2, 1, 1, gp0, gp1, gp0, gp1)
-            dx = ops.affine_act(d_xa, None, res=d_xb2)
+            ksf = D.cached(("flip", q + "skip.Blur.kernel"), [ks], lambda: torch.flip(D.p(q + "skip.Blur.kernel"), [0, 1]).contiguous())
+            d_xb2 = ops.upfirdn2d_raw(d_xs, ksf, 2, 2, 1, 1, gp0, gp1, gp0, gp1)
+            # dx = d_xa + d_xb2: the fan-in add rides on the epilogue of conv1's input-gradient conv (its ``residual``)
+            if TRAIN_FUSE["d_fanin"]:
+                dx = self._dgrad(q + "conv1.Conv.weight", "dgrad", sc1)(g1, residual=d_xb2)
+            else:
+                d_xa = self._dgrad(q + "conv1.Conv.weight", "dgrad", sc1)(g1)
+                dx = ops.affine_act(d_xa, None, res=d_xb2)
             if keep is not None:
                 keep["blocks"].append(dict(g1=g1, g2=g2, gs=gs))
         # FromRGB: 1x1 conv (no bias) + fused lrelu

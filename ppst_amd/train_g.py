@@ -21,7 +21,8 @@ from .train import DiscriminatorTrainer, ddp_average_
 SQRT2 = math.sqrt(2.0)
 INV_SQRT2 = 1.0 / SQRT2
 # tuning switches of the differentiable generator (tests/train_ab.py flips them for same-process A/B timing)
-TRAIN_FUSE = {"merge": True, "res_up2": True}
+# "gate": StyledConv's leaky-ReLU gate rides on the norm backward's apply pass (round 5; off while the gate tape records / replays)
+TRAIN_FUSE = {"merge": True, "res_up2": True, "gate": True}
 HEAD_CH = [(256, 256), (256, 256), (256, 384), (384, 512)]
 UP = [(16, 512, 512), (32, 512, 256), (64, 256, 128)]
 TAGS = ["9", "0", "1", "2"]
@@ -272,11 +273,13 @@ class GeneratorTrainer:
             B, H, W = x.shape[0], x.shape[1] * (2 if upsample else 1), x.shape[2] * (2 if upsample else 1)
             nz = torch.randn(B, 1, H, W, device=x.device)          # NoiseInjection draws N(0,1) (stylegan2_layers.py:388-390)
         wn = p + "conv.weight"
+        from . import gates
+        fuse_gate = TRAIN_FUSE["gate"] and gates.MODE["value"] is None     # (`a` has exactly one consumer: the norm below)
         a, st = A.conv(x, P(wn), net, wn, bias=bias, kind=kind, act=A.LRELU, noise_w=P(p + "noise.weight"), noise=nz.contiguous(), stats=True,
-                       noise_w_host=self.fp["G"].scalar(p + "noise.weight"), bias_params=bias_params)
+                       noise_w_host=self.fp["G"].scalar(p + "noise.weight"), bias_params=bias_params, gate_downstream=fuse_gate)
         wl = P(p + "epi1.style_mod.lin.weight")
         style = A.linear(code, wl, P(p + "epi1.style_mod.lin.bias"), wscale=wl.shape[1] ** -0.5)
-        return A.instance_norm(a, st, style=style, res=res, out_scale=out_scale, res_up2=res_up2)     # res: the block's (skip + res) / sqrt2 merge
+        return A.instance_norm(a, st, style=style, res=res, out_scale=out_scale, res_up2=res_up2, post_gate=fuse_gate)     # res: the block's (skip + res) / sqrt2 merge
 
     def generator(self, sp, global_codes, noise=None, extract_features=False):
         """sp NHWC (B,h,w,256), codes 4 x (B,2048) -> rgb NCHW (B,3,8h,8w) [, feat NHWC, feat1 NHWC]."""

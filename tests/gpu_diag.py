@@ -268,18 +268,18 @@ def t_fuse_tail():
     noise = {k: v.to(dev) for k, v in W.make_noise(4, 2).items()}
     sp = g(torch.randn(2, 256, 64, 64))
     gl = [g(torch.randn(2, 2048)) for _ in range(4)]
-    prev = ops.FUSE_TAIL["value"]
+    prev = dict(ops.FUSE_TAIL)
     try:
         outs = {}
         for on in (False, True):
-            ops.FUSE_TAIL["value"] = on
+            ops.FUSE_TAIL.update(value=on, torgb=on)
             with torch.no_grad():
                 outs[on] = (m.G(sp, gl, noise=noise), m.G(sp, gl, extract_features=True, noise=noise))
         report("generator image pass, tail fused vs passes", outs[True][0], outs[False][0], 1e-5)
         for name, a, b in zip(("rgb", "feat", "feat1"), outs[True][1], outs[False][1]):
             report("generator feature pass %s, tail fused vs passes" % name, a, b, 1e-5)
     finally:
-        ops.FUSE_TAIL["value"] = prev
+        ops.FUSE_TAIL.update(prev)
 
 
 def t_layout_misc():

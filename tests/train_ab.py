@@ -27,6 +27,24 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
     run(2)
+    from ppst_amd import autograd as A, ops, train
+    if len(sys.argv) > 1 and sys.argv[1] == "r5":
+        # round 5: the backward fusions one at a time (same process, three rounds): the discriminator's fan-in add on the input-gradient
+        # conv + skip-branch scale on its consumers, StyledConv's gate on the norm backward, the linear backward in 2-3 launches
+        def setall(on):
+            train.TRAIN_FUSE.update(d_fanin=on, d_skip_scale=on)
+            train_g.TRAIN_FUSE["gate"] = on
+            A.FUSE_LINEAR["value"] = on
+        for rep in range(3):
+            for name, fn in (("all off", lambda: setall(False)),
+                             ("D fan-in + skip scale", lambda: (setall(False), train.TRAIN_FUSE.update(d_fanin=True, d_skip_scale=True))),
+                             ("StyledConv gate", lambda: (setall(False), train_g.TRAIN_FUSE.update(gate=True))),
+                             ("linear backward", lambda: (setall(False), A.FUSE_LINEAR.update(value=True))),
+                             ("all on", lambda: setall(True))):
+                fn()
+                run(1)
+                print(rep, "%-24s %.2f ms / step" % (name, run(4)), flush=True)
+        return
     for rep in range(3):
         for cfg in ({"merge": False, "res_up2": False}, {"merge": True, "res_up2": False}, {"merge": True, "res_up2": True}):
             train_g.TRAIN_FUSE.update(cfg)
