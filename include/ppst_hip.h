@@ -628,6 +628,17 @@ int ppst_bilinear_bwd(const void* dy, void* dx, int B, int H, int W, int C, int 
 int ppst_avgpool_bwd(const void* dy, void* dx, int B, int H, int W, int C, int dx_ld, int f, int dy_ld, void* stream);
 int ppst_gap_gmp_bwd(const void* x, const void* mask, const void* v, const void* g, void* dx, void* arg_ws /* B*C int32 */, int B,
                      int64_t hw, int C, int ld, int accumulate, void* stream);
+/* Round 5: GAP || GMP of x * mask (encoder_col.py:162-168, 217-245) for SEVERAL masks in one read of the feature map, and its adjoint
+ * in one pass.  heads: h = 0 the unmasked pooling (with_plain = 1), then one per channel of masks [B][hw][nm] (nm in 1..3: the NHWC
+ * planes of the one-hot mask pyramid); out / v / g are [(nm + with_plain) * B][2C], head-major.  A head's forward values are the
+ * single-head launch's bit for bit (same block geometry and summation order); the backward writes the SUM over the heads once
+ * (accumulate: adds into dx).  C % 4 == 0, 16-byte aligned rows; the backward needs hw % 16 == 0.
+ * ws: ppst_gap_gmp_multi_ws bytes; arg_ws: (nm + with_plain) * B * C ints. */
+int64_t ppst_gap_gmp_multi_ws(int B, int64_t hw, int C, int heads);
+int ppst_gap_gmp_multi(const void* x, const void* masks, void* out, void* ws, int B, int H, int W, int C, int ld, int nm,
+                       int with_plain, void* stream);
+int ppst_gap_gmp_multi_bwd(const void* x, const void* masks, const void* v, const void* g, void* dx, void* arg_ws, int B, int64_t hw,
+                           int C, int ld, int nm, int with_plain, int accumulate, void* stream);
 /* backward of ppst_l2norm_rows (mode 0: util.normalize, 1: F.normalize), ppst_softmax_rows (in place on g) and
  * ppst_corr_prep (ppst_model.py:343-356) */
 int ppst_l2norm_rows_bwd(const void* g, const void* x, void* dx, int B, int K, float eps, int mode, void* stream);

@@ -154,6 +154,9 @@ _SIGS = {
     "ppst_bilinear_bwd": (i32, [vp, vp] + [i32] * 8 + [vp]),
     "ppst_avgpool_bwd": (i32, [vp, vp] + [i32] * 7 + [vp]),
     "ppst_gap_gmp_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp]),
+    "ppst_gap_gmp_multi_ws": (i64, [i32, i64, i32, i32]),
+    "ppst_gap_gmp_multi": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ppst_gap_gmp_multi_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp]),
     "ppst_l2norm_rows_bwd": (i32, [vp, vp, vp, i32, i32, f32, i32, vp]),
     "ppst_softmax_rows_bwd": (i32, [vp, vp, i64, i32, f32, vp]),
     "ppst_corr_prep_bwd": (i32, [vp, vp, vp, i64, i32, i32, f32, vp]),

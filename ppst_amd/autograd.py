@@ -79,7 +79,9 @@ def _noted(p):
 def _flipped(net, kname):
     """the blur taps of ``kname`` flipped (the adjoint FIR, upfirdn2d.py:116-121), kept per network: one flip + copy per train step
     and blur was 69 torch launches"""
-    return net.cached(("flip", kname), [net.p(kname)], lambda: torch.flip(net.p(kname), [0, 1]).contiguous())
+    build = lambda: torch.flip(net.p(kname), [0, 1]).contiguous()
+    cached = getattr(net, "cached", None)          # (BaseNetwork; a bare parameter holder of the tests has none)
+    return cached(("flip", kname), [net.p(kname)], build) if cached is not None else build()
 
 
 def _conv_grads(net, wname, kind, scale, pad_mode, x, gpre, need_x, need_w, out_hw=None, dw_out=None, want_bias=False, bias_out=None):
@@ -427,6 +429,24 @@ class GapGmpFn(Function):
         x, mask, v = ctx.saved_tensors
         x, v = gates.values("gmp-argmax", x, v)          # (they only pick the arg-max pixel; the tape can replay another run's)
         return ops.gap_gmp_bwd(x, mask, v, _c(g)), None
+
+
+class GapGmpMultiFn(Function):
+    """GapGmpFn for the unmasked pooling and the three class-masked poolings of ONE feature map at once (encoder_col.py:162-168,
+    217-245): -> (4 * B, 2C) head-major [plain | mask 0 | mask 1 | mask 2].  One read of x forward; backward one pass that writes the
+    sum of the four heads' gradients (round 5: four dense gradients and three autograd adds per map before)."""
+
+    @staticmethod
+    def forward(ctx, x, masks):
+        x = _c(x)
+        v = ops.gap_gmp_multi(x, masks, True)
+        ctx.save_for_backward(x, masks, v)
+        return v
+
+    @staticmethod
+    def backward(ctx, g):
+        x, masks, v = ctx.saved_tensors
+        return ops.gap_gmp_multi_bwd(x, masks, v, _c(g), True), None
 
 
 class LinearFn(Function):

@@ -607,6 +607,96 @@ extern "C" int ppst_gap_gmp(const void* x, const void* mask, void* out, void* ws
   return ppst_gap_gmp_st(x, mask, out, ws, B, H, W, C, ld, PPST_ST_F32, stream);
 }
 
+
+// ---- GAP || GMP of x * mask for SEVERAL masks in one read of x (round 5; the masked E2 heads of encoder_col.py:217-245 pool every
+// feature map four times -- unmasked and under each of the three class masks).  heads: h = 0 the plain pooling (with_plain), then one
+// per mask channel; masks [B][hw][nm] (the NHWC planes of the one-hot pyramid), nm <= 3.  Same block geometry, lane map and summation
+// order per head as chan_reduce4_kernel<1>: a head's values equal the single-head launch's bit for bit.
+// partial [(h * B + b)][nchunks][C][2] -> gap_gmp_finalize_kernel over heads * B rows.
+#define GGM_MAXH 4
+__global__ __launch_bounds__(256) void gap_gmp_multi_kernel(const float* __restrict__ x, const float* __restrict__ masks,
+                                                            float* __restrict__ partial, int P, int C, int ld, int nm, int with_plain,
+                                                            int B, int nchunks, int PIX_CHUNK) {
+  __shared__ float4 s0[256], s1[256];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int pbeg = chunk * PIX_CHUNK;
+  const int pend = (pbeg + PIX_CHUNK < P) ? pbeg + PIX_CHUNK : P;
+  const int c4n = C >> 2;
+  int lanes = 1;
+  while (lanes < c4n && lanes < 256) lanes <<= 1;
+  const int rows = 256 / lanes;
+  const int cl = threadIdx.x % lanes, pr = threadIdx.x / lanes;
+  const int nh = nm + (with_plain ? 1 : 0);
+  const float* mb = masks + (int64_t)b * P * nm;
+  for (int cbase = 0; cbase < c4n; cbase += lanes) {
+    const int c = (cbase + cl) * 4;
+    float4 a0[GGM_MAXH], a1[GGM_MAXH];
+#pragma unroll
+    for (int h = 0; h < GGM_MAXH; ++h) { a0[h] = make_float4(0.f, 0.f, 0.f, 0.f); a1[h] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); }
+    if (c < C) {
+      for (int p = pbeg + pr; p < pend; p += rows) {
+        const float4 v = *(const float4*)(x + ((int64_t)b * P + p) * ld + c);
+        float m[GGM_MAXH];
+#pragma unroll
+        for (int h = 0; h < GGM_MAXH; ++h) {
+          const int mi = h - (with_plain ? 1 : 0);
+          m[h] = (mi < 0) ? 1.f : (mi < nm ? mb[(int64_t)p * nm + mi] : 0.f);
+        }
+#pragma unroll
+        for (int h = 0; h < GGM_MAXH; ++h) {
+          if (h < nh) {
+            const float4 w = make_float4(v.x * m[h], v.y * m[h], v.z * m[h], v.w * m[h]);
+            a0[h].x += w.x; a0[h].y += w.y; a0[h].z += w.z; a0[h].w += w.w;
+            a1[h].x = fmaxf(a1[h].x, w.x); a1[h].y = fmaxf(a1[h].y, w.y); a1[h].z = fmaxf(a1[h].z, w.z); a1[h].w = fmaxf(a1[h].w, w.w);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < GGM_MAXH; ++h) {
+      if (h < nh) {
+        s0[threadIdx.x] = a0[h];
+        s1[threadIdx.x] = a1[h];
+        __syncthreads();
+        if (pr == 0 && c < C) {
+          float4 t0 = a0[h], t1 = a1[h];
+          for (int r = 1; r < rows; ++r) {
+            const float4 u = s0[r * lanes + cl], w = s1[r * lanes + cl];
+            t0.x += u.x; t0.y += u.y; t0.z += u.z; t0.w += u.w;
+            t1.x = fmaxf(t1.x, w.x); t1.y = fmaxf(t1.y, w.y); t1.z = fmaxf(t1.z, w.z); t1.w = fmaxf(t1.w, w.w);
+          }
+          float4* o = (float4*)(partial + ((((int64_t)h * B + b) * nchunks + chunk) * C + c) * 2);
+          o[0] = make_float4(t0.x, t1.x, t0.y, t1.y);
+          o[1] = make_float4(t0.z, t1.z, t0.w, t1.w);
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+extern "C" int64_t ppst_gap_gmp_multi_ws(int B, int64_t hw, int C, int heads) {
+  if (B <= 0 || hw <= 0 || heads <= 0) return 0;
+  return cdiv64(hw, pix_chunk(B, hw)) * C * 2 * B * heads * (int64_t)sizeof(float);
+}
+// x [B][hw][ld] fp32, masks [B][hw][nm] (nm in 1..3), with_plain 0 / 1 -> out [(nm + with_plain) * B][2C], head-major
+extern "C" int ppst_gap_gmp_multi(const void* x, const void* masks, void* out, void* ws, int B, int H, int W, int C, int ld, int nm,
+                                  int with_plain, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || ld % 4 || ld < C || nm < 1 || nm > 3 || (with_plain != 0 && with_plain != 1))
+    return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !masks || !out || !ws) return PPST_ENULL;
+  if ((int64_t)H * W > 0x7fffffffll || ((uintptr_t)x % 16)) return PPST_EINVAL;
+  const int chunk = pix_chunk(B, (int64_t)H * W);
+  const int nchunks = (int)cdiv64((int64_t)H * W, chunk), heads = nm + with_plain;
+  PPST_LAUNCH(gap_gmp_multi_kernel, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)masks, (float*)ws,
+              H * W, C, ld, nm, with_plain, B, nchunks, chunk);
+  int e = PPST_LAUNCH_CHECK();
+  if (e) return e;
+  PPST_LAUNCH(gap_gmp_finalize_kernel, dim3(heads * B * cdiv(C, FIN_CH)), dim3(256), 0, as_stream(stream), (const float*)ws, nchunks,
+              (float*)out, heads * B, C, (double)H * W);
+  return PPST_LAUNCH_CHECK();
+}
+
 // ------------------------------------------------------ pooling / resize ---
 __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
                                                       int C, int x_ld, int f, int y_ld, unsigned total, FastDiv d_c,

@@ -659,6 +659,112 @@ extern "C" int ppst_gap_gmp_bwd(const void* x, const void* mask, const void* v, 
   return PPST_LAUNCH_CHECK();
 }
 
+
+// ---- the same adjoint for SEVERAL pooling heads of one feature map in one pass (round 5; forward: ppst_gap_gmp_multi): heads h = 0
+// plain (with_plain), then one per mask channel of masks [B][hw][nm]; v / g [(h * B + b)][2C].  Per head the arithmetic of the
+// single-head kernels; dx = the SUM over heads, written once (eight dense per-head gradients and seven autograd adds per pyramid
+// level before).  Strip form only (hw % GMP_NP == 0: every level of the 512 / 256 pyramids).
+#define GGM_MAXH 4
+__global__ __launch_bounds__(256) void gmp_argmax_multi4_kernel(const float4* __restrict__ x, const float* __restrict__ masks,
+                                                                const float* __restrict__ v, int* __restrict__ arg, unsigned hw, int C, int ld4,
+                                                                int nm, int with_plain, int B, unsigned total_strips, FastDiv d_c4,
+                                                                FastDiv d_hwn) {
+  const int nh = nm + with_plain;
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total_strips; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned c4;
+    const unsigned strip = fd_divmod((unsigned)t64, d_c4, c4);
+    const unsigned b = fd_div(strip, d_hwn);
+    const unsigned bp0 = strip * GMP_NP;
+    const int pix0 = (int)(bp0 - b * hw);
+    float4 mv[GGM_MAXH];
+    int f[GGM_MAXH][4];
+#pragma unroll
+    for (int h = 0; h < GGM_MAXH; ++h) {
+      mv[h] = h < nh ? *(const float4*)(v + ((int64_t)h * B + b) * 2 * C + C + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      f[h][0] = f[h][1] = f[h][2] = f[h][3] = -1;
+    }
+#pragma unroll
+    for (int j = GMP_NP - 1; j >= 0; --j) {                         // descending: the last assignment is the first match
+      const float4 xv = x[(int64_t)(bp0 + j) * ld4 + c4];
+#pragma unroll
+      for (int h = 0; h < GGM_MAXH; ++h) {
+        if (h < nh) {
+          const int mi = h - with_plain;
+          const float m = mi < 0 ? 1.f : masks[(int64_t)(bp0 + j) * nm + mi];
+          if (xv.x * m == mv[h].x) f[h][0] = j;
+          if (xv.y * m == mv[h].y) f[h][1] = j;
+          if (xv.z * m == mv[h].z) f[h][2] = j;
+          if (xv.w * m == mv[h].w) f[h][3] = j;
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < GGM_MAXH; ++h) {
+      if (h < nh) {
+        int* ap = arg + ((int64_t)h * B + b) * C + c4 * 4;
+        const volatile int* cur = ap;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (f[h][q] >= 0 && pix0 + f[h][q] < cur[q]) atomicMin(ap + q, pix0 + f[h][q]);
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void gap_gmp_bwd_multi4_kernel(const float* __restrict__ masks, const int* __restrict__ arg,
+                                                                 const float* __restrict__ g, float4* __restrict__ dx, unsigned hw, int C,
+                                                                 int nm, int with_plain, int B, int accumulate, unsigned total, FastDiv d_c4,
+                                                                 FastDiv d_hw) {
+  const float invP = 1.f / (float)hw;
+  const int nh = nm + with_plain;
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned c4;
+    const unsigned bpu = fd_divmod((unsigned)t64, d_c4, c4);
+    const unsigned b = fd_div(bpu, d_hw);
+    const int pix = (int)(bpu - b * hw);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int h = 0; h < GGM_MAXH; ++h) {
+      if (h < nh) {
+        const int mi = h - with_plain;
+        const float m = mi < 0 ? 1.f : masks[(int64_t)bpu * nm + mi];
+        const int64_t row = (int64_t)h * B + b;
+        const int4 ar = *(const int4*)(arg + row * C + c4 * 4);
+        const float4 ga = *(const float4*)(g + row * 2 * C + c4 * 4), gm = *(const float4*)(g + row * 2 * C + C + c4 * 4);
+        o.x += m * (ga.x * invP + (pix == ar.x ? gm.x : 0.f));
+        o.y += m * (ga.y * invP + (pix == ar.y ? gm.y : 0.f));
+        o.z += m * (ga.z * invP + (pix == ar.z ? gm.z : 0.f));
+        o.w += m * (ga.w * invP + (pix == ar.w ? gm.w : 0.f));
+      }
+    }
+    float4* d = dx + (int64_t)bpu * (C >> 2) + c4;
+    if (accumulate) { const float4 p = *d; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+    *d = o;
+  }
+}
+// x [B][hw][ld], masks [B][hw][nm], v / g [(nm + with_plain) * B][2C] head-major, dx [B][hw][C] dense, arg_ws >= heads * B * C ints
+extern "C" int ppst_gap_gmp_multi_bwd(const void* x, const void* masks, const void* v, const void* g, void* dx, void* arg_ws, int B,
+                                      int64_t hw, int C, int ld, int nm, int with_plain, int accumulate, void* stream) {
+  if (B < 0 || hw <= 0 || hw > 0x7fffffffll || C <= 0 || C % 4 || ld % 4 || ld < C || nm < 1 || nm > 3 ||
+      (with_plain != 0 && with_plain != 1) || hw % GMP_NP)
+    return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !masks || !v || !g || !dx || !arg_ws) return PPST_ENULL;
+  const int64_t total = (int64_t)B * hw * C;
+  if (total > PPST_IDX32_MAX) return PPST_EINVAL;
+  if ((((uintptr_t)x | (uintptr_t)v | (uintptr_t)g | (uintptr_t)dx | (uintptr_t)arg_ws) % 16) != 0) return PPST_EINVAL;
+  const int heads = nm + with_plain;
+  hipError_t e = hipMemsetAsync(arg_ws, 0x7f, (size_t)heads * B * C * sizeof(int), as_stream(stream));
+  if (e != hipSuccess) return (int)e;
+  const int64_t t4 = total / 4, strips = t4 / GMP_NP;
+  PPST_LAUNCH(gmp_argmax_multi4_kernel, dim3(tg_grid(strips)), dim3(256), 0, as_stream(stream), (const float4*)x, (const float*)masks,
+              (const float*)v, (int*)arg_ws, (unsigned)hw, C, ld / 4, nm, with_plain, B, (unsigned)strips, make_fastdiv((unsigned)(C / 4)),
+              make_fastdiv((unsigned)(hw / GMP_NP)));
+  PPST_LAUNCH(gap_gmp_bwd_multi4_kernel, dim3(tg_grid(t4)), dim3(256), 0, as_stream(stream), (const float*)masks, (const int*)arg_ws,
+              (const float*)g, (float4*)dx, (unsigned)hw, C, nm, with_plain, B, accumulate, (unsigned)t4, make_fastdiv((unsigned)(C / 4)),
+              make_fastdiv((unsigned)hw));
+  return PPST_LAUNCH_CHECK();
+}
+
 // ------------------------------------------------------------ row-wise ops ----
 // y = x * s, s = rsqrt(sum x^2 + eps) (mode 0, util.normalize) or 1 / max(||x||, eps) (mode 1, F.normalize):
 // dx = s * (g - y * sum(g*y))   (mode 1 with ||x|| < eps: dx = g / eps)

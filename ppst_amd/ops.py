@@ -1379,6 +1379,40 @@ def gap_gmp_bwd(x, mask, v, g, out=None):
     return out
 
 
+def gap_gmp_multi(x, masks, with_plain=True):
+    """GAP || GMP of x * mask for every channel of ``masks`` (B,H,W,nm) -- and unmasked first when with_plain -- in one read of x:
+    -> ((nm + with_plain) * B, 2C), head-major (ppst_gap_gmp_multi)."""
+    ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    _chk(masks, "masks")
+    masks = masks.contiguous()
+    nm = masks.shape[3]
+    assert tuple(masks.shape[:3]) == (B, H, W) and 1 <= nm <= 3
+    heads = nm + (1 if with_plain else 0)
+    ws = torch.empty(lib.ppst_gap_gmp_multi_ws(B, H * W, C, heads) // 4, device=x.device, dtype=torch.float32)
+    out = torch.empty((heads * B, 2 * C), device=x.device, dtype=torch.float32)
+    check(lib.ppst_gap_gmp_multi(_p(x), _p(masks), _p(out), _p(ws), B, H, W, C, ld, nm, 1 if with_plain else 0, _stream()),
+          "ppst_gap_gmp_multi")
+    return out
+
+
+def gap_gmp_multi_bwd(x, masks, v, g, with_plain=True, out=None):
+    """adjoint of gap_gmp_multi: the sum over the heads, one pass (out given -> accumulate into it)."""
+    ld = _nhwc_ld(x)
+    B, H, W, C = x.shape
+    _chk(masks); _chk(v); _chk(g)
+    masks = masks.contiguous()
+    nm = masks.shape[3]
+    heads = nm + (1 if with_plain else 0)
+    acc = out is not None
+    if out is None:
+        out = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+    arg = torch.empty((heads * B, C), device=x.device, dtype=torch.int32)
+    check(lib.ppst_gap_gmp_multi_bwd(_p(x), _p(masks), _p(v.contiguous()), _p(g.contiguous()), _p(out), ctypes.c_void_p(arg.data_ptr()), B,
+                                     H * W, C, ld, nm, 1 if with_plain else 0, 1 if acc else 0, _stream()), "ppst_gap_gmp_multi_bwd")
+    return out
+
+
 def l2norm_rows_bwd(g, x, eps, mode):
     _chk(g); _chk(x)
     g, x = g.contiguous(), x.contiguous()

@@ -22,7 +22,8 @@ SQRT2 = math.sqrt(2.0)
 INV_SQRT2 = 1.0 / SQRT2
 # tuning switches of the differentiable generator (tests/train_ab.py flips them for same-process A/B timing)
 # "gate": StyledConv's leaky-ReLU gate rides on the norm backward's apply pass (round 5; off while the gate tape records / replays)
-TRAIN_FUSE = {"merge": True, "res_up2": True, "gate": True}
+# "gmp_multi": the four poolings of a feature map (plain + three class masks) as one multi-head launch, forward and backward
+TRAIN_FUSE = {"merge": True, "res_up2": True, "gate": True, "gmp_multi": True}
 HEAD_CH = [(256, 256), (256, 256), (256, 384), (384, 512)]
 UP = [(16, 512, 512), (32, 512, 256), (64, 256, 128)]
 TAGS = ["9", "0", "1", "2"]
@@ -186,14 +187,18 @@ class GeneratorTrainer:
         return A.instance_norm(y, st)
 
     # ------------------------------------------------------------ E2 (encoder_col.py:150-251)
-    def _e2_heads(self, tag, items):
+    def _e2_heads(self, tag, items, pooled=None):
         """The projection head of level ``tag`` (encoder_col.py:162-168, 217-245: GAP || GMP of x * mask -> conv1x1 as a linear ->
         three ReLU + linear projectors -> F.normalize) for several (feature map, mask) pairs at once: the pooled vectors are
         stacked and go through the shared linears as ONE batch -- the same arithmetic per row (the weight gradients sum over rows
         either way), a chain of launches per level instead of one per head (76 heads per generator iteration)."""
         P = self.E2.p
-        vs = [A.GapGmpFn.apply(x, mask) for x, mask in items]
-        v = vs[0] if len(vs) == 1 else torch.cat(vs, 0)
+        if pooled is not None:          # (stacked pooled vectors of n heads, from the multi-head pooling)
+            v, n = pooled
+            vs = [None] * n
+        else:
+            vs = [A.GapGmpFn.apply(x, mask) for x, mask in items]
+            v = vs[0] if len(vs) == 1 else torch.cat(vs, 0)
         v = A.linear(v, P("conv1x1_%s.weight" % tag), P("conv1x1_%s.bias" % tag))
         q = "projector%s." % tag
         for i in (1, 3, 5):
@@ -201,7 +206,7 @@ class GeneratorTrainer:
         v = A.L2NormFn.apply(v, 1e-12, 1)
         if len(vs) == 1:
             return [v]
-        B = vs[0].shape[0]
+        B = v.shape[0] // len(vs)
         return [v[i * B:(i + 1) * B] for i in range(len(vs))]
 
     def encoder_col(self, img, mask=None, corrmatrix=None):
@@ -213,17 +218,29 @@ class GeneratorTrainer:
         levels = net._mask_planes(mask) if mask is not None else None
         sw = net._mask_planes(glue.swap(mask)) if (mask is not None and warped is not None) else None
         vectors, vectors_w, pm, pmw = [], [], [], []
+        from . import gates
+        multi = TRAIN_FUSE["gmp_multi"] and mask is not None and gates.MODE["value"] is None
         for lvl, (t, f) in enumerate(zip(TAGS, feats)):
             # every head of this level in one batch, in the reference's order of use
-            items = [(f, None)]
-            if warped is not None:
-                items.append((warped[lvl], None))
-            if mask is not None:
-                for i in range(3):
-                    items.append((f, levels[lvl][..., i].contiguous()))
-                    if warped is not None:
-                        items.append((warped[lvl], sw[lvl][..., i].contiguous()))
-            out = self._e2_heads(t, items)
+            if multi and (f.shape[1] * f.shape[2]) % 16 == 0:
+                # the four poolings of a map (plain + three class masks) in ONE read of it, their gradients written as one sum
+                B = f.shape[0]
+                vf = A.GapGmpMultiFn.apply(f, levels[lvl])                       # rows [plain | mask 0 | mask 1 | mask 2] x B
+                if warped is not None:
+                    # the reference's order of use alternates map / warped map per head: one interleaving copy, no per-head slices
+                    vw = A.GapGmpMultiFn.apply(warped[lvl], sw[lvl])
+                    vf = torch.stack((vf.view(4, B, -1), vw.view(4, B, -1)), 1).reshape(8 * B, -1)
+                out = self._e2_heads(t, None, pooled=(vf, vf.shape[0] // B))
+            else:
+                items = [(f, None)]
+                if warped is not None:
+                    items.append((warped[lvl], None))
+                if mask is not None:
+                    for i in range(3):
+                        items.append((f, levels[lvl][..., i].contiguous()))
+                        if warped is not None:
+                            items.append((warped[lvl], sw[lvl][..., i].contiguous()))
+                out = self._e2_heads(t, items)
             vectors.append(out[0])
             k = 1
             if warped is not None:

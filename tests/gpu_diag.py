@@ -282,6 +282,46 @@ def t_fuse_tail():
         ops.FUSE_TAIL.update(prev)
 
 
+def t_gmp_multi():
+    """Round 5: the multi-head GAP || GMP (ppst_gap_gmp_multi / _bwd: the plain and the three class-masked poolings of one feature map in
+    one read) against the single-head kernels: forward bit-equal per head, backward = the sum of the four single-head gradients
+    (1e-6: another summation order over the heads), with and without the unmasked head; the fused linear backward (ReLU gate on the
+    input-gradient reduction, relu(x) and the bias column sums inside the weight-gradient launch) against the separate launches."""
+    torch.manual_seed(23)
+    for (B, H, Wd, C) in [(2, 64, 64, 32), (1, 16, 48, 256), (3, 32, 32, 64)]:
+        x = g(torch.randn(B, H, Wd, C))
+        lab = torch.randint(0, 3, (B, H, Wd))
+        masks = g(F.one_hot(lab, 3).float())
+        for plain in (True, False):
+            v = ops.gap_gmp_multi(x, masks, plain)
+            heads = ([None] if plain else []) + [masks[..., i].contiguous() for i in range(3)]
+            ref = torch.cat([ops.gap_gmp(x, m) for m in heads], 0)
+            ok = bool(torch.equal(v, ref))
+            RES.append(("gap_gmp_multi %s plain=%s forward bit-equal to the single-head launches" % ((B, H, Wd, C), plain), ok))
+            print("gap_gmp_multi fwd %s plain=%s %s" % ((B, H, Wd, C), plain, "ok" if ok else "FAIL %.3e" % (v - ref).abs().max().item()), flush=True)
+            gg = g(torch.randn(v.shape))
+            dx = ops.gap_gmp_multi_bwd(x, masks, v, gg, plain)
+            dref = None
+            for h, m in enumerate(heads):
+                dref = ops.gap_gmp_bwd(x, m, ref[h * B:(h + 1) * B], gg[h * B:(h + 1) * B].contiguous(), out=dref)
+            report("gap_gmp_multi %s plain=%s backward vs summed single-head gradients" % ((B, H, Wd, C), plain), dx, dref, 1e-6)
+    for (B, N, K, relu) in [(16, 1024, 32, True), (8, 2048, 1024, True), (4, 512, 2048, False), (32, 2048, 2048, True)]:
+        dy, x, w = g(torch.randn(B, N)), g(torch.randn(B, K)), g(torch.randn(N, K))
+        gate = lambda t: ops.fused_bias_act_raw(t, None, x, 3, 1, 0.0, 1.0)
+        xin = gate(x) if relu else x
+        dw_ref, db_ref = ops.linear_wgrad(dy, xin, 0.37), ops.colsum(dy, 1.5)
+        dw, db = ops.linear_wgrad_fused(dy, x, 0.37, relu_in=relu, want_bias=True, bias_scale=1.5)
+        report("linear_wgrad_fused (%d,%d,%d) relu=%s dW" % (B, N, K, relu), dw, dw_ref, 1e-6)
+        report("linear_wgrad_fused (%d,%d,%d) db" % (B, N, K), db, db_ref, 1e-5)
+        acc_w, acc_b = g(torch.randn(N, K)), g(torch.randn(N))
+        w0, b0 = acc_w.clone(), acc_b.clone()
+        ops.linear_wgrad_fused(dy, x, 0.37, out=acc_w, accumulate=True, relu_in=relu, bias_out=acc_b, bias_scale=1.5, bias_accumulate=True)
+        report("linear_wgrad_fused accumulate dW", acc_w, w0 + dw_ref, 1e-6)
+        report("linear_wgrad_fused accumulate db", acc_b, b0 + db_ref, 1e-5)
+        dx_ref = gate(ops.linear_dgrad(dy, w, 0.5))
+        report("linear_dgrad_gate (%d,%d,%d)" % (B, N, K), ops.linear_dgrad_gate(dy, w, x, 0.5), dx_ref, 1e-6)
+
+
 def t_layout_misc():
     torch.manual_seed(1)
     for (B, C, H, Wd) in [(2, 3, 17, 19), (1, 32, 64, 64), (2, 70, 9, 33)]:
@@ -1491,6 +1531,8 @@ def main():
     if which == "opshalf":
         run(t_ops_half)
         run(t_ops_f64)
+    if which == "gmp":
+        run(t_gmp_multi)
     if which == "tail":
         run(t_fuse_tail)
     if which == "up9":
