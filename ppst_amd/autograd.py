@@ -329,7 +329,14 @@ class InstanceNormFn(Function):
         part = ops.dual_stats(g, y, gate)
         want = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         coef, dstyle = ops.in_bwd_finalize(part, H * W, mr, style, want_dstyle=want)
-        dy = ops.in_bwd_apply(g, y, coef, gate=gate, post_gate=ctx.post_gate) if ctx.needs_input_grad[0] else None
+        dy = None
+        if ctx.needs_input_grad[0]:
+            if ctx.post_gate and gates.MODE["value"] is not None:
+                # gate tape recording / replaying (decided at BACKWARD time: the tape is switched on around backward()): the
+                # producer's leaky-ReLU gate goes through the tape exactly where ConvFn's own gate pass would have put it
+                dy = lrelu_bwd(ops.in_bwd_apply(g, y, coef, gate=gate), y)
+            else:
+                dy = ops.in_bwd_apply(g, y, coef, gate=gate, post_gate=ctx.post_gate)
         dpb = None
         if ctx.needs_input_grad[3]:
             (post_bias,) = ctx.refs
@@ -446,7 +453,15 @@ class GapGmpMultiFn(Function):
     @staticmethod
     def backward(ctx, g):
         x, masks, v = ctx.saved_tensors
-        return ops.gap_gmp_multi_bwd(x, masks, v, _c(g), True), None
+        g = _c(g)
+        if gates.MODE["value"] is not None:
+            # gate tape (switched on around backward()): the arg-max of every head goes through the tape like GapGmpFn's, head by head
+            B, dx = x.shape[0], None
+            for h in range(4):
+                xh, vh = gates.values("gmp-argmax", x, v[h * B:(h + 1) * B].contiguous())
+                dx = ops.gap_gmp_bwd(xh, None if h == 0 else masks[..., h - 1].contiguous(), vh, g[h * B:(h + 1) * B].contiguous(), out=dx)
+            return dx, None
+        return ops.gap_gmp_multi_bwd(x, masks, v, g, True), None
 
 
 class LinearFn(Function):

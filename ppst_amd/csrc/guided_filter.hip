@@ -615,6 +615,172 @@ __global__ __launch_bounds__(256) void gf_v2_final_slide_kernel(const float* __r
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 5: the radius-30 filter in TWO launches that keep every box sum on the chip (round-4 verdict: 439 B / pixel of HBM traffic
+// by counter against 9 B / pixel algorithmic -- the three-launch form hands 21 + 12 fp32 planes through HBM and re-reads them).
+//   gf_s1_fused_kernel: a block owns GS_WC = 192 output columns (+ RR on both sides = 252 of its 256 threads) and GS_VS1 rows.  Thread =
+//     column: its 21 vertical window sums live in REGISTERS and slide down the rows (the entering / leaving row's moments formed from
+//     the 6 uint8 bytes of the pixel, exact uint32); per row the 252 column sums go to LDS, 21 x 12 threads slide the horizontal
+//     window over 16-output segments (exact uint32), the window sums go back to LDS and thread = pixel solves its 3x3 system.
+//     Only (a, b) leave the kernel -- as 12 IEEE-half planes (24 B / pixel; they feed a 61 x 61 mean): each thread carries the
+//     rounding residual of every value down its column (error diffusion), so a vertical window sum of the stored halves differs from
+//     the fp32 sum by at most the two end residuals -- not 61 correlated roundings (a flat image region rounds every b alike).
+//   gf_s2_fused_kernel: the same structure over the 12 half planes (fp32 sums, sliding with the bounded drift of the round-4
+//     passes), ending in q = mean(a) . I + mean(b), rounded to uint8 like cv2 (saturate_cast<uchar>(cvRound)).
+// HBM traffic per pixel: 6 B x halo factors in, 24 out; 24 x (1.31 columns x (VS2 + 60) / VS2 rows) in, 3 guide, 12 (+ 3) out.
+// Same stage-1 integers as the three-launch form, so the same (a, b) before their rounding to half.
+#define GS_WC 192
+#define GS_NSEG (GS_WC / GF_SEG)
+template <int RR, int VS>
+__global__ __launch_bounds__(256) void gf_s1_fused_kernel(const unsigned char* __restrict__ guide, const unsigned char* __restrict__ src,
+                                                          unsigned short* __restrict__ ab, int H, int W, float eps) {
+  static_assert(GS_WC + 2 * RR <= 256 && GS_WC % GF_SEG == 0 && 21 * GS_NSEG <= 256, "strip geometry");
+  __shared__ unsigned col[21][GF_ROW(256) + 1];
+  __shared__ unsigned win[21][GF_ROW(GS_WC) + 1];
+  const int t = threadIdx.x, x0 = blockIdx.x * GS_WC, y0 = blockIdx.y * VS, b = blockIdx.z;
+  const int64_t P = (int64_t)H * W;
+  const int xc = reflect_idx(min(x0 - RR + t, W - 1 + RR), W);          // (columns past the image's reflected margin are never used)
+  const unsigned char* gp = guide + ((int64_t)b * P + xc) * 3;
+  const unsigned char* sp = src + ((int64_t)b * P + xc) * 3;
+  unsigned cs[21];
+#pragma unroll
+  for (int pl = 0; pl < 21; ++pl) cs[pl] = 0;
+  auto row = [&](int y, bool add) __attribute__((always_inline)) {
+    const int64_t o = (int64_t)reflect_idx(y, H) * W * 3;
+    const unsigned I0 = gp[o], I1 = gp[o + 1], I2 = gp[o + 2], P0 = sp[o], P1 = sp[o + 1], P2 = sp[o + 2];
+#define GFM(a_, b_) ((unsigned)__umul24(a_, b_))
+    const unsigned m[21] = {I0, I1, I2, P0, P1, P2, GFM(I0, I0), GFM(I0, I1), GFM(I0, I2), GFM(I1, I1), GFM(I1, I2), GFM(I2, I2),
+                            GFM(I0, P0), GFM(I1, P0), GFM(I2, P0), GFM(I0, P1), GFM(I1, P1), GFM(I2, P1), GFM(I0, P2), GFM(I1, P2), GFM(I2, P2)};
+#undef GFM
+#pragma unroll
+    for (int pl = 0; pl < 21; ++pl) cs[pl] = add ? cs[pl] + m[pl] : cs[pl] - m[pl];
+  };
+  for (int k = -RR; k <= RR; ++k) row(y0 + k, true);
+  const int y1 = min(y0 + VS, H);
+  const int ipl = t % 21, iseg = t / 21;                                 // horizontal item of this thread: (plane, 16-output segment)
+  const bool pix_ok = t < GS_WC && x0 + t < W;
+  const float inv = 1.f / (float)((2 * RR + 1) * (2 * RR + 1));
+  float res[12];                                                         // rounding residuals carried down the column
+#pragma unroll
+  for (int i = 0; i < 12; ++i) res[i] = 0.f;
+  unsigned short* op = ab + (int64_t)b * 12 * P + x0 + t;
+  for (int y = y0; y < y1; ++y) {
+#pragma unroll
+    for (int pl = 0; pl < 21; ++pl) col[pl][GF_ROW(t)] = cs[pl];
+    __syncthreads();
+    if (iseg < GS_NSEG) {
+      const unsigned* r = col[ipl];
+      unsigned* wv = win[ipl];
+      const int j0 = iseg * GF_SEG;
+      unsigned sum = 0;
+      for (int k = 0; k <= 2 * RR; ++k) sum += r[GF_ROW(j0 + k)];
+      wv[GF_ROW(j0)] = sum;
+#pragma unroll
+      for (int j = 1; j < GF_SEG; ++j) {
+        sum += r[GF_ROW(j0 + j + 2 * RR)] - r[GF_ROW(j0 + j - 1)];
+        wv[GF_ROW(j0 + j)] = sum;
+      }
+    }
+    __syncthreads();
+    if (pix_ok) {
+      float m[21];
+#pragma unroll
+      for (int pl = 0; pl < 21; ++pl) m[pl] = (float)win[pl][GF_ROW(t)] * inv;
+      const float mI0 = m[0], mI1 = m[1], mI2 = m[2];
+      const float a00 = m[6] - mI0 * mI0 + eps, a01 = m[7] - mI0 * mI1, a02 = m[8] - mI0 * mI2;
+      const float a11 = m[9] - mI1 * mI1 + eps, a12 = m[10] - mI1 * mI2, a22 = m[11] - mI2 * mI2 + eps;
+      const float c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+      const float c11 = a00 * a22 - a02 * a02, c12 = a02 * a01 - a00 * a12, c22 = a00 * a11 - a01 * a01;
+      const float det = a00 * c00 + a01 * c01 + a02 * c02;
+      const float i00 = c00 / det, i01 = c01 / det, i02 = c02 / det, i11 = c11 / det, i12 = c12 / det, i22 = c22 / det;
+      float v[12];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float mp_c = m[3 + c];
+        const float cp0 = m[12 + c * 3 + 0] - mI0 * mp_c, cp1 = m[12 + c * 3 + 1] - mI1 * mp_c, cp2 = m[12 + c * 3 + 2] - mI2 * mp_c;
+        v[c * 4 + 0] = i00 * cp0 + i01 * cp1 + i02 * cp2;
+        v[c * 4 + 1] = i01 * cp0 + i11 * cp1 + i12 * cp2;
+        v[c * 4 + 2] = i02 * cp0 + i12 * cp1 + i22 * cp2;
+        v[c * 4 + 3] = mp_c - v[c * 4 + 0] * mI0 - v[c * 4 + 1] * mI1 - v[c * 4 + 2] * mI2;
+      }
+      const int64_t po = (int64_t)y * W;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const float want = v[i] + res[i];
+        const _Float16 h = (_Float16)want;
+        res[i] = want - (float)h;
+        op[i * P + po] = __builtin_bit_cast(unsigned short, h);
+      }
+    }
+    if (y + 1 < y1) {
+      row(y + 1 + RR, true);
+      row(y - RR, false);
+    }
+  }
+}
+
+template <int RR, int VS>
+__global__ __launch_bounds__(256) void gf_s2_fused_kernel(const unsigned short* __restrict__ ab, const unsigned char* __restrict__ guide,
+                                                          float* __restrict__ out, unsigned char* __restrict__ out_u8, int H, int W) {
+  __shared__ float col[12][GF_ROW(256) + 1];
+  __shared__ float win[12][GF_ROW(GS_WC) + 1];
+  const int t = threadIdx.x, x0 = blockIdx.x * GS_WC, y0 = blockIdx.y * VS, b = blockIdx.z;
+  const int64_t P = (int64_t)H * W;
+  const int xc = reflect_idx(min(x0 - RR + t, W - 1 + RR), W);
+  const unsigned short* in = ab + (int64_t)b * 12 * P + xc;
+  auto ld = [&](int i, int64_t ro) -> float { return (float)__builtin_bit_cast(_Float16, in[i * P + ro]); };
+  float s[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = 0.f;
+  for (int k = -RR; k <= RR; ++k) {
+    const int64_t ro = (int64_t)reflect_idx(y0 + k, H) * W;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] += ld(i, ro);
+  }
+  const int y1 = min(y0 + VS, H);
+  const int ipl = t % 12, iseg = t / 12;
+  const bool pix_ok = t < GS_WC && x0 + t < W;
+  const float inv = 1.f / (float)((2 * RR + 1) * (2 * RR + 1));
+  for (int y = y0; y < y1; ++y) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) col[i][GF_ROW(t)] = s[i];
+    __syncthreads();
+    if (iseg < GS_NSEG) {
+      const float* r = col[ipl];
+      float* wv = win[ipl];
+      const int j0 = iseg * GF_SEG;
+      float sum = 0.f;
+      for (int k = 0; k <= 2 * RR; ++k) sum += r[GF_ROW(j0 + k)];
+      wv[GF_ROW(j0)] = sum;
+#pragma unroll
+      for (int j = 1; j < GF_SEG; ++j) {
+        sum += r[GF_ROW(j0 + j + 2 * RR)] - r[GF_ROW(j0 + j - 1)];
+        wv[GF_ROW(j0 + j)] = sum;
+      }
+    }
+    __syncthreads();
+    if (pix_ok) {
+      const int x = x0 + t;
+      const unsigned char* g = guide + (((int64_t)b * H + y) * W + x) * 3;
+      const float I0 = g[0], I1 = g[1], I2 = g[2];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float qv = (win[c * 4][GF_ROW(t)] * inv) * I0 + (win[c * 4 + 1][GF_ROW(t)] * inv) * I1 + (win[c * 4 + 2][GF_ROW(t)] * inv) * I2 +
+                         win[c * 4 + 3][GF_ROW(t)] * inv;
+        const float rq = fminf(fmaxf(rintf(qv), 0.f), 255.f);
+        if (out_u8) out_u8[(((int64_t)b * H + y) * W + x) * 3 + c] = (unsigned char)rq;
+        if (out) out[((int64_t)b * 3 + c) * P + (int64_t)y * W + x] = (rq / 255.0f - 0.5f) * 2.f;  // ToTensor, (x-0.5)*2 (ppst_model.py:301-303)
+      }
+    }
+    if (y + 1 < y1) {
+      const int64_t rin = (int64_t)reflect_idx(y + 1 + RR, H) * W, rout = (int64_t)reflect_idx(y - RR, H) * W;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) s[i] += ld(i, rin) - ld(i, rout);
+    }
+  }
+}
+
 extern "C" int64_t ppst_guided_filter_ws(int B, int H, int W) { return (int64_t)B * 42 * H * W * (int64_t)sizeof(float); }
 
 extern "C" int ppst_guided_filter(const void* guide_u8, const void* src_u8, void* out, void* out_u8, int B, int H, int W, int r,
@@ -630,6 +796,21 @@ extern "C" int ppst_guided_filter(const void* guide_u8, const void* src_u8, void
   const unsigned char* s = (const unsigned char*)src_u8;
   auto blocks_for = [](int64_t total) { int64_t b = cdiv64(total, 256); return (unsigned)(b > 256 * 32 ? 256 * 32 : b); };
   int e;
+#ifndef GF_THREE_LAUNCH   // (round 4's three-launch form: kept for A/B behind -DGF_THREE_LAUNCH)
+  if (r == 30) {       // the path's radius (photo_gif.py:43): two fused launches, box sums kept on the chip (round 5)
+    unsigned short* abh = (unsigned short*)work;            // [B][12][P] IEEE half
+    PPST_LAUNCH((gf_s1_fused_kernel<30, 64>), dim3(cdiv(W, GS_WC), cdiv(H, 64), B), dim3(256), 0, st, g, s, abh, H, W, eps);
+    if ((e = PPST_LAUNCH_CHECK())) return e;
+    // rows per block of stage 2: 128 (halo re-read factor 1.47) when that still gives two blocks per CU, else 64
+    if ((int64_t)cdiv(W, GS_WC) * cdiv(H, 128) * B >= 512)
+      PPST_LAUNCH((gf_s2_fused_kernel<30, 128>), dim3(cdiv(W, GS_WC), cdiv(H, 128), B), dim3(256), 0, st, (const unsigned short*)abh, g,
+                  (float*)out, (unsigned char*)out_u8, H, W);
+    else
+      PPST_LAUNCH((gf_s2_fused_kernel<30, 64>), dim3(cdiv(W, GS_WC), cdiv(H, 64), B), dim3(256), 0, st, (const unsigned short*)abh, g,
+                  (float*)out, (unsigned char*)out_u8, H, W);
+    return PPST_LAUNCH_CHECK();
+  }
+#endif
   if (r == 30) {       // the path's radius (photo_gif.py:43): sliding-window passes (round 4)
 #ifdef GF_STAGE1_HV      // (the first sliding form: H pass over the moments, then V pass + solve; kept for A/B)
     PPST_LAUNCH(gf_h1_slide_kernel<30>, dim3(H, cdiv(W, GF_HCW), B), dim3(256), 0, st, g, s, bufA, H, W);

@@ -218,8 +218,7 @@ class GeneratorTrainer:
         levels = net._mask_planes(mask) if mask is not None else None
         sw = net._mask_planes(glue.swap(mask)) if (mask is not None and warped is not None) else None
         vectors, vectors_w, pm, pmw = [], [], [], []
-        from . import gates
-        multi = TRAIN_FUSE["gmp_multi"] and mask is not None and gates.MODE["value"] is None
+        multi = TRAIN_FUSE["gmp_multi"] and mask is not None      # (under the gate tape its backward walks the heads one by one)
         for lvl, (t, f) in enumerate(zip(TAGS, feats)):
             # every head of this level in one batch, in the reference's order of use
             if multi and (f.shape[1] * f.shape[2]) % 16 == 0:
@@ -290,8 +289,7 @@ class GeneratorTrainer:
             B, H, W = x.shape[0], x.shape[1] * (2 if upsample else 1), x.shape[2] * (2 if upsample else 1)
             nz = torch.randn(B, 1, H, W, device=x.device)          # NoiseInjection draws N(0,1) (stylegan2_layers.py:388-390)
         wn = p + "conv.weight"
-        from . import gates
-        fuse_gate = TRAIN_FUSE["gate"] and gates.MODE["value"] is None     # (`a` has exactly one consumer: the norm below)
+        fuse_gate = TRAIN_FUSE["gate"]     # (`a` has exactly one consumer: the norm below; under the gate tape the norm's backward runs the gate pass itself)
         a, st = A.conv(x, P(wn), net, wn, bias=bias, kind=kind, act=A.LRELU, noise_w=P(p + "noise.weight"), noise=nz.contiguous(), stats=True,
                        noise_w_host=self.fp["G"].scalar(p + "noise.weight"), bias_params=bias_params, gate_downstream=fuse_gate)
         wl = P(p + "epi1.style_mod.lin.weight")
