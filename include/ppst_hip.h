@@ -502,6 +502,10 @@ int ppst_tensor2im_u8(const void* x, void* y, int B, int C, int H, int W, void* 
 int64_t ppst_guided_filter_ws(int B, int H, int W);
 int ppst_guided_filter(const void* guide_u8, const void* src_u8, void* out, void* out_u8,
                        int B, int H, int W, int r, float eps, void* work, void* stream);
+/* tuning aid (process-wide, diagnostic like ppst_prof_enable): rows per block of the two fused launches of the radius-30 filter;
+ * 0 = the library's rule, 32 / 64 (/ 128 for the second) = forced.  Results do not depend on it beyond the rounding of the sliding
+ * fp32 sums of the second launch. */
+int ppst_guided_filter_tune(int vs1, int vs2);
 
 /* local-affine photo smoothing (smooth_filter.py:332-378 smooth_local_affine and its three NVRTC kernels :149-321):
  * output (stylised), input (content = guide), result: planar fp32 [B][3][H][W]; model_ws: >= ppst_smooth_local_affine_ws()

@@ -59,6 +59,7 @@ class ConvArgs(ctypes.Structure):
 
 _SIGS = {
     "ppst_version": (i32, []),
+    "ppst_guided_filter_tune": (i32, [i32, i32]),
     "ppst_upfirdn2d": (i32, [vp, vp, vp] + [i32] * 14 + [i32, vp]),
     "ppst_blur_nhwc": (i32, [vp, vp, vp] + [i32] * 10 + [vp, i32, vp]),
     "ppst_blur_nhwc_st": (i32, [vp, vp, vp] + [i32] * 10 + [vp, i32, i32, vp]),

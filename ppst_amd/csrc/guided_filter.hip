@@ -646,9 +646,13 @@ __global__ __launch_bounds__(256) void gf_s1_fused_kernel(const unsigned char* _
   unsigned cs[21];
 #pragma unroll
   for (int pl = 0; pl < 21; ++pl) cs[pl] = 0;
-  auto row = [&](int y, bool add) __attribute__((always_inline)) {
+  struct Px { unsigned I0, I1, I2, P0, P1, P2; };
+  auto fetch = [&](int y) __attribute__((always_inline)) -> Px {
     const int64_t o = (int64_t)reflect_idx(y, H) * W * 3;
-    const unsigned I0 = gp[o], I1 = gp[o + 1], I2 = gp[o + 2], P0 = sp[o], P1 = sp[o + 1], P2 = sp[o + 2];
+    return Px{gp[o], gp[o + 1], gp[o + 2], sp[o], sp[o + 1], sp[o + 2]};
+  };
+  auto apply = [&](const Px& q, bool add) __attribute__((always_inline)) {
+    const unsigned I0 = q.I0, I1 = q.I1, I2 = q.I2, P0 = q.P0, P1 = q.P1, P2 = q.P2;
 #define GFM(a_, b_) ((unsigned)__umul24(a_, b_))
     const unsigned m[21] = {I0, I1, I2, P0, P1, P2, GFM(I0, I0), GFM(I0, I1), GFM(I0, I2), GFM(I1, I1), GFM(I1, I2), GFM(I2, I2),
                             GFM(I0, P0), GFM(I1, P0), GFM(I2, P0), GFM(I0, P1), GFM(I1, P1), GFM(I2, P1), GFM(I0, P2), GFM(I1, P2), GFM(I2, P2)};
@@ -656,7 +660,7 @@ __global__ __launch_bounds__(256) void gf_s1_fused_kernel(const unsigned char* _
 #pragma unroll
     for (int pl = 0; pl < 21; ++pl) cs[pl] = add ? cs[pl] + m[pl] : cs[pl] - m[pl];
   };
-  for (int k = -RR; k <= RR; ++k) row(y0 + k, true);
+  for (int k = -RR; k <= RR; ++k) apply(fetch(y0 + k), true);
   const int y1 = min(y0 + VS, H);
   const int ipl = t % 21, iseg = t / 21;                                 // horizontal item of this thread: (plane, 16-output segment)
   const bool pix_ok = t < GS_WC && x0 + t < W;
@@ -666,6 +670,11 @@ __global__ __launch_bounds__(256) void gf_s1_fused_kernel(const unsigned char* _
   for (int i = 0; i < 12; ++i) res[i] = 0.f;
   unsigned short* op = ab + (int64_t)b * 12 * P + x0 + t;
   for (int y = y0; y < y1; ++y) {
+    // the bytes of the entering / leaving rows are requested here, ahead of the two LDS phases (a barrier is a fence: hipcc does not
+    // move the loads up by itself), and used at the bottom of the iteration.  (Requested a whole iteration earlier still -- two sets in
+    // flight -- the kernel was SLOWER, 0.36 -> 0.44 ms per batch: the extra registers cost a resident block per CU, and three co-resident
+    // blocks hide the latency better than a deeper prefetch in two.)
+    const Px pin = fetch(min(y + 1 + RR, H - 1 + RR)), pout = fetch(y - RR);
 #pragma unroll
     for (int pl = 0; pl < 21; ++pl) col[pl][GF_ROW(t)] = cs[pl];
     __syncthreads();
@@ -693,7 +702,8 @@ __global__ __launch_bounds__(256) void gf_s1_fused_kernel(const unsigned char* _
       const float c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
       const float c11 = a00 * a22 - a02 * a02, c12 = a02 * a01 - a00 * a12, c22 = a00 * a11 - a01 * a01;
       const float det = a00 * c00 + a01 * c01 + a02 * c02;
-      const float i00 = c00 / det, i01 = c01 / det, i02 = c02 / det, i11 = c11 / det, i12 = c12 / det, i22 = c22 / det;
+      const float rdet = 1.f / det;          // (one division: the three-launch form's six differ from it in the last bit)
+      const float i00 = c00 * rdet, i01 = c01 * rdet, i02 = c02 * rdet, i11 = c11 * rdet, i12 = c12 * rdet, i22 = c22 * rdet;
       float v[12];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -714,8 +724,8 @@ __global__ __launch_bounds__(256) void gf_s1_fused_kernel(const unsigned char* _
       }
     }
     if (y + 1 < y1) {
-      row(y + 1 + RR, true);
-      row(y - RR, false);
+      apply(pin, true);
+      apply(pout, false);
     }
   }
 }
@@ -743,6 +753,12 @@ __global__ __launch_bounds__(256) void gf_s2_fused_kernel(const unsigned short* 
   const bool pix_ok = t < GS_WC && x0 + t < W;
   const float inv = 1.f / (float)((2 * RR + 1) * (2 * RR + 1));
   for (int y = y0; y < y1; ++y) {
+    unsigned short din[12], dout[12];      // entering / leaving row (raw halves), requested ahead of the two LDS phases
+    {
+      const int64_t rin = (int64_t)reflect_idx(min(y + 1 + RR, H - 1 + RR), H) * W, rout = (int64_t)reflect_idx(y - RR, H) * W;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) { din[i] = in[i * P + rin]; dout[i] = in[i * P + rout]; }
+    }
 #pragma unroll
     for (int i = 0; i < 12; ++i) col[i][GF_ROW(t)] = s[i];
     __syncthreads();
@@ -774,12 +790,14 @@ __global__ __launch_bounds__(256) void gf_s2_fused_kernel(const unsigned short* 
       }
     }
     if (y + 1 < y1) {
-      const int64_t rin = (int64_t)reflect_idx(y + 1 + RR, H) * W, rout = (int64_t)reflect_idx(y - RR, H) * W;
 #pragma unroll
-      for (int i = 0; i < 12; ++i) s[i] += ld(i, rin) - ld(i, rout);
+      for (int i = 0; i < 12; ++i) s[i] += (float)__builtin_bit_cast(_Float16, din[i]) - (float)__builtin_bit_cast(_Float16, dout[i]);
     }
   }
 }
+
+static int g_gf_vs1 = 0, g_gf_vs2 = 0;      // tuning aid: rows per block of the two fused launches (0 = the rule below; 32 / 64 / 128 = forced)
+extern "C" int ppst_guided_filter_tune(int vs1, int vs2) { g_gf_vs1 = vs1; g_gf_vs2 = vs2; return PPST_OK; }
 
 extern "C" int64_t ppst_guided_filter_ws(int B, int H, int W) { return (int64_t)B * 42 * H * W * (int64_t)sizeof(float); }
 
@@ -799,11 +817,19 @@ extern "C" int ppst_guided_filter(const void* guide_u8, const void* src_u8, void
 #ifndef GF_THREE_LAUNCH   // (round 4's three-launch form: kept for A/B behind -DGF_THREE_LAUNCH)
   if (r == 30) {       // the path's radius (photo_gif.py:43): two fused launches, box sums kept on the chip (round 5)
     unsigned short* abh = (unsigned short*)work;            // [B][12][P] IEEE half
-    PPST_LAUNCH((gf_s1_fused_kernel<30, 64>), dim3(cdiv(W, GS_WC), cdiv(H, 64), B), dim3(256), 0, st, g, s, abh, H, W, eps);
+    // rows per block: 32 in the first launch (its halo re-reads are uint8 rows: 6 B / pixel each), 64 in the second (24 B / pixel each).
+    // Measured, batch of four 1024^2 images (tests/gf_prof.sh): (64, 64) 0.36 ms, (32, 64) 0.33 ms, (32, 32) 0.30 ms with 1.25x the traffic,
+    // (64, 128) 0.44 ms -- three co-resident blocks per CU (768 blocks) are what hides the per-row latency.
+    const int vs1 = g_gf_vs1 ? g_gf_vs1 : 32;
+    if (vs1 == 32) PPST_LAUNCH((gf_s1_fused_kernel<30, 32>), dim3(cdiv(W, GS_WC), cdiv(H, 32), B), dim3(256), 0, st, g, s, abh, H, W, eps);
+    else PPST_LAUNCH((gf_s1_fused_kernel<30, 64>), dim3(cdiv(W, GS_WC), cdiv(H, 64), B), dim3(256), 0, st, g, s, abh, H, W, eps);
     if ((e = PPST_LAUNCH_CHECK())) return e;
-    // rows per block of stage 2: 128 (halo re-read factor 1.47) when that still gives two blocks per CU, else 64
-    if ((int64_t)cdiv(W, GS_WC) * cdiv(H, 128) * B >= 512)
+    const int vs2 = g_gf_vs2 ? g_gf_vs2 : 64;
+    if (vs2 == 128)
       PPST_LAUNCH((gf_s2_fused_kernel<30, 128>), dim3(cdiv(W, GS_WC), cdiv(H, 128), B), dim3(256), 0, st, (const unsigned short*)abh, g,
+                  (float*)out, (unsigned char*)out_u8, H, W);
+    else if (vs2 == 32)
+      PPST_LAUNCH((gf_s2_fused_kernel<30, 32>), dim3(cdiv(W, GS_WC), cdiv(H, 32), B), dim3(256), 0, st, (const unsigned short*)abh, g,
                   (float*)out, (unsigned char*)out_u8, H, W);
     else
       PPST_LAUNCH((gf_s2_fused_kernel<30, 64>), dim3(cdiv(W, GS_WC), cdiv(H, 64), B), dim3(256), 0, st, (const unsigned short*)abh, g,

@@ -3,6 +3,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ppst_amd import ops
+from ppst_amd._lib import lib
+if os.environ.get("GF_VS"):          # "vs1,vs2": rows per block of the two fused launches
+    lib.ppst_guided_filter_tune(*[int(v) for v in os.environ["GF_VS"].split(",")])
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 g = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, device="cuda")
