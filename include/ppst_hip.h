@@ -640,9 +640,9 @@ int ppst_gap_gmp_bwd(const void* x, const void* mask, const void* v, const void*
  * ws: ppst_gap_gmp_multi_ws bytes; arg_ws: (nm + with_plain) * B * C ints. */
 int64_t ppst_gap_gmp_multi_ws(int B, int64_t hw, int C, int heads);
 int ppst_gap_gmp_multi(const void* x, const void* masks, void* out, void* ws, int B, int H, int W, int C, int ld, int nm,
-                       int with_plain, void* stream);
+                       int with_plain, int x_st, void* stream);
 int ppst_gap_gmp_multi_bwd(const void* x, const void* masks, const void* v, const void* g, void* dx, void* arg_ws, int B, int64_t hw,
-                           int C, int ld, int nm, int with_plain, int accumulate, void* stream);
+                           int C, int ld, int nm, int with_plain, int accumulate, int st /* x and dx */, void* stream);
 /* backward of ppst_l2norm_rows (mode 0: util.normalize, 1: F.normalize), ppst_softmax_rows (in place on g) and
  * ppst_corr_prep (ppst_model.py:343-356) */
 int ppst_l2norm_rows_bwd(const void* g, const void* x, void* dx, int B, int K, float eps, int mode, void* stream);
@@ -680,6 +680,36 @@ int ppst_prof_collect(double* ms, int64_t* launches, double* flop);
 int ppst_prof_detail(int idx, double* ms, double* flop, int32_t* info);
 /* profiling only: number of steps of the NEXT weight-gradient launch that carry real weights (default: all of them) */
 int ppst_wgrad_flop_steps(int flop_steps);
+
+/* ---- Round 5: half-precision storage of the TRAINING activations and their gradients (precision mode 1: BASELINE configs[3]'s
+ * "bf16" -- the accuracy class of bf16 autocast, where conv outputs and their gradients are bfloat16 tensors).  `_st` twins of the
+ * backward kernels: ``st`` = the storage type (PPST_ST_*) of every ACTIVATION-shaped tensor of the call (inputs, gradients, outputs);
+ * partial sums, coefficient tables, parameter gradients and pooled vectors stay fp32.  Arithmetic in fp32, one rounding at the store
+ * (the contract of the forward `_st` kernels).  With st = PPST_ST_F32 each IS its plain form.  Half tensors: C and every leading
+ * dimension a multiple of 4, 8-byte aligned. */
+int ppst_dual_stats_st(const void* g, const void* y, const void* gate, void* partial, int B, int64_t hw, int C, int g_ld, int y_ld,
+                       int gate_ld, int* n_partials, int st, void* stream);
+int ppst_in_bwd_apply_st(const void* g, const void* y, const void* gate, const void* coef, void* dx, int B, int64_t hw, int C, int g_ld,
+                         int y_ld, int gate_ld, int dx_ld, int post_gate, int st, void* stream);
+int ppst_pad2d_st(const void* x, void* y, int B, int H, int W, int C, int x_ld, int py0, int py1, int px0, int px1, int mode, int st,
+                  void* stream);
+int ppst_pad2d_bwd_st(const void* dy, void* dx, int B, int H, int W, int C, int py0, int py1, int px0, int px1, int mode, int st,
+                      void* stream);
+int ppst_bilinear_bwd_st(const void* dy, void* dx, int B, int H, int W, int C, int dx_ld, int OH, int OW, int dy_ld, int st, void* stream);
+int ppst_gap_gmp_bwd_st(const void* x, const void* mask, const void* v, const void* g, void* dx, void* arg_ws, int B, int64_t hw, int C,
+                        int ld, int accumulate, int st, void* stream);          /* st: x and dx */
+int ppst_noise_wgrad_st(const void* dpre, const void* noise, void* out, void* ws, int64_t npix, int C, int ld, int accumulate, int st,
+                        void* stream);                                          /* st: dpre */
+int ppst_space_to_depth_st(const void* x, void* y, int B, int H, int W, int C, int x_ld, int st, void* stream);
+int ppst_colsum_st(const void* x, void* out, void* ws, int64_t rows, int C, int ld, float scale, int accumulate, int st, void* stream);
+int ppst_wgrad_small_cin_st(const void* x, const void* dy, void* dw, void* ws, int64_t npix, int cin, int in_ld, int cout, float scale,
+                            int accumulate, int dy_st, void* stream);           /* x stays fp32 (the image / RGB gradient) */
+/* ppst_conv_wgrad_tr2 on bf16-STORED operands (st = PPST_ST_BF16, passes = 1 only): the tiles arrive as the MFMA operand type by
+ * LDS-DMA -- half the bytes of the fp32 tiles, no conversion pass, double-buffered images (conv_wgrad_tr2b_kernel).  cout, in_ld and
+ * dy_ld multiples of 8, x / dy 16-byte aligned.  partial / csum as ppst_conv_wgrad_tr2. */
+int ppst_conv_wgrad_tr2_st(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial, void* csum, int B,
+                           int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps, int nchunks, int splits,
+                           int max_taps, int min_taps, int halo, int passes, int st, void* stream);
 
 #ifdef __cplusplus
 }

@@ -156,8 +156,19 @@ _SIGS = {
     "ppst_avgpool_bwd": (i32, [vp, vp] + [i32] * 7 + [vp]),
     "ppst_gap_gmp_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp]),
     "ppst_gap_gmp_multi_ws": (i64, [i32, i64, i32, i32]),
-    "ppst_gap_gmp_multi": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "ppst_gap_gmp_multi_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp]),
+    "ppst_gap_gmp_multi": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ppst_gap_gmp_multi_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, i32, vp]),
+    "ppst_gap_gmp_bwd_st": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]),
+    "ppst_dual_stats_st": (i32, [vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, ctypes.POINTER(i32), i32, vp]),
+    "ppst_in_bwd_apply_st": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ppst_pad2d_st": (i32, [vp, vp] + [i32] * 11 + [vp]),
+    "ppst_pad2d_bwd_st": (i32, [vp, vp] + [i32] * 10 + [vp]),
+    "ppst_bilinear_bwd_st": (i32, [vp, vp] + [i32] * 9 + [vp]),
+    "ppst_noise_wgrad_st": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "ppst_space_to_depth_st": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ppst_colsum_st": (i32, [vp, vp, vp, i64, i32, i32, f32, i32, i32, vp]),
+    "ppst_wgrad_small_cin_st": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, i32, vp]),
+    "ppst_conv_wgrad_tr2_st": (i32, [vp, vp, vp, vp, vp, vp] + [i32] * 16 + [vp]),
     "ppst_l2norm_rows_bwd": (i32, [vp, vp, vp, i32, i32, f32, i32, vp]),
     "ppst_softmax_rows_bwd": (i32, [vp, vp, i64, i32, f32, vp]),
     "ppst_corr_prep_bwd": (i32, [vp, vp, vp, i64, i32, i32, f32, vp]),

@@ -23,6 +23,14 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _gl(g, like):
+    """an incoming gradient, contiguous and in the STORAGE TYPE of the tensor it belongs to (round 5: the training activations of
+    precision mode 1 are bfloat16; a gradient that arrives from an fp32 island -- a loss, the 3-channel image, a pooled vector -- is
+    rounded once here)"""
+    g = g if g.dtype == like.dtype else g.to(like.dtype)
+    return g if g.is_contiguous() else g.contiguous()
+
+
 def lrelu_bwd(g, out, scale=1.0):
     """d/d(pre-activation) of y = lrelu(x)*sqrt2 given d/dy, gated by the sign of the saved output
     (fused_bias_act_kernel.cu:43)."""
@@ -143,7 +151,7 @@ class ConvFn(Function):
         x, y, noise = ctx.saved_tensors
         net, wname, kind, scale, pad_mode, act, has_b, has_n = ctx.cfg
         w, bias, noise_w, bias_params = ctx.refs
-        g = _c(g)
+        g = _gl(g, x)
         gpre = lrelu_bwd(g, y) if (act == LRELU and not ctx.gate_downstream) else g
         C = gpre.shape[3]
         db = dnw = None
@@ -215,7 +223,7 @@ class BlurConvFn(Function):
     def backward(ctx, g, _gst):
         xb, y = ctx.saved_tensors
         net, wname, kname, scale, p0, p1, pad_mode, act, bhw, has_b = ctx.cfg
-        g = _c(g)
+        g = _gl(g, xb)
         gpre = lrelu_bwd(g, y) if act == LRELU else g
         C = gpre.shape[3]
         w, bias = ctx.refs
@@ -262,6 +270,7 @@ class BlurDownFn(Function):
         k = net.p(kname)
         y, _ = ops.blur_nhwc(x, k, p0, p1, Z, down=2)
         ctx.cfg = (net, kname, p0, p1, x.shape[1], x.shape[2])
+        ctx.like = y
         return y
 
     @staticmethod
@@ -269,7 +278,7 @@ class BlurDownFn(Function):
         net, kname, p0, p1, H, W = ctx.cfg
         k = net.p(kname)
         ks = k.shape[0]
-        g = _c(g)
+        g = _gl(g, ctx.like)
         oh, ow = g.shape[1], g.shape[2]
         # UpFirDn2dBackward (upfirdn2d.py:24-60): zero-insert x2, FIR with the flipped taps, g_pad
         gp0 = ks - p0 - 1
@@ -314,7 +323,7 @@ class InstanceNormFn(Function):
     @staticmethod
     def backward(ctx, g):
         y, out, mr, style, ss, prelu = ctx.saved_tensors
-        g = _c(g)
+        g = _gl(g, y)
         B, H, W, C = y.shape
         dprelu = None
         gate = gates.sign_gate(out, "in-lrelu") if ctx.act == LRELU else None
@@ -358,11 +367,12 @@ class AddScaleFn(Function):
     @staticmethod
     def forward(ctx, a, b, s):
         ctx.s = s
+        ctx.like = a
         return ops.affine_act(_c(a), None, res=_c(b), out_scale=s)
 
     @staticmethod
     def backward(ctx, g):
-        gs = ops.affine_act(_c(g), None, out_scale=ctx.s)
+        gs = ops.affine_act(_gl(g, ctx.like), None, out_scale=ctx.s)
         return gs, gs, None
 
 
@@ -435,7 +445,7 @@ class GapGmpFn(Function):
     def backward(ctx, g):
         x, mask, v = ctx.saved_tensors
         x, v = gates.values("gmp-argmax", x, v)          # (they only pick the arg-max pixel; the tape can replay another run's)
-        return ops.gap_gmp_bwd(x, mask, v, _c(g)), None
+        return ops.gap_gmp_bwd(x, mask, v, _c(g).float()), None
 
 
 class GapGmpMultiFn(Function):
@@ -453,7 +463,7 @@ class GapGmpMultiFn(Function):
     @staticmethod
     def backward(ctx, g):
         x, masks, v = ctx.saved_tensors
-        g = _c(g)
+        g = _c(g).float()
         if gates.MODE["value"] is not None:
             # gate tape (switched on around backward()): the arg-max of every head goes through the tape like GapGmpFn's, head by head
             B, dx = x.shape[0], None
@@ -551,12 +561,12 @@ class SpatialModFn(Function):
     def forward(ctx, sp, scale, shift):
         sp, scale = _c(sp), _c(scale)
         ctx.save_for_backward(sp, scale)
-        return ops.spatial_modulation(sp, scale, _c(shift))
+        return ops.spatial_modulation(sp, scale, _c(shift), out_dtype=ops.train_dtype())
 
     @staticmethod
     def backward(ctx, g):
         sp, scale = ctx.saved_tensors
-        g = _c(g)
+        g = _gl(g, sp)                      # (sp is an fp32 tensor: the 64 x 64 spatial code)
         B, H, W, C = sp.shape
         dsp = None
         if ctx.needs_input_grad[0]:
@@ -572,7 +582,7 @@ class FromRGBFn(Function):
     @staticmethod
     def forward(ctx, x, w, b, scale):
         x = _c(x)
-        y = ops.conv1x1_small_cin(x, w, b, scale, LRELU)
+        y = ops.conv1x1_small_cin(x, w, b, scale, LRELU, out_dtype=ops.train_dtype())
         ctx.save_for_backward(x, w, y)
         ctx.scale = scale
         ctx.refs = (w, b)
@@ -581,7 +591,7 @@ class FromRGBFn(Function):
     @staticmethod
     def backward(ctx, g):
         x, w, y = ctx.saved_tensors
-        g0 = lrelu_bwd(_c(g), y)
+        g0 = lrelu_bwd(_gl(g, y), y)
         C = g0.shape[3]
         wp, bp = ctx.refs
         db = dw = None
@@ -617,11 +627,11 @@ class ToRGBConvFn(Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        g = _c(g)
+        g = _c(g).float()
         cout, cin = w.shape[0], w.shape[1]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.conv1x1_small_cin(g, w.reshape(cout, cin).t().contiguous(), None, ctx.scale, NONE)
+            dx = ops.conv1x1_small_cin(g, w.reshape(cout, cin).t().contiguous(), None, ctx.scale, NONE, out_dtype=x.dtype)
         if ctx.needs_input_grad[1]:
             dw = ops.wgrad_small_cin(g, x, ctx.scale).reshape(cin, cout).t().contiguous().view_as(w)   # (cin, cout) -> (cout, cin, 1, 1)
         if ctx.needs_input_grad[2]:

@@ -614,7 +614,8 @@ extern "C" int ppst_gap_gmp(const void* x, const void* mask, void* out, void* ws
 // order per head as chan_reduce4_kernel<1>: a head's values equal the single-head launch's bit for bit.
 // partial [(h * B + b)][nchunks][C][2] -> gap_gmp_finalize_kernel over heads * B rows.
 #define GGM_MAXH 4
-__global__ __launch_bounds__(256) void gap_gmp_multi_kernel(const float* __restrict__ x, const float* __restrict__ masks,
+template <int XS = PPST_ST_F32>
+__global__ __launch_bounds__(256) void gap_gmp_multi_kernel(const void* __restrict__ x, const float* __restrict__ masks,
                                                             float* __restrict__ partial, int P, int C, int ld, int nm, int with_plain,
                                                             int B, int nchunks, int PIX_CHUNK) {
   __shared__ float4 s0[256], s1[256];
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(256) void gap_gmp_multi_kernel(const float* __restr
     for (int h = 0; h < GGM_MAXH; ++h) { a0[h] = make_float4(0.f, 0.f, 0.f, 0.f); a1[h] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); }
     if (c < C) {
       for (int p = pbeg + pr; p < pend; p += rows) {
-        const float4 v = *(const float4*)(x + ((int64_t)b * P + p) * ld + c);
+        const float4 v = st_ld4<XS>(x, ((int64_t)b * P + p) * ld + c);
         float m[GGM_MAXH];
 #pragma unroll
         for (int h = 0; h < GGM_MAXH; ++h) {
@@ -680,16 +681,17 @@ extern "C" int64_t ppst_gap_gmp_multi_ws(int B, int64_t hw, int C, int heads) {
 }
 // x [B][hw][ld] fp32, masks [B][hw][nm] (nm in 1..3), with_plain 0 / 1 -> out [(nm + with_plain) * B][2C], head-major
 extern "C" int ppst_gap_gmp_multi(const void* x, const void* masks, void* out, void* ws, int B, int H, int W, int C, int ld, int nm,
-                                  int with_plain, void* stream) {
+                                  int with_plain, int x_st, void* stream) {
+  if ((unsigned)x_st > 2u) return PPST_EINVAL;
   if (B < 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || ld % 4 || ld < C || nm < 1 || nm > 3 || (with_plain != 0 && with_plain != 1))
     return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!x || !masks || !out || !ws) return PPST_ENULL;
-  if ((int64_t)H * W > 0x7fffffffll || ((uintptr_t)x % 16)) return PPST_EINVAL;
+  if ((int64_t)H * W > 0x7fffffffll || ((uintptr_t)x % (x_st ? 8 : 16))) return PPST_EINVAL;
   const int chunk = pix_chunk(B, (int64_t)H * W);
   const int nchunks = (int)cdiv64((int64_t)H * W, chunk), heads = nm + with_plain;
-  PPST_LAUNCH(gap_gmp_multi_kernel, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)masks, (float*)ws,
-              H * W, C, ld, nm, with_plain, B, nchunks, chunk);
+  PPST_ST_SWITCH(x_st, PPST_LAUNCH(gap_gmp_multi_kernel<ST_>, dim3(nchunks, B), dim3(256), 0, as_stream(stream), x, (const float*)masks,
+                                   (float*)ws, H * W, C, ld, nm, with_plain, B, nchunks, chunk));
   int e = PPST_LAUNCH_CHECK();
   if (e) return e;
   PPST_LAUNCH(gap_gmp_finalize_kernel, dim3(heads * B * cdiv(C, FIN_CH)), dim3(256), 0, as_stream(stream), (const float*)ws, nchunks,

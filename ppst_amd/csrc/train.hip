@@ -764,6 +764,179 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr2_kernel(const float* __r
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: the same weight gradient on bf16-STORED operands (precision mode 1 with half-precision storage of the training
+// activations and their gradients: BASELINE configs[3]'s "bf16").  What bounded conv_wgrad_tr2_kernel in that mode was the feed:
+// 49 KB of raw fp32 per tile through L2 -> LDS and a conversion pass, for a third of the MFMA work of the fp32-class mode.  Here the
+// tile arrives as the MFMA operand type: LDS-DMA of [pixel][32 channels] bf16 rows (64 B per pixel: 16 + 9 pieces of 1 KB per tile
+// instead of 32 + 17), NO conversion pass, the transposed reads (ds_read_b64_tr_b16) straight on the DMA'd image -- a half-wave's 32
+// eight-byte reads cover four pixels x 64 B = 256 contiguous bytes: conflict-free without the [hi | lo] swap of the fp32 form.  With
+// 25 KB per tile the images are DOUBLE-BUFFERED: the next tile's pieces are requested right behind the barrier that publishes the
+// current one and land under its MFMAs (one barrier per tile).  The bias column sums read the dY image from LDS (chunk-0 blocks only).
+template <int NCH, int TM, bool EXACT, bool HALO = true>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tr2b_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
+                                                               const int4* __restrict__ steps, const int* __restrict__ chunk_start,
+                                                               float* __restrict__ partial, float* __restrict__ csum, int B, int in_h,
+                                                               int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
+                                                               int tiles_x, int tiles_per_image, int tiles_total, int tiles_per_split) {
+  constexpr int XW = HALO ? WT_XW : WG_TC, XPX = HALO ? WT_XPX : WT_PX, XO = HALO ? 1 : 0;
+  constexpr int PXB = 64;                                     // bytes of one pixel's 32 channels
+  constexpr int XPC = (XPX + 15) / 16;                        // DMA pieces (16 pixels x 64 B) per chunk: 9 / 4
+  constexpr int SLAB = WT_PX * PXB;                           // 4096: one 32-channel slab of the dY tile
+  constexpr int IMG_DY = 4 * SLAB, IMG_X = XPC * 1024, BUF = IMG_DY + NCH * IMG_X;
+  static_assert(!HALO ? TM == 1 : true, "the no-halo image serves 1x1 tables");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63, nw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kb = lane >> 5;
+  int bx, by, bz;                                             // XCD-aware block map (conv_wgrad_tr_kernel)
+  {
+    const int nb = gridDim.x * gridDim.y * gridDim.z;
+    const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int q8 = nb >> 3, r8 = nb & 7, xcd = id & 7;
+    int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+    bx = v % (int)gridDim.x; v /= (int)gridDim.x;
+    by = v % (int)gridDim.y; bz = v / (int)gridDim.y;
+  }
+  const int n0 = bx * 128;
+  int s0[NCH], T[NCH], chan[NCH];
+  int tdy[NCH][TM], tdx[NCH][TM];
+#pragma unroll
+  for (int ci = 0; ci < NCH; ++ci) {
+    s0[ci] = chunk_start[by * NCH + ci];
+    T[ci] = chunk_start[by * NCH + ci + 1] - s0[ci];
+    chan[ci] = steps[s0[ci]].x;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      int4 d = steps[s0[ci] + (t < T[ci] ? t : 0)];
+      tdy[ci][t] = d.y; tdx[ci][t] = d.z;
+    }
+  }
+  auto chan_of = [&](int ci) {
+    int c = chan[0];
+#pragma unroll
+    for (int j = 1; j < NCH; ++j) c = ci == j ? chan[j] : c;
+    return c;
+  };
+  f32x16 acc[NCH][TM];
+#pragma unroll
+  for (int ci = 0; ci < NCH; ++ci)
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[ci][t][i] = 0.f;
+  const int t_begin = bz * tiles_per_split;
+  const int t_end = min(t_begin + tiles_per_split, tiles_total);
+  const bool wave_live = n0 + nw * 32 < cout;
+  const int nslab = min(4, (cout - n0 + 31) >> 5);
+  const bool want_csum = csum != nullptr && by == 0;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int g = lane >> 4, qd = (lane & 15) >> 2, pp = lane & 3;
+  const int tr_unit = (8 * (g >> 1) + qd) * PXB + (4 * (g & 1) + pp) * 8;
+  auto frag = [&](const unsigned char* u, bf16x8& h) {
+    const wt_v4s h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wt_v4s __attribute__((address_space(3)))*)u);
+    const wt_v4s h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wt_v4s __attribute__((address_space(3)))*)(u + 4 * PXB));
+    h = (bf16x8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+  };
+  // LDS-DMA of one tile: 16 pieces of dY (slab, 16 pixels: 16 x 64 B) + XPC per chunk of the input image; lane = (pixel, 16-byte quarter)
+  auto issue = [&](int tile, unsigned char* buf) {
+    const int b = tile / tiles_per_image;
+    const int r = tile - b * tiles_per_image;
+    const int ty0 = (r / tiles_x) * WG_TR, tx0 = (r - (r / tiles_x) * tiles_x) * WG_TC;
+    const int q = lane & 3, pl = lane >> 2;
+    for (int wi = nw; wi < 16 + NCH * XPC; wi += 4) {
+      const void* src = g_wg_zero;
+      if (wi < 16 && (wi >> 2) >= nslab) continue;          // slab beyond cout: no wave reads it
+      if (wi < 16) {
+        const int p = 16 * (wi & 3) + pl, n = n0 + (wi >> 2) * 32 + q * 8;
+        const int y = ty0 + (p >> 5), xx = tx0 + (p & 31);
+        if (y < oh && xx < ow && n < cout) src = dy + (((int64_t)b * oh + y) * ow + xx) * dy_ld + n;
+      } else {
+        const int ci = (wi - 16) / XPC, pj = (wi - 16) - ci * XPC;        // wave-uniform
+        const int P = 16 * pj + pl;
+        const int row = P / XW, col = P - row * XW;
+        const int iy = ty0 - XO + row, ix = tx0 - XO + col;
+        if (P < XPX && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w)
+          src = x + (((int64_t)b * in_h + iy) * in_w + ix) * in_ld + chan_of(ci) + q * 8;
+      }
+      unsigned char* dst = buf + (wi < 16 ? wi * 1024 : IMG_DY + (wi - 16) * 1024);
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+    }
+  };
+  if (t_begin < t_end) issue(t_begin, smem);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    unsigned char* const cur = smem + ((tile - t_begin) & 1) * BUF;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of the current tile have landed (hipcc adds no wait for LDS-DMA)
+    __syncthreads();                                        // ... everybody's have, and the previous tile's MFMA reads are done
+    if (tile + 1 < t_end) issue(tile + 1, smem + (((tile - t_begin) & 1) ^ 1) * BUF);
+    if (want_csum) {                                        // bias column sums: 4 channels per thread over its pixels of the dY image
+      const int NQ = 8 * nslab, stride = (256 / NQ) * NQ;
+      if (tid < stride)
+        for (int i = tid; i < 64 * NQ; i += stride) {
+          const int p = i / NQ, cq = i - p * NQ;
+          const uint2 u = *(const uint2*)(cur + (cq >> 3) * SLAB + p * PXB + (cq & 7) * 8);
+          cs.x += __uint_as_float(u.x << 16); cs.y += __uint_as_float(u.x & 0xffff0000u);
+          cs.z += __uint_as_float(u.y << 16); cs.w += __uint_as_float(u.y & 0xffff0000u);
+        }
+    }
+    if (wave_live) {
+#pragma unroll 1
+      for (int ks = 0; ks < 4; ++ks) {
+        const int row = ks >> 1, xh = (ks & 1) * 16;
+        bf16x8 a_h;
+        frag(cur + nw * SLAB + (row * 32 + xh) * PXB + tr_unit, a_h);
+#pragma unroll
+        for (int ci = 0; ci < NCH; ++ci) {
+          const unsigned char* const im = cur + IMG_DY + ci * IMG_X;
+          const int pb0 = (row + XO + tdy[ci][0]) * XW + xh + XO + tdx[ci][0];
+          bf16x8 b_h;
+          frag(im + pb0 * PXB + tr_unit, b_h);
+#pragma unroll
+          for (int t = 0; t < TM; ++t) {
+            if (EXACT || t < T[ci]) {
+              bf16x8 n_h = b_h;
+              if (t + 1 < TM && (EXACT || t + 1 < T[ci])) {
+                const int pb = (row + XO + tdy[ci][t + 1]) * XW + xh + XO + tdx[ci][t + 1];
+                frag(im + pb * PXB + tr_unit, n_h);
+              }
+              acc[ci][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_h, acc[ci][t], 0, 0, 0);
+              b_h = n_h;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (want_csum) {
+    __syncthreads();
+    float4* red = (float4*)smem;
+    const int NQ = 8 * nslab, stride = (256 / NQ) * NQ;
+    red[tid] = tid < stride ? cs : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (tid < NQ) {
+      float4 a = red[tid];
+      for (int r = tid + NQ; r < stride; r += NQ) { const float4 v = red[r]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+      const int n = n0 + tid * 4;
+      float* o = csum + (int64_t)bz * cout + n;
+      if (n < cout) { o[0] = a.x; if (n + 1 < cout) o[1] = a.y; if (n + 2 < cout) o[2] = a.z; if (n + 3 < cout) o[3] = a.w; }
+    }
+  }
+  if (!wave_live) return;
+#pragma unroll
+  for (int ci = 0; ci < NCH; ++ci)
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      if (EXACT || t < T[ci]) {
+        float* o = partial + (((int64_t)bz * nsteps + s0[ci] + t) * cout) * 32;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+          int nn = n0 + nw * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kb;
+          if (nn < cout) o[(int64_t)nn * 32 + li] = acc[ci][t][rg];
+        }
+      }
+    }
+}
+
 // profiling brackets of conv_mfma.hip: a weight-gradient launch is recorded with info = {B, oh, ow, nsteps, cout, nchunks, splits, 0}
 // (bn = 0 marks it) and the algorithmic 2 * 32 * flop_steps * cout * B * oh * ow (flop_steps < nsteps where the table carries
 // zero-weight pad steps)
@@ -829,9 +1002,22 @@ extern "C" int ppst_conv_wgrad_tr(const void* x, const void* dy, const void* ste
 
 // two-blocks-per-CU form (conv_wgrad_tr2_kernel, in-place conversion): ``splits`` partial slots = pixel ranges; csum (optional):
 // [splits][cout] partial column sums of dy
+extern "C" int ppst_conv_wgrad_tr2_st(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial, void* csum,
+                                      int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
+                                      int nchunks, int splits, int max_taps, int min_taps, int halo, int passes, int st, void* stream);
 extern "C" int ppst_conv_wgrad_tr2(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial, void* csum,
                                    int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
                                    int nchunks, int splits, int max_taps, int min_taps, int halo, int passes, void* stream) {
+  return ppst_conv_wgrad_tr2_st(x, dy, steps, chunk_start, partial, csum, B, in_h, in_w, in_ld, oh, ow, dy_ld, cout, nsteps, nchunks, splits,
+                                max_taps, min_taps, halo, passes, PPST_ST_F32, stream);
+}
+// st: storage type of x and dy -- PPST_ST_F32, or PPST_ST_BF16 with passes == 1 (conv_wgrad_tr2b_kernel: the operands arrive as the
+// MFMA type; cout, in_ld, dy_ld multiples of 8, 16-byte aligned x / dy)
+extern "C" int ppst_conv_wgrad_tr2_st(const void* x, const void* dy, const void* steps, const void* chunk_start, void* partial, void* csum,
+                                      int B, int in_h, int in_w, int in_ld, int oh, int ow, int dy_ld, int cout, int nsteps,
+                                      int nchunks, int splits, int max_taps, int min_taps, int halo, int passes, int st, void* stream) {
+  if (st != PPST_ST_F32 && st != PPST_ST_BF16) return PPST_EINVAL;
+  if (st == PPST_ST_BF16 && (passes != 1 || cout % 8 || dy_ld % 8 || in_ld % 8)) return PPST_EINVAL;
   if (B < 0 || in_h <= 0 || in_w <= 0 || in_ld <= 0 || oh <= 0 || ow <= 0 || dy_ld < cout || cout <= 0 || nsteps <= 0 ||
       nchunks <= 0 || splits <= 0 || (passes != 1 && passes != 3))
     return PPST_EINVAL;
@@ -865,6 +1051,19 @@ extern "C" int ppst_conv_wgrad_tr2(const void* x, const void* dy, const void* st
                   (const float*)dy, (const int4*)steps, (const int*)chunk_start, (float*)partial, (float*)csum, B, in_h, in_w, in_ld,  \
                   oh, ow, dy_ld, cout, nsteps, tiles_x, tiles_per_image, tiles_total, tps);                                            \
   } while (0)
+  if (st == PPST_ST_BF16) {
+#define WGB(NCH, TM, EX, HALO)                                                                                                          \
+  PPST_LAUNCH((conv_wgrad_tr2b_kernel<NCH, TM, EX, HALO>), grid, dim3(256), 0, as_stream(stream), (const unsigned short*)x,               \
+              (const unsigned short*)dy, (const int4*)steps, (const int*)chunk_start, (float*)partial, (float*)csum, B, in_h, in_w, in_ld, \
+              oh, ow, dy_ld, cout, nsteps, tiles_x, tiles_per_image, tiles_total, tps)
+    if (one == 4) WGB(4, 1, true, false);
+    else if (one == 2) WGB(2, 1, true, false);
+    else if (pair) { if (min_taps == 4 && max_taps == 4) WGB(2, 4, true, true); else WGB(2, 4, false, true); }
+    else { if (min_taps == WG_MAXT && max_taps == WG_MAXT) WGB(1, WG_MAXT, true, true); else WGB(1, WG_MAXT, false, true); }
+#undef WGB
+    ppst_prof_end_(slot, as_stream(stream));
+    return PPST_LAUNCH_CHECK();
+  }
   // max_taps / min_taps: the caller's promise about the table's chunk lengths (the table lives on the device)
   if (one == 4) WG2N(4);
   else if (one == 2) WG2N(2);
@@ -999,7 +1198,8 @@ __global__ __launch_bounds__(256) void wgrad_small_cin_kernel(const float* __res
 }
 // float4 form for cout = 4 Q with Q a divisor of 256 (FromRGB: cout = 32 -> the scalar form above ran half its lanes, 128 B per
 // wave load): thread = (pixel slot tid / Q, channel quad tid % Q); 256 / Q pixels per block pass, four passes in flight.
-__global__ __launch_bounds__(256) void wgrad_small_cin4_kernel(const float* __restrict__ x, const float4* __restrict__ dy,
+template <int ST = PPST_ST_F32>     // storage type of dy (x: the fp32 image / RGB gradient)
+__global__ __launch_bounds__(256) void wgrad_small_cin4_kernel(const float* __restrict__ x, const void* __restrict__ dy,
                                                                float* __restrict__ partial, int64_t npix, int cin, int in_ld, int Q,
                                                                int64_t pix_per_block) {
   __shared__ float4 sm[4][256];                              // [input channel][thread]
@@ -1010,7 +1210,8 @@ __global__ __launch_bounds__(256) void wgrad_small_cin4_kernel(const float* __re
   for (int c = 0; c < 4; ++c) a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   int64_t p = p0 + slot;
   for (; p + 3 * P < p1; p += 4 * P) {
-    const float4 g0 = dy[p * Q + q], g1 = dy[(p + P) * Q + q], g2 = dy[(p + 2 * P) * Q + q], g3 = dy[(p + 3 * P) * Q + q];
+    const float4 g0 = st_ld4<ST>(dy, (p * Q + q) * 4), g1 = st_ld4<ST>(dy, ((p + P) * Q + q) * 4), g2 = st_ld4<ST>(dy, ((p + 2 * P) * Q + q) * 4),
+                 g3 = st_ld4<ST>(dy, ((p + 3 * P) * Q + q) * 4);
 #pragma unroll
     for (int c = 0; c < 4; ++c)
       if (c < cin) {
@@ -1022,7 +1223,7 @@ __global__ __launch_bounds__(256) void wgrad_small_cin4_kernel(const float* __re
       }
   }
   for (; p < p1; p += P) {
-    const float4 g = dy[p * Q + q];
+    const float4 g = st_ld4<ST>(dy, (p * Q + q) * 4);
 #pragma unroll
     for (int c = 0; c < 4; ++c)
       if (c < cin) {
@@ -1073,14 +1274,23 @@ __global__ __launch_bounds__(256) void sum_blocks_kernel(const float* __restrict
 }
 #define WSC_PIX 1024    // pixels per block of the FromRGB weight gradient (4096 left half the chip idle at 2 x 512^2 pixels)
 extern "C" int64_t ppst_wgrad_small_cin_ws(int64_t npix, int cin, int cout) { return cdiv64(npix, WSC_PIX) * cout * cin * (int64_t)sizeof(float); }
+extern "C" int ppst_wgrad_small_cin_st(const void* x, const void* dy, void* dw, void* ws, int64_t npix, int cin, int in_ld, int cout,
+                                       float scale, int accumulate, int dy_st, void* stream);
 extern "C" int ppst_wgrad_small_cin(const void* x, const void* dy, void* dw, void* ws, int64_t npix, int cin, int in_ld, int cout,
                                     float scale, int accumulate, void* stream) {
+  return ppst_wgrad_small_cin_st(x, dy, dw, ws, npix, cin, in_ld, cout, scale, accumulate, PPST_ST_F32, stream);
+}
+extern "C" int ppst_wgrad_small_cin_st(const void* x, const void* dy, void* dw, void* ws, int64_t npix, int cin, int in_ld, int cout,
+                                       float scale, int accumulate, int dy_st, void* stream) {
+  if ((unsigned)dy_st > 2u) return PPST_EINVAL;
   if (npix <= 0 || cin <= 0 || cin > 4 || in_ld < cin || cout <= 0) return PPST_EINVAL;
   if (!x || !dy || !dw || !ws) return PPST_ENULL;
   int nblocks = (int)cdiv64(npix, WSC_PIX);
-  if (cout % 4 == 0 && cout / 4 <= 256 && 256 % (cout / 4) == 0 && (uintptr_t)dy % 16 == 0)
-    PPST_LAUNCH(wgrad_small_cin4_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), (const float*)x, (const float4*)dy, (float*)ws,
-                npix, cin, in_ld, cout / 4, (int64_t)WSC_PIX);
+  if (cout % 4 == 0 && cout / 4 <= 256 && 256 % (cout / 4) == 0 && (uintptr_t)dy % (dy_st ? 8 : 16) == 0)
+    PPST_ST_SWITCH(dy_st, PPST_LAUNCH(wgrad_small_cin4_kernel<ST_>, dim3(nblocks), dim3(256), 0, as_stream(stream), (const float*)x, dy,
+                                      (float*)ws, npix, cin, in_ld, cout / 4, (int64_t)WSC_PIX));
+  else if (dy_st)
+    return PPST_EINVAL;
   else
     PPST_LAUNCH(wgrad_small_cin_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (float*)ws,
                 npix, cin, in_ld, cout, (int64_t)WSC_PIX);
@@ -1115,7 +1325,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   }
 }
 // 16-B-per-lane version (C % 4 == 0, ld % 4 == 0): lane = 4 columns, 4 rows in flight per thread
-__global__ __launch_bounds__(256) void colsum4_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t rows,
+template <int ST = PPST_ST_F32>
+__global__ __launch_bounds__(256) void colsum4_partial_kernel(const void* __restrict__ x, float* __restrict__ partial, int64_t rows,
                                                               int C, int ld, int64_t rows_per_block) {
   __shared__ float4 sm[256];
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, rows);
@@ -1129,15 +1340,15 @@ __global__ __launch_bounds__(256) void colsum4_partial_kernel(const float* __res
     if (c < C) {
       int64_t r = r0 + pr;
       for (; r + 3 * (int64_t)nrows < r1; r += 4 * (int64_t)nrows) {
-        const float4 v0 = *(const float4*)(x + r * ld + c), v1 = *(const float4*)(x + (r + nrows) * ld + c);
-        const float4 v2 = *(const float4*)(x + (r + 2 * nrows) * ld + c), v3 = *(const float4*)(x + (r + 3 * nrows) * ld + c);
+        const float4 v0 = st_ld4<ST>(x, r * ld + c), v1 = st_ld4<ST>(x, (r + nrows) * ld + c);
+        const float4 v2 = st_ld4<ST>(x, (r + 2 * nrows) * ld + c), v3 = st_ld4<ST>(x, (r + 3 * nrows) * ld + c);
         a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
         a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
         a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
         a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
       }
       for (; r < r1; r += nrows) {
-        const float4 v0 = *(const float4*)(x + r * ld + c);
+        const float4 v0 = st_ld4<ST>(x, r * ld + c);
         a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
       }
     }
@@ -1152,12 +1363,21 @@ __global__ __launch_bounds__(256) void colsum4_partial_kernel(const float* __res
   }
 }
 extern "C" int64_t ppst_colsum_ws(int64_t rows, int C) { return cdiv64(rows, 2048) * C * (int64_t)sizeof(float); }
+extern "C" int ppst_colsum_st(const void* x, void* out, void* ws, int64_t rows, int C, int ld, float scale, int accumulate, int st, void* stream);
 extern "C" int ppst_colsum(const void* x, void* out, void* ws, int64_t rows, int C, int ld, float scale, int accumulate, void* stream) {
+  return ppst_colsum_st(x, out, ws, rows, C, ld, scale, accumulate, PPST_ST_F32, stream);
+}
+// st: storage type of x (round 5: the bf16-stored gradients of precision mode 1); sums and out fp32
+extern "C" int ppst_colsum_st(const void* x, void* out, void* ws, int64_t rows, int C, int ld, float scale, int accumulate, int st, void* stream) {
+  if ((unsigned)st > 2u) return PPST_EINVAL;
   if (rows <= 0 || C <= 0 || ld < C) return PPST_EINVAL;
   if (!x || !out || !ws) return PPST_ENULL;
   int nblocks = (int)cdiv64(rows, 2048);
-  if (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)ws % 16) == 0)
-    PPST_LAUNCH(colsum4_partial_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), (const float*)x, (float*)ws, rows, C, ld, (int64_t)2048);
+  if (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % (st ? 8 : 16)) == 0 && ((uintptr_t)ws % 16) == 0)
+    PPST_ST_SWITCH(st, PPST_LAUNCH(colsum4_partial_kernel<ST_>, dim3(nblocks), dim3(256), 0, as_stream(stream), x, (float*)ws, rows, C, ld,
+                                   (int64_t)2048));
+  else if (st)
+    return PPST_EINVAL;
   else
     PPST_LAUNCH(colsum_partial_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), (const float*)x, (float*)ws, rows, C, ld, (int64_t)2048);
   int e = PPST_LAUNCH_CHECK();

@@ -65,8 +65,11 @@ __global__ __launch_bounds__(256) void dual_stats_kernel(const float* __restrict
   }
 }
 // four channels per thread (C and the pixel strides multiples of 4, 16-byte aligned tensors: every tensor of the train step)
-__global__ __launch_bounds__(256) void dual_stats4_kernel(const float4* __restrict__ g, const float4* __restrict__ y,
-                                                          const float4* __restrict__ gate, float* __restrict__ partial, int P, int C4,
+// ST (round 5: half-precision storage of the TRAINING activations and their gradients in precision mode 1): storage type of g, y and
+// gate; the sums are fp32 either way
+template <int ST = PPST_ST_F32>
+__global__ __launch_bounds__(256) void dual_stats4_kernel(const void* __restrict__ g, const void* __restrict__ y,
+                                                          const void* __restrict__ gate, float* __restrict__ partial, int P, int C4,
                                                           int g_ld4, int y_ld4, int gate_ld4, int nchunks, int PIX_CHUNK) {
   __shared__ float4 s0[256], s1[256];
   const int b = blockIdx.y, chunk = blockIdx.x;
@@ -82,10 +85,10 @@ __global__ __launch_bounds__(256) void dual_stats4_kernel(const float4* __restri
     if (c < C4) {
       for (int p = pbeg + pr; p < pend; p += rows) {
         const int64_t bp = (int64_t)b * P + p;
-        float4 gv = g[bp * g_ld4 + c];
-        const float4 yv = y[bp * y_ld4 + c];
+        float4 gv = st_ld4<ST>(g, (bp * g_ld4 + c) * 4);
+        const float4 yv = st_ld4<ST>(y, (bp * y_ld4 + c) * 4);
         if (gate) {
-          const float4 t = gate[bp * gate_ld4 + c];
+          const float4 t = st_ld4<ST>(gate, (bp * gate_ld4 + c) * 4);
           gv.x *= lrelu_gate(t.x); gv.y *= lrelu_gate(t.y); gv.z *= lrelu_gate(t.z); gv.w *= lrelu_gate(t.w);
         }
         a0.x += gv.x; a0.y += gv.y; a0.z += gv.z; a0.w += gv.w;
@@ -108,8 +111,9 @@ __global__ __launch_bounds__(256) void dual_stats4_kernel(const float4* __restri
     __syncthreads();
   }
 }
-extern "C" int ppst_dual_stats(const void* g, const void* y, const void* gate, void* partial, int B, int64_t hw, int C, int g_ld,
-                               int y_ld, int gate_ld, int* n_partials, void* stream) {
+extern "C" int ppst_dual_stats_st(const void* g, const void* y, const void* gate, void* partial, int B, int64_t hw, int C, int g_ld,
+                                  int y_ld, int gate_ld, int* n_partials, int st, void* stream) {
+  if ((unsigned)st > 2u) return PPST_EINVAL;
   if (B < 0 || hw <= 0 || hw > 0x7fffffffll || C <= 0 || g_ld < C || y_ld < C || (gate && gate_ld < C)) return PPST_EINVAL;
   const int chunk = tg_pix_chunk(B, hw);
   const int nchunks = (int)cdiv64(hw, chunk);
@@ -118,14 +122,20 @@ extern "C" int ppst_dual_stats(const void* g, const void* y, const void* gate, v
   if (B == 0) return PPST_OK;
   if (!g || !y || !partial) return PPST_ENULL;
   if (C % 4 == 0 && g_ld % 4 == 0 && y_ld % 4 == 0 && (!gate || gate_ld % 4 == 0) &&
-      ((uintptr_t)g | (uintptr_t)y | (uintptr_t)gate | (uintptr_t)partial) % 16 == 0) {
-    PPST_LAUNCH(dual_stats4_kernel, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float4*)g, (const float4*)y,
-                (const float4*)gate, (float*)partial, (int)hw, C / 4, g_ld / 4, y_ld / 4, gate_ld / 4, nchunks, chunk);
+      ((uintptr_t)g | (uintptr_t)y | (uintptr_t)gate) % (st ? 8 : 16) == 0 && (uintptr_t)partial % 16 == 0) {
+    PPST_ST_SWITCH(st, PPST_LAUNCH(dual_stats4_kernel<ST_>, dim3(nchunks, B), dim3(256), 0, as_stream(stream), g, y, gate, (float*)partial,
+                                   (int)hw, C / 4, g_ld / 4, y_ld / 4, gate_ld / 4, nchunks, chunk));
     return PPST_LAUNCH_CHECK();
   }
+  if (st) return PPST_EINVAL;      // half storage: the four-channel form only
   PPST_LAUNCH(dual_stats_kernel, dim3(nchunks, B), dim3(256), 0, as_stream(stream), (const float*)g, (const float*)y,
               (const float*)gate, (float*)partial, (int)hw, C, g_ld, y_ld, gate_ld, nchunks, chunk);
   return PPST_LAUNCH_CHECK();
+}
+
+extern "C" int ppst_dual_stats(const void* g, const void* y, const void* gate, void* partial, int B, int64_t hw, int C, int g_ld,
+                               int y_ld, int gate_ld, int* n_partials, void* stream) {
+  return ppst_dual_stats_st(g, y, gate, partial, B, hw, C, g_ld, y_ld, gate_ld, n_partials, PPST_ST_F32, stream);
 }
 
 // Pass 2: reduce the partials (double accumulation) -> coef[b][c] = (k0, k1, k2) with dy = k0*g' + k1*y + k2 and,
@@ -216,9 +226,10 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* __restri
     dx[bp * dx_ld + c] = o;
   }
 }
-__global__ __launch_bounds__(256) void in_bwd_apply4_kernel(const float4* __restrict__ g, const float4* __restrict__ y,
-                                                            const float4* __restrict__ gate, const float4* __restrict__ coef,
-                                                            float4* __restrict__ dx, unsigned hw, int C4, int g_ld4, int y_ld4,
+template <int ST = PPST_ST_F32>
+__global__ __launch_bounds__(256) void in_bwd_apply4_kernel(const void* __restrict__ g, const void* __restrict__ y,
+                                                            const void* __restrict__ gate, const float4* __restrict__ coef,
+                                                            void* __restrict__ dx, unsigned hw, int C4, int g_ld4, int y_ld4,
                                                             int gate_ld4, int dx_ld4, int post_gate, unsigned total, FastDiv d_c,
                                                             FastDiv d_hw) {
   for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
@@ -229,36 +240,43 @@ __global__ __launch_bounds__(256) void in_bwd_apply4_kernel(const float4* __rest
     const int64_t bp = bpu;
     const float4* k = coef + ((int64_t)b * C4 + c) * 4;      // (k0, k1, k2, -) of the thread's four channels
     const float4 k0 = k[0], k1 = k[1], k2 = k[2], k3 = k[3];
-    float4 gv = g[bp * g_ld4 + c];
-    const float4 yv = y[bp * y_ld4 + c];
+    float4 gv = st_ld4<ST>(g, (bp * g_ld4 + c) * 4);
+    const float4 yv = st_ld4<ST>(y, (bp * y_ld4 + c) * 4);
     if (gate) {
-      const float4 t = gate[bp * gate_ld4 + c];
+      const float4 t = st_ld4<ST>(gate, (bp * gate_ld4 + c) * 4);
       gv.x *= lrelu_gate(t.x); gv.y *= lrelu_gate(t.y); gv.z *= lrelu_gate(t.z); gv.w *= lrelu_gate(t.w);
     }
     float4 o = make_float4(k0.x * gv.x + k0.y * yv.x + k0.z, k1.x * gv.y + k1.y * yv.y + k1.z, k2.x * gv.z + k2.y * yv.z + k2.z,
                            k3.x * gv.w + k3.y * yv.w + k3.z);
     if (post_gate) { o.x *= lrelu_gate(yv.x); o.y *= lrelu_gate(yv.y); o.z *= lrelu_gate(yv.z); o.w *= lrelu_gate(yv.w); }
-    dx[bp * dx_ld4 + c] = o;
+    st_st4<ST>(dx, (bp * dx_ld4 + c) * 4, o);
   }
 }
-extern "C" int ppst_in_bwd_apply(const void* g, const void* y, const void* gate, const void* coef, void* dx, int B, int64_t hw, int C,
-                                 int g_ld, int y_ld, int gate_ld, int dx_ld, int post_gate, void* stream) {
+extern "C" int ppst_in_bwd_apply_st(const void* g, const void* y, const void* gate, const void* coef, void* dx, int B, int64_t hw, int C,
+                                    int g_ld, int y_ld, int gate_ld, int dx_ld, int post_gate, int st, void* stream) {
+  if ((unsigned)st > 2u) return PPST_EINVAL;
   if (B < 0 || hw <= 0 || C <= 0 || g_ld < C || y_ld < C || dx_ld < C || (gate && gate_ld < C)) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!g || !y || !coef || !dx) return PPST_ENULL;
   const int64_t total = (int64_t)B * hw * C;
   if (total > PPST_IDX32_MAX) return PPST_EINVAL;
   if (C % 4 == 0 && g_ld % 4 == 0 && y_ld % 4 == 0 && dx_ld % 4 == 0 && (!gate || gate_ld % 4 == 0) &&
-      ((uintptr_t)g | (uintptr_t)y | (uintptr_t)gate | (uintptr_t)coef | (uintptr_t)dx) % 16 == 0) {
-    PPST_LAUNCH(in_bwd_apply4_kernel, dim3(tg_grid(total / 4)), dim3(256), 0, as_stream(stream), (const float4*)g, (const float4*)y,
-                (const float4*)gate, (const float4*)coef, (float4*)dx, (unsigned)hw, C / 4, g_ld / 4, y_ld / 4, gate_ld / 4, dx_ld / 4,
-                post_gate, (unsigned)(total / 4), make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)hw));
+      ((uintptr_t)g | (uintptr_t)y | (uintptr_t)gate | (uintptr_t)dx) % (st ? 8 : 16) == 0 && (uintptr_t)coef % 16 == 0) {
+    PPST_ST_SWITCH(st, PPST_LAUNCH(in_bwd_apply4_kernel<ST_>, dim3(tg_grid(total / 4)), dim3(256), 0, as_stream(stream), g, y, gate,
+                                   (const float4*)coef, dx, (unsigned)hw, C / 4, g_ld / 4, y_ld / 4, gate_ld / 4, dx_ld / 4, post_gate,
+                                   (unsigned)(total / 4), make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)hw)));
     return PPST_LAUNCH_CHECK();
   }
+  if (st) return PPST_EINVAL;
   PPST_LAUNCH(in_bwd_apply_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)g, (const float*)y,
               (const float*)gate, (const float*)coef, (float*)dx, (unsigned)hw, C, g_ld, y_ld, gate_ld, dx_ld, post_gate,
               (unsigned)total, make_fastdiv((unsigned)C), make_fastdiv((unsigned)hw));
   return PPST_LAUNCH_CHECK();
+}
+
+extern "C" int ppst_in_bwd_apply(const void* g, const void* y, const void* gate, const void* coef, void* dx, int B, int64_t hw, int C,
+                                 int g_ld, int y_ld, int gate_ld, int dx_ld, int post_gate, void* stream) {
+  return ppst_in_bwd_apply_st(g, y, gate, coef, dx, B, hw, C, g_ld, y_ld, gate_ld, dx_ld, post_gate, PPST_ST_F32, stream);
 }
 
 // PReLU (single slope, nn.PReLU()) applied to a normalised tensor: out = prelu(a*y + s) (feature heads,
@@ -332,8 +350,16 @@ __global__ __launch_bounds__(256) void pad2d_kernel(const VT* __restrict__ x, VT
     y[t64] = v;
   }
 }
+extern "C" int ppst_pad2d_st(const void* x, void* y, int B, int H, int W, int C, int x_ld, int py0, int py1, int px0, int px1, int mode,
+                             int st, void* stream);
 extern "C" int ppst_pad2d(const void* x, void* y, int B, int H, int W, int C, int x_ld, int py0, int py1, int px0, int px1, int mode,
                           void* stream) {
+  return ppst_pad2d_st(x, y, B, H, W, C, x_ld, py0, py1, px0, px1, mode, PPST_ST_F32, stream);
+}
+// st: storage type of x and y -- pure data movement: a half tensor's four channels travel as one 8-byte element
+extern "C" int ppst_pad2d_st(const void* x, void* y, int B, int H, int W, int C, int x_ld, int py0, int py1, int px0, int px1, int mode,
+                             int st, void* stream) {
+  if ((unsigned)st > 2u) return PPST_EINVAL;
   const int OH = H + py0 + py1, OW = W + px0 + px1;
   if (B < 0 || H <= 0 || W <= 0 || C <= 0 || x_ld < C || OH <= 0 || OW <= 0 || mode < 0 || mode > 2) return PPST_EINVAL;
   if (mode == PPST_PAD_REFLECT && (py0 >= H || py1 >= H || px0 >= W || px1 >= W)) return PPST_EINVAL;
@@ -341,6 +367,13 @@ extern "C" int ppst_pad2d(const void* x, void* y, int B, int H, int W, int C, in
   if (!x || !y) return PPST_ENULL;
   const int64_t total = (int64_t)B * OH * OW * C;
   if (total > PPST_IDX32_MAX) return PPST_EINVAL;
+  if (st) {
+    if (C % 4 || x_ld % 4 || ((uintptr_t)x | (uintptr_t)y) % 8) return PPST_EINVAL;
+    PPST_LAUNCH(pad2d_kernel<uint2>, dim3(tg_grid(total / 4)), dim3(256), 0, as_stream(stream), (const uint2*)x, (uint2*)y, H, W, C / 4,
+                x_ld / 4, OH, OW, py0, px0, mode, (unsigned)(total / 4), make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)OW),
+                make_fastdiv((unsigned)OH));
+    return PPST_LAUNCH_CHECK();
+  }
   if (C % 4 == 0 && x_ld % 4 == 0 && ((uintptr_t)x | (uintptr_t)y) % 16 == 0) {
     PPST_LAUNCH(pad2d_kernel<float4>, dim3(tg_grid(total / 4)), dim3(256), 0, as_stream(stream), (const float4*)x, (float4*)y, H, W, C / 4,
                 x_ld / 4, OH, OW, py0, px0, mode, (unsigned)(total / 4), make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)OW),
@@ -382,8 +415,42 @@ __global__ __launch_bounds__(256) void pad2d_bwd_kernel(const VT* __restrict__ d
     dx[t64] = acc;
   }
 }
+// half storage: the same sums (fp32) over four channels per thread, one rounding at the store
+template <int ST>
+__global__ __launch_bounds__(256) void pad2d_bwd_st_kernel(const void* __restrict__ dy, void* __restrict__ dx, int H, int W, int C4,
+                                                           int OH, int OW, int py0, int py1, int px0, int px1, int mode, unsigned total,
+                                                           FastDiv d_c, FastDiv d_w, FastDiv d_h) {
+  const int ny = 1 + (py0 > 0 ? py0 : 0) + (py1 > 0 ? py1 : 0), nx = 1 + (px0 > 0 ? px0 : 0) + (px1 > 0 ? px1 : 0);
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned c, xx, yy;
+    unsigned r = fd_divmod((unsigned)t64, d_c, c);
+    r = fd_divmod(r, d_w, xx);
+    const unsigned b = fd_divmod(r, d_h, yy);
+    const int64_t base = (int64_t)b * OH * OW * C4 + c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int iy = 0; iy < ny; ++iy) {
+      int ty = iy == 0 ? (int)yy : (iy <= (py0 > 0 ? py0 : 0) ? -iy : H - 1 + (iy - (py0 > 0 ? py0 : 0)));
+      if (ty + py0 < 0 || ty + py0 >= OH) continue;
+      if (pad_src(ty, H, mode) != (int)yy) continue;
+      for (int ix = 0; ix < nx; ++ix) {
+        int tx = ix == 0 ? (int)xx : (ix <= (px0 > 0 ? px0 : 0) ? -ix : W - 1 + (ix - (px0 > 0 ? px0 : 0)));
+        if (tx + px0 < 0 || tx + px0 >= OW) continue;
+        if (pad_src(tx, W, mode) != (int)xx) continue;
+        pad_acc(acc, st_ld4<ST>(dy, (base + ((int64_t)(ty + py0) * OW + (tx + px0)) * C4) * 4));
+      }
+    }
+    st_st4<ST>(dx, (int64_t)t64 * 4, acc);
+  }
+}
+extern "C" int ppst_pad2d_bwd_st(const void* dy, void* dx, int B, int H, int W, int C, int py0, int py1, int px0, int px1, int mode,
+                                 int st, void* stream);
 extern "C" int ppst_pad2d_bwd(const void* dy, void* dx, int B, int H, int W, int C, int py0, int py1, int px0, int px1, int mode,
                               void* stream) {
+  return ppst_pad2d_bwd_st(dy, dx, B, H, W, C, py0, py1, px0, px1, mode, PPST_ST_F32, stream);
+}
+extern "C" int ppst_pad2d_bwd_st(const void* dy, void* dx, int B, int H, int W, int C, int py0, int py1, int px0, int px1, int mode,
+                                 int st, void* stream) {
+  if ((unsigned)st > 2u) return PPST_EINVAL;
   const int OH = H + py0 + py1, OW = W + px0 + px1;
   if (B < 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || mode < 0 || mode > 2) return PPST_EINVAL;
   if (mode == PPST_PAD_REFLECT && (py0 >= H || py1 >= H || px0 >= W || px1 >= W)) return PPST_EINVAL;
@@ -391,6 +458,13 @@ extern "C" int ppst_pad2d_bwd(const void* dy, void* dx, int B, int H, int W, int
   if (!dy || !dx) return PPST_ENULL;
   const int64_t total = (int64_t)B * H * W * C;
   if (total > PPST_IDX32_MAX || (int64_t)B * OH * OW * C > PPST_IDX32_MAX) return PPST_EINVAL;
+  if (st) {
+    if (C % 4 || ((uintptr_t)dy | (uintptr_t)dx) % 8) return PPST_EINVAL;
+    PPST_ST_SWITCH(st, PPST_LAUNCH(pad2d_bwd_st_kernel<ST_>, dim3(tg_grid(total / 4)), dim3(256), 0, as_stream(stream), dy, dx, H, W, C / 4, OH,
+                                   OW, py0, py1, px0, px1, mode, (unsigned)(total / 4), make_fastdiv((unsigned)(C / 4)),
+                                   make_fastdiv((unsigned)W), make_fastdiv((unsigned)H)));
+    return PPST_LAUNCH_CHECK();
+  }
   if (C % 4 == 0 && ((uintptr_t)dy | (uintptr_t)dx) % 16 == 0) {     // four channels per thread (same sums, same order)
     PPST_LAUNCH(pad2d_bwd_kernel<float4>, dim3(tg_grid(total / 4)), dim3(256), 0, as_stream(stream), (const float4*)dy, (float4*)dx, H, W,
                 C / 4, OH, OW, py0, py1, px0, px1, mode, (unsigned)(total / 4), make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)W),
@@ -430,7 +504,8 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
 // 2x2 footprint can touch it (a generous index window; each tap re-derives the forward's (y0, y1, ly) and takes the weight
 // that lands on this pixel), in a fixed order: no atomics, bit-reproducible, and the 4 x over-read of dy stays in L2.
 // (The scatter form above cost 0.3 ms per launch on the x8 / x4 upsamplings of the train step.)
-__global__ __launch_bounds__(256) void bilinear_bwd_gather_kernel(const float4* __restrict__ dy, float4* __restrict__ dx, int H, int W,
+template <int ST = PPST_ST_F32>
+__global__ __launch_bounds__(256) void bilinear_bwd_gather_kernel(const void* __restrict__ dy, void* __restrict__ dx, int H, int W,
                                                                   int C4, int OH, int OW, int dy_ld4, int dx_ld4, float sy, float sx,
                                                                   unsigned total, FastDiv d_c, FastDiv d_w, FastDiv d_h) {
   for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
@@ -452,38 +527,46 @@ __global__ __launch_bounds__(256) void bilinear_bwd_gather_kernel(const float4* 
       const float ly = fy - (float)y0;
       const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
       if (wy == 0.f) continue;
-      const float4* row = dy + (((int64_t)b * OH + oy) * OW) * dy_ld4 + c4;
+      const int64_t row = (((int64_t)b * OH + oy) * OW) * dy_ld4 + c4;
       for (int ox = ox_lo; ox <= ox_hi; ++ox) {
         const float fx = fmaxf(((float)ox + 0.5f) * sx - 0.5f, 0.f);
         const int x0 = min((int)fx, W - 1), x1 = x0 + (x0 < W - 1);
         const float lx = fx - (float)x0;
         const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
         if (wx == 0.f) continue;
-        const float4 g = row[(int64_t)ox * dy_ld4];
+        const float4 g = st_ld4<ST>(dy, (row + (int64_t)ox * dy_ld4) * 4);
         // the forward's four products hy*hx, hy*lx, ly*hx, ly*lx: when both corners of an axis clamp onto this pixel their
         // weights add (1 - l) + l; the scatter form adds the two products separately -- equal to rounding
         const float w = wy * wx;
         acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
       }
     }
-    float4* d = dx + (((int64_t)b * H + y) * W + x) * dx_ld4 + c4;
-    const float4 p = *d;
-    *d = make_float4(p.x + acc.x, p.y + acc.y, p.z + acc.z, p.w + acc.w);
+    const int64_t d = ((((int64_t)b * H + y) * W + x) * dx_ld4 + c4) * 4;
+    const float4 p = st_ld4<ST>(dx, d);
+    st_st4<ST>(dx, d, make_float4(p.x + acc.x, p.y + acc.y, p.z + acc.z, p.w + acc.w));
   }
 }
+extern "C" int ppst_bilinear_bwd_st(const void* dy, void* dx, int B, int H, int W, int C, int dx_ld, int OH, int OW, int dy_ld, int st,
+                                    void* stream);
 extern "C" int ppst_bilinear_bwd(const void* dy, void* dx, int B, int H, int W, int C, int dx_ld, int OH, int OW, int dy_ld,
                                  void* stream) {
+  return ppst_bilinear_bwd_st(dy, dx, B, H, W, C, dx_ld, OH, OW, dy_ld, PPST_ST_F32, stream);
+}
+extern "C" int ppst_bilinear_bwd_st(const void* dy, void* dx, int B, int H, int W, int C, int dx_ld, int OH, int OW, int dy_ld, int st,
+                                    void* stream) {
+  if ((unsigned)st > 2u) return PPST_EINVAL;
   if (B < 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || dx_ld < C || dy_ld < C) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!dy || !dx) return PPST_ENULL;
-  if (C % 4 == 0 && dx_ld % 4 == 0 && dy_ld % 4 == 0 && (((uintptr_t)dy | (uintptr_t)dx) % 16) == 0 &&
+  if (C % 4 == 0 && dx_ld % 4 == 0 && dy_ld % 4 == 0 && (((uintptr_t)dy | (uintptr_t)dx) % (st ? 8 : 16)) == 0 &&
       (int64_t)B * H * W * (C / 4) <= PPST_IDX32_MAX) {
     const int64_t t4 = (int64_t)B * H * W * (C / 4);
-    PPST_LAUNCH(bilinear_bwd_gather_kernel, dim3(tg_grid(t4)), dim3(256), 0, as_stream(stream), (const float4*)dy, (float4*)dx, H, W,
-                C / 4, OH, OW, dy_ld / 4, dx_ld / 4, (float)H / (float)OH, (float)W / (float)OW, (unsigned)t4,
-                make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)W), make_fastdiv((unsigned)H));
+    PPST_ST_SWITCH(st, PPST_LAUNCH(bilinear_bwd_gather_kernel<ST_>, dim3(tg_grid(t4)), dim3(256), 0, as_stream(stream), dy, dx, H, W,
+                                   C / 4, OH, OW, dy_ld / 4, dx_ld / 4, (float)H / (float)OH, (float)W / (float)OW, (unsigned)t4,
+                                   make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)W), make_fastdiv((unsigned)H)));
     return PPST_LAUNCH_CHECK();
   }
+  if (st) return PPST_EINVAL;
   const int64_t total = (int64_t)B * OH * OW * C;
   if (total > PPST_IDX32_MAX) return PPST_EINVAL;
   PPST_LAUNCH(bilinear_bwd_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)dy, (float*)dx, H, W, C, OH, OW,
@@ -557,7 +640,8 @@ __global__ __launch_bounds__(256) void gap_gmp_bwd_kernel(const float* __restric
 // guarded atomicMin per channel (round 2 did the guard read + atomic per ELEMENT: four volatile loads per pixel, 140 us for a
 // (4, 512, 512, 32) tensor that a plain read moves in 30).  Needs hw % GMP_NP == 0 (a strip stays inside one image).
 #define GMP_NP 16
-__global__ __launch_bounds__(256) void gmp_argmax4_kernel(const float4* __restrict__ x, const float* __restrict__ mask,
+template <int ST = PPST_ST_F32>
+__global__ __launch_bounds__(256) void gmp_argmax4_kernel(const void* __restrict__ x, const float* __restrict__ mask,
                                                           const float* __restrict__ v, int* __restrict__ arg, unsigned hw, int C, int ld4,
                                                           unsigned total_strips, FastDiv d_c4, FastDiv d_hwn) {
   for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total_strips; t64 += (uint64_t)gridDim.x * 256) {
@@ -571,7 +655,7 @@ __global__ __launch_bounds__(256) void gmp_argmax4_kernel(const float4* __restri
 #pragma unroll
     for (int j = GMP_NP - 1; j >= 0; --j) {                         // descending: the last assignment is the first match
       const float m = mask ? mask[bp0 + j] : 1.f;
-      const float4 xv = x[(int64_t)(bp0 + j) * ld4 + c4];
+      const float4 xv = st_ld4<ST>(x, ((int64_t)(bp0 + j) * ld4 + c4) * 4);
       if (xv.x * m == mv.x) f0 = j;
       if (xv.y * m == mv.y) f1 = j;
       if (xv.z * m == mv.z) f2 = j;
@@ -607,8 +691,9 @@ __global__ __launch_bounds__(256) void gmp_argmax4e_kernel(const float4* __restr
     if (xv.w * m == mv.w && pix < cur[3]) atomicMin(ap + 3, pix);
   }
 }
+template <int ST = PPST_ST_F32>
 __global__ __launch_bounds__(256) void gap_gmp_bwd4_kernel(const float* __restrict__ mask, const int* __restrict__ arg,
-                                                           const float* __restrict__ g, float4* __restrict__ dx, unsigned hw, int C,
+                                                           const float* __restrict__ g, void* __restrict__ dx, unsigned hw, int C,
                                                            int accumulate, unsigned total, FastDiv d_c4, FastDiv d_hw) {
   const float invP = 1.f / (float)hw;
   for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
@@ -621,13 +706,21 @@ __global__ __launch_bounds__(256) void gap_gmp_bwd4_kernel(const float* __restri
     const float4 ga = *(const float4*)(g + (int64_t)b * 2 * C + c4 * 4), gm = *(const float4*)(g + (int64_t)b * 2 * C + C + c4 * 4);
     float4 o = make_float4(m * (ga.x * invP + (pix == ar.x ? gm.x : 0.f)), m * (ga.y * invP + (pix == ar.y ? gm.y : 0.f)),
                            m * (ga.z * invP + (pix == ar.z ? gm.z : 0.f)), m * (ga.w * invP + (pix == ar.w ? gm.w : 0.f)));
-    float4* d = dx + (int64_t)bpu * (C >> 2) + c4;
-    if (accumulate) { const float4 p = *d; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-    *d = o;
+    const int64_t d = ((int64_t)bpu * (C >> 2) + c4) * 4;
+    if (accumulate) { const float4 p = st_ld4<ST>(dx, d); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+    st_st4<ST>(dx, d, o);
   }
 }
+extern "C" int ppst_gap_gmp_bwd_st(const void* x, const void* mask, const void* v, const void* g, void* dx, void* arg_ws, int B,
+                                   int64_t hw, int C, int ld, int accumulate, int st, void* stream);
 extern "C" int ppst_gap_gmp_bwd(const void* x, const void* mask, const void* v, const void* g, void* dx, void* arg_ws, int B,
                                 int64_t hw, int C, int ld, int accumulate, void* stream) {
+  return ppst_gap_gmp_bwd_st(x, mask, v, g, dx, arg_ws, B, hw, C, ld, accumulate, PPST_ST_F32, stream);
+}
+// st: storage type of x and dx (v, g, mask fp32)
+extern "C" int ppst_gap_gmp_bwd_st(const void* x, const void* mask, const void* v, const void* g, void* dx, void* arg_ws, int B,
+                                   int64_t hw, int C, int ld, int accumulate, int st, void* stream) {
+  if ((unsigned)st > 2u) return PPST_EINVAL;
   if (B < 0 || hw <= 0 || hw > 0x7fffffffll || C <= 0 || ld < C) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!x || !v || !g || !dx || !arg_ws) return PPST_ENULL;
@@ -635,20 +728,23 @@ extern "C" int ppst_gap_gmp_bwd(const void* x, const void* mask, const void* v, 
   if (total > PPST_IDX32_MAX) return PPST_EINVAL;
   hipError_t e = hipMemsetAsync(arg_ws, 0x7f, (size_t)B * C * sizeof(int), as_stream(stream));   // 0x7f7f7f7f: above any pixel index
   if (e != hipSuccess) return (int)e;
-  if (C % 4 == 0 && ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)v | (uintptr_t)g | (uintptr_t)dx | (uintptr_t)arg_ws) % 16) == 0) {
+  if (st && (C % 4 || ld % 4 || hw % GMP_NP || ((uintptr_t)x | (uintptr_t)dx) % 8 || ((uintptr_t)v | (uintptr_t)g | (uintptr_t)arg_ws) % 16))
+    return PPST_EINVAL;          // half storage: the strip form only
+  if (C % 4 == 0 && ld % 4 == 0 && (((uintptr_t)v | (uintptr_t)g | (uintptr_t)arg_ws) % 16) == 0 &&
+      (((uintptr_t)x | (uintptr_t)dx) % (st ? 8 : 16)) == 0) {
     const int64_t t4 = total / 4;
     if (hw % GMP_NP == 0) {
       const int64_t strips = t4 / GMP_NP;
-      PPST_LAUNCH(gmp_argmax4_kernel, dim3(tg_grid(strips)), dim3(256), 0, as_stream(stream), (const float4*)x, (const float*)mask,
-                  (const float*)v, (int*)arg_ws, (unsigned)hw, C, ld / 4, (unsigned)strips, make_fastdiv((unsigned)(C / 4)),
-                  make_fastdiv((unsigned)(hw / GMP_NP)));
+      PPST_ST_SWITCH(st, PPST_LAUNCH(gmp_argmax4_kernel<ST_>, dim3(tg_grid(strips)), dim3(256), 0, as_stream(stream), x, (const float*)mask,
+                                     (const float*)v, (int*)arg_ws, (unsigned)hw, C, ld / 4, (unsigned)strips,
+                                     make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)(hw / GMP_NP))));
     } else {
       PPST_LAUNCH(gmp_argmax4e_kernel, dim3(tg_grid(t4)), dim3(256), 0, as_stream(stream), (const float4*)x, (const float*)mask,
                   (const float*)v, (int*)arg_ws, (unsigned)hw, C, ld / 4, (unsigned)t4, make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)hw));
     }
-    PPST_LAUNCH(gap_gmp_bwd4_kernel, dim3(tg_grid(t4)), dim3(256), 0, as_stream(stream), (const float*)mask, (const int*)arg_ws,
-                (const float*)g, (float4*)dx, (unsigned)hw, C, accumulate, (unsigned)t4, make_fastdiv((unsigned)(C / 4)),
-                make_fastdiv((unsigned)hw));
+    PPST_ST_SWITCH(st, PPST_LAUNCH(gap_gmp_bwd4_kernel<ST_>, dim3(tg_grid(t4)), dim3(256), 0, as_stream(stream), (const float*)mask,
+                                   (const int*)arg_ws, (const float*)g, dx, (unsigned)hw, C, accumulate, (unsigned)t4,
+                                   make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)hw)));
     return PPST_LAUNCH_CHECK();
   }
   PPST_LAUNCH(gmp_argmax_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)mask,
@@ -665,7 +761,8 @@ extern "C" int ppst_gap_gmp_bwd(const void* x, const void* mask, const void* v, 
 // single-head kernels; dx = the SUM over heads, written once (eight dense per-head gradients and seven autograd adds per pyramid
 // level before).  Strip form only (hw % GMP_NP == 0: every level of the 512 / 256 pyramids).
 #define GGM_MAXH 4
-__global__ __launch_bounds__(256) void gmp_argmax_multi4_kernel(const float4* __restrict__ x, const float* __restrict__ masks,
+template <int ST = PPST_ST_F32>
+__global__ __launch_bounds__(256) void gmp_argmax_multi4_kernel(const void* __restrict__ x, const float* __restrict__ masks,
                                                                 const float* __restrict__ v, int* __restrict__ arg, unsigned hw, int C, int ld4,
                                                                 int nm, int with_plain, int B, unsigned total_strips, FastDiv d_c4,
                                                                 FastDiv d_hwn) {
@@ -685,7 +782,7 @@ __global__ __launch_bounds__(256) void gmp_argmax_multi4_kernel(const float4* __
     }
 #pragma unroll
     for (int j = GMP_NP - 1; j >= 0; --j) {                         // descending: the last assignment is the first match
-      const float4 xv = x[(int64_t)(bp0 + j) * ld4 + c4];
+      const float4 xv = st_ld4<ST>(x, ((int64_t)(bp0 + j) * ld4 + c4) * 4);
 #pragma unroll
       for (int h = 0; h < GGM_MAXH; ++h) {
         if (h < nh) {
@@ -710,8 +807,9 @@ __global__ __launch_bounds__(256) void gmp_argmax_multi4_kernel(const float4* __
     }
   }
 }
+template <int ST = PPST_ST_F32>
 __global__ __launch_bounds__(256) void gap_gmp_bwd_multi4_kernel(const float* __restrict__ masks, const int* __restrict__ arg,
-                                                                 const float* __restrict__ g, float4* __restrict__ dx, unsigned hw, int C,
+                                                                 const float* __restrict__ g, void* __restrict__ dx, unsigned hw, int C,
                                                                  int nm, int with_plain, int B, int accumulate, unsigned total, FastDiv d_c4,
                                                                  FastDiv d_hw) {
   const float invP = 1.f / (float)hw;
@@ -736,14 +834,16 @@ __global__ __launch_bounds__(256) void gap_gmp_bwd_multi4_kernel(const float* __
         o.w += m * (ga.w * invP + (pix == ar.w ? gm.w : 0.f));
       }
     }
-    float4* d = dx + (int64_t)bpu * (C >> 2) + c4;
-    if (accumulate) { const float4 p = *d; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-    *d = o;
+    const int64_t d = ((int64_t)bpu * (C >> 2) + c4) * 4;
+    if (accumulate) { const float4 p = st_ld4<ST>(dx, d); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+    st_st4<ST>(dx, d, o);
   }
 }
-// x [B][hw][ld], masks [B][hw][nm], v / g [(nm + with_plain) * B][2C] head-major, dx [B][hw][C] dense, arg_ws >= heads * B * C ints
+// x [B][hw][ld], masks [B][hw][nm], v / g [(nm + with_plain) * B][2C] head-major, dx [B][hw][C] dense, arg_ws >= heads * B * C ints;
+// st: storage type of x and dx
 extern "C" int ppst_gap_gmp_multi_bwd(const void* x, const void* masks, const void* v, const void* g, void* dx, void* arg_ws, int B,
-                                      int64_t hw, int C, int ld, int nm, int with_plain, int accumulate, void* stream) {
+                                      int64_t hw, int C, int ld, int nm, int with_plain, int accumulate, int st, void* stream) {
+  if ((unsigned)st > 2u) return PPST_EINVAL;
   if (B < 0 || hw <= 0 || hw > 0x7fffffffll || C <= 0 || C % 4 || ld % 4 || ld < C || nm < 1 || nm > 3 ||
       (with_plain != 0 && with_plain != 1) || hw % GMP_NP)
     return PPST_EINVAL;
@@ -751,17 +851,17 @@ extern "C" int ppst_gap_gmp_multi_bwd(const void* x, const void* masks, const vo
   if (!x || !masks || !v || !g || !dx || !arg_ws) return PPST_ENULL;
   const int64_t total = (int64_t)B * hw * C;
   if (total > PPST_IDX32_MAX) return PPST_EINVAL;
-  if ((((uintptr_t)x | (uintptr_t)v | (uintptr_t)g | (uintptr_t)dx | (uintptr_t)arg_ws) % 16) != 0) return PPST_EINVAL;
+  if ((((uintptr_t)v | (uintptr_t)g | (uintptr_t)arg_ws) % 16) != 0 || (((uintptr_t)x | (uintptr_t)dx) % (st ? 8 : 16)) != 0) return PPST_EINVAL;
   const int heads = nm + with_plain;
   hipError_t e = hipMemsetAsync(arg_ws, 0x7f, (size_t)heads * B * C * sizeof(int), as_stream(stream));
   if (e != hipSuccess) return (int)e;
   const int64_t t4 = total / 4, strips = t4 / GMP_NP;
-  PPST_LAUNCH(gmp_argmax_multi4_kernel, dim3(tg_grid(strips)), dim3(256), 0, as_stream(stream), (const float4*)x, (const float*)masks,
-              (const float*)v, (int*)arg_ws, (unsigned)hw, C, ld / 4, nm, with_plain, B, (unsigned)strips, make_fastdiv((unsigned)(C / 4)),
-              make_fastdiv((unsigned)(hw / GMP_NP)));
-  PPST_LAUNCH(gap_gmp_bwd_multi4_kernel, dim3(tg_grid(t4)), dim3(256), 0, as_stream(stream), (const float*)masks, (const int*)arg_ws,
-              (const float*)g, (float4*)dx, (unsigned)hw, C, nm, with_plain, B, accumulate, (unsigned)t4, make_fastdiv((unsigned)(C / 4)),
-              make_fastdiv((unsigned)hw));
+  PPST_ST_SWITCH(st, PPST_LAUNCH(gmp_argmax_multi4_kernel<ST_>, dim3(tg_grid(strips)), dim3(256), 0, as_stream(stream), x, (const float*)masks,
+                                 (const float*)v, (int*)arg_ws, (unsigned)hw, C, ld / 4, nm, with_plain, B, (unsigned)strips,
+                                 make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)(hw / GMP_NP))));
+  PPST_ST_SWITCH(st, PPST_LAUNCH(gap_gmp_bwd_multi4_kernel<ST_>, dim3(tg_grid(t4)), dim3(256), 0, as_stream(stream), (const float*)masks,
+                                 (const int*)arg_ws, (const float*)g, dx, (unsigned)hw, C, nm, with_plain, B, accumulate, (unsigned)t4,
+                                 make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)hw)));
   return PPST_LAUNCH_CHECK();
 }
 
@@ -893,7 +993,8 @@ __global__ __launch_bounds__(256) void noise_wgrad_kernel(const float* __restric
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 // float4 form (C, ld multiples of 4, aligned): a wave covers 256 / C4 ... whole pixels per pass -- lane -> (pixel, channel quad)
-__global__ __launch_bounds__(256) void noise_wgrad4_kernel(const float4* __restrict__ dpre, const float* __restrict__ noise,
+template <int ST = PPST_ST_F32>
+__global__ __launch_bounds__(256) void noise_wgrad4_kernel(const void* __restrict__ dpre, const float* __restrict__ noise,
                                                            float* __restrict__ partial, int64_t npix, int C4, int ld4) {
   __shared__ float red[4];
   float acc = 0.f;
@@ -903,7 +1004,7 @@ __global__ __launch_bounds__(256) void noise_wgrad4_kernel(const float4* __restr
   if (pr < ppb)
     for (int64_t p = (int64_t)blockIdx.x * ppb + pr; p < npix; p += (int64_t)gridDim.x * ppb) {
       float s = 0.f;
-      for (int c = cl; c < C4; c += lanes) { const float4 v = dpre[p * ld4 + c]; s += (v.x + v.y) + (v.z + v.w); }
+      for (int c = cl; c < C4; c += lanes) { const float4 v = st_ld4<ST>(dpre, (p * ld4 + c) * 4); s += (v.x + v.y) + (v.z + v.w); }
       acc += s * noise[p];
     }
   acc = wave_sum(acc);
@@ -929,16 +1030,25 @@ extern "C" int64_t ppst_noise_wgrad_ws(int64_t npix) {
   if (b > 2048) b = 2048;
   return (b < 1 ? 1 : b) * (int64_t)sizeof(float);
 }
+extern "C" int ppst_noise_wgrad_st(const void* dpre, const void* noise, void* out, void* ws, int64_t npix, int C, int ld, int accumulate,
+                                   int st, void* stream);
 extern "C" int ppst_noise_wgrad(const void* dpre, const void* noise, void* out, void* ws, int64_t npix, int C, int ld, int accumulate,
                                 void* stream) {
+  return ppst_noise_wgrad_st(dpre, noise, out, ws, npix, C, ld, accumulate, PPST_ST_F32, stream);
+}
+extern "C" int ppst_noise_wgrad_st(const void* dpre, const void* noise, void* out, void* ws, int64_t npix, int C, int ld, int accumulate,
+                                   int st, void* stream) {
+  if ((unsigned)st > 2u) return PPST_EINVAL;
   if (npix < 0 || C <= 0 || ld < C) return PPST_EINVAL;
   if (!out) return PPST_ENULL;
   if (npix == 0) return accumulate ? PPST_OK : (int)hipMemsetAsync(out, 0, sizeof(float), as_stream(stream));
   if (!dpre || !noise || !ws) return PPST_ENULL;
   const int blocks = (int)(ppst_noise_wgrad_ws(npix) / (int64_t)sizeof(float));
-  if (C % 4 == 0 && ld % 4 == 0 && (uintptr_t)dpre % 16 == 0 && (C / 4 >= 256 || 256 % (C / 4) == 0))
-    PPST_LAUNCH(noise_wgrad4_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float4*)dpre, (const float*)noise, (float*)ws,
-                npix, C / 4, ld / 4);
+  if (C % 4 == 0 && ld % 4 == 0 && (uintptr_t)dpre % (st ? 8 : 16) == 0 && (C / 4 >= 256 || 256 % (C / 4) == 0))
+    PPST_ST_SWITCH(st, PPST_LAUNCH(noise_wgrad4_kernel<ST_>, dim3(blocks), dim3(256), 0, as_stream(stream), dpre, (const float*)noise,
+                                   (float*)ws, npix, C / 4, ld / 4));
+  else if (st)
+    return PPST_EINVAL;
   else
     PPST_LAUNCH(noise_wgrad_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)dpre, (const float*)noise, (float*)ws,
                 npix, C, ld);
@@ -993,13 +1103,25 @@ __global__ __launch_bounds__(256) void s2d_kernel(const VT* __restrict__ x, VT* 
     y[t64] = v;
   }
 }
+extern "C" int ppst_space_to_depth_st(const void* x, void* y, int B, int H, int W, int C, int x_ld, int st, void* stream);
 extern "C" int ppst_space_to_depth(const void* x, void* y, int B, int H, int W, int C, int x_ld, void* stream) {
+  return ppst_space_to_depth_st(x, y, B, H, W, C, x_ld, PPST_ST_F32, stream);
+}
+extern "C" int ppst_space_to_depth_st(const void* x, void* y, int B, int H, int W, int C, int x_ld, int st, void* stream) {
+  if ((unsigned)st > 2u) return PPST_EINVAL;
   if (B < 0 || H <= 0 || W <= 0 || C <= 0 || x_ld < C) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   if (!x || !y) return PPST_ENULL;
   const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
   const int64_t total = (int64_t)B * H2 * W2 * 4 * C;
   if (total > PPST_IDX32_MAX) return PPST_EINVAL;
+  if (st) {       // half storage: four channels = one 8-byte element (pure data movement)
+    if (C % 4 || x_ld % 4 || ((uintptr_t)x | (uintptr_t)y) % 8) return PPST_EINVAL;
+    PPST_LAUNCH(s2d_kernel<uint2>, dim3(tg_grid(total / 4)), dim3(256), 0, as_stream(stream), (const uint2*)x, (uint2*)y, H, W, C / 4,
+                x_ld / 4, H2, W2, (unsigned)(total / 4), make_fastdiv((unsigned)(C / 4)), make_fastdiv(4u), make_fastdiv((unsigned)W2),
+                make_fastdiv((unsigned)H2));
+    return PPST_LAUNCH_CHECK();
+  }
   if (C % 4 == 0 && x_ld % 4 == 0 && ((uintptr_t)x | (uintptr_t)y) % 16 == 0)
     PPST_LAUNCH(s2d_kernel<float4>, dim3(tg_grid(total / 4)), dim3(256), 0, as_stream(stream), (const float4*)x, (float4*)y, H, W, C / 4,
                 x_ld / 4, H2, W2, (unsigned)(total / 4), make_fastdiv((unsigned)(C / 4)), make_fastdiv(4u), make_fastdiv((unsigned)W2),

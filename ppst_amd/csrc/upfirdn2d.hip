@@ -276,7 +276,8 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic_f64(const double* __res
 // One thread = 4 channels of one output pixel; only the taps whose upsampled coordinate is even touch an input sample
 // (at most ceil(K/2)^2 of them).  32-bit index math with multiplier division (the generic kernel's int64 % and / cost
 // ~100 instructions per element: 0.11 ms per launch in the train step).
-__global__ __launch_bounds__(256) void upfirdn2d_up2_chan(const float4* __restrict__ x, float4* __restrict__ y, UfParams p, unsigned total,
+template <int ST = PPST_ST_F32>
+__global__ __launch_bounds__(256) void upfirdn2d_up2_chan(const void* __restrict__ x, void* __restrict__ y, UfParams p, unsigned total,
                                                           FastDiv d_c, FastDiv d_w, FastDiv d_h) {
   const int c4n = p.minor >> 2;
   for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
@@ -289,16 +290,16 @@ __global__ __launch_bounds__(256) void upfirdn2d_up2_chan(const float4* __restri
     for (int ky = 0; ky < p.kh; ++ky) {
       const int Y = oy + ky - p.pad_y0;
       if (Y < 0 || (Y & 1) || (Y >> 1) >= p.in_h) continue;
-      const float4* row = x + ((int64_t)m * p.in_h + (Y >> 1)) * p.in_w * c4n + c4;
+      const int64_t row = ((int64_t)m * p.in_h + (Y >> 1)) * p.in_w * c4n + c4;
       for (int kx = 0; kx < p.kw; ++kx) {
         const int X = ox + kx - p.pad_x0;
         if (X < 0 || (X & 1) || (X >> 1) >= p.in_w) continue;
-        const float4 v = row[(int64_t)(X >> 1) * c4n];
+        const float4 v = st_ld4<ST>(x, (row + (int64_t)(X >> 1) * c4n) * 4);
         const float f = p.k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
         acc.x += v.x * f; acc.y += v.y * f; acc.z += v.z * f; acc.w += v.w * f;
       }
     }
-    y[(((int64_t)m * p.out_h + oy) * p.out_w + ox) * c4n + c4] = acc;
+    st_st4<ST>(y, ((((int64_t)m * p.out_h + oy) * p.out_w + ox) * c4n + c4) * 4, acc);
   }
 }
 
@@ -372,6 +373,13 @@ extern "C" int ppst_upfirdn2d(const void* x, const void* k, void* y, int major, 
     if (fast && kh == 4) return launch_fast<4, 4, ST_>(x, y, p, st);                            \
     if (down2 && kh == 3) return launch_chan<3, 3, ST_>(x, y, p, 2, false, st);                 \
     if (down2 && kh == 4) return launch_chan<4, 4, ST_>(x, y, p, 2, false, st);                 \
+    if (up_x == 2 && up_y == 2 && down_x == 1 && down_y == 1 && minor % 4 == 0 && n / 4 <= PPST_IDX32_MAX) {   \
+      int64_t b4_ = cdiv64(n / 4, 256);                                                         \
+      if (b4_ > 256 * 32) b4_ = 256 * 32;                                                       \
+      PPST_LAUNCH(upfirdn2d_up2_chan<ST_>, dim3((unsigned)b4_), dim3(256), 0, st, x, y, p, (unsigned)(n / 4),   \
+                  make_fastdiv((unsigned)(minor / 4)), make_fastdiv((unsigned)p.out_w), make_fastdiv((unsigned)p.out_h)); \
+      return PPST_LAUNCH_CHECK();                                                               \
+    }                                                                                           \
     int64_t blocks_ = cdiv64(n, 256);                                                           \
     if (blocks_ > 256 * 32) blocks_ = 256 * 32;                                                 \
     PPST_LAUNCH(upfirdn2d_generic<ST_>, dim3((unsigned)blocks_), dim3(256), 0, st, x, y, p, n); \
@@ -389,7 +397,7 @@ extern "C" int ppst_upfirdn2d(const void* x, const void* k, void* y, int major, 
       (((uintptr_t)x | (uintptr_t)y) % 16) == 0) {
     int64_t b4 = cdiv64(n / 4, 256);
     if (b4 > 256 * 32) b4 = 256 * 32;
-    PPST_LAUNCH(upfirdn2d_up2_chan, dim3((unsigned)b4), dim3(256), 0, st, (const float4*)xf, (float4*)yf, p, (unsigned)(n / 4),
+    PPST_LAUNCH(upfirdn2d_up2_chan<PPST_ST_F32>, dim3((unsigned)b4), dim3(256), 0, st, (const void*)xf, (void*)yf, p, (unsigned)(n / 4),
                 make_fastdiv((unsigned)(minor / 4)), make_fastdiv((unsigned)p.out_w), make_fastdiv((unsigned)p.out_h));
     return PPST_LAUNCH_CHECK();
   }

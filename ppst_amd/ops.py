@@ -153,6 +153,18 @@ def act_dtype():
     return torch.float32
 
 
+# Round 5: half-precision storage of the TRAINING activations and their gradients in precision mode 1 (BASELINE configs[3]'s "bf16": the
+# accuracy class of bf16 autocast, whose conv outputs and activation gradients are bfloat16 tensors).  The differentiable networks
+# (train_g.py) and the discriminator tape (train.py) start their trunks in train_dtype(); every kernel downstream keeps its input's
+# type, gradients take the type of the tensor they belong to.  Parameters, their gradients, Adam, statistics, pooled vectors, style
+# codes and the whole correspondence branch stay fp32.
+TRAIN_HALF = {"value": os.environ.get("PPST_TRAIN_HALF", "1") != "0"}
+
+
+def train_dtype():
+    return torch.bfloat16 if (TRAIN_HALF["value"] and PRECISION["value"] == 1) else torch.float32
+
+
 def _chk_act(t, name="activation"):
     if t is None:
         return
@@ -972,14 +984,21 @@ def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=No
     pass that scales dy; not with the bias outputs)."""
     assert plan.kind in ("conv", "s2d", "dgradT")
     assert dy_scale == 1.0 or not (want_bias or bias_out is not None)
-    in_ld = _nhwc_ld(x, "x")
-    dy_ld = _nhwc_ld(dy, "dy")
+    in_ld = _nhwc_ld(x, "x", half_ok=True)
+    dy_ld = _nhwc_ld(dy, "dy", half_ok=True)
+    half = x.dtype != torch.float32 or dy.dtype != torch.float32
+    if half and not (x.dtype == dy.dtype == torch.bfloat16 and PRECISION["value"] == 1 and WGRAD_X3["value"] and WGRAD_TR["value"]
+                     and WGRAD_TR["form"] == 2 and WGRAD_TR["bf16_single_pass"]):
+        raise RuntimeError("conv_wgrad on half-stored operands: both bfloat16, precision mode 1, the single-pass transposed-read kernel "
+                           "(got %s / %s, mode %d)" % (x.dtype, dy.dtype, PRECISION["value"]))
     B, H, W, _ = x.shape
     _, oh, ow, cout = dy.shape
     assert cout == plan.cout
     nchunks = plan.chunk_start.numel() - 1
     want_bias = want_bias or bias_out is not None
     aligned = cout % 4 == 0 and dy_ld % 4 == 0 and in_ld % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
+    if half and not (aligned and cout % 8 == 0 and dy_ld % 8 == 0 and in_ld % 8 == 0):
+        raise RuntimeError("conv_wgrad on bfloat16 operands needs channel counts / strides divisible by 8 and 16-byte aligned tensors")
     x3 = WGRAD_X3["value"] and plan.precision != 2 and aligned
     use_tr = x3 and WGRAD_TR["value"]
     per = nchunks * ((cout + 127) // 128)
@@ -1012,12 +1031,12 @@ def conv_wgrad(plan, x, dy, splits=None, out=None, accumulate=False, bias_out=No
         lib.ppst_wgrad_flop_steps(int(plan.flop_steps))
     if use_tr:
         if WGRAD_TR["form"] == 2:
-            check(lib.ppst_conv_wgrad_tr2(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), _p(csum), B, H, W, in_ld, oh, ow,
-                                          dy_ld, cout, plan.nsteps, nchunks, splits, plan.max_chunk_steps if WGRAD_TR["pair"] else 0,
-                                          plan.min_chunk_steps if WGRAD_TR["exact"] else 0,
-                                          0 if (WGRAD_TR["nohalo"] and plan.kind == "conv" and plan.k == 1 and plan.halo == 0) else 1,
-                                          1 if (PRECISION["value"] == 1 and WGRAD_TR["bf16_single_pass"]) else 3,
-                                          _stream()), "ppst_conv_wgrad_tr2")
+            check(lib.ppst_conv_wgrad_tr2_st(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), _p(csum), B, H, W, in_ld, oh, ow,
+                                             dy_ld, cout, plan.nsteps, nchunks, splits, plan.max_chunk_steps if WGRAD_TR["pair"] else 0,
+                                             plan.min_chunk_steps if WGRAD_TR["exact"] else 0,
+                                             0 if (WGRAD_TR["nohalo"] and plan.kind == "conv" and plan.k == 1 and plan.halo == 0) else 1,
+                                             1 if (PRECISION["value"] == 1 and WGRAD_TR["bf16_single_pass"]) else 3,
+                                             _ST[x.dtype], _stream()), "ppst_conv_wgrad_tr2")
         else:
             check(lib.ppst_conv_wgrad_tr(_p(x), _p(dy), _p(plan.steps), _p(plan.chunk_start), _p(partial), _p(csum), B, H, W, in_ld, oh, ow,
                                          dy_ld, cout, plan.nsteps, nchunks, splits, _stream()), "ppst_conv_wgrad_tr")
@@ -1056,24 +1075,24 @@ def wgrad_small_cin(x, dy, scale, out=None, accumulate=False):
     in_ld = _nhwc_ld(x)
     B, H, W, cin = x.shape
     cout = dy.shape[3]
-    assert _nhwc_ld(dy) == cout
+    assert _nhwc_ld(dy, "dy", half_ok=True) == cout
     ws = torch.empty(lib.ppst_wgrad_small_cin_ws(B * H * W, cin, cout) // 4, device=x.device, dtype=torch.float32)
     dw = _grad_out(out, (cout, cin, 1, 1), x)
-    check(lib.ppst_wgrad_small_cin(_p(x), _p(dy), _p(dw), _p(ws), B * H * W, cin, in_ld, cout, float(scale),
-                                   1 if (accumulate and out is not None) else 0, _stream()), "ppst_wgrad_small_cin")
+    check(lib.ppst_wgrad_small_cin_st(_p(x), _p(dy), _p(dw), _p(ws), B * H * W, cin, in_ld, cout, float(scale),
+                                      1 if (accumulate and out is not None) else 0, _ST[dy.dtype], _stream()), "ppst_wgrad_small_cin")
     return dw
 
 
 def colsum(x2d, scale=1.0, out=None, accumulate=False):
-    """x2d (rows, C) [row stride ld] -> (C,) column sums (bias gradients)."""
-    _chk(x2d)
+    """x2d (rows, C) [row stride ld] -> (C,) column sums (bias gradients); x2d fp32 or half-stored, the sums fp32."""
+    _chk_act(x2d)
     rows, C = x2d.shape
     ld = x2d.stride(0)
     assert x2d.stride(1) == 1
     ws = torch.empty(lib.ppst_colsum_ws(rows, C) // 4, device=x2d.device, dtype=torch.float32)
     dst = _grad_out(out, (C,), x2d)
-    check(lib.ppst_colsum(_p(x2d), _p(dst), _p(ws), rows, C, ld, float(scale), 1 if (accumulate and out is not None) else 0, _stream()),
-          "ppst_colsum")
+    check(lib.ppst_colsum_st(_p(x2d), _p(dst), _p(ws), rows, C, ld, float(scale), 1 if (accumulate and out is not None) else 0,
+                             _ST[x2d.dtype], _stream()), "ppst_colsum")
     return dst
 
 
@@ -1226,10 +1245,10 @@ def upscale_weight_bwd(dw4, cout, cin, scale=1.0, out=None, accumulate=False):
 
 
 def space_to_depth(x):
-    ld = _nhwc_ld(x)
+    ld = _nhwc_ld(x, half_ok=True)
     B, H, W, C = x.shape
-    y = torch.empty((B, (H + 1) // 2, (W + 1) // 2, 4 * C), device=x.device, dtype=torch.float32)
-    check(lib.ppst_space_to_depth(_p(x), _p(y), B, H, W, C, ld, _stream()), "ppst_space_to_depth")
+    y = torch.empty((B, (H + 1) // 2, (W + 1) // 2, 4 * C), device=x.device, dtype=x.dtype)
+    check(lib.ppst_space_to_depth_st(_p(x), _p(y), B, H, W, C, ld, _ST[x.dtype], _stream()), "ppst_space_to_depth")
     return y
 
 
@@ -1278,14 +1297,16 @@ def in_finalize_train(partial, count, style=None, post_bias=None, eps=1e-5):
 
 def dual_stats(g, y, gate=None):
     """per-(b, c) partial sums (sum g', sum g'*y), g' = g * lrelu'(gate) when gate is given."""
-    g_ld, y_ld = _nhwc_ld(g, "g"), _nhwc_ld(y, "y")
-    gate_ld = _nhwc_ld(gate, "gate") if gate is not None else 0
+    g_ld, y_ld = _nhwc_ld(g, "g", half_ok=True), _nhwc_ld(y, "y", half_ok=True)
+    gate_ld = _nhwc_ld(gate, "gate", half_ok=True) if gate is not None else 0
     B, H, W, C = g.shape
     assert y.shape == g.shape
+    if y.dtype != g.dtype or (gate is not None and gate.dtype != g.dtype):
+        raise RuntimeError("dual_stats: g, y and gate share one storage type (got %s / %s / %s)" % (g.dtype, y.dtype, None if gate is None else gate.dtype))
     n = ctypes.c_int(0)
     check(lib.ppst_dual_stats(None, None, None, None, B, H * W, C, g_ld, y_ld, gate_ld, ctypes.byref(n), None), "ppst_dual_stats(size)")
     part = torch.empty((B, n.value, C, 2), device=g.device, dtype=torch.float32)
-    check(lib.ppst_dual_stats(_p(g), _p(y), _p(gate), _p(part), B, H * W, C, g_ld, y_ld, gate_ld, ctypes.byref(n), _stream()),
+    check(lib.ppst_dual_stats_st(_p(g), _p(y), _p(gate), _p(part), B, H * W, C, g_ld, y_ld, gate_ld, ctypes.byref(n), _ST[g.dtype], _stream()),
           "ppst_dual_stats")
     return part
 
@@ -1306,12 +1327,14 @@ def in_bwd_finalize(partial, count, mean_rstd=None, style=None, want_dstyle=Fals
 
 
 def in_bwd_apply(g, y, coef, gate=None, post_gate=False):
-    g_ld, y_ld = _nhwc_ld(g, "g"), _nhwc_ld(y, "y")
-    gate_ld = _nhwc_ld(gate, "gate") if gate is not None else 0
+    g_ld, y_ld = _nhwc_ld(g, "g", half_ok=True), _nhwc_ld(y, "y", half_ok=True)
+    gate_ld = _nhwc_ld(gate, "gate", half_ok=True) if gate is not None else 0
     B, H, W, C = g.shape
-    dx = torch.empty((B, H, W, C), device=g.device, dtype=torch.float32)
-    check(lib.ppst_in_bwd_apply(_p(g), _p(y), _p(gate), _p(coef), _p(dx), B, H * W, C, g_ld, y_ld, gate_ld, C, 1 if post_gate else 0,
-                                _stream()), "ppst_in_bwd_apply")
+    if y.dtype != g.dtype or (gate is not None and gate.dtype != g.dtype):
+        raise RuntimeError("in_bwd_apply: g, y and gate share one storage type")
+    dx = torch.empty((B, H, W, C), device=g.device, dtype=g.dtype)
+    check(lib.ppst_in_bwd_apply_st(_p(g), _p(y), _p(gate), _p(coef), _p(dx), B, H * W, C, g_ld, y_ld, gate_ld, C, 1 if post_gate else 0,
+                                   _ST[g.dtype], _stream()), "ppst_in_bwd_apply")
     return dx
 
 
@@ -1332,28 +1355,28 @@ def prelu_bwd(g, y, prelu, scale_shift=None, res=None):
 
 
 def pad2d(x, py0, py1, px0, px1, mode):
-    ld = _nhwc_ld(x)
+    ld = _nhwc_ld(x, half_ok=True)
     B, H, W, C = x.shape
-    y = torch.empty((B, H + py0 + py1, W + px0 + px1, C), device=x.device, dtype=torch.float32)
-    check(lib.ppst_pad2d(_p(x), _p(y), B, H, W, C, ld, py0, py1, px0, px1, mode, _stream()), "ppst_pad2d")
+    y = torch.empty((B, H + py0 + py1, W + px0 + px1, C), device=x.device, dtype=x.dtype)
+    check(lib.ppst_pad2d_st(_p(x), _p(y), B, H, W, C, ld, py0, py1, px0, px1, mode, _ST[x.dtype], _stream()), "ppst_pad2d")
     return y
 
 
 def pad2d_bwd(dy, py0, py1, px0, px1, mode):
-    _chk(dy)
+    _chk_act(dy)
     dy = dy.contiguous()
     B, OH, OW, C = dy.shape
     H, W = OH - py0 - py1, OW - px0 - px1
-    dx = torch.empty((B, H, W, C), device=dy.device, dtype=torch.float32)
-    check(lib.ppst_pad2d_bwd(_p(dy), _p(dx), B, H, W, C, py0, py1, px0, px1, mode, _stream()), "ppst_pad2d_bwd")
+    dx = torch.empty((B, H, W, C), device=dy.device, dtype=dy.dtype)
+    check(lib.ppst_pad2d_bwd_st(_p(dy), _p(dx), B, H, W, C, py0, py1, px0, px1, mode, _ST[dy.dtype], _stream()), "ppst_pad2d_bwd")
     return dx
 
 
 def bilinear_bwd(dy, H, W):
-    dy_ld = _nhwc_ld(dy)
+    dy_ld = _nhwc_ld(dy, half_ok=True)
     B, OH, OW, C = dy.shape
-    dx = torch.zeros((B, H, W, C), device=dy.device, dtype=torch.float32)
-    check(lib.ppst_bilinear_bwd(_p(dy), _p(dx), B, H, W, C, C, OH, OW, dy_ld, _stream()), "ppst_bilinear_bwd")
+    dx = torch.zeros((B, H, W, C), device=dy.device, dtype=dy.dtype)
+    check(lib.ppst_bilinear_bwd_st(_p(dy), _p(dx), B, H, W, C, C, OH, OW, dy_ld, _ST[dy.dtype], _stream()), "ppst_bilinear_bwd")
     return dx
 
 
@@ -1366,23 +1389,23 @@ def avgpool_bwd(dy, f):
 
 
 def gap_gmp_bwd(x, mask, v, g, out=None):
-    """adjoint of gap_gmp; out given -> accumulate into it."""
-    ld = _nhwc_ld(x)
+    """adjoint of gap_gmp; out given -> accumulate into it.  The gradient takes x's storage type."""
+    ld = _nhwc_ld(x, half_ok=True)
     B, H, W, C = x.shape
     _chk(mask); _chk(v); _chk(g)
     acc = out is not None
     if out is None:
-        out = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+        out = torch.empty((B, H, W, C), device=x.device, dtype=x.dtype)
     arg = torch.empty((B, C), device=x.device, dtype=torch.int32)
-    check(lib.ppst_gap_gmp_bwd(_p(x), _p(mask), _p(v.contiguous()), _p(g.contiguous()), _p(out), ctypes.c_void_p(arg.data_ptr()), B, H * W, C, ld,
-                               1 if acc else 0, _stream()), "ppst_gap_gmp_bwd")
+    check(lib.ppst_gap_gmp_bwd_st(_p(x), _p(mask), _p(v.contiguous()), _p(g.contiguous()), _p(out), ctypes.c_void_p(arg.data_ptr()), B, H * W, C,
+                                  ld, 1 if acc else 0, _ST[x.dtype], _stream()), "ppst_gap_gmp_bwd")
     return out
 
 
 def gap_gmp_multi(x, masks, with_plain=True):
     """GAP || GMP of x * mask for every channel of ``masks`` (B,H,W,nm) -- and unmasked first when with_plain -- in one read of x:
     -> ((nm + with_plain) * B, 2C), head-major (ppst_gap_gmp_multi)."""
-    ld = _nhwc_ld(x)
+    ld = _nhwc_ld(x, half_ok=True)
     B, H, W, C = x.shape
     _chk(masks, "masks")
     masks = masks.contiguous()
@@ -1391,14 +1414,14 @@ def gap_gmp_multi(x, masks, with_plain=True):
     heads = nm + (1 if with_plain else 0)
     ws = torch.empty(lib.ppst_gap_gmp_multi_ws(B, H * W, C, heads) // 4, device=x.device, dtype=torch.float32)
     out = torch.empty((heads * B, 2 * C), device=x.device, dtype=torch.float32)
-    check(lib.ppst_gap_gmp_multi(_p(x), _p(masks), _p(out), _p(ws), B, H, W, C, ld, nm, 1 if with_plain else 0, _stream()),
+    check(lib.ppst_gap_gmp_multi(_p(x), _p(masks), _p(out), _p(ws), B, H, W, C, ld, nm, 1 if with_plain else 0, _ST[x.dtype], _stream()),
           "ppst_gap_gmp_multi")
     return out
 
 
 def gap_gmp_multi_bwd(x, masks, v, g, with_plain=True, out=None):
     """adjoint of gap_gmp_multi: the sum over the heads, one pass (out given -> accumulate into it)."""
-    ld = _nhwc_ld(x)
+    ld = _nhwc_ld(x, half_ok=True)
     B, H, W, C = x.shape
     _chk(masks); _chk(v); _chk(g)
     masks = masks.contiguous()
@@ -1406,10 +1429,11 @@ def gap_gmp_multi_bwd(x, masks, v, g, with_plain=True, out=None):
     heads = nm + (1 if with_plain else 0)
     acc = out is not None
     if out is None:
-        out = torch.empty((B, H, W, C), device=x.device, dtype=torch.float32)
+        out = torch.empty((B, H, W, C), device=x.device, dtype=x.dtype)
     arg = torch.empty((heads * B, C), device=x.device, dtype=torch.int32)
     check(lib.ppst_gap_gmp_multi_bwd(_p(x), _p(masks), _p(v.contiguous()), _p(g.contiguous()), _p(out), ctypes.c_void_p(arg.data_ptr()), B,
-                                     H * W, C, ld, nm, 1 if with_plain else 0, 1 if acc else 0, _stream()), "ppst_gap_gmp_multi_bwd")
+                                     H * W, C, ld, nm, 1 if with_plain else 0, 1 if acc else 0, _ST[x.dtype], _stream()),
+          "ppst_gap_gmp_multi_bwd")
     return out
 
 
@@ -1489,15 +1513,15 @@ def scale_by(x, s):
 
 
 def noise_wgrad(dpre, noise, out=None, accumulate=False):
-    ld = _nhwc_ld(dpre)
+    ld = _nhwc_ld(dpre, half_ok=True)
     B, H, W, C = dpre.shape
     _chk(noise)
     noise = noise.contiguous()
     assert noise.numel() == B * H * W
     ws = torch.empty(lib.ppst_noise_wgrad_ws(B * H * W) // 4, device=dpre.device, dtype=torch.float32)
     dst = _grad_out(out, (1,), dpre)
-    check(lib.ppst_noise_wgrad(_p(dpre), _p(noise), _p(dst), _p(ws), B * H * W, C, ld, 1 if (accumulate and out is not None) else 0,
-                               _stream()), "ppst_noise_wgrad")
+    check(lib.ppst_noise_wgrad_st(_p(dpre), _p(noise), _p(dst), _p(ws), B * H * W, C, ld, 1 if (accumulate and out is not None) else 0,
+                                  _ST[dpre.dtype], _stream()), "ppst_noise_wgrad")
     return dst
 
 

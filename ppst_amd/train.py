@@ -105,7 +105,7 @@ class DiscriminatorTrainer:
         x0 = to_nhwc(img)
         x0 = x0 if x0.is_contiguous() else x0.contiguous()
         tape["img"] = x0
-        x = D.from_rgb(x0, p + "convs.0.")
+        x = D.from_rgb(x0, p + "convs.0.", out_dtype=ops.train_dtype())      # (bfloat16 storage of the tape in precision mode 1)
         tape["x0"] = x
         blocks = []
         for name in weights.discriminator_block_names(self.size):
@@ -126,7 +126,7 @@ class DiscriminatorTrainer:
         cin = x.shape[3]
         fc = D.plan(p + "final_conv.Conv.weight", scale=1.0 / math.sqrt(cin * 9))(x, bias=D.p(p + "final_conv.Act.bias"), act=ops.ACT_LRELU)
         tape["x_last"], tape["fc"] = x, fc
-        f = ops.nhwc_to_nchw(fc).reshape(fc.shape[0], -1)
+        f = ops.nhwc_to_nchw(fc.float()).reshape(fc.shape[0], -1)           # (the 4 x 4 head and the two linears are fp32)
         w0, w1 = D.p(p + "final_linear.0.weight"), D.p(p + "final_linear.1.weight")
         h = ops.linear(f, w0, D.p(p + "final_linear.0.bias"), wscale=1.0 / math.sqrt(w0.shape[1]), act=ops.ACT_LRELU)
         pred = ops.linear(h, w1, D.p(p + "final_linear.1.bias"), wscale=1.0 / math.sqrt(w1.shape[1]))
@@ -162,7 +162,7 @@ class DiscriminatorTrainer:
         df = ops.linear_dgrad(gpre_h, w0, s0)
         fc = tape["fc"]
         B, hh, ww, C = fc.shape
-        dfc = ops.nchw_to_nhwc(df.view(B, C, hh, ww))
+        dfc = ops.nchw_to_nhwc(df.view(B, C, hh, ww)).to(fc.dtype)
         # final_conv (3x3 + fused lrelu)
         gpre = _lrelu_bwd(dfc, fc)
         scf = 1.0 / math.sqrt(tape["x_last"].shape[3] * 9)
@@ -274,7 +274,7 @@ class DiscriminatorTrainer:
         w = D.p(p + "convs.0.Conv.weight")
         sc0 = 1.0 / math.sqrt(w.shape[1])
         ops.wgrad_small_cin(t, keep["g0"], sc0, out=G("convs.0.Conv.weight"), accumulate=True)
-        t = ops.conv1x1_small_cin(t, w, None, sc0, ops.ACT_NONE)
+        t = ops.conv1x1_small_cin(t, w, None, sc0, ops.ACT_NONE, out_dtype=tape["x0"].dtype)
         t = _lrelu_bwd(t, tape["x0"])
         for blk, kb in zip(tape["blocks"], keep["blocks"]):
             q, cin = blk["q"], blk["cin"]
@@ -296,7 +296,7 @@ class DiscriminatorTrainer:
         ops.conv_wgrad(D.plan(p + "final_conv.Conv.weight", scale=scf), t, keep["gpre_fc"], out=G("final_conv.Conv.weight"), accumulate=True)
         t = D.plan(p + "final_conv.Conv.weight", scale=scf)(t)
         t = _lrelu_bwd(t, tape["fc"])
-        tf = ops.nhwc_to_nchw(t).reshape(B, -1)
+        tf = ops.nhwc_to_nchw(t.float()).reshape(B, -1)
         w0, w1 = D.p(p + "final_linear.0.weight"), D.p(p + "final_linear.1.weight")
         s0, s1 = 1.0 / math.sqrt(w0.shape[1]), 1.0 / math.sqrt(w1.shape[1])
         ops.linear_wgrad(keep["gpre_h"], tf, s0, out=G("final_linear.0.weight"), accumulate=True)

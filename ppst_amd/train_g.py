@@ -257,6 +257,7 @@ class GeneratorTrainer:
         """E2.warp (encoder_col.py:100-138) for the four levels with one GEMM; the correspondence matrix receives a
         gradient through the first level only (the others use corrmatrix.detach(), :197)."""
         B = feats[0].shape[0]
+        feats = [f.float() for f in feats]          # (the correspondence branch is fp32: a half-stored trunk is widened here, differentiably)
         pooled = [f if f.shape[1] == 64 else A.AvgPoolFn.apply(f, f.shape[1] // 64) for f in feats]
         V = torch.cat(pooled, dim=3).reshape(B, 4096, sum(CH))
         Wv = A.WarpGemmFn.apply(corr, V, CH[0]).view(B, 64, 64, sum(CH))
@@ -312,6 +313,7 @@ class GeneratorTrainer:
                 noise[name] = flat[off:off + n_].view(B, 1, H0 << e, W0 << e)
                 off += n_
         codes = [A.L2NormFn.apply(c, 1e-8, 0) for c in global_codes]
+        sp = sp.float()                             # (E1 hands over its last activation: bfloat16 in precision mode 1; the modulation reads fp32)
         g = codes[-1]
         ws = P("SpatialCodeModulation.scale.weight")
         inv = 1.0 / math.sqrt(ws.shape[1])
@@ -329,7 +331,7 @@ class GeneratorTrainer:
                 x = A.AddScaleFn.apply(skip, self._styled_conv(r, q + "conv2.", g, "HeadResnetBlock%d.conv2" % i, noise), INV_SQRT2)
         feas = []
         if extract_features:
-            feas.append(self._feat_head(x.detach(), "layer32.", 3))
+            feas.append(self._feat_head(x.detach().float(), "layer32.", 3))
         for j, (key, ci, co) in enumerate(UP):
             q = "UpsamplingResBlock%d." % key
             g = codes[-2 - j]
@@ -349,7 +351,7 @@ class GeneratorTrainer:
             else:
                 x = A.AddScaleFn.apply(skip, self._styled_conv(r, q + "conv2.", g, "UpsamplingResBlock%d.conv2" % key, noise), INV_SQRT2)
             if extract_features:
-                feas.append(self._feat_head(x.detach(), "layer%d." % (2 ** (j + 6)), 3 if j < 2 else 1))
+                feas.append(self._feat_head(x.detach().float(), "layer%d." % (2 ** (j + 6)), 3 if j < 2 else 1))
         wr = P("ToRGB.conv.weight")
         brgb = P("ToRGB.conv.bias") + P("ToRGB.bias").reshape(-1)
         y = A.ToRGBConvFn.apply(x, wr, brgb, 1.0 / math.sqrt(wr.shape[1]))

@@ -322,6 +322,73 @@ def t_gmp_multi():
         report("linear_dgrad_gate (%d,%d,%d)" % (B, N, K), ops.linear_dgrad_gate(dy, w, x, 0.5), dx_ref, 1e-6)
 
 
+def t_train_half():
+    """Round 5: the `_st` twins of the BACKWARD kernels (half-precision storage of the training activations and their gradients in
+    precision mode 1) against their fp32 forms on the widened inputs: statistics / parameter-gradient outputs (fp32 either way)
+    bit-equal, activation-shaped outputs bit-equal to the fp32 result rounded once; the bf16-input weight gradient
+    (conv_wgrad_tr2b_kernel) against the fp32-tile single-pass kernel on the same (bf16-representable) values: equal partial sums."""
+    torch.manual_seed(29)
+    bf = torch.bfloat16
+    prev = ops.PRECISION["value"]
+    ops.set_precision(1)
+    try:
+        B, H, Wd, C = 2, 34, 38, 64
+        gq, yq, tq = (g(torch.randn(B, H, Wd, C)).to(bf) for _ in range(3))
+        gf, yf, tf = gq.float(), yq.float(), tq.float()
+        def same(name, a, b):
+            ok = bool(torch.equal(a, b))
+            RES.append((name, ok))
+            print("%-70s %s" % (name, "ok" if ok else "FAIL max diff %.3e" % (a.float() - b.float()).abs().max().item()), flush=True)
+        same("dual_stats bf16 == fp32 on the widened inputs", ops.dual_stats(gq, yq, tq), ops.dual_stats(gf, yf, tf))
+        coef = g(torch.randn(B, C, 4))
+        for pg in (False, True):
+            same("in_bwd_apply bf16 (post_gate=%s) == fp32 result rounded" % pg, ops.in_bwd_apply(gq, yq, coef, gate=tq, post_gate=pg),
+                 ops.in_bwd_apply(gf, yf, coef, gate=tf, post_gate=pg).to(bf))
+        for mode in (ops.PAD_ZERO, ops.PAD_REFLECT, ops.PAD_REPLICATE):
+            same("pad2d bf16 mode %d" % mode, ops.pad2d(gq, 1, 1, 1, 1, mode), ops.pad2d(gf, 1, 1, 1, 1, mode).to(bf))
+            same("pad2d_bwd bf16 mode %d" % mode, ops.pad2d_bwd(gq, 1, 1, 1, 1, mode), ops.pad2d_bwd(gf, 1, 1, 1, 1, mode).to(bf))
+        same("pad2d_bwd bf16 asymmetric reflect (2, 1)", ops.pad2d_bwd(gq, 2, 1, 2, 1, ops.PAD_REFLECT), ops.pad2d_bwd(gf, 2, 1, 2, 1, ops.PAD_REFLECT).to(bf))
+        same("space_to_depth bf16", ops.space_to_depth(gq), ops.space_to_depth(gf).to(bf))
+        same("bilinear_bwd bf16 (x2)", ops.bilinear_bwd(gq, H // 2, Wd // 2), ops.bilinear_bwd(gf, H // 2, Wd // 2).to(bf))
+        same("colsum bf16", ops.colsum(gq.view(-1, C), 0.5), ops.colsum(gf.view(-1, C), 0.5))
+        nz = g(torch.randn(B, 1, H, Wd))
+        same("noise_wgrad bf16", ops.noise_wgrad(gq, nz), ops.noise_wgrad(gf, nz))
+        img = g(torch.randn(B, H, Wd, 3))
+        same("wgrad_small_cin bf16 dy", ops.wgrad_small_cin(img, gq, 0.3), ops.wgrad_small_cin(img, gf, 0.3))
+        x64 = g(torch.randn(2, 64, 64, C)).to(bf)
+        m1 = g((torch.rand(2, 64, 64) > 0.5).float())
+        v = ops.gap_gmp(x64, m1)
+        same("gap_gmp bf16 forward == fp32 on the widened input", v, ops.gap_gmp(x64.float(), m1))
+        gv = g(torch.randn(2, 2 * C))
+        same("gap_gmp_bwd bf16", ops.gap_gmp_bwd(x64, m1, v, gv), ops.gap_gmp_bwd(x64.float(), m1, v, gv).to(bf))
+        masks = g(F.one_hot(torch.randint(0, 3, (2, 64, 64)), 3).float())
+        vm = ops.gap_gmp_multi(x64, masks, True)
+        same("gap_gmp_multi bf16 forward", vm, ops.gap_gmp_multi(x64.float(), masks, True))
+        gm = g(torch.randn(vm.shape))
+        same("gap_gmp_multi_bwd bf16", ops.gap_gmp_multi_bwd(x64, masks, vm, gm, True), ops.gap_gmp_multi_bwd(x64.float(), masks, vm, gm, True).to(bf))
+        k4 = torch.tensor([1., 3., 3., 1.]); k4 = g((k4[:, None] * k4[None, :] / 64))
+        same("upfirdn2d up 2 (NHWC, 64 channels) bf16", ops.upfirdn2d_raw(gq, k4, 2, 2, 1, 1, 2, 1, 2, 1), ops.upfirdn2d_raw(gf, k4, 2, 2, 1, 1, 2, 1, 2, 1).to(bf))
+        # the weight gradient: every table family (3x3, stride-2 s2d, fused upscale's dgradT, 1x1 with 4 / 2 chunks per block, thin cout)
+        for name, kind, ci, co, k, Hh, Ww in [("3x3 64->128", "conv", 64, 128, 3, 36, 40), ("3x3 32->32 (thin)", "conv", 32, 32, 3, 33, 70),
+                                              ("1x1 128->64", "conv", 128, 64, 1, 32, 48), ("1x1 64->256", "conv", 64, 256, 1, 20, 36),
+                                              ("s2d 64->128", "s2d", 64, 128, 3, 33, 37), ("3x3 96->160 (ragged)", "conv", 96, 160, 3, 30, 34)]:
+            w = g(torch.randn(co, ci, k, k))
+            plan = ops.ConvPlan(w, kind=kind, scale=0.7, precision=1)
+            if kind == "s2d":
+                xx = g(torch.randn(2, (Hh + 1) // 2, (Ww + 1) // 2, 4 * ci)).to(bf)
+                oh, ow = (Hh - 3) // 2 + 1, (Ww - 3) // 2 + 1
+            else:
+                xx = g(torch.randn(2, Hh, Ww, ci)).to(bf)
+                oh, ow = Hh, Ww
+            dy = g(torch.randn(2, oh, ow, co)).to(bf)
+            dw_h, db_h = ops.conv_wgrad(plan, xx, dy, want_bias=True)
+            dw_f, db_f = ops.conv_wgrad(plan, xx.float(), dy.float(), want_bias=True)
+            report("conv_wgrad bf16-stored operands %s vs fp32 tiles (single pass)" % name, dw_h, dw_f, 1e-6)
+            report("conv_wgrad bf16-stored operands %s bias column sums" % name, db_h, db_f, 1e-6)
+    finally:
+        ops.set_precision(prev)
+
+
 def t_layout_misc():
     torch.manual_seed(1)
     for (B, C, H, Wd) in [(2, 3, 17, 19), (1, 32, 64, 64), (2, 70, 9, 33)]:
@@ -1531,6 +1598,8 @@ def main():
     if which == "opshalf":
         run(t_ops_half)
         run(t_ops_f64)
+    if which == "trainhalf":
+        run(t_train_half)
     if which == "gmp":
         run(t_gmp_multi)
     if which == "tail":
