@@ -1044,7 +1044,9 @@ extern "C" int ppst_noise_wgrad_st(const void* dpre, const void* noise, void* ou
   if (npix == 0) return accumulate ? PPST_OK : (int)hipMemsetAsync(out, 0, sizeof(float), as_stream(stream));
   if (!dpre || !noise || !ws) return PPST_ENULL;
   const int blocks = (int)(ppst_noise_wgrad_ws(npix) / (int64_t)sizeof(float));
-  if (C % 4 == 0 && ld % 4 == 0 && (uintptr_t)dpre % (st ? 8 : 16) == 0 && (C / 4 >= 256 || 256 % (C / 4) == 0))
+  // (C / 4 not a divisor of 256, e.g. 96: the last 256 % (C / 4) threads of a block idle -- the fp32 path keeps its scalar form for
+  //  those widths, bit for bit as before; a half tensor takes the four-channel form at every width)
+  if (C % 4 == 0 && ld % 4 == 0 && (uintptr_t)dpre % (st ? 8 : 16) == 0 && (st || C / 4 >= 256 || 256 % (C / 4) == 0))
     PPST_ST_SWITCH(st, PPST_LAUNCH(noise_wgrad4_kernel<ST_>, dim3(blocks), dim3(256), 0, as_stream(stream), dpre, (const float*)noise,
                                    (float*)ws, npix, C / 4, ld / 4));
   else if (st)
