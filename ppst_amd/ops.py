@@ -67,7 +67,7 @@ TWO_BLOCK_8ROW = {"value": False, "min_blocks": 64}
 # layers at batch 1-4, where one launch has 32-128 blocks for 256 CUs: with fewer than ``fill`` blocks a Cout % 256 layer leaves
 # the N-256 kernel for the tile kernel (twice the N tiles) and the tile kernel takes its 8-row form (twice the M tiles, two blocks
 # per CU).  Outputs are bit-identical across these forms; tile statistics differ in the last bit.
-BATCH_AWARE = {"value": False, "fill": 192, "single_bn64": True}
+BATCH_AWARE = {"value": False, "fill": 192}
 
 
 class batch_aware:
@@ -726,13 +726,6 @@ class ConvPlan:
             elif (self.bn == 128 and TALL_TILE_128["value"] and
                   ((th + 31) // 32) * ((tw + 15) // 16) * self.n_groups * ((self.cout + 127) // 128) >= TALL_TILE_128["min_blocks"]):
                 variant, rows = 7, 32                    # block tile 32 x 16 px x 128 ch, one activation slot (WMW = 4)
-        # batch-aware passes in the SINGLE-PASS modes (the bf16 train step): the 8-row form above is fp32-class only, so an under-filled
-        # launch of a halo-1 layer takes the 64-channel N tile of the tile kernel instead (a 64 x 64 layer at batch 2 starts 64 blocks
-        # of the 128- / 256-channel tiles on 256 CUs: 2-4x the blocks, the same outputs)
-        if (BATCH_AWARE["value"] and BATCH_AWARE["single_bn64"] and B is not None and single and self.halo == 1 and self.early_a
-                and variant in (0, 2) and rows == TILE_ROWS["value"] and self.cout >= 128):
-            if tiles16 * ((self.cout + (256 if variant == 2 else 128) - 1) // (256 if variant == 2 else 128)) * B < BATCH_AWARE["fill"]:
-                variant, bn = 0, 64
         same = (th, tw) == (oh, ow)
         if STREAM_1X1["value"] and self.halo == 0 and self.n_groups == 1 and osy == 1 and same and (oh, ow) == (H, W):
             variant, bn, rows = 4, 64, TILE_ROWS["value"]            # 1x1 convs: streaming kernel, no activation staging
