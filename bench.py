@@ -135,6 +135,20 @@ def pmc_traffic(what, prefixes=None):
         return None
 
 
+def gf_traffic():
+    """the guided filter's PMC summary (profiles/rNN_gf_pmc.json, tests/gf_prof.sh): bytes per pixel of a batch of four 1024^2 images"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gf_pmc.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return {"bytes_per_pixel": d["bytes_per_pixel"], "bytes_per_pixel_fetch_doubled": d["bytes_per_pixel_fetch_doubled"],
+                "file": "profiles/" + os.path.basename(files[-1]), "note": d.get("note"), "command": d.get("command")}
+    except Exception:
+        return None
+
+
 def conv_traffic():
     """HBM bytes per conv launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of this
     same command; summary committed under profiles/); None if absent."""
@@ -498,7 +512,7 @@ def bench_hires(args, rank, world, dev, barrier, max_over_ranks):
     gf_bytes = 9.0 * S * S * B
     pmc_what = "hires" if (args.precision == "fp16" and B == 4) else None
     conv_tr = pmc_traffic(pmc_what) if pmc_what else None
-    gf_tr = pmc_traffic(pmc_what, ("gf_",)) if pmc_what else None
+    gf_tr = gf_traffic() if B == 4 else None
     swaps = world * B * args.steps
     return {"metric": "1024x1024 swaps/sec (encode + decode + guided filter)", "value": swaps / dt, "unit": "swaps/s (all GPUs)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -511,17 +525,17 @@ def bench_hires(args, rank, world, dev, barrier, max_over_ranks):
                          "peak_note": "bf16 / fp16 dense MFMA 2500 TF / %d MFMA passes per algorithmic MAC" % passes,
                          "frac_vs_dense_bf16": achieved / PEAK_BF16_DENSE_TF, **issued_fields(detail), "launches": conv_launches, "kernel_ms_total": conv_ms, "share_of_step_time": conv_ms * 1e-3 / dt,
                          "traffic": conv_tr["hbm_bytes_per_launch"] if conv_tr else None, "traffic_source": conv_tr},
-            "roofline_guided_filter": {"kernel": "gf_v1m_slide / gf_h1s_solve_h2 / gf_v2_final_slide kernels<30> (guided_filter.hip): 33 box-filtered planes, "
-                                                 "r = 30, colour guide, sliding-window sums, stage-1 V pass on the uint8 rows", "bound": "hbm",
-                                       "achieved": gf_bytes / (gf_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline_guided_filter": {"kernel": "gf_s1_fused_kernel<30, 32> + gf_s2_fused_kernel<30, 64> (guided_filter.hip, round 5): two launches, every box "
+                                                 "sum kept on the chip (column sums in registers, row windows through LDS), (a, b) between them as 12 half planes",
+                                       "bound": "hbm", "achieved": gf_bytes / (gf_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": gf_bytes / (gf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_batch": gf_ms,
-                                       "bytes_note": "algorithmic minimum 9 B / pixel (uint8 guide + source in, uint8 out); between their passes the "
-                                                     "kernels keep 21 moment row sums (fp32, exact integers), 12 coefficient planes and their 12 "
-                                                     "row sums: traffic (PMC) / pixels is the figure the round-3 verdict bounds at 120 B / pixel",
+                                       "bytes_note": "algorithmic minimum 9 B / pixel (uint8 guide + source in, uint8 out); the implementation moves "
+                                                     "uint8 rows + halo in, 24 B / pixel of half planes out and back in (x halo factors), 12 (+ 3) out",
                                        "share_of_step_time": gf_ms * args.steps * 1e-3 / dt,
-                                       "traffic": gf_tr["hbm_bytes_per_launch"] * 3 if gf_tr else None,
-                                       "traffic_note": "HBM bytes per batch = the three kernels of one call",
-                                       "traffic_bytes_per_pixel": gf_tr["hbm_bytes_per_launch"] * 3 / (S * S * B) if gf_tr else None,
+                                       "traffic": gf_tr["bytes_per_pixel"] * S * S * B if gf_tr else None,
+                                       "traffic_note": "HBM bytes per batch = the two kernels of one call (PMC; narrow loads: raw FETCH_SIZE, see traffic_source.note)",
+                                       "traffic_bytes_per_pixel": gf_tr["bytes_per_pixel"] if gf_tr else None,
+                                       "traffic_bytes_per_pixel_fetch_doubled": gf_tr["bytes_per_pixel_fetch_doubled"] if gf_tr else None,
                                        "traffic_source": gf_tr}}
 
 

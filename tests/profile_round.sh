@@ -3,7 +3,7 @@
 # (one run per counter, --kernel-trace only beside --pmc, the program itself after `--`: MI355X_MICROARCH.md) of bench.py's
 # workloads.  The raw databases stay on the box (gpurun merges at most 64 MiB back): the summaries -- the files that go to
 # profiles/ -- are made there by tests/prof_summary.py / pmc_summary.py / pmc_mfma_summary.py.
-#   tests/profile_round.sh r04 swap|train|train_bf16|hires <commit>
+#   tests/profile_round.sh r05 swap|train|train_bf16|train_b8|hires <commit>
 set -e
 tag=$1; what=$2; commit=$3
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -11,6 +11,7 @@ case $what in
   swap) args="--steps 8 --warmup 1 --no-cpu-baseline --no-extras"; nsteps=9;;
   train) args="--workload train --steps 6 --warmup 1"; nsteps=7;;
   train_bf16) args="--workload train --precision bf16 --steps 6 --warmup 1"; nsteps=7;;
+  train_b8) args="--workload train --train-batch 8 --steps 3 --warmup 1"; nsteps=4;;
   hires) args="--workload hires --precision fp16 --batch 4 --steps 6 --warmup 1"; nsteps=7;;
 esac
 raw=/tmp/prof_${tag}_${what}
