@@ -13,9 +13,10 @@ def main():
     sd = W.make_state_dict(0, bias_std=0.1, noise_weight=0.1)
     model = create_model(Options(training_stage=2, lambda_Cycwarp=0.0), state_dict=sd, with_D=True, with_nce=True, device=dev)
     model.noise = "random"
-    real = W.synthetic_images(40, 2).to(dev)
+    NB = int(os.environ.get("AB_BATCH", "2"))
+    real = W.synthetic_images(40, NB).to(dev)
     g = torch.Generator().manual_seed(7)
-    lab = torch.randint(0, 3, (2, 32, 32), generator=g).repeat_interleave(16, 1).repeat_interleave(16, 2)
+    lab = torch.randint(0, 3, (NB, 32, 32), generator=g).repeat_interleave(16, 1).repeat_interleave(16, 2)
     mask = torch.nn.functional.one_hot(lab, 3).permute(0, 3, 1, 2).float().contiguous().to(dev)
     opt = PPSTOptimizer(model)
     data = {"real_A": real, "mask_A": mask}
@@ -34,12 +35,14 @@ def main():
         def setall(on):
             train.TRAIN_FUSE.update(d_fanin=on, d_skip_scale=on)
             train_g.TRAIN_FUSE["gate"] = on
+            train_g.TRAIN_FUSE["gmp_multi"] = on
             A.FUSE_LINEAR["value"] = on
         for rep in range(3):
             for name, fn in (("all off", lambda: setall(False)),
                              ("D fan-in + skip scale", lambda: (setall(False), train.TRAIN_FUSE.update(d_fanin=True, d_skip_scale=True))),
                              ("StyledConv gate", lambda: (setall(False), train_g.TRAIN_FUSE.update(gate=True))),
                              ("linear backward", lambda: (setall(False), A.FUSE_LINEAR.update(value=True))),
+                             ("multi-head GAP/GMP", lambda: (setall(False), train_g.TRAIN_FUSE.update(gmp_multi=True))),
                              ("all on", lambda: setall(True))):
                 fn()
                 run(1)
