@@ -20,7 +20,13 @@ class StyleGAN2ResnetEncodercon(BaseNetwork):
         B, H, W, C = x.shape
         sc = 1.0 / math.sqrt(C)
         y, st = self.plan("ToSpatialCode.0.Conv.weight", scale=sc)(x, stats=True)
-        x, _ = self._norm_act(y, st, H * W, self.p("ToSpatialCode.0.Act.bias"), ops.ACT_LRELU)
-        y, st = self.plan("ToSpatialCode.1.Conv.weight", scale=sc)(x, bias=self.p("ToSpatialCode.1.Conv.bias"), stats=True)
+        if ops.FUSE_TAIL["value"]:
+            # the norm + leaky ReLU of ToSpatialCode.0 has ONE consumer, the 1x1 conv behind it: applied while that conv loads (round 5)
+            ss = ops.in_finalize(st, H * W, post_bias=self.p("ToSpatialCode.0.Act.bias"))
+            y, st = self.plan("ToSpatialCode.1.Conv.weight", scale=sc)(y, bias=self.p("ToSpatialCode.1.Conv.bias"), stats=True,
+                                                                       in_ss=ss, in_act=ops.ACT_LRELU)
+        else:
+            x, _ = self._norm_act(y, st, H * W, self.p("ToSpatialCode.0.Act.bias"), ops.ACT_LRELU)
+            y, st = self.plan("ToSpatialCode.1.Conv.weight", scale=sc)(x, bias=self.p("ToSpatialCode.1.Conv.bias"), stats=True)
         sp, _ = self._norm_act(y, st, H * W, out_dtype=torch.float32)    # the spatial code leaves the network as fp32
         return as_nchw(sp)
