@@ -308,9 +308,23 @@ typedef struct ppst_conv_args {
                                     Same fp32 operations in the same order as ppst_affine_act(res_before_act) followed by the plain
                                     conv (the test holds the pair to 2e-6 of each other).  fp32 storage, precision 0; NULL: none */
   int32_t in_res_ld;             /* pixel stride of in_res in elements */
+  int32_t ksplit;                /* round 5: 0 / 1 none; S = 2, 4 or 8 (variant 0, 2 or 10; nsteps % S == 0 and -- the CALLER's promise --
+                                    step i * nsteps / S opens a chunk for every i): the reduction is split over S blocks per output
+                                    tile (grid y), each running nsteps / S steps of the table; the first S - 1 leave their raw
+                                    accumulators in a scratch buffer of the library and raise a flag, the last block of the tile
+                                    (dispatched behind them) adds them in a fixed order and runs the epilogue.  For launches whose
+                                    grid fills a fraction of the chip and whose blocks are one long serial chain of steps (the
+                                    64^2 ... 4^2 layers of a train step at batch 2: 4-128 blocks, 72-160 steps): S x the blocks,
+                                    1 / S of the chain.  Results equal the unsplit launch's up to fp32 summation order.  At most
+                                    256 (S - 1) x tiles per launch; launches that use it are serialised per stream by the library
+                                    (one scratch buffer per stream, four streams). */
 } ppst_conv_args;
 
 int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream);
+/* diagnostic of ppst_conv_args.ksplit: 1 if a block of a K-split launch on `stream` ever gave up waiting for its partner blocks (that
+ * launch's output is wrong; cannot happen while blocks are dispatched in grid order), 0 if none did, < 0 if the stream never ran a
+ * K-split launch.  Synchronises the stream and resets the marker. */
+int ppst_conv_ksplit_check(void* stream);
 /* Weights of a plain 3x3 stride-1 conv for ppst_conv_args.variant 10 (conv_wino.hip: Winograd F(2,3) along x, direct along y --
  * 12 K-steps per 32-channel chunk and pixel PAIR instead of 9 per pixel, 1.5x fewer MFMAs; EqualConv2d / StyledConv conv,
  * stylegan2_layers.py:184-193, 275-348, 439-475).  Element (n, c, ky, kx) of the kernel at w[n*sn + c*sc + ky*sy + kx*sx] (any

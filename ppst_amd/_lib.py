@@ -53,7 +53,7 @@ class ConvArgs(ctypes.Structure):
         ("act", i32), ("precision", i32), ("res_ld", i32), ("tile_h", i32), ("tile_w", i32),
         ("halo", i32), ("bn", i32), ("in_scale_shift", vp), ("in_prelu", vp), ("in_c", i32), ("in_act", i32),
         ("flop_steps", i32), ("tile_rows", i32), ("a_slots", i32), ("early_a", i32), ("variant", i32), ("in_presplit", i32), ("dual_b", i32), ("io_st", i32), ("k64", i32),
-        ("in_res", vp), ("in_res_ld", i32),
+        ("in_res", vp), ("in_res_ld", i32), ("ksplit", i32),
     ]
 
 
@@ -78,6 +78,7 @@ _SIGS = {
     "ppst_conv_pack_batch": (i32, [vp, i32, i32, vp]),
     "ppst_upscale_weight_batch": (i32, [vp, i32, i32, vp]),
     "ppst_conv2d_mfma": (i32, [ctypes.POINTER(ConvArgs), vp]),
+    "ppst_conv_ksplit_check": (i32, [vp]),
     "ppst_has_experiments": (i32, []),
     "ppst_presplit": (i32, [vp, vp, i64, i32, i32, i32, vp]),
     "ppst_conv2d_f32": (i32, [ctypes.POINTER(ConvArgs), vp, i64, i64, i64, i64, f32, vp, vp, vp, vp]),

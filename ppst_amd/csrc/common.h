@@ -30,6 +30,90 @@ struct EpiR { int value; };
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
+// ---- across-block K split of a conv launch (ppst_conv_args.ksplit; conv_mfma.hip holds the state).  The S blocks of an output
+// tile are grid rows y = 0 .. S-1 of the same x: rows 0 .. S-2 (dispatched first: x runs fastest) store their accumulators --
+// component e of register r of thread t at float ((r * 4 + e) * NT + t), coalesced -- and raise flag[tile][y] to the launch's epoch; row S-1 waits for the
+// S-1 flags (they belong to blocks dispatched before it, which wait for nothing: no deadlock whatever the residency), adds the
+// partial sums in row order and goes on to its unchanged epilogue.  The wait is bounded (about a second): a block that gives up
+// sets the error word instead of hanging the device.
+// Coherence: the XCDs' L2s are not coherent with each other.  The hand-over goes through coherent accesses (sc bits: stores write
+// through to memory, loads do not hit a stale line), ordered by counters -- all of a wave's stores acknowledged (vmcnt 0), block
+// barrier, flag -- and NOT through release / acquire fences: a fence at agent scope writes back / invalidates the WHOLE L2 of the
+// XCD (buffer_wbl2 / buffer_inv sc1), under blocks that are streaming their weights from it (first form of this code: the split
+// launches were SLOWER than the unsplit ones, 67 -> 85 us on 256 -> 256 @64^2 x 2).
+struct KSplitDev {
+  float* scratch;        // [tile][S-1][acc regs][NT] floats
+  unsigned* flags;       // [tile][S-1]; word KS_FLAG_WORDS - 1: error marker
+  unsigned epoch;
+  int S, ksteps;         // ksteps = nsteps / S
+};
+#define KS_FLAG_WORDS 4096
+#define KS_MAX_SLOTS 512
+#define KS_SCRATCH_BYTES ((size_t)256 * 512 * 128 * 4)      /* 256 producer blocks x 512 threads x 128 accumulator registers (512 of the tile kernel's) */
+int ppst_ksplit_prepare_(int S, int64_t tiles, int nsteps, int acc_regs, int threads, hipStream_t st, KSplitDev* out);   // conv_mfma.hip
+
+// Agent-scope relaxed atomic accesses, one dword each (sc1; a 16-byte volatile access gets sc0 sc1 -- system scope -- and measured
+// ~3 us slower per launch).  hipcc tracks them with counted vmcnt like plain loads but is free to hoist them: left alone it moved the
+// (S - 1) x 64 .. 128 requests of a thread to the front and spilled 200-700 registers to scratch in EVERY instance of the kernels.
+// The scheduling fences below pin the order instead: the requests of register r + 1, then the adds of register r.
+template <int NTHR>
+__device__ __forceinline__ void ks_vst(float* p, f32x4 v) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) __hip_atomic_store(p + e * NTHR, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int NTHR>
+__device__ __forceinline__ f32x4 ks_vld(const float* p) {
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = __hip_atomic_load(p + e * NTHR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
+// acc[I][J] (f32x4 each) += the S-1 partner slots; component e of register r of thread t lives at float ((r * 4 + e) * NTHR + t) of
+// a slot: a wave's request is 256 contiguous bytes (`slot0` already points at this thread's float of slot 0).  Double-buffered by hand: the S-1 requests of register r+1 go out before the adds of
+// register r, so 2 (S - 1) float4 are live and one memory round trip is exposed, not one per register.
+#define KS_GATHER_BODY(ACC, I_, J_, NTHR_, P_, SLOT0)                                                  \
+  {                                                                                                   \
+    constexpr int R_ = (I_) * (J_);                                                                   \
+    f32x4 t_[2][P_];                                                                                  \
+    _Pragma("unroll") for (int z = 0; z < (P_); ++z) t_[0][z] = ks_vld<NTHR_>((SLOT0) + (int64_t)z * (R_ * 4 * (NTHR_)));        \
+    _Pragma("unroll") for (int r = 0; r < R_; ++r) {                                                  \
+      if (r + 1 < R_) {                                                                               \
+        _Pragma("unroll") for (int z = 0; z < (P_); ++z)                                              \
+          t_[(r + 1) & 1][z] = ks_vld<NTHR_>((SLOT0) + (int64_t)z * (R_ * 4 * (NTHR_)) + (r + 1) * 4 * (NTHR_));                 \
+      }                                                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                              \
+      _Pragma("unroll") for (int z = 0; z < (P_); ++z) ACC[r / (J_)][r % (J_)] += t_[r & 1][z];       \
+      __builtin_amdgcn_sched_barrier(0);                                                              \
+    }                                                                                                 \
+  }
+// (S = 8 only where a thread holds 64 accumulator registers: with 128 the 56 registers of its double buffer spill)
+#define KS_GATHER(ACC, I_, J_, NTHR_, S_, SLOT0)                                                       \
+  do {                                                                                                \
+    if ((S_) == 2) KS_GATHER_BODY(ACC, I_, J_, NTHR_, 1, SLOT0)                                       \
+    else if ((S_) == 4 || (I_) * (J_) > 16) KS_GATHER_BODY(ACC, I_, J_, NTHR_, 3, SLOT0)              \
+    else KS_GATHER_BODY(ACC, I_, J_, NTHR_, (((I_) * (J_) > 16) ? 3 : 7), SLOT0)                      \
+  } while (0)
+#define KS_SCATTER(ACC, I_, J_, NTHR_, DST)                                                            \
+  _Pragma("unroll") for (int i_ = 0; i_ < (I_); ++i_)                                                 \
+    _Pragma("unroll") for (int j_ = 0; j_ < (J_); ++j_) ks_vst<NTHR_>((DST) + (i_ * (J_) + j_) * 4 * (NTHR_), ACC[i_][j_]);
+__device__ __forceinline__ void ks_publish(const KSplitDev& k, int tile, int y, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores are acknowledged
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(k.flags + tile * (k.S - 1) + y, k.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ks_wait(const KSplitDev& k, int tile, int tid) {
+  if (tid < k.S - 1) {
+    const unsigned* f = k.flags + tile * (k.S - 1) + tid;
+    int spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != k.epoch) {
+      if (++spins > (1 << 21)) { __hip_atomic_store(k.flags + KS_FLAG_WORDS - 1, 0xdeadu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+  asm volatile("" ::: "memory");
+}
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

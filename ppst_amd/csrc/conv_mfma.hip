@@ -46,6 +46,7 @@ struct ConvKArgs {
   int in_c, in_act;
   int early_a;              // step table guarantees chunks of >= 2 steps: a chunk's global loads go out one step early
   unsigned long long* dbg;  // stamp build: [block][wave][8] cycle sums (else unused)
+  KSplitDev ks;             // ks.S > 1: grid row y runs steps [y * ks.ksteps, (y + 1) * ks.ksteps) of every group (common.h)
 };
 // (the storage type of x / residual / y -- ppst_conv_args.io_st, single-pass precision modes only -- is a template parameter IOS of
 // the kernels, not a field: the pointers above are then half / bfloat16 tensors behind their `float*` type)
@@ -159,6 +160,16 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   StepPtr steps = (StepPtr)(a.steps + (int64_t)group * a.nsteps);
   const unsigned char* wblob = (const unsigned char*)a.wpack + ((int64_t)nidx * a.nsteps) * BBUF;
   const unsigned char* xb = (const unsigned char*)a.x + (int64_t)b * a.in_h * a.in_w * a.in_ld * ES;
+  // across-block K split (ppst_conv_args.ksplit): this block runs `nst` steps from step y * ksteps on -- the first of them opens a
+  // chunk (the caller's promise), so the sub-table is a table of its own; a next-chunk flag on its last step requests one tile that
+  // is never stored (drained by the last step's vmcnt(0))
+  int nst = a.nsteps;
+  if (a.ks.S > 1) {
+    const int s0 = (int)blockIdx.y * a.ks.ksteps;
+    steps += s0;
+    wblob += (int64_t)s0 * BBUF;
+    nst = a.ks.ksteps;
+  }
 
   constexpr int A_WCH = (HP + 7) / 8;                      // wave-chunks of 8 pixels x 8 float4
   constexpr int A_IT2 = (A_WCH * 64 + NT - 1) / NT;
@@ -343,7 +354,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   if (PRES) a_dma(d.x, 0); else a_load(d.x);
   b_dma(0, 0);
   if (!PRES) a_store(0);
-  if (a.nsteps > 1) {
+  if (nst > 1) {
     d = steps[1];
     dy1 = d.y; dx1 = d.z;
     sl1 = (d.w & 1) ? 1 : 0;
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
     }
   }
   int4 dE = d, dO = d;                       // descriptor of step s+2, alternating register sets
-  if (a.nsteps > 2) dE = steps[2];
+  if (nst > 2) dE = steps[2];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA of steps 0/1 (see the note at the loop barrier)
   __syncthreads();
 
@@ -525,18 +536,32 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   // steady state: both steps of the unrolled pair have successors s+1 and s+2 (no existence tests / branches);
   // the last <= 3 steps run the general form
   int s = 0;
-  for (; s + 3 < a.nsteps; s += 2) {
+  for (; s + 3 < nst; s += 2) {
     CONV_STEP(b0h, b0l, b1h, b1l, s, dE, dO, true, true)
     CONV_STEP(b1h, b1l, b0h, b0l, s + 1, dO, dE, true, true)
   }
-  for (; s < a.nsteps; s += 2) {
-    CONV_STEP(b0h, b0l, b1h, b1l, s, dE, dO, s + 1 < a.nsteps, s + 2 < a.nsteps)
-    if (s + 1 < a.nsteps) CONV_STEP(b1h, b1l, b0h, b0l, s + 1, dO, dE, s + 2 < a.nsteps, s + 3 < a.nsteps)
+  for (; s < nst; s += 2) {
+    CONV_STEP(b0h, b0l, b1h, b1l, s, dE, dO, s + 1 < nst, s + 2 < nst)
+    if (s + 1 < nst) CONV_STEP(b1h, b1l, b0h, b0l, s + 1, dO, dE, s + 2 < nst, s + 3 < nst)
   }
 #undef CONV_STEP
 #undef STEP_HEAD_IF
 #undef TOP_WORK
 #undef A_OFF
+
+  // ---- across-block K split: rows 0 .. S-2 hand their partial sums over and leave; row S-1 adds them (row order) and goes on
+  if (a.ks.S > 1) {
+    const int S = a.ks.S, y = (int)blockIdx.y;
+    float* const slot0 = a.ks.scratch + (int64_t)wid * (S - 1) * (64 * NT) + tid;
+    if (y < S - 1) {
+      float* const dst = slot0 + (int64_t)y * (64 * NT);
+      KS_SCATTER(acc, 4, 4, NT, dst)
+      ks_publish(a.ks, wid, y, tid);
+      return;
+    }
+    ks_wait(a.ks, wid, tid);
+    KS_GATHER(acc, 4, 4, NT, S, slot0);
+  }
 
   // ---- epilogue: + bias + noise [+ residual] -> act -> * out_scale -> store, tile statistics.
   // The accumulators (lane = channel, registers = pixels) are transposed through a per-wave
@@ -1039,13 +1064,62 @@ extern "C" int ppst_has_experiments(void) {
 #endif
 }
 
+// ---- state of the across-block K split (common.h): one scratch + flag buffer per (device, stream) that has used it -- launches on one
+// stream are ordered, so a buffer is never shared by two launches in flight; the epoch makes a flag of an earlier launch stale
+// without a fill between launches.  Allocated at first use (64 MB + 16 KB), never freed.
+struct KsState { int dev; hipStream_t st; float* scratch; unsigned* flags; unsigned epoch; };
+static KsState g_ks[4];
+static int g_ks_n = 0;
+int ppst_ksplit_prepare_(int S, int64_t tiles, int nsteps, int acc_regs, int threads, hipStream_t st, KSplitDev* out) {
+  if ((S != 2 && S != 4 && S != 8) || nsteps % S || tiles <= 0 || acc_regs <= 0 || acc_regs % 4 || threads <= 0) return PPST_EINVAL;
+  const int64_t slots = (int64_t)(S - 1) * tiles;
+  if (slots > KS_MAX_SLOTS || slots > KS_FLAG_WORDS - 1 || (size_t)slots * threads * acc_regs * 4 > KS_SCRATCH_BYTES) return PPST_EINVAL;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return PPST_EINVAL;
+  KsState* e = nullptr;
+  for (int i = 0; i < g_ks_n; ++i)
+    if (g_ks[i].dev == dev && g_ks[i].st == st) e = &g_ks[i];
+  if (!e) {
+    if (g_ks_n == 4) return PPST_EINVAL;
+    KsState n;
+    n.dev = dev; n.st = st; n.epoch = 0; n.scratch = nullptr; n.flags = nullptr;
+    if (hipMalloc((void**)&n.scratch, KS_SCRATCH_BYTES) != hipSuccess) return (int)hipGetLastError();
+    if (hipMalloc((void**)&n.flags, KS_FLAG_WORDS * 4) != hipSuccess || hipMemset(n.flags, 0, KS_FLAG_WORDS * 4) != hipSuccess) {
+      (void)hipFree(n.scratch);
+      if (n.flags) (void)hipFree(n.flags);
+      return (int)hipGetLastError();
+    }
+    g_ks[g_ks_n] = n;
+    e = &g_ks[g_ks_n++];
+  }
+  if (++e->epoch == 0) ++e->epoch;            // (0 is the value of a fresh flag)
+  out->scratch = e->scratch; out->flags = e->flags; out->epoch = e->epoch; out->S = S; out->ksteps = nsteps / S;
+  return PPST_OK;
+}
+// 1 if a block of a K-split launch on `stream` ever gave up waiting for its partners (the results of that launch are wrong), 0 if
+// none did, < 0 if the stream has no K-split state; resets the marker.  Synchronises the stream.
+extern "C" int ppst_conv_ksplit_check(void* stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  for (int i = 0; i < g_ks_n; ++i)
+    if (g_ks[i].dev == dev && g_ks[i].st == as_stream(stream)) {
+      unsigned v = 0, z = 0;
+      if (hipStreamSynchronize(g_ks[i].st) != hipSuccess) return -1;
+      if (hipMemcpy(&v, g_ks[i].flags + KS_FLAG_WORDS - 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+      if (v) (void)hipMemcpy(g_ks[i].flags + KS_FLAG_WORDS - 1, &z, 4, hipMemcpyHostToDevice);
+      return v ? 1 : 0;
+    }
+  return -1;
+}
+
 // (tile_rows 15 = variant 11: blocks of 15 x 15 input positions)
 extern "C" int ppst_conv_tiles(int tile_h, int tile_w, int tile_rows) { return cdiv(tile_h, tile_rows) * cdiv(tile_w, tile_rows == 15 ? 15 : 16); }
 
 template <int WM, int WN, int HALO, bool X3, int NAS = 0, bool F16 = false, bool X2 = false, int IOS = PPST_ST_F32>
 static void launch_conv(const ConvKArgs& k, int blocks, hipStream_t st) {
-  if (k.in_ss) PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, true, NAS, F16, X2, false, IOS>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
-  else PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, false, NAS, F16, X2, false, IOS>), dim3(blocks), dim3(64 * WM * WN), 0, st, k);
+  const dim3 grid(blocks, k.ks.S > 1 ? k.ks.S : 1);
+  if (k.in_ss) PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, true, NAS, F16, X2, false, IOS>), grid, dim3(64 * WM * WN), 0, st, k);
+  else PPST_LAUNCH((conv_mfma_kernel<WM, WN, HALO, X3, false, NAS, F16, X2, false, IOS>), grid, dim3(64 * WM * WN), 0, st, k);
 }
 
 extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
@@ -1146,6 +1220,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   k.in_c = a->in_c; k.in_act = a->in_act;
   k.early_a = a->early_a ? 1 : 0;
   k.dbg = nullptr;
+  k.ks.scratch = nullptr; k.ks.flags = nullptr; k.ks.epoch = 0; k.ks.S = 1; k.ks.ksteps = a->nsteps;
 #ifdef PPST_CONV_TRACE
   k.dbg = (unsigned long long*)a->prelu;  // diagnostic builds: the (unused) prelu slot carries the debug buffer
   k.prelu = nullptr;
@@ -1154,6 +1229,14 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   if (blocks64 > 0x7fffffff) return PPST_EINVAL;
   int blocks = (int)blocks64;
   hipStream_t st = as_stream(stream);
+  if (a->ksplit > 1) {
+    // the tile kernel (variant 0, 16-row tiles); the N-256 and Winograd kernels take theirs in their own launchers
+    if (a->variant == 0) {
+      if ((a->tile_rows != 16 && a->tile_rows != 8) || a->in_presplit) return PPST_EINVAL;
+      const int e0 = ppst_ksplit_prepare_(a->ksplit, blocks, a->nsteps, 64, (a->bn == 128 && a->tile_rows == 16) ? 512 : 256, st, &k.ks);
+      if (e0 != PPST_OK) return e0;
+    } else if (a->variant != 2 && a->variant != 10) return PPST_EINVAL;
+  }
   int slot = -1;
   if (g_prof_on) {
     // info[7]: bits 0-11 the N tile, 12-19 the kernel variant that runs the launch, 20 k64, 24-27 the precision mode (bench.py derives

@@ -39,6 +39,7 @@ struct Conv2KArgs {
   int in_c, in_act;
   int early_a;
   unsigned long long* dbg;   // -DPPST_CONV_TRACE builds only
+  KSplitDev ks;              // across-block K split (common.h): grid row y runs steps [y * ks.ksteps, (y + 1) * ks.ksteps)
 };
 
 // Diagnostic build -DPPST_CONV_TRACE (tests/build_variant.sh): the per-step timeline of conv_mfma.hip's trace, same buffer
@@ -91,7 +92,7 @@ __device__ __forceinline__ unsigned short f2h_2(float f) { return __builtin_bit_
 // step, the activation tile is staged once for two phases, and the layer runs on this kernel's 128 x 64 wave tiles instead of
 // the tile kernel's 64 x 64.  Per output element the MFMA sequence is the tile kernel's (dy-major taps): bit-identical outputs.
 template <int NT, int HALO, bool INSS, int WNW = 2, bool BDB = true, int NA_ = 2, int WMW = 2, int PREC = 0, int MT_ = 8, bool DUAL = false,
-          int IOS = PPST_ST_F32, bool UP9 = false, bool K64 = false>
+          int IOS = PPST_ST_F32, bool UP9 = false, bool K64 = false, bool KS = false>
 __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW == 8 || NA_ == 1) ? 2 : 1)) void conv_mfma2_kernel(Conv2KArgs a) {
   constexpr bool X3 = PREC == 0;
   // K64 (single-pass modes on half-stored activations): a step covers 64 input channels instead of 32 -- channels 0-31 of the chunk sit
@@ -157,6 +158,15 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   StepPtr steps = (StepPtr)(a.steps + (int64_t)group * a.nsteps);
   const unsigned char* wblob = (const unsigned char*)a.wpack + ((int64_t)nidx * a.nsteps) * BBUF;
   const unsigned char* xb = (const unsigned char*)a.x + (int64_t)b * a.in_h * a.in_w * a.in_ld * ES;
+  // across-block K split (template KS: instances of their own -- the hand-over code costs the 128-accumulator kernels a few spilled
+  // registers, which the plain instances, the swap path's, must not pay): this block's share of the table (conv_mfma.hip)
+  int nst = a.nsteps;
+  if (KS && a.ks.S > 1) {
+    const int s0 = (int)blockIdx.y * a.ks.ksteps;
+    steps += s0;
+    wblob += (int64_t)s0 * BBUF;
+    nst = a.ks.ksteps;
+  }
 
   // ---- A staging (as conv_mfma.hip: one wave-instruction = 8 pixels x 128 B; fp32 -> bf16 hi/lo planes)
   constexpr int A_WCH = (HP + 7) / 8;
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   a_load(d.x);
   b_dma(0, 0);
   a_store(0);
-  if (a.nsteps > 1) {
+  if (nst > 1) {
     d = steps[1];
     dy1 = d.y; dx1 = DXW(d.z);
     sl1 = (d.w & 1) ? 1 : 0;
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
     if (NA > 1 && a.early_a && (d.w & 2)) a_load(d.w >> 8);
   }
   int4 dE = d, dO = d;
-  if (a.nsteps > 2) dE = steps[2];
+  if (nst > 2) dE = steps[2];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -424,36 +434,36 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
     // chunks of four steps = the four input shifts (0,0), (-1,0), (0,-1), (-1,-1); the n-tiles of a wave are the four u types
     // [ee, eo, oe, oo] of its 16 channels, and a shift feeds 4 / 2 / 2 / 1 of them: nine products per input pixel instead of the
     // sixteen of the four-phase form (masks are compile-time: the skipped MFMAs and fragment reads are not in the code)
-    for (; s + 5 < a.nsteps; s += 4) {
+    for (; s + 5 < nst; s += 4) {
       STEP2N(b0h, b0l, b0h, b0l, s, dE, dO, true, true, 0xF, 0x3, 0x5)
       STEP2N(b0h, b0l, b0h, b0l, s + 1, dO, dE, true, true, 0x3, 0x5, 0x1)
       STEP2N(b0h, b0l, b0h, b0l, s + 2, dE, dO, true, true, 0x5, 0x1, 0xF)
       STEP2N(b0h, b0l, b0h, b0l, s + 3, dO, dE, true, true, 0x1, 0xF, 0x3)
     }
-    for (; s < a.nsteps; s += 4) {
-      STEP2N(b0h, b0l, b0h, b0l, s, dE, dO, s + 1 < a.nsteps, s + 2 < a.nsteps, 0xF, 0x3, 0x5)
-      STEP2N(b0h, b0l, b0h, b0l, s + 1, dO, dE, s + 2 < a.nsteps, s + 3 < a.nsteps, 0x3, 0x5, 0x1)
-      STEP2N(b0h, b0l, b0h, b0l, s + 2, dE, dO, s + 3 < a.nsteps, s + 4 < a.nsteps, 0x5, 0x1, 0xF)
-      STEP2N(b0h, b0l, b0h, b0l, s + 3, dO, dE, s + 4 < a.nsteps, s + 5 < a.nsteps, 0x1, 0xF, 0x3)
+    for (; s < nst; s += 4) {
+      STEP2N(b0h, b0l, b0h, b0l, s, dE, dO, s + 1 < nst, s + 2 < nst, 0xF, 0x3, 0x5)
+      STEP2N(b0h, b0l, b0h, b0l, s + 1, dO, dE, s + 2 < nst, s + 3 < nst, 0x3, 0x5, 0x1)
+      STEP2N(b0h, b0l, b0h, b0l, s + 2, dE, dO, s + 3 < nst, s + 4 < nst, 0x5, 0x1, 0xF)
+      STEP2N(b0h, b0l, b0h, b0l, s + 3, dO, dE, s + 4 < nst, s + 5 < nst, 0x1, 0xF, 0x3)
     }
   } else
   if (BDB) {
-    for (; s + 3 < a.nsteps; s += 2) {
+    for (; s + 3 < nst; s += 2) {
       STEP2(b0h, b0l, b1h, b1l, s, dE, dO, true, true)
       STEP2(b1h, b1l, b0h, b0l, s + 1, dO, dE, true, true)
     }
-    for (; s < a.nsteps; s += 2) {
-      STEP2(b0h, b0l, b1h, b1l, s, dE, dO, s + 1 < a.nsteps, s + 2 < a.nsteps)
-      if (s + 1 < a.nsteps) STEP2(b1h, b1l, b0h, b0l, s + 1, dO, dE, s + 2 < a.nsteps, s + 3 < a.nsteps)
+    for (; s < nst; s += 2) {
+      STEP2(b0h, b0l, b1h, b1l, s, dE, dO, s + 1 < nst, s + 2 < nst)
+      if (s + 1 < nst) STEP2(b1h, b1l, b0h, b0l, s + 1, dO, dE, s + 2 < nst, s + 3 < nst)
     }
   } else {
-    for (; s + 3 < a.nsteps; s += 2) {
+    for (; s + 3 < nst; s += 2) {
       STEP2(b0h, b0l, b0h, b0l, s, dE, dO, true, true)
       STEP2(b0h, b0l, b0h, b0l, s + 1, dO, dE, true, true)
     }
-    for (; s < a.nsteps; s += 2) {
-      STEP2(b0h, b0l, b0h, b0l, s, dE, dO, s + 1 < a.nsteps, s + 2 < a.nsteps)
-      if (s + 1 < a.nsteps) STEP2(b0h, b0l, b0h, b0l, s + 1, dO, dE, s + 2 < a.nsteps, s + 3 < a.nsteps)
+    for (; s < nst; s += 2) {
+      STEP2(b0h, b0l, b0h, b0l, s, dE, dO, s + 1 < nst, s + 2 < nst)
+      if (s + 1 < nst) STEP2(b0h, b0l, b0h, b0l, s + 1, dO, dE, s + 2 < nst, s + 3 < nst)
     }
   }
 #undef STEP2
@@ -600,6 +610,20 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
       }
     }
     return;
+  }
+  // ---- across-block K split (conv_mfma.hip): rows 0 .. S-2 hand their partial sums over and leave, row S-1 adds them and goes on
+  if (KS && a.ks.S > 1) {
+    const int S = a.ks.S, y = (int)blockIdx.y;
+    constexpr int NTHR = 64 * WNW * WMW;
+    float* const slot0 = a.ks.scratch + (int64_t)wid * (S - 1) * (MT * NT * 4 * NTHR) + tid;
+    if (y < S - 1) {
+      float* const dst = slot0 + (int64_t)y * (MT * NT * 4 * NTHR);
+      KS_SCATTER(acc, MT, NT, NTHR, dst)
+      ks_publish(a.ks, wid, y, tid);
+      return;
+    }
+    ks_wait(a.ks, wid, tid);
+    KS_GATHER(acc, MT, NT, NTHR, S, slot0);
   }
   // ---- epilogue (as conv_mfma.hip): per wave, passes of 64 pixels x 32 channels through an LDS transposition tile
   const int gy = DUAL ? group : group >> 1, gx = DUAL ? wn / (WNW / 2) : group & 1;   // output row / column phase
@@ -778,18 +802,38 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
   k.prelu = nullptr;
 #endif
   const int blocks = a->n_groups * n_tiles * a->B * tiles_y * tiles_x;
+  k.ks.scratch = nullptr; k.ks.flags = nullptr; k.ks.epoch = 0; k.ks.S = 1; k.ks.ksteps = a->nsteps;
+  if (a->ksplit > 1) {
+    // across-block K split: the N-256 kernel in its plain forms (8 m-tiles x 4 n-tiles per wave, 8 waves) -- fp32-class mode on fp32
+    // tensors, single-pass modes on half-stored ones (what the train step launches); S <= 4 (128 accumulator registers per thread)
+    if (a->variant != 2 || a->dual_b || a->ksplit > 4 || (a->precision == 0 ? a->io_st != 0 : a->io_st == 0) || (a->k64 && !a->halo)) return PPST_EINVAL;
+    const int e0 = ppst_ksplit_prepare_(a->ksplit, blocks, a->nsteps, 128, 512, st, &k.ks);
+    if (e0 != PPST_OK) return e0;
+    const dim3 gridk(blocks, k.ks.S);
+#define LKS(HALO_, PREC_, IOS_, K64_)                                                                            \
+  do {                                                                                                          \
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 4, false, 2, 2, PREC_, 8, false, IOS_, false, K64_, true>), gridk, dim3(512), 0, st, k);   \
+    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 4, false, 2, 2, PREC_, 8, false, IOS_, false, K64_, true>), gridk, dim3(512), 0, st, k);          \
+  } while (0)
+    if (a->precision == 0) { if (a->halo) LKS(1, 0, PPST_ST_F32, false); else LKS(0, 0, PPST_ST_F32, false); }
+    else if (a->precision == 1) { if (a->k64) LKS(1, 1, PPST_ST_BF16, true); else if (a->halo) LKS(1, 1, PPST_ST_BF16, false); else LKS(0, 1, PPST_ST_BF16, false); }
+    else { if (a->k64) LKS(1, 3, PPST_ST_F16, true); else if (a->halo) LKS(1, 3, PPST_ST_F16, false); else LKS(0, 3, PPST_ST_F16, false); }
+#undef LKS
+    return PPST_LAUNCH_CHECK();
+  }
+  const dim3 grid(blocks);
   if (a->k64) {               // single-pass modes on half-stored activations, 64 input channels per step (the entry point checked the shape)
 #define LK(PREC_, IOS_)                                                                                          \
   do {                                                                                                          \
     if (a->variant == 2 && a->dual_b) {                                                                         \
-      if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, 1, true, 4, false, 2, 2, PREC_, 8, true, IOS_, false, true>), dim3(blocks), dim3(512), 0, st, k);   \
-      else PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 4, false, 2, 2, PREC_, 8, true, IOS_, false, true>), dim3(blocks), dim3(512), 0, st, k);          \
+      if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, 1, true, 4, false, 2, 2, PREC_, 8, true, IOS_, false, true>), grid, dim3(512), 0, st, k);   \
+      else PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 4, false, 2, 2, PREC_, 8, true, IOS_, false, true>), grid, dim3(512), 0, st, k);          \
     } else if (a->variant == 2 && a->halo) {                                                                    \
-      if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, 1, true, 4, false, 2, 2, PREC_, 8, false, IOS_, false, true>), dim3(blocks), dim3(512), 0, st, k);  \
-      else PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 4, false, 2, 2, PREC_, 8, false, IOS_, false, true>), dim3(blocks), dim3(512), 0, st, k);         \
+      if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, 1, true, 4, false, 2, 2, PREC_, 8, false, IOS_, false, true>), grid, dim3(512), 0, st, k);  \
+      else PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 4, false, 2, 2, PREC_, 8, false, IOS_, false, true>), grid, dim3(512), 0, st, k);         \
     } else if (a->variant == 9 && a->halo) {   /* Cout = 128-class layers: 24 x 16 px x 128 ch tiles (two 61-KB activation slots) */ \
-      if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, 1, true, 2, false, 2, 4, PREC_, 6, false, IOS_, false, true>), dim3(blocks), dim3(512), 0, st, k);  \
-      else PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 2, false, 2, 4, PREC_, 6, false, IOS_, false, true>), dim3(blocks), dim3(512), 0, st, k);         \
+      if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, 1, true, 2, false, 2, 4, PREC_, 6, false, IOS_, false, true>), grid, dim3(512), 0, st, k);  \
+      else PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 2, false, 2, 4, PREC_, 6, false, IOS_, false, true>), grid, dim3(512), 0, st, k);         \
     } else return PPST_EINVAL;                                                                                  \
   } while (0)
     if (a->precision == 3) LK(3, PPST_ST_F16); else LK(1, PPST_ST_BF16);
@@ -797,28 +841,28 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
     return PPST_LAUNCH_CHECK();
   }
   if (a->variant == 11) {     // the fused upscale as nine products per input pixel + box sum (UP9); shape conditions checked by the entry point
-    PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 4, false, 2, 2, 0, 8, false, PPST_ST_F32, true>), dim3(blocks), dim3(512), 0, st, k);
+    PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 4, false, 2, 2, 0, 8, false, PPST_ST_F32, true>), grid, dim3(512), 0, st, k);
     return PPST_LAUNCH_CHECK();
   }
 #define L2(NT_, HALO_, WNW_, BDB_, NA_)                                                                         \
   do {                                                                                                          \
-    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<NT_, HALO_, true, WNW_, BDB_, NA_>), dim3(blocks), dim3(128 * WNW_), 0, st, k);  \
-    else PPST_LAUNCH((conv_mfma2_kernel<NT_, HALO_, false, WNW_, BDB_, NA_>), dim3(blocks), dim3(128 * WNW_), 0, st, k);         \
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<NT_, HALO_, true, WNW_, BDB_, NA_>), grid, dim3(128 * WNW_), 0, st, k);  \
+    else PPST_LAUNCH((conv_mfma2_kernel<NT_, HALO_, false, WNW_, BDB_, NA_>), grid, dim3(128 * WNW_), 0, st, k);         \
   } while (0)
 #define L7(HALO_)                                                                                               \
   do {                                                                                                          \
-    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 1, 4>), dim3(blocks), dim3(512), 0, st, k);   \
-    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 1, 4>), dim3(blocks), dim3(512), 0, st, k);          \
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 1, 4>), grid, dim3(512), 0, st, k);   \
+    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 1, 4>), grid, dim3(512), 0, st, k);          \
   } while (0)
 #define L9(HALO_)                                                                                               \
   do {                                                                                                          \
-    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 2, 4, 0, 6>), dim3(blocks), dim3(512), 0, st, k);   \
-    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 2, 4, 0, 6>), dim3(blocks), dim3(512), 0, st, k);          \
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 2, 4, 0, 6>), grid, dim3(512), 0, st, k);   \
+    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 2, 4, 0, 6>), grid, dim3(512), 0, st, k);          \
   } while (0)
 #define L2Q(HALO_, PREC_, IOS_)                                                                                 \
   do {                                                                                                          \
-    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 4, false, 2, 2, PREC_, 8, false, IOS_>), dim3(blocks), dim3(512), 0, st, k);   \
-    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 4, false, 2, 2, PREC_, 8, false, IOS_>), dim3(blocks), dim3(512), 0, st, k);          \
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 4, false, 2, 2, PREC_, 8, false, IOS_>), grid, dim3(512), 0, st, k);   \
+    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 4, false, 2, 2, PREC_, 8, false, IOS_>), grid, dim3(512), 0, st, k);          \
   } while (0)
 #define L2P(HALO_, PREC_)                                                                                       \
   do {                                                                                                          \
@@ -826,8 +870,8 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
   } while (0)
 #define L2D(PREC_, IOS_)                                                                                        \
   do {                                                                                                          \
-    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, 1, true, 4, false, 2, 2, PREC_, 8, true, IOS_>), dim3(blocks), dim3(512), 0, st, k);   \
-    else PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 4, false, 2, 2, PREC_, 8, true, IOS_>), dim3(blocks), dim3(512), 0, st, k);          \
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, 1, true, 4, false, 2, 2, PREC_, 8, true, IOS_>), grid, dim3(512), 0, st, k);   \
+    else PPST_LAUNCH((conv_mfma2_kernel<4, 1, false, 4, false, 2, 2, PREC_, 8, true, IOS_>), grid, dim3(512), 0, st, k);          \
   } while (0)
   if (a->variant == 2 && a->dual_b) {     // Cout % 128 == 0 fused upscale as two phase pairs (halo 1)
     if (a->precision == 3) { if (a->io_st) L2D(3, PPST_ST_F16); else L2D(3, PPST_ST_F32); }
@@ -839,8 +883,8 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
   // ceiling on 128 -> 128 @1024^2, bound by fragment reads and barriers per MFMA
 #define L7Q(HALO_, PREC_, IOS_)                                                                                 \
   do {                                                                                                          \
-    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 2, 4, PREC_, 8, false, IOS_>), dim3(blocks), dim3(512), 0, st, k);   \
-    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 2, 4, PREC_, 8, false, IOS_>), dim3(blocks), dim3(512), 0, st, k);          \
+    if (k.in_ss) PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, true, 2, false, 2, 4, PREC_, 8, false, IOS_>), grid, dim3(512), 0, st, k);   \
+    else PPST_LAUNCH((conv_mfma2_kernel<4, HALO_, false, 2, false, 2, 4, PREC_, 8, false, IOS_>), grid, dim3(512), 0, st, k);          \
   } while (0)
 #define L7P(PREC_)                                                                                              \
   do {                                                                                                          \

@@ -47,6 +47,7 @@ struct WinoKArgs {
   const float* in_ss;
   const float* in_prelu;
   int in_c, in_act;
+  KSplitDev ks;          // across-block K split (common.h): grid row y runs chunks [y * nchunk / S, (y + 1) * nchunk / S)
 };
 
 __device__ __forceinline__ int wino_pad_index(int i, int n, int mode) {
@@ -110,7 +111,7 @@ __device__ __forceinline__ int wino_lane() {
 // (wave tile 128 pairs x 128 ch, 256 accumulator registers), reads every A fragment ONCE per K-step (16 ds_read_b128 per 192 MFMAs
 // instead of 32 per 96 ... reloaded half a step ahead) and has no SIMD
 // partner running the same program phase.
-template <int INMODE, bool FAT>
+template <int INMODE, bool FAT, bool KS = false>
 __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 1 : 2) void conv_wino_kernel(WinoKArgs a) {
   constexpr bool INSS = INMODE != 0;
   constexpr int NWV = FAT ? 4 : 8, NTH = 64 * NWV, NTW = FAT ? 8 : 4;      // waves, threads, n-tiles per wave
@@ -151,7 +152,14 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 1 : 2) void conv_wino_kernel
   typedef const int4* StepPtr;
 #endif
   StepPtr steps = (StepPtr)a.steps;
-  const int nchunk = a.nchunk, nsteps = nchunk * 3;
+  // across-block K split (ppst_conv_args.ksplit, conv_mfma.hip): this block's chunks; its weight stream starts 3 c0 steps in
+  int nchunk = a.nchunk, c0 = 0;
+  if (KS && !FAT && a.ks.S > 1) {      // (instances of their own: the plain ones -- the swap path's -- keep their register allocation)
+    nchunk = a.nchunk / a.ks.S;
+    c0 = (int)blockIdx.y * nchunk;
+    steps += c0 * 9;
+  }
+  const int nsteps = nchunk * 3;
   const int64_t xoff_ = (int64_t)b * a.in_h * a.in_w * a.in_ld;
   const float* xb = a.x + (((int64_t)__builtin_amdgcn_readfirstlane((int)(xoff_ >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)xoff_));
 
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 1 : 2) void conv_wino_kernel
 
   // ---- weight fragments: this wave's stream [step][n-tile 0..3][hi | lo][lane][16 B], straight into registers
   // (block- and wave-uniform, but computed with vector divisions: say so, or every load through it becomes a waterfall loop)
-  const int64_t woff_ = ((((int64_t)ntile * 4 + xi) * 2 + nh) * nsteps) * WINO_STEP_BYTES;
+  const int64_t woff_ = ((((int64_t)ntile * 4 + xi) * 2 + nh) * (a.nchunk * 3) + c0 * 3) * WINO_STEP_BYTES;
   const unsigned char* wbase = a.wpack + (((int64_t)__builtin_amdgcn_readfirstlane((int)(woff_ >> 32)) << 32) |
                                           (unsigned)__builtin_amdgcn_readfirstlane((int)woff_));
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, (FAT ? 2 : 1) * nsteps * WINO_STEP_BYTES, 0x00020000);
@@ -526,6 +534,21 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 1 : 2) void conv_wino_kernel
   }
 #undef WA_OFF
 
+  // ---- across-block K split: the partial sums are exchanged in the TRANSFORM domain (the output transform is linear): rows
+  // 0 .. S-2 hand their 128 accumulator registers over and leave, row S-1 adds them (row order) and goes on
+  if (KS && !FAT && a.ks.S > 1) {
+    const int S = a.ks.S, y = (int)blockIdx.y;
+    float* const slot0 = a.ks.scratch + (int64_t)wid * (S - 1) * (8 * NTW * 4 * NTH) + tid;
+    if (y < S - 1) {
+      float* const dst = slot0 + (int64_t)y * (8 * NTW * 4 * NTH);
+      KS_SCATTER(acc, 8, NTW, NTH, dst)
+      ks_publish(a.ks, wid, y, tid);
+      return;
+    }
+    ks_wait(a.ks, wid, tid);
+    KS_GATHER(acc, 8, NTW, NTH, S, slot0);
+  }
+
   // ---- output transform + epilogue: four passes of 4 tile rows (two m-tiles) x all 128 channels.  In a pass EVERY wave puts
   // its accumulators of those two m-tiles into LDS ([position][32 pairs][128 channels + 4]: 32 ds_write_b32 per wave and pass,
   // conflict-free), then all eight waves form y[2p] = m0 + m1 + m2, y[2p+1] = m1 - m2 + m3: a thread takes 4 consecutive
@@ -664,14 +687,31 @@ int ppst_conv_wino_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int
   k.in_ss = (const float*)a->in_scale_shift; k.in_prelu = (const float*)a->in_prelu;
   k.in_c = a->in_c; k.in_act = a->in_act;
   const int blocks = n_tiles * a->B * tiles_y * tiles_x;
+  k.ks.scratch = nullptr; k.ks.flags = nullptr; k.ks.epoch = 0; k.ks.S = 1; k.ks.ksteps = a->nsteps;
+#ifndef WINO_FAT
+  if (a->ksplit > 1) {        // across-block K split: whole chunks per block (k.nchunk % S == 0 follows from nsteps % S with 9-step chunks
+                              // only if the caller kept its promise; checked here)
+    if (k.nchunk % a->ksplit || a->ksplit > 4) return PPST_EINVAL;
+    const int e0 = ppst_ksplit_prepare_(a->ksplit, blocks, a->nsteps, 128, 512, st, &k.ks);
+    if (e0 != PPST_OK) return e0;
+  }
+#endif
+  if (k.ks.S > 1) {
+    const dim3 gridk(blocks, k.ks.S);
+    if (k.in_ss && k.in_act != PPST_ACT_NONE) PPST_LAUNCH((conv_wino_kernel<2, false, true>), gridk, dim3(512), 0, st, k);
+    else if (k.in_ss) PPST_LAUNCH((conv_wino_kernel<1, false, true>), gridk, dim3(512), 0, st, k);
+    else PPST_LAUNCH((conv_wino_kernel<0, false, true>), gridk, dim3(512), 0, st, k);
+    return PPST_LAUNCH_CHECK();
+  }
+  const dim3 grid(blocks);
 #ifdef WINO_FAT
   if (k.in_ss && k.in_act != PPST_ACT_NONE) PPST_LAUNCH((conv_wino_kernel<2, true>), dim3(blocks), dim3(256), 0, st, k);
   else if (k.in_ss) PPST_LAUNCH((conv_wino_kernel<1, true>), dim3(blocks), dim3(256), 0, st, k);
   else PPST_LAUNCH((conv_wino_kernel<0, true>), dim3(blocks), dim3(256), 0, st, k);
 #else
-  if (k.in_ss && k.in_act != PPST_ACT_NONE) PPST_LAUNCH((conv_wino_kernel<2, false>), dim3(blocks), dim3(512), 0, st, k);
-  else if (k.in_ss) PPST_LAUNCH((conv_wino_kernel<1, false>), dim3(blocks), dim3(512), 0, st, k);
-  else PPST_LAUNCH((conv_wino_kernel<0, false>), dim3(blocks), dim3(512), 0, st, k);
+  if (k.in_ss && k.in_act != PPST_ACT_NONE) PPST_LAUNCH((conv_wino_kernel<2, false>), grid, dim3(512), 0, st, k);
+  else if (k.in_ss) PPST_LAUNCH((conv_wino_kernel<1, false>), grid, dim3(512), 0, st, k);
+  else PPST_LAUNCH((conv_wino_kernel<0, false>), grid, dim3(512), 0, st, k);
 #endif
   return PPST_LAUNCH_CHECK();
 }

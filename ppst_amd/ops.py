@@ -45,6 +45,12 @@ STREAM_1X1 = {"value": True}       # 1x1 convs (halo 0) on the streaming kernel 
 # variant 8 (conv_ksplit.hip: the block's waves split K in two, 128 px x 64 ch wave tiles, two activation slots) for the
 # Cout = 128-class layers when one image gives >= min_blocks: measured 3-7 % SLOWER than the tile kernel (128->128 @512^2
 # 342-348 vs 358-368 TFLOP/s; in-kernel trace: step pair 5 750 cycles against an issue floor of 3 072) and not bit-identical -- off
+# round 5: across-block K split (ppst_conv_args.ksplit) of launches whose grid fills a fraction of the chip while every block runs
+# one long serial chain of steps -- the 64^2 ... 4^2 layers of a train step at batch 2 (4-128 blocks of 72-160 steps: ~0.9 us per
+# step whatever the grid).  S = the largest of 8 / 4 / 2 with S x blocks <= max_blocks, chunk count divisible by S and >= min_steps
+# steps left per block.  Results equal the unsplit launch's up to fp32 summation order: batch-aware passes (the train step) only.
+# PPST_KSPLIT=0 turns it off.
+KSPLIT = {"value": os.environ.get("PPST_KSPLIT", "1") != "0", "max_blocks": 256, "min_steps": 16, "variants": (0, 2, 10)}
 KSPLIT_128 = {"value": False, "min_blocks": 32}
 # variant 7 (32 x 16 px x 128 ch blocks, conv_mfma2.hip WMW = 4) when one image gives >= min_blocks: measured 3-5 % SLOWER than
 # the tile kernel on the Cout = 128 layers (one activation slot: the chunk store sits between two barriers; 33-44 spills) -- off
@@ -84,7 +90,10 @@ class batch_aware:
 # (the choice stays a function of the plan and one image's geometry).
 # ``fill`` (batch-aware passes only, i.e. the train step): with fewer than this many blocks in the LAUNCH the choice falls through to
 # the direct kernels' under-filled forms (8-row two-block tiles: twice the blocks)
-WINO = {"value": True, "min_blocks": 16, "fill": 0}
+# ``ksplit_fill`` (batch-aware passes with ops.KSPLIT on): a Cout <= 256 layer whose launch has at most this many Winograd blocks runs
+# on the tile kernel with the across-block K split instead (256 -> 256 @64^2 x 2: 38 us with S = 4 against 48 on the Winograd kernel
+# with S = 2 -- its 128 accumulator registers per thread make the hand-over twice as large; tests/conv_ksplit_time.py)
+WINO = {"value": True, "min_blocks": 16, "fill": 0, "ksplit_fill": 64}
 # round 5: apply passes whose only consumer is a 1x1 conv are applied by that conv while it loads -- layert1's resnet merge by
 # layert1.1 (ConvPlan in_res), the last upsampling block's merge by ToRGB in the image pass (torgb_apply).  Off: the round-4 passes.
 # "torgb": measured SLOWER (rocprofv3, batch-8 swap step: 1.09 ms against 0.56 + 0.23 for the pass + the conv -- the 32-lanes-per-pixel ToRGB
@@ -679,10 +688,12 @@ class ConvPlan:
         single = self.precision in (1, 3)
         if self.precision not in (0, 1, 3):
             return variant, bn, rows                     # fp16x2 experiment / exact-fp32 verification: the tile kernel only
-        if WINO["value"] and self.wino_ok(th, tw, oh, ow, H, W, osy) and not (
-                BATCH_AWARE["value"] and B is not None and
-                ((th + 15) // 16) * ((tw + 15) // 16) * ((self.cout + 127) // 128) * B < WINO["fill"]):
-            return 10, 128, 16
+        if WINO["value"] and self.wino_ok(th, tw, oh, ow, H, W, osy):
+            wblocks = ((th + 15) // 16) * ((tw + 15) // 16) * ((self.cout + 127) // 128) * (B or 1)
+            aware_b = BATCH_AWARE["value"] and B is not None
+            if not (aware_b and (wblocks < WINO["fill"] or (KSPLIT["value"] and 0 in KSPLIT["variants"] and self.cout <= 256
+                                                             and wblocks <= WINO["ksplit_fill"]))):
+                return 10, 128, 16
         tiles16 = ((th + 15) // 16) * ((tw + 15) // 16) * self.n_groups          # blocks PER IMAGE per N tile
         cv = CONV_VARIANT["value"]
         if cv in (1, 3) or TWO_BLOCK_128["value"] or KSPLIT_128["value"] or TILE24_128["value"] or TALL_TILE_128["value"]:
@@ -737,6 +748,22 @@ class ConvPlan:
         elif (not single and self.kind in ("conv", "dgrad") and self.k == 3 and 64 < self.cout <= DIRECT_MAX["cout3x3"] and same):
             variant, bn, rows = 6, 128, TILE_ROWS["value"]           # (experiment) 32 px x 128 ch waves for Cout in 65..128
         return variant, bn, rows
+
+    def _ksplit(self, variant, a, skip):
+        """ppst_conv_args.ksplit of the launch described by ``a`` (0: none) -- ops.KSPLIT."""
+        if (skip or variant not in KSPLIT["variants"] or a.in_presplit or self.max_chunk_steps != self.min_chunk_steps
+                or not (a.tile_rows == 16 or (variant == 0 and a.tile_rows == 8))):
+            return 0
+        chunk = self.max_chunk_steps            # steps per chunk of the launch's table (a K64 table keeps the taps of every second chunk)
+        if a.dual_b or (variant == 2 and ((self.precision == 0) != (a.io_st == 0) or (a.k64 and not a.halo))):
+            return 0                    # (the N-256 kernel's K-split instances: fp32-class on fp32 tensors, single-pass on half-stored ones)
+        n_tiles = -(-self.cout // a.bn)
+        blocks = a.B * lib.ppst_conv_tiles(a.tile_h, a.tile_w, a.tile_rows) * a.n_groups * n_tiles
+        # (the N-256 and Winograd kernels hold 128 accumulator registers per thread: S <= 4, include/ppst_hip.h)
+        # -- and what the hand-over of 256 KB per block costs them (tests/conv_ksplit_time.py): the Winograd kernel gains from S = 2 with
+        # >= 4 chunks left per block only, the N-256 kernel needs >= 32 steps left
+        max_s, min_steps = {0: (8, KSPLIT["min_steps"]), 2: (4, 2 * KSPLIT["min_steps"]), 10: (2, 36)}[variant]
+        return _ksplit_choice(blocks, a.nsteps, chunk, KSPLIT["max_blocks"], min_steps, max_s)
 
     def __call__(self, x, bias=None, noise=None, noise_weight=0.0, act=ACT_NONE, prelu=None, stats=False,
                  residual=None, out=None, out_scale=1.0, pad_mode=PAD_ZERO, out_hw=None, res_after_act=False,
@@ -844,6 +871,9 @@ class ConvPlan:
             if variant != 0 or bn != 128 or in_ss is not None or self.nsteps // max(1, self.chunks_per_group) < 4:
                 raise RuntimeError("pre-split input: tile kernel (bn 128) plans with chunks of >= 4 steps and no in_ss only")
             a.in_presplit = 1
+        # (batch-aware passes only: the split depends on the batch in the launch and changes the summation order -- a shard of an
+        #  inference batch has to reproduce the whole batch bit for bit)
+        a.ksplit = self._ksplit(variant, a, self.precision == 2) if (KSPLIT["value"] and BATCH_AWARE["value"]) else 0
         if self.precision == 2:
             sn, sc, sy, sx = self.wstrides
             c_, ky_, kx_ = self.src_dev
@@ -854,6 +884,19 @@ class ConvPlan:
         if stats:
             return out, st
         return out
+
+
+def _ksplit_choice(blocks, nsteps, chunk_steps, max_blocks, min_steps, max_s=8):
+    """S of ppst_conv_args.ksplit for a launch of ``blocks`` blocks x ``nsteps`` steps in chunks of ``chunk_steps`` (0: none)."""
+    if chunk_steps <= 0 or nsteps % chunk_steps:
+        return 0
+    nchunks = nsteps // chunk_steps
+    for S in (8, 4, 2):
+        if S > max_s:
+            continue
+        if nchunks % S == 0 and blocks * S <= max_blocks and nsteps // S >= min_steps and (S - 1) * blocks <= 256:
+            return S
+    return 0
 
 
 def repack_plans(plans):

@@ -282,6 +282,82 @@ def t_fuse_tail():
         ops.FUSE_TAIL.update(prev)
 
 
+def t_conv_ksplit():
+    """ppst_conv_args.ksplit (round 5): the across-block K split of small grids against float64 torch at the bar of the unsplit
+    kernels, beside the unsplit launch (same values up to fp32 summation order), with every epilogue option, normalise-on-load,
+    the stride-2 input-gradient scatter, half storage; the give-up marker of the flag wait stays clear."""
+    torch.manual_seed(11)
+    lrelu = lambda t: F.leaky_relu(t, 0.2) * math.sqrt(2.0)
+    prevk, prevw, prevp, prevb = dict(ops.KSPLIT), dict(ops.WINO), ops.PRECISION["value"], ops.BATCH_AWARE["value"]
+    ops.BATCH_AWARE["value"] = True          # (the split is a batch-aware choice: the train step's)
+    ops.WINO["ksplit_fill"] = 0              # (every shape below that the Winograd kernel takes stays on it)
+    try:
+        for variants, wino, tag in (((0,), False, "tile"), (ops.KSPLIT["variants"], True, "prod")):
+            ops.WINO["value"] = wino
+            for name, B, ci, co, H, Wd in [("256->256 64x64 B2", 2, 256, 256, 64, 64), ("512->512 16x16 B4", 4, 512, 512, 16, 16),
+                                           ("512->512 8x8 B4", 4, 512, 512, 8, 8), ("512->512 4x4 B5", 5, 512, 512, 4, 4),
+                                           ("384->256 33x20 B1 ragged", 1, 384, 256, 33, 20), ("256->64 32x32 B2 (bn 64)", 2, 256, 64, 32, 32)]:
+                x = torch.randn(B, ci, H, Wd); w = torch.randn(co, ci, 3, 3) / math.sqrt(ci * 9)
+                bias = torch.randn(co); noise = torch.randn(B, 1, H, Wd); res = torch.randn(B, co, H, Wd)
+                conv = F.conv2d(x.double(), w.double(), padding=1)
+                ref = lrelu(conv + 0.3 * noise.double() + bias.double().view(1, -1, 1, 1))
+                plan = ops.ConvPlan(g(w))
+                outs = {}
+                for on in (False, True):
+                    ops.KSPLIT.update(value=on, variants=variants)
+                    outs[on] = plan(g(nhwc(x)), bias=g(bias), noise=g(noise), noise_weight=0.3, act=ops.ACT_LRELU, stats=True)
+                y, st = outs[True]
+                report("ksplit %s %s vs float64" % (tag, name), nchw(y.cpu()), ref, 3e-5)
+                report("ksplit %s %s vs unsplit" % (tag, name), y.cpu(), outs[False][0].cpu(), 3e-6)
+                report("ksplit %s %s stats" % (tag, name), st.cpu().double().sum(1)[..., 1], (ref ** 2).sum((2, 3)), 1e-5)
+        ops.KSPLIT.update(value=True, variants=prevk["variants"])
+        ops.WINO.update(prevw)
+        ops.WINO["ksplit_fill"] = 0
+        # a launch that really splits (the choice is the host's: say so)
+        a_ = lambda B, H, Wd, co, bn, nst, ch: ops._ksplit_choice(B * ((H + 15) // 16) * ((Wd + 15) // 16) * -(-co // bn), nst, ch, 256, 16)
+        assert a_(2, 64, 64, 256, 128, 72, 9) == 4 and a_(4, 4, 4, 512, 128, 144, 9) == 8 and a_(8, 512, 512, 128, 128, 36, 9) == 0
+        B, ci, co, H, Wd = 2, 256, 256, 32, 32
+        x = torch.randn(B, ci, H, Wd); w = torch.randn(co, ci, 3, 3) / 48.0
+        bias = torch.randn(co); res = torch.randn(B, co, H, Wd); a1 = torch.tensor([0.25])
+        conv = F.conv2d(x.double(), w.double(), padding=1)
+        plan = ops.ConvPlan(g(w))
+        y = plan(g(nhwc(x)), bias=g(bias), act=ops.ACT_PRELU, prelu=g(a1), residual=g(nhwc(res)))
+        t = conv + bias.double().view(1, -1, 1, 1) + res.double()
+        report("ksplit residual before prelu", nchw(y.cpu()), torch.where(t >= 0, t, 0.25 * t), 3e-5)
+        y = plan(g(nhwc(x)), bias=g(bias), act=ops.ACT_LRELU, residual=g(nhwc(res)), res_after_act=True, out_scale=0.5)
+        report("ksplit residual after act * scale", nchw(y.cpu()), (lrelu(conv + bias.double().view(1, -1, 1, 1)) + res.double()) * 0.5, 3e-5)
+        ss = torch.stack([torch.rand(B, ci) + 0.5, torch.randn(B, ci)], -1).contiguous()
+        xn = x.double() * ss[..., 0].double().view(B, ci, 1, 1) + ss[..., 1].double().view(B, ci, 1, 1)
+        for pm in (0, 1, 2):
+            y = plan(g(nhwc(x)), pad_mode=pm, in_ss=g(ss), in_act=ops.ACT_LRELU)
+            xp = F.pad(lrelu(xn), (1, 1, 1, 1), mode={0: "constant", 1: "reflect", 2: "replicate"}[pm])
+            report("ksplit normalise-on-load pad %d" % pm, nchw(y.cpu()), F.conv2d(xp, w.double()), 3e-5)
+        pd = ops.ConvPlan(g(w), kind="dgrad")
+        dy = torch.randn(B, co, H, Wd)
+        report("ksplit dgrad", nchw(pd(g(nhwc(dy))).cpu()), F.conv_transpose2d(dy.double(), w.double(), padding=1), 3e-5)
+        ws = torch.randn(256, 256, 3, 3) / 48.0          # stride-2 conv on a 33x33 tensor: its scattered input gradient
+        pg = ops.ConvPlan(g(ws), kind="dgrad_s2d")
+        dys = torch.randn(B, 256, 16, 16)
+        report("ksplit dgrad_s2d", nchw(pg(g(nhwc(dys)), out_hw=(33, 33)).cpu()), F.conv_transpose2d(dys.double(), ws.double(), stride=2), 3e-5)
+        # single-pass bf16 on bf16-stored activations (the train step's mode): against the unsplit launch, one bf16 ulp
+        ops.set_precision(1)
+        wb = torch.randn(256, 256, 3, 3) / 48.0
+        xb = g(nhwc(torch.randn(2, 256, 64, 64))).to(torch.bfloat16)
+        pb = ops.ConvPlan(g(wb))
+        outs = {}
+        for on in (False, True):
+            ops.KSPLIT["value"] = on
+            outs[on] = pb(xb, bias=g(bias), act=ops.ACT_LRELU).float().cpu()
+        report("ksplit bf16 storage vs unsplit", outs[True], outs[False], 8e-3)
+        report("ksplit bf16 storage vs float64", nchw(outs[True]), lrelu(F.conv2d(nchw(xb.float().cpu()).double(), wb.double(), padding=1) + bias.double().view(1, -1, 1, 1)), 2e-2)
+        ops.set_precision(prevp)
+        rc = ops.lib.ppst_conv_ksplit_check(ops._stream())
+        RES.append(("ksplit wait marker clear", rc == 0))
+        print("ksplit give-up marker: %d (0 = every wait ended on its flag)" % rc, flush=True)
+    finally:
+        ops.KSPLIT.update(prevk); ops.WINO.update(prevw); ops.set_precision(prevp); ops.BATCH_AWARE["value"] = prevb
+
+
 def t_gmp_multi():
     """Round 5: the multi-head GAP || GMP (ppst_gap_gmp_multi / _bwd: the plain and the three class-masked poolings of one feature map in
     one read) against the single-head kernels: forward bit-equal per head, backward = the sum of the four single-head gradients
@@ -1602,6 +1678,8 @@ def main():
         run(t_train_half)
     if which == "gmp":
         run(t_gmp_multi)
+    if which == "ksplit":
+        run(t_conv_ksplit)
     if which == "tail":
         run(t_fuse_tail)
     if which == "up9":

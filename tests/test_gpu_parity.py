@@ -38,7 +38,7 @@ def test_native_library_is_loaded():
     assert "libppst_hip.so" in maps
 
 
-@pytest.mark.parametrize("fn", ["t_upfirdn2d", "t_fused_act", "t_ops_half", "t_ops_f64", "t_layout_misc", "t_conv", "t_conv_wino", "t_conv_dual", "t_conv_up9", "t_conv_variants", "t_conv_variants_single_pass", "t_half_storage", "t_conv_k64", "t_conv1x1_stream", "t_fuse_tail", "t_gmp_multi", "t_train_half", "t_norm_pool", "t_corr", "t_guided"])
+@pytest.mark.parametrize("fn", ["t_upfirdn2d", "t_fused_act", "t_ops_half", "t_ops_f64", "t_layout_misc", "t_conv", "t_conv_wino", "t_conv_dual", "t_conv_up9", "t_conv_variants", "t_conv_variants_single_pass", "t_half_storage", "t_conv_k64", "t_conv1x1_stream", "t_conv_ksplit", "t_fuse_tail", "t_gmp_multi", "t_train_half", "t_norm_pool", "t_corr", "t_guided"])
 def test_kernels_vs_oracle(fn):
     _run(fn)
 
