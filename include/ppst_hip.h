@@ -318,6 +318,11 @@ typedef struct ppst_conv_args {
                                     1 / S of the chain.  Results equal the unsplit launch's up to fp32 summation order.  At most
                                     256 (S - 1) x tiles per launch; launches that use it are serialised per stream by the library
                                     (one scratch buffer per stream, four streams). */
+  const int32_t* ksplit_starts;  /* HOST pointer to ksplit + 1 ascending step indices, starts[0] = 0, starts[ksplit] = nsteps, every one of
+                                    them a step that opens a chunk (the caller's promise): block row i runs steps
+                                    [starts[i], starts[i + 1]) -- tables whose chunks differ in length (the stride-2 conv on a
+                                    space-to-depth tensor: 4 / 2 / 2 / 2 taps per phase).  NULL: equal shares of nsteps / ksplit
+                                    steps.  Read during the call, not kept. */
 } ppst_conv_args;
 
 int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream);

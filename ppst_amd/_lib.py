@@ -53,7 +53,7 @@ class ConvArgs(ctypes.Structure):
         ("act", i32), ("precision", i32), ("res_ld", i32), ("tile_h", i32), ("tile_w", i32),
         ("halo", i32), ("bn", i32), ("in_scale_shift", vp), ("in_prelu", vp), ("in_c", i32), ("in_act", i32),
         ("flop_steps", i32), ("tile_rows", i32), ("a_slots", i32), ("early_a", i32), ("variant", i32), ("in_presplit", i32), ("dual_b", i32), ("io_st", i32), ("k64", i32),
-        ("in_res", vp), ("in_res_ld", i32), ("ksplit", i32),
+        ("in_res", vp), ("in_res_ld", i32), ("ksplit", i32), ("ksplit_starts", vp),
     ]
 
 

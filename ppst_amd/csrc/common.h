@@ -45,12 +45,13 @@ struct KSplitDev {
   float* scratch;        // [tile][S-1][acc regs][NT] floats
   unsigned* flags;       // [tile][S-1]; word KS_FLAG_WORDS - 1: error marker
   unsigned epoch;
-  int S, ksteps;         // ksteps = nsteps / S
+  int S;
+  int start[9];          // block row y runs steps [start[y], start[y + 1]) of every group; start[S] = nsteps
 };
 #define KS_FLAG_WORDS 4096
 #define KS_MAX_SLOTS 512
 #define KS_SCRATCH_BYTES ((size_t)256 * 512 * 128 * 4)      /* 256 producer blocks x 512 threads x 128 accumulator registers (512 of the tile kernel's) */
-int ppst_ksplit_prepare_(int S, int64_t tiles, int nsteps, int acc_regs, int threads, hipStream_t st, KSplitDev* out);   // conv_mfma.hip
+int ppst_ksplit_prepare_(int S, const int32_t* starts, int64_t tiles, int nsteps, int acc_regs, int threads, hipStream_t st, KSplitDev* out);   // conv_mfma.hip
 
 // Agent-scope relaxed atomic accesses, one dword each (sc1; a 16-byte volatile access gets sc0 sc1 -- system scope -- and measured
 // ~3 us slower per launch).  hipcc tracks them with counted vmcnt like plain loads but is free to hoist them: left alone it moved the

@@ -46,7 +46,7 @@ struct ConvKArgs {
   int in_c, in_act;
   int early_a;              // step table guarantees chunks of >= 2 steps: a chunk's global loads go out one step early
   unsigned long long* dbg;  // stamp build: [block][wave][8] cycle sums (else unused)
-  KSplitDev ks;             // ks.S > 1: grid row y runs steps [y * ks.ksteps, (y + 1) * ks.ksteps) of every group (common.h)
+  KSplitDev ks;             // ks.S > 1: grid row y runs steps [ks.start[y], ks.start[y + 1]) of every group (common.h)
 };
 // (the storage type of x / residual / y -- ppst_conv_args.io_st, single-pass precision modes only -- is a template parameter IOS of
 // the kernels, not a field: the pointers above are then half / bfloat16 tensors behind their `float*` type)
@@ -160,15 +160,15 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   StepPtr steps = (StepPtr)(a.steps + (int64_t)group * a.nsteps);
   const unsigned char* wblob = (const unsigned char*)a.wpack + ((int64_t)nidx * a.nsteps) * BBUF;
   const unsigned char* xb = (const unsigned char*)a.x + (int64_t)b * a.in_h * a.in_w * a.in_ld * ES;
-  // across-block K split (ppst_conv_args.ksplit): this block runs `nst` steps from step y * ksteps on -- the first of them opens a
+  // across-block K split (ppst_conv_args.ksplit): this block runs `nst` steps from step start[y] on -- the first of them opens a
   // chunk (the caller's promise), so the sub-table is a table of its own; a next-chunk flag on its last step requests one tile that
   // is never stored (drained by the last step's vmcnt(0))
   int nst = a.nsteps;
   if (a.ks.S > 1) {
-    const int s0 = (int)blockIdx.y * a.ks.ksteps;
+    const int s0 = a.ks.start[blockIdx.y];
     steps += s0;
     wblob += (int64_t)s0 * BBUF;
-    nst = a.ks.ksteps;
+    nst = a.ks.start[blockIdx.y + 1] - s0;
   }
 
   constexpr int A_WCH = (HP + 7) / 8;                      // wave-chunks of 8 pixels x 8 float4
@@ -1070,8 +1070,13 @@ extern "C" int ppst_has_experiments(void) {
 struct KsState { int dev; hipStream_t st; float* scratch; unsigned* flags; unsigned epoch; };
 static KsState g_ks[4];
 static int g_ks_n = 0;
-int ppst_ksplit_prepare_(int S, int64_t tiles, int nsteps, int acc_regs, int threads, hipStream_t st, KSplitDev* out) {
-  if ((S != 2 && S != 4 && S != 8) || nsteps % S || tiles <= 0 || acc_regs <= 0 || acc_regs % 4 || threads <= 0) return PPST_EINVAL;
+int ppst_ksplit_prepare_(int S, const int32_t* starts, int64_t tiles, int nsteps, int acc_regs, int threads, hipStream_t st, KSplitDev* out) {
+  if ((S != 2 && S != 4 && S != 8) || (!starts && nsteps % S) || tiles <= 0 || acc_regs <= 0 || acc_regs % 4 || threads <= 0) return PPST_EINVAL;
+  for (int i = 0; i <= S; ++i) {
+    out->start[i] = starts ? starts[i] : i * (nsteps / S);
+    if (i && out->start[i] <= out->start[i - 1]) return PPST_EINVAL;
+  }
+  if (out->start[0] != 0 || out->start[S] != nsteps) return PPST_EINVAL;
   const int64_t slots = (int64_t)(S - 1) * tiles;
   if (slots > KS_MAX_SLOTS || slots > KS_FLAG_WORDS - 1 || (size_t)slots * threads * acc_regs * 4 > KS_SCRATCH_BYTES) return PPST_EINVAL;
   int dev = 0;
@@ -1093,7 +1098,7 @@ int ppst_ksplit_prepare_(int S, int64_t tiles, int nsteps, int acc_regs, int thr
     e = &g_ks[g_ks_n++];
   }
   if (++e->epoch == 0) ++e->epoch;            // (0 is the value of a fresh flag)
-  out->scratch = e->scratch; out->flags = e->flags; out->epoch = e->epoch; out->S = S; out->ksteps = nsteps / S;
+  out->scratch = e->scratch; out->flags = e->flags; out->epoch = e->epoch; out->S = S;
   return PPST_OK;
 }
 // 1 if a block of a K-split launch on `stream` ever gave up waiting for its partners (the results of that launch are wrong), 0 if
@@ -1220,7 +1225,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
   k.in_c = a->in_c; k.in_act = a->in_act;
   k.early_a = a->early_a ? 1 : 0;
   k.dbg = nullptr;
-  k.ks.scratch = nullptr; k.ks.flags = nullptr; k.ks.epoch = 0; k.ks.S = 1; k.ks.ksteps = a->nsteps;
+  k.ks.scratch = nullptr; k.ks.flags = nullptr; k.ks.epoch = 0; k.ks.S = 1;
 #ifdef PPST_CONV_TRACE
   k.dbg = (unsigned long long*)a->prelu;  // diagnostic builds: the (unused) prelu slot carries the debug buffer
   k.prelu = nullptr;
@@ -1233,7 +1238,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
     // the tile kernel (variant 0, 16-row tiles); the N-256 and Winograd kernels take theirs in their own launchers
     if (a->variant == 0) {
       if ((a->tile_rows != 16 && a->tile_rows != 8) || a->in_presplit) return PPST_EINVAL;
-      const int e0 = ppst_ksplit_prepare_(a->ksplit, blocks, a->nsteps, 64, (a->bn == 128 && a->tile_rows == 16) ? 512 : 256, st, &k.ks);
+      const int e0 = ppst_ksplit_prepare_(a->ksplit, a->ksplit_starts, blocks, a->nsteps, 64, (a->bn == 128 && a->tile_rows == 16) ? 512 : 256, st, &k.ks);
       if (e0 != PPST_OK) return e0;
     } else if (a->variant != 2 && a->variant != 10) return PPST_EINVAL;
   }

@@ -39,7 +39,7 @@ struct Conv2KArgs {
   int in_c, in_act;
   int early_a;
   unsigned long long* dbg;   // -DPPST_CONV_TRACE builds only
-  KSplitDev ks;              // across-block K split (common.h): grid row y runs steps [y * ks.ksteps, (y + 1) * ks.ksteps)
+  KSplitDev ks;              // across-block K split (common.h): grid row y runs steps [ks.start[y], ks.start[y + 1])
 };
 
 // Diagnostic build -DPPST_CONV_TRACE (tests/build_variant.sh): the per-step timeline of conv_mfma.hip's trace, same buffer
@@ -162,10 +162,10 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   // registers, which the plain instances, the swap path's, must not pay): this block's share of the table (conv_mfma.hip)
   int nst = a.nsteps;
   if (KS && a.ks.S > 1) {
-    const int s0 = (int)blockIdx.y * a.ks.ksteps;
+    const int s0 = a.ks.start[blockIdx.y];
     steps += s0;
     wblob += (int64_t)s0 * BBUF;
-    nst = a.ks.ksteps;
+    nst = a.ks.start[blockIdx.y + 1] - s0;
   }
 
   // ---- A staging (as conv_mfma.hip: one wave-instruction = 8 pixels x 128 B; fp32 -> bf16 hi/lo planes)
@@ -802,12 +802,12 @@ int ppst_conv2d_mfma2_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, 
   k.prelu = nullptr;
 #endif
   const int blocks = a->n_groups * n_tiles * a->B * tiles_y * tiles_x;
-  k.ks.scratch = nullptr; k.ks.flags = nullptr; k.ks.epoch = 0; k.ks.S = 1; k.ks.ksteps = a->nsteps;
+  k.ks.scratch = nullptr; k.ks.flags = nullptr; k.ks.epoch = 0; k.ks.S = 1;
   if (a->ksplit > 1) {
     // across-block K split: the N-256 kernel in its plain forms (8 m-tiles x 4 n-tiles per wave, 8 waves) -- fp32-class mode on fp32
     // tensors, single-pass modes on half-stored ones (what the train step launches); S <= 4 (128 accumulator registers per thread)
     if (a->variant != 2 || a->dual_b || a->ksplit > 4 || (a->precision == 0 ? a->io_st != 0 : a->io_st == 0) || (a->k64 && !a->halo)) return PPST_EINVAL;
-    const int e0 = ppst_ksplit_prepare_(a->ksplit, blocks, a->nsteps, 128, 512, st, &k.ks);
+    const int e0 = ppst_ksplit_prepare_(a->ksplit, a->ksplit_starts, blocks, a->nsteps, 128, 512, st, &k.ks);
     if (e0 != PPST_OK) return e0;
     const dim3 gridk(blocks, k.ks.S);
 #define LKS(HALO_, PREC_, IOS_, K64_)                                                                            \

@@ -155,8 +155,8 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 1 : 2) void conv_wino_kernel
   // across-block K split (ppst_conv_args.ksplit, conv_mfma.hip): this block's chunks; its weight stream starts 3 c0 steps in
   int nchunk = a.nchunk, c0 = 0;
   if (KS && !FAT && a.ks.S > 1) {      // (instances of their own: the plain ones -- the swap path's -- keep their register allocation)
-    nchunk = a.nchunk / a.ks.S;
-    c0 = (int)blockIdx.y * nchunk;
+    c0 = a.ks.start[blockIdx.y] / 9;
+    nchunk = a.ks.start[blockIdx.y + 1] / 9 - c0;
     steps += c0 * 9;
   }
   const int nsteps = nchunk * 3;
@@ -687,13 +687,15 @@ int ppst_conv_wino_launch(const ppst_conv_args* a, int n_tiles, int tiles_y, int
   k.in_ss = (const float*)a->in_scale_shift; k.in_prelu = (const float*)a->in_prelu;
   k.in_c = a->in_c; k.in_act = a->in_act;
   const int blocks = n_tiles * a->B * tiles_y * tiles_x;
-  k.ks.scratch = nullptr; k.ks.flags = nullptr; k.ks.epoch = 0; k.ks.S = 1; k.ks.ksteps = a->nsteps;
+  k.ks.scratch = nullptr; k.ks.flags = nullptr; k.ks.epoch = 0; k.ks.S = 1;
 #ifndef WINO_FAT
   if (a->ksplit > 1) {        // across-block K split: whole chunks per block (k.nchunk % S == 0 follows from nsteps % S with 9-step chunks
                               // only if the caller kept its promise; checked here)
-    if (k.nchunk % a->ksplit || a->ksplit > 4) return PPST_EINVAL;
-    const int e0 = ppst_ksplit_prepare_(a->ksplit, blocks, a->nsteps, 128, 512, st, &k.ks);
+    if ((!a->ksplit_starts && k.nchunk % a->ksplit) || a->ksplit > 4) return PPST_EINVAL;
+    const int e0 = ppst_ksplit_prepare_(a->ksplit, a->ksplit_starts, blocks, a->nsteps, 128, 512, st, &k.ks);
     if (e0 != PPST_OK) return e0;
+    for (int i = 1; i < a->ksplit; ++i)
+      if (k.ks.start[i] % 9) return PPST_EINVAL;           // whole chunks per block
   }
 #endif
   if (k.ks.S > 1) {

@@ -308,7 +308,7 @@ class ConvPlan:
     # changed), ~150 per D + G iteration: the tables are shared between plans of one geometry, only the weights are new.
     _GEOMETRY = {}
     _GEOM_ATTRS = ("kind", "cout", "cin", "k", "bn", "n_groups", "halo", "src", "max_chan", "wstrides", "nsteps", "flop_steps",
-                   "early_a", "ksplit_ok", "steps", "src_dev", "chunk_start", "chunks_per_group", "w4_shape", "max_chunk_steps",
+                   "early_a", "ksplit_ok", "chunk_starts0", "chunk_starts0_k64", "steps", "src_dev", "chunk_start", "chunks_per_group", "w4_shape", "max_chunk_steps",
                    "min_chunk_steps", "full_cover", "steps_dual", "src_dual", "steps_up9", "steps_k64", "src_k64", "steps_dual_k64",
                    "src_dual_k64")
 
@@ -528,6 +528,8 @@ class ConvPlan:
         enc = encode(steps)
         starts = [i for i, t in enumerate(steps) if t[3] == 1] + [len(steps)]
         lens = [b_ - a_ for a_, b_ in zip(starts[:-1], starts[1:])]
+        self.chunk_starts0 = [i for i in starts if i < ns_] + [ns_]          # chunk starts of ONE group (every group has the same)
+        self.chunk_starts0_k64 = None
         self.early_a = 1 if (min(lens) >= 2 and ns_ >= 3) else 0
         self.max_chunk_steps = max(lens)
         self.min_chunk_steps = min(lens)
@@ -563,6 +565,8 @@ class ConvPlan:
                 ci += 1 if f_ else 0
                 nxt = st[i + 1] if (i + 1) % per2 != 0 else None
                 enc2.append((c_, dy_, dx_, f_ | ((2 | (nxt[0] << 8)) if (nxt is not None and nxt[3]) else 0) | ((ci & 1) << 2)))
+            if ngroups == self.n_groups:
+                self.chunk_starts0_k64 = [i for i, t in enumerate(st[:per2]) if t[3]] + [per2]
             sr = torch.tensor([src_[i] for i in keep], dtype=torch.int32, device=dev)
             return (torch.tensor(enc2 + [(0, 0, 0, 0)] * 4, dtype=torch.int32, device=dev).contiguous(),
                     (sr[:, 0].contiguous(), sr[:, 1].contiguous(), sr[:, 2].contiguous()))
@@ -751,19 +755,21 @@ class ConvPlan:
 
     def _ksplit(self, variant, a, skip):
         """ppst_conv_args.ksplit of the launch described by ``a`` (0: none) -- ops.KSPLIT."""
-        if (skip or variant not in KSPLIT["variants"] or a.in_presplit or self.max_chunk_steps != self.min_chunk_steps
+        if (skip or variant not in KSPLIT["variants"] or a.in_presplit
                 or not (a.tile_rows == 16 or (variant == 0 and a.tile_rows == 8))):
-            return 0
-        chunk = self.max_chunk_steps            # steps per chunk of the launch's table (a K64 table keeps the taps of every second chunk)
+            return 0, None
+        cs = self.chunk_starts0_k64 if a.k64 else self.chunk_starts0       # chunk starts of one group of the launch's table
+        if cs is None or cs[-1] != a.nsteps:
+            return 0, None
         if a.dual_b or (variant == 2 and ((self.precision == 0) != (a.io_st == 0) or (a.k64 and not a.halo))):
-            return 0                    # (the N-256 kernel's K-split instances: fp32-class on fp32 tensors, single-pass on half-stored ones)
+            return 0, None              # (the N-256 kernel's K-split instances: fp32-class on fp32 tensors, single-pass on half-stored ones)
         n_tiles = -(-self.cout // a.bn)
         blocks = a.B * lib.ppst_conv_tiles(a.tile_h, a.tile_w, a.tile_rows) * a.n_groups * n_tiles
         # (the N-256 and Winograd kernels hold 128 accumulator registers per thread: S <= 4, include/ppst_hip.h)
         # -- and what the hand-over of 256 KB per block costs them (tests/conv_ksplit_time.py): the Winograd kernel gains from S = 2 with
         # >= 4 chunks left per block only, the N-256 kernel needs >= 32 steps left
         max_s, min_steps = {0: (8, KSPLIT["min_steps"]), 2: (4, 2 * KSPLIT["min_steps"]), 10: (2, 36)}[variant]
-        return _ksplit_choice(blocks, a.nsteps, chunk, KSPLIT["max_blocks"], min_steps, max_s)
+        return _ksplit_choice(blocks, cs, KSPLIT["max_blocks"], min_steps, max_s)
 
     def __call__(self, x, bias=None, noise=None, noise_weight=0.0, act=ACT_NONE, prelu=None, stats=False,
                  residual=None, out=None, out_scale=1.0, pad_mode=PAD_ZERO, out_hw=None, res_after_act=False,
@@ -873,7 +879,10 @@ class ConvPlan:
             a.in_presplit = 1
         # (batch-aware passes only: the split depends on the batch in the launch and changes the summation order -- a shard of an
         #  inference batch has to reproduce the whole batch bit for bit)
-        a.ksplit = self._ksplit(variant, a, self.precision == 2) if (KSPLIT["value"] and BATCH_AWARE["value"]) else 0
+        ks_S, ks_cuts = self._ksplit(variant, a, self.precision == 2) if (KSPLIT["value"] and BATCH_AWARE["value"]) else (0, None)
+        a.ksplit = ks_S
+        ks_arr = (ctypes.c_int32 * (ks_S + 1))(*ks_cuts) if ks_S else None         # (alive until the call returns)
+        a.ksplit_starts = ctypes.cast(ks_arr, ctypes.c_void_p) if ks_S else None
         if self.precision == 2:
             sn, sc, sy, sx = self.wstrides
             c_, ky_, kx_ = self.src_dev
@@ -886,17 +895,22 @@ class ConvPlan:
         return out
 
 
-def _ksplit_choice(blocks, nsteps, chunk_steps, max_blocks, min_steps, max_s=8):
-    """S of ppst_conv_args.ksplit for a launch of ``blocks`` blocks x ``nsteps`` steps in chunks of ``chunk_steps`` (0: none)."""
-    if chunk_steps <= 0 or nsteps % chunk_steps:
-        return 0
-    nchunks = nsteps // chunk_steps
+def _ksplit_choice(blocks, chunk_starts, max_blocks, min_steps, max_s=8):
+    """(S, starts) of ppst_conv_args.ksplit / ksplit_starts for a launch of ``blocks`` blocks over a table whose chunks open at
+    ``chunk_starts`` (ascending, from 0; the last entry = nsteps): the largest S of 8 / 4 / 2 that keeps S x blocks <= max_blocks with
+    every share -- cut at the chunk starts nearest to equal shares -- at least ``min_steps`` long.  (0, None): no split."""
+    nsteps = chunk_starts[-1]
     for S in (8, 4, 2):
-        if S > max_s:
+        if S > max_s or blocks * S > max_blocks or (S - 1) * blocks > 256 or len(chunk_starts) - 1 < S:
             continue
-        if nchunks % S == 0 and blocks * S <= max_blocks and nsteps // S >= min_steps and (S - 1) * blocks <= 256:
-            return S
-    return 0
+        cuts = [0]
+        for i in range(1, S):
+            t = i * nsteps / S
+            cuts.append(min(chunk_starts, key=lambda c: (abs(c - t), c)))
+        cuts.append(nsteps)
+        if all(b_ - a_ >= min_steps for a_, b_ in zip(cuts[:-1], cuts[1:])):
+            return S, cuts
+    return 0, None
 
 
 def repack_plans(plans):

@@ -21,9 +21,20 @@ if wino:
 dev = torch.device("cuda:0")
 dt = torch.bfloat16 if prec == "bf16" else torch.float32
 forced = {"S": 0}
-def _forced_choice(blocks, nsteps, chunk, mb, ms, max_s=8):
+_choice = ops._ksplit_choice
+
+
+def _forced_choice(blocks, chunk_starts, mb, ms, max_s=8):
     S = forced["S"]
-    return S if (S and S <= max_s and chunk > 0 and nsteps % chunk == 0 and (nsteps // chunk) % S == 0 and (S - 1) * blocks <= 256) else 0
+    if not S or S > max_s or (S - 1) * blocks > 256:
+        return 0, None
+    # the production cut rule, forced to this S: every share allowed, the block budget lifted
+    for cand in (S,):
+        nsteps = chunk_starts[-1]
+        cuts = [0] + [min(chunk_starts, key=lambda c: (abs(c - i * nsteps / cand), c)) for i in range(1, cand)] + [nsteps]
+        if all(b_ > a_ for a_, b_ in zip(cuts[:-1], cuts[1:])):
+            return cand, cuts
+    return 0, None
 
 
 ops._ksplit_choice = _forced_choice

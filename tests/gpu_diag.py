@@ -314,8 +314,23 @@ def t_conv_ksplit():
         ops.WINO.update(prevw)
         ops.WINO["ksplit_fill"] = 0
         # a launch that really splits (the choice is the host's: say so)
-        a_ = lambda B, H, Wd, co, bn, nst, ch: ops._ksplit_choice(B * ((H + 15) // 16) * ((Wd + 15) // 16) * -(-co // bn), nst, ch, 256, 16)
+        a_ = lambda B, H, Wd, co, bn, nst, ch: ops._ksplit_choice(B * ((H + 15) // 16) * ((Wd + 15) // 16) * -(-co // bn), list(range(0, nst + 1, ch)), 256, 16)[0]
         assert a_(2, 64, 64, 256, 128, 72, 9) == 4 and a_(4, 4, 4, 512, 128, 144, 9) == 8 and a_(8, 512, 512, 128, 128, 36, 9) == 0
+        # chunks of unequal length (the stride-2 conv on the space-to-depth tensor: 4 / 2 / 2 / 2 taps per phase): cuts at chunk starts
+        s2d_starts = [4 * i for i in range(16)] + [64 + 2 * i for i in range(48)] + [160]
+        S_, cuts_ = ops._ksplit_choice(4, s2d_starts, 256, 16)
+        assert S_ == 8 and cuts_ == [0, 20, 40, 60, 80, 100, 120, 140, 160] and all(c in s2d_starts for c in cuts_)
+        ws2 = torch.randn(512, 512, 3, 3) / 68.0
+        xs2 = torch.randn(4, 512, 16, 16)
+        kb = torch.tensor([1., 3., 3., 1.]); kb2 = kb[:, None] * kb[None, :]; kb2 = kb2 / kb2.sum()
+        xs2b, bhw2 = ops.blur_nhwc(g(nhwc(xs2)), g(kb2), 2, 2, ops.PAD_ZERO, s2d=True)        # as ConvLayer(downsample=True): 17 x 17 blurred
+        ps2 = ops.ConvPlan(g(ws2), "s2d")
+        outs2 = {}
+        for on in (False, True):
+            ops.KSPLIT["value"] = on
+            outs2[on] = ps2(xs2b, out_hw=((bhw2[0] - 3) // 2 + 1, (bhw2[1] - 3) // 2 + 1)).cpu()
+        report("ksplit s2d 512->512 (unequal chunks) vs float64", nchw(outs2[True]), F.conv2d(O.upfirdn2d(xs2, kb2, pad=(2, 2)).double(), ws2.double(), stride=2), 3e-5)
+        report("ksplit s2d 512->512 vs unsplit", outs2[True], outs2[False], 3e-6)
         B, ci, co, H, Wd = 2, 256, 256, 32, 32
         x = torch.randn(B, ci, H, Wd); w = torch.randn(co, ci, 3, 3) / 48.0
         bias = torch.randn(co); res = torch.randn(B, co, H, Wd); a1 = torch.tensor([0.25])
