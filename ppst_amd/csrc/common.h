@@ -97,6 +97,14 @@ __device__ __forceinline__ f32x4 ks_vld(const float* p) {
 #define KS_SCATTER(ACC, I_, J_, NTHR_, DST)                                                            \
   _Pragma("unroll") for (int i_ = 0; i_ < (I_); ++i_)                                                 \
     _Pragma("unroll") for (int j_ = 0; j_ < (J_); ++j_) ks_vst<NTHR_>((DST) + (i_ * (J_) + j_) * 4 * (NTHR_), ACC[i_][j_]);
+// steps [s0, s1) of block row y (a compare chain over constant indices: indexing the kernel-argument array with y made hipcc copy the
+// whole argument structure to scratch memory)
+__device__ __forceinline__ void ks_range(const KSplitDev& k, int y, int& s0, int& s1) {
+  s0 = 0; s1 = k.start[1];
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (y == i) { s0 = k.start[i]; s1 = k.start[i + 1]; }
+}
 __device__ __forceinline__ void ks_publish(const KSplitDev& k, int tile, int y, int tid) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores are acknowledged
   __syncthreads();

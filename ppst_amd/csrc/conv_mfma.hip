@@ -165,12 +165,12 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   // is never stored (drained by the last step's vmcnt(0))
   int nst = a.nsteps;
   if (a.ks.S > 1) {
-    const int s0 = a.ks.start[blockIdx.y];
+    int s0, s1;
+    ks_range(a.ks, (int)blockIdx.y, s0, s1);
     steps += s0;
     wblob += (int64_t)s0 * BBUF;
-    nst = a.ks.start[blockIdx.y + 1] - s0;
+    nst = s1 - s0;
   }
-
   constexpr int A_WCH = (HP + 7) / 8;                      // wave-chunks of 8 pixels x 8 float4
   constexpr int A_IT2 = (A_WCH * 64 + NT - 1) / NT;
   float4 ra[A_IT2];
@@ -348,6 +348,21 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   // step descriptors live in scalars (cur = 0, next = 1); the descriptor of step s+2 is
   // loaded one step before it is needed (its scalar-load latency would otherwise sit
   // between the barrier and the first instruction of every step)
+  // Split launches are small grids whose every block streams weight blobs nobody has touched since the last optimizer step: the
+  // chain of steps then runs at memory latency (two blobs in flight), ~0.35 us per step slower than on hot weights (rocprofv3 of the
+  // train step against tests/conv_ksplit_time.py).  The block requests its whole share up front -- one 128-byte line per thread and
+  // round, results unused -- so the blobs are in this XCD's L2 when the DMA asks for them.  The requests retire with the prologue's
+  // own vmcnt(0) (the same memory round trip), before the accumulators are live: no register of the loop is theirs.
+  constexpr int PF_ROUNDS = 6;
+  float pf[PF_ROUNDS];
+  if (a.ks.S > 1) {
+    const int pf_bytes = nst * BBUF;
+#pragma unroll
+    for (int r = 0; r < PF_ROUNDS; ++r) {
+      const int o = (r * NT + tid) * 128;
+      pf[r] = o < pf_bytes ? *(const volatile float*)(wblob + o) : 0.f;
+    }
+  }
   int4 d = steps[0];
   int dy0 = d.y, dx0 = d.z, sl0 = 0;
   int dy1 = d.y, dx1 = d.z, sl1 = 0;
@@ -369,6 +384,10 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   int4 dE = d, dO = d;                       // descriptor of step s+2, alternating register sets
   if (nst > 2) dE = steps[2];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA of steps 0/1 (see the note at the loop barrier)
+  if (a.ks.S > 1) {
+#pragma unroll
+    for (int r = 0; r < PF_ROUNDS; ++r) asm volatile("" ::"v"(pf[r]));
+  }
   __syncthreads();
 
   bf16x8 b0h[4], b0l[4], b1h[4], b1l[4];

@@ -162,10 +162,11 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   // registers, which the plain instances, the swap path's, must not pay): this block's share of the table (conv_mfma.hip)
   int nst = a.nsteps;
   if (KS && a.ks.S > 1) {
-    const int s0 = a.ks.start[blockIdx.y];
+    int s0, s1;
+    ks_range(a.ks, (int)blockIdx.y, s0, s1);
     steps += s0;
     wblob += (int64_t)s0 * BBUF;
-    nst = a.ks.start[blockIdx.y + 1] - s0;
+    nst = s1 - s0;
   }
 
   // ---- A staging (as conv_mfma.hip: one wave-instruction = 8 pixels x 128 B; fp32 -> bf16 hi/lo planes)
@@ -291,6 +292,19 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // K-split instances: the block's share of the weight blobs requested up front, one 128-byte line per thread and round, so that the
+  // chain of steps finds them in this XCD's L2 instead of running at memory latency (conv_mfma.hip; the requests retire with the
+  // prologue's vmcnt(0), before the accumulators are live)
+  constexpr int PF_ROUNDS = KS ? 12 : 1;
+  float pf[PF_ROUNDS];
+  if (KS && a.ks.S > 1) {
+    const int pf_bytes = nst * BBUF;
+#pragma unroll
+    for (int r = 0; r < PF_ROUNDS; ++r) {
+      const int o = (r * (64 * WNW * WMW) + tid) * 128;
+      pf[r] = o < pf_bytes ? *(const volatile float*)(wblob + o) : 0.f;
+    }
+  }
   // ---- prologue: steps 0 and 1 staged, descriptors of step 2 fetched
   int4 d = steps[0];
   int dy0 = d.y, dx0 = DXW(d.z), sl0 = 0;
@@ -310,6 +324,10 @@ __global__ __launch_bounds__(64 * WNW * WMW, WNW * WMW == 12 ? 3 : ((WNW * WMW =
   int4 dE = d, dO = d;
   if (nst > 2) dE = steps[2];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (KS && a.ks.S > 1) {
+#pragma unroll
+    for (int r = 0; r < PF_ROUNDS; ++r) asm volatile("" ::"v"(pf[r]));
+  }
   __syncthreads();
 
   bf16x8 b0h[NT], b0l[NT], b1h[BDB ? NT : 1], b1l[BDB ? NT : 1];

@@ -155,8 +155,10 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 1 : 2) void conv_wino_kernel
   // across-block K split (ppst_conv_args.ksplit, conv_mfma.hip): this block's chunks; its weight stream starts 3 c0 steps in
   int nchunk = a.nchunk, c0 = 0;
   if (KS && !FAT && a.ks.S > 1) {      // (instances of their own: the plain ones -- the swap path's -- keep their register allocation)
-    c0 = a.ks.start[blockIdx.y] / 9;
-    nchunk = a.ks.start[blockIdx.y + 1] / 9 - c0;
+    int s0, s1;
+    ks_range(a.ks, (int)blockIdx.y, s0, s1);
+    c0 = s0 / 9;
+    nchunk = s1 / 9 - c0;
     steps += c0 * 9;
   }
   const int nsteps = nchunk * 3;

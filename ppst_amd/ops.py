@@ -714,7 +714,10 @@ class ConvPlan:
         aware = BATCH_AWARE["value"] and B is not None and not single and self.bn == 128 and self.early_a and self.halo == 1
         if aware and n256_ok and tiles16 * (self.cout // 256) * B < BATCH_AWARE["fill"]:
             n256_ok = False                              # under-filled: the tile kernel has twice the N tiles
-        small = aware and tiles16 * ((self.cout + 127) // 128) * B < BATCH_AWARE["fill"]
+        # (with the across-block K split on, an under-filled launch keeps its 16-row tiles and splits K instead: 256 -> 256 @64^2 x 2
+        #  38 us with S = 4 against 69 us on 8-row tiles with S = 2)
+        small = (aware and tiles16 * ((self.cout + 127) // 128) * B < BATCH_AWARE["fill"]
+                 and not (KSPLIT["value"] and 0 in KSPLIT["variants"]))
         if cv == 1 and not single and self.early_a and self.cout >= 128:
             variant, bn = 1, (256 if n256_ok else 128)
         elif cv in (2, 3) and self.early_a:
@@ -767,8 +770,8 @@ class ConvPlan:
         blocks = a.B * lib.ppst_conv_tiles(a.tile_h, a.tile_w, a.tile_rows) * a.n_groups * n_tiles
         # (the N-256 and Winograd kernels hold 128 accumulator registers per thread: S <= 4, include/ppst_hip.h)
         # -- and what the hand-over of 256 KB per block costs them (tests/conv_ksplit_time.py): the Winograd kernel gains from S = 2 with
-        # >= 4 chunks left per block only, the N-256 kernel needs >= 32 steps left
-        max_s, min_steps = {0: (8, KSPLIT["min_steps"]), 2: (4, 2 * KSPLIT["min_steps"]), 10: (2, 36)}[variant]
+        # >= 4 chunks left per block only, the N-256 kernel needs >= 24 steps left
+        max_s, min_steps = {0: (8, KSPLIT["min_steps"]), 2: (4, 24), 10: (2, 36)}[variant]
         return _ksplit_choice(blocks, cs, KSPLIT["max_blocks"], min_steps, max_s)
 
     def __call__(self, x, bias=None, noise=None, noise_weight=0.0, act=ACT_NONE, prelu=None, stats=False,
