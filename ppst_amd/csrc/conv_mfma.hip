@@ -47,6 +47,7 @@ struct ConvKArgs {
   int early_a;              // step table guarantees chunks of >= 2 steps: a chunk's global loads go out one step early
   unsigned long long* dbg;  // stamp build: [block][wave][8] cycle sums (else unused)
   KSplitDev ks;             // ks.S > 1: grid row y runs steps [ks.start[y], ks.start[y + 1]) of every group (common.h)
+  int prefetch_w;           // small grid (<= 512 blocks): a block requests its weight blobs up front (see the kernel's prologue)
 };
 // (the storage type of x / residual / y -- ppst_conv_args.io_st, single-pass precision modes only -- is a template parameter IOS of
 // the kernels, not a field: the pointers above are then half / bfloat16 tensors behind their `float*` type)
@@ -348,14 +349,14 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   // step descriptors live in scalars (cur = 0, next = 1); the descriptor of step s+2 is
   // loaded one step before it is needed (its scalar-load latency would otherwise sit
   // between the barrier and the first instruction of every step)
-  // Split launches are small grids whose every block streams weight blobs nobody has touched since the last optimizer step: the
+  // Small grids (<= 512 blocks, split or not): every block streams weight blobs nobody has touched since the last optimizer step: the
   // chain of steps then runs at memory latency (two blobs in flight), ~0.35 us per step slower than on hot weights (rocprofv3 of the
   // train step against tests/conv_ksplit_time.py).  The block requests its whole share up front -- one 128-byte line per thread and
   // round, results unused -- so the blobs are in this XCD's L2 when the DMA asks for them.  The requests retire with the prologue's
   // own vmcnt(0) (the same memory round trip), before the accumulators are live: no register of the loop is theirs.
   constexpr int PF_ROUNDS = 6;
   float pf[PF_ROUNDS];
-  if (a.ks.S > 1) {
+  if (a.prefetch_w) {
     const int pf_bytes = nst * BBUF;
 #pragma unroll
     for (int r = 0; r < PF_ROUNDS; ++r) {
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(64 * WM * WN, NAS ? 2 : 1) void conv_mfma_kernel(Co
   int4 dE = d, dO = d;                       // descriptor of step s+2, alternating register sets
   if (nst > 2) dE = steps[2];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA of steps 0/1 (see the note at the loop barrier)
-  if (a.ks.S > 1) {
+  if (a.prefetch_w) {
 #pragma unroll
     for (int r = 0; r < PF_ROUNDS; ++r) asm volatile("" ::"v"(pf[r]));
   }
@@ -1261,6 +1262,7 @@ extern "C" int ppst_conv2d_mfma(const ppst_conv_args* a, void* stream) {
       if (e0 != PPST_OK) return e0;
     } else if (a->variant != 2 && a->variant != 10) return PPST_EINVAL;
   }
+  k.prefetch_w = (int64_t)blocks * k.ks.S <= 512 ? 1 : 0;
   int slot = -1;
   if (g_prof_on) {
     // info[7]: bits 0-11 the N tile, 12-19 the kernel variant that runs the launch, 20 k64, 24-27 the precision mode (bench.py derives

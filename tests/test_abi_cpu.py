@@ -393,12 +393,30 @@ def _direct_kernel_table(ops, plan, ck):
     for B in (1, 2, 16):
         assert plan("conv", 256, 256, 3, 72, 1).choose_kernel(64, 64, 64, 64, 64, 64, 1, B) == (0, 128, 16)
         assert plan("conv", 512, 512, 3, 144, 1).choose_kernel(64, 64, 64, 64, 64, 64, 1, B) == (2, 256, 16)
-    # ... inside it an under-filled launch takes twice the N tiles (tile kernel instead of N-256) and twice the M tiles (8 rows)
-    with ops.batch_aware():
-        assert plan("conv", 256, 256, 3, 72, 1).choose_kernel(64, 64, 64, 64, 64, 64, 1, 2) == (0, 128, 8)
-        assert plan("conv", 512, 512, 3, 144, 1).choose_kernel(64, 64, 64, 64, 64, 64, 1, 2) == (0, 128, 8)
-        assert plan("conv", 512, 512, 3, 144, 1).choose_kernel(64, 64, 64, 64, 64, 64, 1, 16) == (2, 256, 16)
-        assert plan("conv", 128, 128, 3, 36, 1).choose_kernel(512, 512, 512, 512, 512, 512, 1, 2) == (0, 128, 16)
+    # ... inside it an under-filled launch takes twice the N tiles (tile kernel instead of N-256) and -- round 5 -- keeps its 16-row
+    # tiles: the launch splits K across blocks instead (ops.KSPLIT, ppst_conv_args.ksplit); with the split off, twice the M tiles (8 rows)
+    prev_ks = ops.KSPLIT["value"]
+    try:
+        with ops.batch_aware():
+            ops.KSPLIT["value"] = True
+            assert plan("conv", 256, 256, 3, 72, 1).choose_kernel(64, 64, 64, 64, 64, 64, 1, 2) == (0, 128, 16)
+            assert plan("conv", 512, 512, 3, 144, 1).choose_kernel(64, 64, 64, 64, 64, 64, 1, 2) == (0, 128, 16)
+            ops.KSPLIT["value"] = False
+            assert plan("conv", 256, 256, 3, 72, 1).choose_kernel(64, 64, 64, 64, 64, 64, 1, 2) == (0, 128, 8)
+            assert plan("conv", 512, 512, 3, 144, 1).choose_kernel(64, 64, 64, 64, 64, 64, 1, 2) == (0, 128, 8)
+            assert plan("conv", 512, 512, 3, 144, 1).choose_kernel(64, 64, 64, 64, 64, 64, 1, 16) == (2, 256, 16)
+            assert plan("conv", 128, 128, 3, 36, 1).choose_kernel(512, 512, 512, 512, 512, 512, 1, 2) == (0, 128, 16)
+    finally:
+        ops.KSPLIT["value"] = prev_ks
+    # the split itself: the largest S of 8 / 4 / 2 that fills at most 256 blocks, cut at chunk starts, >= min_steps per share
+    assert ops._ksplit_choice(64, list(range(0, 73, 9)), 256, 16) == (4, [0, 18, 36, 54, 72])
+    assert ops._ksplit_choice(4, list(range(0, 145, 9)), 256, 16) == (8, [0, 18, 36, 54, 72, 90, 108, 126, 144])
+    assert ops._ksplit_choice(4, list(range(0, 145, 9)), 256, 16, 4) == (4, [0, 36, 72, 108, 144])
+    assert ops._ksplit_choice(256, list(range(0, 73, 9)), 256, 16) == (0, None)          # a full grid is left alone
+    assert ops._ksplit_choice(64, [0, 9, 18], 256, 16) == (0, None)                      # 9 steps per share: too short
+    s2d = [4 * i for i in range(16)] + [64 + 2 * i for i in range(48)] + [160]           # unequal chunks: 4 / 2 / 2 / 2 taps per phase
+    S_, cuts_ = ops._ksplit_choice(4, s2d, 256, 16)
+    assert S_ == 8 and cuts_ == [0, 20, 40, 60, 80, 100, 120, 140, 160] and all(c in s2d for c in cuts_)
     assert not ops.BATCH_AWARE["value"]
     # single-pass modes: the N-256 and streaming kernels are built for them, the experiments are not
     assert ck(plan("conv", 256, 256, 3, 72, 1, precision=3), 256) == (2, 256, 16)
