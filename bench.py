@@ -398,6 +398,7 @@ def bench_train(args, rank, world, dev, barrier, max_over_ranks):
     ops.prof_collect()
     ops.prof_enable(False)
     assert all(v == v for v in list(dl.values()) + list(gl.values())), "NaN loss"
+    assert ops.ksplit_check(), "a K-split conv launch gave up waiting for its partner blocks (ppst_conv_ksplit_check)"
     # one R1 pass alone (zero_grad -> compute_R1_loss -> x16 -> backward -> Adam on D), warmed up once
     r1_ms = None
     if opt.dis is not None and float(getattr(model.opt, "lambda_R1", 10.0)) > 0.0:

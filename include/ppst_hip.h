@@ -317,7 +317,7 @@ typedef struct ppst_conv_args {
                                     64^2 ... 4^2 layers of a train step at batch 2: 4-128 blocks, 72-160 steps): S x the blocks,
                                     1 / S of the chain.  Results equal the unsplit launch's up to fp32 summation order.  At most
                                     256 (S - 1) x tiles per launch; launches that use it are serialised per stream by the library
-                                    (one scratch buffer per stream, four streams). */
+                                    (one scratch buffer per stream that uses it, sixteen (device, stream) pairs per process). */
   const int32_t* ksplit_starts;  /* HOST pointer to ksplit + 1 ascending step indices, starts[0] = 0, starts[ksplit] = nsteps, every one of
                                     them a step that opens a chunk (the caller's promise): block row i runs steps
                                     [starts[i], starts[i + 1]) -- tables whose chunks differ in length (the stride-2 conv on a

@@ -1086,9 +1086,9 @@ extern "C" int ppst_has_experiments(void) {
 
 // ---- state of the across-block K split (common.h): one scratch + flag buffer per (device, stream) that has used it -- launches on one
 // stream are ordered, so a buffer is never shared by two launches in flight; the epoch makes a flag of an earlier launch stale
-// without a fill between launches.  Allocated at first use (64 MB + 16 KB), never freed.
+// without a fill between launches.  Allocated at first use (64 MB + 16 KB per pair), never freed.
 struct KsState { int dev; hipStream_t st; float* scratch; unsigned* flags; unsigned epoch; };
-static KsState g_ks[4];
+static KsState g_ks[16];
 static int g_ks_n = 0;
 int ppst_ksplit_prepare_(int S, const int32_t* starts, int64_t tiles, int nsteps, int acc_regs, int threads, hipStream_t st, KSplitDev* out) {
   if ((S != 2 && S != 4 && S != 8) || (!starts && nsteps % S) || tiles <= 0 || acc_regs <= 0 || acc_regs % 4 || threads <= 0) return PPST_EINVAL;
@@ -1105,7 +1105,7 @@ int ppst_ksplit_prepare_(int S, const int32_t* starts, int64_t tiles, int nsteps
   for (int i = 0; i < g_ks_n; ++i)
     if (g_ks[i].dev == dev && g_ks[i].st == st) e = &g_ks[i];
   if (!e) {
-    if (g_ks_n == 4) return PPST_EINVAL;
+    if (g_ks_n == 16) return PPST_EINVAL;           // (sixteen (device, stream) pairs per process)
     KsState n;
     n.dev = dev; n.st = st; n.epoch = 0; n.scratch = nullptr; n.flags = nullptr;
     if (hipMalloc((void**)&n.scratch, KS_SCRATCH_BYTES) != hipSuccess) return (int)hipGetLastError();

@@ -12,6 +12,7 @@
 //   * generic: any up/down/minor, one output per thread (modes 3-6 of the reference
 //     dispatcher, never hit on the PPST path).
 #include "common.h"
+#include <stdlib.h>
 
 #define UF_MAXK 8
 
@@ -432,7 +433,11 @@ extern "C" int ppst_blur_nhwc_st(const void* x, const void* k, void* y, int B, i
   if (p.out_h <= 0 || p.out_w <= 0) return PPST_EINVAL;
   if (B == 0) return PPST_OK;
   // half tensors: 8 channels per thread when every item is 16-byte addressable
-  const bool c8 = st != PPST_ST_F32 && C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) % 16) == 0;
+  // (3 x 3 taps only: the 4 x 4 kernel with 8-channel items needs > 256 registers -- ONE wave per SIMD -- and the bf16 blurs of the
+  //  train step's discriminator ran at half the speed of their fp32 twins on tensors half the size, 66 against 36 us per launch;
+  //  PPST_UF_C8_4X4=1 restores that form for A/B)
+  static const bool c8_4x4 = getenv("PPST_UF_C8_4X4") != nullptr;
+  const bool c8 = st != PPST_ST_F32 && C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) % 16) == 0 && (ksize == 3 || c8_4x4);
   if (st != PPST_ST_F32 && (((uintptr_t)x | (uintptr_t)y) % 8)) return PPST_EINVAL;
 #define UF_GO(K_)                                                                                             \
   do {                                                                                                        \

@@ -898,6 +898,12 @@ class ConvPlan:
         return out
 
 
+def ksplit_check():
+    """ppst_conv_ksplit_check on the current stream: True if every flag wait of the K-split launches so far ended on its flag (or none
+    ran), False if a block gave up (that launch's output is wrong).  Synchronises the stream."""
+    return lib.ppst_conv_ksplit_check(_stream()) <= 0
+
+
 def _ksplit_choice(blocks, chunk_starts, max_blocks, min_steps, max_s=8):
     """(S, starts) of ppst_conv_args.ksplit / ksplit_starts for a launch of ``blocks`` blocks over a table whose chunks open at
     ``chunk_starts`` (ascending, from 0; the last entry = nsteps): the largest S of 8 / 4 / 2 that keeps S x blocks <= max_blocks with

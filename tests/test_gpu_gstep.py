@@ -218,6 +218,9 @@ def test_generator_adam_step_and_alternation():
         live = g.abs() > 1e-12
         assert float((f.flat.cpu().double() - ref)[live].abs().max()) < 2e-6, k
         assert f.step_count == 1
+    # the step's small-grid conv launches split K across blocks (ops.KSPLIT, round 5): they ran, and none gave up on its partner blocks
+    from ppst_amd import ops
+    assert ops.KSPLIT["value"] and ops.lib.ppst_conv_ksplit_check(ops._stream()) == 0
 
 
 def test_training_loop_runs_saves_and_resumes(tmp_path):
