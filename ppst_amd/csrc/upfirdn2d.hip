@@ -218,6 +218,156 @@ __global__ __launch_bounds__(256) void upfirdn2d_chan(const void* __restrict__ x
   }
 }
 
+// ---- sliding form of upfirdn2d_chan for DOWN == 1 (round 5: the 4 x 4 blur of the train step's discriminator) ------------------
+// upfirdn2d_chan re-requests a (PY - 1 + KH) x (PX - 1 + KW) patch per PX x PY outputs: 49 requests per 16 outputs with 4 x 4 taps --
+// and it is bound by those requests, not by bytes (a bf16 tensor half the size ran SLOWER than its fp32 twin).  Here a thread owns a
+// column strip of PX outputs and walks UF_SLIDE rows down it: every input row is requested ONCE per strip (PX - 1 + KW items) and
+// feeds the KH output rows it belongs to, kept in a ring of KH accumulator rows (static slots: the row loop is unrolled by KH).  An
+// output element receives its taps in the same order as in upfirdn2d_chan (patch rows ascending, columns ascending, one fma each):
+// bit-identical results.  Same block order (XCD bands), padding modes, normalise-on-load and space-to-depth output.
+#ifndef UF_SLIDE
+#define UF_SLIDE 16
+#endif
+template <int KH, int KW, bool S2D, int ST = PPST_ST_F32, int CV = 4>
+__global__ __launch_bounds__(256) void upfirdn2d_slide(const void* __restrict__ x, void* __restrict__ y, UfParams p, unsigned nwork,
+                                                       FastDiv d_c, FastDiv d_xs, FastDiv d_oh) {
+  constexpr int PX = 4, NQ = CV / 4, NJ = PX - 1 + KW, NR = UF_SLIDE + KH - 1;
+  const int cvn = p.minor / CV;
+  float kf[KH * KW];
+#pragma unroll
+  for (int i = 0; i < KH * KW; ++i) kf[i] = p.k[KH * KW - 1 - i];
+  const int ew = S2D ? ((p.out_w + 1) & ~1) : p.out_w;
+  const int oh2 = (p.out_h + 1) >> 1, ow2 = (p.out_w + 1) >> 1;
+  const int eh = S2D ? 2 * oh2 : p.out_h;
+  const unsigned nblk = (nwork + 255u) >> 8, per = (nblk + 7u) >> 3;
+  auto ldv = [&](float4 (&v)[NQ], int64_t item) {
+    if (CV == 8) st_ld8<ST>(x, item * 8, v[0], v[NQ - 1]);
+    else v[0] = st_ld4<ST>(x, item * 4);
+  };
+  auto stv = [&](int64_t item, const float4 (&v)[NQ]) {
+    if (CV == 8) st_st8<ST>(y, item * 8, v[0], v[NQ - 1]);
+    else st_st4<ST>(y, item * 4, v[0]);
+  };
+  for (unsigned v = blockIdx.x; v < per * 8u; v += gridDim.x) {
+    const unsigned wblk = (v & 7u) * per + (v >> 3);
+    const uint64_t t64 = (uint64_t)wblk * 256 + threadIdx.x;
+    if (wblk >= nblk || t64 >= nwork) continue;
+    unsigned cqu, sxu, bandu;
+    unsigned r = fd_divmod((unsigned)t64, d_c, cqu);
+    r = fd_divmod(r, d_xs, sxu);
+    const int m = (int)fd_divmod(r, d_oh, bandu);   // d_oh divides by the number of UF_SLIDE-row bands
+    const int cq = (int)cqu, oy0 = (int)bandu * UF_SLIDE, ox0 = (int)sxu * PX;
+    float4 acc[KH][PX][NQ];
+#pragma unroll
+    for (int j = 0; j < KH; ++j)
+#pragma unroll
+      for (int i = 0; i < PX; ++i)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[j][i][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sa[NQ], sb[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { sa[q] = make_float4(1.f, 1.f, 1.f, 1.f); sb[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    if (p.in_ss) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const float4* qp = (const float4*)(p.in_ss + ((int64_t)m * p.minor + cq * CV + q * 4) * 2);
+        float4 q0 = qp[0], q1 = qp[1];
+        sa[q] = make_float4(q0.x, q0.z, q1.x, q1.z); sb[q] = make_float4(q0.y, q0.w, q1.y, q1.w);
+      }
+    }
+    // the column offsets of the strip's NJ items are the same in every row
+    int colo[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      int ix = ox0 + j - p.pad_x0;
+      if (p.pad_mode == PPST_PAD_REFLECT) ix = uf_reflect(ix, p.in_w);
+      colo[j] = (ix >= 0 && ix < p.in_w) ? ix * cvn : -1;
+    }
+    float4 zero[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) zero[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r0 = 0; r0 < NR; r0 += KH) {
+#pragma unroll
+      for (int rr = 0; rr < KH; ++rr) {
+        const int ry = r0 + rr;
+        if (ry >= NR) continue;
+        int iy = oy0 + ry - p.pad_y0;
+        if (p.pad_mode == PPST_PAD_REFLECT) iy = uf_reflect(iy, p.in_h);
+        const bool yok = iy >= 0 && iy < p.in_h;
+        const int64_t row = ((int64_t)m * p.in_h + (yok ? iy : 0)) * p.in_w * cvn + cq;
+        float4 vv[NJ][NQ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) vv[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (yok && colo[j] >= 0) {
+            ldv(vv[j], row + colo[j]);
+            if (p.in_ss) {  // normalise on load; zero padding stays zero (it pads the normalised tensor)
+#pragma unroll
+              for (int q = 0; q < NQ; ++q) {
+                float4& t = vv[j][q];
+                t.x = sa[q].x * t.x + sb[q].x; t.y = sa[q].y * t.y + sb[q].y; t.z = sa[q].z * t.z + sb[q].z; t.w = sa[q].w * t.w + sb[q].w;
+                if (p.in_act == PPST_ACT_LRELU) {
+                  t.x = (t.x > 0.f ? t.x : t.x * 0.2f) * 1.41421356237309515f; t.y = (t.y > 0.f ? t.y : t.y * 0.2f) * 1.41421356237309515f;
+                  t.z = (t.z > 0.f ? t.z : t.z * 0.2f) * 1.41421356237309515f; t.w = (t.w > 0.f ? t.w : t.w * 0.2f) * 1.41421356237309515f;
+                }
+              }
+            }
+          }
+        }
+        // this input row is tap row ky of output row py = ry - ky (ring slot (rr - ky) mod KH: r0 is a multiple of KH)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int ky = 0; ky < KH; ++ky) {
+            const int py = ry - ky;
+            if (py < 0 || py >= UF_SLIDE) continue;
+            constexpr int KHc = KH;
+            const int slot = (rr - ky + KHc) % KHc;
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+              const int kx = j - i;
+              if (kx >= 0 && kx < KW) {
+                const float f = kf[ky * KW + kx];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                  acc[slot][i][q].x += vv[j][q].x * f; acc[slot][i][q].y += vv[j][q].y * f;
+                  acc[slot][i][q].z += vv[j][q].z * f; acc[slot][i][q].w += vv[j][q].w * f;
+                }
+              }
+            }
+          }
+        // output row ry - (KH - 1) has all its tap rows: store it, free its slot
+        if (ry >= KH - 1) {
+          const int slot = (rr + 1) % KH;
+          const int oy = oy0 + ry - (KH - 1);
+          const bool row_ok = oy < p.out_h;
+          if (S2D) {
+            if (oy < eh) {
+#pragma unroll
+              for (int i = 0; i < PX; ++i) {
+                const int ox = ox0 + i;
+                if (ox < ew)
+                  stv(((((int64_t)m * oh2 + (oy >> 1)) * ow2 + (ox >> 1)) * 4 + (oy & 1) * 2 + (ox & 1)) * cvn + cq,
+                      (row_ok && ox < p.out_w) ? acc[slot][i] : zero);
+              }
+            }
+          } else if (row_ok) {
+            const int64_t orow = ((int64_t)m * p.out_h + oy) * p.out_w * cvn + cq;
+#pragma unroll
+            for (int i = 0; i < PX; ++i)
+              if (ox0 + i < p.out_w) stv(orow + (int64_t)(ox0 + i) * cvn, acc[slot][i]);
+          }
+#pragma unroll
+          for (int i = 0; i < PX; ++i)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[slot][i][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+  }
+}
+
 // ---- generic ---------------------------------------------------------------
 template <int ST = PPST_ST_F32>
 __global__ __launch_bounds__(256) void upfirdn2d_generic(const void* __restrict__ x, void* __restrict__ y, UfParams p, int64_t n) {
@@ -307,6 +457,22 @@ __global__ __launch_bounds__(256) void upfirdn2d_up2_chan(const void* __restrict
 template <int KH, int KW, int ST = PPST_ST_F32, int CV = 4>
 static int launch_chan(const void* x, void* y, const UfParams& p, int down, bool s2d, hipStream_t st) {
   const int eh = s2d ? ((p.out_h + 1) & ~1) : p.out_h, ew = s2d ? ((p.out_w + 1) & ~1) : p.out_w;
+  static const bool no_slide = getenv("PPST_UF_NO_SLIDE") != nullptr;      // (A/B: the patch form for the 4 x 4 taps too)
+  // 4 x 4 taps on half tensors of >= 192 rows: the sliding form (bit-identical, fewer requests per output).  Measured
+  // (tests/blur_time.py, 4 images, us: patch form -> sliding form): bf16 512^2 x 64 158 -> 125, 256^2 x 128 88 -> 65, but 128^2 x 256
+  // 52 -> 60 and 64^2 x 512 32 -> 47 (a band of 16 rows per thread leaves too few threads), and fp32 116 -> 128 / 52 -> 65: the fp32
+  // patch form already moves its bytes at the HBM rate (4.6 TB/s) with all 49 requests of a thread in flight
+  if (KH * KW >= 16 && down == 1 && !no_slide && ST != PPST_ST_F32 && eh >= 192) {
+    const int bands = cdiv(eh, UF_SLIDE);
+    const int64_t nwork = (int64_t)p.major * bands * cdiv(ew, 4) * (p.minor / CV);
+    if (nwork > PPST_IDX32_MAX) return PPST_EINVAL;
+    int64_t blocks = cdiv64(cdiv64(nwork, 256), 8) * 8;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const FastDiv d_c = make_fastdiv(p.minor / CV), d_xs = make_fastdiv(cdiv(ew, 4)), d_oh = make_fastdiv(bands);
+    if (s2d) PPST_LAUNCH((upfirdn2d_slide<KH, KW, true, ST, CV>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, p, (unsigned)nwork, d_c, d_xs, d_oh);
+    else PPST_LAUNCH((upfirdn2d_slide<KH, KW, false, ST, CV>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, p, (unsigned)nwork, d_c, d_xs, d_oh);
+    return PPST_LAUNCH_CHECK();
+  }
   const int upy = CV == 8 ? UF_PY / 2 : UF_PY;
   const int rows = down == 1 ? cdiv(eh, upy) : eh;   // row groups: PY output rows per thread when down == 1
   int64_t nwork = (int64_t)p.major * rows * cdiv(ew, 4) * (p.minor / CV);
