@@ -577,7 +577,8 @@ class GeneratorTrainer:
             # have to be issued in the same order everywhere.  One small all_gather, once (and after relearn_overlap()).
             keys = list(self.fp)
             mine = torch.tensor([counts[k] for k in keys], dtype=torch.int64, device=self.fp[keys[0]].grad.device)
-            got = [torch.empty_like(mine) for _ in range(self.world)]
+            # (the communicator's size, not self.world: the one-GPU rehearsal of bench.py tells the optimizer world = 2 on a 1-rank group)
+            got = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
             dist.all_gather(got, mine)
             if any(not torch.equal(g_, got[0]) for g_ in got):
                 raise RuntimeError("gradient contribution counts differ between ranks (%s per rank for %s): the overlapped "
