@@ -188,6 +188,15 @@ int ppst_upscale_weight_batch(const void* jobs, int njobs, int total_blocks, voi
 /* EqualizedConv2d fused-upscale weight (stylegan2_layers.py:314-319):
  * w (Cout,Cin,3,3)*scale -> out (Cin,Cout,4,4), the F.conv_transpose2d operand */
 int ppst_upscale_weight(const void* w, void* out, int cout, int cin, float scale, void* stream);
+/* Round 5: the input gradient of the stride-2 3x3 conv (stylegan2_layers.py:497-555, ConvLayer(downsample=True)) as ONE stride-1 conv
+ * with 2 x 2 taps whose 4 x cin output channels stack the four output phases -- out (4*cin, cout, 2, 2) from the forward weight w
+ * (cout, cin, 3, 3): out[(py*2+px)*cin + n][c][ty][tx] = w[c][n][ky][kx], a phase p using tap offset 0 with k = (p == 0 ? 0 : 1) and
+ * offset 1 (one position back) with k = 2 when p == 0; zero elsewhere.  The stacked output goes through ppst_depth_to_space_st.  For
+ * thin layers (cin 32 / 64) the four-group scattered form ran 2 312-5 780 four-wave blocks that each staged the same tile. */
+int ppst_dgrad_s2d_stack_weight(const void* w, void* out, int cout, int cin, void* stream);
+/* x [B][th][tw][4 C] (channel block py*2+px = output phase) -> y [B][oh][ow][C], y[b][2q+py][2p+px][c] = x[b][q][p][(py*2+px)*C + c];
+ * oh <= 2 th, ow <= 2 tw; st = PPST_ST_* of both tensors (C % 4 == 0 fp32, % 8 half; 16-byte aligned). */
+int ppst_depth_to_space_st(const void* x, void* y, int B, int th, int tw, int oh, int ow, int C, int st, void* stream);
 
 typedef struct ppst_conv_args {
   const void* x;        /* NHWC fp32 input, pixel stride in_ld floats */

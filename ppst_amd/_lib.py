@@ -74,6 +74,8 @@ _SIGS = {
     "ppst_conv_pack_wino": (i32, [vp, i64, i64, i64, i64, f32, i32, i32, vp, vp]),
     "ppst_conv_pack_dual": (i32, [vp, i64, i64, i64, i64, f32, i32, vp, vp, vp, i32, i32, i32, vp, vp]),
     "ppst_upscale_weight": (i32, [vp, vp, i32, i32, f32, vp]),
+    "ppst_dgrad_s2d_stack_weight": (i32, [vp, vp, i32, i32, vp]),
+    "ppst_depth_to_space_st": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ppst_pack_job_blocks": (i32, [i64]),
     "ppst_conv_pack_batch": (i32, [vp, i32, i32, vp]),
     "ppst_upscale_weight_batch": (i32, [vp, i32, i32, vp]),

@@ -243,7 +243,7 @@ class BlurConvFn(Function):
             _noted(bias); db = None
         dx = None
         if ctx.needs_input_grad[0]:
-            d_xb = net.plan(wname, "dgrad_s2d", scale)(gpre, out_hw=bhw)
+            d_xb = ops.dgrad_s2d(net, wname, scale, gpre, bhw)
             k = net.p(kname)
             ks = k.shape[0]
             kf = _flipped(net, kname)

@@ -994,6 +994,29 @@ extern "C" int ppst_upscale_weight(const void* w, void* out, int cout, int cin, 
   PPST_LAUNCH(upscale_weight_kernel, dim3((unsigned)j.nblocks), dim3(256), 0, as_stream(stream), j);
   return PPST_LAUNCH_CHECK();
 }
+// Input gradient of the stride-2 3x3 conv as ONE stride-1 conv with 2 x 2 taps whose output channels stack the four output phases
+// (round 5, ops kind "dgrad_s2ds"): out[(py*2+px)*cin + n][c][ty][tx] = w[c][n][ky][kx] where a phase uses tap offset t = 0 with
+// k = (p == 0 ? 0 : 1) and t = 1 (one input position back) with k = 2 for p == 0 only; 0 elsewhere.  w: the forward (cout, cin, 3, 3).
+__global__ __launch_bounds__(256) void dgrad_s2d_stack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin,
+                                                                     int64_t total) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int tx = (int)(t & 1), ty = (int)((t >> 1) & 1);
+    int64_t r = t >> 2;
+    const int c = (int)(r % cout); r /= cout;
+    const int n = (int)(r % cin), g = (int)(r / cin);
+    const int py = g >> 1, px = g & 1;
+    const int ky = ty == 0 ? (py == 0 ? 0 : 1) : (py == 0 ? 2 : -1), kx = tx == 0 ? (px == 0 ? 0 : 1) : (px == 0 ? 2 : -1);
+    out[t] = (ky >= 0 && kx >= 0) ? w[((int64_t)c * cin + n) * 9 + ky * 3 + kx] : 0.f;
+  }
+}
+extern "C" int ppst_dgrad_s2d_stack_weight(const void* w, void* out, int cout, int cin, void* stream) {
+  if (cout <= 0 || cin <= 0) return PPST_EINVAL;
+  if (!w || !out) return PPST_ENULL;
+  const int64_t total = (int64_t)4 * cin * cout * 4;
+  PPST_LAUNCH(dgrad_s2d_stack_weight_kernel, dim3((unsigned)pack_blocks(total)), dim3(256), 0, as_stream(stream), (const float*)w, (float*)out,
+              cout, cin, total);
+  return PPST_LAUNCH_CHECK();
+}
 extern "C" int ppst_upscale_weight_batch(const void* jobs, int njobs, int total_blocks, void* stream) {
   static_assert(sizeof(UpscaleJob) == sizeof(ppst_upscale_job), "ppst_upscale_job layout");
   if (njobs < 0 || total_blocks < 0) return PPST_EINVAL;

@@ -1243,3 +1243,32 @@ extern "C" int ppst_rselfcorr_bwd(const void* fea, const void* dout, void* dfea,
               (float*)dfea, B, H, W, dout_ld, 2.220446049250313e-16f, npatch);
   return PPST_LAUNCH_CHECK();
 }
+
+// ---- depth to space (round 5): x [B][th][tw][4 C] (channel block g = py*2+px holds output phase (py, px)) -> y [B][oh][ow][C],
+// y[b][2q+py][2p+px][c] = x[b][q][p][g*C + c], oh <= 2 th, ow <= 2 tw (an odd extent drops the last phase-1 row / column).  Pure data
+// movement: 16-byte items of either storage type (C % 4 == 0 for fp32, % 8 for half tensors).
+__global__ __launch_bounds__(256) void depth_to_space_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int th, int tw, int oh, int ow,
+                                                             int cq, unsigned total, FastDiv d_cq, FastDiv d_ow, FastDiv d_oh) {
+  for (uint64_t t64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t64 < total; t64 += (uint64_t)gridDim.x * 256) {
+    unsigned c, ox, oy;
+    unsigned r = fd_divmod((unsigned)t64, d_cq, c);
+    r = fd_divmod(r, d_ow, ox);
+    const unsigned b = fd_divmod(r, d_oh, oy);
+    const unsigned g = (oy & 1) * 2 + (ox & 1);
+    y[t64] = x[(((uint64_t)b * th + (oy >> 1)) * tw + (ox >> 1)) * (4u * cq) + g * cq + c];
+  }
+}
+extern "C" int ppst_depth_to_space_st(const void* x, void* y, int B, int th, int tw, int oh, int ow, int C, int st, void* stream) {
+  if ((unsigned)st > 2u) return PPST_EINVAL;
+  const int per = st ? 8 : 4;                     // elements per 16-byte item
+  if (B < 0 || th <= 0 || tw <= 0 || oh <= 0 || ow <= 0 || oh > 2 * th || ow > 2 * tw || C <= 0 || C % per) return PPST_EINVAL;
+  if (B == 0) return PPST_OK;
+  if (!x || !y) return PPST_ENULL;
+  if (((uintptr_t)x | (uintptr_t)y) % 16) return PPST_EINVAL;
+  const int cq = C / per;
+  const int64_t total = (int64_t)B * oh * ow * cq;
+  if (total > PPST_IDX32_MAX) return PPST_EINVAL;
+  PPST_LAUNCH(depth_to_space_kernel, dim3(tg_grid(total)), dim3(256), 0, as_stream(stream), (const uint4*)x, (uint4*)y, th, tw, oh, ow, cq,
+              (unsigned)total, make_fastdiv(cq), make_fastdiv(ow), make_fastdiv(oh));
+  return PPST_LAUNCH_CHECK();
+}

@@ -333,6 +333,9 @@ class ConvPlan:
             scale = 1.0
         elif kind == "dgrad":
             wsrc = w.view(-1)[k * k - 1:]
+        elif kind == "dgrad_s2ds":
+            wsrc = torch.empty((4 * cin, cout, 2, 2), device=w.device, dtype=torch.float32)
+            check(lib.ppst_dgrad_s2d_stack_weight(_p(w), _p(wsrc), cout, cin, _stream()), "ppst_dgrad_s2d_stack_weight")
         else:
             wsrc = w
         self.scale = float(scale)
@@ -470,6 +473,25 @@ class ConvPlan:
             sn, sc, sy, sx = 9, cin * 9, 3, 1     # n' = c (stride 9), c' = n (stride cin*9), no flip
             self.cout, self.cin = cin, cout
             cout, cin = cin, cout
+            self.bn = 128 if cout >= 128 else 64
+        elif kind == "dgrad_s2ds":
+            # round 5: the same input gradient with the four output phases STACKED as 4 x Cin output channels of ONE stride-1 conv
+            # with 2 x 2 taps (offsets 0 / -1 per axis), followed by ops.depth_to_space: one group, every step real (the four-group
+            # table pads 7 of its 16 steps per chunk), the tile staged once instead of once per phase, and 4 x Cin >= 128 output
+            # channels put a thin layer (Cin 32 / 64) on the 8-wave kernels -- its four-group launches ran 2 312-5 780 FOUR-wave
+            # blocks at 21-65 TFLOP/s.  Weights: ppst_dgrad_s2d_stack_weight (out (4 Cin, Cout, 2, 2) from the forward parameter).
+            assert k == 3 and cout % 32 == 0
+            self.n_groups = 1
+            self.halo = 1
+            for c in range(cout // 32):
+                for i, (ty, tx) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+                    steps.append((32 * c, -ty, -tx, 1 if i == 0 else 0))
+                    src.append((32 * c, ty, tx))
+            wsrc = torch.empty((4 * cin, cout, 2, 2), device=w.device, dtype=torch.float32)
+            check(lib.ppst_dgrad_s2d_stack_weight(_p(w), _p(wsrc), cout, cin, _stream()), "ppst_dgrad_s2d_stack_weight")
+            sn, sc, sy, sx = cout * 4, 4, 2, 1
+            self.cout, self.cin = 4 * cin, cout
+            cout, cin = 4 * cin, cout
             self.bn = 128 if cout >= 128 else 64
         elif kind == "dgradT":
             # input gradient of the fused 4x4 stride-2 transposed conv (kind 'convT'): a stride-2 4x4 conv (pad 1) of
@@ -795,7 +817,7 @@ class ConvPlan:
         elif self.kind == "dgrad_s2d":
             oh, ow = out_hw                      # extent of the (blurred) tensor the forward conv read
             th, tw, osy = (oh + 1) // 2, (ow + 1) // 2, 2
-        elif self.kind == "s2d":
+        elif self.kind in ("s2d", "dgrad_s2ds"):     # (dgrad_s2ds: out_hw = the stacked extents, ceil(input-grid extent / 2))
             oh, ow = out_hw
             th, tw, osy = oh, ow, 1
         else:
@@ -932,6 +954,8 @@ def repack_plans(plans):
     for pl in plans:
         if pl.precision == 2:
             continue
+        if pl.kind == "dgrad_s2ds":              # the phase-stacked 2 x 2 kernel: refreshed from the parameter before the packs read it
+            wino.append(("s2ds", pl.wparam, pl.wsrc, pl.wparam.shape[0], pl.wparam.shape[1], None))
         if pl.kind in ("convT", "dgradT"):
             cin4, cout4 = pl.wsrc.shape[0], pl.wsrc.shape[1]         # wsrc is the (Cin, Cout, 4, 4) kernel of the FORWARD conv
             up.append((pl.wparam.data_ptr(), pl.wsrc.data_ptr(), cin4 * cout4 * 16, float(pl.up_scale), cout4, cin4))
@@ -997,9 +1021,14 @@ def run_repack(tables):
     tu, nu, nbu, tp, npk, nbp, wino = tables
     if nu:
         check(lib.ppst_upscale_weight_batch(_p(tu), nu, nbu, _stream()), "ppst_upscale_weight_batch")
+    for e in wino:
+        if isinstance(e[0], str) and e[0] == "s2ds":
+            check(lib.ppst_dgrad_s2d_stack_weight(_p(e[1]), _p(e[2]), e[3], e[4], _stream()), "ppst_dgrad_s2d_stack_weight")
     if npk:
         check(lib.ppst_conv_pack_batch(_p(tp), npk, nbp, _stream()), "ppst_conv_pack_batch")
     for wsrc, strides, scale, cout, cin, wpack in wino:
+        if isinstance(wsrc, str) and wsrc == "s2ds":
+            continue
         if isinstance(wsrc, str):                # ("up9", the 3x3 parameter, ...): variant 11
             check(lib.ppst_conv_pack_up9(_p(strides), cin * 9, 9, 3, 1, scale, cout, cin, _p(wpack), _stream()), "ppst_conv_pack_up9")
             continue
@@ -1308,6 +1337,35 @@ def upscale_weight_bwd(dw4, cout, cin, scale=1.0, out=None, accumulate=False):
     check(lib.ppst_upscale_weight_bwd(_p(dw4.contiguous()), _p(dw), cout, cin, float(scale), 1 if (accumulate and out is not None) else 0,
                                       _stream()), "ppst_upscale_weight_bwd")
     return dw
+
+
+# round 5: thin stride-2 layers (forward Cin <= max_cin) take their input gradient as the phase-stacked stride-1 conv + depth_to_space
+# (plan kind "dgrad_s2ds") instead of the four-group scattered form ("dgrad_s2d").  PPST_DGRAD_S2D_STACK=0: the four-group form.
+DGRAD_S2D_STACK = {"value": os.environ.get("PPST_DGRAD_S2D_STACK", "1") != "0", "max_cin": int(os.environ.get("PPST_DGRAD_S2D_MAXCIN", "64"))}
+
+
+def depth_to_space(x, out_hw):
+    """x (B, th, tw, 4 C) with channel block py*2+px = output phase -> (B, oh, ow, C), y[b, 2q+py, 2p+px] = x[b, q, p, phase block]."""
+    ld = _nhwc_ld(x, "depth_to_space input", half_ok=True)
+    B, th, tw, c4 = x.shape
+    if ld != c4 or c4 % 4:
+        raise RuntimeError("depth_to_space needs a dense tensor with 4 C channels")
+    oh, ow = out_hw
+    y = torch.empty((B, oh, ow, c4 // 4), device=x.device, dtype=x.dtype)
+    check(lib.ppst_depth_to_space_st(_p(x), _p(y), B, th, tw, oh, ow, c4 // 4, _ST[x.dtype], _stream()), "ppst_depth_to_space_st")
+    return y
+
+
+def dgrad_s2d(net, wname, scale, g, out_hw):
+    """Input gradient of the stride-2 3x3 conv ``wname`` of ``net`` (on the blurred tensor of extent ``out_hw``) from the gradient g at
+    its output: the phase-stacked form for thin layers (ops.DGRAD_S2D_STACK), else the four-group scattered form."""
+    cin = net.p(wname).shape[1]
+    per = 8 if g.dtype != torch.float32 else 4
+    if DGRAD_S2D_STACK["value"] and cin <= DGRAD_S2D_STACK["max_cin"] and cin % per == 0:
+        oh, ow = out_hw
+        ys = net.plan(wname, "dgrad_s2ds", scale)(g, out_hw=((oh + 1) // 2, (ow + 1) // 2))
+        return depth_to_space(ys, out_hw)
+    return net.plan(wname, "dgrad_s2d", scale)(g, out_hw=out_hw)
 
 
 def space_to_depth(x):

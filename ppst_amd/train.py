@@ -183,7 +183,7 @@ class DiscriminatorTrainer:
             if pg:
                 ops.conv_wgrad(D.plan(q + "conv2.Conv.weight", "s2d", sc1), blk["xb"], g2, out=G(name + "conv2.Conv.weight"), accumulate=True,
                                bias_out=G(name + "conv2.Act.bias"), bias_accumulate=True)
-            d_xb = self._dgrad(q + "conv2.Conv.weight", "dgrad_s2d", sc1)(g2, out_hw=blk["bhw"])
+            d_xb = ops.dgrad_s2d(self.D, q + "conv2.Conv.weight", sc1, g2, blk["bhw"])
             # blur backward: upfirdn2d with the flipped (symmetric) taps and g_pad = (1, 1)
             kf = D.cached(("flip", q + "conv2.Blur.kernel"), [D.p(q + "conv2.Blur.kernel")],
                           lambda: torch.flip(D.p(q + "conv2.Blur.kernel"), [0, 1]).contiguous())

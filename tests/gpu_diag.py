@@ -1612,6 +1612,21 @@ def t_train_ops():
         dy2g = to_nhwc(g(dy2)).contiguous()
         dxb = ops.ConvPlan(wg, "dgrad_s2d", sc)(dy2g, out_hw=bhw)
         report("dgrad_s2d %d->%d out %dx%d" % (cout, cin, bhw[0], bhw[1]), dxb.permute(0, 3, 1, 2), xbr.grad, 3e-5)
+        # round 5: the same gradient as ONE stride-1 conv whose output channels stack the four phases + depth_to_space (thin layers)
+        ys = ops.ConvPlan(wg, "dgrad_s2ds", sc)(dy2g, out_hw=((bhw[0] + 1) // 2, (bhw[1] + 1) // 2))
+        dxs = ops.depth_to_space(ys, bhw)
+        report("dgrad_s2ds (phase-stacked) %d->%d out %dx%d" % (cout, cin, bhw[0], bhw[1]), dxs.permute(0, 3, 1, 2), xbr.grad, 3e-5)
+        report("dgrad_s2ds vs four-group form", dxs, dxb, 3e-6)
+        if cin % 8 == 0:
+            prevp = ops.PRECISION["value"]
+            ops.set_precision(1)
+            try:
+                gh = dy2g.to(torch.bfloat16)
+                a4 = ops.ConvPlan(wg, "dgrad_s2d", sc)(gh, out_hw=bhw).float()
+                as_ = ops.depth_to_space(ops.ConvPlan(wg, "dgrad_s2ds", sc)(gh, out_hw=((bhw[0] + 1) // 2, (bhw[1] + 1) // 2)), bhw).float()
+                report("dgrad_s2ds bf16 storage vs four-group form", as_, a4, 8e-3)
+            finally:
+                ops.set_precision(prevp)
         dw2 = ops.conv_wgrad(ops.ConvPlan(wg, "s2d", sc), xb, dy2g)
         report("wgrad s2d %d->%d" % (cin, cout), dw2, wr2.grad, 3e-5)
 
